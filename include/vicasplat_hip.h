@@ -1,0 +1,133 @@
+/*
+ * vicasplat_hip.h -- C ABI of libvicasplat_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for VicaSplat's feed-forward hot path.  Every entry point takes
+ * plain device pointers + sizes + a hipStream_t (passed as void*), never a torch type.  The Python packages
+ * vicasplat_amd.diff_gaussian_rasterization / vicasplat_amd.curope / vicasplat_amd.model.* are thin ctypes
+ * wrappers over these symbols and re-export the reference's own call surface.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - every function is asynchronous on `stream` except where noted (vs_raster_forward performs exactly one
+ *     stream synchronisation to learn the number of (Gaussian,tile) instances, like the reference extension);
+ *   - return value: >= 0 on success, < 0 on error; vs_last_error() returns a thread-local message
+ *     (mirrors TORCH_CHECK in /root/reference/src/model/encoder/backbone/croco/curope/curope.cpp:54-59);
+ *   - the library never frees caller memory and keeps no global mutable state besides the thread-local error
+ *     string; variable-size scratch comes from the caller's allocator callback (PyTorch caching allocator).
+ *   - matrices follow the reference's storage: viewmatrix/projmatrix are 16 floats with element [4*c+r] =
+ *     M[r][c] (what cuda_splatting.py:191-194 hands to diff_gaussian_rasterization).
+ */
+#ifndef VICASPLAT_HIP_H
+#define VICASPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *vs_stream_t; /* hipStream_t */
+
+const char *vs_last_error(void);
+/* ABI version, bumped on any signature change. */
+int vs_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rasterizer (replaces diff_gaussian_rasterization._C.rasterize_gaussians / _backward, imported at
+ * /root/reference/src/model/decoder/cuda_splatting.py:5-8 and called at :207-235; per-view Python loop
+ * at :199-238 becomes ONE batched call over all cameras of all scenes).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct VsRasterIn {
+    int32_t num_cameras; /* C: rendered views in this call */
+    int32_t num_scenes;  /* S: distinct Gaussian sets; Gaussians are shared by all cameras of a scene */
+    int32_t P;           /* Gaussians per scene */
+    int32_t sh_degree;   /* active degree as given by the caller (VicaSplat passes 4; bands > 3 are ignored) */
+    int32_t sh_coeffs;   /* M: coefficients per channel in memory (25) */
+    int32_t width, height;
+    int32_t flags;       /* VS_RASTER_* */
+    const float *means3D;        /* [S,P,3] */
+    const float *cov3D;          /* [S,P,6]  xx xy xz yy yz zz (cov3D_precomp) */
+    const float *shs;            /* [S,P,M,3] or NULL */
+    const float *colors_precomp; /* [S,P,3]  or NULL (exactly one of shs / colors_precomp) */
+    const float *opacities;      /* [S,P] */
+    const int32_t *cam_scene;    /* [C] scene index of every camera, or NULL (camera c -> scene c % S) */
+    const float *viewmatrix;     /* [C,16] */
+    const float *projmatrix;     /* [C,16] */
+    const float *campos;         /* [C,3] */
+    const float *tanfov;         /* [C,2] (x,y) -- on the DEVICE: no .item() host sync (cuda_splatting.py:210-211) */
+    const float *background;     /* [C,3] */
+} VsRasterIn;
+
+enum {
+    VS_RASTER_COUNT_TOUCHED = 1, /* fill n_touched (MonoGS bookkeeping; VicaSplat discards it) */
+    VS_RASTER_SAVE_FOR_BACKWARD = 2,
+    VS_RASTER_SH_RGB_MAJOR = 4,  /* shs laid out [S,P,3,M] (the encoder's native `harmonics` layout,
+                                    gaussian_adapter.py:183) instead of [S,P,M,3]: saves the transpose copy of
+                                    cuda_splatting.py:182 */
+    VS_RASTER_COV_3X3 = 8,       /* cov3D laid out [S,P,3,3] (full symmetric matrix) instead of [S,P,6]: saves the
+                                    triu gather of cuda_splatting.py:224,232 */
+};
+
+/* Scratch / saved-state buffers are requested through this callback, tagged so that the caller can keep the
+ * ones the backward needs.  Must return 256-byte aligned device memory valid until the caller releases it. */
+enum {
+    VS_BUF_GEOM = 0,      /* [C,P,12] f32: x y depth pad | conic.x conic.y conic.z opacity | r g b pad  */
+    VS_BUF_RECT = 1,      /* [C,P,4] u16 tile rectangle (min.x min.y max.x max.y) */
+    VS_BUF_CLAMPED = 2,   /* [C,P] u8 bit c set => colour channel c clamped at 0 */
+    VS_BUF_TILE_RANGES = 3, /* [C,tiles,2] i32 */
+    VS_BUF_TILE_CURSOR = 4, /* [C,tiles] i32 scratch */
+    VS_BUF_KEYS = 5,      /* [R] u64 (depth_bits<<32 | gaussian) */
+    VS_BUF_POINT_LIST = 6, /* [R] u32 sorted Gaussian ids, per (camera,tile) segment */
+    VS_BUF_SORT_SCRATCH = 7, /* [2R] u64 for oversize tiles */
+    VS_BUF_FINAL_T = 8,   /* [C,H,W] f32 */
+    VS_BUF_N_CONTRIB = 9, /* [C,H,W] i32 */
+    VS_BUF_MISC = 10,     /* small control block */
+    VS_BUF_COUNT = 11
+};
+typedef void *(*VsAllocFn)(void *ctx, int32_t tag, size_t bytes);
+
+typedef struct VsRasterOut {
+    float *color;       /* [C,3,H,W] */
+    float *depth;       /* [C,H,W]   alpha-weighted depth (un-normalised) */
+    float *opacity;     /* [C,H,W]   1 - T */
+    int32_t *radii;     /* [C,P] */
+    int32_t *n_touched; /* [C,P] (zero-filled unless VS_RASTER_COUNT_TOUCHED) */
+    int64_t num_rendered; /* R, filled on return */
+    void *buffers[VS_BUF_COUNT]; /* filled on return with what the allocator handed out */
+} VsRasterOut;
+
+/* returns R (>= 0) or < 0 */
+int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsAllocFn alloc, void *alloc_ctx, vs_stream_t stream);
+
+typedef struct VsRasterGrads {
+    /* incoming */
+    const float *dL_dcolor; /* [C,3,H,W] */
+    const float *dL_ddepth; /* [C,H,W] or NULL */
+    /* outgoing; each is accumulated over the cameras of a scene */
+    float *dL_dmeans3D;   /* [S,P,3] */
+    float *dL_dcov3D;     /* [S,P,6] */
+    float *dL_dshs;       /* [S,P,M,3] or NULL */
+    float *dL_dcolors_precomp; /* [S,P,3] or NULL */
+    float *dL_dopacities; /* [S,P] */
+    float *dL_dmeans2D;   /* [C,P,2] (NDC units, as upstream's screen-space gradient holder) or NULL */
+    float *dL_dtau;       /* [C,6] (rho, theta) for T_cw' = Exp(tau) T_cw, or NULL */
+} VsRasterGrads;
+
+/* `saved` is the VsRasterOut of the matching forward (buffers[] must still be alive). */
+int vs_raster_backward(const VsRasterIn *in, const VsRasterOut *saved, const VsRasterGrads *g, VsAllocFn alloc,
+                       void *alloc_ctx, vs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-D RoPE (replaces curope.rope_2d, /root/reference/src/model/encoder/backbone/croco/curope/curope.cpp:49-69,
+ * kernels.cu:17-108).  In place on tokens viewed as [B,N,H,D]: requires stride(3)=1, stride(2)=D;
+ * stride(0)=sB, stride(1)=sN in elements.  pos: int64 [B,N,2] contiguous (y,x).  dtype: 0=f32 1=f16 2=bf16.
+ * fwd = +F0 forward, -F0 backward.
+ * ------------------------------------------------------------------------------------------------ */
+int vs_rope2d(void *tokens, const int64_t *pos, int32_t B, int32_t N, int32_t H, int32_t D, int64_t sB, int64_t sN,
+              float base, float fwd, int32_t dtype, vs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VICASPLAT_HIP_H */

@@ -1,0 +1,233 @@
+"""Parity of the HIP rasterizer forward (through the C ABI) against the CPU oracle.  -m gpu.
+
+Bar: integer tile data (radii, tile rectangles, tile ranges, sorted ids) BIT-IDENTICAL;
+renders float-tolerant (|d color| <= 2e-5 typical; a handful of pixels may differ by one alpha threshold flip
+because v_exp_f32 and glibc expf differ in the last ulp) and PSNR-equivalent (|dPSNR| <= 1e-4 dB vs a common target).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_ref as rr
+
+pytestmark = pytest.mark.gpu
+
+K09 = np.array([[0.9, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1]], np.float32)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _gpu_cams(cams):
+    d = _dev()
+    t = lambda a: torch.tensor(np.stack(a), dtype=torch.float32, device=d)
+    return dict(viewmatrix=t([c.viewmatrix for c in cams]), projmatrix=t([c.projmatrix for c in cams]),
+                campos=t([c.campos for c in cams]), tanfov=t([[c.tanfovx, c.tanfovy] for c in cams]))
+
+
+def _run_gpu(means, cov6, shs, op, cams, W, H, bg, **kw):
+    from vicasplat_amd.raster import forward_debug
+    d = _dev()
+    g = _gpu_cams(cams)
+    C = len(cams)
+    return forward_debug(torch.tensor(means, dtype=torch.float32, device=d)[None], torch.tensor(cov6, device=d)[None],
+                         torch.tensor(op, dtype=torch.float32, device=d)[None], g["viewmatrix"], g["projmatrix"], g["campos"],
+                         g["tanfov"], torch.tensor(bg, dtype=torch.float32, device=d).expand(C, 3).contiguous(), H, W,
+                         shs=None if shs is None else torch.tensor(shs, dtype=torch.float32, device=d)[None], sh_degree=4, **kw)
+
+
+def _compare(o, g, c, color_atol=2e-5, max_bad_frac=2e-4):
+    """o: oracle dict of view c; g: gpu dict."""
+    vis = o["radii"] > 0
+    assert np.array_equal(g["radii"][c].cpu().numpy(), o["radii"]), "radii"
+    assert np.array_equal(g["rect"][c].cpu().numpy()[vis].astype(np.int32), o["rect"][vis]), "tile rectangles"
+    assert g["ranges"][c].cpu().numpy().shape == o["ranges"].shape
+    # ranges are offsets into the per-call list; compare per-tile populations and the concatenated sorted ids
+    rg = g["ranges"][c].cpu().numpy()
+    assert np.array_equal(rg[:, 1] - rg[:, 0], o["ranges"][:, 1] - o["ranges"][:, 0]), "tile populations"
+    pl = g["point_list"].cpu().numpy().astype(np.uint32)
+    lo, hi = rg[:, 0].min(), rg[:, 1].max()
+    assert np.array_equal(pl[lo:hi], o["point_list"]), "sorted Gaussian ids"
+    gm = g["geom"][c].cpu().numpy()
+    assert np.array_equal(gm[vis, 0:2], o["xy"][vis]), "pixel centres bit-exact (same op order)"
+    assert np.array_equal(gm[vis, 2], o["depths"][vis]), "depth keys bit-exact"
+    assert np.array_equal(gm[vis, 4:8], o["conic_opacity"][vis]), "conic bit-exact"
+    assert np.allclose(gm[vis, 8:11], o["rgb"][vis], atol=1e-6), "SH colours"
+    assert np.array_equal(g["clamped"][c].cpu().numpy()[vis], (o["clamped"][vis] * np.array([1, 2, 4], np.uint8)).sum(-1)), "clamp mask"
+    col = g["color"][c].cpu().numpy()
+    bad = np.abs(col - o["color"]) > color_atol
+    assert bad.mean() <= max_bad_frac, f"{bad.sum()} colour values differ by > {color_atol}"
+    assert np.abs(col - o["color"]).max() < 2e-2
+    dep = g["depth"][c].cpu().numpy()
+    assert (np.abs(dep - o["depth"]) > 1e-4 * max(1.0, np.abs(o["depth"]).max())).mean() <= max_bad_frac
+    assert (np.abs(g["opacity"][c].cpu().numpy() - o["opacity"]) > color_atol).mean() <= max_bad_frac
+    assert (g["n_contrib"][c].cpu().numpy() != o["n_contrib"]).mean() <= 10 * max_bad_frac
+    nt = g["n_touched"][c].cpu().numpy()
+    assert (nt != o["n_touched"]).mean() <= 1e-3 and np.abs(nt - o["n_touched"]).max() <= 2
+
+
+def _random_small(P, seed, spread=0.9):
+    rng = np.random.default_rng(seed)
+    means = np.stack([rng.uniform(-spread, spread, P), rng.uniform(-0.6, 0.6, P), rng.uniform(1.5, 4.0, P)], -1).astype(np.float32)
+    A = rng.standard_normal((P, 3, 3)) * 0.08
+    cov = (A @ A.transpose(0, 2, 1) + 1e-4 * np.eye(3)).astype(np.float32)
+    sh = (rng.standard_normal((P, 25, 3)) * rr.SH_MASK[None, :, None]).astype(np.float32)
+    sh[:, 0] = rng.standard_normal((P, 3)) * 0.7
+    op = rng.uniform(0.2, 0.95, P).astype(np.float32)
+    return means, cov, sh, op
+
+
+def _two_cams():
+    yaw = 0.1
+    E = np.eye(4, dtype=np.float32)
+    E[:3, :3] = [[math.cos(yaw), 0, math.sin(yaw)], [0, 1, 0], [-math.sin(yaw), 0, math.cos(yaw)]]
+    E[:3, 3] = [0.1, -0.05, 0.02]
+    Es = np.stack([np.eye(4, dtype=np.float32), E])
+    return rr.make_cameras(Es, np.stack([K09, K09]), np.full(2, 0.01, np.float32), np.full(2, 100.0, np.float32))
+
+
+@pytest.mark.parametrize("W,H,P", [(48, 32, 60), (64, 64, 500), (50, 37, 300), (256, 256, 5000)])
+def test_forward_matches_oracle_small(W, H, P):
+    means, cov, sh, op = _random_small(P, seed=P)
+    cams = _two_cams()
+    bg = np.array([0.2, 0.1, 0.3], np.float32)
+    c6 = rr.cov6(cov)
+    g = _run_gpu(means, c6, sh, op, cams, W, H, bg)
+    tot = 0
+    for c, cam in enumerate(cams):
+        o = rr.rasterize_forward(cam, W, H, bg, means, c6, sh, op)
+        _compare(o, g, c)
+        tot += o["R"]
+    assert g["R"] == tot
+
+
+def test_forward_config3_scene_131k():
+    """BASELINE.json config 3: re10k_2view-sized scene, ~131k Gaussians, 256x256, 4 target views."""
+    sc = rr.synthetic_scene(V=2, res=256, Vt=4, seed=0)
+    cams = rr.make_cameras(sc["extrinsics"], sc["intrinsics"], sc["near"], sc["far"])
+    shs = np.ascontiguousarray(np.transpose(sc["harmonics"], (0, 2, 1)))
+    c6 = rr.cov6(sc["covariances"])
+    bg = np.zeros(3, np.float32)
+    g = _run_gpu(sc["means"], c6, shs, sc["opacities"], cams, 256, 256, bg)
+    rng = np.random.default_rng(0)
+    target = rng.uniform(0, 1, (3, 256, 256)).astype(np.float32)
+    for c, cam in enumerate(cams):
+        o = rr.rasterize_forward(cam, 256, 256, bg, sc["means"], c6, shs, sc["opacities"])
+        _compare(o, g, c)
+        psnr = lambda img: -10 * math.log10(float(((np.clip(img, 0, 1) - target) ** 2).mean()))
+        assert abs(psnr(g["color"][c].cpu().numpy()) - psnr(o["color"])) <= 1e-4
+
+
+def test_oversize_tile_falls_back_to_global_sort():
+    # > 8192 Gaussians in ONE tile: exercises the global-memory bitonic path
+    P = 9000
+    rng = np.random.default_rng(1)
+    means = np.stack([rng.uniform(-0.02, 0.02, P), rng.uniform(-0.02, 0.02, P), rng.uniform(2.0, 3.0, P)], -1).astype(np.float32)
+    means[:, 2] = np.round(means[:, 2] * 64) / 64  # many exact depth ties -> index tie-break matters
+    cov = np.tile((1e-6 * np.eye(3, dtype=np.float32))[None], (P, 1, 1))
+    sh = np.zeros((P, 25, 3), np.float32); sh[:, 0] = rng.standard_normal((P, 3))
+    op = np.full(P, 0.02, np.float32)
+    cams = _two_cams()[:1]
+    W = H = 32
+    bg = np.zeros(3, np.float32)
+    g = _run_gpu(means, rr.cov6(cov), sh, op, cams, W, H, bg)
+    o = rr.rasterize_forward(cams[0], W, H, bg, means, rr.cov6(cov), sh, op)
+    assert (o["ranges"][:, 1] - o["ranges"][:, 0]).max() > 8192
+    _compare(o, g, 0, color_atol=1e-4)
+
+
+def test_empty_and_culled():
+    d = _dev()
+    cams = _two_cams()
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    means = np.array([[0, 0, 0.2], [0, 0, -1.0], [50.0, 0, 1.0]], np.float32)  # z<=0.2, behind, far off-screen
+    cov = np.tile((1e-4 * np.eye(3, dtype=np.float32))[None], (3, 1, 1))
+    sh = np.zeros((3, 25, 3), np.float32)
+    g = _run_gpu(means, rr.cov6(cov), sh, np.ones(3, np.float32), cams, 32, 32, bg)
+    assert g["R"] == 0 and int(g["radii"].abs().sum()) == 0
+    assert torch.allclose(g["color"], torch.tensor(bg, device=d)[None, :, None, None].expand(2, 3, 32, 32))
+    assert float(g["depth"].abs().max()) == 0 and float(g["opacity"].abs().max()) == 0
+    # P == 0
+    g = _run_gpu(np.zeros((0, 3), np.float32), np.zeros((0, 6), np.float32), np.zeros((0, 25, 3), np.float32),
+                 np.zeros(0, np.float32), cams, 32, 32, bg)
+    assert g["R"] == 0 and torch.allclose(g["color"][0, :, 0, 0].cpu(), torch.tensor(bg))
+
+
+def test_layout_flags_and_precomputed_colors():
+    """[S,P,3,M] SH + [S,P,3,3] covariance (encoder-native) give the same bits as [S,P,M,3] + cov6."""
+    from vicasplat_amd.raster import forward_debug
+    d = _dev()
+    means, cov, sh, op = _random_small(400, seed=11)
+    cams = _two_cams()
+    gc = _gpu_cams(cams)
+    bg = torch.zeros(2, 3, device=d)
+    T = lambda a: torch.tensor(a, dtype=torch.float32, device=d)[None]
+    a = forward_debug(T(means), T(rr.cov6(cov)), T(op), gc["viewmatrix"], gc["projmatrix"], gc["campos"], gc["tanfov"], bg, 64, 64,
+                      shs=T(sh), sh_degree=4)
+    b = forward_debug(T(means), T(cov), T(op), gc["viewmatrix"], gc["projmatrix"], gc["campos"], gc["tanfov"], bg, 64, 64,
+                      shs=T(np.ascontiguousarray(sh.transpose(0, 2, 1))), sh_degree=4, sh_rgb_major=True)
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["radii"], b["radii"]) and torch.equal(a["point_list"], b["point_list"])
+    # colors_precomp path vs oracle
+    cp = np.random.default_rng(3).uniform(0, 1, (400, 3)).astype(np.float32)
+    g = forward_debug(T(means), T(rr.cov6(cov)), T(op), gc["viewmatrix"], gc["projmatrix"], gc["campos"], gc["tanfov"], bg, 64, 64,
+                      colors_precomp=T(cp))
+    o = rr.rasterize_forward(cams[1], 64, 64, np.zeros(3, np.float32), means, rr.cov6(cov), None, op, colors_precomp=cp)
+    assert np.abs(g["color"][1].cpu().numpy() - o["color"]).max() < 2e-5
+
+
+def test_render_cuda_call_surface():
+    """render_cuda(...) with the reference's argument layout: [b,g,...] per-camera sets and [g,...] shared sets."""
+    from vicasplat_amd.model.decoder.cuda_splatting import render_cuda
+    from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
+    from vicasplat_amd.model.types import Gaussians
+    d = _dev()
+    sc = rr.synthetic_scene(V=2, res=64, Vt=3, seed=2)
+    T = lambda a: torch.tensor(a, dtype=torch.float32, device=d)
+    E, K, near, far = T(sc["extrinsics"]), T(sc["intrinsics"]), T(sc["near"]), T(sc["far"])
+    bgc = torch.zeros(3, 3, device=d)
+    m, cv, sh, op = T(sc["means"]), T(sc["covariances"]), T(sc["harmonics"]), T(sc["opacities"])
+    img_shared, dep_shared = render_cuda(E, K, near, far, (64, 64), bgc, m, cv, sh, op)
+    rep = lambda t: t[None].expand(3, *t.shape).contiguous()
+    img_rep, dep_rep = render_cuda(E, K, near, far, (64, 64), bgc, rep(m), rep(cv), rep(sh), rep(op))
+    assert img_shared.shape == (3, 3, 64, 64) and dep_shared.shape == (3, 64, 64)
+    assert torch.equal(img_shared, img_rep) and torch.equal(dep_shared, dep_rep)
+    outs = rr.render_views(sc, res=64)
+    for c in range(3):
+        assert np.abs(img_shared[c].cpu().numpy() - outs[c]["color"]).max() < 5e-4  # camera matrices built independently
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
+    out = dec(Gaussians(m[None], cv[None], sh[None], op[None]), E[None], K[None], near[None], far[None], (64, 64))
+    assert out.color.shape == (1, 3, 3, 64, 64) and torch.equal(out.color[0], img_shared)
+
+
+def test_diff_gaussian_rasterization_drop_in():
+    from vicasplat_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    d = _dev()
+    means, cov, sh, op = _random_small(300, seed=5)
+    cam = _two_cams()[1]
+    T = lambda a: torch.tensor(a, dtype=torch.float32, device=d)
+    st = GaussianRasterizationSettings(image_height=48, image_width=64, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                       bg=torch.zeros(3, device=d), scale_modifier=1.0, viewmatrix=T(cam.viewmatrix).view(4, 4),
+                                       projmatrix=T(cam.projmatrix).view(4, 4), projmatrix_raw=T(cam.projmatrix_raw).view(4, 4),
+                                       sh_degree=4, campos=T(cam.campos), prefiltered=False, debug=False)
+    image, radii, depth, opacity, n_touched = GaussianRasterizer(st)(
+        means3D=T(means), means2D=torch.zeros(300, 3, device=d), shs=T(sh), colors_precomp=None, opacities=T(op)[:, None],
+        cov3D_precomp=T(rr.cov6(cov)), theta=None, rho=None)
+    o = rr.rasterize_forward(cam, 64, 48, np.zeros(3, np.float32), means, rr.cov6(cov), sh, op)
+    assert image.shape == (3, 48, 64) and depth.shape == (1, 48, 64) and opacity.shape == (1, 48, 64)
+    assert radii.dtype == torch.int32 and np.array_equal(radii.cpu().numpy(), o["radii"])
+    assert np.abs(image.cpu().numpy() - o["color"]).max() < 2e-5
+    assert np.array_equal(n_touched.cpu().numpy(), o["n_touched"])
+    with pytest.raises(Exception):
+        GaussianRasterizer(st)(means3D=T(means), means2D=None, shs=None, colors_precomp=None, opacities=T(op), cov3D_precomp=T(rr.cov6(cov)))
+
+
+def test_no_cpu_fallback():
+    from vicasplat_amd.model.decoder.cuda_splatting import render_cuda
+    sc = rr.synthetic_scene(V=2, res=16, Vt=1, seed=2)
+    T = lambda a: torch.tensor(a, dtype=torch.float32)
+    with pytest.raises(RuntimeError):
+        render_cuda(T(sc["extrinsics"]), T(sc["intrinsics"]), T(sc["near"]), T(sc["far"]), (16, 16), torch.zeros(1, 3),
+                    T(sc["means"]), T(sc["covariances"]), T(sc["harmonics"]), T(sc["opacities"]))

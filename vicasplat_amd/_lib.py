@@ -1,0 +1,129 @@
+"""ctypes binding of libvicasplat_hip.so (the C ABI declared in include/vicasplat_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a tensor is not on a HIP device the
+call raises.  PyTorch is used only for device memory (caching allocator) and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvicasplat_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+VS_BUF_GEOM, VS_BUF_RECT, VS_BUF_CLAMPED, VS_BUF_TILE_RANGES, VS_BUF_TILE_CURSOR, VS_BUF_KEYS, VS_BUF_POINT_LIST, \
+    VS_BUF_SORT_SCRATCH, VS_BUF_FINAL_T, VS_BUF_N_CONTRIB, VS_BUF_MISC, VS_BUF_COUNT = range(12)
+VS_RASTER_COUNT_TOUCHED = 1
+VS_RASTER_SAVE_FOR_BACKWARD = 2
+VS_RASTER_SH_RGB_MAJOR = 4
+VS_RASTER_COV_3X3 = 8
+
+AllocFn = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
+
+
+class VsRasterIn(C.Structure):
+    _fields_ = [
+        ("num_cameras", C.c_int32), ("num_scenes", C.c_int32), ("P", C.c_int32), ("sh_degree", C.c_int32),
+        ("sh_coeffs", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("flags", C.c_int32),
+        ("means3D", C.c_void_p), ("cov3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("cam_scene", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("campos", C.c_void_p), ("tanfov", C.c_void_p), ("background", C.c_void_p),
+    ]
+
+
+class VsRasterOut(C.Structure):
+    _fields_ = [
+        ("color", C.c_void_p), ("depth", C.c_void_p), ("opacity", C.c_void_p), ("radii", C.c_void_p),
+        ("n_touched", C.c_void_p), ("num_rendered", C.c_int64), ("buffers", C.c_void_p * VS_BUF_COUNT),
+    ]
+
+
+class VsRasterGrads(C.Structure):
+    _fields_ = [
+        ("dL_dcolor", C.c_void_p), ("dL_ddepth", C.c_void_p), ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+        ("dL_dshs", C.c_void_p), ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p),
+        ("dL_dmeans2D", C.c_void_p), ("dL_dtau", C.c_void_p),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir)
+                 if f.endswith((".hip", ".h", "Makefile")))
+    newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "vicasplat_hip.h")))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
+        subprocess.check_call(["make", "-C", src_dir, "-j8"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib() -> C.CDLL:
+    """Load the C-ABI library; raise loudly when it is absent (no silent fallback)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_SO):
+                raise RuntimeError(
+                    f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(vicasplat_amd has no CPU / PyTorch fallback path)")
+            L = C.CDLL(_SO)
+            L.vs_last_error.restype = C.c_char_p
+            L.vs_abi_version.restype = C.c_int
+            L.vs_raster_forward.restype = C.c_int64
+            L.vs_raster_forward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), AllocFn, C.c_void_p, C.c_void_p]
+            L.vs_rope2d.restype = C.c_int
+            L.vs_rope2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                    C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_void_p]
+            if hasattr(L, "vs_raster_backward"):
+                L.vs_raster_backward.restype = C.c_int
+                L.vs_raster_backward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), C.POINTER(VsRasterGrads),
+                                                 AllocFn, C.c_void_p, C.c_void_p]
+            _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise RuntimeError(f"{what}: {lib().vs_last_error().decode()}")
+    return rc
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("vicasplat_amd kernels need HIP device tensors (got a CPU tensor); there is no CPU fallback")
+        dev = dev or t.device
+        if t.device != dev:
+            raise RuntimeError("all tensors must live on the same device")
+    return dev
+
+
+def stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(None) if t is None else C.c_void_p(t.data_ptr())
+
+
+class TorchAllocator:
+    """VsAllocFn backed by the PyTorch caching allocator; keeps the tensors alive, indexed by tag."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.tensors: dict[int, torch.Tensor] = {}
+        self.fn = AllocFn(self._alloc)
+
+    def _alloc(self, _ctx, tag, nbytes):
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.tensors[int(tag)] = t
+        return t.data_ptr()

@@ -1,0 +1,38 @@
+// Shared host-side helpers for libvicasplat_hip.so (gfx950 only; no CUDA / multi-backend paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/vicasplat_hip.h"
+
+namespace vs {
+
+void set_error(const char *fmt, ...);
+
+#define VS_CHECK(cond, ...)            \
+    do {                               \
+        if (!(cond)) {                 \
+            vs::set_error(__VA_ARGS__); \
+            return -1;                 \
+        }                              \
+    } while (0)
+
+#define VS_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            vs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kTile = 16;           // 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y)
+constexpr int kGeomFloats = 12;     // VS_BUF_GEOM record
+
+}  // namespace vs

@@ -1,0 +1,574 @@
+// Tile-based 3D Gaussian splatting rasterizer, forward pass, hand-written for gfx950 (MI355X).
+//
+// Replaces diff_gaussian_rasterization._C.rasterize_gaussians as called from
+// /root/reference/src/model/decoder/cuda_splatting.py:207-235 (semantics: SURVEY.md Appendix B.1-B.4).
+// NOT a translation of upstream's pipeline.  MI355X-first differences:
+//   * ONE batched launch set for all cameras of all scenes (grid.y = camera); Gaussians are shared by the cameras
+//     of a scene instead of being replicated per view (decoder_splatting_cuda.py:86-89 copies them Vt times);
+//   * binning without a global 64-bit radix sort: per-(camera,tile) counts -> one tiny scan gives the tile ranges
+//     directly -> atomic-cursor scatter -> one workgroup per tile sorts its own segment in LDS.  The sort key is
+//     (depth_bits << 32 | gaussian_index): a total order, so the result equals upstream's stable sort of
+//     (tile | depth) keys emitted in Gaussian order, independent of the scatter order;
+//   * per-Gaussian render attributes are packed into one 48-byte record (3 x dwordx4 gathers per staged entry);
+//   * tan(fov) etc. are read from device memory: no per-view .item() host sync (cuda_splatting.py:210-211).
+//
+// Arithmetic contract (shared with oracle/raster_ref.c): everything that feeds an integer decision (cull, radius,
+// tile rectangle, depth key) is computed in float32 with FMA contraction OFF in the operation order below, so
+// radii / tile ranges / sorted ids are bit-identical to the CPU oracle.
+#include "common.h"
+
+namespace {
+
+using vs::kGeomFloats;
+using vs::kTile;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+__device__ __forceinline__ int f2i(float x) {
+    x = fminf(fmaxf(x, -1.0e6f), 1.0e6f);
+    return (int)x;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: preprocess.  grid = (ceil(P/256), S), block = 256.  A thread owns ONE Gaussian of scene s: it loads the
+// Gaussian's 58 input floats once into registers and then walks over every camera of that scene (the 232 input
+// bytes per Gaussian are read once per scene, not once per view).  Per camera the block bins its (Gaussian,tile)
+// instances in an LDS histogram and flushes one global atomic per non-empty bin, instead of one contended global
+// atomic per instance.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHistTiles = 4096;  // LDS histogram capacity (16 KiB); larger tile grids use global atomics directly
+
+struct __attribute__((packed, aligned(4))) f3_t { float x, y, z; };
+
+__global__ void __launch_bounds__(256)
+preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped,
+                  int32_t *__restrict__ radii, int32_t *__restrict__ tile_count) {
+#pragma clang fp contract(off)
+    __shared__ int hist[kHistTiles];
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int P = in.P;
+    const bool live = i < P;
+    const size_t gi = (size_t)s * P + (live ? i : 0);
+    const int W = in.width, H = in.height;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const int tiles = gx * gy;
+    const bool use_lds = tiles <= kHistTiles;
+
+    // ---- per-Gaussian inputs, loaded once ----
+    float px = 0.f, py = 0.f, pz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f, opac = 0.f;
+    float sh[16][3];
+    const bool has_sh = in.colors_precomp == nullptr;
+    const int deg = in.sh_degree;
+    if (live) {
+        const f3_t m = *reinterpret_cast<const f3_t *>(in.means3D + 3 * gi);
+        px = m.x; py = m.y; pz = m.z;
+        if (in.flags & VS_RASTER_COV_3X3) {
+            const float *__restrict__ cv = in.cov3D + 9 * gi;
+            c0 = cv[0]; c1 = cv[1]; c2 = cv[2]; c3 = cv[4]; c4 = cv[5]; c5 = cv[8];
+        } else {
+            const f3_t a = *reinterpret_cast<const f3_t *>(in.cov3D + 6 * gi);
+            const f3_t b = *reinterpret_cast<const f3_t *>(in.cov3D + 6 * gi + 3);
+            c0 = a.x; c1 = a.y; c2 = a.z; c3 = b.x; c4 = b.y; c5 = b.z;
+        }
+        opac = in.opacities[gi];
+        if (has_sh) {
+            const float *__restrict__ shp = in.shs + gi * (size_t)in.sh_coeffs * 3;
+            const int ncoef = deg >= 3 ? 16 : (deg + 1) * (deg + 1);
+            if (in.flags & VS_RASTER_SH_RGB_MAJOR) {
+                const int M = in.sh_coeffs;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) sh[k][ch] = k < ncoef ? shp[ch * M + k] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < ncoef) {
+                        const f3_t v = *reinterpret_cast<const f3_t *>(shp + 3 * k);
+                        sh[k][0] = v.x; sh[k][1] = v.y; sh[k][2] = v.z;
+                    } else {
+                        sh[k][0] = sh[k][1] = sh[k][2] = 0.f;
+                    }
+                }
+            }
+        } else {
+            const f3_t v = *reinterpret_cast<const f3_t *>(in.colors_precomp + 3 * gi);
+            sh[0][0] = v.x; sh[0][1] = v.y; sh[0][2] = v.z;
+        }
+    }
+    const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
+
+    for (int c = 0; c < in.num_cameras; ++c) {
+        const int cs = in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes);
+        if (cs != s) continue;  // block-uniform
+        if (use_lds) {
+            for (int t = threadIdx.x; t < tiles; t += 256) hist[t] = 0;
+            __syncthreads();
+        }
+        const size_t ci = (size_t)c * P + i;
+        bool visible = false;
+        int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+        if (live) {
+            const float *__restrict__ vm = in.viewmatrix + 16 * c;
+            const float *__restrict__ pm = in.projmatrix + 16 * c;
+            const float tanfovx = in.tanfov[2 * c], tanfovy = in.tanfov[2 * c + 1];
+            const float focal_x = (float)W / (2.0f * tanfovx), focal_y = (float)H / (2.0f * tanfovy);
+            int radius_i = 0;
+            uint32_t clamp_bits = 0;
+            do {
+                const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+                const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+                const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+                if (!(vz > 0.2f)) break;
+                const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+                const float hy = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+                const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+                const float p_w = 1.0f / (hw + 0.0000001f);
+                const float projx = hx * p_w, projy = hy * p_w;
+
+                const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+                const float txtz = vx / vz, tytz = vy / vz;
+                const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+                const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+                const float tz = vz;
+                const float J00 = focal_x / tz, J02 = -(focal_x * tx) / (tz * tz);
+                const float J11 = focal_y / tz, J12 = -(focal_y * ty) / (tz * tz);
+                float M0[3], M1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    M0[k] = J00 * vm[4 * k + 0] + J02 * vm[4 * k + 2];
+                    M1[k] = J11 * vm[4 * k + 1] + J12 * vm[4 * k + 2];
+                }
+                float t0[3], t1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    t0[k] = S[k][0] * M0[0] + S[k][1] * M0[1] + S[k][2] * M0[2];
+                    t1[k] = S[k][0] * M1[0] + S[k][1] * M1[1] + S[k][2] * M1[2];
+                }
+                const float a = M0[0] * t0[0] + M0[1] * t0[1] + M0[2] * t0[2] + 0.3f;
+                const float b = M0[0] * t1[0] + M0[1] * t1[1] + M0[2] * t1[2];
+                const float cc = M1[0] * t1[0] + M1[1] * t1[1] + M1[2] * t1[2] + 0.3f;
+                const float det = a * cc - b * b;
+                if (det == 0.0f) break;
+                const float det_inv = 1.0f / det;
+                const float conx = cc * det_inv, cony = -b * det_inv, conz = a * det_inv;
+                const float mid = 0.5f * (a + cc);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda1 = mid + sq, lambda2 = mid - sq;
+                const float my_radius = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+                const float pixx = ((projx + 1.0f) * (float)W - 1.0f) * 0.5f;
+                const float pixy = ((projy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                rminx = min(gx, max(0, f2i((pixx - my_radius) / (float)kTile)));
+                rminy = min(gy, max(0, f2i((pixy - my_radius) / (float)kTile)));
+                rmaxx = min(gx, max(0, f2i((pixx + my_radius + (float)(kTile - 1)) / (float)kTile)));
+                rmaxy = min(gy, max(0, f2i((pixy + my_radius + (float)(kTile - 1)) / (float)kTile)));
+                if ((rmaxx - rminx) * (rmaxy - rminy) <= 0) break;
+
+                float rgb[3];
+                if (!has_sh) {
+                    rgb[0] = sh[0][0]; rgb[1] = sh[0][1]; rgb[2] = sh[0][2];
+                } else {
+                    const float *__restrict__ cp = in.campos + 3 * c;
+                    const float dx = px - cp[0], dy = py - cp[1], dz = pz - cp[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    const float x = dx / len, y = dy / len, z = dz / len;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float r = SH_C0 * sh[0][ch];
+                        if (deg > 0) {
+                            r = r - SH_C1 * y * sh[1][ch] + SH_C1 * z * sh[2][ch] - SH_C1 * x * sh[3][ch];
+                            if (deg > 1) {
+                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                                r = r + SH_C2[0] * xy * sh[4][ch] + SH_C2[1] * yz * sh[5][ch] +
+                                    SH_C2[2] * (2.0f * zz - xx - yy) * sh[6][ch] + SH_C2[3] * xz * sh[7][ch] +
+                                    SH_C2[4] * (xx - yy) * sh[8][ch];
+                                if (deg > 2) {
+                                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * sh[9][ch] + SH_C3[1] * xy * z * sh[10][ch] +
+                                        SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[11][ch] +
+                                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12][ch] +
+                                        SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[13][ch] +
+                                        SH_C3[5] * z * (xx - yy) * sh[14][ch] + SH_C3[6] * x * (xx - 3.0f * yy) * sh[15][ch];
+                                }
+                            }
+                        }
+                        r += 0.5f;
+                        if (r < 0.0f) clamp_bits |= (1u << ch);
+                        rgb[ch] = fmaxf(r, 0.0f);
+                    }
+                }
+                float4 *g4 = reinterpret_cast<float4 *>(geom + ci * kGeomFloats);
+                g4[0] = make_float4(pixx, pixy, vz, my_radius);
+                g4[1] = make_float4(conx, cony, conz, opac);
+                g4[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                radius_i = f2i(my_radius);
+                visible = true;
+            } while (false);
+            radii[ci] = radius_i;
+            rect[ci] = visible ? make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy)
+                               : make_ushort4(0, 0, 0, 0);
+            clamped[ci] = (uint8_t)clamp_bits;
+        }
+        int32_t *tc = tile_count + (size_t)c * tiles;
+        if (visible) {
+            for (int y = rminy; y < rmaxy; ++y)
+                for (int x = rminx; x < rmaxx; ++x) {
+                    if (use_lds) atomicAdd(&hist[y * gx + x], 1);
+                    else atomicAdd(&tc[y * gx + x], 1);
+                }
+        }
+        if (use_lds) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < tiles; t += 256) {
+                const int v = hist[t];
+                if (v) atomicAdd(&tc[t], v);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: exclusive scan of the C*tiles counts -> tile ranges; zeroes the counters (re-used as scatter cursors).
+// Single workgroup (n is a few thousand).  misc[0] = R (int64), misc[1] = max tile population.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tile_scan_kernel(int32_t *__restrict__ count, int2 *__restrict__ ranges, int n,
+                                                          long long *__restrict__ misc) {
+    __shared__ long long wave_tot[16];
+    __shared__ long long carry_s;
+    __shared__ int max_s[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    int local_max = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int idx = base + tid;
+        const int v = idx < n ? count[idx] : 0;
+        local_max = max(local_max, v);
+        long long x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            long long y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+        const long long carry = carry_s;
+        const long long incl = carry + woff + x;
+        if (idx < n) {
+            ranges[idx] = make_int2((int)(incl - v), (int)incl);
+            count[idx] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = incl;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local_max = max(local_max, __shfl_xor(local_max, o, 64));
+    if (lane == 0) max_s[wid] = local_max;
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int w = 0; w < 16; ++w) m = max(m, max_s[w]);
+        misc[0] = carry_s;
+        misc[1] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: scatter (depth_bits<<32 | gaussian) keys into the per-(camera,tile) segments.  grid = (ceil(P/256), C).
+// Block-aggregated: instances are counted in an LDS histogram, one returning global atomic per non-empty bin
+// reserves the block's slots in the tile segment, then each instance takes an LDS-local slot.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+scatter_kernel(int P, int tiles, int gx, const float *__restrict__ geom, const ushort4 *__restrict__ rect,
+               const int32_t *__restrict__ radii, const int2 *__restrict__ ranges, int32_t *__restrict__ cursor,
+               unsigned long long *__restrict__ keys) {
+    __shared__ int hist[kHistTiles];
+    __shared__ int base[kHistTiles];
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool use_lds = tiles <= kHistTiles;
+    const size_t ci = (size_t)c * P + (i < P ? i : 0);
+    const bool visible = i < P && radii[ci] > 0;
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    unsigned long long key = 0;
+    if (visible) {
+        r = rect[ci];
+        key = ((unsigned long long)__float_as_uint(geom[ci * kGeomFloats + 2]) << 32) | (unsigned)i;
+    }
+    const size_t t0 = (size_t)c * tiles;
+    if (!use_lds) {
+        for (int y = r.y; y < r.w; ++y)
+            for (int x = r.x; x < r.z; ++x) {
+                const size_t t = t0 + y * gx + x;
+                const int slot = atomicAdd(&cursor[t], 1);
+                keys[(size_t)ranges[t].x + slot] = key;
+            }
+        return;
+    }
+    for (int t = threadIdx.x; t < tiles; t += 256) hist[t] = 0;
+    __syncthreads();
+    for (int y = r.y; y < r.w; ++y)
+        for (int x = r.x; x < r.z; ++x) atomicAdd(&hist[y * gx + x], 1);
+    __syncthreads();
+    for (int t = threadIdx.x; t < tiles; t += 256) {
+        const int v = hist[t];
+        if (v) {
+            base[t] = ranges[t0 + t].x + atomicAdd(&cursor[t0 + t], v);
+            hist[t] = 0;
+        }
+    }
+    __syncthreads();
+    for (int y = r.y; y < r.w; ++y)
+        for (int x = r.x; x < r.z; ++x) {
+            const int t = y * gx + x;
+            const int slot = atomicAdd(&hist[t], 1);
+            keys[(size_t)base[t] + slot] = key;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K4: one workgroup per (camera, tile) sorts its key segment.  n <= kSortLds: bitonic network in LDS;
+// larger segments: same network on a padded copy in global scratch (bump-allocated).  Output: sorted ids.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSortLds = 8192;  // 64 KiB of LDS -> 2 workgroups per CU
+
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr a, int N) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (N >> 1); t += 256) {
+                const int i = 2 * t - (t & (j - 1));
+                const int l = i + j;
+                const bool up = ((i & k) == 0);
+                const unsigned long long x = a[i], y = a[l];
+                if ((x > y) == up) { a[i] = y; a[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict__ keys, uint32_t *__restrict__ point_list,
+                 unsigned long long *__restrict__ scratch, unsigned long long *__restrict__ bump) {
+    __shared__ unsigned long long skeys[kSortLds];
+    __shared__ unsigned long long sbase;
+    const size_t t = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int2 rg = ranges[t];
+    const int n = rg.y - rg.x;
+    if (n <= 0) return;
+    unsigned long long *seg = keys + rg.x;
+    if (n == 1) {
+        if (threadIdx.x == 0) point_list[rg.x] = (uint32_t)seg[0];
+        return;
+    }
+    int N = 2;
+    while (N < n) N <<= 1;
+    if (N <= kSortLds) {
+        for (int k = threadIdx.x; k < N; k += 256) skeys[k] = k < n ? seg[k] : ~0ull;
+        __syncthreads();
+        bitonic_sort(skeys, N);
+        for (int k = threadIdx.x; k < n; k += 256) point_list[rg.x + k] = (uint32_t)skeys[k];
+    } else {
+        if (threadIdx.x == 0) sbase = atomicAdd(bump, (unsigned long long)N);
+        __syncthreads();
+        unsigned long long *g = scratch + sbase;
+        for (int k = threadIdx.x; k < N; k += 256) g[k] = k < n ? seg[k] : ~0ull;
+        __syncthreads();
+        bitonic_sort(g, N);
+        for (int k = threadIdx.x; k < n; k += 256) point_list[rg.x + k] = (uint32_t)g[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5: render.  One workgroup of 256/PXL threads per (camera, tile); every lane owns PXL pixels of one column
+// (x = tid%16, y = (tid/16)*PXL + k).  PXL=4 is "one wavefront per tile".  Entries are staged through LDS in
+// batches of blockDim records (coalesced id read, 3 x 16-byte gathers of the packed record).
+// ---------------------------------------------------------------------------------------------------------
+template <int PXL, bool COUNT_TOUCHED>
+__global__ void __launch_bounds__(256 / PXL)
+render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+              const float *__restrict__ geom, const float *__restrict__ background, float *__restrict__ out_color,
+              float *__restrict__ out_depth, float *__restrict__ out_opacity, float *__restrict__ final_T,
+              int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched) {
+    constexpr int NT = 256 / PXL;
+    __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
+    const int c = blockIdx.y;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tiles = gridDim.x;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int tile_x = tile % gx, tile_y = tile / gx;
+    const int pxi = tile_x * kTile + (tid & 15);
+    const int py0 = tile_y * kTile + (tid >> 4) * PXL;
+    const float pixfx = (float)pxi;
+    const int2 rg = ranges[(size_t)c * tiles + tile];
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
+
+    float T[PXL], Cr[PXL], Cg[PXL], Cb[PXL], Dd[PXL], pixfy[PXL];
+    int last_contrib[PXL];
+    bool done[PXL];
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) {
+        T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = Dd[k] = 0.0f; last_contrib[k] = 0;
+        pixfy[k] = (float)(py0 + k);
+        done[k] = !(pxi < W && (py0 + k) < H);
+    }
+
+    int todo = rg.y - rg.x;
+    int contributor = 0;
+    for (int base = rg.x; base < rg.y; base += NT, todo -= NT) {
+        bool all_done = true;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) all_done = all_done && done[k];
+        if (__syncthreads_count(all_done) == NT) break;
+        if (base + tid < rg.y) {
+            const uint32_t g = point_list[base + tid];
+            const float4 q0 = g4[(size_t)g * 3 + 0];
+            const float4 q1 = g4[(size_t)g * 3 + 1];
+            float4 q2 = g4[(size_t)g * 3 + 2];
+            q2.w = __uint_as_float(g);
+            sq0[tid] = q0; sq1[tid] = q1; sq2[tid] = q2;
+        }
+        __syncthreads();
+        const int cnt = min(NT, todo);
+        for (int j = 0; j < cnt; ++j) {
+            ++contributor;
+            const float4 q0 = sq0[j];
+            const float4 q1 = sq1[j];
+            const float dx = q0.x - pixfx;
+            int touched = 0;
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) {
+                if (done[k]) continue;
+                const float dy = q0.y - pixfy[k];
+                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, q1.w * __expf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T[k] * (1.0f - alpha);
+                if (test_T < 0.0001f) { done[k] = true; continue; }
+                const float4 q2 = sq2[j];
+                const float w = alpha * T[k];
+                Cr[k] += q2.x * w; Cg[k] += q2.y * w; Cb[k] += q2.z * w;
+                Dd[k] += q0.z * w;
+                if (COUNT_TOUCHED && test_T > 0.5f) ++touched;
+                T[k] = test_T;
+                last_contrib[k] = contributor;
+            }
+            if (COUNT_TOUCHED) {
+                // wave-level reduction, one atomic per wave per entry
+                int tot = touched;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                if ((tid & 63) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + __float_as_uint(sq2[j].w)], tot);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float bgr = background[3 * c], bgg = background[3 * c + 1], bgb = background[3 * c + 2];
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) {
+        const int py = py0 + k;
+        if (pxi < W && py < H) {
+            const size_t pix = (size_t)py * W + pxi;
+            final_T[c * HW + pix] = T[k];
+            n_contrib[c * HW + pix] = last_contrib[k];
+            out_color[(c * 3 + 0) * HW + pix] = Cr[k] + T[k] * bgr;
+            out_color[(c * 3 + 1) * HW + pix] = Cg[k] + T[k] * bgg;
+            out_color[(c * 3 + 2) * HW + pix] = Cb[k] + T[k] * bgb;
+            out_depth[c * HW + pix] = Dd[k];
+            out_opacity[c * HW + pix] = 1.0f - T[k];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsAllocFn alloc, void *actx, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && out && alloc, "vs_raster_forward: null argument");
+    VS_CHECK(in->num_cameras > 0 && in->num_scenes > 0 && in->P >= 0, "vs_raster_forward: bad sizes C=%d S=%d P=%d",
+             in->num_cameras, in->num_scenes, in->P);
+    VS_CHECK(in->width > 0 && in->height > 0, "vs_raster_forward: bad image size %dx%d", in->width, in->height);
+    VS_CHECK(in->P == 0 || (in->shs != nullptr) != (in->colors_precomp != nullptr),
+             "vs_raster_forward: exactly one of shs / colors_precomp must be given");
+    if (in->shs) {
+        const int need = in->sh_degree >= 3 ? 16 : (in->sh_degree + 1) * (in->sh_degree + 1);
+        VS_CHECK(in->sh_coeffs >= need, "vs_raster_forward: sh_coeffs=%d too small for sh_degree=%d", in->sh_coeffs, in->sh_degree);
+    }
+    VS_CHECK(in->P == 0 || (in->means3D && in->cov3D && in->opacities), "vs_raster_forward: null Gaussian pointer");
+    VS_CHECK(in->viewmatrix && in->projmatrix && in->campos && in->tanfov && in->background,
+             "vs_raster_forward: null camera pointer");
+    VS_CHECK(out->color && out->depth && out->opacity && (out->radii || in->P == 0), "vs_raster_forward: null output pointer");
+    const int C = in->num_cameras, P = in->P, W = in->width, H = in->height;
+    const int gx = vs::cdiv(W, kTile), gy = vs::cdiv(H, kTile), tiles = gx * gy;
+    VS_CHECK(gx <= 65535 && gy <= 65535, "vs_raster_forward: image too large");
+    const size_t CP = (size_t)C * P;
+
+    for (int k = 0; k < VS_BUF_COUNT; ++k) out->buffers[k] = nullptr;
+    auto get = [&](int tag, size_t bytes) -> void * {
+        void *p = alloc(actx, tag, bytes ? bytes : 16);
+        out->buffers[tag] = p;
+        return p;
+    };
+    float *geom = (float *)get(VS_BUF_GEOM, CP * kGeomFloats * sizeof(float));
+    ushort4 *rect = (ushort4 *)get(VS_BUF_RECT, CP * sizeof(ushort4));
+    uint8_t *clamped = (uint8_t *)get(VS_BUF_CLAMPED, CP);
+    int2 *ranges = (int2 *)get(VS_BUF_TILE_RANGES, (size_t)C * tiles * sizeof(int2));
+    int32_t *cursor = (int32_t *)get(VS_BUF_TILE_CURSOR, (size_t)C * tiles * sizeof(int32_t));
+    long long *misc = (long long *)get(VS_BUF_MISC, 4 * sizeof(long long));
+    float *final_T = (float *)get(VS_BUF_FINAL_T, (size_t)C * H * W * sizeof(float));
+    int32_t *n_contrib = (int32_t *)get(VS_BUF_N_CONTRIB, (size_t)C * H * W * sizeof(int32_t));
+    VS_CHECK(geom && rect && clamped && ranges && cursor && misc && final_T && n_contrib, "vs_raster_forward: allocator returned null");
+
+    VS_HIP(hipMemsetAsync(cursor, 0, (size_t)C * tiles * sizeof(int32_t), stream));
+    VS_HIP(hipMemsetAsync(misc, 0, 4 * sizeof(long long), stream));
+    if (out->n_touched) VS_HIP(hipMemsetAsync(out->n_touched, 0, CP * sizeof(int32_t), stream));
+    if (P > 0) {
+        dim3 grid(vs::cdiv(P, 256), in->num_scenes);
+        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, stream, *in, geom, rect, clamped, out->radii, cursor);
+    }
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, cursor, ranges, C * tiles, misc);
+    long long host_misc[2] = {0, 0};
+    VS_HIP(hipMemcpyAsync(host_misc, misc, sizeof(host_misc), hipMemcpyDeviceToHost, stream));
+    VS_HIP(hipStreamSynchronize(stream));
+    const long long R = host_misc[0];
+    const long long max_tile = host_misc[1];
+    VS_CHECK(R >= 0 && R < 2147483647LL, "vs_raster_forward: %lld (Gaussian,tile) instances overflow int32 ranges", R);
+    out->num_rendered = R;
+
+    unsigned long long *keys = (unsigned long long *)get(VS_BUF_KEYS, (size_t)R * 8);
+    uint32_t *point_list = (uint32_t *)get(VS_BUF_POINT_LIST, (size_t)R * 4);
+    unsigned long long *scratch = nullptr;
+    if (max_tile > kSortLds) scratch = (unsigned long long *)get(VS_BUF_SORT_SCRATCH, (size_t)R * 2 * 8);
+    VS_CHECK(keys && point_list && (max_tile <= kSortLds || scratch), "vs_raster_forward: allocator returned null");
+    if (R > 0) {
+        dim3 grid(vs::cdiv(P, 256), C);
+        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, geom, rect, out->radii, ranges, cursor, keys);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch,
+                           (unsigned long long *)(misc + 2));
+    }
+    const bool count = (in->flags & VS_RASTER_COUNT_TOUCHED) && out->n_touched;
+    dim3 rgrid(tiles, C);
+    if (count)
+        hipLaunchKernelGGL((render_kernel<4, true>), rgrid, dim3(64), 0, stream, P, W, H, ranges, point_list, geom, in->background,
+                           out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched);
+    else
+        hipLaunchKernelGGL((render_kernel<4, false>), rgrid, dim3(64), 0, stream, P, W, H, ranges, point_list, geom, in->background,
+                           out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched);
+    VS_HIP(hipGetLastError());
+    return R;
+}

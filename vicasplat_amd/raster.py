@@ -1,0 +1,162 @@
+"""Batched Gaussian rasterizer op (autograd-aware) on top of the C ABI (vs_raster_forward / vs_raster_backward).
+
+One call renders every camera of every scene in the batch: Gaussians are stored once per scene and shared by the
+scene's cameras (the reference replicates them per view, decoder_splatting_cuda.py:86-89, and loops over views in
+Python, cuda_splatting.py:199-238).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
+                  cam_scene, H, W, sh_degree, flags):
+    """Calls vs_raster_forward; returns (outputs, state) where state keeps every device buffer alive."""
+    dev = L.require_device(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background)
+    lib = L.lib()
+    S, P = means3D.shape[0], means3D.shape[1]
+    Cn = viewmatrix.shape[0]
+    cov33 = cov3D.dim() == 4
+    M = 0
+    if shs is not None:
+        M = shs.shape[3] if (flags & L.VS_RASTER_SH_RGB_MAJOR) else shs.shape[2]
+    if cov33:
+        flags |= L.VS_RASTER_COV_3X3
+    inp = L.VsRasterIn()
+    inp.num_cameras, inp.num_scenes, inp.P = Cn, S, P
+    inp.sh_degree, inp.sh_coeffs, inp.width, inp.height, inp.flags = int(sh_degree), int(M), int(W), int(H), int(flags)
+    inp.means3D, inp.cov3D, inp.shs, inp.colors_precomp = L.ptr(means3D), L.ptr(cov3D), L.ptr(shs), L.ptr(colors_precomp)
+    inp.opacities, inp.cam_scene = L.ptr(opacities), L.ptr(cam_scene)
+    inp.viewmatrix, inp.projmatrix, inp.campos = L.ptr(viewmatrix), L.ptr(projmatrix), L.ptr(campos)
+    inp.tanfov, inp.background = L.ptr(tanfov), L.ptr(background)
+
+    color = torch.empty((Cn, 3, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
+    opacity = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((Cn, P), dtype=torch.int32, device=dev)
+    n_touched = torch.empty((Cn, P), dtype=torch.int32, device=dev) if (flags & L.VS_RASTER_COUNT_TOUCHED) else None
+    out = L.VsRasterOut()
+    out.color, out.depth, out.opacity, out.radii, out.n_touched = L.ptr(color), L.ptr(depth), L.ptr(opacity), L.ptr(radii), L.ptr(n_touched)
+    alloc = L.TorchAllocator(dev)
+    with torch.cuda.device(dev):
+        R = lib.vs_raster_forward(C.byref(inp), C.byref(out), alloc.fn, None, L.stream_ptr(dev))
+    L.check(R, "vs_raster_forward")
+    if n_touched is None:
+        n_touched = torch.zeros((Cn, P), dtype=torch.int32, device=dev)
+    state = dict(inp=inp, out=out, alloc=alloc, dims=(S, P, Cn, M, H, W, cov33), num_rendered=int(R),
+                 keep=(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
+                       cam_scene, color, depth, opacity, radii))
+    return (color, radii, depth, opacity, n_touched), state
+
+
+def forward_debug(means3D, cov3D, opacities, viewmatrix, projmatrix, campos, tanfov, background, H, W, *, shs=None,
+                  colors_precomp=None, sh_degree=0, sh_rgb_major=False, cam_scene=None, count_touched=True) -> dict:
+    """Forward + typed views of the internal buffers (for the parity tests: integer data must be bit-exact)."""
+    flags = (L.VS_RASTER_SH_RGB_MAJOR if sh_rgb_major else 0) | (L.VS_RASTER_COUNT_TOUCHED if count_touched else 0)
+    Cn = viewmatrix.shape[0]
+    if cam_scene is not None:
+        cam_scene = cam_scene.to(torch.int32).contiguous()
+    outs, st = _forward_impl(_f32c(means3D), _f32c(cov3D), _f32c(shs), _f32c(colors_precomp), _f32c(opacities),
+                             _f32c(viewmatrix).reshape(Cn, 16), _f32c(projmatrix).reshape(Cn, 16), _f32c(campos),
+                             _f32c(tanfov), _f32c(background), cam_scene, int(H), int(W), int(sh_degree), flags)
+    S, P, Cn, M, H, W, _ = st["dims"]
+    t = st["alloc"].tensors
+    R = st["num_rendered"]
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return dict(color=outs[0], radii=outs[1], depth=outs[2], opacity=outs[3], n_touched=outs[4], R=R,
+                geom=t[L.VS_BUF_GEOM].view(torch.float32)[:Cn * P * 12].view(Cn, P, 12),
+                rect=t[L.VS_BUF_RECT].view(torch.int16)[:Cn * P * 4].view(Cn, P, 4),
+                clamped=t[L.VS_BUF_CLAMPED][:Cn * P].view(Cn, P),
+                ranges=t[L.VS_BUF_TILE_RANGES].view(torch.int32)[:Cn * tiles * 2].view(Cn, tiles, 2),
+                point_list=t[L.VS_BUF_POINT_LIST].view(torch.int32)[:R],
+                final_T=t[L.VS_BUF_FINAL_T].view(torch.float32)[:Cn * H * W].view(Cn, H, W),
+                n_contrib=t[L.VS_BUF_N_CONTRIB].view(torch.int32)[:Cn * H * W].view(Cn, H, W), _state=st)
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
+                cam_scene, theta, rho, projmatrix_raw, H, W, sh_degree, flags):
+        outs, st = _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov,
+                                 background, cam_scene, H, W, sh_degree, flags)
+        color, radii, depth, opacity, n_touched = outs
+        ctx.inp, ctx.out, ctx.alloc = st["inp"], st["out"], st["alloc"]
+        ctx.keep = (means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
+                    cam_scene, projmatrix_raw, color, depth, opacity, radii)
+        ctx.want_tau = theta is not None or rho is not None
+        ctx.dims = st["dims"]
+        ctx.num_rendered = st["num_rendered"]
+        ctx.mark_non_differentiable(radii, n_touched, opacity)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_opacity, g_touched):
+        lib = L.lib()
+        if not hasattr(lib, "vs_raster_backward"):
+            raise RuntimeError("libvicasplat_hip.so was built without vs_raster_backward")
+        (means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background, cam_scene,
+         projmatrix_raw, *_rest) = ctx.keep
+        S, P, Cn, M, H, W, cov33 = ctx.dims
+        dev = means3D.device
+        g_color = _f32c(g_color) if g_color is not None else torch.zeros((Cn, 3, H, W), dtype=torch.float32, device=dev)
+        g_depth = _f32c(g_depth)
+        g = L.VsRasterGrads()
+        d_means = torch.zeros_like(means3D)
+        d_cov = torch.zeros((S, P, 6), dtype=torch.float32, device=dev)
+        d_shs = torch.zeros_like(shs) if shs is not None else None
+        d_cp = torch.zeros_like(colors_precomp) if colors_precomp is not None else None
+        d_op = torch.zeros_like(opacities)
+        d_m2d = torch.zeros((Cn, P, 2), dtype=torch.float32, device=dev)
+        d_tau = torch.zeros((Cn, 6), dtype=torch.float32, device=dev) if ctx.want_tau else None
+        g.dL_dcolor, g.dL_ddepth = L.ptr(g_color), L.ptr(g_depth)
+        g.dL_dmeans3D, g.dL_dcov3D, g.dL_dshs, g.dL_dcolors_precomp = L.ptr(d_means), L.ptr(d_cov), L.ptr(d_shs), L.ptr(d_cp)
+        g.dL_dopacities, g.dL_dmeans2D, g.dL_dtau = L.ptr(d_op), L.ptr(d_m2d), L.ptr(d_tau)
+        alloc = L.TorchAllocator(dev)
+        with torch.cuda.device(dev):
+            rc = lib.vs_raster_backward(C.byref(ctx.inp), C.byref(ctx.out), C.byref(g), alloc.fn, None, L.stream_ptr(dev))
+        L.check(rc, "vs_raster_backward")
+        if cov33:  # spread the 6 unique partials back onto the symmetric 3x3 layout the caller differentiates
+            d33 = torch.empty((S, P, 3, 3), dtype=torch.float32, device=dev)
+            d33[..., 0, 0] = d_cov[..., 0]; d33[..., 1, 1] = d_cov[..., 3]; d33[..., 2, 2] = d_cov[..., 5]
+            d33[..., 0, 1] = d33[..., 1, 0] = 0.5 * d_cov[..., 1]
+            d33[..., 0, 2] = d33[..., 2, 0] = 0.5 * d_cov[..., 2]
+            d33[..., 1, 2] = d33[..., 2, 1] = 0.5 * d_cov[..., 4]
+            d_cov = d33
+        d_theta = d_tau[:, 3:] if d_tau is not None else None
+        d_rho = d_tau[:, :3] if d_tau is not None else None
+        return (d_means, d_cov, d_shs, d_cp, d_op, None, None, None, None, None, None, d_theta, d_rho, None, None, None,
+                None, None)
+
+
+def rasterize(means3D, cov3D, opacities, viewmatrix, projmatrix, campos, tanfov, background, image_height, image_width, *,
+              shs=None, colors_precomp=None, sh_degree=0, sh_rgb_major=False, cam_scene=None, theta=None, rho=None,
+              projmatrix_raw=None, count_touched=False):
+    """means3D [S,P,3]; cov3D [S,P,6] | [S,P,3,3]; shs [S,P,M,3] | [S,P,3,M] (sh_rgb_major); opacities [S,P];
+    viewmatrix / projmatrix [C,16] (or [C,4,4], row-major flatten == the reference's transposed storage);
+    campos [C,3]; tanfov [C,2]; background [C,3]; cam_scene int32 [C] or None.
+    Returns (color [C,3,H,W], radii [C,P], depth [C,H,W], opacity [C,H,W], n_touched [C,P])."""
+    flags = 0
+    if sh_rgb_major:
+        flags |= L.VS_RASTER_SH_RGB_MAJOR
+    if count_touched:
+        flags |= L.VS_RASTER_COUNT_TOUCHED
+    Cn = viewmatrix.shape[0]
+    if cam_scene is not None:
+        cam_scene = cam_scene.to(torch.int32).contiguous()
+    return _Rasterize.apply(
+        _f32c(means3D), _f32c(cov3D), _f32c(shs), _f32c(colors_precomp), _f32c(opacities), _f32c(viewmatrix).reshape(Cn, 16),
+        _f32c(projmatrix).reshape(Cn, 16), _f32c(campos), _f32c(tanfov), _f32c(background), cam_scene, theta, rho,
+        _f32c(projmatrix_raw), int(image_height), int(image_width), int(sh_degree), flags)
