@@ -1,0 +1,98 @@
+"""Generates tests/golden/encoder_*.npz by running the REAL reference encoder (imported from /root/reference on
+CPU, see ref_import.py) on seeded synthetic inputs with key-seeded golden weights, in float32 AND float64.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_encoder_golden.py
+The fixtures are data (inputs are re-derivable from seeds; outputs are sampled), never reference source.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_import  # noqa: E402
+from oracle import encoder_ref as er  # noqa: E402  (only golden_weights / synthetic_input: shared seeded generators)
+
+LATTICE = slice(8, 256, 16)  # 16x16 pixel lattice
+PROBE = [0, 1, 7, 100, 1000, 5000, 20000, 50000]  # fixed flat indices (mod numel)
+
+
+def checksum(t: torch.Tensor) -> np.ndarray:
+    f = t.detach().double().flatten()
+    idx = torch.tensor([p % f.numel() for p in PROBE])
+    return torch.cat([f.mean()[None], f.abs().mean()[None], f[idx]]).numpy()
+
+
+def run(model, image, K, dtype):
+    model = model.to(dtype)
+    sums = {}
+    hooks = []
+    def enc_hook(i):
+        def h(m, a, o):
+            sums[f"enc{i:02d}"] = checksum(o)  # returns None: a forward hook's return value would replace the output
+        return h
+
+    def dec_hook(i):
+        def h(m, a, o):
+            sums[f"dec{i:02d}_img"] = checksum(o[0])
+            sums[f"dec{i:02d}_cam"] = checksum(o[1])
+        return h
+
+    for i, blk in enumerate(model.backbone.enc_blocks):
+        hooks.append(blk.register_forward_hook(enc_hook(i)))
+    for i, blk in enumerate(model.backbone.dec_blocks):
+        hooks.append(blk.register_forward_hook(dec_hook(i)))
+    with torch.no_grad():
+        out = model(dict(image=image.to(dtype), intrinsics=K.to(dtype)), compute_viewspace_depth=False)
+    for h in hooks:
+        h.remove()
+    g = out["gaussians"]
+    lat = lambda t: t[:, :, LATTICE, LATTICE].double().numpy()
+    res = dict(pred_extrins=out["pred_extrins"].double().numpy(), c2w=out["gaussian_camera_extrins"].double().numpy(),
+               raw=lat(out["raw_gaussians"]), means=lat(g.means), covariances=lat(g.covariances), harmonics=lat(g.harmonics),
+               opacities=lat(g.opacities), scales=lat(g.scales), rotations=lat(g.rotations),
+               blocks=np.stack([sums[k] for k in sorted(sums)]), block_names=np.array(sorted(sums)))
+    return res
+
+
+def make(name, overrides, B, V, seed=0, do_f64=True):
+    t0 = time.time()
+    model = ref_import.build_reference_encoder(overrides)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    W = er.golden_weights(shapes, seed=seed)
+    missing, unexpected = model.load_state_dict(W, strict=True), None
+    image, K = er.synthetic_input(B, V, 256, seed=seed)
+    out = {}
+    r32 = run(model, image, K, torch.float32)
+    out.update({f"f32_{k}": v for k, v in r32.items()})
+    if do_f64:
+        r64 = run(model, image, K, torch.float64)
+        out.update({f"f64_{k}": v for k, v in r64.items()})
+    out["cfg_B"], out["cfg_V"], out["cfg_seed"] = B, V, seed
+    out["cfg_overrides"] = np.array(repr(sorted((overrides or {}).items())))
+    out["n_params"] = sum(int(np.prod(s)) for s in shapes.values())
+    path = os.path.join(HERE, f"encoder_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] {path}: {os.path.getsize(path)/1e6:.2f} MB in {time.time()-t0:.1f}s; "
+          f"f32 vs f64 max|d raw| = {np.abs(r32['raw'] - r64['raw']).max() if do_f64 else float('nan'):.3e}")
+
+
+TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tiny_v3", "tiny_v2", "full_v2", "full_v8"]
+    if "tiny_v3" in which:
+        make("tiny_v3", TINY, B=2, V=3)
+    if "tiny_v2" in which:
+        make("tiny_v2", TINY, B=1, V=2)
+    if "full_v2" in which:
+        make("full_v2", None, B=1, V=2)
+    if "full_v8" in which:
+        make("full_v8", None, B=1, V=8)

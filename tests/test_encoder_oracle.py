@@ -1,0 +1,91 @@
+"""Pins the CPU encoder oracle (oracle/encoder_ref.py) against golden vectors produced by the REAL reference
+encoder imported from /root/reference (tests/golden/gen_encoder_golden.py).  CPU only (`-m "not gpu"`).
+
+Tolerances: float32 oracle vs float32 reference <= 1e-4 relative (both round differently through 36 blocks and
+expm1); float64 oracle vs float64 reference <= 1e-6 (the reference builds its RoPE tables in float32)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_ref as er
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
+LAT = slice(8, 256, 16)
+
+
+def _load(name):
+    z = np.load(os.path.join(G, f"encoder_{name}.npz"))
+    kind = "tiny" if name.startswith("tiny") else "full"
+    shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))
+    cfg = er.default_cfg(**(TINY if kind == "tiny" else {}))
+    return z, shapes, cfg
+
+
+def _run(name, dtype):
+    z, shapes, cfg = _load(name)
+    B, V, seed = int(z["cfg_B"]), int(z["cfg_V"]), int(z["cfg_seed"])
+    W = er.golden_weights(shapes, seed=seed, dtype=dtype)
+    img, K = er.synthetic_input(B, V, 256, seed)
+    return z, er.forward(W, cfg, img.to(dtype), K.to(dtype))
+
+
+def _check(z, out, tag, rtol):
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64).reshape(a.shape)
+        return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+
+    assert rel(out["pred_extrins"].double().numpy(), z[f"{tag}_pred_extrins"]) < rtol
+    assert rel(out["gaussian_camera_extrins"].double().numpy(), z[f"{tag}_c2w"]) < rtol
+    raw = out["raw_gaussians"][:, :, LAT, LAT].double().numpy()
+    ref = z[f"{tag}_raw"]
+    for sl in (slice(0, 3), slice(3, 4), slice(4, 7), slice(7, 11), slice(11, 86)):
+        assert rel(raw[..., sl], ref[..., sl]) < rtol, sl
+    g = out["gaussians"]
+    for k in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
+        assert rel(g[k][:, :, LAT, LAT].double().numpy(), z[f"{tag}_{k}"]) < rtol, k
+
+
+@pytest.mark.parametrize("name", ["tiny_v2", "tiny_v3"])
+def test_oracle_matches_reference_f32(name):
+    z, out = _run(name, torch.float32)
+    _check(z, out, "f32", 1e-4)
+
+
+def test_oracle_matches_reference_f64():
+    z, out = _run("tiny_v2", torch.float64)
+    _check(z, out, "f64", 1e-6)
+
+
+def test_oracle_matches_reference_full_vitl_2view():
+    """The real architecture (ViT-L 24+12 blocks, 578 M parameters), 2 views."""
+    z, out = _run("full_v2", torch.float32)
+    assert int(z["n_params"]) > 5.7e8
+    _check(z, out, "f32", 2e-4)
+    # f32 reference vs f64 reference (same fixture) bounds what any float32-class implementation can reach
+    assert np.abs(z["f32_raw"] - z["f64_raw"]).max() / np.abs(z["f64_raw"]).max() < 1e-4
+
+
+def test_pose_algebra_properties():
+    """dq -> (R,t): R orthonormal, frame 0 identity, unit real part (pypose restated, closed form)."""
+    torch.manual_seed(0)
+    W = {"camera_extrinsic_head.1.weight": torch.randn(8, 32), "camera_extrinsic_head.1.bias": torch.randn(8)}
+    dq, c2w = er.pose_from_camera_tokens(W, torch.randn(2, 3, 32))
+    assert torch.allclose(dq[..., :4].norm(dim=-1), torch.ones(2, 3), atol=1e-6)
+    R = c2w[..., :3, :3]
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand_as(R), atol=1e-5)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(2, 4), atol=1e-5)
+    assert torch.equal(c2w[:, 0], torch.eye(4).expand(2, 4, 4))
+    # translation formula t = vec(2 q_d (x) conj(q_r)); for unit q_r, (2 q_d (x) conj(q_r)) (x) q_r == 2 q_d
+    qr, t = dq[..., :4], c2w[:, 1:, :3, 3]
+    full = er.quat_mul_xyzw(2.0 * dq[..., 4:], qr * torch.tensor([-1.0, -1.0, -1.0, 1.0]))
+    assert torch.allclose(full[..., :3], t, atol=1e-6)
+    assert torch.allclose(0.5 * er.quat_mul_xyzw(full, qr), dq[..., 4:], atol=1e-5)
+
+
+def test_camera_mask_rows():
+    m = er.camera_mask(8, 257)
+    assert m.shape == (8, 8 * 258) and m.sum(1).tolist() == [258 * (t + 1) for t in range(8)]
