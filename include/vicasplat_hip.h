@@ -127,6 +127,39 @@ int vs_raster_backward(const VsRasterIn *in, const VsRasterOut *saved, const VsR
 int vs_rope2d(void *tokens, const int64_t *pos, int32_t B, int32_t N, int32_t H, int32_t D, int64_t sB, int64_t sN,
               float base, float fwd, int32_t dtype, vs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ViT block operators (replace nn.LayerNorm / nn.Linear / softmax attention / F.scaled_dot_product_attention on the
+ * encoder path: croco/blocks.py:73-130, backbone_vica.py:76-126,152-191,268-335).  dtype: 1 = f16, 2 = bf16 operands;
+ * accumulation, LayerNorm, softmax and the residual stream are f32.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* y = LN(x; w, b, eps) [* (1 + scale[row / mod_rows]) + shift[row / mod_rows]].  x f32 [M,C] (row stride ldx);
+ * out_dtype 0 = f32, 1 = f16, 2 = bf16 (row stride ldo); output row = (row / grp_in) * grp_out + grp_off + row % grp_in
+ * (grp_in <= 0: identity).  scale/shift may be NULL. */
+int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, const float *b, const float *scale, const float *shift,
+                     int32_t mod_rows, int32_t mod_ld, void *out, int64_t ldo, int32_t out_dtype, int32_t M, int32_t C,
+                     float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream);
+
+/* out = epilogue(A[M,K] * W[N,K]^T + bias).  epilogue: 0 store 16-bit, 1 exact-erf GELU then store 16-bit,
+ * 2 f32 residual update out += (1 + gate[row / gate_rows]) * (.), 3 store f32.  K % 64 == 0; lda/ldw % 8 == 0.
+ * Output row mapping as in vs_layernorm_mod. */
+int vs_gemm_bias_act(const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M, int32_t N,
+                     int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype, int32_t grp_in,
+                     int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, vs_stream_t stream);
+
+/* In-place RoPE on the q (column 0) and k (column k_col) blocks of a packed projection buffer [rows, ld], H heads of
+ * 64.  pos int32 [rows,2] (y,x) or (t,-); kind uint8 [rows] (0 = 2-D, 1 = temporal 1-D interleaved, 2 = none) or NULL. */
+int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos, const uint8_t *kind,
+               float base2d, float theta1d, int32_t dtype, vs_stream_t stream);
+
+/* Fused attention, head dim 64.  Batch item b, head h: queries rows b*q_batch_rows + [0,Lq) of q (row stride ldq,
+ * head h at column h*64); keys/values rows b*k_batch_rows + [0,Lk) of k / v -- or, when kv_seg != NULL, the two row
+ * segments kv_seg[b] = {base0, len0, base1, len1} concatenated.  q_kvlen (optional, [nbatch*Lq]) limits query i to
+ * the first q_kvlen keys.  out: [rows, ldo], head h at column h*64. */
+int vs_attention(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
+                 int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                 const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype, vs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

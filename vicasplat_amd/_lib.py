@@ -80,6 +80,15 @@ def lib() -> C.CDLL:
             L.vs_rope2d.restype = C.c_int
             L.vs_rope2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_void_p]
+            i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+            L.vs_layernorm_mod.restype = C.c_int
+            L.vs_layernorm_mod.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, i32, i32, i32, f32, i32, i32, i32, vp]
+            L.vs_gemm_bias_act.restype = C.c_int
+            L.vs_gemm_bias_act.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_rope_qk.restype = C.c_int
+            L.vs_rope_qk.argtypes = [vp, i64, i32, i32, i32, vp, vp, f32, f32, i32, vp]
+            L.vs_attention.restype = C.c_int
+            L.vs_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp]
             if hasattr(L, "vs_raster_backward"):
                 L.vs_raster_backward.restype = C.c_int
                 L.vs_raster_backward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), C.POINTER(VsRasterGrads),

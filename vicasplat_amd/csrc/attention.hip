@@ -1,0 +1,254 @@
+// Fused multi-head attention forward (head_dim 64) for gfx950: softmax(Q K^T * scale) V without materialising the
+// score matrix.  One kernel serves the three attention shapes of VicaSplat:
+//   * frame encoder        croco/blocks.py:94-112        257 queries x 257 keys per (frame, head)
+//   * video/camera         backbone_vica.py:76-126        T*258 queries x T*258 keys; camera-token queries see the
+//                                                         key PREFIX of frames <= t (the blocked-causal mask of
+//                                                         :585-593 is exactly a per-query key-prefix length)
+//   * cross-neighbour      backbone_vica.py:152-191       257 queries x keys of frames t-1 and t+1: expressed as two
+//                                                         key SEGMENTS per batch item, gathered by row index -- no
+//                                                         roll / cat copies of K and V
+// Q, K, V are read in place from the packed projection output ([row, 3*H*64] with q | k | v column blocks): no
+// head transposes.  Output is token-major [row, H*64], directly the A operand of the projection GEMM.
+//
+// CDNA4 mapping: 256 threads = 4 waves, 16 query rows per wave (64 per workgroup), 64-key tiles staged in LDS
+// (K row-major, V transposed so that MFMA B fragments are two ds_read_b64).  Scores are computed TRANSPOSED
+// (S^T = K Q^T with v_mfma_f32_16x16x32) so that every lane owns ONE query column: the online-softmax row
+// reductions are 15 in-register max/adds + 2 cross-lane steps, and the f32->16-bit P fragments are already in
+// the A-operand layout of the P.V MFMA (keys permuted consistently on the V side).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64;       // head dim
+constexpr int QB = 64;       // queries per workgroup
+constexpr int KB = 64;       // keys per tile
+constexpr int KROW = HD + 8; // halfs, K tile row stride (144 B)
+constexpr int VROW = KB + 8; // halfs, V^T tile row stride (144 B)
+
+struct AttnArgs {
+    const unsigned short *q, *k, *v;
+    unsigned short *out;
+    const int32_t *kv_seg;   // [nbatch,4] base0,len0,base1,len1 (rows) or null
+    const int32_t *q_kvlen;  // [nbatch*Lq] or null
+    int nbatch, H, Lq, Lk;
+    long long q_batch_rows, k_batch_rows;
+    int ldq, ldk, ldv, ldo;
+    float scale_log2e;
+};
+
+template <bool BF16>
+__device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
+}
+
+template <bool BF16>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    if constexpr (BF16) {
+        unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        ua += 0x7FFFu + ((ua >> 16) & 1u);
+        ub += 0x7FFFu + ((ub >> 16) & 1u);
+        return (ua >> 16) | (ub & 0xFFFF0000u);
+    } else {
+        _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        return (unsigned)(*reinterpret_cast<unsigned short *>(&ha)) | ((unsigned)(*reinterpret_cast<unsigned short *>(&hb)) << 16);
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ unsigned short to16(float v) {
+    return (unsigned short)(pack2<BF16>(v, 0.f) & 0xFFFFu);
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[KB * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned short sVT[HD * VROW];
+    __shared__ int s_maxlen;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+
+    int base0, len0, base1, len1;
+    if (a.kv_seg) {
+        base0 = a.kv_seg[4 * b + 0]; len0 = a.kv_seg[4 * b + 1]; base1 = a.kv_seg[4 * b + 2]; len1 = a.kv_seg[4 * b + 3];
+    } else {
+        base0 = (int)(b * a.k_batch_rows); len0 = a.Lk; base1 = 0; len1 = 0;
+    }
+    const int Lk = len0 + len1;
+
+    // ---- this lane's query (column of S^T): q index within the batch item ----
+    const int qi = q0 + wid * 16 + c16;
+    const bool qvalid = qi < a.Lq;
+    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+    int my_len = Lk;
+    if (a.q_kvlen && qvalid) my_len = min(Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+    if (!qvalid) my_len = 0;
+    // block-uniform loop bound
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    atomicMax(&s_maxlen, my_len);
+    __syncthreads();
+    const int maxlen = s_maxlen;
+
+    // Q fragments (B operand of S^T = K Q^T): lane holds q = c16, d = ks*32 + g*8 .. +7
+    uint4 qf[2];
+    {
+        const unsigned short *qp = a.q + qrow * a.ldq + h * HD + g * 8;
+        qf[0] = *reinterpret_cast<const uint4 *>(qp);
+        qf[1] = *reinterpret_cast<const uint4 *>(qp + 32);
+    }
+    f4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging roles
+    const int k_key = tid >> 2, k_chunk = (tid & 3) * 16;  // K: one key row, 2 x 16B
+    const int v_kp = tid & 31, v_c = tid >> 5;              // V: key pair (2kp, 2kp+1), d chunk v_c*8
+
+    auto key_row = [&](int j) -> long long {
+        j = min(j, Lk - 1);
+        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
+    };
+
+    for (int kt = 0; kt < maxlen; kt += KB) {
+        // ---- stage K tile (row-major) and V tile (transposed) ----
+        {
+            const unsigned short *kp = a.k + key_row(kt + k_key) * a.ldk + h * HD + k_chunk;
+            const uint4 k0 = *reinterpret_cast<const uint4 *>(kp);
+            const uint4 k1 = *reinterpret_cast<const uint4 *>(kp + 8);
+            const unsigned short *vp0 = a.v + key_row(kt + 2 * v_kp) * a.ldv + h * HD + v_c * 8;
+            const unsigned short *vp1 = a.v + key_row(kt + 2 * v_kp + 1) * a.ldv + h * HD + v_c * 8;
+            const uint4 va = *reinterpret_cast<const uint4 *>(vp0);
+            const uint4 vb = *reinterpret_cast<const uint4 *>(vp1);
+            __syncthreads();  // previous tile fully consumed
+            *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk]) = k0;
+            *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk + 8]) = k1;
+            const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+            unsigned *vt = reinterpret_cast<unsigned *>(sVT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // d = v_c*8 + 2i   : (key 2kp, key 2kp+1) ; d+1 likewise
+                vt[((v_c * 8 + 2 * i) * VROW) / 2 + v_kp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
+                vt[((v_c * 8 + 2 * i + 1) * VROW) / 2 + v_kp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
+            }
+            __syncthreads();
+        }
+        // ---- S^T = K Q^T : 4 key blocks x 2 d-steps ----
+        f4 st[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            st[nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[(nb * 16 + c16) * KROW + ks * 32 + g * 8]);
+                st[nb] = mfma<BF16>(kf, qf[ks], st[nb]);
+            }
+        }
+        // lane holds, for query c16, keys kt + nb*16 + g*4 + r
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + nb * 16 + g * 4 + r;
+                float s = st[nb][r] * a.scale_log2e;
+                s = key < my_len ? s : -INFINITY;
+                st[nb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(st[nb][r] - m_use);
+                st[nb][r] = p;
+                rs += p;
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        // rescale O: its rows are q = g*4 + r -> fetch that query's alpha from lane (g*4 + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][r] *= ar;
+        }
+        // P fragments (A operand): ks -> key blocks (2ks, 2ks+1); k index g*8 + j <-> key (2ks + j/4)*16 + g*4 + j%4
+        uint4 pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            pf[ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
+            pf[ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
+            pf[ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+            pf[ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+        }
+        // O += P V : B operand lane (d = db*16 + c16, g) = V^T[d][(2ks)*16 + g*4 .. +3], V^T[d][(2ks+1)*16 + g*4 .. +3]
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short *vr = &sVT[(db * 16 + c16) * VROW + g * 4];
+                const uint2 lo = *reinterpret_cast<const uint2 *>(vr + (2 * ks) * 16);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                o[db] = mfma<BF16>(pf[ks], vf, o[db]);
+            }
+        }
+    }
+
+    // ---- epilogue: O rows q = g*4 + r, cols d = db*16 + c16 ----
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lr = __shfl(l_run, g * 4 + r, 64);
+        const int qo = q0 + wid * 16 + g * 4 + r;
+        if (qo >= a.Lq) continue;
+        const float inv = lr > 0.f ? 1.0f / lr : 0.f;
+        unsigned short *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[db][r] * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int vs_attention(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq,
+                            int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv,
+                            int32_t ldo, const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype,
+                            vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(q && k && v && out, "vs_attention: null pointer");
+    VS_CHECK(nbatch >= 0 && H > 0 && Lq >= 0, "vs_attention: bad sizes");
+    VS_CHECK(kv_seg || Lk > 0, "vs_attention: Lk must be positive when kv_seg is null");
+    VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "vs_attention: row strides must be multiples of 8 elements");
+    VS_CHECK(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "vs_attention: 16-byte alignment required");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_attention: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(H <= 65535 && nbatch <= 65535, "vs_attention: grid too large");
+    if (nbatch == 0 || Lq == 0) return 0;
+    AttnArgs a;
+    a.q = (const unsigned short *)q; a.k = (const unsigned short *)k; a.v = (const unsigned short *)v;
+    a.out = (unsigned short *)out; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;
+    a.nbatch = nbatch; a.H = H; a.Lq = Lq; a.Lk = Lk; a.q_batch_rows = q_batch_rows; a.k_batch_rows = k_batch_rows;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    dim3 grid(vs::cdiv(Lq, QB), H, nbatch), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(attention_kernel<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(attention_kernel<false>, grid, block, 0, stream, a);
+    VS_HIP(hipGetLastError());
+    return 0;
+}

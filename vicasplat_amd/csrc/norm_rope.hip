@@ -1,0 +1,183 @@
+// Memory-bound token kernels of the ViT blocks for gfx950: LayerNorm (+AdaLN modulation) and RoPE on the packed
+// q|k|v projection buffer.  One wavefront per token row, 16-byte vector accesses, wave-shuffle reductions.
+//
+//  vs_layernorm_mod : y = LN(x; w, b, eps) [* (1 + scale[g]) + shift[g]]   f32 in -> f16/bf16/f32 out
+//      reference: nn.LayerNorm(eps=1e-6) backbone_vica.py:370; _modulate :268-273 (scale/shift come from the frame's
+//      camera token, AdaLNModulation :194-212), g = row / mod_rows.  Output rows can be re-mapped
+//      (row -> (row / grp_in) * grp_out + grp_off + row % grp_in) to interleave camera and image tokens.
+//  vs_rope_qk       : in-place rotary embedding of the q and k column blocks of a packed [rows, ld] projection
+//      kind 0 : 2-D RoPE (croco/pos_embed.py:112-159 == curope/kernels.cu:39-80), pairs (i, i+16) per 32-wide half,
+//               angle = pos * base^(-i/16);   kind 1 : 1-D temporal RoPE with interleaved pairs (2j, 2j+1),
+//               angle = t * theta^(-2j/64) (misc/rope_utils.py:133-188, camera tokens);   kind 2 : untouched.
+#include "common.h"
+
+namespace {
+
+template <int DT> struct Out;
+template <> struct Out<0> {
+    using T = float;
+    static __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); }
+};
+template <> struct Out<1> {
+    using T = unsigned short;
+    static __device__ __forceinline__ unsigned short cv(float v) { _Float16 h = (_Float16)v; return *reinterpret_cast<unsigned short *>(&h); }
+    static __device__ __forceinline__ void st4(unsigned short *p, float a, float b, float c, float d) {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(cv(a) | ((unsigned)cv(b) << 16), cv(c) | ((unsigned)cv(d) << 16));
+    }
+};
+template <> struct Out<2> {
+    using T = unsigned short;
+    static __device__ __forceinline__ unsigned short cv(float v) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+    static __device__ __forceinline__ void st4(unsigned short *p, float a, float b, float c, float d) {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(cv(a) | ((unsigned)cv(b) << 16), cv(c) | ((unsigned)cv(d) << 16));
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int kMaxVec = 8;  // C <= 64 lanes * 8 * 4 = 2048
+
+template <int DT>
+__global__ void __launch_bounds__(256)
+layernorm_mod_kernel(const float *__restrict__ x, long long ldx, const float *__restrict__ w, const float *__restrict__ b,
+                     const float *__restrict__ scale, const float *__restrict__ shift, int mod_rows, int mod_ld,
+                     typename Out<DT>::T *__restrict__ out, long long ldo, int M, int C, float eps, int grp_in, int grp_out,
+                     int grp_off) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float *xr = x + (long long)m * ldx;
+    const int nvec = C >> 2;
+    float4 v[kMaxVec];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nvec) {
+            v[i] = *reinterpret_cast<const float4 *>(xr + 4 * idx);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nvec) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const long long orow = (long long)(m / grp_in) * grp_out + grp_off + (m % grp_in);
+    const float *sc = scale ? scale + (long long)(m / mod_rows) * mod_ld : nullptr;
+    const float *sh = shift ? shift + (long long)(m / mod_rows) * mod_ld : nullptr;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nvec) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + 4 * idx);
+            const float4 bv = *reinterpret_cast<const float4 *>(b + 4 * idx);
+            float y0 = (v[i].x - mean) * rstd * ww.x + bv.x, y1 = (v[i].y - mean) * rstd * ww.y + bv.y;
+            float y2 = (v[i].z - mean) * rstd * ww.z + bv.z, y3 = (v[i].w - mean) * rstd * ww.w + bv.w;
+            if (sc) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(sc + 4 * idx);
+                y0 *= 1.0f + s4.x; y1 *= 1.0f + s4.y; y2 *= 1.0f + s4.z; y3 *= 1.0f + s4.w;
+            }
+            if (sh) {
+                const float4 h4 = *reinterpret_cast<const float4 *>(sh + 4 * idx);
+                y0 += h4.x; y1 += h4.y; y2 += h4.z; y3 += h4.w;
+            }
+            Out<DT>::st4(out + orow * ldo + 4 * idx, y0, y1, y2, y3);
+        }
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ float ld16(const unsigned short *p) {
+    if constexpr (BF16) return __uint_as_float(((unsigned)*p) << 16);
+    else return (float)*reinterpret_cast<const _Float16 *>(p);
+}
+template <bool BF16>
+__device__ __forceinline__ void st16(unsigned short *p, float v) {
+    if constexpr (BF16) *p = Out<2>::cv(v);
+    else *p = Out<1>::cv(v);
+}
+
+// one wave per row; lane = (q|k selector) * 32 + pair index; loops over heads. head_dim fixed at 64.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+rope_qk_kernel(unsigned short *__restrict__ buf, long long ld, int rows, int H, int k_col, const int32_t *__restrict__ pos,
+               const uint8_t *__restrict__ kind, float base2d, float theta1d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int kd = kind ? kind[row] : 0;
+    if (kd == 2) return;
+    const int p = lane & 31, sel = lane >> 5;
+    int iu, iv;
+    float ang;
+    if (kd == 0) {
+        const int half = p >> 4, i = p & 15;
+        iu = half * 32 + i; iv = iu + 16;
+        ang = (float)pos[2 * row + half] / powf(base2d, (float)i / 16.0f);
+    } else {
+        iu = 2 * p; iv = iu + 1;
+        ang = (float)pos[2 * row] / powf(theta1d, (float)(2 * p) / 64.0f);
+    }
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    unsigned short *r = buf + (long long)row * ld + (sel ? k_col : 0);
+    for (int h = 0; h < H; ++h) {
+        unsigned short *pu = r + h * 64 + iu, *pv = r + h * 64 + iv;
+        const float u = ld16<BF16>(pu), v = ld16<BF16>(pv);
+        st16<BF16>(pu, u * cs - v * sn);
+        st16<BF16>(pv, v * cs + u * sn);
+    }
+}
+
+}  // namespace
+
+extern "C" int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, const float *b, const float *scale,
+                                const float *shift, int32_t mod_rows, int32_t mod_ld, void *out, int64_t ldo,
+                                int32_t out_dtype, int32_t M, int32_t C, float eps, int32_t grp_in, int32_t grp_out,
+                                int32_t grp_off, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && w && b && out, "vs_layernorm_mod: null pointer");
+    VS_CHECK(C > 0 && C % 4 == 0 && C <= 64 * 4 * kMaxVec, "vs_layernorm_mod: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * kMaxVec);
+    VS_CHECK(ldx % 4 == 0 && ldo % 4 == 0, "vs_layernorm_mod: row strides must be multiples of 4 elements");
+    VS_CHECK(out_dtype >= 0 && out_dtype <= 2, "vs_layernorm_mod: bad out_dtype %d", out_dtype);
+    if (M <= 0) return 0;
+    if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
+    if (mod_rows <= 0) mod_rows = M;
+    if (mod_ld <= 0) mod_ld = C;
+    dim3 grid(vs::cdiv(M, 4)), block(256);
+    switch (out_dtype) {
+        case 0: hipLaunchKernelGGL(layernorm_mod_kernel<0>, grid, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, (float *)out, ldo, M, C, eps, grp_in, grp_out, grp_off); break;
+        case 1: hipLaunchKernelGGL(layernorm_mod_kernel<1>, grid, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off); break;
+        default: hipLaunchKernelGGL(layernorm_mod_kernel<2>, grid, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off); break;
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos,
+                          const uint8_t *kind, float base2d, float theta1d, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(buf && pos, "vs_rope_qk: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_rope_qk: dtype must be 1 (f16) or 2 (bf16)");
+    if (rows <= 0 || H <= 0) return 0;
+    dim3 grid(vs::cdiv(rows, 4)), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(rope_qk_kernel<true>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d);
+    else hipLaunchKernelGGL(rope_qk_kernel<false>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d);
+    VS_HIP(hipGetLastError());
+    return 0;
+}

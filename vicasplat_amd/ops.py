@@ -1,0 +1,88 @@
+"""Python front-ends of the ViT-block HIP operators (thin ctypes wrappers over include/vicasplat_hip.h).
+
+Every function requires HIP device tensors and raises otherwise -- there is no PyTorch/CPU fallback path.
+16-bit operand dtype: torch.float16 (default; 10-bit mantissa like the TF32 the reference runs at) or torch.bfloat16.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+EPI_STORE16, EPI_GELU16, EPI_RESID32, EPI_STORE32 = 0, 1, 2, 3
+
+
+def layernorm_mod(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, *, eps: float = 1e-6,
+                  scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, mod_rows: int = 0,
+                  grp_in: int = 0, grp_out: int = 0, grp_off: int = 0) -> torch.Tensor:
+    """x f32 [M,C] -> out [*,C] (f32/f16/bf16).  scale/shift: [G,C] f32 views (row stride taken from .stride(0))."""
+    dev = L.require_device(x, weight, bias, out, scale, shift)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, C = x.shape
+    mod_ld = 0
+    if scale is not None:
+        assert scale.stride(-1) == 1 and (shift is None or shift.stride(0) == scale.stride(0))
+        mod_ld = scale.stride(0)
+    elif shift is not None:
+        mod_ld = shift.stride(0)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_layernorm_mod(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+                                      mod_rows, mod_ld, L.ptr(out), out.stride(-2), _DT[out.dtype], M, C, eps, grp_in,
+                                      grp_out, grp_off, L.stream_ptr(dev))
+    L.check(rc, "vs_layernorm_mod")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int, *,
+         gate: Optional[torch.Tensor] = None, gate_rows: int = 0, grp_in: int = 0, grp_out: int = 0, grp_off: int = 0) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w 16-bit; out 16-bit (epilogue 0/1) or f32 (2: in-place residual
+    update with optional per-group gate [G,N]; 3: store)."""
+    dev = L.require_device(a, w, bias, out, gate)
+    assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    if epilogue in (EPI_STORE16, EPI_GELU16):
+        assert out.dtype == a.dtype
+    else:
+        assert out.dtype == torch.float32
+    gate_ld = gate.stride(0) if gate is not None else 0
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_bias_act(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(gate), M, N, K, a.stride(0),
+                                      w.stride(0), out.stride(-2), epilogue, _DT[a.dtype], grp_in, grp_out, grp_off,
+                                      gate_rows, gate_ld, L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_bias_act")
+    return out
+
+
+def rope_qk(buf: torch.Tensor, H: int, k_col: int, pos: torch.Tensor, kind: Optional[torch.Tensor] = None,
+            base2d: float = 100.0, theta1d: float = 30.0) -> torch.Tensor:
+    """In-place RoPE on q (col 0) and k (col k_col) of buf [rows, ld]; pos int32 [rows,2]; kind uint8 [rows] or None."""
+    dev = L.require_device(buf, pos, kind)
+    assert buf.dim() == 2 and buf.stride(1) == 1 and pos.dtype == torch.int32 and pos.is_contiguous()
+    assert kind is None or (kind.dtype == torch.uint8 and kind.is_contiguous())
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_rope_qk(L.ptr(buf), buf.stride(0), buf.shape[0], H, k_col, L.ptr(pos), L.ptr(kind), base2d, theta1d,
+                                _DT[buf.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_rope_qk")
+    return buf
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, nbatch: int, H: int, Lq: int,
+              Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0, kv_seg: Optional[torch.Tensor] = None,
+              q_kvlen: Optional[torch.Tensor] = None, scale: float = 0.125) -> torch.Tensor:
+    """q/k/v: 2-D views [rows, ld] whose column 0 is head 0 (e.g. slices of a packed q|k|v buffer); out [rows, H*64]."""
+    dev = L.require_device(q, k, v, out, kv_seg, q_kvlen)
+    for t in (q, k, v, out):
+        assert t.dim() == 2 and t.stride(1) == 1
+    assert kv_seg is None or (kv_seg.dtype == torch.int32 and kv_seg.is_contiguous())
+    assert q_kvlen is None or (q_kvlen.dtype == torch.int32 and q_kvlen.is_contiguous())
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_attention(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
+                                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
+                                  _DT[q.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_attention")
+    return out
