@@ -142,10 +142,12 @@ int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, const float *b
 
 /* out = epilogue(A[M,K] * W[N,K]^T + bias).  epilogue: 0 store 16-bit, 1 exact-erf GELU then store 16-bit,
  * 2 f32 residual update out += (1 + gate[row / gate_rows]) * (.), 3 store f32.  K % 64 == 0; lda/ldw % 8 == 0.
- * Output row mapping as in vs_layernorm_mod. */
+ * Output row mapping (grp_*) as in vs_layernorm_mod; a_grp_* is the same mapping applied to the rows of A that are
+ * READ (lets a GEMM consume only the image-token rows, or only the camera-token rows, of an interleaved buffer). */
 int vs_gemm_bias_act(const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M, int32_t N,
                      int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype, int32_t grp_in,
-                     int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, vs_stream_t stream);
+                     int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in,
+                     int32_t a_grp_out, int32_t a_grp_off, vs_stream_t stream);
 
 /* In-place RoPE on the q (column 0) and k (column k_col) blocks of a packed projection buffer [rows, ld], H heads of
  * 64.  pos int32 [rows,2] (y,x) or (t,-); kind uint8 [rows] (0 = 2-D, 1 = temporal 1-D interleaved, 2 = none) or NULL. */

@@ -84,7 +84,7 @@ def lib() -> C.CDLL:
             L.vs_layernorm_mod.restype = C.c_int
             L.vs_layernorm_mod.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, i32, i32, i32, f32, i32, i32, i32, vp]
             L.vs_gemm_bias_act.restype = C.c_int
-            L.vs_gemm_bias_act.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_gemm_bias_act.argtypes = [vp, vp, vp, vp, vp] + [i32] * 16 + [vp]
             L.vs_rope_qk.restype = C.c_int
             L.vs_rope_qk.argtypes = [vp, i64, i32, i32, i32, vp, vp, f32, f32, i32, vp]
             L.vs_attention.restype = C.c_int

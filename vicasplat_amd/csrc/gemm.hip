@@ -41,6 +41,7 @@ struct GemmArgs {
     int grp_in, grp_out, grp_off;
     int gate_rows;  // rows of A per gate vector
     int gate_ld;
+    int a_grp_in, a_grp_out, a_grp_off;  // INPUT row map: A row of m = (m / a_grp_in) * a_grp_out + a_grp_off + m % a_grp_in
 };
 
 template <bool BF16>
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
         const int ra_ = min(m0 + srow + 32 * i, g.M - 1);
         const int rw_ = min(n0 + srow + 32 * i, g.N - 1);
-        oa[i] = (size_t)ra_ * g.lda + schunk * 8;
+        const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+        oa[i] = arow * g.lda + schunk * 8;
         ow[i] = (size_t)rw_ * g.ldw + schunk * 8;
     }
     uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;  // named registers: arrays here end up in scratch
@@ -194,7 +196,7 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
 extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M,
                                 int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype,
                                 int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld,
-                                vs_stream_t stream_) {
+                                int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(A && W && out, "vs_gemm_bias_act: null pointer");
     VS_CHECK(M >= 0 && N > 0 && K > 0, "vs_gemm_bias_act: bad sizes M=%d N=%d K=%d", M, N, K);
@@ -212,6 +214,9 @@ extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias,
     g.grp_off = grp_off;
     g.gate_rows = gate_rows > 0 ? gate_rows : (M > 0 ? M : 1);
     g.gate_ld = gate_ld > 0 ? gate_ld : N;
+    g.a_grp_in = a_grp_in > 0 ? a_grp_in : (M > 0 ? M : 1);
+    g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
+    g.a_grp_off = a_grp_off;
     const int rc = dtype == 2 ? launch<true>(g, epilogue, stream) : launch<false>(g, epilogue, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());

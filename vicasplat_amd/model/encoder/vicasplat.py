@@ -1,0 +1,155 @@
+"""VicaSplat encoder, MI355X-native, with the reference's module API (vicasplat.py:38-290):
+`VicaSplat(cfg).forward(context, global_step=0, visualization_dump=None, distill=False,
+compute_viewspace_depth=True) -> dict`, attributes `.cfg`, `.backbone.config`, `enable_gradient_checkpointing()`,
+`get_data_shim()`, and the state_dict keys of SURVEY.md Appendix C."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Literal, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .backbone.backbone_vica import VicaNet
+from .common.gaussian_adapter import GaussianAdapterCfg, Gaussians, MyGaussianAdapter
+from .encoder import Encoder
+from .heads.dpt import PixelwiseTaskWithDPT
+
+
+@dataclass
+class OpacityMappingCfg:
+    initial: float
+    final: float
+    warm_up: int
+
+
+@dataclass
+class VicaSplatCfg:
+    name: str
+    backbone: dict
+    visualizer: object
+    gaussian_adapter: GaussianAdapterCfg
+    apply_bounds_shim: bool
+    opacity_mapping: OpacityMappingCfg
+    predict_opacity: bool
+    input_mean: tuple = (0.5, 0.5, 0.5)
+    input_std: tuple = (0.5, 0.5, 0.5)
+    pretrained_weights: str = ""
+    gs_center_head_type: str = "dpt"
+    gs_param_head_type: str = "dpt_gs"
+    predict_conf: bool = False
+    camera_type: Literal["dq", "qt"] = "dq"
+
+
+def quat_mul_xyzw(a, b):
+    x1, y1, z1, w1 = a.unbind(-1)
+    x2, y2, z2, w2 = b.unbind(-1)
+    return torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], -1)
+
+
+def camera_matrix_from_dq_array(dq: torch.Tensor) -> torch.Tensor:
+    """[...,8] (q_r xyzw | q_d xyzw, q_r unit) -> [...,4,4]: R = rotmat(q_r), t = vec(2 q_d (x) conj(q_r))
+    (misc/cam_utils.py:203-207, misc/dq.py:224-262; the quaternion algebra pypose provides there is restated)."""
+    qr, qd = dq[..., :4], dq[..., 4:]
+    x, y, z, w = qr.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(*qr.shape[:-1], 3, 3)
+    t = quat_mul_xyzw(2.0 * qd, qr * qr.new_tensor([-1.0, -1.0, -1.0, 1.0]))[..., :3]
+    M = torch.zeros(*qr.shape[:-1], 4, 4, dtype=dq.dtype, device=dq.device)
+    M[..., :3, :3] = R
+    M[..., :3, 3] = t
+    M[..., 3, 3] = 1
+    return M
+
+
+class VicaSplat(Encoder[VicaSplatCfg]):
+    patch_size: int = 16
+
+    def __init__(self, cfg: VicaSplatCfg, weight_dtype: Optional[torch.dtype] = None, device=None,
+                 compute_dtype: torch.dtype = torch.float16) -> None:
+        super().__init__(cfg)
+        if cfg.camera_type != "dq" or cfg.gs_center_head_type != "dpt" or cfg.gs_param_head_type != "dpt_gs" or cfg.predict_conf:
+            raise NotImplementedError("only the released configuration (dq camera, dpt + dpt_gs heads, no confidence) is implemented")
+        self.camera_extrinsic_channels = 8
+        self.backbone = VicaNet(**dict(cfg.backbone), compute_dtype=compute_dtype)
+        self.gaussian_adapter = MyGaussianAdapter(cfg.gaussian_adapter)
+        self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
+        self.predict_confidence = False
+        self.downstream_head1 = PixelwiseTaskWithDPT(self.backbone, 3, "regression")
+        self.gaussian_param_head = PixelwiseTaskWithDPT(self.backbone, self.raw_gs_dim, "gs_params")
+        self.camera_extrinsic_head = nn.Sequential(nn.ReLU(), nn.Linear(self.backbone.config.dec_embed_dim, 8))
+        nn.init.zeros_(self.camera_extrinsic_head[1].weight)  # predicts the identity pose at init (vicasplat.py:126-127)
+        nn.init.zeros_(self.camera_extrinsic_head[1].bias)
+        self.camera_intrinsic_head = None
+        self.set_compute_dtype(compute_dtype)
+        if device is not None or weight_dtype is not None:
+            self.to(device=device, dtype=weight_dtype)
+
+    def set_compute_dtype(self, dt: torch.dtype):
+        self.backbone.compute_dtype = dt
+        self.downstream_head1.compute_dtype = dt
+        self.gaussian_param_head.compute_dtype = dt
+
+    def enable_gradient_checkpointing(self):
+        self.backbone.enable_gradient_checkpointing()
+
+    def map_pdf_to_opacity(self, pdf: torch.Tensor, global_step: int) -> torch.Tensor:
+        c = self.cfg.opacity_mapping
+        exponent = 2 ** (c.initial + min(global_step / c.warm_up, 1) * (c.final - c.initial))
+        return 0.5 * (1 - (1 - pdf) ** exponent + pdf ** (1 / exponent))
+
+    @torch.no_grad()
+    def forward(self, context: dict, global_step: int = 0, visualization_dump: Optional[dict] = None, distill: bool = False,
+                compute_viewspace_depth: bool = True, **kwargs) -> dict:
+        image = context["image"]
+        if not image.is_cuda:
+            raise RuntimeError("VicaSplat.forward needs HIP device tensors: vicasplat_amd has no CPU fallback path")
+        B, T, _, H, Wd = image.shape
+        dev = image.device
+        gh, gw = H // self.patch_size, Wd // self.patch_size
+        video = image.permute(0, 2, 1, 3, 4)
+        _, camera_embeds, _global, interms = self.backbone(video, context.get("intrinsics", None))
+
+        pred = self.camera_extrinsic_head(camera_embeds)
+        pred = torch.cat([pred[..., :3], pred[..., 3:4] + 1.0, pred[..., 4:]], -1)
+        pred_extrins = pred / pred[..., :4].norm(dim=-1, keepdim=True)
+        eye = torch.eye(4, device=dev, dtype=pred_extrins.dtype).expand(B, 1, 4, 4)
+        pred_extrinsics_4x4 = torch.cat([eye, camera_matrix_from_dq_array(pred_extrins)], dim=1)
+
+        tokens = [None if t is None else t.flatten(0, 1) for t in interms]
+        gs_centers = self.downstream_head1.forward_pts3d(tokens, gh, gw).unflatten(0, (B, T))
+        viewspace_depth = None
+        if compute_viewspace_depth:
+            E = context["extrinsics"]
+            vp = torch.einsum("bvij,bvhwj->bvhwi", torch.linalg.inv(E[:, :, :3, :3]), gs_centers - E[:, :, None, None, :3, 3])
+            viewspace_depth = vp[..., -1]
+        if distill:
+            return dict(pred_extrins=pred_extrins, pred_intrins=None, gaussian_camera_extrins=pred_extrinsics_4x4,
+                        gaussian_camera_intrins=None, gaussian_centers=gs_centers, confidence=None,
+                        context_view_depths=viewspace_depth)
+        gs_params = self.gaussian_param_head.forward_gs(tokens, image.flatten(0, 1), gh, gw)
+        gs_params = gs_params.unflatten(0, (B, T)).permute(0, 1, 3, 4, 2)
+        raw_gaussians = torch.cat([gs_centers, gs_params], dim=-1)
+        gaussians = self.gaussian_adapter(
+            raw_gaussians, None if self.cfg.predict_opacity else (lambda o: self.map_pdf_to_opacity(o, global_step)))
+        if visualization_dump is not None:
+            visualization_dump["depth"] = gaussians.means[..., -1:]
+        return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=None, raw_gaussians=raw_gaussians,
+                    gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=None, gaussian_centers=gs_centers,
+                    confidence=None, context_view_depths=viewspace_depth)
+
+    def get_data_shim(self):
+        mean, std = self.cfg.input_mean, self.cfg.input_std
+
+        def data_shim(batch):
+            """(image - mean) / std on the context images (dataset/shims/normalize_shim.py:21-27)."""
+            ctx = batch["context"]
+            m = ctx["image"].new_tensor(mean)[:, None, None]
+            s = ctx["image"].new_tensor(std)[:, None, None]
+            return {**batch, "context": {**ctx, "image": (ctx["image"] - m) / s}}
+
+        return data_shim

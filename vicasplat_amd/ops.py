@@ -37,13 +37,15 @@ def layernorm_mod(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int, *,
-         gate: Optional[torch.Tensor] = None, gate_rows: int = 0, grp_in: int = 0, grp_out: int = 0, grp_off: int = 0) -> torch.Tensor:
+         gate: Optional[torch.Tensor] = None, gate_rows: int = 0, grp_in: int = 0, grp_out: int = 0, grp_off: int = 0,
+         M: Optional[int] = None, a_grp_in: int = 0, a_grp_out: int = 0, a_grp_off: int = 0) -> torch.Tensor:
     """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w 16-bit; out 16-bit (epilogue 0/1) or f32 (2: in-place residual
     update with optional per-group gate [G,N]; 3: store)."""
     dev = L.require_device(a, w, bias, out, gate)
     assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
-    M, K = a.shape
+    K = a.shape[1]
+    M = a.shape[0] if M is None else M  # with an input row map, M counts the rows actually consumed
     N = w.shape[0]
     if epilogue in (EPI_STORE16, EPI_GELU16):
         assert out.dtype == a.dtype
@@ -53,7 +55,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     with torch.cuda.device(dev):
         rc = L.lib().vs_gemm_bias_act(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(gate), M, N, K, a.stride(0),
                                       w.stride(0), out.stride(-2), epilogue, _DT[a.dtype], grp_in, grp_out, grp_off,
-                                      gate_rows, gate_ld, L.stream_ptr(dev))
+                                      gate_rows, gate_ld, a_grp_in, a_grp_out, a_grp_off, L.stream_ptr(dev))
     L.check(rc, "vs_gemm_bias_act")
     return out
 
