@@ -1,0 +1,235 @@
+"""bench.py -- headline benchmark of the VicaSplat hot path on MI355X (BASELINE.json metric):
+
+    scenes/sec, 8-view 256x256 scenes: ViT-L encoder + video/camera decoder + DPT heads + Gaussian adapter
+    (-> 524 288 Gaussians + 7 poses per scene) followed by rasterization of 12 target views per scene
+    (re10k_8view: num_context_views 8, num_target_views 12, config/experiment/re10k_8view.yaml:19-20).
+
+A "step" = one pass of that path over one batch of `--scenes-per-gpu` synthetic scenes already resident in HBM.
+`python bench.py --gpus N --steps K --warmup W`; for N>1 launch with torch.distributed.run (one rank per GPU, RCCL).
+Scenes are independent: they are sharded over ranks with NO data-path collective ("scaling": "weak").
+Prints ONE JSON line (rank 0) with `roofline` (dominant hand-written kernel, measured with HIP events on the launch
+stream in an extra instrumented step) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_16BIT_TFLOPS = 2500.0  # dense bf16/f16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes-per-gpu", type=int, default=2)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--targets", type=int, default=12)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def target_cameras(B, Vt, dev):
+    """Vt target cameras per scene in frame-0 coordinates: identity rotation, x translation j*0.05."""
+    E = torch.eye(4, device=dev).repeat(B, Vt, 1, 1)
+    E[:, :, 0, 3] = (torch.arange(Vt, device=dev) * 0.05)[None]
+    K = torch.tensor([[0.9, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1.0]], device=dev).repeat(B, Vt, 1, 1)
+    near = torch.full((B, Vt), 0.01, device=dev)
+    far = torch.full((B, Vt), 100.0, device=dev)
+    return E, K, near, far
+
+
+class KernelTimer:
+    """Wraps the HIP op front-ends with event pairs recorded on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def wrap(self, mod, name, meta_fn):
+        orig = getattr(mod, name)
+
+        def f(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            self.rec.append((name, s, e, meta_fn(r, *a, **k)))
+            return r
+
+        setattr(mod, name, f)
+        return orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, meta in self.rec:
+            d = out.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
+            d["ms"] += s.elapsed_time(e); d["calls"] += 1
+            d["flops"] += meta.get("flops", 0.0); d["bytes"] += meta.get("bytes", 0.0)
+        return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import json as _json
+    from vicasplat_amd import ops, raster, synthetic
+    from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    from vicasplat_amd.model.types import Gaussians
+
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    B, V, Vt = args.scenes_per_gpu, args.views, args.targets
+    shapes = _json.load(open(os.path.join(ROOT, "tests", "golden", "shapes_full.json")))
+    W = synthetic.golden_weights(shapes, seed=0)
+    enc, _ = get_encoder(default_cfg())
+    enc.load_state_dict(W, strict=True)
+    enc = enc.to(dev).eval()
+    enc.set_compute_dtype(dt)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(dev)
+    img, K = synthetic.synthetic_input(B, V, 256, seed=rank)
+    ctx = dict(image=img.to(dev), intrinsics=K.to(dev))
+    tE, tK, tnear, tfar = target_cameras(B, Vt, dev)
+
+    def step():
+        out = enc(ctx, compute_viewspace_depth=False)
+        g = out["gaussians"]
+        gs = Gaussians(g.means, g.covariances, g.harmonics, g.opacities)
+        r = dec(gs, tE, tK, tnear, tfar, (256, 256))
+        return out, r
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    roofline, extra = None, {}
+    if rank == 0 and not args.no_roofline:
+        kt = KernelTimer()
+        P = V * 256 * 256
+
+        def gemm_meta(r, a, w, *rest, **k):
+            M = k.get("M") or a.shape[0]
+            return dict(flops=2.0 * M * w.shape[0] * a.shape[1])
+
+        def attn_meta(r, q, k_, v, out, **k):
+            nb, H, Lq = k["nbatch"], k["H"], k["Lq"]
+            Lk = k.get("Lk") or 0
+            if k.get("kv_seg") is not None:
+                Lk = 2 * Lq if V > 2 else Lq
+            return dict(flops=4.0 * nb * H * Lq * Lk * 64)
+
+        def raster_meta(r, *a, **k):
+            st = r[1]
+            S, Pn, Cn, M, H, Wd, _ = st["dims"]
+            return dict(bytes=Cn * (Pn * 280.0 + 1.8e6) + st["num_rendered"] * 68.0, R=st["num_rendered"])
+
+        o1 = kt.wrap(ops, "gemm", gemm_meta); o2 = kt.wrap(ops, "attention", attn_meta)
+        o3 = kt.wrap(ops, "layernorm_mod", lambda r, x, *a, **k: dict(bytes=x.numel() * 6.0))
+        o4 = kt.wrap(ops, "rope_qk", lambda r, b, H, kc, *a, **k: dict(bytes=b.shape[0] * 2 * H * 64 * 2 * 2.0))
+        o5 = kt.wrap(raster, "_forward_impl", raster_meta)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); out, r = step(); e.record()
+        summ = kt.summary()
+        ops.gemm, ops.attention, ops.layernorm_mod, ops.rope_qk, raster._forward_impl = o1, o2, o3, o4, o5
+        tot_ms = s.elapsed_time(e)
+        gm, at, rs = summ["gemm"], summ["attention"], summ["_forward_impl"]
+        R = [m for n, _, _, m in kt.rec if n == "_forward_impl"][0]["R"]
+        gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+        # dominant hand-written kernel of the step: the MFMA GEMM (ViT encoder/decoder linears)
+        roofline = dict(kernel="gemm_kernel<f16> (vs_gemm_bias_act)", bound="mfma", achieved=round(gemm_tf, 1),
+                        peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s", frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4), traffic=None,
+                        launches=gm["calls"], avg_launch_us=round(gm["ms"] * 1e3 / gm["calls"], 2))
+        extra = dict(
+            step_breakdown_ms=dict(total=round(tot_ms, 3), gemm=round(gm["ms"], 3), attention=round(at["ms"], 3),
+                                   layernorm=round(summ["layernorm_mod"]["ms"], 3), rope=round(summ["rope_qk"]["ms"], 3),
+                                   rasterizer=round(rs["ms"], 3),
+                                   other_heads_adapter_glue=round(tot_ms - gm["ms"] - at["ms"] - summ["layernorm_mod"]["ms"] - summ["rope_qk"]["ms"] - rs["ms"], 3)),
+            roofline_attention=dict(bound="mfma", achieved=round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s"),
+            roofline_rasterizer=dict(bound="hbm", achieved=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                     frac=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), num_rendered=int(R),
+                                     gaussians=P * B, views=B * Vt),
+            mfma_util_vit=round((gm["flops"] + at["flops"]) / ((gm["ms"] + at["ms"]) * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4))
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline leg: the oracle (a restatement of the reference, "port"), timed on the host cores ----
+        from oracle import encoder_ref as er
+        from oracle import raster_ref as rr
+        import numpy as np
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        ncores = max(1, min(avail, 32))  # more threads than that only add sync overhead on this problem size
+        torch.set_num_threads(ncores)
+        cfg = er.default_cfg()
+        Vs = 2  # bounded sample: ONE 2-view scene through the full ViT-L encoder (about 1/4 of an 8-view scene's FLOPs)
+        t1 = time.perf_counter()
+        o = er.forward(W, cfg, img[:1, :Vs], K[:1, :Vs])
+        t_enc = time.perf_counter() - t1
+        g = o["gaussians"]
+        sc = dict(means=g["means"].reshape(-1, 3).numpy(), covariances=g["covariances"].reshape(-1, 3, 3).numpy(),
+                  harmonics=g["harmonics"].reshape(-1, 3, 25).numpy(), opacities=g["opacities"].reshape(-1).numpy(),
+                  extrinsics=tE[0, :2].cpu().numpy(), intrinsics=tK[0, :2].cpu().numpy(), near=tnear[0, :2].cpu().numpy(), far=tfar[0, :2].cpu().numpy())
+        t1 = time.perf_counter()
+        rr.render_views(sc, res=256)
+        t_ras = (time.perf_counter() - t1) / 2
+        # linear extrapolation to the bench workload: encoder FLOPs 3407/817.6, rasterizer work ~ Gaussians x views
+        est = t_enc * (3407.0 / 817.6) + t_ras * (V / Vs) * Vt
+        cpu_baseline = dict(value=round(1.0 / est, 5), unit="scenes/s", cores=ncores, kind="port",
+                            sample=f"oracle (restated reference) on ONE {Vs}-view scene: encoder {t_enc:.1f}s f32 on {ncores} threads, "
+                                   f"rasterizer {t_ras:.2f}s/view (131k Gaussians, 1 thread, 2 views); extrapolated to 8 views + {Vt} "
+                                   f"target views by FLOPs (x{3407.0 / 817.6:.2f}) and Gaussians x views")
+
+    if rank == 0:
+        line = dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(value, 3), unit="scenes/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype=args.dtype, data="synthetic",
+                    config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
+                                         f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
+                                parallelism=f"scene-sharded x{world} (no collective)"),
+                    roofline=roofline, cpu_baseline=cpu_baseline, **extra)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

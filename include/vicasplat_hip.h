@@ -72,7 +72,7 @@ enum {
 /* Scratch / saved-state buffers are requested through this callback, tagged so that the caller can keep the
  * ones the backward needs.  Must return 256-byte aligned device memory valid until the caller releases it. */
 enum {
-    VS_BUF_GEOM = 0,      /* [C,P,12] f32: x y depth pad | conic.x conic.y conic.z opacity | r g b pad  */
+    VS_BUF_GEOM = 0,      /* [C,P,12] f32: x y ext_x ext_y | conic.x conic.y conic.z opacity | r g b depth (ext = {alpha>=1/255} half extents) */
     VS_BUF_RECT = 1,      /* [C,P,4] u16 tile rectangle (min.x min.y max.x max.y) */
     VS_BUF_CLAMPED = 2,   /* [C,P] u8 bit c set => colour channel c clamped at 0 */
     VS_BUF_TILE_RANGES = 3, /* [C,tiles,2] i32 */
@@ -161,6 +161,20 @@ int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, co
 int vs_attention(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
                  int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                  const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype, vs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused DPT post-process + Gaussian adapter (replaces heads/postprocess.py:46-56, the raw_gaussians cat of
+ * vicasplat.py:256 and MyGaussianAdapter.forward, common/gaussian_adapter.py:168-212).  One Gaussian per pixel.
+ * pts: 3 channels, gs: 8 + 3*d_sh channels (opacity | scale 3 | quaternion xyzw | SH rgb-major), both addressed
+ * as base[pixel * *_pix + channel * *_ch] (elements), in_dtype 0 f32 / 1 f16 / 2 bf16.  scale_act 0 bounded,
+ * 1 exp, 2 softplus.  opacity_exponent = 2^x of map_pdf_to_opacity (<= 0: predict_opacity, no mapping).
+ * Outputs (f32): means [n,3], cov [n,3,3], harmonics [n,3,d_sh], opacities [n], scales [n,3], rotations [n,4],
+ * raw [n, 11 + 3*d_sh] (may be NULL).
+ * ------------------------------------------------------------------------------------------------ */
+int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts_ch, const void *gs, int64_t gs_pix, int64_t gs_ch,
+                        int32_t in_dtype, int64_t npix, int32_t d_sh, const float *sh_mask, int32_t scale_act,
+                        float scale_min, float scale_max, float opacity_exponent, float *means, float *cov, float *harmonics,
+                        float *opacities, float *scales, float *rotations, float *raw, vs_stream_t stream);
 
 #ifdef __cplusplus
 }

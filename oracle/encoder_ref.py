@@ -341,56 +341,6 @@ def forward(W: dict, cfg: dict, image: torch.Tensor, intrinsics: torch.Tensor, r
     return out
 
 
-# ---------------------------------------------------------------------------------------------------------
-# deterministic golden weights: independent of module construction order
-# ---------------------------------------------------------------------------------------------------------
-def golden_weights(shapes: dict, seed: int = 0, dtype=torch.float32) -> dict:
-    """shapes: {state_dict key: shape}.  Sorted keys, one numpy PCG64 stream per key: >=2-D tensors get
-    randn*sqrt(2/(fan_in+fan_out)), norm weights 1+0.02*randn, biases / tokens 0.02*randn (the pose head too,
-    which the reference zero-initialises and would otherwise always predict identity)."""
-    import zlib
-
-    import numpy as np
-
-    import re
-
-    W = {}
-    for k in sorted(shapes):
-        shp = tuple(shapes[k])
-        # the reference registers scratch.layer{n}_rn and scratch.layer_rn.{n-1} for the SAME tensor (Appendix C)
-        canon = re.sub(r"scratch\.layer(\d)_rn\.", lambda m: f"scratch.layer_rn.{int(m.group(1)) - 1}.", k)
-        rng = np.random.default_rng([seed, zlib.crc32(canon.encode())])
-        r = rng.standard_normal(shp, dtype=np.float32)
-        if len(shp) >= 2:
-            recept = int(np.prod(shp[2:])) if len(shp) > 2 else 1
-            fan_out, fan_in = shp[0] * recept, shp[1] * recept
-            r *= math.sqrt(2.0 / (fan_in + fan_out))
-        elif k.endswith("weight") and ("norm" in k):
-            r = 1.0 + 0.02 * r
-        else:
-            r *= 0.02
-        # Output-layer calibration so that random weights still yield a renderable scene (documented in DESIGN.md):
-        # pts3d head: zero-mean rows, small gain, +1.2 on z => points ~2.5 units in front of the camera, spread over the
-        # image; GS-parameter head: smaller gain so SH colours / opacities / scales stay in their useful range.
-        if k == "downstream_head1.dpt.head.4.weight":
-            r = (r - r.mean(axis=1, keepdims=True)) * 0.15
-        elif k == "downstream_head1.dpt.head.4.bias":
-            r = r + np.array([0.0, 0.0, 1.2] + [0.0] * (shp[0] - 3), dtype=np.float32)
-        elif k == "gaussian_param_head.dpt.head.4.weight":
-            r = r * 0.3
-        W[k] = torch.from_numpy(np.ascontiguousarray(r)).to(dtype)
-    return W
-
-
-def synthetic_input(B: int, V: int, res: int = 256, seed: int = 0):
-    """analytic sinusoid + noise images (then normalised), K = [[.9,0,.5],[0,.9,.5],[0,0,1]]."""
-    g = torch.Generator().manual_seed(seed)
-    ys, xs = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing="ij")
-    U = torch.rand((B, V, 3, res, res), generator=g)
-    img = torch.empty(B, V, 3, res, res)
-    for v in range(V):
-        for c in range(3):
-            img[:, v, c] = 0.5 + 0.25 * torch.sin(2 * math.pi * (3 * xs + 5 * ys) / res + c + v) + 0.25 * (U[:, v, c] - 0.5)
-    img = (img - 0.5) / 0.5
-    K = torch.tensor([[0.9, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1.0]]).expand(B, V, 3, 3).contiguous()
-    return img, K
+# deterministic golden weights + synthetic inputs live in the (algorithm-free) vicasplat_amd.synthetic module so that
+# bench.py / smoke() can build the SAME weights for the product path without importing the oracle
+from vicasplat_amd.synthetic import golden_weights, synthetic_input  # noqa: E402,F401

@@ -53,7 +53,7 @@ def _compare(o, g, c, color_atol=2e-5, max_bad_frac=2e-4):
     assert np.array_equal(pl[lo:hi], o["point_list"]), "sorted Gaussian ids"
     gm = g["geom"][c].cpu().numpy()
     assert np.array_equal(gm[vis, 0:2], o["xy"][vis]), "pixel centres bit-exact (same op order)"
-    assert np.array_equal(gm[vis, 2], o["depths"][vis]), "depth keys bit-exact"
+    assert np.array_equal(gm[vis, 11], o["depths"][vis]), "depth keys bit-exact"
     assert np.array_equal(gm[vis, 4:8], o["conic_opacity"][vis]), "conic bit-exact"
     assert np.allclose(gm[vis, 8:11], o["rgb"][vis], atol=1e-6), "SH colours"
     assert np.array_equal(g["clamped"][c].cpu().numpy()[vis], (o["clamped"][vis] * np.array([1, 2, 4], np.uint8)).sum(-1)), "clamp mask"

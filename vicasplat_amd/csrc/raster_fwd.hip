@@ -203,10 +203,20 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                         rgb[ch] = fmaxf(r, 0.0f);
                     }
                 }
+                // conservative footprint of {alpha >= 1/255}: alpha = o*exp(power) >= 1/255  <=>  1/2 d^T Q d <= tau with
+                // tau = ln(255 o), Q = conic = inverse of the dilated 2-D covariance (a, b, cc): the ellipse's axis-aligned
+                // half extents are sqrt(2 tau a), sqrt(2 tau cc).  A pixel outside it is skipped by the render loop's
+                // alpha < 1/255 test anyway, so culling with (1% + 0.05 px) margin never changes a result.
+                const float tau = logf(255.0f * opac);
+                float ext_x = -1.0f, ext_y = -1.0f;
+                if (tau > 0.0f) {
+                    ext_x = sqrtf(2.0f * tau * a) * 1.01f + 0.05f;
+                    ext_y = sqrtf(2.0f * tau * cc) * 1.01f + 0.05f;
+                }
                 float4 *g4 = reinterpret_cast<float4 *>(geom + ci * kGeomFloats);
-                g4[0] = make_float4(pixx, pixy, vz, my_radius);
+                g4[0] = make_float4(pixx, pixy, ext_x, ext_y);
                 g4[1] = make_float4(conx, cony, conz, opac);
-                g4[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+                g4[2] = make_float4(rgb[0], rgb[1], rgb[2], vz);
                 radius_i = f2i(my_radius);
                 visible = true;
             } while (false);
@@ -303,7 +313,7 @@ scatter_kernel(int P, int tiles, int gx, const float *__restrict__ geom, const u
     unsigned long long key = 0;
     if (visible) {
         r = rect[ci];
-        key = ((unsigned long long)__float_as_uint(geom[ci * kGeomFloats + 2]) << 32) | (unsigned)i;
+        key = ((unsigned long long)__float_as_uint(geom[ci * kGeomFloats + 11]) << 32) | (unsigned)i;
     }
     const size_t t0 = (size_t)c * tiles;
     if (!use_lds) {
@@ -391,107 +401,101 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K5: render.  One workgroup of 256/PXL threads per (camera, tile); every lane owns PXL pixels of one column
-// (x = tid%16, y = (tid/16)*PXL + k).  PXL=4 is "one wavefront per tile".  Entries are staged through LDS in
-// batches of blockDim records (coalesced id read, 3 x 16-byte gathers of the packed record).
+// K5: render.  One workgroup (4 waves) per (camera, 16x16 tile); wave w owns the 8x8 pixel quadrant (w&1, w>>1),
+// one pixel per lane.  The tile's sorted list is staged through LDS in batches of 256 records (coalesced id read,
+// 3 x 16-byte gathers of the packed record).  Per entry a wave first tests the Gaussian's conservative
+// {alpha >= 1/255} footprint against its quadrant -- a wave-uniform branch on broadcast LDS data -- so the
+// exp / blend body only runs for the quadrants a Gaussian can reach (for pixel-sized Gaussians ~1 of 4).
+// Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds, `contributor`
+// counts every list entry, so final_T / n_contrib match the oracle.
 // ---------------------------------------------------------------------------------------------------------
-template <int PXL, bool COUNT_TOUCHED>
-__global__ void __launch_bounds__(256 / PXL)
+template <bool COUNT_TOUCHED>
+__global__ void __launch_bounds__(256)
 render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ background, float *__restrict__ out_color,
               float *__restrict__ out_depth, float *__restrict__ out_opacity, float *__restrict__ final_T,
               int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched) {
-    constexpr int NT = 256 / PXL;
+    constexpr int NT = 256;
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
+    __shared__ uint32_t sid[NT];
     const int c = blockIdx.y;
     const int gx = (W + kTile - 1) / kTile;
     const int tiles = gridDim.x;
     const int tile = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile_x = tile % gx, tile_y = tile / gx;
-    const int pxi = tile_x * kTile + (tid & 15);
-    const int py0 = tile_y * kTile + (tid >> 4) * PXL;
-    const float pixfx = (float)pxi;
+    const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const float pixfx = (float)pxi, pixfy = (float)pyi;
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;  // quadrant centre; half size 3.5 px
     const int2 rg = ranges[(size_t)c * tiles + tile];
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
+    const bool inside = pxi < W && pyi < H;
 
-    float T[PXL], Cr[PXL], Cg[PXL], Cb[PXL], Dd[PXL], pixfy[PXL];
-    int last_contrib[PXL];
-    bool done[PXL];
-#pragma unroll
-    for (int k = 0; k < PXL; ++k) {
-        T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = Dd[k] = 0.0f; last_contrib[k] = 0;
-        pixfy[k] = (float)(py0 + k);
-        done[k] = !(pxi < W && (py0 + k) < H);
-    }
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f;
+    int last_contrib = 0;
+    bool done = !inside;
 
     int todo = rg.y - rg.x;
     int contributor = 0;
     for (int base = rg.x; base < rg.y; base += NT, todo -= NT) {
-        bool all_done = true;
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) all_done = all_done && done[k];
-        if (__syncthreads_count(all_done) == NT) break;
+        if (__syncthreads_count(done) == NT) break;
         if (base + tid < rg.y) {
             const uint32_t g = point_list[base + tid];
-            const float4 q0 = g4[(size_t)g * 3 + 0];
-            const float4 q1 = g4[(size_t)g * 3 + 1];
-            float4 q2 = g4[(size_t)g * 3 + 2];
-            q2.w = __uint_as_float(g);
-            sq0[tid] = q0; sq1[tid] = q1; sq2[tid] = q2;
+            sq0[tid] = g4[(size_t)g * 3 + 0];
+            sq1[tid] = g4[(size_t)g * 3 + 1];
+            sq2[tid] = g4[(size_t)g * 3 + 2];
+            sid[tid] = g;
         }
         __syncthreads();
         const int cnt = min(NT, todo);
-        for (int j = 0; j < cnt; ++j) {
-            ++contributor;
-            const float4 q0 = sq0[j];
-            const float4 q1 = sq1[j];
-            const float dx = q0.x - pixfx;
-            int touched = 0;
-#pragma unroll
-            for (int k = 0; k < PXL; ++k) {
-                if (done[k]) continue;
-                const float dy = q0.y - pixfy[k];
+        if (!__all(done)) {
+            for (int j = 0; j < cnt; ++j) {
+                const float4 q0 = sq0[j];
+                // wave-uniform footprint test (q0 is a broadcast read: same value in every lane)
+                if (fabsf(q0.x - qcx) > q0.z + 3.5f || fabsf(q0.y - qcy) > q0.w + 3.5f) continue;
+                const float4 q1 = sq1[j];
+                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
                 const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, q1.w * __expf(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = T[k] * (1.0f - alpha);
-                if (test_T < 0.0001f) { done[k] = true; continue; }
-                const float4 q2 = sq2[j];
-                const float w = alpha * T[k];
-                Cr[k] += q2.x * w; Cg[k] += q2.y * w; Cb[k] += q2.z * w;
-                Dd[k] += q0.z * w;
-                if (COUNT_TOUCHED && test_T > 0.5f) ++touched;
-                T[k] = test_T;
-                last_contrib[k] = contributor;
-            }
-            if (COUNT_TOUCHED) {
-                // wave-level reduction, one atomic per wave per entry
-                int tot = touched;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-                if ((tid & 63) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + __float_as_uint(sq2[j].w)], tot);
+                bool touched = false;
+                if (!done && power <= 0.0f) {
+                    const float alpha = fminf(0.99f, q1.w * __expf(power));
+                    if (alpha >= 1.0f / 255.0f) {
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < 0.0001f) {
+                            done = true;
+                        } else {
+                            const float4 q2 = sq2[j];
+                            const float w = alpha * T;
+                            Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
+                            Dd += q2.w * w;
+                            touched = test_T > 0.5f;
+                            T = test_T;
+                            last_contrib = contributor + j + 1;
+                        }
+                    }
+                }
+                if (COUNT_TOUCHED) {
+                    const int tot = __popcll(__ballot(touched));
+                    if (lane == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+                }
             }
         }
+        contributor += cnt;
         __syncthreads();
     }
 
-    const float bgr = background[3 * c], bgg = background[3 * c + 1], bgb = background[3 * c + 2];
-    const size_t HW = (size_t)H * W;
-#pragma unroll
-    for (int k = 0; k < PXL; ++k) {
-        const int py = py0 + k;
-        if (pxi < W && py < H) {
-            const size_t pix = (size_t)py * W + pxi;
-            final_T[c * HW + pix] = T[k];
-            n_contrib[c * HW + pix] = last_contrib[k];
-            out_color[(c * 3 + 0) * HW + pix] = Cr[k] + T[k] * bgr;
-            out_color[(c * 3 + 1) * HW + pix] = Cg[k] + T[k] * bgg;
-            out_color[(c * 3 + 2) * HW + pix] = Cb[k] + T[k] * bgb;
-            out_depth[c * HW + pix] = Dd[k];
-            out_opacity[c * HW + pix] = 1.0f - T[k];
-        }
+    if (inside) {
+        const float bgr = background[3 * c], bgg = background[3 * c + 1], bgb = background[3 * c + 2];
+        const size_t HW = (size_t)H * W;
+        const size_t pix = (size_t)pyi * W + pxi;
+        final_T[c * HW + pix] = T;
+        n_contrib[c * HW + pix] = last_contrib;
+        out_color[(c * 3 + 0) * HW + pix] = Cr + T * bgr;
+        out_color[(c * 3 + 1) * HW + pix] = Cg + T * bgg;
+        out_color[(c * 3 + 2) * HW + pix] = Cb + T * bgb;
+        out_depth[c * HW + pix] = Dd;
+        out_opacity[c * HW + pix] = 1.0f - T;
     }
 }
 
@@ -564,10 +568,10 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     const bool count = (in->flags & VS_RASTER_COUNT_TOUCHED) && out->n_touched;
     dim3 rgrid(tiles, C);
     if (count)
-        hipLaunchKernelGGL((render_kernel<4, true>), rgrid, dim3(64), 0, stream, P, W, H, ranges, point_list, geom, in->background,
+        hipLaunchKernelGGL((render_kernel<true>), rgrid, dim3(256), 0, stream, P, W, H, ranges, point_list, geom, in->background,
                            out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched);
     else
-        hipLaunchKernelGGL((render_kernel<4, false>), rgrid, dim3(64), 0, stream, P, W, H, ranges, point_list, geom, in->background,
+        hipLaunchKernelGGL((render_kernel<false>), rgrid, dim3(256), 0, stream, P, W, H, ranges, point_list, geom, in->background,
                            out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched);
     VS_HIP(hipGetLastError());
     return R;

@@ -105,21 +105,26 @@ class PixelwiseTaskWithDPT(nn.Module):
         with torch.autocast("cuda", dtype=self.compute_dtype):
             return fn()
 
-    def forward_pts3d(self, tokens, gh: int, gw: int) -> torch.Tensor:
-        """-> [BT,H,W,3] f32 points; 'exp' depth mode (postprocess.py:46-56)."""
+    def forward_pts3d_raw(self, tokens, gh: int, gw: int) -> torch.Tensor:
+        """-> [BT,3,H,W] head output in the compute dtype, channels-last, BEFORE the 'exp' post-process."""
         def fn():
             d = self.dpt
             x = d.head[0](d.trunk(tokens, gh, gw))
             x = d.head[2](_up2(x))
             return d.head[4](F.relu(x))
-        xyz = self._run(fn).float().permute(0, 2, 3, 1)[..., :3]
+        return self._run(fn)[:, :3].contiguous(memory_format=torch.channels_last)
+
+    def forward_pts3d(self, tokens, gh: int, gw: int) -> torch.Tensor:
+        """-> [BT,H,W,3] f32 points; 'exp' depth mode (postprocess.py:46-56).  (distillation path only; the main
+        path fuses this into the adapter kernel.)"""
+        xyz = self.forward_pts3d_raw(tokens, gh, gw).float().permute(0, 2, 3, 1)
         dist = xyz.norm(dim=-1, keepdim=True)
         return xyz / dist.clip(min=1e-8) * torch.expm1(dist)
 
     def forward_gs(self, tokens, frames: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
-        """-> [BT,C,H,W] f32 raw Gaussian parameters (dpt_gs_head.py:120-157)."""
+        """-> [BT,C,H,W] raw Gaussian parameters in the compute dtype, channels-last (dpt_gs_head.py:120-157)."""
         def fn():
             d = self.dpt
             x = _up2(d.trunk(tokens, gh, gw)) + d.input_merger(frames.contiguous(memory_format=torch.channels_last))
             return d.head[4](F.relu(d.head[0](x)))  # Dropout(0.1) is the identity at inference
-        return self._run(fn).float()
+        return self._run(fn).contiguous(memory_format=torch.channels_last)

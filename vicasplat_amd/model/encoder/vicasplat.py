@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ... import ops
 from .backbone.backbone_vica import VicaNet
 from .common.gaussian_adapter import GaussianAdapterCfg, Gaussians, MyGaussianAdapter
 from .encoder import Encoder
@@ -121,26 +122,39 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         pred_extrinsics_4x4 = torch.cat([eye, camera_matrix_from_dq_array(pred_extrins)], dim=1)
 
         tokens = [None if t is None else t.flatten(0, 1) for t in interms]
-        gs_centers = self.downstream_head1.forward_pts3d(tokens, gh, gw).unflatten(0, (B, T))
-        viewspace_depth = None
-        if compute_viewspace_depth:
-            E = context["extrinsics"]
-            vp = torch.einsum("bvij,bvhwj->bvhwi", torch.linalg.inv(E[:, :, :3, :3]), gs_centers - E[:, :, None, None, :3, 3])
-            viewspace_depth = vp[..., -1]
         if distill:
+            gs_centers = self.downstream_head1.forward_pts3d(tokens, gh, gw).unflatten(0, (B, T))
             return dict(pred_extrins=pred_extrins, pred_intrins=None, gaussian_camera_extrins=pred_extrinsics_4x4,
                         gaussian_camera_intrins=None, gaussian_centers=gs_centers, confidence=None,
-                        context_view_depths=viewspace_depth)
-        gs_params = self.gaussian_param_head.forward_gs(tokens, image.flatten(0, 1), gh, gw)
-        gs_params = gs_params.unflatten(0, (B, T)).permute(0, 1, 3, 4, 2)
-        raw_gaussians = torch.cat([gs_centers, gs_params], dim=-1)
-        gaussians = self.gaussian_adapter(
-            raw_gaussians, None if self.cfg.predict_opacity else (lambda o: self.map_pdf_to_opacity(o, global_step)))
+                        context_view_depths=self._viewspace_depth(context, gs_centers) if compute_viewspace_depth else None)
+        # heads -> ONE fused kernel: 'exp' depth post-process + raw_gaussians concat + Gaussian adapter
+        pts_raw = self.downstream_head1.forward_pts3d_raw(tokens, gh, gw)
+        gs_raw = self.gaussian_param_head.forward_gs(tokens, image.flatten(0, 1), gh, gw)
+        if pts_raw.dtype != gs_raw.dtype:
+            pts_raw = pts_raw.to(gs_raw.dtype)
+        ga = self.gaussian_adapter
+        c = self.cfg.opacity_mapping
+        exponent = -1.0 if self.cfg.predict_opacity else 2 ** (c.initial + min(global_step / c.warm_up, 1) * (c.final - c.initial))
+        o = ops.gaussian_adapter(pts_raw, gs_raw, ga.sh_mask, scale_act=ga.cfg.scale_act, scale_min=ga.cfg.gaussian_scale_min,
+                                 scale_max=ga.cfg.gaussian_scale_max, opacity_exponent=float(exponent))
+        un = lambda t: t.unflatten(0, (B, T))
+        gaussians = Gaussians(means=un(o["means"]), covariances=un(o["covariances"]), harmonics=un(o["harmonics"]),
+                              opacities=un(o["opacities"]), scales=un(o["scales"]), rotations=un(o["rotations"]))
+        raw_gaussians = un(o["raw"])
+        gs_centers = gaussians.means
+        viewspace_depth = self._viewspace_depth(context, gs_centers) if compute_viewspace_depth else None
         if visualization_dump is not None:
             visualization_dump["depth"] = gaussians.means[..., -1:]
         return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=None, raw_gaussians=raw_gaussians,
                     gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=None, gaussian_centers=gs_centers,
                     confidence=None, context_view_depths=viewspace_depth)
+
+    @staticmethod
+    def _viewspace_depth(context: dict, gs_centers: torch.Tensor) -> torch.Tensor:
+        """z of the predicted centres in each context camera (vicasplat.py:224-232)."""
+        E = context["extrinsics"]
+        vp = torch.einsum("bvij,bvhwj->bvhwi", torch.linalg.inv(E[:, :, :3, :3]), gs_centers - E[:, :, None, None, :3, 3])
+        return vp[..., -1]
 
     def get_data_shim(self):
         mean, std = self.cfg.input_mean, self.cfg.input_std

@@ -88,3 +88,34 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
                                   _DT[q.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_attention")
     return out
+
+
+def gaussian_adapter(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torch.Tensor, *, scale_act: str = "softplus",
+                     scale_min: float = 0.0, scale_max: float = 0.0, opacity_exponent: float = 1.0, want_raw: bool = True):
+    """pts [N,3,H,W], gs [N,8+3*d_sh,H,W] (any strides, f32/f16/bf16, same dtype) -> dict of f32 tensors shaped
+    [N,H,W,...] (means, covariances, harmonics, opacities [...,1], scales, rotations, raw)."""
+    dev = L.require_device(pts, gs, sh_mask)
+    assert pts.dtype == gs.dtype and pts.dim() == 4 and gs.dim() == 4 and pts.shape[1] == 3
+    N, Cg, H, W = gs.shape
+    d_sh = (Cg - 8) // 3
+    assert Cg == 8 + 3 * d_sh and sh_mask.numel() == d_sh and sh_mask.dtype == torch.float32
+    # one flat pixel index must address both inputs: require (n,h,w) to be jointly contiguous in each (NCHW or NHWC)
+    for t in (pts, gs):
+        sn, sc, sh_, sw = t.stride()
+        if not (sh_ == W * sw and sn == H * sh_):  # not pixel-linear (e.g. plain NCHW): make it channels-last
+            raise RuntimeError("gaussian_adapter expects channels-last (NHWC) head outputs")
+    f = dict(dtype=torch.float32, device=dev)
+    npix = N * H * W
+    out = dict(means=torch.empty(N, H, W, 3, **f), covariances=torch.empty(N, H, W, 3, 3, **f),
+               harmonics=torch.empty(N, H, W, 3, d_sh, **f), opacities=torch.empty(N, H, W, 1, **f),
+               scales=torch.empty(N, H, W, 3, **f), rotations=torch.empty(N, H, W, 4, **f),
+               raw=torch.empty(N, H, W, 11 + 3 * d_sh, **f) if want_raw else None)
+    act = {"bounded": 0, "exp": 1, "softplus": 2}[scale_act]
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gaussian_adapter(L.ptr(pts), pts.stride(3), pts.stride(1), L.ptr(gs), gs.stride(3), gs.stride(1),
+                                         _DT[pts.dtype], npix, d_sh, L.ptr(sh_mask), act, scale_min, scale_max,
+                                         opacity_exponent, L.ptr(out["means"]), L.ptr(out["covariances"]), L.ptr(out["harmonics"]),
+                                         L.ptr(out["opacities"]), L.ptr(out["scales"]), L.ptr(out["rotations"]), L.ptr(out["raw"]),
+                                         L.stream_ptr(dev))
+    L.check(rc, "vs_gaussian_adapter")
+    return out
