@@ -1,0 +1,50 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol include/*.h declares.
+No compute calls here (CPU suite).  Also: argument validation returns an error code + message, never crashes."""
+import ctypes as C
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    syms = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        syms |= set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", txt))
+    return syms
+
+
+def test_library_exports_every_declared_symbol():
+    from vicasplat_amd import _lib
+    so = _lib.build()
+    assert os.path.exists(so)
+    L = C.CDLL(so)
+    syms = _declared_symbols()
+    assert {"vs_raster_forward", "vs_raster_backward", "vs_rope2d", "vs_gemm_bias_act", "vs_attention", "vs_layernorm_mod",
+            "vs_rope_qk", "vs_gaussian_adapter", "vs_last_error", "vs_abi_version"} <= syms
+    missing = [s for s in sorted(syms) if not hasattr(L, s)]
+    assert not missing, missing
+    assert _lib.lib().vs_abi_version() >= 1
+
+
+def test_argument_validation_reports_errors():
+    from vicasplat_amd import _lib
+    L = _lib.lib()
+    rc = L.vs_rope2d(None, None, 1, 1, 1, 64, 64, 64, 100.0, 1.0, 0, None)
+    assert rc < 0 and b"null" in L.vs_last_error()
+    rc = L.vs_gemm_bias_act(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), None, 4, 4, 30, 32, 32, 4, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, None)
+    assert rc < 0 and b"multiple of 64" in L.vs_last_error()
+    rc = L.vs_raster_forward(None, None, _lib.AllocFn(lambda a, b, c: 0), None, None)
+    assert rc < 0
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under vicasplat_amd/ may import it."""
+    bad = []
+    for f in glob.glob(os.path.join(ROOT, "vicasplat_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+            bad.append(f)
+    assert not bad, bad

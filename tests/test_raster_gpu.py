@@ -231,3 +231,76 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         render_cuda(T(sc["extrinsics"]), T(sc["intrinsics"]), T(sc["near"]), T(sc["far"]), (16, 16), torch.zeros(1, 3),
                     T(sc["means"]), T(sc["covariances"]), T(sc["harmonics"]), T(sc["opacities"]))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# backward (SURVEY.md a21): HIP kernels vs the C oracle (itself pinned to autograd + finite differences)
+# ---------------------------------------------------------------------------------------------------------
+def _close(a, b, name, rtol):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = np.abs(b).max() + 1e-12
+    assert np.abs(a - b).max() <= rtol * scale, (name, float(np.abs(a - b).max()), float(scale))
+
+
+@pytest.mark.parametrize("W,H,P", [(48, 32, 60), (64, 64, 400)])
+def test_backward_matches_oracle(W, H, P):
+    from vicasplat_amd.raster import rasterize
+    d = _dev()
+    means, cov, sh, op = _random_small(P, seed=100 + P)
+    cams = _two_cams()
+    gc = _gpu_cams(cams)
+    bg = np.array([0.2, 0.1, 0.3], np.float32)
+    rng = np.random.default_rng(7)
+    gC = rng.standard_normal((2, 3, H, W)).astype(np.float32)
+    gD = (rng.standard_normal((2, H, W)) * 0.3).astype(np.float32)
+    T = lambda a, g=False: torch.tensor(a, dtype=torch.float32, device=d).requires_grad_(g)
+    tm, tc, ts, to = T(means[None], True), T(rr.cov6(cov)[None], True), T(sh[None], True), T(op[None], True)
+    theta, rho = torch.zeros(2, 3, device=d, requires_grad=True), torch.zeros(2, 3, device=d, requires_grad=True)
+    color, radii, depth, _, _ = rasterize(tm, tc, to, gc["viewmatrix"], gc["projmatrix"], gc["campos"], gc["tanfov"],
+                                          T(bg).expand(2, 3).contiguous(), H, W, shs=ts, sh_degree=4, theta=theta, rho=rho)
+    ((color * T(gC)).sum() + (depth * T(gD)).sum()).backward()
+    c6 = rr.cov6(cov)
+    exp = dict(means=0, cov=0, sh=0, op=0)
+    taus = []
+    for c, cam in enumerate(cams):
+        fwd = rr.rasterize_forward(cam, W, H, bg, means, c6, sh, op)
+        b = rr.rasterize_backward(cam, W, H, bg, means, c6, sh, op, fwd, gC[c], gD[c])
+        exp["means"] = exp["means"] + b["means3D"]; exp["cov"] = exp["cov"] + b["cov3D"]
+        exp["sh"] = exp["sh"] + b["shs"]; exp["op"] = exp["op"] + b["opacities"]
+        taus.append(b["tau"])
+    _close(tm.grad[0].cpu(), exp["means"], "means3D", 2e-3)
+    _close(tc.grad[0].cpu(), exp["cov"], "cov3D", 2e-3)
+    _close(ts.grad[0].cpu(), exp["sh"], "shs", 2e-3)
+    _close(to.grad[0].cpu(), exp["op"], "opacity", 2e-3)
+    assert float(ts.grad[0, :, 16:].abs().max()) == 0.0  # band 4: never read, zero gradient
+    tau = np.stack(taus)
+    _close(rho.grad.cpu(), tau[:, :3], "rho", 5e-3)
+    _close(theta.grad.cpu(), tau[:, 3:], "theta", 5e-3)
+
+
+def test_backward_through_render_cuda_native_layouts():
+    """[S,P,3,3] covariances + [S,P,3,25] harmonics (encoder-native layouts): gradients land in those layouts."""
+    from vicasplat_amd.model.decoder.cuda_splatting import render_cuda
+    d = _dev()
+    sc = rr.synthetic_scene(V=1, res=32, Vt=2, seed=4)
+    T = lambda a, g=False: torch.tensor(a, dtype=torch.float32, device=d).requires_grad_(g)
+    m, cv, sh, op = T(sc["means"], True), T(sc["covariances"], True), T(sc["harmonics"], True), T(sc["opacities"], True)
+    img, dep = render_cuda(T(sc["extrinsics"]), T(sc["intrinsics"]), T(sc["near"]), T(sc["far"]), (32, 32), torch.zeros(2, 3, device=d), m, cv, sh, op)
+    rng = np.random.default_rng(3)
+    gC = rng.standard_normal((2, 3, 32, 32)).astype(np.float32)
+    (img * T(gC)).sum().backward()
+    cams = rr.make_cameras(sc["extrinsics"], sc["intrinsics"], sc["near"], sc["far"])
+    shs = np.ascontiguousarray(np.transpose(sc["harmonics"], (0, 2, 1)))
+    c6 = rr.cov6(sc["covariances"])
+    e_m = e_c = e_s = e_o = 0
+    for c, cam in enumerate(cams):
+        fwd = rr.rasterize_forward(cam, 32, 32, np.zeros(3, np.float32), sc["means"], c6, shs, sc["opacities"])
+        b = rr.rasterize_backward(cam, 32, 32, np.zeros(3, np.float32), sc["means"], c6, shs, sc["opacities"], fwd, gC[c], None)
+        e_m = e_m + b["means3D"]; e_c = e_c + b["cov3D"]; e_s = e_s + b["shs"]; e_o = e_o + b["opacities"]
+    _close(m.grad.cpu(), e_m, "means", 3e-3)
+    _close(op.grad.cpu(), e_o, "opacity", 3e-3)
+    _close(sh.grad.cpu(), np.transpose(e_s, (0, 2, 1)), "harmonics [P,3,25]", 3e-3)
+    g33 = cv.grad.cpu().numpy()
+    assert np.allclose(g33, np.transpose(g33, (0, 2, 1)))  # symmetric spread
+    g6 = np.stack([g33[:, 0, 0], 2 * g33[:, 0, 1], 2 * g33[:, 0, 2], g33[:, 1, 1], 2 * g33[:, 1, 2], g33[:, 2, 2]], -1)
+    _close(g6, e_c, "covariances", 3e-3)

@@ -1,0 +1,424 @@
+// Tile-based Gaussian rasterizer, BACKWARD pass (incl. camera-twist gradients), hand-written for gfx950.
+//
+// Replaces diff_gaussian_rasterization._C.rasterize_gaussians_backward behind the autograd Function VicaSplat calls at
+// /root/reference/src/model/decoder/cuda_splatting.py:226-235 (semantics: SURVEY.md Appendix B.5; mathematics pinned
+// by oracle/raster_ref.c against PyTorch autograd + finite differences, tests/test_raster_oracle.py).
+//
+//   K1 render_backward_kernel : per (camera, tile) back-to-front replay from final_T / n_contrib; gradients w.r.t. the
+//        screen-space mean (NDC units), conic (true partials), opacity, colour and depth of every (camera, Gaussian)
+//        are accumulated with hardware f32 atomics.  Same 4-wave quadrant layout and wave-uniform footprint cull as
+//        the forward, so a wave only touches the Gaussians that can reach its 8x8 pixels; lanes that do not
+//        contribute issue no atomics.
+//   K2 preprocess_backward_kernel : thread = Gaussian of a scene, loops over the scene's cameras and sums the
+//        per-camera contributions in registers -> ONE plain store per output element (no atomics over views), plus a
+//        block-reduced atomic for the per-camera twist gradient dL/dtau = (rho, theta), T_cw' = Exp(tau) T_cw.
+#include "common.h"
+
+namespace {
+
+using vs::kGeomFloats;
+using vs::kTile;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// per-(camera,Gaussian) gradient record written by K1: mean2D.xy | conic.xyz | opacity | rgb | depth
+constexpr int kG = 10;
+
+__global__ void __launch_bounds__(256)
+render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                       const float *__restrict__ geom, const float *__restrict__ background, const float *__restrict__ final_T,
+                       const int32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, const float *__restrict__ dL_dpixdepth,
+                       float *__restrict__ grec) {
+    constexpr int NT = 256;
+    __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
+    __shared__ uint32_t sid[NT];
+    __shared__ int s_max;
+    const int c = blockIdx.y;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tiles = gridDim.x;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile_x = tile % gx, tile_y = tile / gx;
+    const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const float pixfx = (float)pxi, pixfy = (float)pyi;
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
+    const int2 rg = ranges[(size_t)c * tiles + tile];
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
+    const bool inside = pxi < W && pyi < H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)pyi * W + pxi;
+
+    const int last = inside ? n_contrib[c * HW + pix] : 0;
+    const float T_final = inside ? final_T[c * HW + pix] : 0.f;
+    float T = T_final;
+    float dLr = 0.f, dLg = 0.f, dLb = 0.f, dLd = 0.f;
+    if (inside) {
+        dLr = dL_dpix[(c * 3 + 0) * HW + pix]; dLg = dL_dpix[(c * 3 + 1) * HW + pix]; dLb = dL_dpix[(c * 3 + 2) * HW + pix];
+        if (dL_dpixdepth) dLd = dL_dpixdepth[c * HW + pix];
+    }
+    const float bg_dot = background[3 * c] * dLr + background[3 * c + 1] * dLg + background[3 * c + 2] * dLb;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f, last_alpha = 0.f;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    atomicMax(&s_max, last);
+    __syncthreads();
+    const int nmax = s_max;  // entries [0, nmax) of the tile list can contribute to some pixel of this tile
+    int wave_max = last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
+
+    float *__restrict__ gr = grec + (size_t)c * P * kG;
+    // walk the list back to front in batches of NT: batch b covers positions [b*NT, min((b+1)*NT, nmax))
+    for (int b = (nmax + NT - 1) / NT - 1; b >= 0; --b) {
+        const int p0 = b * NT;
+        const int cnt = min(NT, nmax - p0);
+        __syncthreads();
+        if (tid < cnt) {
+            const uint32_t g = point_list[rg.x + p0 + tid];
+            sq0[tid] = g4[(size_t)g * 3 + 0];
+            sq1[tid] = g4[(size_t)g * 3 + 1];
+            sq2[tid] = g4[(size_t)g * 3 + 2];
+            sid[tid] = g;
+        }
+        __syncthreads();
+        if (p0 >= wave_max) continue;  // nothing in this batch reaches the wave's pixels
+        for (int j = cnt - 1; j >= 0; --j) {
+            const int posn = p0 + j;  // 0-based position; upstream's `contributor` = posn + 1
+            if (posn >= wave_max) continue;
+            const float4 q0 = sq0[j];
+            if (fabsf(q0.x - qcx) > q0.z + 3.5f || fabsf(q0.y - qcy) > q0.w + 3.5f) continue;
+            if (posn >= last) continue;
+            const float4 q1 = sq1[j];
+            const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+            const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, q1.w * G);
+            if (alpha < 1.0f / 255.0f) continue;
+            const float4 q2 = sq2[j];
+            T = T / (1.0f - alpha);
+            const float dch = alpha * T;
+            float dL_dalpha = 0.f;
+            acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r; last_r = q2.x; dL_dalpha += (q2.x - acc_r) * dLr;
+            acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g; last_g = q2.y; dL_dalpha += (q2.y - acc_g) * dLg;
+            acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b; last_b = q2.z; dL_dalpha += (q2.z - acc_b) * dLb;
+            acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d; last_d = q2.w; dL_dalpha += (q2.w - acc_d) * dLd;
+            dL_dalpha *= T;
+            last_alpha = alpha;
+            dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
+            const float dL_dG = q1.w * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            float *r = gr + (size_t)sid[j] * kG;
+            atomicAdd(r + 0, dL_dG * (-gdx * q1.x - gdy * q1.y) * ddelx_dx);
+            atomicAdd(r + 1, dL_dG * (-gdy * q1.z - gdx * q1.y) * ddely_dy);
+            atomicAdd(r + 2, -0.5f * gdx * dx * dL_dG);
+            atomicAdd(r + 3, -1.0f * gdx * dy * dL_dG);
+            atomicAdd(r + 4, -0.5f * gdy * dy * dL_dG);
+            atomicAdd(r + 5, G * dL_dalpha);
+            atomicAdd(r + 6, dch * dLr);
+            atomicAdd(r + 7, dch * dLg);
+            atomicAdd(r + 8, dch * dLb);
+            atomicAdd(r + 9, dch * dLd);
+        }
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float *sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
+                           const float *__restrict__ grec, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D,
+                           float *__restrict__ dL_dshs, float *__restrict__ dL_dcolors_precomp, float *__restrict__ dL_dopac,
+                           float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dtau) {
+    __shared__ float sm[4];
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int P = in.P;
+    const bool live = i < P;
+    const size_t gi = (size_t)s * P + (live ? i : 0);
+    const int W = in.width, H = in.height;
+    const bool has_sh = in.colors_precomp == nullptr;
+    const bool rgb_major = (in.flags & VS_RASTER_SH_RGB_MAJOR) != 0;
+    const int M = in.sh_coeffs;
+    const int deg = in.sh_degree;
+    const int ncoef = deg >= 3 ? 16 : (deg + 1) * (deg + 1);
+
+    float px = 0.f, py = 0.f, pz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    float sh[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sh[k][0] = sh[k][1] = sh[k][2] = 0.f;
+    if (live) {
+        px = in.means3D[3 * gi]; py = in.means3D[3 * gi + 1]; pz = in.means3D[3 * gi + 2];
+        if (in.flags & VS_RASTER_COV_3X3) {
+            const float *cv = in.cov3D + 9 * gi;
+            c0 = cv[0]; c1 = cv[1]; c2 = cv[2]; c3 = cv[4]; c4 = cv[5]; c5 = cv[8];
+        } else {
+            const float *cv = in.cov3D + 6 * gi;
+            c0 = cv[0]; c1 = cv[1]; c2 = cv[2]; c3 = cv[3]; c4 = cv[4]; c5 = cv[5];
+        }
+        if (has_sh) {
+            const float *shp = in.shs + gi * (size_t)M * 3;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    if (k < ncoef) sh[k][ch] = rgb_major ? shp[ch * M + k] : shp[3 * k + ch];
+        }
+    }
+    const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
+
+    float g_mean[3] = {0.f, 0.f, 0.f}, g_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g_op = 0.f, g_cp[3] = {0.f, 0.f, 0.f};
+    float g_sh[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
+
+    for (int c = 0; c < in.num_cameras; ++c) {
+        const int cs = in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes);
+        if (cs != s) continue;  // block-uniform
+        const size_t ci = (size_t)c * P + (live ? i : 0);
+        float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live && radii[ci] > 0) {
+            const float *__restrict__ vm = in.viewmatrix + 16 * c;
+            const float *__restrict__ pm = in.projmatrix + 16 * c;
+            const float tanfovx = in.tanfov[2 * c], tanfovy = in.tanfov[2 * c + 1];
+            const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+            const float *__restrict__ r = grec + ci * kG;
+            const float g2x = r[0], g2y = r[1], gA = r[2], gB = r[3], gC = r[4];
+            g_op += r[5];
+            const float gcol[3] = {r[6], r[7], r[8]};
+            const float gdep = r[9];
+            if (dL_dmeans2D) { dL_dmeans2D[2 * ci] = g2x; dL_dmeans2D[2 * ci + 1] = g2y; }
+            const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+            const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+            const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+            float gpc[3] = {0.f, 0.f, 0.f};
+            float gR[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            // ---- 2-D covariance path ----
+            {
+                const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+                const float txtz = vx / vz, tytz = vy / vz;
+                const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz, ty = fminf(limy, fmaxf(-limy, tytz)) * vz, tz = vz;
+                const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+                const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+                const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+                float M0[3], M1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    M0[k] = J00 * vm[4 * k + 0] + J02 * vm[4 * k + 2];
+                    M1[k] = J11 * vm[4 * k + 1] + J12 * vm[4 * k + 2];
+                }
+                float t0[3], t1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    t0[k] = S[k][0] * M0[0] + S[k][1] * M0[1] + S[k][2] * M0[2];
+                    t1[k] = S[k][0] * M1[0] + S[k][1] * M1[1] + S[k][2] * M1[2];
+                }
+                const float a = M0[0] * t0[0] + M0[1] * t0[1] + M0[2] * t0[2] + 0.3f;
+                const float b = M0[0] * t1[0] + M0[1] * t1[1] + M0[2] * t1[2];
+                const float cc = M1[0] * t1[0] + M1[1] * t1[1] + M1[2] * t1[2] + 0.3f;
+                const float det = a * cc - b * b;
+                const float d2inv = 1.0f / (det * det + 0.0000001f);
+                float ga = 0.f, gb = 0.f, gc = 0.f;
+                if (d2inv != 0.0f) {
+                    ga = d2inv * (-cc * cc * gA + b * cc * gB - b * b * gC);
+                    gc = d2inv * (-b * b * gA + a * b * gB - a * a * gC);
+                    gb = d2inv * (2.0f * b * cc * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+                }
+                g_cov[0] += M0[0] * M0[0] * ga + M0[0] * M1[0] * gb + M1[0] * M1[0] * gc;
+                g_cov[3] += M0[1] * M0[1] * ga + M0[1] * M1[1] * gb + M1[1] * M1[1] * gc;
+                g_cov[5] += M0[2] * M0[2] * ga + M0[2] * M1[2] * gb + M1[2] * M1[2] * gc;
+                g_cov[1] += 2.f * M0[0] * M0[1] * ga + (M0[0] * M1[1] + M0[1] * M1[0]) * gb + 2.f * M1[0] * M1[1] * gc;
+                g_cov[2] += 2.f * M0[0] * M0[2] * ga + (M0[0] * M1[2] + M0[2] * M1[0]) * gb + 2.f * M1[0] * M1[2] * gc;
+                g_cov[4] += 2.f * M0[1] * M0[2] * ga + (M0[1] * M1[2] + M0[2] * M1[1]) * gb + 2.f * M1[1] * M1[2] * gc;
+                float gM0[3], gM1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    gM0[k] = 2.f * ga * t0[k] + gb * t1[k];
+                    gM1[k] = 2.f * gc * t1[k] + gb * t0[k];
+                }
+                float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    gJ00 += gM0[k] * vm[4 * k + 0]; gJ02 += gM0[k] * vm[4 * k + 2];
+                    gJ11 += gM1[k] * vm[4 * k + 1]; gJ12 += gM1[k] * vm[4 * k + 2];
+                    gR[0][k] += J00 * gM0[k];
+                    gR[1][k] += J11 * gM1[k];
+                    gR[2][k] += J02 * gM0[k] + J12 * gM1[k];
+                }
+                const float tz2 = 1.0f / (tz * tz), tz3 = tz2 / tz;
+                gpc[0] += xmul * (-fx * tz2) * gJ02;
+                gpc[1] += ymul * (-fy * tz2) * gJ12;
+                gpc[2] += -fx * tz2 * gJ00 - fy * tz2 * gJ11 + (2.f * fx * tx) * tz3 * gJ02 + (2.f * fy * ty) * tz3 * gJ12;
+            }
+            // ---- projected mean path ----
+            {
+                const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+                const float hy = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+                const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+                const float m_w = 1.0f / (hw + 0.0000001f);
+                const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+                float gw[3];
+                gw[0] = (pm[0] * m_w - pm[3] * mul1) * g2x + (pm[1] * m_w - pm[3] * mul2) * g2y;
+                gw[1] = (pm[4] * m_w - pm[7] * mul1) * g2x + (pm[5] * m_w - pm[7] * mul2) * g2y;
+                gw[2] = (pm[8] * m_w - pm[11] * mul1) * g2x + (pm[9] * m_w - pm[11] * mul2) * g2y;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) gpc[rr] += vm[0 + rr] * gw[0] + vm[4 + rr] * gw[1] + vm[8 + rr] * gw[2];
+            }
+            // ---- depth path ----
+            gpc[2] += gdep;
+            // ---- colour path ----
+            float gdir[3] = {0.f, 0.f, 0.f};
+            if (!has_sh) {
+                g_cp[0] += gcol[0]; g_cp[1] += gcol[1]; g_cp[2] += gcol[2];
+            } else {
+                const float *__restrict__ cp = in.campos + 3 * c;
+                const float dxo = px - cp[0], dyo = py - cp[1], dzo = pz - cp[2];
+                const float len = sqrtf(dxo * dxo + dyo * dyo + dzo * dzo);
+                const float x = dxo / len, y = dyo / len, z = dzo / len;
+                const uint32_t cb = clamped[ci];
+                float g[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) g[ch] = (cb >> ch) & 1u ? 0.f : gcol[ch];
+                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float dRx = 0.f, dRy = 0.f, dRz = 0.f;
+                    g_sh[0][ch] += SH_C0 * g[ch];
+                    if (deg > 0) {
+                        g_sh[1][ch] += -SH_C1 * y * g[ch];
+                        g_sh[2][ch] += SH_C1 * z * g[ch];
+                        g_sh[3][ch] += -SH_C1 * x * g[ch];
+                        dRx = -SH_C1 * sh[3][ch]; dRy = -SH_C1 * sh[1][ch]; dRz = SH_C1 * sh[2][ch];
+                        if (deg > 1) {
+                            g_sh[4][ch] += SH_C2[0] * xy * g[ch];
+                            g_sh[5][ch] += SH_C2[1] * yz * g[ch];
+                            g_sh[6][ch] += SH_C2[2] * (2.0f * zz - xx - yy) * g[ch];
+                            g_sh[7][ch] += SH_C2[3] * xz * g[ch];
+                            g_sh[8][ch] += SH_C2[4] * (xx - yy) * g[ch];
+                            dRx += SH_C2[0] * y * sh[4][ch] + SH_C2[2] * 2.0f * -x * sh[6][ch] + SH_C2[3] * z * sh[7][ch] + SH_C2[4] * 2.0f * x * sh[8][ch];
+                            dRy += SH_C2[0] * x * sh[4][ch] + SH_C2[1] * z * sh[5][ch] + SH_C2[2] * 2.0f * -y * sh[6][ch] + SH_C2[4] * 2.0f * -y * sh[8][ch];
+                            dRz += SH_C2[1] * y * sh[5][ch] + SH_C2[2] * 4.0f * z * sh[6][ch] + SH_C2[3] * x * sh[7][ch];
+                            if (deg > 2) {
+                                g_sh[9][ch] += SH_C3[0] * y * (3.0f * xx - yy) * g[ch];
+                                g_sh[10][ch] += SH_C3[1] * xy * z * g[ch];
+                                g_sh[11][ch] += SH_C3[2] * y * (4.0f * zz - xx - yy) * g[ch];
+                                g_sh[12][ch] += SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * g[ch];
+                                g_sh[13][ch] += SH_C3[4] * x * (4.0f * zz - xx - yy) * g[ch];
+                                g_sh[14][ch] += SH_C3[5] * z * (xx - yy) * g[ch];
+                                g_sh[15][ch] += SH_C3[6] * x * (xx - 3.0f * yy) * g[ch];
+                                dRx += SH_C3[0] * sh[9][ch] * 6.0f * xy + SH_C3[1] * sh[10][ch] * yz + SH_C3[2] * sh[11][ch] * -2.0f * xy +
+                                       SH_C3[3] * sh[12][ch] * -6.0f * xz + SH_C3[4] * sh[13][ch] * (-3.0f * xx + 4.0f * zz - yy) +
+                                       SH_C3[5] * sh[14][ch] * 2.0f * xz + SH_C3[6] * sh[15][ch] * 3.0f * (xx - yy);
+                                dRy += SH_C3[0] * sh[9][ch] * 3.0f * (xx - yy) + SH_C3[1] * sh[10][ch] * xz +
+                                       SH_C3[2] * sh[11][ch] * (-3.0f * yy + 4.0f * zz - xx) + SH_C3[3] * sh[12][ch] * -6.0f * yz +
+                                       SH_C3[4] * sh[13][ch] * -2.0f * xy + SH_C3[5] * sh[14][ch] * -2.0f * yz + SH_C3[6] * sh[15][ch] * -6.0f * xy;
+                                dRz += SH_C3[1] * sh[10][ch] * xy + SH_C3[2] * sh[11][ch] * 8.0f * yz +
+                                       SH_C3[3] * sh[12][ch] * 3.0f * (2.0f * zz - xx - yy) + SH_C3[4] * sh[13][ch] * 8.0f * xz +
+                                       SH_C3[5] * sh[14][ch] * (xx - yy);
+                            }
+                        }
+                    }
+                    ddx += dRx * g[ch]; ddy += dRy * g[ch]; ddz += dRz * g[ch];
+                }
+                const float dot = x * ddx + y * ddy + z * ddz;
+                gdir[0] = (ddx - x * dot) / len; gdir[1] = (ddy - y * dot) / len; gdir[2] = (ddz - z * dot) / len;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) tau[rr] += vm[0 + rr] * gdir[0] + vm[4 + rr] * gdir[1] + vm[8 + rr] * gdir[2];
+            }
+            // ---- assemble: p_C = R p + t ----
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                g_mean[k] += gdir[k] + vm[4 * k + 0] * gpc[0] + vm[4 * k + 1] * gpc[1] + vm[4 * k + 2] * gpc[2];
+            tau[0] += gpc[0]; tau[1] += gpc[1]; tau[2] += gpc[2];
+            tau[3] += vy * gpc[2] - vz * gpc[1];
+            tau[4] += vz * gpc[0] - vx * gpc[2];
+            tau[5] += vx * gpc[1] - vy * gpc[0];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float r0 = vm[4 * j + 0], r1 = vm[4 * j + 1], r2 = vm[4 * j + 2];
+                tau[3] += r1 * gR[2][j] - r2 * gR[1][j];
+                tau[4] += r2 * gR[0][j] - r0 * gR[2][j];
+                tau[5] += r0 * gR[1][j] - r1 * gR[0][j];
+            }
+        }
+        if (dL_dtau) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float tsum = block_sum(tau[k], sm);
+                if (threadIdx.x == 0 && tsum != 0.f) atomicAdd(&dL_dtau[6 * c + k], tsum);
+            }
+        }
+    }
+    if (!live) return;
+    dL_dmeans3D[3 * gi] = g_mean[0]; dL_dmeans3D[3 * gi + 1] = g_mean[1]; dL_dmeans3D[3 * gi + 2] = g_mean[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * gi + k] = g_cov[k];
+    dL_dopac[gi] = g_op;
+    if (has_sh) {
+        if (dL_dshs) {
+            float *o = dL_dshs + gi * (size_t)M * 3;
+            for (int k = 0; k < M; ++k)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) v = (kk == k) ? g_sh[kk][ch] : v;
+                    if (rgb_major) o[ch * M + k] = v; else o[3 * k + ch] = v;
+                }
+        }
+    } else if (dL_dcolors_precomp) {
+        dL_dcolors_precomp[3 * gi] = g_cp[0]; dL_dcolors_precomp[3 * gi + 1] = g_cp[1]; dL_dcolors_precomp[3 * gi + 2] = g_cp[2];
+    }
+}
+
+}  // namespace
+
+extern "C" int vs_raster_backward(const VsRasterIn *in, const VsRasterOut *saved, const VsRasterGrads *g, VsAllocFn alloc,
+                                  void *actx, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && saved && g && alloc, "vs_raster_backward: null argument");
+    VS_CHECK(g->dL_dcolor && g->dL_dmeans3D && g->dL_dcov3D && g->dL_dopacities, "vs_raster_backward: null gradient pointer");
+    const int C = in->num_cameras, P = in->P, W = in->width, H = in->height;
+    if (P == 0) return 0;
+    const int gx = vs::cdiv(W, kTile), gy = vs::cdiv(H, kTile), tiles = gx * gy;
+    const float *geom = (const float *)saved->buffers[VS_BUF_GEOM];
+    const uint8_t *clamped = (const uint8_t *)saved->buffers[VS_BUF_CLAMPED];
+    const int2 *ranges = (const int2 *)saved->buffers[VS_BUF_TILE_RANGES];
+    const uint32_t *point_list = (const uint32_t *)saved->buffers[VS_BUF_POINT_LIST];
+    const float *final_T = (const float *)saved->buffers[VS_BUF_FINAL_T];
+    const int32_t *n_contrib = (const int32_t *)saved->buffers[VS_BUF_N_CONTRIB];
+    VS_CHECK(geom && clamped && ranges && point_list && final_T && n_contrib && saved->radii,
+             "vs_raster_backward: forward state missing (buffers[] of the matching vs_raster_forward must be alive)");
+    const size_t rec_bytes = (size_t)C * P * kG * sizeof(float);
+    float *grec = (float *)alloc(actx, VS_BUF_MISC, rec_bytes);
+    VS_CHECK(grec, "vs_raster_backward: allocator returned null");
+    VS_HIP(hipMemsetAsync(grec, 0, rec_bytes, stream));
+    if (g->dL_dtau) VS_HIP(hipMemsetAsync(g->dL_dtau, 0, (size_t)C * 6 * sizeof(float), stream));
+    if (g->dL_dmeans2D) VS_HIP(hipMemsetAsync(g->dL_dmeans2D, 0, (size_t)C * P * 2 * sizeof(float), stream));
+    if (saved->num_rendered > 0)
+        hipLaunchKernelGGL(render_backward_kernel, dim3(tiles, C), dim3(256), 0, stream, P, W, H, ranges, point_list, geom,
+                           in->background, final_T, n_contrib, g->dL_dcolor, g->dL_ddepth, grec);
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(vs::cdiv(P, 256), in->num_scenes), dim3(256), 0, stream, *in, saved->radii,
+                       clamped, grec, g->dL_dmeans3D, g->dL_dcov3D, g->dL_dshs, g->dL_dcolors_precomp, g->dL_dopacities,
+                       g->dL_dmeans2D, g->dL_dtau);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
