@@ -228,3 +228,33 @@ def test_attention_online_softmax_rescale_branch():
     f = qkv.float()
     ref = _sdpa_ref(f[:, :64], f[:, 64:128], f[:, 128:], 0.125)
     assert (out.float() - ref).abs().max() <= 3e-3
+
+
+@pytest.mark.parametrize("dt,layout", [(torch.float16, "nhwc"), (torch.bfloat16, "nhwc"), (torch.float32, "nhwc"), (torch.float16, "nchw_slice")])
+def test_gaussian_adapter_fused(dt, layout):
+    """Fused post-process + adapter vs the plain PyTorch formulation (postprocess.py:46-56 + MyGaussianAdapter)."""
+    from vicasplat_amd import ops
+    from vicasplat_amd.model.encoder.common.gaussian_adapter import GaussianAdapterCfg, MyGaussianAdapter
+    d = _dev()
+    torch.manual_seed(3)
+    N, H, W = 3, 20, 37  # 2220 pixels: not a multiple of 64 -> exercises the tail block
+    pts = (torch.randn(N, 3, H, W, device=d) * 0.7).to(dt)
+    gs = (torch.randn(N, 83, H, W, device=d) * 2.0).to(dt)
+    if layout == "nhwc":
+        pts_in, gs_in = pts.contiguous(memory_format=torch.channels_last), gs.contiguous(memory_format=torch.channels_last)
+    else:  # a channel slice of a wider NHWC tensor: pixel stride != channel count -> generic kernel
+        wide = torch.zeros(N, 90, H, W, device=d, dtype=dt).contiguous(memory_format=torch.channels_last)
+        wide[:, :83] = gs
+        gs_in = wide[:, :83]
+        pts_in = pts.contiguous(memory_format=torch.channels_last)
+    ad = MyGaussianAdapter(GaussianAdapterCfg(0.005, 0.04, 4, "softplus")).to(d)
+    o = ops.gaussian_adapter(pts_in, gs_in, ad.sh_mask, scale_act="softplus", opacity_exponent=1.0)
+    xyz = pts.float().permute(0, 2, 3, 1)
+    dist = xyz.norm(dim=-1, keepdim=True)
+    centers = xyz / dist.clip(min=1e-8) * torch.expm1(dist)
+    raw = torch.cat([centers, gs.float().permute(0, 2, 3, 1)], -1)
+    ref = ad(raw, lambda p: 0.5 * (1 - (1 - p) ** 1.0 + p ** 1.0))
+    for k, r in (("means", ref.means), ("covariances", ref.covariances), ("harmonics", ref.harmonics), ("opacities", ref.opacities),
+                 ("scales", ref.scales), ("rotations", ref.rotations), ("raw", raw)):
+        assert o[k].shape == r.shape, k
+        assert (o[k] - r).abs().max() <= 2e-5 * max(1.0, float(r.abs().max())), k

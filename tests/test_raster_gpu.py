@@ -121,8 +121,8 @@ def test_forward_config3_scene_131k():
         assert abs(psnr(g["color"][c].cpu().numpy()) - psnr(o["color"])) <= 1e-4
 
 
-def test_oversize_tile_falls_back_to_global_sort():
-    # > 8192 Gaussians in ONE tile: exercises the global-memory bitonic path
+def test_oversize_tile_radix_path():
+    # > 8192 Gaussians in ONE tile: exercises the workgroup radix sort (global ping-pong) incl. depth ties
     P = 9000
     rng = np.random.default_rng(1)
     means = np.stack([rng.uniform(-0.02, 0.02, P), rng.uniform(-0.02, 0.02, P), rng.uniform(2.0, 3.0, P)], -1).astype(np.float32)

@@ -104,6 +104,134 @@ __global__ void __launch_bounds__(256) adapter_kernel(const AdapterArgs a) {
     }
 }
 
+
+// ---- fast path: dense NHWC 16-bit inputs (what the heads produce).  One wave handles 64 consecutive pixels: the
+// 64 x (8+3*d_sh) input block and every output block are CONTIGUOUS in HBM, so they move as 16-byte coalesced
+// vectors through an LDS staging tile; the per-pixel math runs on LDS-resident values. ----
+constexpr int kMaxCh = 96;  // 11 + 3*d_sh <= 96  (d_sh <= 28)
+
+template <bool BF16>
+__device__ __forceinline__ float cvt16(unsigned short h) {
+    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
+    else { _Float16 f = *reinterpret_cast<_Float16 *>(&h); return (float)f; }
+}
+
+__device__ __forceinline__ void flush_block(const float *__restrict__ sm, float *__restrict__ dst, int nfloat, int lane) {
+    // dst is 16-byte aligned (block start * per-pixel floats * 64 pixels); nfloat % 4 == 0 for full blocks
+    const int nv = nfloat >> 2;
+    for (int k = lane; k < nv; k += 64) reinterpret_cast<float4 *>(dst)[k] = reinterpret_cast<const float4 *>(sm)[k];
+    for (int k = (nv << 2) + lane; k < nfloat; k += 64) dst[k] = sm[k];
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sin[64 * (kMaxCh - 3) + 64 * 3 + 16];
+    __shared__ __attribute__((aligned(16))) float sout[64 * kMaxCh];
+    const int lane = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int np = (int)min((long long)64, a.npix - p0);
+    const int nsh = a.d_sh, cg = 8 + 3 * nsh, craw = 11 + 3 * nsh;
+    unsigned short *sgs = sin, *spt = sin + 64 * cg;
+    {   // coalesced 16-byte loads of the two input blocks
+        const unsigned short *ggs = reinterpret_cast<const unsigned short *>(a.gs) + p0 * cg;
+        const unsigned short *gpt = reinterpret_cast<const unsigned short *>(a.pts) + p0 * 3;
+        const int n1 = np * cg, n2 = np * 3;
+        for (int k = lane; k < (n1 >> 3); k += 64) reinterpret_cast<uint4 *>(sgs)[k] = reinterpret_cast<const uint4 *>(ggs)[k];
+        for (int k = ((n1 >> 3) << 3) + lane; k < n1; k += 64) sgs[k] = ggs[k];
+        for (int k = lane; k < (n2 >> 3); k += 64) reinterpret_cast<uint4 *>(spt)[k] = reinterpret_cast<const uint4 *>(gpt)[k];
+        for (int k = ((n2 >> 3) << 3) + lane; k < n2; k += 64) spt[k] = gpt[k];
+    }
+    __syncthreads();
+    const bool live = lane < np;
+    const unsigned short *mg = sgs + lane * cg;
+    float mx = 0.f, my = 0.f, mz = 0.f, p = 0.f, s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 1.f}, cov[9];
+    float o_raw = 0.f, sr[3] = {0.f, 0.f, 0.f}, qr[4] = {0.f, 0.f, 0.f, 1.f};
+    if (live) {
+        const float x = cvt16<BF16>(spt[lane * 3]), y = cvt16<BF16>(spt[lane * 3 + 1]), z = cvt16<BF16>(spt[lane * 3 + 2]);
+        const float d = sqrtf(x * x + y * y + z * z);
+        const float k = expm1f(d) / fmaxf(d, 1e-8f);
+        mx = x * k; my = y * k; mz = z * k;
+        o_raw = cvt16<BF16>(mg[0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sr[c] = cvt16<BF16>(mg[1 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qr[c] = cvt16<BF16>(mg[4 + c]);
+        p = 1.0f / (1.0f + expf(-o_raw));
+        if (a.opacity_exponent > 0.0f && a.opacity_exponent != 1.0f) {
+            const float e = a.opacity_exponent;
+            p = 0.5f * (1.0f - powf(1.0f - p, e) + powf(p, 1.0f / e));
+        } else if (a.opacity_exponent == 1.0f) {
+            p = 0.5f * (1.0f - (1.0f - p) + p);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = sr[c];
+            if (a.scale_act == 0) v = a.scale_min + (a.scale_max - a.scale_min) / (1.0f + expf(-v));
+            else if (a.scale_act == 1) v = fminf(expf(v), 0.3f);
+            else v = fminf(0.001f * (v > 20.0f ? v : log1pf(expf(v))), 0.3f);
+            s[c] = v;
+        }
+        const float qn = fmaxf(sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]), 1e-12f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = qr[c] / qn;
+        const float qi = q[0], qj = q[1], qk = q[2], qw = q[3];
+        const float two_s = 2.0f / (qi * qi + qj * qj + qk * qk + qw * qw + 1e-8f);
+        const float R[3][3] = {{1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qw), two_s * (qi * qk + qj * qw)},
+                               {two_s * (qi * qj + qk * qw), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qw)},
+                               {two_s * (qi * qk - qj * qw), two_s * (qj * qk + qi * qw), 1 - two_s * (qi * qi + qj * qj)}};
+        float RS[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) RS[r][c] = R[r][c] * s[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cov[3 * r + c] = RS[r][0] * RS[c][0] + RS[r][1] * RS[c][1] + RS[r][2] * RS[c][2];
+    }
+    // ---- raw [px][craw] ----
+    if (a.raw) {
+        if (live) {
+            float *r = sout + lane * craw;
+            r[0] = mx; r[1] = my; r[2] = mz; r[3] = o_raw;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[4 + c] = sr[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[7 + c] = qr[c];
+            for (int c = 0; c < 3 * nsh; ++c) r[11 + c] = cvt16<BF16>(mg[8 + c]);
+        }
+        __syncthreads();
+        flush_block(sout, a.raw + p0 * craw, np * craw, lane);
+        __syncthreads();
+    }
+    // ---- harmonics [px][3*nsh] ----
+    if (live) {
+        float *r = sout + lane * 3 * nsh;
+        for (int c = 0; c < 3 * nsh; ++c) r[c] = cvt16<BF16>(mg[8 + c]) * a.sh_mask[c % nsh];
+    }
+    __syncthreads();
+    flush_block(sout, a.harmonics + p0 * 3 * nsh, np * 3 * nsh, lane);
+    __syncthreads();
+    // ---- covariances [px][9] | means [px][3] | scales [px][3] | rotations [px][4] | opacities [px] packed in one LDS tile ----
+    float *s_cov = sout, *s_mean = sout + 64 * 9, *s_scale = s_mean + 64 * 3, *s_rot = s_scale + 64 * 3, *s_op = s_rot + 64 * 4;
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s_cov[lane * 9 + c] = cov[c];
+        s_mean[lane * 3] = mx; s_mean[lane * 3 + 1] = my; s_mean[lane * 3 + 2] = mz;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_scale[lane * 3 + c] = s[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_rot[lane * 4 + c] = q[c];
+        s_op[lane] = p;
+    }
+    __syncthreads();
+    flush_block(s_cov, a.cov + p0 * 9, np * 9, lane);
+    flush_block(s_mean, a.means + p0 * 3, np * 3, lane);
+    flush_block(s_scale, a.scales + p0 * 3, np * 3, lane);
+    flush_block(s_rot, a.rotations + p0 * 4, np * 4, lane);
+    flush_block(s_op, a.opacities + p0, np, lane);
+}
+
 }  // namespace
 
 extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts_ch, const void *gs, int64_t gs_pix,
@@ -117,6 +245,15 @@ extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts
     if (npix <= 0) return 0;
     AdapterArgs a{pts, gs, pts_pix, pts_ch, gs_pix, gs_ch, in_dtype, npix, d_sh, sh_mask, scale_act, scale_min, scale_max,
                   opacity_exponent, means, cov, harmonics, opacities, scales, rotations, raw};
+    const bool dense16 = in_dtype != 0 && pts_ch == 1 && pts_pix == 3 && gs_ch == 1 && gs_pix == 8 + 3 * d_sh &&
+                         11 + 3 * d_sh <= kMaxCh && ((uintptr_t)pts & 15) == 0 && ((uintptr_t)gs & 15) == 0;
+    if (dense16) {
+        dim3 g64((unsigned)vs::cdiv64(npix, 64));
+        if (in_dtype == 1) hipLaunchKernelGGL(adapter_nhwc16_kernel<false>, g64, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(adapter_nhwc16_kernel<true>, g64, dim3(64), 0, stream, a);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     dim3 grid((unsigned)vs::cdiv64(npix, 256)), block(256);
     if (in_dtype == 0) hipLaunchKernelGGL(adapter_kernel<0>, grid, block, 0, stream, a);
     else if (in_dtype == 1) hipLaunchKernelGGL(adapter_kernel<1>, grid, block, 0, stream, a);

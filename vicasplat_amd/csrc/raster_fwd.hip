@@ -347,10 +347,14 @@ scatter_kernel(int P, int tiles, int gx, const float *__restrict__ geom, const u
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K4: one workgroup per (camera, tile) sorts its key segment.  n <= kSortLds: bitonic network in LDS;
-// larger segments: same network on a padded copy in global scratch (bump-allocated).  Output: sorted ids.
+// K4: one workgroup per (camera, tile) sorts its key segment; output = sorted Gaussian ids.
+//   n <= 1024 : bitonic network in LDS (8 KiB);
+//   larger    : workgroup-level stable LSD radix sort, 8-bit digits, ping-pong between the key segment and a scratch
+//               segment in global memory (L2-resident).  O(n) per pass, any n; passes whose digit is constant over the
+//               segment (high depth-exponent bits, unused index bits) are skipped.  Stable ranking inside a 256-key
+//               chunk uses wave ballots (8 per key) + a 4x256 per-wave digit-count table.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSortLds = 8192;  // 64 KiB of LDS -> 2 workgroups per CU
+constexpr int kSortLds = 1024;
 
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr a, int N) {
@@ -370,34 +374,81 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, int N) {
 
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict__ keys, uint32_t *__restrict__ point_list,
-                 unsigned long long *__restrict__ scratch, unsigned long long *__restrict__ bump) {
+                 unsigned long long *__restrict__ scratch) {
     __shared__ unsigned long long skeys[kSortLds];
-    __shared__ unsigned long long sbase;
+    __shared__ int hist[256];
+    __shared__ int wcnt[4][256];
+    __shared__ int wave_tot[4];
     const size_t t = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int2 rg = ranges[t];
     const int n = rg.y - rg.x;
     if (n <= 0) return;
-    unsigned long long *seg = keys + rg.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    unsigned long long *a = keys + rg.x;
     if (n == 1) {
-        if (threadIdx.x == 0) point_list[rg.x] = (uint32_t)seg[0];
+        if (tid == 0) point_list[rg.x] = (uint32_t)a[0];
         return;
     }
-    int N = 2;
-    while (N < n) N <<= 1;
-    if (N <= kSortLds) {
-        for (int k = threadIdx.x; k < N; k += 256) skeys[k] = k < n ? seg[k] : ~0ull;
+    if (n <= kSortLds) {
+        int N = 2;
+        while (N < n) N <<= 1;
+        for (int k = tid; k < N; k += 256) skeys[k] = k < n ? a[k] : ~0ull;
         __syncthreads();
         bitonic_sort(skeys, N);
-        for (int k = threadIdx.x; k < n; k += 256) point_list[rg.x + k] = (uint32_t)skeys[k];
-    } else {
-        if (threadIdx.x == 0) sbase = atomicAdd(bump, (unsigned long long)N);
-        __syncthreads();
-        unsigned long long *g = scratch + sbase;
-        for (int k = threadIdx.x; k < N; k += 256) g[k] = k < n ? seg[k] : ~0ull;
-        __syncthreads();
-        bitonic_sort(g, N);
-        for (int k = threadIdx.x; k < n; k += 256) point_list[rg.x + k] = (uint32_t)g[k];
+        for (int k = tid; k < n; k += 256) point_list[rg.x + k] = (uint32_t)skeys[k];
+        return;
     }
+    unsigned long long *b = scratch + rg.x;
+    for (int shift = 0; shift < 64; shift += 8) {
+        hist[tid] = 0;
+        wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) atomicAdd(&hist[(int)((a[i] >> shift) & 255ull)], 1);
+        __syncthreads();
+        const int mine = hist[tid];
+        if (__syncthreads_or(mine == n)) continue;  // constant digit: nothing moves
+        // exclusive scan of the 256 bins -> hist[] becomes the running base of every digit
+        int x = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+        hist[tid] = woff + x - mine;
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int i = c0 + tid;
+            const bool valid = i < n;
+            const unsigned long long key = valid ? a[i] : 0ull;
+            const int d = (int)((key >> shift) & 255ull);
+            // lanes of this wave holding the same digit
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long bb = __ballot((d >> bit) & 1);
+                m &= ((d >> bit) & 1) ? bb : ~bb;
+            }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int rank = __popcll(m & lt);
+            if (valid && rank == 0) wcnt[wid][d] = __popcll(m);
+            __syncthreads();
+            if (valid) {
+                int off = hist[d] + rank;
+                for (int w = 0; w < wid; ++w) off += wcnt[w][d];
+                b[off] = key;
+            }
+            __syncthreads();
+            hist[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+            wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+            __syncthreads();
+        }
+        unsigned long long *tmp = a; a = b; b = tmp;
+    }
+    for (int k = tid; k < n; k += 256) point_list[rg.x + k] = (uint32_t)a[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -557,13 +608,12 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     unsigned long long *keys = (unsigned long long *)get(VS_BUF_KEYS, (size_t)R * 8);
     uint32_t *point_list = (uint32_t *)get(VS_BUF_POINT_LIST, (size_t)R * 4);
     unsigned long long *scratch = nullptr;
-    if (max_tile > kSortLds) scratch = (unsigned long long *)get(VS_BUF_SORT_SCRATCH, (size_t)R * 2 * 8);
+    if (max_tile > kSortLds) scratch = (unsigned long long *)get(VS_BUF_SORT_SCRATCH, (size_t)R * 8);
     VS_CHECK(keys && point_list && (max_tile <= kSortLds || scratch), "vs_raster_forward: allocator returned null");
     if (R > 0) {
         dim3 grid(vs::cdiv(P, 256), C);
         hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, geom, rect, out->radii, ranges, cursor, keys);
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch,
-                           (unsigned long long *)(misc + 2));
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch);
     }
     const bool count = (in->flags & VS_RASTER_COUNT_TOUCHED) && out->n_touched;
     dim3 rgrid(tiles, C);
