@@ -1,0 +1,10 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vicasplat_amd import ops
+d = torch.device("cuda:0")
+M, N, K = 4112, 4096, 1024
+a = torch.randn(M, K, device=d).half(); w = (torch.randn(N, K, device=d) / K ** 0.5).half(); b = torch.randn(N, device=d)
+o = torch.empty(M, N, device=d, dtype=torch.float16)
+for _ in range(5): ops.gemm(a, w, b, o, ops.EPI_STORE16)
+torch.cuda.synchronize()

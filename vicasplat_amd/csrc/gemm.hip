@@ -8,8 +8,9 @@
 // residual stream stays f32 (the epilogue adds into it), which is the TF32-class precision the reference runs at.
 //
 // Tiling (CDNA4-shaped, not a warp-shaped CUDA tile): 128x128x64 block tile, 256 threads = 4 waves as 2x2, each
-// wave owns 64x64 = 4x4 MFMA 16x16 fragments (64 accumulator VGPRs), operands staged global -> VGPR -> LDS with
-// 144-byte padded rows (conflict-free ds_read_b128 fragment reads), double-buffered, one barrier pair per K tile.
+// wave owns 64x64 = 4x4 MFMA 16x16 fragments (64 accumulator VGPRs).  Operands go HBM -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR round trip), XOR-swizzled for conflict-free ds_read_b128 fragment reads; 32 KiB of
+// LDS per workgroup keeps 4 workgroups (16 waves) resident per CU, whose interleaving hides the load latency.
 // blockIdx is remapped so that consecutive tiles of one XCD share A/W panels in that XCD's L2.
 //
 // Epilogues (all fused, nothing round-trips HBM):
@@ -27,8 +28,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDS_ROW = BK + 8;  // halfs; 144 B row stride
+constexpr int BN = 128, BK = 64;  // BM = 32*MI (MI = 16-row fragments per wave in M: 4 -> 128 rows, 8 -> 256 rows)
 
 struct GemmArgs {
     const void *A;
@@ -65,10 +65,15 @@ __device__ __forceinline__ unsigned short to16(float v) {
     }
 }
 
-template <bool BF16, int EPI>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) unsigned short sW[2][BN * LDS_ROW];
+template <bool BF16, int EPI, int MI>
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g) {
+    constexpr int BM = 32 * MI;
+    // One 128x64 A tile + one 128x64 W tile, 16-bit, rows of 128 B, NO padding: the tiles are written by
+    // global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16), so the layout must be lane-linear.  Bank
+    // conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk index with
+    // (row & 7), applied on the GLOBAL source address of every lane and again on the fragment read address.
+    __shared__ __attribute__((aligned(1024))) unsigned short sA[BM * BK];
+    __shared__ __attribute__((aligned(1024))) unsigned short sW[BN * BK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
@@ -85,65 +90,62 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // staging: tile = 128 rows x 64 halfs = 128 x 8 x 16B; thread t loads rows (t>>3) + 32*i, 16B chunk (t&7)
+    // staging: wave w issues MI A pieces + 4 W pieces per K tile; piece p covers tile rows p*8 .. p*8+7;
+    // lane l lands at (row p*8 + (l>>3), chunk slot l&7) and therefore fetches global chunk (l&7) ^ (l>>3).
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
-    const int srow = tid >> 3, schunk = tid & 7;
-    size_t oa[4], ow[4];
+    const int rho = lane >> 3, gchunk = (lane & 7) ^ rho;
+    const unsigned short *pa[MI], *pw[4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ra_ = min(m0 + (wid * MI + i) * 8 + rho, g.M - 1);
+        const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+        pa[i] = A + arow * g.lda + gchunk * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ra_ = min(m0 + srow + 32 * i, g.M - 1);
-        const int rw_ = min(n0 + srow + 32 * i, g.N - 1);
-        const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
-        oa[i] = arow * g.lda + schunk * 8;
-        ow[i] = (size_t)rw_ * g.ldw + schunk * 8;
+        const int rw_ = min(n0 + (wid * 4 + i) * 8 + rho, g.N - 1);
+        pw[i] = W + (size_t)rw_ * g.ldw + gchunk * 8;
     }
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;  // named registers: arrays here end up in scratch
-#define VS_GLOAD(k0)                                                                                                  \
-    ra0 = *reinterpret_cast<const uint4 *>(A + oa[0] + (k0)); rw0 = *reinterpret_cast<const uint4 *>(W + ow[0] + (k0)); \
-    ra1 = *reinterpret_cast<const uint4 *>(A + oa[1] + (k0)); rw1 = *reinterpret_cast<const uint4 *>(W + ow[1] + (k0)); \
-    ra2 = *reinterpret_cast<const uint4 *>(A + oa[2] + (k0)); rw2 = *reinterpret_cast<const uint4 *>(W + ow[2] + (k0)); \
-    ra3 = *reinterpret_cast<const uint4 *>(A + oa[3] + (k0)); rw3 = *reinterpret_cast<const uint4 *>(W + ow[3] + (k0));
-#define VS_LS1(buf, i, va, vw)                                                                   \
-    *reinterpret_cast<uint4 *>(&sA[buf][(srow + 32 * i) * LDS_ROW + schunk * 8]) = va;           \
-    *reinterpret_cast<uint4 *>(&sW[buf][(srow + 32 * i) * LDS_ROW + schunk * 8]) = vw;
-#define VS_LSTORE(buf) VS_LS1(buf, 0, ra0, rw0) VS_LS1(buf, 1, ra1, rw1) VS_LS1(buf, 2, ra2, rw2) VS_LS1(buf, 3, ra3, rw3)
+    typedef const void __attribute__((address_space(1))) *gptr_t;
+    typedef void __attribute__((address_space(3))) *lptr_t;
 
-    f4 acc[4][4];
+    f4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int frow = lane & 15, fg = lane >> 4;
     const int nk = g.K / BK;
-    VS_GLOAD(0)
-    VS_LSTORE(0)
-    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) { VS_GLOAD((kt + 1) * BK) }
+        const int k0 = kt * BK;
 #pragma unroll
-        for (int ks = 0; ks < BK; ks += 32) {
-            uint4 fa[4], fb[4];
+        for (int i = 0; i < MI; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(pa[i] + k0), (lptr_t)(sA + (wid * MI + i) * 512), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const uint4 *>(&sA[buf][(wr * 64 + i * 16 + frow) * LDS_ROW + ks + fk]);
-                fb[i] = *reinterpret_cast<const uint4 *>(&sW[buf][(wc * 64 + i * 16 + frow) * LDS_ROW + ks + fk]);
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(pw[i] + k0), (lptr_t)(sW + (wid * 4 + i) * 512), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb_ = wc * 64 + j * 16 + frow;
+                fb[j] = *reinterpret_cast<const uint4 *>(&sW[rb_ * BK + (((ks * 4 + fg) ^ (rb_ & 7)) << 3)]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i) {
+                const int ra_ = wr * (16 * MI) + i * 16 + frow;
+                const uint4 fa = *reinterpret_cast<const uint4 *>(&sA[ra_ * BK + (((ks * 4 + fg) ^ (ra_ & 7)) << 3)]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);
+            }
         }
-        if (kt + 1 < nk) {
-            VS_LSTORE(buf ^ 1)
-            __syncthreads();
-        }
+        __syncthreads();
     }
-#undef VS_GLOAD
-#undef VS_LSTORE
-#undef VS_LS1
 
     // epilogue: fragment (i,j): rows m0 + wr*64 + i*16 + (lane>>4)*4 + r, col n0 + wc*64 + j*16 + (lane&15)
     const int ccol = lane & 15, crow = (lane >> 4) * 4;
@@ -153,10 +155,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         if (n >= g.N) continue;
         const float bv = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + i * 16 + crow + r;
+                const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
                 if (m >= g.M) continue;
                 const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
                 float v = acc[i][j][r] + bv;
@@ -177,18 +179,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     }
 }
 
-template <bool BF16>
-int launch(const GemmArgs &g, int epi, hipStream_t stream) {
-    const int nwg = vs::cdiv(g.M, BM) * vs::cdiv(g.N, BN);
+template <bool BF16, int MI>
+int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
+    const int nwg = vs::cdiv(g.M, 32 * MI) * vs::cdiv(g.N, BN);
     dim3 grid(nwg), block(256);
     switch (epi) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<BF16, 0>), grid, block, 0, stream, g); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<BF16, 1>), grid, block, 0, stream, g); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<BF16, 2>), grid, block, 0, stream, g); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<BF16, 3>), grid, block, 0, stream, g); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<BF16, 0, MI>), grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<BF16, 1, MI>), grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<BF16, 2, MI>), grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<BF16, 3, MI>), grid, block, 0, stream, g); break;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
+}
+
+template <bool BF16>
+int launch(const GemmArgs &g, int epi, hipStream_t stream) {
+    // 256x128 tiles halve the W-panel traffic per flop (the 128x128 kernel is L2->LDS bandwidth bound on MI355X) but
+    // need enough tiles to fill 256 CUs x 2 resident workgroups; otherwise fall back to 128x128.
+    const long long big_tiles = (long long)vs::cdiv(g.M, 256) * vs::cdiv(g.N, BN);
+    if (big_tiles >= 256) return launch_mi<BF16, 8>(g, epi, stream);
+    return launch_mi<BF16, 4>(g, epi, stream);
 }
 
 }  // namespace
