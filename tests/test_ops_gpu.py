@@ -258,3 +258,47 @@ def test_gaussian_adapter_fused(dt, layout):
                  ("scales", ref.scales), ("rotations", ref.rotations), ("raw", raw)):
         assert o[k].shape == r.shape, k
         assert (o[k] - r).abs().max() <= 2e-5 * max(1.0, float(r.abs().max())), k
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 37, 21, 128, 256), (3, 64, 64, 256, 256), (1, 8, 8, 768, 256), (1, 256, 256, 128, 128)])
+def test_conv3x3_nhwc_implicit_gemm(dt, N, H, W, Cin, Cout):
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(N * H + Cin)
+    x = torch.randn(N, Cin, H, W, device=d).to(dt)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1).to(d)
+    res = torch.randn(N, Cout, H, W, device=d).to(dt)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = ops.pack_conv3x3_weight(conv.weight, dt)
+    rtol = 3e-3 if dt == torch.float16 else 2e-2
+    with torch.no_grad():
+        ref = F.conv2d(x.float(), conv.weight.to(dt).float(), conv.bias, padding=1)
+        out = ops.conv3x3_nhwc(xn, wp, conv.bias).permute(0, 3, 1, 2).float()
+        assert (out - ref).abs().max() <= rtol * ref.abs().max()
+        # fused pre-activation + residual + output ReLU (ResidualConvUnit pattern)
+        ref2 = F.relu(F.conv2d(F.relu(x.float()), conv.weight.to(dt).float(), conv.bias, padding=1) + res.float())
+        out2 = ops.conv3x3_nhwc(xn, wp, conv.bias, residual=res.permute(0, 2, 3, 1).contiguous(), relu_in=True, relu_out=True)
+        assert (out2.permute(0, 3, 1, 2).float() - ref2).abs().max() <= rtol * ref2.abs().max()
+        out3 = ops.conv3x3_nhwc(xn, wp, None)
+        assert (out3.permute(0, 3, 1, 2).float() - (ref - conv.bias[None, :, None, None])).abs().max() <= rtol * ref.abs().max()
+        if H <= 64:  # stride 2 (act_postprocess[3], dpt_block.py:404-409)
+            ref4 = F.conv2d(x.float(), conv.weight.to(dt).float(), conv.bias, padding=1, stride=2)
+            out4 = ops.conv3x3_nhwc(xn, wp, conv.bias, stride=2).permute(0, 3, 1, 2).float()
+            assert out4.shape == ref4.shape and (out4 - ref4).abs().max() <= rtol * ref4.abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_upsample2x_nhwc(dt):
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(2)
+    for (N, H, W, C) in [(2, 8, 8, 256), (1, 5, 7, 16), (1, 128, 128, 256)]:
+        x = torch.randn(N, C, H, W, device=d).to(dt)
+        add = torch.randn(N, C, 2 * H, 2 * W, device=d).to(dt)
+        ref = F.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=True)
+        out = ops.upsample2x_nhwc(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2).float()
+        tol = 2e-3 if dt == torch.float16 else 1.6e-2
+        assert (out - ref).abs().max() <= tol * ref.abs().max()
+        out = ops.upsample2x_nhwc(x.permute(0, 2, 3, 1).contiguous(), add.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2).float()
+        assert (out - (ref + add.float())).abs().max() <= tol * (ref + add.float()).abs().max()

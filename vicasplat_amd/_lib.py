@@ -91,6 +91,10 @@ def lib() -> C.CDLL:
             L.vs_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp]
             L.vs_gaussian_adapter.restype = C.c_int
             L.vs_gaussian_adapter.argtypes = [vp, i64, i64, vp, i64, i64, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.vs_conv3x3_nhwc.restype = C.c_int
+            L.vs_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_upsample2x_nhwc.restype = C.c_int
+            L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
             if hasattr(L, "vs_raster_backward"):
                 L.vs_raster_backward.restype = C.c_int
                 L.vs_raster_backward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), C.POINTER(VsRasterGrads),

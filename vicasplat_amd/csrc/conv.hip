@@ -1,0 +1,271 @@
+// DPT-head convolutions for gfx950: 3x3 (stride 1, pad 1) implicit-GEMM on MFMA + bilinear x2 upsampling.
+// the two DPT heads are 42 % of the forward FLOPs and one layer (conv3 256->256 @256^2,
+// heads/dpt_block.py:338) is 18 % of a frame.  Replaces nn.Conv2d(k=3,p=1) / ResidualConvUnit / F.interpolate(scale 2,
+// bilinear, align_corners=True) of heads/dpt_block.py:79-218,316-343 on NHWC 16-bit activations.
+//
+// conv3x3 as GEMM:  M = N*H*W output pixels, N = Cout, K = 9*Cin ordered (tap, cin); A[m, (t,c)] = in[n, y+dy, x+dx, c].
+// With NHWC activations the 64-channel slice of one tap is 128 contiguous bytes of the shifted pixel, i.e. exactly one
+// A-tile row of the GEMM kernel (gemm.hip): the same global_load_lds_dwordx4 + XOR-swizzle staging applies, only the
+// per-row source pointer changes with the tap, and out-of-image taps read a 128-byte zero page.  No im2col buffer ever
+// exists.  Fused: ReLU on the input (ResidualConvUnit applies the activation BEFORE each conv), bias, residual add,
+// ReLU on the output.
+#include "common.h"
+
+__device__ __attribute__((aligned(128))) unsigned short vs_zero_page[64] = {0};
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int BN = 128, BK = 64;
+
+struct ConvArgs {
+    const unsigned short *in;   // [N,H,W,Cin]
+    const unsigned short *w;    // [Cout, 3, 3, Cin]
+    const float *bias;          // [Cout] or null
+    const unsigned short *res;  // [N,H,W,Cout] or null
+    unsigned short *out;        // [N,H,W,Cout]
+    int Nimg, H, W, Cin, Cout;  // H, W: OUTPUT size
+    int relu_in, relu_out;
+    int Hin, Win, stride;
+};
+
+template <bool BF16>
+__device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
+}
+
+template <bool BF16>
+__device__ __forceinline__ unsigned short to16(float v) {
+    if constexpr (BF16) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    } else {
+        _Float16 h = (_Float16)v;
+        return *reinterpret_cast<unsigned short *>(&h);
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ float from16(unsigned short h) {
+    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
+    else return (float)*reinterpret_cast<_Float16 *>(&h);
+}
+
+// max(x, 0) on two packed 16-bit floats (f16 or bf16): clear every half whose sign bit is set
+__device__ __forceinline__ unsigned relu2(unsigned x) {
+    const unsigned m = ((x >> 15) & 0x00010001u) * 0xFFFFu;
+    return x & ~m;
+}
+
+template <bool BF16, int MI>
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
+    constexpr int BM = 32 * MI;
+    __shared__ __attribute__((aligned(1024))) unsigned short sA[BM * BK];
+    __shared__ __attribute__((aligned(1024))) unsigned short sW[BN * BK];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int HW = g.H * g.W;
+    const int M = g.Nimg * HW;
+    const int K = 9 * g.Cin;
+    const int tiles_n = (g.Cout + BN - 1) / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // n-fastest tile order: the (few) Cout tiles of one pixel tile run back to back and share the A panel in L2
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int rho = lane >> 3, gchunk = (lane & 7) ^ rho;
+    // per staged A row: linear pixel index and packed (y, x); rows beyond M are marked invalid (y = 0x7fff)
+    int pix[MI];
+    unsigned yx[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + (wid * MI + i) * 8 + rho;
+        const int p = m < M ? m : 0;
+        const int nimg = p / HW, rem = p - nimg * HW;
+        const int y = (rem / g.W) * g.stride, x = (rem % g.W) * g.stride;  // centre tap in INPUT coordinates
+        pix[i] = (nimg * g.Hin + y) * g.Win + x;
+        yx[i] = m < M ? ((unsigned)y << 16) | (unsigned)x : 0x7fff0000u;
+    }
+    const unsigned short *pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rw_ = min(n0 + (wid * 4 + i) * 8 + rho, g.Cout - 1);
+        pw[i] = g.w + (size_t)rw_ * K + gchunk * 8;
+    }
+    typedef const void __attribute__((address_space(1))) *gptr_t;
+    typedef void __attribute__((address_space(3))) *lptr_t;
+
+    f4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4;
+    const int kt_per_tap = g.Cin / BK;
+    const int nk = K / BK;
+    int tap = 0, kc = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int shift = dy * g.Win + dx;
+        const int cin0 = kc * BK;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int y = (int)(yx[i] >> 16) + dy, x = (int)(yx[i] & 0xffffu) + dx;
+            const bool ok = (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win;
+            const unsigned short *src = ok ? g.in + ((size_t)(pix[i] + shift) * g.Cin + cin0 + gchunk * 8) : vs_zero_page + gchunk * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wid * MI + i) * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(pw[i] + (size_t)kt * BK), (lptr_t)(sW + (wid * 4 + i) * 512), 16, 0, 0);
+        if (++kc == kt_per_tap) { kc = 0; ++tap; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb_ = wc * 64 + j * 16 + frow;
+                fb[j] = *reinterpret_cast<const uint4 *>(&sW[rb_ * BK + (((ks * 4 + fg) ^ (rb_ & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ra_ = wr * (16 * MI) + i * 16 + frow;
+                uint4 fa = *reinterpret_cast<const uint4 *>(&sA[ra_ * BK + (((ks * 4 + fg) ^ (ra_ & 7)) << 3)]);
+                if (g.relu_in) { fa.x = relu2(fa.x); fa.y = relu2(fa.y); fa.z = relu2(fa.z); fa.w = relu2(fa.w); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int ccol = lane & 15, crow = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + ccol;
+        if (n >= g.Cout) continue;
+        const float bv = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.res) v += from16<BF16>(g.res[(size_t)m * g.Cout + n]);
+                if (g.relu_out) v = fmaxf(v, 0.0f);
+                g.out[(size_t)m * g.Cout + n] = to16<BF16>(v);
+            }
+        }
+    }
+}
+
+// ---- bilinear x2, align_corners=True, NHWC 16-bit; optional fused "+ add" (gs head: up2(trunk) + image features) ----
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *__restrict__ add, unsigned short *__restrict__ out,
+                  int Nimg, int H, int W, int C) {
+    const int Ho = 2 * H, Wo = 2 * W, c8 = C >> 3;
+    const long long total = (long long)Nimg * Ho * Wo * c8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cc = (int)(idx % c8);
+    long long p = idx / c8;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float sy = Ho > 1 ? (float)yo * (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)xo * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const size_t base = (size_t)n * H * W;
+    const uint4 v00 = *reinterpret_cast<const uint4 *>(in + ((base + (size_t)y0 * W + x0) * C + cc * 8));
+    const uint4 v01 = *reinterpret_cast<const uint4 *>(in + ((base + (size_t)y0 * W + x1) * C + cc * 8));
+    const uint4 v10 = *reinterpret_cast<const uint4 *>(in + ((base + (size_t)y1 * W + x0) * C + cc * 8));
+    const uint4 v11 = *reinterpret_cast<const uint4 *>(in + ((base + (size_t)y1 * W + x1) * C + cc * 8));
+    const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * C + cc * 8;
+    uint4 av = make_uint4(0, 0, 0, 0);
+    if (add) av = *reinterpret_cast<const uint4 *>(add + o);
+    const unsigned a00[4] = {v00.x, v00.y, v00.z, v00.w}, a01[4] = {v01.x, v01.y, v01.z, v01.w};
+    const unsigned a10[4] = {v10.x, v10.y, v10.z, v10.w}, a11[4] = {v11.x, v11.y, v11.z, v11.w};
+    const unsigned aa[4] = {av.x, av.y, av.z, av.w};
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float lo, hi;
+        {
+            const float t = from16<BF16>((unsigned short)(a00[k] & 0xffff)) * (1.f - lx) + from16<BF16>((unsigned short)(a01[k] & 0xffff)) * lx;
+            const float b = from16<BF16>((unsigned short)(a10[k] & 0xffff)) * (1.f - lx) + from16<BF16>((unsigned short)(a11[k] & 0xffff)) * lx;
+            lo = t * (1.f - ly) + b * ly + (add ? from16<BF16>((unsigned short)(aa[k] & 0xffff)) : 0.f);
+        }
+        {
+            const float t = from16<BF16>((unsigned short)(a00[k] >> 16)) * (1.f - lx) + from16<BF16>((unsigned short)(a01[k] >> 16)) * lx;
+            const float b = from16<BF16>((unsigned short)(a10[k] >> 16)) * (1.f - lx) + from16<BF16>((unsigned short)(a11[k] >> 16)) * lx;
+            hi = t * (1.f - ly) + b * ly + (add ? from16<BF16>((unsigned short)(aa[k] >> 16)) : 0.f);
+        }
+        r[k] = (unsigned)to16<BF16>(lo) | ((unsigned)to16<BF16>(hi) << 16);
+    }
+    *reinterpret_cast<uint4 *>(out + o) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+}  // namespace
+
+extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg,
+                               int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,
+                               int32_t dtype, vs_stream_t stream_) {
+    const int H = (Hin - 1) / (stride > 0 ? stride : 1) + 1, W = (Win - 1) / (stride > 0 ? stride : 1) + 1;  // k=3, pad=1
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && w && out, "vs_conv3x3_nhwc: null pointer");
+    VS_CHECK(Nimg >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), "vs_conv3x3_nhwc: bad sizes");
+    VS_CHECK(Cin % BK == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of %d (pad the channels)", Cin, BK);
+    VS_CHECK(Hin < 32767 && Win < 65536 && (long long)Nimg * Hin * Win < 2147483647LL, "vs_conv3x3_nhwc: image too large");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_conv3x3_nhwc: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
+    if (Nimg == 0) return 0;
+    ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
+               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride};
+    const long long M = (long long)Nimg * H * W;
+    const long long big = vs::cdiv64(M, 256) * vs::cdiv(Cout, BN);
+    if (big >= 256) {
+        dim3 grid((unsigned)big);
+        if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<true, 8>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_kernel<false, 8>), grid, dim3(256), 0, stream, g);
+    } else {
+        dim3 grid((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN)));
+        if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<true, 4>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_kernel<false, 4>), grid, dim3(256), 0, stream, g);
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg, int32_t H, int32_t W, int32_t C,
+                                  int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && out, "vs_upsample2x_nhwc: null pointer");
+    VS_CHECK(C % 8 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 8", C);
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_upsample2x_nhwc: dtype must be 1 (f16) or 2 (bf16)");
+    const long long total = (long long)Nimg * 4 * H * W * (C / 8);
+    if (total <= 0) return 0;
+    dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C);
+    else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C);
+    VS_HIP(hipGetLastError());
+    return 0;
+}

@@ -2,15 +2,17 @@
 (gaussian_param_head).  Reference: heads/dpt_block.py:79-218,264-419, heads/dpt_head.py:21-119,
 heads/dpt_gs_head.py:98-206, heads/postprocess.py:10-63.  Parameter names == the reference's state_dict keys.
 
-SURVEY.md 8(f)-1 marks hand-written conv kernels as the NEXT row; this round the convolutions run on MIOpen
-through PyTorch-ROCm in the compute dtype with channels-last activations (host code stays Python); the token
-reshapes, the `exp` depth post-process and the head fusion are done here.  HIP device tensors only.
+SURVEY.md 8(f)-1: the heads are 42 % of the forward FLOPs.  All 3x3 / 1x1 / transposed convolutions and the
+bilinear upsampling run on the hand-written HIP kernels (implicit-GEMM MFMA conv, GEMM, upsample) on NHWC 16-bit
+activations; only the 7x7 RGB stem conv (3 input channels) stays on MIOpen.  HIP device tensors only.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from .... import ops
 
 
 def _up2(x):
@@ -88,8 +90,20 @@ class _DPT(nn.Module):
         return s.refinenet1(p2, maps[0])
 
 
+def _pad_to(n: int, m: int = 64) -> int:
+    return (n + m - 1) // m * m
+
+
 class PixelwiseTaskWithDPT(nn.Module):
-    """`.dpt` holds the parameters (reference naming: <head>.dpt.<...>)."""
+    """`.dpt` holds the parameters (reference naming: <head>.dpt.<...>).  The forward drives the hand-written HIP
+    kernels on NHWC 16-bit activations:
+      * every 3x3 convolution (layer_rn, the 16 ResidualConvUnit convs, head convs, the stride-2 reassemble conv) is the
+        implicit-GEMM MFMA kernel `vs_conv3x3_nhwc` with pre-activation ReLU / bias / residual / ReLU fused;
+      * every 1x1 convolution and both ConvTranspose2d(k == stride) layers are plain GEMMs (`vs_gemm_bias_act`) -- tokens
+        [BT, 256, C] ARE an NHWC 16x16 map, so no reshape copy is needed on the way in;
+      * bilinear x2 (align_corners=True) is `vs_upsample2x_nhwc` (with the image-feature add of the GS head fused).
+    Only the 7x7 stem conv on the RGB image (3 input channels, 2.7 % of the head FLOPs) stays on MIOpen.
+    Channel counts that are not multiples of 64 (96, 192) are zero-padded inside the packed weights."""
 
     def __init__(self, net, num_channels: int, head_type: str):
         super().__init__()
@@ -97,22 +111,117 @@ class PixelwiseTaskWithDPT(nn.Module):
         assert L > 9
         self.dpt = _DPT([net.enc_embed_dim] + [net.dec_embed_dim] * 3, [0, L * 2 // 4, L * 3 // 4, L], num_channels, head_type)
         self.head_type = head_type
+        self.num_channels = num_channels
         self.compute_dtype = torch.float16
+        self._pk: dict = {}
+        self._pk_key = None
 
-    def _run(self, fn):
-        if self.compute_dtype == torch.float32:
-            return fn()
-        with torch.autocast("cuda", dtype=self.compute_dtype):
-            return fn()
+    # ---- packed 16-bit weights (re-made when a parameter changes / moves / the compute dtype changes) ----
+    def _packed(self):
+        d = self.dpt
+        w0 = d.scratch.layer1_rn.weight
+        key = (self.compute_dtype, w0.device, sum(p._version for p in self.parameters()), id(w0))
+        if key == self._pk_key:
+            return self._pk
+        dt = self.compute_dtype
+        P = {}
+
+        def lin(name, conv, n_pad=0, k_pad=0):  # 1x1 conv -> GEMM weight [N(+pad), K(+pad)], f32 bias [N(+pad)]
+            w = conv.weight.detach().flatten(1)
+            N, K = w.shape
+            Np, Kp = max(n_pad, N), max(k_pad, K)
+            wp = torch.zeros(Np, Kp, dtype=dt, device=w.device)
+            wp[:N, :K] = w.to(dt)
+            b = torch.zeros(Np, dtype=torch.float32, device=w.device)
+            if conv.bias is not None:
+                b[:N] = conv.bias.detach().float()
+            P[name + ".w"], P[name + ".b"] = wp, b
+
+        def convT(name, ct, k_pad, co_pad):  # ConvTranspose2d(k == stride) -> GEMM weight [(i, j, co_pad), ci_pad]
+            w = ct.weight.detach()  # [Cin, Cout, k, k]
+            Cin, Cout, k, _ = w.shape
+            wp = torch.zeros(k, k, co_pad, k_pad, dtype=dt, device=w.device)
+            wp[:, :, :Cout, :Cin] = w.permute(2, 3, 1, 0).to(dt)
+            b = torch.zeros(k, k, co_pad, dtype=torch.float32, device=w.device)
+            b[:, :, :Cout] = ct.bias.detach().float()
+            P[name + ".w"], P[name + ".b"] = wp.reshape(k * k * co_pad, k_pad).contiguous(), b.reshape(-1).contiguous()
+
+        def c3(name, conv, cin_pad=0):
+            P[name + ".w"] = ops.pack_conv3x3_weight(conv.weight, dt, cin_pad)
+            P[name + ".b"] = None if conv.bias is None else conv.bias.detach().float().contiguous()
+
+        ap = d.act_postprocess
+        c0, c1 = _pad_to(ap[0][0].out_channels), _pad_to(ap[1][0].out_channels)   # 96 -> 128, 192 -> 192? (192 % 64 == 0)
+        lin("ap0.0", ap[0][0], n_pad=c0); convT("ap0.1", ap[0][1], k_pad=c0, co_pad=c0)
+        lin("ap1.0", ap[1][0], n_pad=c1); convT("ap1.1", ap[1][1], k_pad=c1, co_pad=c1)
+        lin("ap2.0", ap[2][0])
+        lin("ap3.0", ap[3][0]); c3("ap3.1", ap[3][1])
+        for i, cp in enumerate((c0, c1, 0, 0)):
+            c3(f"rn{i}", d.scratch.layer_rn[i], cp)
+        for r in (1, 2, 3, 4):
+            f = getattr(d.scratch, f"refinenet{r}")
+            for u in ("resConfUnit1", "resConfUnit2"):
+                c3(f"rf{r}.{u}.c1", getattr(f, u).conv1); c3(f"rf{r}.{u}.c2", getattr(f, u).conv2)
+            lin(f"rf{r}.out", f.out_conv)
+        if self.head_type == "regression":
+            c3("h0", d.head[0]); c3("h2", d.head[2]); lin("h4", d.head[4])
+        else:
+            c3("h0", d.head[0]); lin("h4", d.head[4])
+        self._pk, self._pk_key = P, key
+        return P
+
+    @staticmethod
+    def _gemm1x1(x, P, name, n_out=None):
+        """x [..., K] NHWC 16-bit -> [..., N] via the GEMM kernel (1x1 convolution)."""
+        w, b = P[name + ".w"], P[name + ".b"]
+        lead = x.shape[:-1]
+        a = x.reshape(-1, x.shape[-1])
+        out = torch.empty(a.shape[0], w.shape[0], dtype=x.dtype, device=x.device)
+        ops.gemm(a, w, b, out, ops.EPI_STORE16)
+        return out.view(*lead, w.shape[0])
+
+    @staticmethod
+    def _rcu(x, P, name):
+        """ResidualConvUnit (dpt_block.py:79-142): x + conv2(relu(conv1(relu(x))))."""
+        t = ops.conv3x3_nhwc(x, P[name + ".c1.w"], P[name + ".c1.b"], relu_in=True, relu_out=True)
+        return ops.conv3x3_nhwc(t, P[name + ".c2.w"], P[name + ".c2.b"], residual=x)
+
+    def _fusion(self, P, r, x, skip=None):
+        if skip is not None:
+            x = x + self._rcu(skip, P, f"rf{r}.resConfUnit1")
+        x = ops.upsample2x_nhwc(self._rcu(x, P, f"rf{r}.resConfUnit2"))
+        return self._gemm1x1(x, P, f"rf{r}.out")
+
+    def _trunk(self, tokens, gh: int, gw: int):
+        """tokens[hook] [BT, gh*gw, C] 16-bit -> path_1 [BT, 8gh, 8gw, 256] (dpt_head.py:35-62)."""
+        P = self._packed()
+        d = self.dpt
+        dt = self.compute_dtype
+        t = [tokens[h] for h in d.hooks]
+        BT = t[0].shape[0]
+        maps = [x.reshape(BT, gh, gw, x.shape[-1]).to(dt).contiguous() for x in t]
+        # reassemble: 1x1 (+ ConvT k=s as a GEMM followed by a depth-to-space copy)
+        def convT(x, name, k):
+            y = self._gemm1x1(x, P, name)                         # [BT, gh, gw, k*k*Cp]
+            Cp = y.shape[-1] // (k * k)
+            return y.view(BT, gh, gw, k, k, Cp).permute(0, 1, 3, 2, 4, 5).reshape(BT, gh * k, gw * k, Cp)
+        l0 = convT(self._gemm1x1(maps[0], P, "ap0.0"), "ap0.1", 4)
+        l1 = convT(self._gemm1x1(maps[1], P, "ap1.0"), "ap1.1", 2)
+        l2 = self._gemm1x1(maps[2], P, "ap2.0")
+        l3 = ops.conv3x3_nhwc(self._gemm1x1(maps[3], P, "ap3.0"), P["ap3.1.w"], P["ap3.1.b"], stride=2)
+        l0, l1, l2, l3 = [ops.conv3x3_nhwc(l.contiguous(), P[f"rn{i}.w"], None) for i, l in enumerate((l0, l1, l2, l3))]
+        p4 = self._fusion(P, 4, l3)[:, :l2.shape[1], :l2.shape[2]].contiguous()
+        p3 = self._fusion(P, 3, p4, l2)
+        p2 = self._fusion(P, 2, p3, l1)
+        return self._fusion(P, 1, p2, l0), P
 
     def forward_pts3d_raw(self, tokens, gh: int, gw: int) -> torch.Tensor:
-        """-> [BT,3,H,W] head output in the compute dtype, channels-last, BEFORE the 'exp' post-process."""
-        def fn():
-            d = self.dpt
-            x = d.head[0](d.trunk(tokens, gh, gw))
-            x = d.head[2](_up2(x))
-            return d.head[4](F.relu(x))
-        return self._run(fn)[:, :3].contiguous(memory_format=torch.channels_last)
+        """-> [BT,3,H,W] view (channels-last memory) of the head output in the compute dtype, BEFORE the 'exp' post-process."""
+        x, P = self._trunk(tokens, gh, gw)
+        x = ops.conv3x3_nhwc(x, P["h0.w"], P["h0.b"])
+        x = ops.conv3x3_nhwc(ops.upsample2x_nhwc(x), P["h2.w"], P["h2.b"], relu_out=True)
+        y = self._gemm1x1(x, P, "h4")[..., :3]
+        return y.contiguous().permute(0, 3, 1, 2)
 
     def forward_pts3d(self, tokens, gh: int, gw: int) -> torch.Tensor:
         """-> [BT,H,W,3] f32 points; 'exp' depth mode (postprocess.py:46-56).  (distillation path only; the main
@@ -122,9 +231,14 @@ class PixelwiseTaskWithDPT(nn.Module):
         return xyz / dist.clip(min=1e-8) * torch.expm1(dist)
 
     def forward_gs(self, tokens, frames: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
-        """-> [BT,C,H,W] raw Gaussian parameters in the compute dtype, channels-last (dpt_gs_head.py:120-157)."""
-        def fn():
-            d = self.dpt
-            x = _up2(d.trunk(tokens, gh, gw)) + d.input_merger(frames.contiguous(memory_format=torch.channels_last))
-            return d.head[4](F.relu(d.head[0](x)))  # Dropout(0.1) is the identity at inference
-        return self._run(fn).contiguous(memory_format=torch.channels_last)
+        """-> [BT,C,H,W] view (channels-last memory) of the raw Gaussian parameters (dpt_gs_head.py:120-157)."""
+        x, P = self._trunk(tokens, gh, gw)
+        d = self.dpt
+        dt = self.compute_dtype
+        with torch.autocast("cuda", dtype=dt):  # 7x7 stem on the RGB image: MIOpen
+            img = d.input_merger(frames.contiguous(memory_format=torch.channels_last))
+        img = img.to(dt).permute(0, 2, 3, 1).contiguous()
+        x = ops.upsample2x_nhwc(x, add=img)
+        x = ops.conv3x3_nhwc(x, P["h0.w"], None, relu_out=True)  # Dropout(0.1) is the identity at inference
+        y = self._gemm1x1(x, P, "h4")
+        return y.permute(0, 3, 1, 2)

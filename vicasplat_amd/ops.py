@@ -119,3 +119,43 @@ def gaussian_adapter(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torch.Tensor,
                                          L.stream_ptr(dev))
     L.check(rc, "vs_gaussian_adapter")
     return out
+
+
+def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 relu_in: bool = False, relu_out: bool = False, out: Optional[torch.Tensor] = None, stride: int = 1) -> torch.Tensor:
+    """x [N,H,W,Cin] contiguous 16-bit, w [Cout,3,3,Cin] (see pack_conv3x3_weight) -> [N,Ho,Wo,Cout] (k=3, pad=1)."""
+    dev = L.require_device(x, w, bias, residual, out)
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dtype in (torch.float16, torch.bfloat16)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape == (Cout, 3, 3, Cin)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=dev)
+    assert residual is None or (residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(residual), L.ptr(out), N, H, W, Cin, Cout, stride,
+                                     int(relu_in), int(relu_out), _DT[x.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_conv3x3_nhwc")
+    return out
+
+
+def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: int = 0) -> torch.Tensor:
+    """nn.Conv2d weight [Cout,Cin,3,3] -> [Cout,3,3,Cin(+pad)] in the operand dtype (tap-major, channel-minor)."""
+    wp = w.detach().permute(0, 2, 3, 1)
+    if cin_pad > w.shape[1]:
+        wp = torch.nn.functional.pad(wp, (0, cin_pad - w.shape[1]))
+    return wp.to(dtype).contiguous()
+
+
+def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit; optional fused `+ add` ([N,2H,2W,C])."""
+    dev = L.require_device(x, add)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float16, torch.bfloat16)
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=dev)
+    assert add is None or (add.shape == out.shape and add.is_contiguous() and add.dtype == x.dtype)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, _DT[x.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_upsample2x_nhwc")
+    return out
