@@ -64,7 +64,7 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {
 }
 
 template <bool BF16, int MI>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) conv3x3_kernel(const ConvArgs g) {
     constexpr int BM = 32 * MI;
     __shared__ __attribute__((aligned(1024))) unsigned short sA[BM * BK];
     __shared__ __attribute__((aligned(1024))) unsigned short sW[BN * BK];

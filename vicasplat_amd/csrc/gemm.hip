@@ -66,7 +66,7 @@ __device__ __forceinline__ unsigned short to16(float v) {
 }
 
 template <bool BF16, int EPI, int MI>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) gemm_kernel(const GemmArgs g) {
     constexpr int BM = 32 * MI;
     // One 128x64 A tile + one 128x64 W tile, 16-bit, rows of 128 B, NO padding: the tiles are written by
     // global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16), so the layout must be lane-linear.  Bank
