@@ -154,24 +154,62 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) conv3x3_kernel(const Con
         __syncthreads();
     }
 
+    // epilogue: per-wave 16 x 64 slabs transposed through LDS -> 16-byte row chunks (see gemm.hip)
     const int ccol = lane & 15, crow = (lane >> 4) * 4;
+    float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wc * 64 + j * 16 + ccol;
-        if (n >= g.Cout) continue;
-        const float bv = g.bias ? g.bias[n] : 0.0f;
+        bv[j] = (g.bias && n < g.Cout) ? g.bias[n] : 0.0f;
+    }
+    const int nbase = n0 + wc * 64;
+    constexpr int PR = 64 + 8;
+    unsigned short *patch = sA + wid * (16 * PR);
+    const bool vec_ok = (g.Cout % 8 == 0) && (nbase + 64 <= g.Cout) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
+                        (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MI; ++i) {
+        if (!g.res) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (g.res) v += from16<BF16>(g.res[(size_t)m * g.Cout + n]);
-                if (g.relu_out) v = fmaxf(v, 0.0f);
-                g.out[(size_t)m * g.Cout + n] = to16<BF16>(v);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if (g.relu_out) v = fmaxf(v, 0.0f);
+                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
+                }
+        } else {  // keep f32 until the residual is added: stage as two 16-bit halves is lossy -> add residual here
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
+                    const int n = nbase + j * 16 + ccol;
+                    float v = acc[i][j][r] + bv[j];
+                    if (m < M && n < g.Cout) v += from16<BF16>(g.res[(size_t)m * g.Cout + n]);
+                    if (g.relu_out) v = fmaxf(v, 0.0f);
+                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
+            const int m = m0 + wr * (16 * MI) + i * 16 + prow;
+            if (m < M) {
+                unsigned short *dst = g.out + (size_t)m * g.Cout + nbase + pch * 8;
+                const uint4 val = *reinterpret_cast<const uint4 *>(&patch[prow * PR + pch * 8]);
+                if (vec_ok) {
+                    *reinterpret_cast<uint4 *>(dst) = val;
+                } else {
+                    const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (nbase + pch * 8 + e < g.Cout) dst[e] = hv[e];
+                }
             }
         }
+        __syncthreads();
     }
 }
 

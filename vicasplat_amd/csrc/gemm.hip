@@ -147,34 +147,101 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) gemm_kernel(const GemmAr
         __syncthreads();
     }
 
-    // epilogue: fragment (i,j): rows m0 + wr*64 + i*16 + (lane>>4)*4 + r, col n0 + wc*64 + j*16 + (lane&15)
+    // ---- epilogue.  A lane's accumulators are 4 rows x 1 column per fragment: storing them directly means 2-byte
+    // (or 4-byte) scattered stores.  Instead every wave transposes one 16 x 64 slab at a time through a private LDS
+    // patch (the operand tiles are dead after the last barrier) and writes / updates full 16-byte row chunks. ----
     const int ccol = lane & 15, crow = (lane >> 4) * 4;
+    float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wc * 64 + j * 16 + ccol;
-        if (n >= g.N) continue;
-        const float bv = g.bias ? g.bias[n] : 0.0f;
+        bv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
+    }
+    const int nbase = n0 + wc * 64;
+    if constexpr (EPI == 0 || EPI == 1) {
+        constexpr int PR = 64 + 8;  // halfs per patch row (144 B: 16-byte aligned, conflict-light)
+        unsigned short *patch = sA + wid * (16 * PR);
+        const bool vec_ok = (g.ldo % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
+                }
+            __syncthreads();
+            // 16 rows x 8 chunks of 8 halfs = 128 chunks, 2 per lane
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
+                const int m = m0 + wr * (16 * MI) + i * 16 + prow;
+                if (m < g.M) {
+                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+                    unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + pch * 8;
+                    const uint4 val = *reinterpret_cast<const uint4 *>(&patch[prow * PR + pch * 8]);
+                    if (vec_ok) {
+                        *reinterpret_cast<uint4 *>(dst) = val;
+                    } else {
+                        const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (nbase + pch * 8 + e < g.N) dst[e] = hv[e];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        constexpr int PR = 64 + 4;  // floats per patch row (272 B)
+        float *patch = reinterpret_cast<float *>(sA) + wid * (16 * PR);
+        const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
-                if (m >= g.M) continue;
-                const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                float v = acc[i][j][r] + bv;
-                if constexpr (EPI == 0) {
-                    reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
-                } else if constexpr (EPI == 1) {
-                    v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
-                } else if constexpr (EPI == 2) {
-                    float *o = reinterpret_cast<float *>(g.out) + orow * g.ldo + n;
-                    const float gt = g.gate ? g.gate[(size_t)(m / g.gate_rows) * g.gate_ld + n] : 0.0f;
-                    *o = *o + (1.0f + gt) * v;
-                } else {
-                    reinterpret_cast<float *>(g.out)[orow * g.ldo + n] = v;
+                const float *gp = nullptr;
+                if (EPI == 2 && g.gate && m < g.M) gp = g.gate + (size_t)(m / g.gate_rows) * g.gate_ld;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nbase + j * 16 + ccol;
+                    float v = acc[i][j][r] + bv[j];
+                    if (gp && n < g.N) v *= 1.0f + gp[n];
+                    patch[(crow + r) * PR + j * 16 + ccol] = v;
                 }
             }
+            __syncthreads();
+            // 16 rows x 16 chunks of 4 floats = 256 chunks, 4 per lane
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = lane + 64 * c, prow = q >> 4, pch = q & 15;
+                const int m = m0 + wr * (16 * MI) + i * 16 + prow;
+                if (m < g.M) {
+                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+                    float *dst = reinterpret_cast<float *>(g.out) + orow * g.ldo + nbase + pch * 4;
+                    const float4 val = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 4]);
+                    if (vec_ok) {
+                        if constexpr (EPI == 2) {
+                            float4 o = *reinterpret_cast<float4 *>(dst);
+                            o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
+                            *reinterpret_cast<float4 *>(dst) = o;
+                        } else {
+                            *reinterpret_cast<float4 *>(dst) = val;
+                        }
+                    } else {
+                        const float *fv = reinterpret_cast<const float *>(&val);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nbase + pch * 4 + e < g.N) {
+                                if constexpr (EPI == 2) dst[e] += fv[e]; else dst[e] = fv[e];
+                            }
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
