@@ -53,6 +53,7 @@ def _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, pr
     alloc = L.TorchAllocator(dev)
     with torch.cuda.device(dev):
         R = lib.vs_raster_forward(C.byref(inp), C.byref(out), alloc.fn, None, L.stream_ptr(dev))
+    alloc.fn = None  # break the allocator <-> ctypes-callback reference cycle so the buffers die with their last user
     L.check(R, "vs_raster_forward")
     if n_touched is None:
         n_touched = torch.zeros((Cn, P), dtype=torch.int32, device=dev)
@@ -127,6 +128,7 @@ class _Rasterize(torch.autograd.Function):
         alloc = L.TorchAllocator(dev)
         with torch.cuda.device(dev):
             rc = lib.vs_raster_backward(C.byref(ctx.inp), C.byref(ctx.out), C.byref(g), alloc.fn, None, L.stream_ptr(dev))
+        alloc.fn = None
         L.check(rc, "vs_raster_backward")
         if cov33:  # spread the 6 unique partials back onto the symmetric 3x3 layout the caller differentiates
             d33 = torch.empty((S, P, 3, 3), dtype=torch.float32, device=dev)
