@@ -372,12 +372,15 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, int N) {
     }
 }
 
+constexpr int kDigitBits = 11;
+constexpr int kBins = 1 << kDigitBits;
+
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict__ keys, uint32_t *__restrict__ point_list,
                  unsigned long long *__restrict__ scratch) {
     __shared__ unsigned long long skeys[kSortLds];
-    __shared__ int hist[256];
-    __shared__ int wcnt[4][256];
+    __shared__ int hist[kBins];
+    __shared__ int wcnt[4][kBins];
     __shared__ int wave_tot[4];
     const size_t t = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int2 rg = ranges[t];
@@ -398,17 +401,23 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
         for (int k = tid; k < n; k += 256) point_list[rg.x + k] = (uint32_t)skeys[k];
         return;
     }
+    // ---- stable LSD radix sort on the DEPTH half of the key (bits 32..63) in three 11/11/10-bit passes ----
     unsigned long long *b = scratch + rg.x;
-    for (int shift = 0; shift < 64; shift += 8) {
-        hist[tid] = 0;
-        wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+    for (int k = tid; k < 4 * kBins; k += 256) (&wcnt[0][0])[k] = 0;
+    for (int shift = 32; shift < 64; shift += kDigitBits) {
+        for (int k = tid; k < kBins; k += 256) hist[k] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) atomicAdd(&hist[(int)((a[i] >> shift) & 255ull)], 1);
+        for (int i = tid; i < n; i += 256) atomicAdd(&hist[(int)((a[i] >> shift) & (kBins - 1))], 1);
         __syncthreads();
-        const int mine = hist[tid];
-        if (__syncthreads_or(mine == n)) continue;  // constant digit: nothing moves
-        // exclusive scan of the 256 bins -> hist[] becomes the running base of every digit
-        int x = mine;
+        bool all_one = false;
+        for (int k = tid; k < kBins; k += 256) all_one |= (hist[k] == n);
+        if (__syncthreads_or(all_one)) continue;  // constant digit: nothing moves
+        // exclusive scan of the bins (8 per thread) -> hist[] becomes the running base of every digit
+        int loc[kBins / 256];
+        int sum = 0;
+#pragma unroll
+        for (int q = 0; q < kBins / 256; ++q) { loc[q] = hist[tid * (kBins / 256) + q]; sum += loc[q]; }
+        int x = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(x, o, 64);
@@ -416,25 +425,27 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
         }
         if (lane == 63) wave_tot[wid] = x;
         __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-        hist[tid] = woff + x - mine;
+        int run = x - sum;
+        for (int w = 0; w < wid; ++w) run += wave_tot[w];
+#pragma unroll
+        for (int q = 0; q < kBins / 256; ++q) { hist[tid * (kBins / 256) + q] = run; run += loc[q]; }
         __syncthreads();
         for (int c0 = 0; c0 < n; c0 += 256) {
             const int i = c0 + tid;
             const bool valid = i < n;
             const unsigned long long key = valid ? a[i] : 0ull;
-            const int d = (int)((key >> shift) & 255ull);
-            // lanes of this wave holding the same digit
+            const int d = (int)((key >> shift) & (kBins - 1));
             unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
+            for (int bit = 0; bit < kDigitBits; ++bit) {
                 const unsigned long long bb = __ballot((d >> bit) & 1);
                 m &= ((d >> bit) & 1) ? bb : ~bb;
             }
             const unsigned long long lt = (1ull << lane) - 1ull;
             const int rank = __popcll(m & lt);
-            if (valid && rank == 0) wcnt[wid][d] = __popcll(m);
+            const int cnt = __popcll(m);
+            const bool leader = valid && rank == 0;
+            if (leader) wcnt[wid][d] = cnt;
             __syncthreads();
             if (valid) {
                 int off = hist[d] + rank;
@@ -442,12 +453,30 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
                 b[off] = key;
             }
             __syncthreads();
-            hist[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-            wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+            if (leader) {
+                atomicAdd(&hist[d], cnt);
+                wcnt[wid][d] = 0;
+            }
             __syncthreads();
         }
         unsigned long long *tmp = a; a = b; b = tmp;
     }
+    // ---- ties: keys with identical depth bits are still in scatter order; order each run by Gaussian index ----
+    for (int i = tid; i < n; i += 256) {
+        const unsigned hi = (unsigned)(a[i] >> 32);
+        const bool start = (i == 0 || (unsigned)(a[i - 1] >> 32) != hi) && (i + 1 < n) && ((unsigned)(a[i + 1] >> 32) == hi);
+        if (start) {
+            int e = i + 1;
+            while (e < n && (unsigned)(a[e] >> 32) == hi) ++e;
+            for (int p = i + 1; p < e; ++p) {  // insertion sort of [i, e)
+                const unsigned long long v = a[p];
+                int q = p - 1;
+                while (q >= i && a[q] > v) { a[q + 1] = a[q]; --q; }
+                a[q + 1] = v;
+            }
+        }
+    }
+    __syncthreads();
     for (int k = tid; k < n; k += 256) point_list[rg.x + k] = (uint32_t)a[k];
 }
 
@@ -501,35 +530,47 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
         __syncthreads();
         const int cnt = min(NT, todo);
         if (!__all(done)) {
-            for (int j = 0; j < cnt; ++j) {
-                const float4 q0 = sq0[j];
-                // wave-uniform footprint test (q0 is a broadcast read: same value in every lane)
-                if (fabsf(q0.x - qcx) > q0.z + 3.5f || fabsf(q0.y - qcy) > q0.w + 3.5f) continue;
-                const float4 q1 = sq1[j];
-                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                bool touched = false;
-                if (!done && power <= 0.0f) {
-                    const float alpha = fminf(0.99f, q1.w * __expf(power));
-                    if (alpha >= 1.0f / 255.0f) {
-                        const float test_T = T * (1.0f - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const float4 q2 = sq2[j];
-                            const float w = alpha * T;
-                            Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
-                            Dd += q2.w * w;
-                            touched = test_T > 0.5f;
-                            T = test_T;
-                            last_contrib = contributor + j + 1;
+            // The 64 lanes test 64 staged entries at once against this wave's quadrant (conservative {alpha >= 1/255}
+            // footprint); only the survivors are walked sequentially, in list order (ascending bit index).
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int je = j0 + lane;
+                bool hit = false;
+                if (je < cnt) {
+                    const float4 t = sq0[je];
+                    hit = fabsf(t.x - qcx) <= t.z + 3.5f && fabsf(t.y - qcy) <= t.w + 3.5f;
+                }
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int j = j0 + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float4 q0 = sq0[j];
+                    const float4 q1 = sq1[j];
+                    const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                    const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+                    bool touched = false;
+                    if (!done && power <= 0.0f) {
+                        const float alpha = fminf(0.99f, q1.w * __expf(power));
+                        if (alpha >= 1.0f / 255.0f) {
+                            const float test_T = T * (1.0f - alpha);
+                            if (test_T < 0.0001f) {
+                                done = true;
+                            } else {
+                                const float4 q2 = sq2[j];
+                                const float w = alpha * T;
+                                Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
+                                Dd += q2.w * w;
+                                touched = test_T > 0.5f;
+                                T = test_T;
+                                last_contrib = contributor + j + 1;
+                            }
                         }
                     }
+                    if (COUNT_TOUCHED) {
+                        const int tot = __popcll(__ballot(touched));
+                        if (lane == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+                    }
                 }
-                if (COUNT_TOUCHED) {
-                    const int tot = __popcll(__ballot(touched));
-                    if (lane == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
-                }
+                if (__all(done)) break;
             }
         }
         contributor += cnt;
