@@ -173,8 +173,15 @@ def main():
         R = [m for n, _, _, m in kt.rec if n == "_forward_impl"][0]["R"]
         gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         # dominant hand-written kernel of the step: the MFMA GEMM (ViT encoder/decoder linears)
+        traffic = {}
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null when the file is absent
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))["kernels"]
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm.items()}
+        except Exception:
+            pass
         roofline = dict(kernel="gemm_kernel<f16> (vs_gemm_bias_act)", bound="mfma", achieved=round(gemm_tf, 1),
-                        peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s", frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4), traffic=None,
+                        peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s", frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4),
+                        traffic=traffic.get("gemm_kernel"),
                         launches=gm["calls"], avg_launch_us=round(gm["ms"] * 1e3 / gm["calls"], 2))
         extra = dict(
             step_breakdown_ms=dict(total=round(tot_ms, 3), gemm=round(gm["ms"], 3), attention=round(at["ms"], 3),
