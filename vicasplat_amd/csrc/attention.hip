@@ -24,7 +24,6 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 64;       // head dim
-constexpr int QB = 64;       // queries per workgroup
 constexpr int KB = 64;       // keys per tile
 constexpr int KROW = HD + 8; // halfs, K tile row stride (144 B)
 constexpr int VROW = KB + 8; // halfs, V^T tile row stride (144 B)
@@ -66,14 +65,16 @@ __device__ __forceinline__ unsigned short to16(float v) {
     return (unsigned short)(pack2<BF16>(v, 0.f) & 0xFFFFu);
 }
 
-template <bool BF16>
+// QG = 16-query MFMA groups per wave (1 -> 64 queries per workgroup, 2 -> 128): more MFMAs per staged K/V tile.
+template <bool BF16, int QG>
 __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
+    constexpr int QBLK = 64 * QG;
     __shared__ __attribute__((aligned(16))) unsigned short sK[KB * KROW];
     __shared__ __attribute__((aligned(16))) unsigned short sVT[HD * VROW];
     __shared__ int s_maxlen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QBLK;
 
     int base0, len0, base1, len1;
     if (a.kv_seg) {
@@ -83,31 +84,40 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
     }
     const int Lk = len0 + len1;
 
-    // ---- this lane's query (column of S^T): q index within the batch item ----
-    const int qi = q0 + wid * 16 + c16;
-    const bool qvalid = qi < a.Lq;
-    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
-    int my_len = Lk;
-    if (a.q_kvlen && qvalid) my_len = min(Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
-    if (!qvalid) my_len = 0;
-    // block-uniform loop bound
+    // ---- this lane's queries (columns of S^T): one per 16-query group ----
+    int my_len[QG];
+    uint4 qf[QG][2];
+    int wave_len = 0;
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int qi = q0 + (wid * QG + u) * 16 + c16;
+        const bool qvalid = qi < a.Lq;
+        const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+        int ml = Lk;
+        if (a.q_kvlen && qvalid) ml = min(Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+        if (!qvalid) ml = 0;
+        my_len[u] = ml;
+        wave_len = max(wave_len, ml);
+        const unsigned short *qp = a.q + qrow * a.ldq + h * HD + g * 8;
+        qf[u][0] = *reinterpret_cast<const uint4 *>(qp);
+        qf[u][1] = *reinterpret_cast<const uint4 *>(qp + 32);
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) wave_len = max(wave_len, __shfl_xor(wave_len, o_, 64));  // wave-uniform
     if (tid == 0) s_maxlen = 0;
     __syncthreads();
-    atomicMax(&s_maxlen, my_len);
+    if (lane == 0) atomicMax(&s_maxlen, wave_len);
     __syncthreads();
     const int maxlen = s_maxlen;
 
-    // Q fragments (B operand of S^T = K Q^T): lane holds q = c16, d = ks*32 + g*8 .. +7
-    uint4 qf[2];
-    {
-        const unsigned short *qp = a.q + qrow * a.ldq + h * HD + g * 8;
-        qf[0] = *reinterpret_cast<const uint4 *>(qp);
-        qf[1] = *reinterpret_cast<const uint4 *>(qp + 32);
-    }
-    f4 o[4];
+    f4 o[QG][4];
+    float m_run[QG], l_run[QG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int u = 0; u < QG; ++u) {
+        m_run[u] = -INFINITY; l_run[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // staging roles
     const int k_key = tid >> 2, k_chunk = (tid & 3) * 16;  // K: one key row, 2 x 16B
@@ -117,88 +127,94 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
         j = min(j, Lk - 1);
         return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
     };
+    uint4 pk0, pk1, pva, pvb;  // register prefetch of the NEXT tile (hides the global latency behind the MFMAs)
+    auto gload = [&](int kt) {
+        const unsigned short *kp = a.k + key_row(kt + k_key) * a.ldk + h * HD + k_chunk;
+        pk0 = *reinterpret_cast<const uint4 *>(kp);
+        pk1 = *reinterpret_cast<const uint4 *>(kp + 8);
+        pva = *reinterpret_cast<const uint4 *>(a.v + key_row(kt + 2 * v_kp) * a.ldv + h * HD + v_c * 8);
+        pvb = *reinterpret_cast<const uint4 *>(a.v + key_row(kt + 2 * v_kp + 1) * a.ldv + h * HD + v_c * 8);
+    };
+    if (maxlen > 0) gload(0);
 
     for (int kt = 0; kt < maxlen; kt += KB) {
-        // ---- stage K tile (row-major) and V tile (transposed) ----
+        // ---- stage K tile (row-major) and V tile (transposed) from the prefetched registers ----
+        __syncthreads();  // previous tile fully consumed
+        *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk]) = pk0;
+        *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk + 8]) = pk1;
         {
-            const unsigned short *kp = a.k + key_row(kt + k_key) * a.ldk + h * HD + k_chunk;
-            const uint4 k0 = *reinterpret_cast<const uint4 *>(kp);
-            const uint4 k1 = *reinterpret_cast<const uint4 *>(kp + 8);
-            const unsigned short *vp0 = a.v + key_row(kt + 2 * v_kp) * a.ldv + h * HD + v_c * 8;
-            const unsigned short *vp1 = a.v + key_row(kt + 2 * v_kp + 1) * a.ldv + h * HD + v_c * 8;
-            const uint4 va = *reinterpret_cast<const uint4 *>(vp0);
-            const uint4 vb = *reinterpret_cast<const uint4 *>(vp1);
-            __syncthreads();  // previous tile fully consumed
-            *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk]) = k0;
-            *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk + 8]) = k1;
-            const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+            const unsigned wa[4] = {pva.x, pva.y, pva.z, pva.w}, wb[4] = {pvb.x, pvb.y, pvb.z, pvb.w};
             unsigned *vt = reinterpret_cast<unsigned *>(sVT);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // d = v_c*8 + 2i   : (key 2kp, key 2kp+1) ; d+1 likewise
                 vt[((v_c * 8 + 2 * i) * VROW) / 2 + v_kp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
                 vt[((v_c * 8 + 2 * i + 1) * VROW) / 2 + v_kp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
             }
-            __syncthreads();
         }
-        // ---- S^T = K Q^T : 4 key blocks x 2 d-steps ----
-        f4 st[4];
+        __syncthreads();
+        if (kt + KB < maxlen) gload(kt + KB);
+        if (kt >= wave_len) continue;  // nothing visible to this wave's queries in this tile (prefix-masked rows)
+        // K fragments are shared by the wave's query groups
+        uint4 kf[4][2];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            st[nb] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kf[nb][ks] = *reinterpret_cast<const uint4 *>(&sK[(nb * 16 + c16) * KROW + ks * 32 + g * 8]);
+        uint4 pf[QG][2];
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            f4 st[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                st[nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) st[nb] = mfma<BF16>(kf[nb][ks], qf[u][ks], st[nb]);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt + nb * 16 + g * 4 + r;
+                    float sv = st[nb][r] * a.scale_log2e;
+                    sv = key < my_len[u] ? sv : -INFINITY;
+                    st[nb][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = exp2f(m_run[u] - m_use);
+            float rs = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(st[nb][r] - m_use);
+                    st[nb][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[u] = l_run[u] * alpha + rs;
+            m_run[u] = m_new;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ar = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[u][db][r] *= ar;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[(nb * 16 + c16) * KROW + ks * 32 + g * 8]);
-                st[nb] = mfma<BF16>(kf, qf[ks], st[nb]);
+                pf[u][ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
+                pf[u][ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
+                pf[u][ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+                pf[u][ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
             }
         }
-        // lane holds, for query c16, keys kt + nb*16 + g*4 + r
-        float mx = -INFINITY;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + nb * 16 + g * 4 + r;
-                float s = st[nb][r] * a.scale_log2e;
-                s = key < my_len ? s : -INFINITY;
-                st[nb][r] = s;
-                mx = fmaxf(mx, s);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
-        float rs = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(st[nb][r] - m_use);
-                st[nb][r] = p;
-                rs += p;
-            }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-        // rescale O: its rows are q = g*4 + r -> fetch that query's alpha from lane (g*4 + r)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ar = __shfl(alpha, g * 4 + r, 64);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) o[db][r] *= ar;
-        }
-        // P fragments (A operand): ks -> key blocks (2ks, 2ks+1); k index g*8 + j <-> key (2ks + j/4)*16 + g*4 + j%4
-        uint4 pf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            pf[ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
-            pf[ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
-            pf[ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-            pf[ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
-        }
-        // O += P V : B operand lane (d = db*16 + c16, g) = V^T[d][(2ks)*16 + g*4 .. +3], V^T[d][(2ks+1)*16 + g*4 .. +3]
+        // O += P V ; V fragments shared by the query groups
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -207,21 +223,25 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
                 const uint2 lo = *reinterpret_cast<const uint2 *>(vr + (2 * ks) * 16);
                 const uint2 hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
                 const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                o[db] = mfma<BF16>(pf[ks], vf, o[db]);
+#pragma unroll
+                for (int u = 0; u < QG; ++u) o[u][db] = mfma<BF16>(pf[u][ks], vf, o[u][db]);
             }
         }
     }
 
     // ---- epilogue: O rows q = g*4 + r, cols d = db*16 + c16 ----
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float lr = __shfl(l_run, g * 4 + r, 64);
-        const int qo = q0 + wid * 16 + g * 4 + r;
-        if (qo >= a.Lq) continue;
-        const float inv = lr > 0.f ? 1.0f / lr : 0.f;
-        unsigned short *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
+    for (int u = 0; u < QG; ++u) {
 #pragma unroll
-        for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[db][r] * inv);
+        for (int r = 0; r < 4; ++r) {
+            const float lr = __shfl(l_run[u], g * 4 + r, 64);
+            const int qo = q0 + (wid * QG + u) * 16 + g * 4 + r;
+            if (qo >= a.Lq) continue;
+            const float inv = lr > 0.f ? 1.0f / lr : 0.f;
+            unsigned short *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[u][db][r] * inv);
+        }
     }
 }
 
@@ -246,9 +266,18 @@ extern "C" int vs_attention(const void *q, const void *k, const void *v, void *o
     a.nbatch = nbatch; a.H = H; a.Lq = Lq; a.Lk = Lk; a.q_batch_rows = q_batch_rows; a.k_batch_rows = k_batch_rows;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.scale_log2e = scale * 1.4426950408889634f;
-    dim3 grid(vs::cdiv(Lq, QB), H, nbatch), block(256);
-    if (dtype == 2) hipLaunchKernelGGL(attention_kernel<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(attention_kernel<false>, grid, block, 0, stream, a);
+    // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; else 64
+    const bool big = (long long)vs::cdiv(Lq, 128) * H * nbatch >= 512;
+    dim3 block(256);
+    if (big) {
+        dim3 grid(vs::cdiv(Lq, 128), H, nbatch);
+        if (dtype == 2) hipLaunchKernelGGL((attention_kernel<true, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((attention_kernel<false, 2>), grid, block, 0, stream, a);
+    } else {
+        dim3 grid(vs::cdiv(Lq, 64), H, nbatch);
+        if (dtype == 2) hipLaunchKernelGGL((attention_kernel<true, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((attention_kernel<false, 1>), grid, block, 0, stream, a);
+    }
     VS_HIP(hipGetLastError());
     return 0;
 }
