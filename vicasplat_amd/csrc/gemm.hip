@@ -28,7 +28,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128, BK = 64;  // BM = 32*MI (MI = 16-row fragments per wave in M: 4 -> 128 rows, 8 -> 256 rows)
+constexpr int BN = 128;  // BM = 32*MI (MI = 16-row fragments per wave in M: 4 -> 128 rows, 8 -> 256 rows)
 
 struct GemmArgs {
     const void *A;
@@ -65,15 +65,30 @@ __device__ __forceinline__ unsigned short to16(float v) {
     }
 }
 
+// XOR swizzle of the 16-byte chunk index (0..3) inside a 64-byte LDS row, keyed on (row >> 2) & 3, chosen so that the
+// four 16-lane service groups of ds_read_b128 each touch 16 distinct 16-byte slots of a 256-byte bank row.
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // f = {0,2,3,1}
+
+// LDS-DMA issued from inline asm: hipcc's waitcnt insertion does not see it, so the counted s_waitcnt vmcnt(N) placed by
+// hand below are the only waits (with the builtin it drains vmcnt(0) before the first ds_read of every step, which
+// serialises the pipeline).  lds_off must be wave-uniform (it goes to M0).
+__device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
+}
+
 template <bool BF16, int EPI, int MI>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) gemm_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g) {
     constexpr int BM = 32 * MI;
-    // One 128x64 A tile + one 128x64 W tile, 16-bit, rows of 128 B, NO padding: the tiles are written by
-    // global_load_lds_dwordx4 (LDS address = wave-uniform base + lane*16), so the layout must be lane-linear.  Bank
-    // conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk index with
-    // (row & 7), applied on the GLOBAL source address of every lane and again on the fragment read address.
-    __shared__ __attribute__((aligned(1024))) unsigned short sA[BM * BK];
-    __shared__ __attribute__((aligned(1024))) unsigned short sW[BN * BK];
+    constexpr int NS = 3;                       // LDS ring depth
+    constexpr int GL = MI / 2 + 2;              // global_load_lds per wave per stage (A: BM/16/4, W: 128/16/4)
+    // K is consumed in 32-wide stages through a 3-deep LDS ring filled by global_load_lds_dwordx4 (LDS address = wave-uniform
+    // base + lane*16, so every stage is lane-linear: rows of 64 B, chunk index XOR-swizzled on the GLOBAL source address and
+    // again on the fragment read).  Two stages are always in flight behind the one being multiplied: counted s_waitcnt
+    // vmcnt(GL) + raw s_barrier, never a full drain inside the loop.
+    // ONE __shared__ object: with a second one hipcc inserts s_waitcnt vmcnt(0) before the first ds_read of every k-step
+    // of a global_load_lds pipeline (cdna_hip_programming.md, "three .s-level traps").
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[NS * (BM + BN) * 32];
+    unsigned short *const sA = smem, *const sW = smem + NS * BM * 32;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
@@ -90,21 +105,21 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) gemm_kernel(const GemmAr
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // staging: wave w issues MI A pieces + 4 W pieces per K tile; piece p covers tile rows p*8 .. p*8+7;
-    // lane l lands at (row p*8 + (l>>3), chunk slot l&7) and therefore fetches global chunk (l&7) ^ (l>>3).
+    // staging: one global_load_lds piece = 16 tile rows x 64 B; lane l lands at (row p*16 + (l>>2), slot l&3) and therefore
+    // fetches global chunk (l&3) ^ swz4(row).  Wave w owns A pieces w*MI/2 .. and W pieces 2w, 2w+1.
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
-    const int rho = lane >> 3, gchunk = (lane & 7) ^ rho;
-    const unsigned short *pa[MI], *pw[4];
+    const int rho = lane >> 2, gchunk = (lane & 3) ^ swz4(rho);
+    const unsigned short *pa[MI / 2], *pw[2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int ra_ = min(m0 + (wid * MI + i) * 8 + rho, g.M - 1);
+    for (int i = 0; i < MI / 2; ++i) {
+        const int ra_ = min(m0 + (wid * (MI / 2) + i) * 16 + rho, g.M - 1);
         const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
         pa[i] = A + arow * g.lda + gchunk * 8;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rw_ = min(n0 + (wid * 4 + i) * 8 + rho, g.N - 1);
+    for (int i = 0; i < 2; ++i) {
+        const int rw_ = min(n0 + (wid * 2 + i) * 16 + rho, g.N - 1);
         pw[i] = W + (size_t)rw_ * g.ldw + gchunk * 8;
     }
     typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -117,35 +132,53 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) gemm_kernel(const GemmAr
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    const int nk = g.K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(pa[i] + k0), (lptr_t)(sA + (wid * MI + i) * 512), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(pw[i] + k0), (lptr_t)(sW + (wid * 4 + i) * 512), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rb_ = wc * 64 + j * 16 + frow;
-                fb[j] = *reinterpret_cast<const uint4 *>(&sW[rb_ * BK + (((ks * 4 + fg) ^ (rb_ & 7)) << 3)]);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int ra_ = wr * (16 * MI) + i * 16 + frow;
-                const uint4 fa = *reinterpret_cast<const uint4 *>(&sA[ra_ * BK + (((ks * 4 + fg) ^ (ra_ & 7)) << 3)]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);
-            }
-        }
-        __syncthreads();
+    const int nk = g.K / 32;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wid * (MI / 2)) * 1024u);
+    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NS * BM * 32 * 2) + (unsigned)(wid * 2) * 1024u);
+#define VS_STAGE(kt_, slot_)                                                                                   \
+    {                                                                                                          \
+        const int k0_ = (kt_) * 32;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MI / 2; ++i)                                                     \
+            glds16(pa[i] + k0_, ldsA + (unsigned)((slot_) * (BM * 32 * 2) + i * 1024));                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+            glds16(pw[i] + k0_, ldsW + (unsigned)((slot_) * (BN * 32 * 2) + i * 1024));                        \
     }
+    // one pipeline step with COMPILE-TIME ring slots (so that hipcc can prove the DMA target and the fragment reads do
+    // not alias and keeps the counted vmcnt instead of draining the queue before the first ds_read)
+#define VS_STEP(kt_, slot_, nslot_)                                                                         \
+    {                                                                                                       \
+        if ((kt_) + 1 < nk) {                                                                               \
+            if constexpr (GL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                           \
+        } else {                                                                                            \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        }                                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if ((kt_) + 2 < nk) VS_STAGE((kt_) + 2, nslot_)                                                     \
+        const unsigned short *cA = sA + (slot_) * (BM * 32), *cW = sW + (slot_) * (BN * 32);                \
+        uint4 fb[4];                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+            const int rb_ = wc * 64 + j * 16 + frow;                                                        \
+            fb[j] = *reinterpret_cast<const uint4 *>(&cW[rb_ * 32 + ((fg ^ swz4(rb_)) << 3)]);              \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                    \
+            const int ra_ = wr * (16 * MI) + i * 16 + frow;                                                 \
+            const uint4 fa = *reinterpret_cast<const uint4 *>(&cA[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);     \
+        }                                                                                                   \
+    }
+    VS_STAGE(0, 0)
+    if (nk > 1) VS_STAGE(1, 1)
+    for (int kt = 0; kt < nk; kt += 3) {
+        VS_STEP(kt, 0, 2)
+        if (kt + 1 < nk) VS_STEP(kt + 1, 1, 0)
+        if (kt + 2 < nk) VS_STEP(kt + 2, 2, 1)
+    }
+#undef VS_STEP
+#undef VS_STAGE
+    __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
     // ---- epilogue.  A lane's accumulators are 4 rows x 1 column per fragment: storing them directly means 2-byte
     // (or 4-byte) scattered stores.  Instead every wave transposes one 16 x 64 slab at a time through a private LDS
@@ -278,7 +311,7 @@ extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias,
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(A && W && out, "vs_gemm_bias_act: null pointer");
     VS_CHECK(M >= 0 && N > 0 && K > 0, "vs_gemm_bias_act: bad sizes M=%d N=%d K=%d", M, N, K);
-    VS_CHECK(K % BK == 0, "vs_gemm_bias_act: K=%d must be a multiple of %d", K, BK);
+    VS_CHECK(K % 64 == 0, "vs_gemm_bias_act: K=%d must be a multiple of 64", K);
     VS_CHECK(lda % 8 == 0 && ldw % 8 == 0, "vs_gemm_bias_act: lda/ldw must be multiples of 8 elements (16-byte rows)");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_bias_act: dtype must be 1 (f16) or 2 (bf16)");
     VS_CHECK((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
