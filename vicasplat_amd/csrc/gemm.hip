@@ -22,6 +22,8 @@
 // (e.g. the 257 image tokens of a frame behind the frame's camera token).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -279,6 +281,79 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
     }
 }
 
+// ---- small-M path (camera-token GEMMs: M = B*T rows).  Weight-streaming bound: one workgroup per 16 output columns,
+// its 4 waves split K, fragments come straight from global memory (A is tiny and L2-resident, W is read exactly once),
+// partial sums meet in LDS, then the same fused epilogues. ----
+template <bool BF16, int EPI>
+__global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
+    __shared__ float red[4][4][256];  // [wave][m-frag][16x16]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
+    const int mfr = (g.M + 15) / 16;  // 1..4
+    const unsigned short *pa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra_ = min(i * 16 + frow, g.M - 1);
+        const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+        pa[i] = A + arow * g.lda + fg * 8;
+    }
+    const unsigned short *pw = W + (size_t)min(n0 + frow, g.N - 1) * g.ldw + fg * 8;
+    f4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = g.K / 32;
+    for (int ks = wid; ks < ksteps; ks += 4) {
+        const uint4 fb = *reinterpret_cast<const uint4 *>(pw + ks * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < mfr) {
+                const uint4 fa = *reinterpret_cast<const uint4 *>(pa[i] + ks * 32);
+                acc[i] = mfma<BF16>(fa, fb, acc[i]);
+            }
+        }
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wid][i][(fg * 4 + r) * 16 + frow] = acc[i][r];
+    __syncthreads();
+    for (int e = tid; e < mfr * 256; e += 256) {
+        const int i = e >> 8, rc = e & 255, m = i * 16 + (rc >> 4), n = n0 + (rc & 15);
+        if (m >= g.M || n >= g.N) continue;
+        float v = red[0][i][rc] + red[1][i][rc] + red[2][i][rc] + red[3][i][rc] + (g.bias ? g.bias[n] : 0.0f);
+        const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+        if constexpr (EPI == 0) {
+            reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
+        } else if constexpr (EPI == 1) {
+            v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
+        } else if constexpr (EPI == 2) {
+            float *o = reinterpret_cast<float *>(g.out) + orow * g.ldo + n;
+            const float gt = g.gate ? g.gate[(size_t)(m / g.gate_rows) * g.gate_ld + n] : 0.0f;
+            *o = *o + (1.0f + gt) * v;
+        } else {
+            reinterpret_cast<float *>(g.out)[orow * g.ldo + n] = v;
+        }
+    }
+}
+
+template <bool BF16>
+int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
+    dim3 grid(vs::cdiv(g.N, 16)), block(256);
+    switch (epi) {
+        case 0: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 0>), grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 1>), grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 2>), grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 3>), grid, block, 0, stream, g); break;
+        default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
+    }
+    return 0;
+}
+
 template <bool BF16, int MI>
 int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M, 32 * MI) * vs::cdiv(g.N, BN);
@@ -297,8 +372,14 @@ template <bool BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // 256x128 tiles halve the W-panel traffic per flop (the 128x128 kernel is L2->LDS bandwidth bound on MI355X) but
     // need enough tiles to fill 256 CUs x 2 resident workgroups; otherwise fall back to 128x128.
-    const long long big_tiles = (long long)vs::cdiv(g.M, 256) * vs::cdiv(g.N, BN);
-    if (big_tiles >= 256) return launch_mi<BF16, 8>(g, epi, stream);
+    // 256x128 tiles (half the W-panel traffic and LDS-DMA issue per flop) whenever there are enough of them to fill the
+    // chip; 128x128 otherwise.  (Measured on the model's shapes: a rounds x cost quantisation model did not beat this rule.)
+    static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
+    if (g.M <= 64 && force == 0) return launch_smallm<BF16>(g, epi, stream);
+    if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
+    if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
+    const long long t8 = (long long)vs::cdiv(g.M, 256) * vs::cdiv(g.N, BN);
+    if (t8 >= 256) return launch_mi<BF16, 8>(g, epi, stream);
     return launch_mi<BF16, 4>(g, epi, stream);
 }
 
