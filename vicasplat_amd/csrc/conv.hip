@@ -19,7 +19,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128, BK = 64;
+constexpr int BN = 128;
 
 struct ConvArgs {
     const unsigned short *in;   // [N,H,W,Cin]
@@ -63,11 +63,20 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {
     return x & ~m;
 }
 
+// XOR swizzle of the 16-byte chunk index inside a 64-byte LDS row (see gemm.hip)
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+__device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
+}
+
 template <bool BF16, int MI>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) conv3x3_kernel(const ConvArgs g) {
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
     constexpr int BM = 32 * MI;
-    __shared__ __attribute__((aligned(1024))) unsigned short sA[BM * BK];
-    __shared__ __attribute__((aligned(1024))) unsigned short sW[BN * BK];
+    constexpr int NS = 3;
+    constexpr int GL = MI / 2 + 2;
+    // same 3-stage LDS ring / counted-vmcnt pipeline as gemm.hip (32-channel stages: one tap x 32 input channels)
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[NS * (BM + BN) * 32];
+    unsigned short *const sA = smem, *const sW = smem + NS * BM * 32;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int HW = g.H * g.W;
@@ -85,27 +94,29 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) conv3x3_kernel(const Con
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int rho = lane >> 3, gchunk = (lane & 7) ^ rho;
-    // per staged A row: linear pixel index and packed (y, x); rows beyond M are marked invalid (y = 0x7fff)
-    int pix[MI];
-    unsigned yx[MI];
+    const int rho = lane >> 2, gchunk = (lane & 3) ^ swz4(rho);
+    // per staged A row (piece = 16 rows x 64 B): linear input pixel index and packed (y, x); rows beyond M are invalid
+    int pix[MI / 2];
+    unsigned yx[MI / 2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + (wid * MI + i) * 8 + rho;
+    for (int i = 0; i < MI / 2; ++i) {
+        const int m = m0 + (wid * (MI / 2) + i) * 16 + rho;
         const int p = m < M ? m : 0;
         const int nimg = p / HW, rem = p - nimg * HW;
         const int y = (rem / g.W) * g.stride, x = (rem % g.W) * g.stride;  // centre tap in INPUT coordinates
         pix[i] = (nimg * g.Hin + y) * g.Win + x;
         yx[i] = m < M ? ((unsigned)y << 16) | (unsigned)x : 0x7fff0000u;
     }
-    const unsigned short *pw[4];
+    const unsigned short *pw[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rw_ = min(n0 + (wid * 4 + i) * 8 + rho, g.Cout - 1);
+    for (int i = 0; i < 2; ++i) {
+        const int rw_ = min(n0 + (wid * 2 + i) * 16 + rho, g.Cout - 1);
         pw[i] = g.w + (size_t)rw_ * K + gchunk * 8;
     }
-    typedef const void __attribute__((address_space(1))) *gptr_t;
     typedef void __attribute__((address_space(3))) *lptr_t;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wid * (MI / 2)) * 1024u);
+    const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NS * BM * 32 * 2) + (unsigned)(wid * 2) * 1024u);
 
     f4 acc[MI][4];
 #pragma unroll
@@ -114,45 +125,61 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 4) conv3x3_kernel(const Con
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    const int kt_per_tap = g.Cin / BK;
-    const int nk = K / BK;
-    int tap = 0, kc = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int shift = dy * g.Win + dx;
-        const int cin0 = kc * BK;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int y = (int)(yx[i] >> 16) + dy, x = (int)(yx[i] & 0xffffu) + dx;
-            const bool ok = (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win;
-            const unsigned short *src = ok ? g.in + ((size_t)(pix[i] + shift) * g.Cin + cin0 + gchunk * 8) : vs_zero_page + gchunk * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wid * MI + i) * 512), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(pw[i] + (size_t)kt * BK), (lptr_t)(sW + (wid * 4 + i) * 512), 16, 0, 0);
-        if (++kc == kt_per_tap) { kc = 0; ++tap; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rb_ = wc * 64 + j * 16 + frow;
-                fb[j] = *reinterpret_cast<const uint4 *>(&sW[rb_ * BK + (((ks * 4 + fg) ^ (rb_ & 7)) << 3)]);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int ra_ = wr * (16 * MI) + i * 16 + frow;
-                uint4 fa = *reinterpret_cast<const uint4 *>(&sA[ra_ * BK + (((ks * 4 + fg) ^ (ra_ & 7)) << 3)]);
-                if (g.relu_in) { fa.x = relu2(fa.x); fa.y = relu2(fa.y); fa.z = relu2(fa.z); fa.w = relu2(fa.w); }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);
-            }
-        }
-        __syncthreads();
+    const int st_per_tap = g.Cin / 32;
+    const int nk = K / 32;
+    // stage kt = (tap, 32-channel slice); issue order is sequential so (tap, kc) are tracked incrementally
+    int s_tap = 0, s_kc = 0;
+#define VS_STAGE(slot_)                                                                                              \
+    {                                                                                                                \
+        const int dy = s_tap / 3 - 1, dx = s_tap - (s_tap / 3) * 3 - 1;                                              \
+        const int shift = dy * g.Win + dx;                                                                           \
+        const int cin0 = s_kc * 32;                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MI / 2; ++i) {                                                         \
+            const int y = (int)(yx[i] >> 16) + dy, x = (int)(yx[i] & 0xffffu) + dx;                                  \
+            const bool ok = (unsigned)y < (unsigned)g.Hin && (unsigned)x < (unsigned)g.Win;                          \
+            const unsigned short *src = ok ? g.in + ((size_t)(pix[i] + shift) * g.Cin + cin0 + gchunk * 8)          \
+                                           : vs_zero_page + gchunk * 8;                                              \
+            glds16(src, ldsA + (unsigned)((slot_) * (BM * 32 * 2) + i * 1024));                                      \
+        }                                                                                                            \
+        const int kglob = (s_tap * st_per_tap + s_kc) * 32;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+            glds16(pw[i] + kglob, ldsW + (unsigned)((slot_) * (BN * 32 * 2) + i * 1024));                            \
+        if (++s_kc == st_per_tap) { s_kc = 0; ++s_tap; }                                                             \
     }
+#define VS_STEP(kt_, slot_, nslot_)                                                                         \
+    {                                                                                                       \
+        if ((kt_) + 1 < nk) {                                                                               \
+            if constexpr (GL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                           \
+        } else {                                                                                            \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        }                                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if ((kt_) + 2 < nk) VS_STAGE(nslot_)                                                                \
+        const unsigned short *cA = sA + (slot_) * (BM * 32), *cW = sW + (slot_) * (BN * 32);                \
+        uint4 fb[4];                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+            const int rb_ = wc * 64 + j * 16 + frow;                                                        \
+            fb[j] = *reinterpret_cast<const uint4 *>(&cW[rb_ * 32 + ((fg ^ swz4(rb_)) << 3)]);              \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                    \
+            const int ra_ = wr * (16 * MI) + i * 16 + frow;                                                 \
+            uint4 fa = *reinterpret_cast<const uint4 *>(&cA[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);           \
+            if (g.relu_in) { fa.x = relu2(fa.x); fa.y = relu2(fa.y); fa.z = relu2(fa.z); fa.w = relu2(fa.w); } \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);     \
+        }                                                                                                   \
+    }
+    VS_STAGE(0)
+    if (nk > 1) VS_STAGE(1)
+    for (int kt = 0; kt < nk; kt += 3) {
+        VS_STEP(kt, 0, 2)
+        if (kt + 1 < nk) VS_STEP(kt + 1, 1, 0)
+        if (kt + 2 < nk) VS_STEP(kt + 2, 2, 1)
+    }
+#undef VS_STEP
+#undef VS_STAGE
+    __syncthreads();
 
     // epilogue: per-wave 16 x 64 slabs transposed through LDS -> 16-byte row chunks (see gemm.hip)
     const int ccol = lane & 15, crow = (lane >> 4) * 4;
@@ -271,7 +298,7 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && w && out, "vs_conv3x3_nhwc: null pointer");
     VS_CHECK(Nimg >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), "vs_conv3x3_nhwc: bad sizes");
-    VS_CHECK(Cin % BK == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of %d (pad the channels)", Cin, BK);
+    VS_CHECK(Cin % 32 == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of 32 (pad the channels)", Cin);
     VS_CHECK(Hin < 32767 && Win < 65536 && (long long)Nimg * Hin * Win < 2147483647LL, "vs_conv3x3_nhwc: image too large");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_conv3x3_nhwc: dtype must be 1 (f16) or 2 (bf16)");
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
