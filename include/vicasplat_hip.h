@@ -181,13 +181,13 @@ int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts_ch, const 
  * F.interpolate(scale_factor=2, bilinear, align_corners=True) of heads/dpt_block.py:79-218,316-343).
  *   vs_conv3x3_nhwc : out = [relu](conv3x3([relu](in)) + bias [+ residual]); implicit GEMM on MFMA, no im2col buffer.
  *                     in [N,H,W,Cin], w [Cout,3,3,Cin] (tap-major, channel-minor), out/residual [N,H,W,Cout]; Cin % 64 == 0.
- *   vs_upsample2x_nhwc : out [N,2H,2W,C] = bilinear(in [N,H,W,C]) [+ add]; C % 8 == 0.
+ *   vs_upsample2x_nhwc : out [N,2H,2W,C] = bilinear(in [N,H,W,C]) [+ add | + relu(add)]; C % 8 == 0.
  * ------------------------------------------------------------------------------------------------ */
 int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg, int32_t Hin,
                     int32_t Win, int32_t Cin, int32_t Cout, int32_t stride /* 1 or 2; out = (in-1)/stride+1 */, int32_t relu_in,
                     int32_t relu_out, int32_t dtype, vs_stream_t stream);
-int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg, int32_t H, int32_t W, int32_t C, int32_t dtype,
-                       vs_stream_t stream);
+int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg, int32_t H, int32_t W, int32_t C,
+                       int32_t relu_add, int32_t dtype, vs_stream_t stream);
 
 #ifdef __cplusplus
 }

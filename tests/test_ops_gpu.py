@@ -302,3 +302,5 @@ def test_upsample2x_nhwc(dt):
         assert (out - ref).abs().max() <= tol * ref.abs().max()
         out = ops.upsample2x_nhwc(x.permute(0, 2, 3, 1).contiguous(), add.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2).float()
         assert (out - (ref + add.float())).abs().max() <= tol * (ref + add.float()).abs().max()
+        out = ops.upsample2x_nhwc(x.permute(0, 2, 3, 1).contiguous(), add.permute(0, 2, 3, 1).contiguous(), relu_add=True).permute(0, 3, 1, 2).float()
+        assert (out - (ref + F.relu(add.float()))).abs().max() <= tol * (ref + add.float()).abs().max()

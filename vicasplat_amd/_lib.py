@@ -94,7 +94,7 @@ def lib() -> C.CDLL:
             L.vs_conv3x3_nhwc.restype = C.c_int
             L.vs_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_upsample2x_nhwc.restype = C.c_int
-            L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+            L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             if hasattr(L, "vs_raster_backward"):
                 L.vs_raster_backward.restype = C.c_int
                 L.vs_raster_backward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), C.POINTER(VsRasterGrads),

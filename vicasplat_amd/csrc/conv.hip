@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *__restrict__ add, unsigned short *__restrict__ out,
-                  int Nimg, int H, int W, int C) {
+                  int Nimg, int H, int W, int C, int relu_add) {
     const int Ho = 2 * H, Wo = 2 * W, c8 = C >> 3;
     const long long total = (long long)Nimg * Ho * Wo * c8;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -266,7 +266,10 @@ upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *_
     const uint4 v11 = *reinterpret_cast<const uint4 *>(in + ((base + (size_t)y1 * W + x1) * C + cc * 8));
     const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * C + cc * 8;
     uint4 av = make_uint4(0, 0, 0, 0);
-    if (add) av = *reinterpret_cast<const uint4 *>(add + o);
+    if (add) {
+        av = *reinterpret_cast<const uint4 *>(add + o);
+        if (relu_add) { av.x = relu2(av.x); av.y = relu2(av.y); av.z = relu2(av.z); av.w = relu2(av.w); }
+    }
     const unsigned a00[4] = {v00.x, v00.y, v00.z, v00.w}, a01[4] = {v01.x, v01.y, v01.z, v01.w};
     const unsigned a10[4] = {v10.x, v10.y, v10.z, v10.w}, a11[4] = {v11.x, v11.y, v11.z, v11.w};
     const unsigned aa[4] = {av.x, av.y, av.z, av.w};
@@ -321,7 +324,7 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
 }
 
 extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg, int32_t H, int32_t W, int32_t C,
-                                  int32_t dtype, vs_stream_t stream_) {
+                                  int32_t relu_add, int32_t dtype, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && out, "vs_upsample2x_nhwc: null pointer");
     VS_CHECK(C % 8 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 8", C);
@@ -329,8 +332,8 @@ extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, in
     const long long total = (long long)Nimg * 4 * H * W * (C / 8);
     if (total <= 0) return 0;
     dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);
-    if (dtype == 2) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C);
-    else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C);
+    if (dtype == 2) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C, relu_add);
+    else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C, relu_add);
     VS_HIP(hipGetLastError());
     return 0;
 }

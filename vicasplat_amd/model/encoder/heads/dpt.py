@@ -170,6 +170,14 @@ class PixelwiseTaskWithDPT(nn.Module):
         self._pk, self._pk_key = P, key
         return P
 
+    def _stem_weights(self):
+        P = self._packed()
+        if "stem.w" not in P:
+            c = self.dpt.input_merger[0]
+            P["stem.w"] = c.weight.detach().to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
+            P["stem.b"] = c.bias.detach().to(self.compute_dtype)
+        return P["stem.w"], P["stem.b"]
+
     @staticmethod
     def _gemm1x1(x, P, name, n_out=None):
         """x [..., K] NHWC 16-bit -> [..., N] via the GEMM kernel (1x1 convolution)."""
@@ -235,10 +243,14 @@ class PixelwiseTaskWithDPT(nn.Module):
         x, P = self._trunk(tokens, gh, gw)
         d = self.dpt
         dt = self.compute_dtype
-        with torch.autocast("cuda", dtype=dt):  # 7x7 stem on the RGB image: MIOpen
-            img = d.input_merger(frames.contiguous(memory_format=torch.channels_last))
-        img = img.to(dt).permute(0, 2, 3, 1).contiguous()
-        x = ops.upsample2x_nhwc(x, add=img)
+        # 7x7 stem on the RGB image: MIOpen, channels-last in and out (the NHWC view is then free); its ReLU is fused into
+        # the upsample-add kernel
+        P7 = self._stem_weights()
+        img = F.conv2d(frames.to(dt).contiguous(memory_format=torch.channels_last), P7[0], P7[1], padding=3)
+        img = img.permute(0, 2, 3, 1)
+        if not img.is_contiguous():
+            img = img.contiguous()
+        x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
         x = ops.conv3x3_nhwc(x, P["h0.w"], None, relu_out=True)  # Dropout(0.1) is the identity at inference
         y = self._gemm1x1(x, P, "h4")
         return y.permute(0, 3, 1, 2)

@@ -148,14 +148,14 @@ def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: int = 0) -
     return wp.to(dtype).contiguous()
 
 
-def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit; optional fused `+ add` ([N,2H,2W,C])."""
+def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_add: bool = False) -> torch.Tensor:
+    """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit; optional fused `+ add` / `+ relu(add)`."""
     dev = L.require_device(x, add)
     assert x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float16, torch.bfloat16)
     N, H, W, Cc = x.shape
     out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=dev)
     assert add is None or (add.shape == out.shape and add.is_contiguous() and add.dtype == x.dtype)
     with torch.cuda.device(dev):
-        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, _DT[x.dtype], L.stream_ptr(dev))
+        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, int(relu_add), _DT[x.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_upsample2x_nhwc")
     return out
