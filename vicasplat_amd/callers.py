@@ -1,0 +1,154 @@
+"""Harness for the callers either side of the hot path.
+
+What is here runs on the HIP rasterizer through `DecoderSplattingCUDA` and is what the reference's evaluation and demo
+scripts do around the encoder/decoder:
+  * `mse_loss`                — LossMse.forward, src/loss/loss_mse.py:23-31
+  * `compute_psnr`            — src/evaluation/metrics.py:21-29
+  * `se3_exp`, `update_pose`  — src/misc/cam_utils.py:59-142 (batched, no per-camera Python loop)
+  * `align_poses`             — ModelWrapper.test_step_align, src/model/model_wrapper.py:442-513
+  * `export_ply`              — src/model/ply_export.py:31-90 (own binary writer, no plyfile dependency)
+  * `export_transforms`       — src/model/model_wrapper.py:390-400 (transforms.json)
+The encoder's training step (backward through the transformer) is not built; see DESIGN.md §7.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .model.types import Gaussians
+
+
+def mse_loss(color: Tensor, target: Tensor, weight: float = 1.0) -> Tensor:
+    return weight * ((color - target) ** 2).mean()
+
+
+@torch.no_grad()
+def compute_psnr(ground_truth: Tensor, predicted: Tensor) -> Tensor:
+    gt = ground_truth.clip(0, 1)
+    pr = predicted.clip(0, 1)
+    return -10 * ((gt - pr) ** 2).flatten(1).mean(1).log10()
+
+
+def _skew(w: Tensor) -> Tensor:
+    z = torch.zeros_like(w[..., 0])
+    return torch.stack([z, -w[..., 2], w[..., 1], w[..., 2], z, -w[..., 0], -w[..., 1], w[..., 0], z], -1).unflatten(-1, (3, 3))
+
+
+def se3_exp(tau: Tensor) -> Tensor:
+    """tau [..., 6] = (rho, theta) -> 4x4; small-angle series below 1e-5 rad exactly as cam_utils.py:70-115."""
+    rho, theta = tau[..., :3], tau[..., 3:]
+    W = _skew(theta)
+    W2 = W @ W
+    angle = theta.norm(dim=-1)[..., None, None]
+    small = angle < 1e-5
+    a = torch.where(small, torch.ones_like(angle), angle)
+    eye = torch.eye(3, dtype=tau.dtype, device=tau.device).expand_as(W)
+    Rm = torch.where(small, eye + W + 0.5 * W2, eye + (torch.sin(a) / a) * W + ((1 - torch.cos(a)) / a**2) * W2)
+    Vm = torch.where(small, eye + 0.5 * W + W2 / 6.0, eye + W * ((1 - torch.cos(a)) / a**2) + W2 * ((a - torch.sin(a)) / a**3))
+    T = torch.zeros(*tau.shape[:-1], 4, 4, dtype=tau.dtype, device=tau.device)
+    T[..., :3, :3] = Rm
+    T[..., :3, 3] = (Vm @ rho[..., None])[..., 0]
+    T[..., 3, 3] = 1
+    return T
+
+
+def update_pose(cam_trans_delta: Tensor, cam_rot_delta: Tensor, extrinsics: Tensor) -> Tensor:
+    """c2w' = (Exp([trans, rot]) · w2c)^-1   (cam_utils.py:118-137)."""
+    tau = torch.cat([cam_trans_delta, cam_rot_delta], dim=-1)
+    return (se3_exp(tau) @ extrinsics.inverse()).inverse()
+
+
+def align_poses(decoder, gaussians, target_image: Tensor, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                steps: int = 100, rot_lr: float = 0.005, trans_lr: float = 0.005, mse_weight: float = 1.0,
+                return_history: bool = False):
+    """Test-time pose alignment: Adam on per-camera twist deltas through the rasterizer's camera-Jacobian backward,
+    folding the delta into the extrinsics after every step (model_wrapper.py:442-513).
+    target_image [b,v,3,h,w]; extrinsics [b,v,4,4] c2w. Returns the refined extrinsics (and the loss history)."""
+    b, v, _, h, w = target_image.shape
+    dev = target_image.device
+    gaussians = Gaussians(gaussians.means.detach(), gaussians.covariances.detach(), gaussians.harmonics.detach(),
+                          gaussians.opacities.detach())
+    rot = torch.nn.Parameter(torch.zeros(b, v, 3, device=dev))
+    trans = torch.nn.Parameter(torch.zeros(b, v, 3, device=dev))
+    opt = torch.optim.Adam([{"params": [rot], "lr": rot_lr}, {"params": [trans], "lr": trans_lr}])
+    extrinsics = extrinsics.clone()
+    history = []
+    with torch.enable_grad():
+        for _ in range(steps):
+            opt.zero_grad()
+            out = decoder.forward(gaussians, extrinsics, intrinsics, near, far, (h, w), cam_rot_delta=rot, cam_trans_delta=trans)
+            loss = mse_loss(out.color, target_image, mse_weight)
+            loss.backward()
+            history.append(loss.detach())
+            with torch.no_grad():
+                opt.step()
+                extrinsics = update_pose(trans.flatten(0, 1), rot.flatten(0, 1), extrinsics.flatten(0, 1)).unflatten(0, (b, v))
+                rot.zero_()
+                trans.zero_()
+    return (extrinsics, torch.stack(history)) if return_history else extrinsics
+
+
+def _ply_attributes(num_rest: int) -> list[str]:
+    names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    names += [f"f_rest_{i}" for i in range(num_rest)]
+    names += ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    return names
+
+
+def export_ply(means: Tensor, scales: Tensor, rotations: Tensor, harmonics: Tensor, opacities: Tensor, path,
+               save_sh_dc_only: bool = False) -> int:
+    """3DGS-compatible binary PLY: pruned at opacity < 0.005, sorted by opacity (descending), opacity as a logit, scales
+    as logs, rotation xyzw -> unit wxyz (ply_export.py:31-90). Returns the number of vertices written."""
+    mask = opacities >= 0.005
+    op, idx = torch.sort(opacities[mask], descending=True)
+    means, scales, rotations, harmonics = (t[mask][idx] for t in (means, scales, rotations, harmonics))
+    q = rotations / rotations.norm(dim=-1, keepdim=True)
+    q = torch.cat([q[:, 3:], q[:, :3]], dim=-1)
+    f_dc = harmonics[..., 0]
+    f_rest = harmonics[..., 1:].flatten(1)
+    cols = [means, torch.zeros_like(means), f_dc]
+    if not save_sh_dc_only:
+        cols.append(f_rest)
+    cols += [torch.log(op / (1 - op))[:, None], scales.log(), q]
+    table = torch.cat([c.detach().float().cpu() for c in cols], dim=1).numpy().astype("<f4")
+    names = _ply_attributes(0 if save_sh_dc_only else f_rest.shape[1])
+    assert table.shape[1] == len(names)
+    path = Path(path)
+    path.parent.mkdir(exist_ok=True, parents=True)
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % table.shape[0]
+    header += "".join(f"property float {n}\n" for n in names) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(np.ascontiguousarray(table).tobytes())
+    return table.shape[0]
+
+
+def read_ply(path) -> dict[str, np.ndarray]:
+    """Reader for the files `export_ply` writes (round-trip tests)."""
+    with open(path, "rb") as f:
+        names, n = [], 0
+        while True:
+            line = f.readline().decode("ascii").strip()
+            if line.startswith("element vertex"):
+                n = int(line.split()[-1])
+            elif line.startswith("property float"):
+                names.append(line.split()[-1])
+            elif line == "end_header":
+                break
+        table = np.frombuffer(f.read(), dtype="<f4").reshape(n, len(names))
+    return {k: table[:, i] for i, k in enumerate(names)}
+
+
+def export_transforms(extrinsics: Tensor, path, file_names: list[str] | None = None) -> None:
+    """transforms.json: a list of `{file_path, transform_matrix}` (4x4 c2w) per context frame (model_wrapper.py:390-400)."""
+    ext = extrinsics.detach().float().cpu().reshape(-1, 4, 4)
+    frames = [{"file_path": file_names[i] if file_names else f"context/{i:0>6}.png", "transform_matrix": ext[i].tolist()}
+              for i in range(ext.shape[0])]
+    path = Path(path)
+    path.parent.mkdir(exist_ok=True, parents=True)
+    with open(path, "w") as f:
+        json.dump(frames, f, indent=4)
