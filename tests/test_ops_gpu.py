@@ -44,7 +44,12 @@ def test_layernorm_mod(M, C, odt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(2056, 3072, 1024), (257, 1024, 4096), (100, 768, 768), (16, 2304, 768), (1, 128, 64), (300, 144, 192)])
+@pytest.mark.parametrize("M,N,K", [(2056, 3072, 1024), (257, 1024, 4096), (100, 768, 768), (16, 2304, 768), (1, 128, 64), (300, 144, 192),
+                                   # tail-split launches: 64 full 256-row tiles + 64 rows (small-M tail) / + 128 rows (128-row tail),
+                                   # and the 128-row-tile variant (M=4112 -> 32 full tiles + 16 rows would not split: no new round)
+                                   (16448, 1024, 64), (16512, 768, 128), (16448, 4096, 64), (98368, 128, 64),
+                                   # 256x256 phase-interleaved kernel (K % 128 == 0, full tile rows fill 256 CUs) + its tails
+                                   (16448, 1024, 256), (16400, 512, 1024), (65536 + 100, 256, 128)])
 def test_gemm_epilogues(dt, M, N, K):
     from vicasplat_amd import ops
     d = _dev()
@@ -76,6 +81,28 @@ def test_gemm_epilogues(dt, M, N, K):
     exp = x0.clone()
     exp[orow] += (1 + gate[rows // gi]) * ref
     assert (x32 - exp).abs().max() <= 1e-4 * exp.abs().max() + 2e-5 * K ** 0.5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm256_is_race_free_and_deterministic(dt):
+    """The 256x256 kernel orders LDS-DMA against ds_reads with counted vmcnt + barriers only: a misplaced wait shows up
+    as rare wrong tiles, so hammer one big shape and demand bit-identical outputs that also match the reference."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    M, N, K = 16384, 2048, 1024
+    a = torch.randn(M, K, generator=g).to(dt).to(d)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dt).to(d)
+    ref = a.float() @ w.float().t()
+    first = None
+    for it in range(25):
+        out = torch.empty(M, N, dtype=dt, device=d)
+        ops.gemm(a, w, None, out, ops.EPI_STORE16)
+        if first is None:
+            first = out
+            assert (out.float() - ref).abs().max() <= (2e-3 if dt == torch.float16 else 1.2e-2) * ref.abs().max()
+        else:
+            assert torch.equal(out, first), f"run {it} differs in {(out != first).sum().item()} elements"
 
 
 def _rope2d_ref(x, pos, base):  # x [rows, H, 64] fp32

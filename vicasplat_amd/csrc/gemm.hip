@@ -20,63 +20,11 @@
 //   3 STORE32   out32[row(m), n] = acc + bias
 // row(m) = (m / grp_in) * grp_out + grp_off + m % grp_in lets a GEMM write straight into a larger token buffer
 // (e.g. the 257 image tokens of a frame behind the frame's camera token).
-#include "common.h"
+#include "gemm256.h"
 
 #include <cstdlib>
 
 namespace {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr int BN = 128;  // BM = 32*MI (MI = 16-row fragments per wave in M: 4 -> 128 rows, 8 -> 256 rows)
-
-struct GemmArgs {
-    const void *A;
-    const void *W;
-    const float *bias;
-    void *out;
-    const float *gate;
-    int M, N, K;
-    int lda, ldw, ldo;
-    int grp_in, grp_out, grp_off;
-    int gate_rows;  // rows of A per gate vector
-    int gate_ld;
-    int a_grp_in, a_grp_out, a_grp_off;  // INPUT row map: A row of m = (m / a_grp_in) * a_grp_out + a_grp_off + m % a_grp_in
-};
-
-template <bool BF16>
-__device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
-    if constexpr (BF16) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
-    }
-}
-
-template <bool BF16>
-__device__ __forceinline__ unsigned short to16(float v) {
-    if constexpr (BF16) {
-        unsigned u = __float_as_uint(v);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        return (unsigned short)(u >> 16);
-    } else {
-        _Float16 h = (_Float16)v;
-        return *reinterpret_cast<unsigned short *>(&h);
-    }
-}
-
-// XOR swizzle of the 16-byte chunk index (0..3) inside a 64-byte LDS row, keyed on (row >> 2) & 3, chosen so that the
-// four 16-lane service groups of ds_read_b128 each touch 16 distinct 16-byte slots of a 256-byte bank row.
-__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // f = {0,2,3,1}
-
-// LDS-DMA issued from inline asm: hipcc's waitcnt insertion does not see it, so the counted s_waitcnt vmcnt(N) placed by
-// hand below are the only waits (with the builtin it drains vmcnt(0) before the first ds_read of every step, which
-// serialises the pipeline).  lds_off must be wave-uniform (it goes to M0).
-__device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
-}
 
 template <bool BF16, int EPI, int MI>
 __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g) {
@@ -97,7 +45,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
     // XCD-aware tile order: blocks b, b+8, b+16.. run on the same XCD (observed, speed only) -> give each XCD a
     // contiguous range of tiles so neighbouring tiles (same A panel) hit that XCD's L2.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tiles_m = (g.M + BM - 1) / BM;
+    const int tiles_m = (g.M - g.m_lo + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
@@ -105,7 +53,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = g.m_lo + tm * BM, n0 = tn * BN;
 
     // staging: one global_load_lds piece = 16 tile rows x 64 B; lane l lands at (row p*16 + (l>>2), slot l&3) and therefore
     // fetches global chunk (l&3) ^ swz4(row).  Wave w owns A pieces w*MI/2 .. and W pieces 2w, 2w+1.
@@ -182,103 +130,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
 #undef VS_STAGE
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
-    // ---- epilogue.  A lane's accumulators are 4 rows x 1 column per fragment: storing them directly means 2-byte
-    // (or 4-byte) scattered stores.  Instead every wave transposes one 16 x 64 slab at a time through a private LDS
-    // patch (the operand tiles are dead after the last barrier) and writes / updates full 16-byte row chunks. ----
-    const int ccol = lane & 15, crow = (lane >> 4) * 4;
-    float bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + ccol;
-        bv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
-    }
-    const int nbase = n0 + wc * 64;
-    if constexpr (EPI == 0 || EPI == 1) {
-        constexpr int PR = 64 + 8;  // halfs per patch row (144 B: 16-byte aligned, conflict-light)
-        unsigned short *patch = sA + wid * (16 * PR);
-        const bool vec_ok = (g.ldo % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
-                }
-            __syncthreads();
-            // 16 rows x 8 chunks of 8 halfs = 128 chunks, 2 per lane
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
-                const int m = m0 + wr * (16 * MI) + i * 16 + prow;
-                if (m < g.M) {
-                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                    unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + pch * 8;
-                    const uint4 val = *reinterpret_cast<const uint4 *>(&patch[prow * PR + pch * 8]);
-                    if (vec_ok) {
-                        *reinterpret_cast<uint4 *>(dst) = val;
-                    } else {
-                        const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (nbase + pch * 8 + e < g.N) dst[e] = hv[e];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    } else {
-        constexpr int PR = 64 + 4;  // floats per patch row (272 B)
-        float *patch = reinterpret_cast<float *>(sA) + wid * (16 * PR);
-        const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
-                const float *gp = nullptr;
-                if (EPI == 2 && g.gate && m < g.M) gp = g.gate + (size_t)(m / g.gate_rows) * g.gate_ld;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = nbase + j * 16 + ccol;
-                    float v = acc[i][j][r] + bv[j];
-                    if (gp && n < g.N) v *= 1.0f + gp[n];
-                    patch[(crow + r) * PR + j * 16 + ccol] = v;
-                }
-            }
-            __syncthreads();
-            // 16 rows x 16 chunks of 4 floats = 256 chunks, 4 per lane
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int q = lane + 64 * c, prow = q >> 4, pch = q & 15;
-                const int m = m0 + wr * (16 * MI) + i * 16 + prow;
-                if (m < g.M) {
-                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                    float *dst = reinterpret_cast<float *>(g.out) + orow * g.ldo + nbase + pch * 4;
-                    const float4 val = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 4]);
-                    if (vec_ok) {
-                        if constexpr (EPI == 2) {
-                            float4 o = *reinterpret_cast<float4 *>(dst);
-                            o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
-                            *reinterpret_cast<float4 *>(dst) = o;
-                        } else {
-                            *reinterpret_cast<float4 *>(dst) = val;
-                        }
-                    } else {
-                        const float *fv = reinterpret_cast<const float *>(&val);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nbase + pch * 4 + e < g.N) {
-                                if constexpr (EPI == 2) dst[e] += fv[e]; else dst[e] = fv[e];
-                            }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    gemm_epilogue<BF16, EPI, MI>(g, acc, m0 + wr * (16 * MI), n0 + wc * 64, smem, wid, lane);
 }
 
 // ---- small-M path (camera-token GEMMs: M = B*T rows).  Weight-streaming bound: one workgroup per 16 output columns,
@@ -292,11 +144,11 @@ __global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
     const int frow = lane & 15, fg = lane >> 4;
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
-    const int mfr = (g.M + 15) / 16;  // 1..4
+    const int mfr = (g.M - g.m_lo + 15) / 16;  // 1..4
     const unsigned short *pa[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ra_ = min(i * 16 + frow, g.M - 1);
+        const int ra_ = min(g.m_lo + i * 16 + frow, g.M - 1);
         const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
         pa[i] = A + arow * g.lda + fg * 8;
     }
@@ -322,7 +174,7 @@ __global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
         for (int r = 0; r < 4; ++r) red[wid][i][(fg * 4 + r) * 16 + frow] = acc[i][r];
     __syncthreads();
     for (int e = tid; e < mfr * 256; e += 256) {
-        const int i = e >> 8, rc = e & 255, m = i * 16 + (rc >> 4), n = n0 + (rc & 15);
+        const int i = e >> 8, rc = e & 255, m = g.m_lo + i * 16 + (rc >> 4), n = n0 + (rc & 15);
         if (m >= g.M || n >= g.N) continue;
         float v = red[0][i][rc] + red[1][i][rc] + red[2][i][rc] + red[3][i][rc] + (g.bias ? g.bias[n] : 0.0f);
         const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
@@ -356,7 +208,7 @@ int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
 
 template <bool BF16, int MI>
 int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
-    const int nwg = vs::cdiv(g.M, 32 * MI) * vs::cdiv(g.N, BN);
+    const int nwg = vs::cdiv(g.M - g.m_lo, 32 * MI) * vs::cdiv(g.N, BN);
     dim3 grid(nwg), block(256);
     switch (epi) {
         case 0: hipLaunchKernelGGL((gemm_kernel<BF16, 0, MI>), grid, block, 0, stream, g); break;
@@ -369,18 +221,63 @@ int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
 }
 
 template <bool BF16>
+int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
+    const int nwg = vs::cdiv(g.M - g.m_lo, 256) * vs::cdiv(g.N, 256);
+    dim3 grid(nwg), block(512);
+    switch (epi) {
+        case 0: hipLaunchKernelGGL((gemm256_kernel<BF16, 0>), grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm256_kernel<BF16, 1>), grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL((gemm256_kernel<BF16, 2>), grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm256_kernel<BF16, 3>), grid, block, 0, stream, g); break;
+        default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
+    }
+    return 0;
+}
+
+// Rows [g.M - rem, g.M) of a split GEMM: <= 64 rows on the weight-streaming kernel, <= 128 on one row of 128x128 tiles.
+template <bool BF16>
+int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
+    GemmArgs t = g;
+    t.m_lo = g.M - rem;
+    return rem <= 64 ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
+}
+
+template <bool BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
-    // 256x128 tiles halve the W-panel traffic per flop (the 128x128 kernel is L2->LDS bandwidth bound on MI355X) but
-    // need enough tiles to fill 256 CUs x 2 resident workgroups; otherwise fall back to 128x128.
-    // 256x128 tiles (half the W-panel traffic and LDS-DMA issue per flop) whenever there are enough of them to fill the
-    // chip; 128x128 otherwise.  (Measured on the model's shapes: a rounds x cost quantisation model did not beat this rule.)
+    // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
     if (g.M <= 64 && force == 0) return launch_smallm<BF16>(g, epi, stream);
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
-    const long long t8 = (long long)vs::cdiv(g.M, 256) * vs::cdiv(g.N, BN);
-    if (t8 >= 256) return launch_mi<BF16, 8>(g, epi, stream);
-    return launch_mi<BF16, 4>(g, epi, stream);
+    // M = frames * 257 tokens is never a multiple of the tile height, and one partial row of tiles past a full wave of
+    // workgroups costs a whole extra round.  Every path below therefore runs the full tile rows as one launch and a
+    // leftover of <= half a tile as a tail launch whenever the partial row would open a new round.
+    // 256x256 tiles (one 8-wave workgroup per CU): for K-tile-aligned shapes whose full tile rows fill the 256 CUs evenly.
+    if (g.K % 128 == 0 && g.M >= 256) {
+        const int tn = vs::cdiv(g.N, 256), rem = g.M % 256, tail = (rem > 0 && rem <= 128) ? rem : 0;
+        const long long tiles = (long long)vs::cdiv(g.M - tail, 256) * tn;
+        const long long rounds = (tiles + 255) / 256;
+        if (force == 16 || tiles * 100 >= rounds * 256 * 85) {
+            GemmArgs main_g = g;
+            main_g.M = g.M - tail;
+            int rc = launch_256<BF16>(main_g, epi, stream);
+            if (rc || !tail) return rc;
+            return launch_tail<BF16>(g, tail, epi, stream);
+        }
+    }
+    // 256x128 tiles (half the W-panel traffic and LDS-DMA issue per flop of 128x128) whenever there are enough of them
+    // to fill 256 CUs x 2 resident workgroups; 128x128 otherwise.
+    const int tiles_n = vs::cdiv(g.N, BN);
+    const long long t8 = (long long)vs::cdiv(g.M, 256) * tiles_n;
+    const int mi = t8 >= 256 ? 8 : 4, bm = 32 * mi, slots = 256 * (mi == 8 ? 2 : 3);
+    const int rem = g.M % bm;
+    const long long full = (long long)(g.M / bm) * tiles_n;
+    const bool split = full > 0 && rem > 0 && rem <= bm / 2 && (full + tiles_n + slots - 1) / slots > (full + slots - 1) / slots;
+    GemmArgs main_g = g;
+    if (split) main_g.M = g.M - rem;
+    int rc = mi == 8 ? launch_mi<BF16, 8>(main_g, epi, stream) : launch_mi<BF16, 4>(main_g, epi, stream);
+    if (rc || !split) return rc;
+    return launch_tail<BF16>(g, rem, epi, stream);
 }
 
 }  // namespace
@@ -409,6 +306,7 @@ extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias,
     g.a_grp_in = a_grp_in > 0 ? a_grp_in : (M > 0 ? M : 1);
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
+    g.m_lo = 0;
     const int rc = dtype == 2 ? launch<true>(g, epilogue, stream) : launch<false>(g, epilogue, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());

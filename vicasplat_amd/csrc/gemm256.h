@@ -1,0 +1,155 @@
+// 256x256x64 GEMM tile kernel for the big ViT-L GEMMs: 8 waves (2 in M x 4 in N, 128x64 outputs each), operands staged
+// HBM/L2 -> LDS with global_load_lds_dwordx4 into a two-K-tile ring, and a phase-interleaved K loop in which the two
+// wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run half a phase apart, so that while one group feeds the
+// MFMA pipe the other issues its ds_reads and the next LDS-DMA.  Same fused epilogues as gemm_kernel.
+//
+// Staging units.  A K-tile (64 wide) is staged as four 16 KiB units of 128 rows x 128 B, cut by REGISTER sub-tile
+// rather than by tile half: A_h = rows {wr*128 + h*64 + 0..63 : wr=0,1}, B_h = W rows {wc*64 + h*32 + 0..31 : wc=0..3}
+// (h = 0,1), so unit A_h / B_h is exactly what every wave reads for its h-th A / B register sub-tile.  One unit is one
+// LDS-DMA round: 512 lanes x 16 B x 2.  Rows are 128 B; the 16-byte chunk index is XORed with (row>>1)&7 on the global
+// source side and again on the read, which makes every 16-lane service group of ds_read_b128 hit 16 distinct slots.
+//
+// Phases.  Per K-tile a wave does 4 phases of 16 MFMAs (one 64x32 output quadrant x K=64):
+//     ph1: read B_0, A_0 -> (A0,B0)   ph2: read B_1 -> (A0,B1)   ph3: read A_1 -> (A1,B1)   ph4: (A1,B0)
+// and every phase re-fills ONE unit, as soon as it is legal (>= 2 phases after its last ds_read, because the other
+// wave group trails by one barrier) and as early as possible:
+//     ph1: B_1 of tile kt+1   ph2: A_1 of kt+1   ph3: A_0 of kt+2   ph4: B_0 of kt+2        (ring slot = tile & 1)
+// so 4 units (64 KiB) are always in flight.  A unit is waited for (counted vmcnt, never 0 in the steady state) in the
+// phase BEFORE the one that reads it, ahead of that phase's first barrier: LDS-DMA data is ordered for another wave's
+// ds_read only by the issuer's vmcnt wait followed by a barrier both have passed.
+#pragma once
+#include "gemm_common.h"
+
+namespace {
+
+template <bool BF16, int EPI>
+__global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
+    constexpr int BM2 = 256, BN2 = 256;
+    constexpr unsigned UNITB = 128 * 128;  // bytes per staged unit
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * UNITB];  // [slot][A0 A1 B0 B1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int tiles_m = (g.M - g.m_lo + BM2 - 1) / BM2;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = g.m_lo + tm * BM2, n0 = tn * BN2;
+
+    // ---- staging addresses: lane l of (wave w, round j) fills LDS row q = w*16 + j*8 + (l>>3), slot l&7 of a unit ----
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
+    const unsigned short *pu[4][2];  // [A0 A1 B0 B1][round]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wid * 16 + j * 8 + (lane >> 3);
+        const int src_chunk = (lane & 7) ^ ((q >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ra_ = min(m0 + (q >> 6) * 128 + h * 64 + (q & 63), g.M - 1);
+            const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+            pu[h][j] = A + arow * g.lda + src_chunk * 8;
+            const int rw_ = min(n0 + (q >> 5) * 64 + h * 32 + (q & 31), g.N - 1);
+            pu[2 + h][j] = W + (size_t)rw_ * g.ldw + src_chunk * 8;
+        }
+    }
+    typedef void __attribute__((address_space(3))) *lptr_t;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wid * 2048u);
+#define VS_STAGE(u_, kt_, d_)                                                            \
+    {                                                                                    \
+        glds16(pu[u_][0] + (kt_) * 64, lds_w + (unsigned)(((d_) * 4 + (u_)) * UNITB));        \
+        glds16(pu[u_][1] + (kt_) * 64, lds_w + (unsigned)(((d_) * 4 + (u_)) * UNITB) + 1024u); \
+    }
+
+    // ---- fragment read addresses ----
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned rd0 = (unsigned)(frow * 128 + (((0 + fg) ^ (frow >> 1)) << 4));
+    const unsigned rd1 = (unsigned)(frow * 128 + (((4 + fg) ^ (frow >> 1)) << 4));
+    const unsigned char *rdA = smem + wr * (64 * 128);
+    const unsigned char *rdB = smem + wc * (32 * 128);
+    uint4 fa[4][2], fb[2][2][2];
+    f4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+#define VS_RD_A(h_, d_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+        fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd0);           \
+        fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd1);           \
+    }
+#define VS_RD_B(h_, d_)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+        fb[h_][j][0] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd0);   \
+        fb[h_][j][1] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd1);   \
+    }
+#define VS_MM(ha_, hb_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fa[i][0], fb[hb_][j][0], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fa[i][1], fb[hb_][j][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
+        }
+#define VS_BAR()                                  \
+    {                                             \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    }
+#define VS_COMPUTE(ha_, hb_)                      \
+    {                                             \
+        VS_BAR()                                  \
+        __builtin_amdgcn_s_setprio(1);            \
+        VS_MM(ha_, hb_)                           \
+        __builtin_amdgcn_s_setprio(0);            \
+        VS_BAR()                                  \
+    }
+#define VS_WAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
+    // MODE 0: steady state (tiles kt+1 and kt+2 exist), 1: kt == KT-2, 2: kt == KT-1
+#define VS_KTILE(kt_, d_, MODE_)                                                  \
+    {                                                                             \
+        VS_RD_B(0, d_) VS_RD_A(0, d_)                                             \
+        if (MODE_ <= 1) { VS_STAGE(3, (kt_) + 1, (d_) ^ 1) VS_WAIT(8) } else { VS_WAIT(2) } \
+        VS_COMPUTE(0, 0)                                                          \
+        VS_RD_B(1, d_)                                                            \
+        if (MODE_ <= 1) { VS_STAGE(1, (kt_) + 1, (d_) ^ 1) VS_WAIT(8) } else { VS_WAIT(0) } \
+        VS_COMPUTE(0, 1)                                                          \
+        VS_RD_A(1, d_)                                                            \
+        if (MODE_ == 0) VS_STAGE(0, (kt_) + 2, d_)                                \
+        VS_COMPUTE(1, 1)                                                          \
+        if (MODE_ == 0) { VS_STAGE(2, (kt_) + 2, d_) VS_WAIT(8) } else if (MODE_ == 1) { VS_WAIT(4) } \
+        VS_COMPUTE(1, 0)                                                          \
+    }
+
+    const int KT = g.K / 64;  // even, >= 2 (checked by the launcher)
+    VS_STAGE(0, 0, 0) VS_STAGE(2, 0, 0) VS_STAGE(3, 0, 0) VS_STAGE(1, 0, 0) VS_STAGE(0, 1, 1) VS_STAGE(2, 1, 1)
+    VS_WAIT(8)
+    VS_BAR()
+    if (wr == 1) VS_BAR()  // the second wave group trails the first by one barrier from here on
+    for (int kt = 0; kt + 2 < KT; kt += 2) {
+        VS_KTILE(kt, 0, 0)
+        VS_KTILE(kt + 1, 1, 0)
+    }
+    VS_KTILE(KT - 2, 0, 1)
+    VS_KTILE(KT - 1, 1, 2)
+    if (wr == 0) VS_BAR()
+#undef VS_KTILE
+#undef VS_WAIT
+#undef VS_COMPUTE
+#undef VS_BAR
+#undef VS_MM
+#undef VS_RD_B
+#undef VS_RD_A
+#undef VS_STAGE
+    __syncthreads();  // every wave is done with the ring before the epilogue reuses it
+    gemm_epilogue<BF16, EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
+}  // namespace

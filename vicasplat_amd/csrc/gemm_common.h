@@ -1,0 +1,162 @@
+// Shared pieces of the GEMM / implicit-GEMM kernels: argument block, MFMA wrappers, LDS-DMA helper, fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int BN = 128;  // BM = 32*MI (MI = 16-row fragments per wave in M: 4 -> 128 rows, 8 -> 256 rows)
+
+struct GemmArgs {
+    const void *A;
+    const void *W;
+    const float *bias;
+    void *out;
+    const float *gate;
+    int M, N, K;
+    int lda, ldw, ldo;
+    int grp_in, grp_out, grp_off;
+    int gate_rows;  // rows of A per gate vector
+    int gate_ld;
+    int m_lo;  // first logical row this launch covers (rows [m_lo, M)); tail launches of a split GEMM start past 0
+    int a_grp_in, a_grp_out, a_grp_off;  // INPUT row map: A row of m = (m / a_grp_in) * a_grp_out + a_grp_off + m % a_grp_in
+};
+
+template <bool BF16>
+__device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
+    if constexpr (BF16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ unsigned short to16(float v) {
+    if constexpr (BF16) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    } else {
+        _Float16 h = (_Float16)v;
+        return *reinterpret_cast<unsigned short *>(&h);
+    }
+}
+
+// XOR swizzle of the 16-byte chunk index (0..3) inside a 64-byte LDS row, keyed on (row >> 2) & 3, chosen so that the
+// four 16-lane service groups of ds_read_b128 each touch 16 distinct 16-byte slots of a 256-byte bank row.
+__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // f = {0,2,3,1}
+
+// LDS-DMA issued from inline asm: hipcc's waitcnt insertion does not see it, so the counted s_waitcnt vmcnt(N) placed by
+// hand below are the only waits (with the builtin it drains vmcnt(0) before the first ds_read of every step, which
+// serialises the pipeline).  lds_off must be wave-uniform (it goes to M0).
+__device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
+}
+
+// ---- epilogue shared by the tile kernels.  A lane's accumulators are 4 rows x 1 column per fragment: storing them
+// directly means 2-byte (or 4-byte) scattered stores.  Instead every wave transposes one 16 x 64 slab at a time through
+// a private LDS patch (`scratch`: the operand tiles, dead after the last barrier; 16*68*4 B per wave) and writes /
+// updates full 16-byte row chunks.  mw0 / nbase = first output row / column of the wave's (16*MI) x 64 tile. ----
+template <bool BF16, int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *scratch, int wid,
+                                              int lane) {
+    const int ccol = lane & 15, crow = (lane >> 4) * 4;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + ccol;
+        bv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
+    }
+    if constexpr (EPI == 0 || EPI == 1) {
+        constexpr int PR = 64 + 8;  // halfs per patch row (144 B: 16-byte aligned, conflict-light)
+        unsigned short *patch = reinterpret_cast<unsigned short *>(scratch) + wid * (16 * PR);
+        const bool vec_ok = (g.ldo % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
+                }
+            __syncthreads();
+            // 16 rows x 8 chunks of 8 halfs = 128 chunks, 2 per lane
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
+                const int m = mw0 + i * 16 + prow;
+                if (m < g.M) {
+                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+                    unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + pch * 8;
+                    const uint4 val = *reinterpret_cast<const uint4 *>(&patch[prow * PR + pch * 8]);
+                    if (vec_ok) {
+                        *reinterpret_cast<uint4 *>(dst) = val;
+                    } else {
+                        const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (nbase + pch * 8 + e < g.N) dst[e] = hv[e];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        constexpr int PR = 64 + 4;  // floats per patch row (272 B)
+        float *patch = reinterpret_cast<float *>(scratch) + wid * (16 * PR);
+        const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mw0 + i * 16 + crow + r;
+                const float *gp = nullptr;
+                if (EPI == 2 && g.gate && m < g.M) gp = g.gate + (size_t)(m / g.gate_rows) * g.gate_ld;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nbase + j * 16 + ccol;
+                    float v = acc[i][j][r] + bv[j];
+                    if (gp && n < g.N) v *= 1.0f + gp[n];
+                    patch[(crow + r) * PR + j * 16 + ccol] = v;
+                }
+            }
+            __syncthreads();
+            // 16 rows x 16 chunks of 4 floats = 256 chunks, 4 per lane
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = lane + 64 * c, prow = q >> 4, pch = q & 15;
+                const int m = mw0 + i * 16 + prow;
+                if (m < g.M) {
+                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+                    float *dst = reinterpret_cast<float *>(g.out) + orow * g.ldo + nbase + pch * 4;
+                    const float4 val = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 4]);
+                    if (vec_ok) {
+                        if constexpr (EPI == 2) {
+                            float4 o = *reinterpret_cast<float4 *>(dst);
+                            o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
+                            *reinterpret_cast<float4 *>(dst) = o;
+                        } else {
+                            *reinterpret_cast<float4 *>(dst) = val;
+                        }
+                    } else {
+                        const float *fv = reinterpret_cast<const float *>(&val);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nbase + pch * 4 + e < g.N) {
+                                if constexpr (EPI == 2) dst[e] += fv[e]; else dst[e] = fv[e];
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
