@@ -288,7 +288,9 @@ def test_gaussian_adapter_fused(dt, layout):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 37, 21, 128, 256), (3, 64, 64, 256, 256), (1, 8, 8, 768, 256), (1, 256, 256, 128, 128)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 37, 21, 128, 256), (3, 64, 64, 256, 256), (1, 8, 8, 768, 256), (1, 256, 256, 128, 128),
+                                            # 256x256-tile kernel (Cout % 256 == 0, >= 224 pixel tiles), incl. a ragged last tile
+                                            (16, 64, 64, 256, 256), (4, 128, 128, 128, 256), (1, 250, 250, 256, 256)])
 def test_conv3x3_nhwc_implicit_gemm(dt, N, H, W, Cin, Cout):
     from vicasplat_amd import ops
     d = _dev()

@@ -9,17 +9,13 @@
 // per-row source pointer changes with the tap, and out-of-image taps read a 128-byte zero page.  No im2col buffer ever
 // exists.  Fused: ReLU on the input (ResidualConvUnit applies the activation BEFORE each conv), bias, residual add,
 // ReLU on the output.
-#include "common.h"
+#include "gemm256.h"
+
+#include <cstdlib>
 
 __device__ __attribute__((aligned(128))) unsigned short vs_zero_page[64] = {0};
 
 namespace {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr int BN = 128;
 
 struct ConvArgs {
     const unsigned short *in;   // [N,H,W,Cin]
@@ -32,41 +28,143 @@ struct ConvArgs {
     int Hin, Win, stride;
 };
 
-template <bool BF16>
-__device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
-    if constexpr (BF16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
-}
-
-template <bool BF16>
-__device__ __forceinline__ unsigned short to16(float v) {
-    if constexpr (BF16) {
-        unsigned u = __float_as_uint(v);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        return (unsigned short)(u >> 16);
-    } else {
-        _Float16 h = (_Float16)v;
-        return *reinterpret_cast<unsigned short *>(&h);
+// epilogue shared by the conv kernels: every wave transposes one 16 x 64 f32 slab (acc + bias) at a time through a
+// private LDS patch, then each lane finishes two 8-channel row chunks: + residual (16-byte load, added in f32), ReLU,
+// round to 16 bit, one 16-byte store.  mw0 / nbase = first output pixel / channel of the wave's tile.
+template <bool BF16, int MI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, int M, void *scratch,
+                                              int wid, int lane) {
+    const int ccol = lane & 15, crow = (lane >> 4) * 4;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + ccol;
+        bv[j] = (g.bias && n < g.Cout) ? g.bias[n] : 0.0f;
+    }
+    constexpr int PR = 64 + 4;  // floats per patch row (272 B)
+    float *patch = reinterpret_cast<float *>(scratch) + wid * (16 * PR);
+    const bool vec_ok = (g.Cout % 8 == 0) && (nbase + 64 <= g.Cout) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
+                        (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) patch[(crow + r) * PR + j * 16 + ccol] = acc[i][j][r] + bv[j];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
+            const int m = mw0 + i * 16 + prow;
+            if (m < M) {
+                const float4 lo = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 8]);
+                const float4 hi = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 8 + 4]);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const size_t o = (size_t)m * g.Cout + nbase + pch * 8;
+                if (vec_ok) {
+                    if (g.res) {
+                        const uint4 rv = *reinterpret_cast<const uint4 *>(g.res + o);
+                        const unsigned rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += from16<BF16>((unsigned short)(rr[e] & 0xffffu));
+                            v[2 * e + 1] += from16<BF16>((unsigned short)(rr[e] >> 16));
+                        }
+                    }
+                    unsigned pk[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = g.relu_out ? fmaxf(v[2 * e], 0.0f) : v[2 * e];
+                        const float a1 = g.relu_out ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
+                        pk[e] = (unsigned)to16<BF16>(a0) | ((unsigned)to16<BF16>(a1) << 16);
+                    }
+                    *reinterpret_cast<uint4 *>(g.out + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (nbase + pch * 8 + e < g.Cout) {
+                            float a = v[e] + (g.res ? from16<BF16>(g.res[o + e]) : 0.0f);
+                            if (g.relu_out) a = fmaxf(a, 0.0f);
+                            g.out[o + e] = to16<BF16>(a);
+                        }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
-template <bool BF16>
-__device__ __forceinline__ float from16(unsigned short h) {
-    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
-    else return (float)*reinterpret_cast<_Float16 *>(&h);
-}
 
-// max(x, 0) on two packed 16-bit floats (f16 or bf16): clear every half whose sign bit is set
-__device__ __forceinline__ unsigned relu2(unsigned x) {
-    const unsigned m = ((x >> 15) & 0x00010001u) * 0xFFFFu;
-    return x & ~m;
-}
+// ---- 256 x 256 x 64 implicit-GEMM variant on the phase-interleaved main loop of gemm256.h (Cout tile 256, one tap x 64
+// input channels per K-tile; needs Cin = 64 << cshift).  Only the staging differs from the GEMM: per staged row the source
+// is the tap-shifted pixel's 128-byte channel slice, or the zero page outside the image. ----
+struct ConvStager256 {
+    const unsigned short *in;
+    const unsigned short *pw[2][2];  // [B_h][round]
+    int pix[2][2];                   // [A_h][round] linear input pixel of the centre tap
+    unsigned yx[2][2];               // packed (y << 16 | x) of the centre tap in input coordinates; 0x7fff0000 = row past M
+    int chunk[2];                    // source 16-byte chunk per round
+    int Cin, Hin, Win, cshift;
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
+        if (u < 2) {
+            const int tap = kt >> cshift, kc = kt & ((1 << cshift) - 1);
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int shift = dy * Win + dx;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = (int)(yx[u][j] >> 16) + dy, x = (int)(yx[u][j] & 0xffffu) + dx;
+                const bool ok = (unsigned)y < (unsigned)Hin && (unsigned)x < (unsigned)Win;
+                const unsigned short *src = ok ? in + ((size_t)(pix[u][j] + shift) * Cin + kc * 64 + chunk[j] * 8)
+                                               : vs_zero_page + chunk[j] * 8;
+                glds16(src, lds + j * 1024u);
+            }
+        } else {
+            glds16(pw[u - 2][0] + kt * 64, lds);
+            glds16(pw[u - 2][1] + kt * 64, lds + 1024u);
+        }
+    }
+};
 
-// XOR swizzle of the 16-byte chunk index inside a 64-byte LDS row (see gemm.hip)
-__device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
-__device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
+template <bool BF16, bool RELU_IN>
+__global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, const int cshift) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int HW = g.H * g.W;
+    const int M = g.Nimg * HW;
+    const int K = 9 * g.Cin;
+    const int tiles_n = (g.Cout + 255) / 256;
+    const int tiles_m = (M + 255) / 256;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    ConvStager256 st;
+    st.in = g.in; st.Cin = g.Cin; st.Hin = g.Hin; st.Win = g.Win; st.cshift = cshift;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = unit_row256(wid, j, lane);
+        st.chunk[j] = unit_src_chunk256(q, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + unit_a_tile_row256(q, h);
+            const int p = m < M ? m : 0;
+            const int nimg = p / HW, rem = p - nimg * HW;
+            const int y = (rem / g.W) * g.stride, x = (rem % g.W) * g.stride;
+            st.pix[h][j] = (nimg * g.Hin + y) * g.Win + x;
+            st.yx[h][j] = m < M ? ((unsigned)y << 16) | (unsigned)x : 0x7fff0000u;
+            const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.Cout - 1);
+            st.pw[h][j] = g.w + (size_t)rw_ * K + st.chunk[j] * 8;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256<BF16, RELU_IN>(st, K / 64, acc, smem, lane, wid);
+    conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
 }
 
 template <bool BF16, int MI>
@@ -181,63 +279,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
 #undef VS_STAGE
     __syncthreads();
 
-    // epilogue: per-wave 16 x 64 slabs transposed through LDS -> 16-byte row chunks (see gemm.hip)
-    const int ccol = lane & 15, crow = (lane >> 4) * 4;
-    float bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + ccol;
-        bv[j] = (g.bias && n < g.Cout) ? g.bias[n] : 0.0f;
-    }
-    const int nbase = n0 + wc * 64;
-    constexpr int PR = 64 + 8;
-    unsigned short *patch = sA + wid * (16 * PR);
-    const bool vec_ok = (g.Cout % 8 == 0) && (nbase + 64 <= g.Cout) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
-                        (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        if (!g.res) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if (g.relu_out) v = fmaxf(v, 0.0f);
-                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
-                }
-        } else {  // keep f32 until the residual is added: stage as two 16-bit halves is lossy -> add residual here
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wr * (16 * MI) + i * 16 + crow + r;
-                    const int n = nbase + j * 16 + ccol;
-                    float v = acc[i][j][r] + bv[j];
-                    if (m < M && n < g.Cout) v += from16<BF16>(g.res[(size_t)m * g.Cout + n]);
-                    if (g.relu_out) v = fmaxf(v, 0.0f);
-                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
-            const int m = m0 + wr * (16 * MI) + i * 16 + prow;
-            if (m < M) {
-                unsigned short *dst = g.out + (size_t)m * g.Cout + nbase + pch * 8;
-                const uint4 val = *reinterpret_cast<const uint4 *>(&patch[prow * PR + pch * 8]);
-                if (vec_ok) {
-                    *reinterpret_cast<uint4 *>(dst) = val;
-                } else {
-                    const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (nbase + pch * 8 + e < g.Cout) dst[e] = hv[e];
-                }
-            }
-        }
-        __syncthreads();
-    }
+    conv_epilogue<BF16, MI>(g, acc, m0 + wr * (16 * MI), n0 + wc * 64, M, smem, wid, lane);
 }
 
 // ---- bilinear x2, align_corners=True, NHWC 16-bit; optional fused "+ add" (gs head: up2(trunk) + image features) ----
@@ -309,8 +351,25 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
                Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride};
     const long long M = (long long)Nimg * H * W;
+    static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
+    int cshift = -1;
+    for (int sft = 0; sft < 4; ++sft)
+        if (Cin == (64 << sft)) cshift = sft;
+    const long long t256 = vs::cdiv64(M, 256) * vs::cdiv(Cout, 256);
+    if (force != 8 && force != 4 && cshift >= 0 && Cout % 256 == 0 && (9 * Cin / 64) % 2 == 0 && t256 >= 224) {
+        dim3 grid((unsigned)t256), block(512);
+        if (dtype == 2) {
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<true, true>), grid, block, 0, stream, g, cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<true, false>), grid, block, 0, stream, g, cshift);
+        } else {
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<false, true>), grid, block, 0, stream, g, cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<false, false>), grid, block, 0, stream, g, cshift);
+        }
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     const long long big = vs::cdiv64(M, 256) * vs::cdiv(Cout, BN);
-    if (big >= 256) {
+    if ((big >= 256 || force == 8) && force != 4) {
         dim3 grid((unsigned)big);
         if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<true, 8>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<false, 8>), grid, dim3(256), 0, stream, g);

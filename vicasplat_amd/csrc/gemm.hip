@@ -133,12 +133,13 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
     gemm_epilogue<BF16, EPI, MI>(g, acc, m0 + wr * (16 * MI), n0 + wc * 64, smem, wid, lane);
 }
 
-// ---- small-M path (camera-token GEMMs: M = B*T rows).  Weight-streaming bound: one workgroup per 16 output columns,
-// its 4 waves split K, fragments come straight from global memory (A is tiny and L2-resident, W is read exactly once),
+// ---- small-M path (camera-token GEMMs: M = B*T rows; and the <= 64 leftover rows of a split GEMM).  Latency bound:
+// one workgroup per 16 output columns, its NW waves split K into contiguous ranges and walk them 4 k-steps at a time
+// with all 20 fragment loads of a batch in flight (A is tiny and L2-resident, W is read exactly once per launch);
 // partial sums meet in LDS, then the same fused epilogues. ----
-template <bool BF16, int EPI>
-__global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
-    __shared__ float red[4][4][256];  // [wave][m-frag][16x16]
+template <bool BF16, int EPI, int NW>
+__global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) {
+    __shared__ float red[NW][4][256];  // [wave][m-frag][16x16]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const int frow = lane & 15, fg = lane >> 4;
@@ -157,7 +158,25 @@ __global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
     const int ksteps = g.K / 32;
-    for (int ks = wid; ks < ksteps; ks += 4) {
+    const int per = (ksteps + NW - 1) / NW;
+    const int ks0 = wid * per, ks1 = min(ks0 + per, ksteps);
+    int ks = ks0;
+    for (; ks + 4 <= ks1; ks += 4) {
+        uint4 fb[4], fa[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            fb[u] = *reinterpret_cast<const uint4 *>(pw + (ks + u) * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < mfr) fa[u][i] = *reinterpret_cast<const uint4 *>(pa[i] + (ks + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < mfr) acc[i] = mfma<BF16>(fa[u][i], fb[u], acc[i]);
+    }
+    for (; ks < ks1; ++ks) {
         const uint4 fb = *reinterpret_cast<const uint4 *>(pw + ks * 32);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -173,10 +192,12 @@ __global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wid][i][(fg * 4 + r) * 16 + frow] = acc[i][r];
     __syncthreads();
-    for (int e = tid; e < mfr * 256; e += 256) {
+    for (int e = tid; e < mfr * 256; e += 64 * NW) {
         const int i = e >> 8, rc = e & 255, m = g.m_lo + i * 16 + (rc >> 4), n = n0 + (rc & 15);
         if (m >= g.M || n >= g.N) continue;
-        float v = red[0][i][rc] + red[1][i][rc] + red[2][i][rc] + red[3][i][rc] + (g.bias ? g.bias[n] : 0.0f);
+        float v = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][i][rc];
         const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
         if constexpr (EPI == 0) {
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
@@ -193,17 +214,26 @@ __global__ void __launch_bounds__(256) gemm_smallm_kernel(const GemmArgs g) {
     }
 }
 
-template <bool BF16>
-int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
-    dim3 grid(vs::cdiv(g.N, 16)), block(256);
+template <bool BF16, int NW>
+int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
+    dim3 grid(vs::cdiv(g.N, 16)), block(64 * NW);
     switch (epi) {
-        case 0: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 0>), grid, block, 0, stream, g); break;
-        case 1: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 1>), grid, block, 0, stream, g); break;
-        case 2: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 2>), grid, block, 0, stream, g); break;
-        case 3: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 3>), grid, block, 0, stream, g); break;
+        case 0: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 0, NW>), grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 1, NW>), grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 2, NW>), grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 3, NW>), grid, block, 0, stream, g); break;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
+}
+
+template <bool BF16>
+int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
+    // enough waves per workgroup that each walks at most ~8 k-steps; more waves when few column blocks fill the chip
+    const int ksteps = g.K / 32;
+    if (ksteps >= 64) return launch_smallm_nw<BF16, 16>(g, epi, stream);
+    if (ksteps >= 24) return launch_smallm_nw<BF16, 8>(g, epi, stream);
+    return launch_smallm_nw<BF16, 4>(g, epi, stream);
 }
 
 template <bool BF16, int MI>

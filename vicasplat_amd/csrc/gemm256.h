@@ -22,60 +22,34 @@
 
 namespace {
 
-template <bool BF16, int EPI>
-__global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
-    constexpr int BM2 = 256, BN2 = 256;
-    constexpr unsigned UNITB = 128 * 128;  // bytes per staged unit
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * UNITB];  // [slot][A0 A1 B0 B1]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+constexpr unsigned kUnitBytes256 = 128 * 128;           // one staged unit: 128 rows x 128 B
+constexpr unsigned kLdsBytes256 = 2 * 4 * kUnitBytes256;  // [ring slot][A0 A1 B0 B1] = 128 KiB
+
+// Staged-unit row q (0..127) of wave `wid`, LDS-DMA round j, lane: which tile row it holds and which 16-byte chunk of
+// the source row this lane must fetch so that the data lands XOR-swizzled.
+__device__ __forceinline__ int unit_row256(int wid, int j, int lane) { return wid * 16 + j * 8 + (lane >> 3); }
+__device__ __forceinline__ int unit_src_chunk256(int q, int lane) { return (lane & 7) ^ ((q >> 1) & 7); }
+__device__ __forceinline__ int unit_a_tile_row256(int q, int h) { return (q >> 6) * 128 + h * 64 + (q & 63); }
+__device__ __forceinline__ int unit_b_tile_row256(int q, int h) { return (q >> 5) * 64 + h * 32 + (q & 31); }
+
+// The K loop.  `st.stage(u, kt, lds_byte_offset)` issues this wave's two global_load_lds_dwordx4 for unit u (0 A_0, 1 A_1,
+// 2 B_0, 3 B_1) of K-tile kt; RELU_A clamps the A fragments at zero on their way to the MFMA (conv: activation-before-conv).
+template <bool BF16, bool RELU_A, class Stager>
+__device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[8][4], const unsigned char *smem, const int lane,
+                                            const int wid) {
+    constexpr unsigned UNITB = kUnitBytes256;
     const int wr = wid >> 2, wc = wid & 3;
-
-    const int tiles_n = (g.N + BN2 - 1) / BN2;
-    const int tiles_m = (g.M - g.m_lo + BM2 - 1) / BM2;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = g.m_lo + tm * BM2, n0 = tn * BN2;
-
-    // ---- staging addresses: lane l of (wave w, round j) fills LDS row q = w*16 + j*8 + (l>>3), slot l&7 of a unit ----
-    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
-    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
-    const unsigned short *pu[4][2];  // [A0 A1 B0 B1][round]
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = wid * 16 + j * 8 + (lane >> 3);
-        const int src_chunk = (lane & 7) ^ ((q >> 1) & 7);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ra_ = min(m0 + (q >> 6) * 128 + h * 64 + (q & 63), g.M - 1);
-            const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
-            pu[h][j] = A + arow * g.lda + src_chunk * 8;
-            const int rw_ = min(n0 + (q >> 5) * 64 + h * 32 + (q & 31), g.N - 1);
-            pu[2 + h][j] = W + (size_t)rw_ * g.ldw + src_chunk * 8;
-        }
-    }
     typedef void __attribute__((address_space(3))) *lptr_t;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wid * 2048u);
-#define VS_STAGE(u_, kt_, d_)                                                            \
-    {                                                                                    \
-        glds16(pu[u_][0] + (kt_) * 64, lds_w + (unsigned)(((d_) * 4 + (u_)) * UNITB));        \
-        glds16(pu[u_][1] + (kt_) * 64, lds_w + (unsigned)(((d_) * 4 + (u_)) * UNITB) + 1024u); \
-    }
+#define VS_STAGE(u_, kt_, d_) st.stage(u_, kt_, lds_w + (unsigned)(((d_) * 4 + (u_)) * UNITB));
 
-    // ---- fragment read addresses ----
     const int frow = lane & 15, fg = lane >> 4;
     const unsigned rd0 = (unsigned)(frow * 128 + (((0 + fg) ^ (frow >> 1)) << 4));
     const unsigned rd1 = (unsigned)(frow * 128 + (((4 + fg) ^ (frow >> 1)) << 4));
     const unsigned char *rdA = smem + wr * (64 * 128);
     const unsigned char *rdB = smem + wc * (32 * 128);
     uint4 fa[4][2], fb[2][2][2];
-    f4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -91,6 +65,14 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
         fb[h_][j][0] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd0);   \
         fb[h_][j][1] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd1);   \
     }
+#define VS_RELU_A()                                                                                              \
+    if constexpr (RELU_A) {                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                   \
+                fa[i][s_].x = relu2(fa[i][s_].x); fa[i][s_].y = relu2(fa[i][s_].y);                              \
+                fa[i][s_].z = relu2(fa[i][s_].z); fa[i][s_].w = relu2(fa[i][s_].w);                              \
+            }                                                                                                    \
+    }
 #define VS_MM(ha_, hb_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
@@ -103,10 +85,11 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_barrier();             \
         __builtin_amdgcn_sched_barrier(0);        \
     }
-#define VS_COMPUTE(ha_, hb_)                      \
+#define VS_COMPUTE(ha_, hb_, relu_)               \
     {                                             \
         VS_BAR()                                  \
         __builtin_amdgcn_s_setprio(1);            \
+        if (relu_) VS_RELU_A()                    \
         VS_MM(ha_, hb_)                           \
         __builtin_amdgcn_s_setprio(0);            \
         VS_BAR()                                  \
@@ -117,18 +100,18 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
     {                                                                             \
         VS_RD_B(0, d_) VS_RD_A(0, d_)                                             \
         if (MODE_ <= 1) { VS_STAGE(3, (kt_) + 1, (d_) ^ 1) VS_WAIT(8) } else { VS_WAIT(2) } \
-        VS_COMPUTE(0, 0)                                                          \
+        VS_COMPUTE(0, 0, true)                                                    \
         VS_RD_B(1, d_)                                                            \
         if (MODE_ <= 1) { VS_STAGE(1, (kt_) + 1, (d_) ^ 1) VS_WAIT(8) } else { VS_WAIT(0) } \
-        VS_COMPUTE(0, 1)                                                          \
+        VS_COMPUTE(0, 1, false)                                                   \
         VS_RD_A(1, d_)                                                            \
         if (MODE_ == 0) VS_STAGE(0, (kt_) + 2, d_)                                \
-        VS_COMPUTE(1, 1)                                                          \
+        VS_COMPUTE(1, 1, true)                                                    \
         if (MODE_ == 0) { VS_STAGE(2, (kt_) + 2, d_) VS_WAIT(8) } else if (MODE_ == 1) { VS_WAIT(4) } \
-        VS_COMPUTE(1, 0)                                                          \
+        VS_COMPUTE(1, 0, false)                                                   \
     }
 
-    const int KT = g.K / 64;  // even, >= 2 (checked by the launcher)
+    // KT is even and >= 2 (checked by the launchers)
     VS_STAGE(0, 0, 0) VS_STAGE(2, 0, 0) VS_STAGE(3, 0, 0) VS_STAGE(1, 0, 0) VS_STAGE(0, 1, 1) VS_STAGE(2, 1, 1)
     VS_WAIT(8)
     VS_BAR()
@@ -145,10 +128,58 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
 #undef VS_COMPUTE
 #undef VS_BAR
 #undef VS_MM
+#undef VS_RELU_A
 #undef VS_RD_B
 #undef VS_RD_A
 #undef VS_STAGE
-    __syncthreads();  // every wave is done with the ring before the epilogue reuses it
+    __syncthreads();  // every wave is done with the ring before an epilogue reuses it
+}
+
+struct GemmStager256 {
+    const unsigned short *pu[4][2];  // [A0 A1 B0 B1][round]
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
+        glds16(pu[u][0] + kt * 64, lds);
+        glds16(pu[u][1] + kt * 64, lds + 1024u);
+    }
+};
+
+template <bool BF16, int EPI>
+__global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int tiles_m = (g.M - g.m_lo + BM2 - 1) / BM2;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = g.m_lo + tm * BM2, n0 = tn * BN2;
+
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
+    GemmStager256 st;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = unit_row256(wid, j, lane);
+        const int src_chunk = unit_src_chunk256(q, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ra_ = min(m0 + unit_a_tile_row256(q, h), g.M - 1);
+            const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+            st.pu[h][j] = A + arow * g.lda + src_chunk * 8;
+            const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.N - 1);
+            st.pu[2 + h][j] = W + (size_t)rw_ * g.ldw + src_chunk * 8;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256<BF16, false>(st, g.K / 64, acc, smem, lane, wid);
     gemm_epilogue<BF16, EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 

@@ -46,6 +46,32 @@ __device__ __forceinline__ unsigned short to16(float v) {
     }
 }
 
+template <bool BF16>
+__device__ __forceinline__ float from16(unsigned short h) {
+    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
+    else return (float)*reinterpret_cast<_Float16 *>(&h);
+}
+
+// max(x, 0) on two packed 16-bit floats (f16 or bf16): clear every half whose sign bit is set
+__device__ __forceinline__ unsigned relu2(unsigned x) {
+    const unsigned m = ((x >> 15) & 0x00010001u) * 0xFFFFu;
+    return x & ~m;
+}
+
+// exact-erf GELU (croco/blocks.py:60,68 uses nn.GELU()): erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the
+// 16-bit output's rounding) on v_rcp/v_exp instead of libm's branchy erff, because in a one-workgroup-per-CU kernel the
+// epilogue is not hidden behind another workgroup's MFMAs.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-x * x);  // erf(|v|/sqrt2)
+    return 0.5f * v * (1.0f + copysignf(e, v));
+}
+
 // XOR swizzle of the 16-byte chunk index (0..3) inside a 64-byte LDS row, keyed on (row >> 2) & 3, chosen so that the
 // four 16-lane service groups of ds_read_b128 each touch 16 distinct 16-byte slots of a 256-byte bank row.
 __device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // f = {0,2,3,1}
@@ -82,7 +108,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bv[j];
-                    if constexpr (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if constexpr (EPI == 1) v = gelu_erf(v);
                     patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
                 }
             __syncthreads();
