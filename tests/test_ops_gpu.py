@@ -318,6 +318,23 @@ def test_conv3x3_nhwc_implicit_gemm(dt, N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,Cout", [(2, 32, 32, 128), (1, 37, 50, 64), (3, 256, 256, 128)])
+def test_conv7x7_rgb_stem(dt, N, H, W, Cout):
+    """gs-head input_merger conv (3 -> C, k=7, p=3) as a window GEMM over the zero-bordered NHWC image."""
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(H + Cout)
+    x = torch.randn(N, 3, H, W, device=d)
+    conv = torch.nn.Conv2d(3, Cout, 7, 1, 3).to(d)
+    with torch.no_grad():
+        ref = F.conv2d(x.to(dt).float(), conv.weight.to(dt).float(), conv.bias, padding=3)
+        out = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(x, dt), ops.pack_conv7x7_rgb_weight(conv.weight, dt), conv.bias.float(), H, W)
+    assert out.shape == (N, H, W, Cout)
+    rtol = 2e-3 if dt == torch.float16 else 1.2e-2
+    assert (out.permute(0, 3, 1, 2).float() - ref).abs().max() <= rtol * ref.abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_upsample2x_nhwc(dt):
     from vicasplat_amd import ops
     d = _dev()

@@ -17,6 +17,8 @@
 // the A-operand layout of the P.V MFMA (keys permuted consistently on the V side).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -66,11 +68,11 @@ __device__ __forceinline__ unsigned short to16(float v) {
 }
 
 // QG = 16-query MFMA groups per wave (1 -> 64 queries per workgroup, 2 -> 128): more MFMAs per staged K/V tile.
-template <bool BF16, int QG>
-__global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
+template <bool BF16, int QG, int WPE>
+__global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
     constexpr int QBLK = 64 * QG;
-    __shared__ __attribute__((aligned(16))) unsigned short sK[KB * KROW];
-    __shared__ __attribute__((aligned(16))) unsigned short sVT[HD * VROW];
+    __shared__ __attribute__((aligned(16))) unsigned short sK2[2][KB * KROW];   // two-tile ring: one barrier per tile
+    __shared__ __attribute__((aligned(16))) unsigned short sVT2[2][HD * VROW];
     __shared__ int s_maxlen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
@@ -104,6 +106,14 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
     }
 #pragma unroll
     for (int o_ = 32; o_ > 0; o_ >>= 1) wave_len = max(wave_len, __shfl_xor(wave_len, o_, 64));  // wave-uniform
+    int wave_minlen[QG];  // smallest key limit among the group's queries: tiles entirely below it need no masking
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        int mn = my_len[u];
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mn = min(mn, __shfl_xor(mn, o_, 64));
+        wave_minlen[u] = mn;
+    }
     if (tid == 0) s_maxlen = 0;
     __syncthreads();
     if (lane == 0) atomicMax(&s_maxlen, wave_len);
@@ -135,25 +145,34 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
         pva = *reinterpret_cast<const uint4 *>(a.v + key_row(kt + 2 * v_kp) * a.ldv + h * HD + v_c * 8);
         pvb = *reinterpret_cast<const uint4 *>(a.v + key_row(kt + 2 * v_kp + 1) * a.ldv + h * HD + v_c * 8);
     };
-    if (maxlen > 0) gload(0);
-
-    for (int kt = 0; kt < maxlen; kt += KB) {
-        // ---- stage K tile (row-major) and V tile (transposed) from the prefetched registers ----
-        __syncthreads();  // previous tile fully consumed
+    auto lds_store = [&](int buf) {  // K tile row-major, V tile transposed, from the prefetched registers
+        unsigned short *sK = sK2[buf];
         *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk]) = pk0;
         *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk + 8]) = pk1;
-        {
-            const unsigned wa[4] = {pva.x, pva.y, pva.z, pva.w}, wb[4] = {pvb.x, pvb.y, pvb.z, pvb.w};
-            unsigned *vt = reinterpret_cast<unsigned *>(sVT);
+        const unsigned wa[4] = {pva.x, pva.y, pva.z, pva.w}, wb[4] = {pvb.x, pvb.y, pvb.z, pvb.w};
+        unsigned *vt = reinterpret_cast<unsigned *>(sVT2[buf]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vt[((v_c * 8 + 2 * i) * VROW) / 2 + v_kp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
-                vt[((v_c * 8 + 2 * i + 1) * VROW) / 2 + v_kp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
-            }
+        for (int i = 0; i < 4; ++i) {
+            vt[((v_c * 8 + 2 * i) * VROW) / 2 + v_kp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
+            vt[((v_c * 8 + 2 * i + 1) * VROW) / 2 + v_kp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
         }
-        __syncthreads();
-        if (kt + KB < maxlen) gload(kt + KB);
-        if (kt >= wave_len) continue;  // nothing visible to this wave's queries in this tile (prefix-masked rows)
+    };
+    if (maxlen > 0) {
+        gload(0);
+        lds_store(0);
+        if (KB < maxlen) gload(KB);
+    }
+    __syncthreads();
+
+    for (int kt = 0, it = 0; kt < maxlen; kt += KB, ++it) {
+        const unsigned short *sK = sK2[it & 1], *sVT = sVT2[it & 1];
+        // tile kt is in ring slot it&1 (ordered by the barrier that closed the previous iteration); the other slot was
+        // last read during iteration it-1, so tile kt+KB can be written into it now and the loads for kt+2KB issued.
+        if (kt + KB < maxlen) {
+            lds_store((it + 1) & 1);
+            if (kt + 2 * KB < maxlen) gload(kt + 2 * KB);
+        }
+        if (kt >= wave_len) { __syncthreads(); continue; }  // nothing visible to this wave's queries in this tile
         // K fragments are shared by the wave's query groups
         uint4 kf[4][2];
 #pragma unroll
@@ -171,41 +190,47 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) st[nb] = mfma<BF16>(kf[nb][ks], qf[u][ks], st[nb]);
             }
-            float mx = -INFINITY;
+            // The softmax is the VALU bottleneck of this kernel (16 scores per lane per group against 16 MFMAs), so it is
+            // kept to max / fma / v_exp_f32 / add per score: the scale is folded into the exponent fma, the prefix mask is
+            // applied only on the tile that straddles a query's key limit, exp2 is the raw hardware instruction (inputs
+            // are <= 0 or -inf: no denormal fix-up needed), and the O rescale is skipped while no lane's max moves.
+            if (kt + KB > wave_minlen[u]) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+                for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + nb * 16 + g * 4 + r;
-                    float sv = st[nb][r] * a.scale_log2e;
-                    sv = key < my_len[u] ? sv : -INFINITY;
-                    st[nb][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+                    for (int r = 0; r < 4; ++r)
+                        if (kt + nb * 16 + g * 4 + r >= my_len[u]) st[nb][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+            for (int nb = 1; nb < 4; ++nb) mx = fmaxf(fmaxf(mx, fmaxf(st[nb][0], st[nb][1])), fmaxf(st[nb][2], st[nb][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[u], mx);
+            const float m_new = fmaxf(m_run[u], mx * a.scale_log2e);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run[u] - m_use);
             float rs = 0.f;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(st[nb][r] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[nb][r], a.scale_log2e, -m_use));
                     st[nb][r] = p;
                     rs += p;
                 }
             rs += __shfl_xor(rs, 16, 64);
             rs += __shfl_xor(rs, 32, 64);
-            l_run[u] = l_run[u] * alpha + rs;
-            m_run[u] = m_new;
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[u]) != 0) {  // wave-uniform: some query's running max moved
+                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
+                l_run[u] *= alpha;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ar = __shfl(alpha, g * 4 + r, 64);
+                for (int r = 0; r < 4; ++r) {
+                    const float ar = __shfl(alpha, g * 4 + r, 64);
 #pragma unroll
-                for (int db = 0; db < 4; ++db) o[u][db][r] *= ar;
+                    for (int db = 0; db < 4; ++db) o[u][db][r] *= ar;
+                }
+                m_run[u] = m_new;
             }
+            l_run[u] += rs;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 pf[u][ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
@@ -227,6 +252,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
                 for (int u = 0; u < QG; ++u) o[u][db] = mfma<BF16>(pf[u][ks], vf, o[u][db]);
             }
         }
+        __syncthreads();
     }
 
     // ---- epilogue: O rows q = g*4 + r, cols d = db*16 + c16 ----
@@ -267,17 +293,26 @@ extern "C" int vs_attention(const void *q, const void *k, const void *v, void *o
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.scale_log2e = scale * 1.4426950408889634f;
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; else 64
-    const bool big = (long long)vs::cdiv(Lq, 128) * H * nbatch >= 512;
+    static const int force_qg = [] { const char *e = getenv("VS_ATTN_QG"); return e ? atoi(e) : 0; }();
+    static const int force_wpe = [] { const char *e = getenv("VS_ATTN_WPE"); return e ? atoi(e) : 0; }();
+    // 128 queries per workgroup only for long key sequences (more MFMAs per staged tile); the 257/516-key shapes are
+    // latency bound and run faster with 64-query workgroups at higher occupancy
+    const int Lk_eff = kv_seg ? 2 * Lk : Lk;
+    bool big = (long long)vs::cdiv(Lq, 128) * H * nbatch >= 512 && Lk_eff > 1024;
+    if (force_qg) big = force_qg == 2;
     dim3 block(256);
-    if (big) {
-        dim3 grid(vs::cdiv(Lq, 128), H, nbatch);
-        if (dtype == 2) hipLaunchKernelGGL((attention_kernel<true, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((attention_kernel<false, 2>), grid, block, 0, stream, a);
-    } else {
-        dim3 grid(vs::cdiv(Lq, 64), H, nbatch);
-        if (dtype == 2) hipLaunchKernelGGL((attention_kernel<true, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((attention_kernel<false, 1>), grid, block, 0, stream, a);
+#define VS_LAUNCH(QG_, WPE_)                                                                                   \
+    {                                                                                                          \
+        dim3 grid(vs::cdiv(Lq, 64 * QG_), H, nbatch);                                                          \
+        if (dtype == 2) hipLaunchKernelGGL((attention_kernel<true, QG_, WPE_>), grid, block, 0, stream, a);    \
+        else hipLaunchKernelGGL((attention_kernel<false, QG_, WPE_>), grid, block, 0, stream, a);              \
     }
+    if (big) {
+        if (force_wpe == 2) VS_LAUNCH(2, 2) else VS_LAUNCH(2, 3)
+    } else {
+        if (force_wpe == 2) VS_LAUNCH(1, 2) else VS_LAUNCH(1, 4)
+    }
+#undef VS_LAUNCH
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
 #pragma unroll
     for (int i = 0; i < MI / 2; ++i) {
         const int ra_ = min(m0 + (wid * (MI / 2) + i) * 16 + rho, g.M - 1);
-        const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+        const int rg_ = ra_ / g.a_grp_in;
+        const size_t arow = (size_t)rg_ * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in) + (size_t)(rg_ / g.a_sup_in) * g.a_sup_extra;
         pa[i] = A + arow * g.lda + gchunk * 8;
     }
 #pragma unroll
@@ -72,7 +73,6 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         const int rw_ = min(n0 + (wid * 2 + i) * 16 + rho, g.N - 1);
         pw[i] = W + (size_t)rw_ * g.ldw + gchunk * 8;
     }
-    typedef const void __attribute__((address_space(1))) *gptr_t;
     typedef void __attribute__((address_space(3))) *lptr_t;
 
     f4 acc[MI][4];
@@ -89,8 +89,9 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
 #define VS_STAGE(kt_, slot_)                                                                                   \
     {                                                                                                          \
         const int k0_ = (kt_) * 32;                                                                            \
+        const long long ka_ = (long long)(kt_) * g.a_kstride;                                                  \
         _Pragma("unroll") for (int i = 0; i < MI / 2; ++i)                                                     \
-            glds16(pa[i] + k0_, ldsA + (unsigned)((slot_) * (BM * 32 * 2) + i * 1024));                        \
+            glds16(pa[i] + ka_, ldsA + (unsigned)((slot_) * (BM * 32 * 2) + i * 1024));                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
             glds16(pw[i] + k0_, ldsW + (unsigned)((slot_) * (BN * 32 * 2) + i * 1024));                        \
     }
@@ -337,7 +338,39 @@ extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias,
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
     const int rc = dtype == 2 ? launch<true>(g, epilogue, stream) : launch<false>(g, epilogue, stream);
+    if (rc) return rc;
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// 7x7 stride-1 pad-3 convolution of an RGB image (the gs head's input_merger, heads/dpt_gs_head.py:112-118) as a window
+// GEMM on gemm_kernel: with a zero-padded NHWC image [Nimg, Hp, Wp, 3] the 7 horizontal taps x 3 channels of one kernel
+// row are 21 CONTIGUOUS halfs starting at padded pixel (y+dy, x), so k-step dy of output pixel (y, x) is the 32-half slice
+// at that address (LDS-DMA takes any 2-byte-aligned source; the 11 trailing halfs are finite image data multiplied by zero
+// weights).  M = Nimg*H*W pixels, N = Cout, K = 7 x 32; no im2col buffer, bias fused.
+extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const float *bias, void *out, int32_t Nimg, int32_t H,
+                                   int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in_padded && w && out, "vs_conv7x7_rgb_nhwc: null pointer");
+    VS_CHECK(Nimg >= 0 && H > 0 && W > 0 && Cout > 0, "vs_conv7x7_rgb_nhwc: bad sizes");
+    VS_CHECK(Hp >= H + 6 && Wp >= W + 6, "vs_conv7x7_rgb_nhwc: padded image must be at least (H+6) x (W+6), got %d x %d", Hp, Wp);
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_conv7x7_rgb_nhwc: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK((long long)Nimg * H * W < 2147483647LL && (long long)Nimg * Hp * Wp * 3 < 2147483647LL, "vs_conv7x7_rgb_nhwc: too large");
+    VS_CHECK((reinterpret_cast<uintptr_t>(w) & 15) == 0, "vs_conv7x7_rgb_nhwc: w must be 16-byte aligned");
+    if (Nimg == 0) return 0;
+    GemmArgs g;
+    g.A = in_padded; g.W = w; g.bias = bias; g.out = out; g.gate = nullptr;
+    g.M = Nimg * H * W; g.N = Cout; g.K = 7 * 32;
+    g.lda = 3; g.ldw = 7 * 32; g.ldo = Cout;
+    g.grp_in = g.M; g.grp_out = g.M; g.grp_off = 0;
+    g.gate_rows = g.M; g.gate_ld = Cout;
+    g.m_lo = 0;
+    g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
+    g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
+    g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
+    const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;

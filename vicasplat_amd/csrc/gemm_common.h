@@ -23,6 +23,9 @@ struct GemmArgs {
     int gate_ld;
     int m_lo;  // first logical row this launch covers (rows [m_lo, M)); tail launches of a split GEMM start past 0
     int a_grp_in, a_grp_out, a_grp_off;  // INPUT row map: A row of m = (m / a_grp_in) * a_grp_out + a_grp_off + m % a_grp_in
+    // window-GEMM extras (7x7 RGB stem, gemm_kernel only): every a_sup_in row groups skip a_sup_extra more A rows (image
+    // padding rows), and k-step kt reads its 32-wide slice at element offset kt * a_kstride (next image row), not kt * 32
+    int a_sup_in, a_sup_extra, a_kstride;
 };
 
 template <bool BF16>

@@ -174,8 +174,8 @@ class PixelwiseTaskWithDPT(nn.Module):
         P = self._packed()
         if "stem.w" not in P:
             c = self.dpt.input_merger[0]
-            P["stem.w"] = c.weight.detach().to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
-            P["stem.b"] = c.bias.detach().to(self.compute_dtype)
+            P["stem.w"] = ops.pack_conv7x7_rgb_weight(c.weight, self.compute_dtype)
+            P["stem.b"] = c.bias.detach().float().contiguous()
         return P["stem.w"], P["stem.b"]
 
     @staticmethod
@@ -243,13 +243,10 @@ class PixelwiseTaskWithDPT(nn.Module):
         x, P = self._trunk(tokens, gh, gw)
         d = self.dpt
         dt = self.compute_dtype
-        # 7x7 stem on the RGB image: MIOpen, channels-last in and out (the NHWC view is then free); its ReLU is fused into
-        # the upsample-add kernel
+        # 7x7 stem on the RGB image (dpt_gs_head.py:112-118): window GEMM on the zero-bordered NHWC frames, bias fused; its
+        # ReLU is fused into the upsample-add kernel below
         P7 = self._stem_weights()
-        img = F.conv2d(frames.to(dt).contiguous(memory_format=torch.channels_last), P7[0], P7[1], padding=3)
-        img = img.permute(0, 2, 3, 1)
-        if not img.is_contiguous():
-            img = img.contiguous()
+        img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
         x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
         x = ops.conv3x3_nhwc(x, P["h0.w"], None, relu_out=True)  # Dropout(0.1) is the identity at inference
         y = self._gemm1x1(x, P, "h4")

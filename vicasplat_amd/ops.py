@@ -148,6 +148,42 @@ def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: int = 0) -
     return wp.to(dtype).contiguous()
 
 
+def pack_conv7x7_rgb_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """nn.Conv2d(3, Cout, 7) weight [Cout,3,7,7] -> [Cout, 7, 32] with w[co, dy, dx*3 + c] and zeros in 21..31."""
+    Cout = w.shape[0]
+    assert w.shape == (Cout, 3, 7, 7)
+    wp = torch.zeros(Cout, 7, 32, dtype=dtype, device=w.device)
+    wp[:, :, :21] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 7, 21).to(dtype)
+    return wp.contiguous()
+
+
+def pad_rgb_nhwc(frames: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """frames [N,3,H,W] -> zero-bordered NHWC 16-bit image [N, H+6, W+8, 3] (3 before, 3/5 after) for conv7x7_rgb_nhwc;
+    the storage carries 64 spare halfs behind the last pixel (the last window slices read past it)."""
+    N, C, H, W = frames.shape
+    assert C == 3
+    Hp, Wp = H + 6, W + 8
+    flat = torch.zeros(N * Hp * Wp * 3 + 64, dtype=dtype, device=frames.device)
+    img = flat[:N * Hp * Wp * 3].view(N, Hp, Wp, 3)
+    img[:, 3:3 + H, 3:3 + W] = frames.permute(0, 2, 3, 1)
+    return img
+
+
+def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], H: int, W: int) -> torch.Tensor:
+    """img_padded from pad_rgb_nhwc, w from pack_conv7x7_rgb_weight -> [N,H,W,Cout] = conv2d(k=7, s=1, p=3) + bias."""
+    dev = L.require_device(img_padded, w, bias)
+    N, Hp, Wp, C = img_padded.shape
+    Cout = w.shape[0]
+    assert C == 3 and img_padded.is_contiguous() and w.shape == (Cout, 7, 32) and w.is_contiguous() and img_padded.dtype == w.dtype
+    assert img_padded.untyped_storage().nbytes() >= (img_padded.storage_offset() + img_padded.numel() + 16) * 2
+    out = torch.empty((N, H, W, Cout), dtype=w.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_conv7x7_rgb_nhwc(L.ptr(img_padded), L.ptr(w), L.ptr(bias), L.ptr(out), N, H, W, Hp, Wp, Cout,
+                                         _DT[w.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_conv7x7_rgb_nhwc")
+    return out
+
+
 def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_add: bool = False) -> torch.Tensor:
     """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit; optional fused `+ add` / `+ relu(add)`."""
     dev = L.require_device(x, add)
