@@ -138,62 +138,59 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
 // one workgroup per 16 output columns, its NW waves split K into contiguous ranges and walk them 4 k-steps at a time
 // with all 20 fragment loads of a batch in flight (A is tiny and L2-resident, W is read exactly once per launch);
 // partial sums meet in LDS, then the same fused epilogues. ----
-template <bool BF16, int EPI, int NW>
+template <bool BF16, int EPI, int NW, int MF>
 __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) {
-    __shared__ float red[NW][4][256];  // [wave][m-frag][16x16]
+    __shared__ float red[NW][MF][256];  // [wave][m-frag][16x16]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const int frow = lane & 15, fg = lane >> 4;
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
-    const int mfr = (g.M - g.m_lo + 15) / 16;  // 1..4
-    const unsigned short *pa[4];
+    // MF 16-row fragments cover rows [m_lo, m_lo + 16*MF); rows past M are clamped duplicates whose results are dropped
+    const unsigned short *pa[MF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MF; ++i) {
         const int ra_ = min(g.m_lo + i * 16 + frow, g.M - 1);
         const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
         pa[i] = A + arow * g.lda + fg * 8;
     }
     const unsigned short *pw = W + (size_t)min(n0 + frow, g.N - 1) * g.ldw + fg * 8;
-    f4 acc[4];
+    f4 acc[MF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MF; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
     const int ksteps = g.K / 32;
     const int per = (ksteps + NW - 1) / NW;
     const int ks0 = wid * per, ks1 = min(ks0 + per, ksteps);
+    constexpr int U = MF == 4 ? 4 : 8;  // k-steps per batch: (MF + 1) * U 16-byte loads in flight per lane
     int ks = ks0;
-    for (; ks + 4 <= ks1; ks += 4) {
-        uint4 fb[4], fa[4][4];
+    for (; ks + U <= ks1; ks += U) {
+        uint4 fb[U], fa[U][MF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             fb[u] = *reinterpret_cast<const uint4 *>(pw + (ks + u) * 32);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < mfr) fa[u][i] = *reinterpret_cast<const uint4 *>(pa[i] + (ks + u) * 32);
+            for (int i = 0; i < MF; ++i) fa[u][i] = *reinterpret_cast<const uint4 *>(pa[i] + (ks + u) * 32);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < mfr) acc[i] = mfma<BF16>(fa[u][i], fb[u], acc[i]);
+            for (int i = 0; i < MF; ++i) acc[i] = mfma<BF16>(fa[u][i], fb[u], acc[i]);
     }
     for (; ks < ks1; ++ks) {
         const uint4 fb = *reinterpret_cast<const uint4 *>(pw + ks * 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < mfr) {
-                const uint4 fa = *reinterpret_cast<const uint4 *>(pa[i] + ks * 32);
-                acc[i] = mfma<BF16>(fa, fb, acc[i]);
-            }
+        for (int i = 0; i < MF; ++i) {
+            const uint4 fa = *reinterpret_cast<const uint4 *>(pa[i] + ks * 32);
+            acc[i] = mfma<BF16>(fa, fb, acc[i]);
         }
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wid][i][(fg * 4 + r) * 16 + frow] = acc[i][r];
     __syncthreads();
-    for (int e = tid; e < mfr * 256; e += 64 * NW) {
+    for (int e = tid; e < MF * 256; e += 64 * NW) {
         const int i = e >> 8, rc = e & 255, m = g.m_lo + i * 16 + (rc >> 4), n = n0 + (rc & 15);
         if (m >= g.M || n >= g.N) continue;
         float v = g.bias ? g.bias[n] : 0.0f;
@@ -203,7 +200,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
         if constexpr (EPI == 0) {
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
         } else if constexpr (EPI == 1) {
-            v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            v = gelu_erf(v);
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
         } else if constexpr (EPI == 2) {
             float *o = reinterpret_cast<float *>(g.out) + orow * g.ldo + n;
@@ -215,14 +212,14 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
     }
 }
 
-template <bool BF16, int NW>
+template <bool BF16, int NW, int MF>
 int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
     dim3 grid(vs::cdiv(g.N, 16)), block(64 * NW);
     switch (epi) {
-        case 0: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 0, NW>), grid, block, 0, stream, g); break;
-        case 1: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 1, NW>), grid, block, 0, stream, g); break;
-        case 2: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 2, NW>), grid, block, 0, stream, g); break;
-        case 3: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 3, NW>), grid, block, 0, stream, g); break;
+        case 0: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 0, NW, MF>), grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 1, NW, MF>), grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 2, NW, MF>), grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 3, NW, MF>), grid, block, 0, stream, g); break;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -230,11 +227,10 @@ int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
 
 template <bool BF16>
 int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
-    // enough waves per workgroup that each walks at most ~8 k-steps; more waves when few column blocks fill the chip
-    const int ksteps = g.K / 32;
-    if (ksteps >= 64) return launch_smallm_nw<BF16, 16>(g, epi, stream);
-    if (ksteps >= 24) return launch_smallm_nw<BF16, 8>(g, epi, stream);
-    return launch_smallm_nw<BF16, 4>(g, epi, stream);
+    // 16 waves split K when it is long (each walks <= 8 k-steps of 4096), 8 otherwise; 1 or 4 row fragments
+    const bool one = g.M - g.m_lo <= 16, deep = g.K / 32 >= 64;
+    if (one) return deep ? launch_smallm_nw<BF16, 16, 1>(g, epi, stream) : launch_smallm_nw<BF16, 8, 1>(g, epi, stream);
+    return deep ? launch_smallm_nw<BF16, 16, 4>(g, epi, stream) : launch_smallm_nw<BF16, 8, 4>(g, epi, stream);
 }
 
 template <bool BF16, int MI>
