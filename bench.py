@@ -160,39 +160,58 @@ def main():
             S, Pn, Cn, M, H, Wd, _ = st["dims"]
             return dict(bytes=Cn * (Pn * 280.0 + 1.8e6) + st["num_rendered"] * 68.0, R=st["num_rendered"])
 
-        o1 = kt.wrap(ops, "gemm", gemm_meta); o2 = kt.wrap(ops, "attention", attn_meta)
-        o3 = kt.wrap(ops, "layernorm_mod", lambda r, x, *a, **k: dict(bytes=x.numel() * 6.0))
-        o4 = kt.wrap(ops, "rope_qk", lambda r, b, H, kc, *a, **k: dict(bytes=b.shape[0] * 2 * H * 64 * 2 * 2.0))
-        o5 = kt.wrap(raster, "_forward_impl", raster_meta)
+        def conv_meta(r, x, w, *a, **k):
+            return dict(flops=2.0 * r.numel() * w.shape[1] * w.shape[2] * w.shape[3])
+
+        wrapped = [(ops, "gemm", gemm_meta), (ops, "gemm_qkv_rope", gemm_meta), (ops, "attention", attn_meta),
+                   (ops, "layernorm_mod", lambda r, x, *a, **k: dict(bytes=x.numel() * 6.0)),
+                   (ops, "conv3x3_nhwc", conv_meta),
+                   (ops, "conv7x7_rgb_nhwc", lambda r, x, w, *a, **k: dict(flops=2.0 * r.numel() * 147)),
+                   (ops, "upsample2x_nhwc", lambda r, x, *a, **k: dict(bytes=r.numel() * 2.0 * (2.25 if (len(a) or k.get("add") is not None) else 1.25))),
+                   (ops, "gaussian_adapter", lambda r, *a, **k: dict()),
+                   (raster, "_forward_impl", raster_meta)]
+        saved = [(m, n, kt.wrap(m, n, f)) for m, n, f in wrapped]
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); out, r = step(); e.record()
         summ = kt.summary()
-        ops.gemm, ops.attention, ops.layernorm_mod, ops.rope_qk, raster._forward_impl = o1, o2, o3, o4, o5
+        for m, n, o in saved:
+            setattr(m, n, o)
+        zero = dict(ms=0.0, calls=0, flops=0.0, bytes=0.0)
+        for k_ in ("gemm", "gemm_qkv_rope", "conv3x3_nhwc", "conv7x7_rgb_nhwc", "upsample2x_nhwc", "gaussian_adapter"):
+            summ.setdefault(k_, dict(zero))
         tot_ms = s.elapsed_time(e)
-        gm, at, rs = summ["gemm"], summ["attention"], summ["_forward_impl"]
+        # every vs_gemm_* launch: plain/fused-epilogue GEMMs and the qkv projections with RoPE in the epilogue
+        gm = {k_: summ["gemm"][k_] + summ["gemm_qkv_rope"][k_] for k_ in ("ms", "calls", "flops")}
+        at, rs, cv, ln = summ["attention"], summ["_forward_impl"], summ["conv3x3_nhwc"], summ["layernorm_mod"]
+        up, ad, stem = summ["upsample2x_nhwc"], summ["gaussian_adapter"], summ["conv7x7_rgb_nhwc"]
         R = [m for n, _, _, m in kt.rec if n == "_forward_impl"][0]["R"]
         gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-        # dominant hand-written kernel of the step: the MFMA GEMM (ViT encoder/decoder linears)
+        # dominant hand-written kernel family of the step: the MFMA GEMM (ViT encoder/decoder linears, 1x1 convolutions)
         traffic = {}
         try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null when the file is absent
             pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))["kernels"]
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm.items()}
         except Exception:
             pass
-        roofline = dict(kernel="gemm_kernel<f16> (vs_gemm_bias_act)", bound="mfma", achieved=round(gemm_tf, 1),
-                        peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s", frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4),
-                        traffic=traffic.get("gemm_kernel"),
+        roofline = dict(kernel="gemm256_kernel/gemm_kernel<f16> (vs_gemm_bias_act, vs_gemm_qkv_rope)", bound="mfma",
+                        achieved=round(gemm_tf, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s",
+                        frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4), traffic=traffic.get("gemm_kernel"),
                         launches=gm["calls"], avg_launch_us=round(gm["ms"] * 1e3 / gm["calls"], 2))
+        known = gm["ms"] + at["ms"] + ln["ms"] + rs["ms"] + cv["ms"] + up["ms"] + ad["ms"] + stem["ms"]
+        mfma_flops = gm["flops"] + at["flops"] + cv["flops"] + stem["flops"]
+        mfma_ms = gm["ms"] + at["ms"] + cv["ms"] + stem["ms"]
         extra = dict(
-            step_breakdown_ms=dict(total=round(tot_ms, 3), gemm=round(gm["ms"], 3), attention=round(at["ms"], 3),
-                                   layernorm=round(summ["layernorm_mod"]["ms"], 3), rope=round(summ["rope_qk"]["ms"], 3),
-                                   rasterizer=round(rs["ms"], 3),
-                                   other_heads_adapter_glue=round(tot_ms - gm["ms"] - at["ms"] - summ["layernorm_mod"]["ms"] - summ["rope_qk"]["ms"] - rs["ms"], 3)),
+            step_breakdown_ms=dict(total=round(tot_ms, 3), gemm=round(gm["ms"], 3), conv3x3=round(cv["ms"], 3),
+                                   conv7x7_stem=round(stem["ms"], 3), attention=round(at["ms"], 3), layernorm=round(ln["ms"], 3),
+                                   upsample=round(up["ms"], 3), adapter=round(ad["ms"], 3), rasterizer=round(rs["ms"], 3),
+                                   other_glue=round(tot_ms - known, 3)),
+            roofline_conv=dict(bound="mfma", achieved=round(cv["flops"] / (cv["ms"] * 1e-3) / 1e12, 1), peak=PEAK_MFMA_16BIT_TFLOPS,
+                               unit="TFLOP/s", frac=round(cv["flops"] / (cv["ms"] * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4)),
             roofline_attention=dict(bound="mfma", achieved=round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s"),
             roofline_rasterizer=dict(bound="hbm", achieved=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                      frac=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), num_rendered=int(R),
                                      gaussians=P * B, views=B * Vt),
-            mfma_util_vit=round((gm["flops"] + at["flops"]) / ((gm["ms"] + at["ms"]) * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4))
+            mfma_util_step=round(mfma_flops / (mfma_ms * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4))
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -149,6 +149,15 @@ int vs_gemm_bias_act(const void *A, const void *W, const float *bias, void *out,
                      int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in,
                      int32_t a_grp_out, int32_t a_grp_off, vs_stream_t stream);
 
+/* Packed qkv projection with the rotary embedding fused into the epilogue: out16[row, :] = A W^T + bias, then q (columns
+ * [0,C)) and k ([C,2C)) of every 64-wide head are rotated exactly as vs_rope_qk would (pos [rows,2] int32 and kind [rows]
+ * uint8 are indexed by OUTPUT row; kind NULL = all 0).  Replaces nn.Linear + RoPE2D.forward (croco/blocks.py:94-104,
+ * pos_embed.py:106-157) / the temporal rope of backbone_vica.py:95-118 without a second pass over the qkv buffer. */
+int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias, void *out, int32_t M, int32_t N, int32_t K, int32_t lda,
+                     int32_t ldw, int32_t ldo, int32_t dtype, int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t a_grp_in,
+                     int32_t a_grp_out, int32_t a_grp_off, const int32_t *pos, const uint8_t *kind, int32_t C, float base2d,
+                     float theta1d, vs_stream_t stream);
+
 /* In-place RoPE on the q (column 0) and k (column k_col) blocks of a packed projection buffer [rows, ld], H heads of
  * 64.  pos int32 [rows,2] (y,x) or (t,-); kind uint8 [rows] (0 = 2-D, 1 = temporal 1-D interleaved, 2 = none) or NULL. */
 int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos, const uint8_t *kind,

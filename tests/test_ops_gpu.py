@@ -129,6 +129,46 @@ def _rope1d_ref(x, t, theta):  # interleaved pairs
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("frames,H,K", [(2, 12, 768), (64, 16, 1024), (5, 3, 192)])
+def test_gemm_qkv_rope_fused(dt, frames, H, K):
+    """qkv projection with RoPE in the epilogue == projection followed by the standalone rope (2-D image rows, 1-D
+    temporal camera rows, untouched v), on every GEMM kernel the dispatcher can pick, tails included."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(frames * H)
+    rows, C = frames * 258, H * 64
+    a = torch.randn(rows, K, generator=g).to(dt).to(d)
+    w = (torch.randn(3 * C, K, generator=g) / math.sqrt(K)).to(dt).to(d)
+    bias = torch.randn(3 * C, generator=g).to(d)
+    kind = torch.zeros(rows, dtype=torch.uint8, device=d)
+    pos = torch.zeros(rows, 2, dtype=torch.int32, device=d)
+    n = torch.arange(rows, device=d) % 258
+    kind[n == 0] = 1
+    pos[n == 0, 0] = (torch.arange(rows, device=d) // 258)[n == 0].int() % 8
+    img = n > 0
+    pos[img, 0] = ((n[img] - 1) // 16).int()
+    pos[img, 1] = ((n[img] - 1) % 16).int()
+    pos[n == 257] = torch.tensor([16, 0], dtype=torch.int32, device=d)
+    kind[n == 5] = 2  # rows that skip the rope entirely
+    ref = (a.float() @ w.float().t() + bias).reshape(rows, 3, H, 64)
+    exp = ref.clone()
+    for blk in (0, 1):
+        x = ref[:, blk]
+        r2, r1 = _rope2d_ref(x, pos, 100.0), _rope1d_ref(x, pos[:, 0], 30.0)
+        exp[:, blk] = torch.where((kind == 1)[:, None, None], r1, torch.where((kind == 2)[:, None, None], x, r2))
+    out = torch.empty(rows, 3 * C, dtype=dt, device=d)
+    ops.gemm_qkv_rope(a, w, bias, out, C, pos, kind, 100.0, 30.0)
+    tol = (3e-3 if dt == torch.float16 else 1.6e-2) * float(exp.abs().max())
+    assert (out.float().reshape(rows, 3, H, 64) - exp).abs().max() <= tol
+    out2 = torch.empty_like(out)  # kind=None: every row is a 2-D row
+    ops.gemm_qkv_rope(a, w, bias, out2, C, pos, None, 100.0, 30.0)
+    exp2 = ref.clone()
+    for blk in (0, 1):
+        exp2[:, blk] = _rope2d_ref(ref[:, blk], pos, 100.0)
+    assert (out2.float().reshape(rows, 3, H, 64) - exp2).abs().max() <= tol
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_rope_qk_packed(dt):
     from vicasplat_amd import ops
     d = _dev()

@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
             L.vs_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp]
             L.vs_gaussian_adapter.restype = C.c_int
             L.vs_gaussian_adapter.argtypes = [vp, i64, i64, vp, i64, i64, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.vs_gemm_qkv_rope.restype = C.c_int
+            L.vs_gemm_qkv_rope.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32,
+                                           C.c_float, C.c_float, vp]
             L.vs_conv7x7_rgb_nhwc.restype = C.c_int
             L.vs_conv7x7_rgb_nhwc.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_conv3x3_nhwc.restype = C.c_int

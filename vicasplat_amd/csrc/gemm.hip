@@ -242,6 +242,7 @@ int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
         case 1: hipLaunchKernelGGL((gemm_kernel<BF16, 1, MI>), grid, block, 0, stream, g); break;
         case 2: hipLaunchKernelGGL((gemm_kernel<BF16, 2, MI>), grid, block, 0, stream, g); break;
         case 3: hipLaunchKernelGGL((gemm_kernel<BF16, 3, MI>), grid, block, 0, stream, g); break;
+        case 4: hipLaunchKernelGGL((gemm_kernel<BF16, 4, MI>), grid, block, 0, stream, g); break;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -256,6 +257,7 @@ int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
         case 1: hipLaunchKernelGGL((gemm256_kernel<BF16, 1>), grid, block, 0, stream, g); break;
         case 2: hipLaunchKernelGGL((gemm256_kernel<BF16, 2>), grid, block, 0, stream, g); break;
         case 3: hipLaunchKernelGGL((gemm256_kernel<BF16, 3>), grid, block, 0, stream, g); break;
+        case 4: hipLaunchKernelGGL((gemm256_kernel<BF16, 4>), grid, block, 0, stream, g); break;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -266,14 +268,15 @@ template <bool BF16>
 int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     GemmArgs t = g;
     t.m_lo = g.M - rem;
-    return rem <= 64 ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
+    // (the RoPE epilogue pairs columns 16 apart: only the tile kernels hold both in one workgroup)
+    return rem <= 64 && epi != 4 ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
 }
 
 template <bool BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
-    if (g.M <= 64 && force == 0) return launch_smallm<BF16>(g, epi, stream);
+    if (g.M <= 64 && force == 0 && epi != 4) return launch_smallm<BF16>(g, epi, stream);
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
     // M = frames * 257 tokens is never a multiple of the tile height, and one partial row of tiles past a full wave of
@@ -309,18 +312,18 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M,
-                                int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype,
-                                int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld,
-                                int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off, vs_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK(A && W && out, "vs_gemm_bias_act: null pointer");
-    VS_CHECK(M >= 0 && N > 0 && K > 0, "vs_gemm_bias_act: bad sizes M=%d N=%d K=%d", M, N, K);
-    VS_CHECK(K % 64 == 0, "vs_gemm_bias_act: K=%d must be a multiple of 64", K);
-    VS_CHECK(lda % 8 == 0 && ldw % 8 == 0, "vs_gemm_bias_act: lda/ldw must be multiples of 8 elements (16-byte rows)");
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_bias_act: dtype must be 1 (f16) or 2 (bf16)");
+namespace {
+int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M, int32_t N,
+               int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype, int32_t grp_in, int32_t grp_out,
+               int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
+               const int32_t *rope_pos, const uint8_t *rope_kind, int32_t rope_C, float base2d, float theta1d, hipStream_t stream) {
+    VS_CHECK(A && W && out, "%s: null pointer", fn);
+    VS_CHECK(M >= 0 && N > 0 && K > 0, "%s: bad sizes M=%d N=%d K=%d", fn, M, N, K);
+    VS_CHECK(K % 64 == 0, "%s: K=%d must be a multiple of 64", fn, K);
+    VS_CHECK(lda % 8 == 0 && ldw % 8 == 0, "%s: lda/ldw must be multiples of 8 elements (16-byte rows)", fn);
+    VS_CHECK(dtype == 1 || dtype == 2, "%s: dtype must be 1 (f16) or 2 (bf16)", fn);
     VS_CHECK((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
-             "vs_gemm_bias_act: A and W must be 16-byte aligned");
+             "%s: A and W must be 16-byte aligned", fn);
     if (M == 0) return 0;
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.out = out; g.gate = gate;
@@ -335,10 +338,36 @@ extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias,
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
+    g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
+    g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
     const int rc = dtype == 2 ? launch<true>(g, epilogue, stream) : launch<false>(g, epilogue, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M,
+                                int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype,
+                                int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld,
+                                int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off, vs_stream_t stream_) {
+    VS_CHECK(epilogue >= 0 && epilogue <= 3, "vs_gemm_bias_act: unknown epilogue %d", epilogue);
+    return gemm_entry("vs_gemm_bias_act", A, W, bias, out, gate, M, N, K, lda, ldw, ldo, epilogue, dtype, grp_in, grp_out, grp_off,
+                      gate_rows, gate_ld, a_grp_in, a_grp_out, a_grp_off, nullptr, nullptr, 0, 0.f, 0.f, (hipStream_t)stream_);
+}
+
+// Packed q|k|v projection with the rotary embedding of q and k applied in the epilogue (head_dim 64): replaces
+// nn.Linear + RoPE2D / temporal RoPE of croco/blocks.py:94-104 and backbone_vica.py:95-118 in one pass over the output.
+extern "C" int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias, void *out, int32_t M, int32_t N, int32_t K,
+                                int32_t lda, int32_t ldw, int32_t ldo, int32_t dtype, int32_t grp_in, int32_t grp_out,
+                                int32_t grp_off, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off, const int32_t *pos,
+                                const uint8_t *kind, int32_t C, float base2d, float theta1d, vs_stream_t stream_) {
+    VS_CHECK(pos, "vs_gemm_qkv_rope: null pos");
+    VS_CHECK(C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0, "vs_gemm_qkv_rope: need C %% 64 == 0, N %% 64 == 0, N >= 2C (C=%d N=%d)", C, N);
+    VS_CHECK(base2d > 0.f && theta1d > 0.f, "vs_gemm_qkv_rope: base2d and theta1d must be positive");
+    return gemm_entry("vs_gemm_qkv_rope", A, W, bias, out, nullptr, M, N, K, lda, ldw, ldo, 4, dtype, grp_in, grp_out, grp_off, 0, 0,
+                      a_grp_in, a_grp_out, a_grp_off, pos, kind, C, base2d, theta1d, (hipStream_t)stream_);
 }
 
 // 7x7 stride-1 pad-3 convolution of an RGB image (the gs head's input_merger, heads/dpt_gs_head.py:112-118) as a window
@@ -366,6 +395,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());

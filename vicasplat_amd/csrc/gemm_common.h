@@ -26,6 +26,12 @@ struct GemmArgs {
     // window-GEMM extras (7x7 RGB stem, gemm_kernel only): every a_sup_in row groups skip a_sup_extra more A rows (image
     // padding rows), and k-step kt reads its 32-wide slice at element offset kt * a_kstride (next image row), not kt * 32
     int a_sup_in, a_sup_extra, a_kstride;
+    // epilogue 4 (STORE16 + RoPE on the q and k column blocks of a packed qkv projection, head_dim 64): per OUTPUT row
+    // pos[2] and kind (0: 2-D pairs (i, i+16) per 32-half with pos[0]/pos[1], 1: 1-D interleaved pairs with pos[0], 2: none)
+    const int32_t *rope_pos;
+    const uint8_t *rope_kind;
+    int rope_C;  // columns [0, C) = q, [C, 2C) = k, rest untouched
+    float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
 };
 
 template <bool BF16>
@@ -75,6 +81,13 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + copysignf(e, v));
 }
 
+// cos/sin of an angle given in radians on the hardware v_cos/v_sin (argument in revolutions; |angle| stays < 2^8 rev)
+__device__ __forceinline__ void sincos_hw(float ang, float &sn, float &cs) {
+    const float rev = ang * 0.15915494309189535f;
+    sn = __builtin_amdgcn_sinf(rev);
+    cs = __builtin_amdgcn_cosf(rev);
+}
+
 // XOR swizzle of the 16-byte chunk index (0..3) inside a 64-byte LDS row, keyed on (row >> 2) & 3, chosen so that the
 // four 16-lane service groups of ds_read_b128 each touch 16 distinct 16-byte slots of a 256-byte bank row.
 __device__ __forceinline__ int swz4(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }  // f = {0,2,3,1}
@@ -100,20 +113,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
         const int n = nbase + j * 16 + ccol;
         bv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
     }
-    if constexpr (EPI == 0 || EPI == 1) {
+    if constexpr (EPI == 0 || EPI == 1 || EPI == 4) {
         constexpr int PR = 64 + 8;  // halfs per patch row (144 B: 16-byte aligned, conflict-light)
         unsigned short *patch = reinterpret_cast<unsigned short *>(scratch) + wid * (16 * PR);
         const bool vec_ok = (g.ldo % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
+        // RoPE (EPI 4): a wave's 64 columns are one head; in the accumulator layout the 2-D pair (c, c+16) of a 32-half is
+        // (fragment 2h, fragment 2h+1) of the SAME lane, the 1-D pair (2p, 2p+1) is the neighbouring lane.
+        [[maybe_unused]] bool rope_on = false;
+        [[maybe_unused]] float inv2d = 0.f;
+        if constexpr (EPI == 4) {
+            rope_on = nbase < 2 * g.rope_C && nbase + 64 <= g.N;
+            inv2d = __builtin_amdgcn_exp2f(-(float)ccol * (1.0f / 16.0f) * g.rope_l2base);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            float vv[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv[j];
-                    if constexpr (EPI == 1) v = gelu_erf(v);
-                    patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(v);
+                    vv[j][r] = acc[i][j][r] + bv[j];
+                    if constexpr (EPI == 1) vv[j][r] = gelu_erf(vv[j][r]);
                 }
+            if constexpr (EPI == 4) {
+                if (rope_on) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = min(mw0 + i * 16 + crow + r, g.M - 1);
+                        const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+                        const int kd = g.rope_kind ? (int)g.rope_kind[orow] : 0;
+                        const float p0 = (float)g.rope_pos[2 * orow], p1 = (float)g.rope_pos[2 * orow + 1];
+                        if (kd == 0) {
+                            float s0, c0, s1, c1;
+                            sincos_hw(p0 * inv2d, s0, c0);
+                            sincos_hw(p1 * inv2d, s1, c1);
+                            const float u0 = vv[0][r], w0 = vv[1][r], u1 = vv[2][r], w1 = vv[3][r];
+                            vv[0][r] = u0 * c0 - w0 * s0; vv[1][r] = w0 * c0 + u0 * s0;
+                            vv[2][r] = u1 * c1 - w1 * s1; vv[3][r] = w1 * c1 + u1 * s1;
+                        }
+                        // camera-token rows (1 in 258): interleaved pairs live in lanes (2p, 2p+1); whole wave joins the swap
+                        if (__builtin_amdgcn_ballot_w64(kd == 1) != 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float other = __shfl_xor(vv[j][r], 1, 64);
+                                if (kd == 1) {
+                                    float sn, cs;
+                                    sincos_hw(p0 * __builtin_amdgcn_exp2f(-(float)((j * 16 + ccol) >> 1) * (1.0f / 32.0f) * g.rope_l2theta), sn, cs);
+                                    vv[j][r] = (ccol & 1) ? vv[j][r] * cs + other * sn : vv[j][r] * cs - other * sn;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(vv[j][r]);
             __syncthreads();
             // 16 rows x 8 chunks of 8 halfs = 128 chunks, 2 per lane
 #pragma unroll

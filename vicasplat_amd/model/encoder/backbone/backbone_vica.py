@@ -233,8 +233,7 @@ class VicaNet(nn.Module):
         hid = torch.empty(BT * N, int(Ce * cfg.mlp_ratio), **f16)
         for i, blk in enumerate(self.enc_blocks):
             ops.layernorm_mod(xe, blk.norm1.weight, blk.norm1.bias, h)
-            ops.gemm(h, W[f"e{i}.qkv"], blk.attn.qkv.bias, qkv, ops.EPI_STORE16)
-            ops.rope_qk(qkv, He, Ce, tabs["pos_img"], None, 100.0, 1.0)
+            ops.gemm_qkv_rope(h, W[f"e{i}.qkv"], blk.attn.qkv.bias, qkv, Ce, tabs["pos_img"], None, 100.0, 1.0)
             ops.attention(qkv[:, :Ce], qkv[:, Ce:2 * Ce], qkv[:, 2 * Ce:], att, nbatch=BT, H=He, Lq=N, Lk=N, q_batch_rows=N, k_batch_rows=N)
             ops.gemm(att, W[f"e{i}.proj"], blk.attn.proj.bias, xe, ops.EPI_RESID32)
             ops.layernorm_mod(xe, blk.norm2.weight, blk.norm2.bias, h)
@@ -274,8 +273,7 @@ class VicaNet(nn.Module):
             ops.layernorm_mod(xd, blk.norm1.weight, blk.norm1.bias, hmix, scale=mod1[:, :Cd], shift=mod1[:, Cd:2 * Cd],
                               mod_rows=N, grp_in=N, grp_out=M2, grp_off=1)
             hmix.view(BT, M2, Cd)[:, 0] = cn.to(dt)
-            ops.gemm(hmix, W[f"d{i}.qkv"], blk.attn.qkv.bias, qkvm, ops.EPI_STORE16)
-            ops.rope_qk(qkvm, Hd, Cd, tabs["pos_mix"], tabs["kind_mix"], 100.0, theta)
+            ops.gemm_qkv_rope(hmix, W[f"d{i}.qkv"], blk.attn.qkv.bias, qkvm, Cd, tabs["pos_mix"], tabs["kind_mix"], 100.0, theta)
             ops.attention(qkvm[:, :Cd], qkvm[:, Cd:2 * Cd], qkvm[:, 2 * Cd:], attm, nbatch=B, H=Hd, Lq=T * M2, Lk=T * M2,
                           q_batch_rows=T * M2, k_batch_rows=T * M2, q_kvlen=tabs["kvlen"])
             ops.gemm(attm, W[f"d{i}.proj"], blk.attn.proj.bias, xd, ops.EPI_RESID32, gate=mod1[:, 2 * Cd:], gate_rows=N,
@@ -287,8 +285,7 @@ class VicaNet(nn.Module):
             ops.gemm(F.silu(cn).to(dt), W[f"d{i}.mod2"], blk.modulation2.proj.bias, mod2, ops.EPI_STORE32)
             # -- cross-neighbour attention (:152-191): keys/values of frames t-1, t+1 gathered by row segments
             ops.layernorm_mod(xd, blk.norm2.weight, blk.norm2.bias, h, scale=mod2[:, :Cd], shift=mod2[:, Cd:2 * Cd], mod_rows=N)
-            ops.gemm(h, W[f"d{i}.cqkv"], W[f"d{i}.cqkv_b"], qkv, ops.EPI_STORE16)
-            ops.rope_qk(qkv, Hd, Cd, tabs["pos_img"], None, 100.0, 1.0)
+            ops.gemm_qkv_rope(h, W[f"d{i}.cqkv"], W[f"d{i}.cqkv_b"], qkv, Cd, tabs["pos_img"], None, 100.0, 1.0)
             ops.attention(qkv[:, :Cd], qkv[:, Cd:2 * Cd], qkv[:, 2 * Cd:], att, nbatch=BT, H=Hd, Lq=N, q_batch_rows=N, kv_seg=tabs["seg"])
             ops.gemm(att, W[f"d{i}.cproj"], blk.cross_attn.proj.bias, xd, ops.EPI_RESID32, gate=mod2[:, 2 * Cd:3 * Cd], gate_rows=N)
             # -- MLPs (:323-333); the camera MLP reads cam_norm2(cam), not a fresh norm

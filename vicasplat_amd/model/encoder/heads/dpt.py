@@ -197,8 +197,9 @@ class PixelwiseTaskWithDPT(nn.Module):
     def _fusion(self, P, r, x, skip=None):
         if skip is not None:
             x = x + self._rcu(skip, P, f"rf{r}.resConfUnit1")
-        x = ops.upsample2x_nhwc(self._rcu(x, P, f"rf{r}.resConfUnit2"))
-        return self._gemm1x1(x, P, f"rf{r}.out")
+        # out_conv (1x1) commutes with the bilinear x2 (both linear, interpolation weights sum to 1): run it on the 4x
+        # smaller map, then upsample (dpt_block.py:210-218 upsamples first)
+        return ops.upsample2x_nhwc(self._gemm1x1(self._rcu(x, P, f"rf{r}.resConfUnit2"), P, f"rf{r}.out"))
 
     def _trunk(self, tokens, gh: int, gw: int):
         """tokens[hook] [BT, gh*gw, C] 16-bit -> path_1 [BT, 8gh, 8gw, 256] (dpt_head.py:35-62)."""

@@ -60,6 +60,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, C: int, pos: torch.Tensor,
+                  kind: Optional[torch.Tensor] = None, base2d: float = 100.0, theta1d: float = 30.0, *, grp_in: int = 0,
+                  grp_out: int = 0, grp_off: int = 0, M: Optional[int] = None, a_grp_in: int = 0, a_grp_out: int = 0,
+                  a_grp_off: int = 0) -> torch.Tensor:
+    """Packed q|k|v projection (w [N >= 2C, K]) with rope_qk(out, C // 64, C, pos, kind, ...) fused into the epilogue."""
+    dev = L.require_device(a, w, bias, out, pos, kind)
+    assert a.dtype == w.dtype == out.dtype and a.dtype in (torch.float16, torch.bfloat16)
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    assert pos.dtype == torch.int32 and pos.is_contiguous() and (kind is None or (kind.dtype == torch.uint8 and kind.is_contiguous()))
+    M = a.shape[0] if M is None else M
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_qkv_rope(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, w.shape[0], a.shape[1], a.stride(0), w.stride(0),
+                                      out.stride(-2), _DT[a.dtype], grp_in, grp_out, grp_off, a_grp_in, a_grp_out, a_grp_off,
+                                      L.ptr(pos), L.ptr(kind), C, base2d, theta1d, L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_qkv_rope")
+    return out
+
+
 def rope_qk(buf: torch.Tensor, H: int, k_col: int, pos: torch.Tensor, kind: Optional[torch.Tensor] = None,
             base2d: float = 100.0, theta1d: float = 30.0) -> torch.Tensor:
     """In-place RoPE on q (col 0) and k (col k_col) of buf [rows, ld]; pos int32 [rows,2]; kind uint8 [rows] or None."""
