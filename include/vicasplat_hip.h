@@ -79,7 +79,7 @@ enum {
     VS_BUF_TILE_CURSOR = 4, /* [C,tiles] i32 scratch */
     VS_BUF_KEYS = 5,      /* [R] u64 (depth_bits<<32 | gaussian) */
     VS_BUF_POINT_LIST = 6, /* [R] u32 sorted Gaussian ids, per (camera,tile) segment */
-    VS_BUF_SORT_SCRATCH = 7, /* [R] u64 ping-pong buffer of the per-tile radix sort */
+    VS_BUF_SORT_SCRATCH = 7, /* [R] u64 bucketized / ping-pong keys of the large-tile sort + its segment table */
     VS_BUF_FINAL_T = 8,   /* [C,H,W] f32 */
     VS_BUF_N_CONTRIB = 9, /* [C,H,W] i32 */
     VS_BUF_MISC = 10,     /* small control block */

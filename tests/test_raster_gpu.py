@@ -139,6 +139,26 @@ def test_oversize_tile_radix_path():
     _compare(o, g, 0, color_atol=1e-4)
 
 
+@pytest.mark.parametrize("P,tied", [(3000, 1500), (20000, 0), (1500, 0), (5000, 400)])
+def test_large_tile_sort_paths(P, tied):
+    """One tile holding P Gaussians: bucket + LDS-sort path (spread depths, any size), the radix fallback (more than 512
+    keys at one depth) and mixtures; the sorted id list must match the oracle's (depth, index) order exactly."""
+    rng = np.random.default_rng(P + tied)
+    means = np.stack([rng.uniform(-0.02, 0.02, P), rng.uniform(-0.02, 0.02, P), rng.uniform(1.5, 6.0, P)], -1).astype(np.float32)
+    if tied:
+        means[rng.permutation(P)[:tied], 2] = 2.75
+    cov = np.tile((1e-6 * np.eye(3, dtype=np.float32))[None], (P, 1, 1))
+    sh = np.zeros((P, 25, 3), np.float32); sh[:, 0] = rng.standard_normal((P, 3))
+    op = np.full(P, 0.01, np.float32)
+    cams = _two_cams()[:1]
+    W = H = 32
+    bg = np.zeros(3, np.float32)
+    g = _run_gpu(means, rr.cov6(cov), sh, op, cams, W, H, bg)
+    o = rr.rasterize_forward(cams[0], W, H, bg, means, rr.cov6(cov), sh, op)
+    assert (o["ranges"][:, 1] - o["ranges"][:, 0]).max() > min(P, 1024) - 1
+    _compare(o, g, 0, color_atol=1e-4)
+
+
 def test_empty_and_culled():
     d = _dev()
     cams = _two_cams()

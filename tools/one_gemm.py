@@ -1,9 +1,10 @@
+"""One GEMM shape, a few launches: the target of rocprofv3 --pmc passes (M N K from argv, default ViT-L fc1 at 64 frames)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vicasplat_amd import ops
 d = torch.device("cuda:0")
-M, N, K = 4112, 4096, 1024
+M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (16384, 4096, 1024)
 a = torch.randn(M, K, device=d).half(); w = (torch.randn(N, K, device=d) / K ** 0.5).half(); b = torch.randn(N, device=d)
 o = torch.empty(M, N, device=d, dtype=torch.float16)
 for _ in range(5): ops.gemm(a, w, b, o, ops.EPI_STORE16)

@@ -29,3 +29,11 @@ rad = d["radii"].float(); vis = rad > 0
 print("visible frac", vis.float().mean().item(), "radius mean", rad[vis].mean().item(), "max", rad.max().item())
 nc = d["n_contrib"].float()
 print("n_contrib mean", nc.mean().item(), "max", nc.max().item(), "final_T mean", d["final_T"].mean().item())
+# depth-tie statistics of the sorted lists: runs of identical depth bits are ordered by an insertion sort in tile_sort_kernel
+pl = d["point_list"].long()
+Pn = m.shape[1]
+cam_of = torch.repeat_interleave(torch.arange(B * Vt, device=dev), (d["ranges"][..., 1].max(1).values - d["ranges"][..., 0].min(1).values))
+dep = d["geom"][cam_of, pl, 11]
+print("adjacent equal-depth fraction in the sorted lists", (dep[1:] == dep[:-1]).float().mean().item())
+hist = torch.histc(n, bins=16, min=0, max=32768)
+print("tile population histogram (2048-wide bins):", hist.int().tolist())

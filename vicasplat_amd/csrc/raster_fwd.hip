@@ -17,6 +17,8 @@
 // radii / tile ranges / sorted ids are bit-identical to the CPU oracle.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 using vs::kGeomFloats;
@@ -372,21 +374,89 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, int N) {
     }
 }
 
-constexpr int kDigitBits = 11;
+// Bitonic sort of 256 keys held by ONE wave, element e = r * 64 + lane in v[r]: compare distances below 64 are lane
+// exchanges (two 32-bit shuffles per key), 64 and 128 are register pairs of the same lane.  No LDS image, no barrier.
+// value of lane (l ^ J): DPP permutes for J < 16 (VALU rate, no LDS crossbar traffic), ds_bpermute for 16 and 32
+template <int J>
+__device__ __forceinline__ unsigned lane_xor(unsigned v) {
+    if constexpr (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {  // (l ^ 7) ^ 3: row_half_mirror then quad_perm [3,2,1,0]
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, false);
+    } else if constexpr (J == 8) {  // (l ^ 15) ^ 7: row_mirror then row_half_mirror
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, false);
+    } else return (unsigned)__shfl_xor((int)v, J, 64);
+}
+template <int J>
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v) {
+    const unsigned lo = lane_xor<J>((unsigned)v), hi = lane_xor<J>((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int K, int J>
+__device__ __forceinline__ void wave_bitonic_step(unsigned long long (&v)[4], int lane) {
+    if constexpr (J >= 64) {
+        constexpr int dr = J >> 6;  // 1 or 2: partner register r ^ dr
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if ((r & dr) == 0) {
+                const bool up = ((r * 64) & K) == 0;  // lane bits are below 64 <= J < K
+                const unsigned long long x = v[r], y = v[r | dr];
+                const bool sw = (x > y) == up;
+                v[r] = sw ? y : x; v[r | dr] = sw ? x : y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = r * 64 + lane;
+            const unsigned long long x = v[r], y = shfl_xor_u64<J>(x);
+            const bool up = (e & K) == 0, lower = (lane & J) == 0;
+            v[r] = ((x > y) == (up == lower)) ? y : x;
+        }
+    }
+    if constexpr (J > 1) wave_bitonic_step<K, (J >> 1)>(v, lane);
+}
+template <int K>
+__device__ __forceinline__ void wave_bitonic_merge(unsigned long long (&v)[4], int lane) {
+    wave_bitonic_step<K, (K >> 1)>(v, lane);
+    if constexpr (K < 256) wave_bitonic_merge<(K << 1)>(v, lane);
+}
+__device__ __forceinline__ void wave_bitonic256(unsigned long long (&v)[4], int lane) { wave_bitonic_merge<2>(v, lane); }
+
+constexpr int kDigitBits = 8;
 constexpr int kBins = 1 << kDigitBits;
+
+// Peers of this lane's digit inside the wave (lanes holding the same digit), by 8 ballots.
+__device__ __forceinline__ unsigned long long digit_peers(int d, bool valid) {
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < kDigitBits; ++bit) {
+        const unsigned long long bb = __ballot((d >> bit) & 1);
+        m &= ((d >> bit) & 1) ? bb : ~bb;
+    }
+    return m;
+}
 
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict__ keys, uint32_t *__restrict__ point_list,
-                 unsigned long long *__restrict__ scratch) {
+                 unsigned long long *__restrict__ scratch, int2 *__restrict__ segs) {
     __shared__ unsigned long long skeys[kSortLds];
-    __shared__ int hist[kBins];
-    __shared__ int wcnt[4][kBins];
+    __shared__ int whist[2][4][kBins];  // [current | next pass][wave][digit]
     __shared__ int wave_tot[4];
     const size_t t = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int2 rg = ranges[t];
     const int n = rg.y - rg.x;
-    if (n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // this tile's slots in the segment table consumed by segment_sort_kernel (see the bucket path): clear them first
+    const size_t seg_base = (size_t)(rg.x >> 7) + t;
+    const int seg_slots = (rg.y >> 7) - (rg.x >> 7) + 1;
+    if (segs) {
+        for (int k = tid; k < seg_slots; k += 256) segs[seg_base + k] = make_int2(0, 0);
+        __syncthreads();
+    }
+    if (n <= 0) return;
     unsigned long long *a = keys + rg.x;
     if (n == 1) {
         if (tid == 0) point_list[rg.x] = (uint32_t)a[0];
@@ -401,22 +471,37 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
         for (int k = tid; k < n; k += 256) point_list[rg.x + k] = (uint32_t)skeys[k];
         return;
     }
-    // ---- stable LSD radix sort on the DEPTH half of the key (bits 32..63) in three 11/11/10-bit passes ----
     unsigned long long *b = scratch + rg.x;
-    for (int k = tid; k < 4 * kBins; k += 256) (&wcnt[0][0])[k] = 0;
-    for (int shift = 32; shift < 64; shift += kDigitBits) {
-        for (int k = tid; k < kBins; k += 256) hist[k] = 0;
+    // ---- large tiles: ONE order-preserving bucket pass + in-LDS sorts.  A radix pass scatters 8-byte keys over the whole
+    // tile (every store its own cache line), so passes are what cost: bucket the keys by (depth - min) >> shift into
+    // kBuckets ranges (one scattered pass, any order inside a bucket), then sort runs of consecutive buckets of <= 1024
+    // keys with the bitonic network on the full 64-bit (depth, index) key and write the index list coalesced.  Tiles
+    // whose depths pile up in one bucket (> 512 keys) take the radix path below instead. ----
+    {
+        constexpr int kBuckets = 2048, kSeg = kSortLds / 2;
+        __shared__ int bstart[kBuckets + 1];
+        __shared__ int bcur[kBuckets];
+        __shared__ unsigned s_mn, s_mx;
+        if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
+        for (int k = tid; k < kBuckets; k += 256) bcur[k] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) atomicAdd(&hist[(int)((a[i] >> shift) & (kBins - 1))], 1);
-        __syncthreads();
-        bool all_one = false;
-        for (int k = tid; k < kBins; k += 256) all_one |= (hist[k] == n);
-        if (__syncthreads_or(all_one)) continue;  // constant digit: nothing moves
-        // exclusive scan of the bins (8 per thread) -> hist[] becomes the running base of every digit
-        int loc[kBins / 256];
-        int sum = 0;
+        unsigned mn = ~0u, mx = 0u;
+        for (int i = tid; i < n; i += 256) {
+            const unsigned hi = (unsigned)(a[i] >> 32);
+            mn = min(mn, hi); mx = max(mx, hi);
+        }
 #pragma unroll
-        for (int q = 0; q < kBins / 256; ++q) { loc[q] = hist[tid * (kBins / 256) + q]; sum += loc[q]; }
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64)); }
+        if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+        __syncthreads();
+        mn = s_mn;
+        const unsigned range = s_mx - mn;
+        const int shift = range >= (unsigned)kBuckets ? (32 - __clz(range)) - 11 : 0;
+        for (int i = tid; i < n; i += 256) atomicAdd(&bcur[(int)((((unsigned)(a[i] >> 32)) - mn) >> shift)], 1);
+        __syncthreads();
+        int loc[kBuckets / 256], sum = 0, big = 0;
+#pragma unroll
+        for (int q = 0; q < kBuckets / 256; ++q) { loc[q] = bcur[tid * (kBuckets / 256) + q]; sum += loc[q]; big = max(big, loc[q]); }
         int x = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -424,43 +509,128 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
             if (lane >= o) x += y;
         }
         if (lane == 63) wave_tot[wid] = x;
-        __syncthreads();
-        int run = x - sum;
-        for (int w = 0; w < wid; ++w) run += wave_tot[w];
+        const bool clustered = __syncthreads_or(big > kSeg);
+        const bool fat = __syncthreads_or(big > 128);  // some bucket too large for the per-wave register sort
+        if (!clustered) {
+            int run = x - sum;
+            for (int w = 0; w < wid; ++w) run += wave_tot[w];
 #pragma unroll
-        for (int q = 0; q < kBins / 256; ++q) { hist[tid * (kBins / 256) + q] = run; run += loc[q]; }
-        __syncthreads();
-        for (int c0 = 0; c0 < n; c0 += 256) {
-            const int i = c0 + tid;
-            const bool valid = i < n;
-            const unsigned long long key = valid ? a[i] : 0ull;
-            const int d = (int)((key >> shift) & (kBins - 1));
-            unsigned long long m = __ballot(valid);
-#pragma unroll
-            for (int bit = 0; bit < kDigitBits; ++bit) {
-                const unsigned long long bb = __ballot((d >> bit) & 1);
-                m &= ((d >> bit) & 1) ? bb : ~bb;
-            }
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const int rank = __popcll(m & lt);
-            const int cnt = __popcll(m);
-            const bool leader = valid && rank == 0;
-            if (leader) wcnt[wid][d] = cnt;
+            for (int q = 0; q < kBuckets / 256; ++q) { bstart[tid * (kBuckets / 256) + q] = run; bcur[tid * (kBuckets / 256) + q] = run; run += loc[q]; }
+            if (tid == 255) bstart[kBuckets] = n;
             __syncthreads();
-            if (valid) {
-                int off = hist[d] + rank;
-                for (int w = 0; w < wid; ++w) off += wcnt[w][d];
-                b[off] = key;
+            for (int i = tid; i < n; i += 256) {
+                const unsigned long long key = a[i];
+                b[atomicAdd(&bcur[(int)((((unsigned)(key >> 32)) - mn) >> shift)], 1)] = key;
             }
             __syncthreads();
-            if (leader) {
-                atomicAdd(&hist[d], cnt);
-                wcnt[wid][d] = 0;
+            auto boundary = [&](int k, int seg, int nseg) -> int {  // largest bucket start <= k * seg (tile end for k == nseg)
+                if (k >= nseg) return n;
+                const int target = k * seg;
+                int lo = 0, hi = kBuckets;  // bstart[0] == 0 <= target
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (bstart[mid] <= target) lo = mid; else hi = mid - 1;
+                }
+                return bstart[lo];
+            };
+            if (!fat) {
+                // every bucket <= 128 keys: runs of consecutive buckets cut every ~128 keys are <= 256 keys.  They are not
+                // sorted here (a 20k-key tile would walk 160 of them on 4 waves while small tiles' CUs idle): publish
+                // them, segment_sort_kernel sorts one run per wave across the whole chip.
+                constexpr int kW = 128;
+                const int nseg = (n + kW - 1) / kW;  // <= seg_slots
+                for (int k = tid; k < nseg; k += 256) {
+                    const int s_lo = boundary(k, kW, nseg), m_ = boundary(k + 1, kW, nseg) - s_lo;
+                    segs[seg_base + k] = make_int2(rg.x + s_lo, m_);
+                }
+                return;
             }
-            __syncthreads();
+            const int nseg = (n + kSeg - 1) / kSeg;
+            int s_lo = 0;
+            for (int k = 0; k < nseg; ++k) {
+                const int s_hi = boundary(k + 1, kSeg, nseg), m_ = s_hi - s_lo;
+                if (m_ > 0) {
+                    int N = 2;
+                    while (N < m_) N <<= 1;
+                    for (int q = tid; q < N; q += 256) skeys[q] = q < m_ ? b[s_lo + q] : ~0ull;
+                    __syncthreads();
+                    bitonic_sort(skeys, N);
+                    for (int q = tid; q < m_; q += 256) point_list[rg.x + s_lo + q] = (uint32_t)skeys[q];
+                    __syncthreads();
+                }
+                s_lo = s_hi;
+            }
+            return;
         }
+        __syncthreads();
+    }
+    // ---- clustered tiles: stable LSD radix sort on the DEPTH half of the key (bits 32..63), four 8-bit passes.  Each wave
+    // owns a contiguous quarter of the positions and its own digit counters, so the scatter loop has NO workgroup barrier:
+    // a wave ranks its 64 keys with ballots, bumps its private running offsets, and adds every key it places to the
+    // histogram of the wave that will own that position in the next pass. ----
+    const int quarter = (n + 3) >> 2;
+    const int w_lo = wid * quarter, w_hi = min(n, w_lo + quarter);
+    auto wave_hist = [&](const unsigned long long *src, int shift, int buf) {  // per-wave histogram of one digit
+        for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < w_hi;
+            const int d = valid ? (int)((src[i] >> shift) & (kBins - 1)) : 0;
+            const unsigned long long m = digit_peers(d, valid);
+            if (valid && (m & ((1ull << lane) - 1ull)) == 0) whist[buf][wid][d] += __popcll(m);
+        }
+    };
+    for (int k = tid; k < 2 * 4 * kBins; k += 256) (&whist[0][0][0])[k] = 0;
+    __syncthreads();
+    wave_hist(a, 32, 0);
+    int cur = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 32 + kDigitBits * pass;
+        __syncthreads();  // whist[cur] complete
+        const int c0 = whist[cur][0][tid], c1 = whist[cur][1][tid], c2 = whist[cur][2][tid], c3 = whist[cur][3][tid];
+        const int tot = c0 + c1 + c2 + c3;
+        if (__syncthreads_or(tot == n)) {  // constant digit: nothing moves; only the next digit's histogram is needed
+            if (pass < 3) {
+                whist[cur][0][tid] = 0; whist[cur][1][tid] = 0; whist[cur][2][tid] = 0; whist[cur][3][tid] = 0;
+                __syncthreads();
+                wave_hist(a, shift + kDigitBits, cur);
+            }
+            continue;
+        }
+        // exclusive scan, digit-major / wave-minor: whist[cur][w][d] becomes wave w's first output slot for digit d
+        int x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        int run = x - tot;
+        for (int w = 0; w < wid; ++w) run += wave_tot[w];
+        whist[cur][0][tid] = run; whist[cur][1][tid] = run + c0; whist[cur][2][tid] = run + c0 + c1; whist[cur][3][tid] = run + c0 + c1 + c2;
+        const int nxt = cur ^ 1;
+        whist[nxt][0][tid] = 0; whist[nxt][1][tid] = 0; whist[nxt][2][tid] = 0; whist[nxt][3][tid] = 0;
+        __syncthreads();
+        unsigned long long key_next = (w_lo + lane < w_hi) ? a[w_lo + lane] : 0ull;
+        for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
+            const unsigned long long key = key_next;
+            const bool valid = i0 + lane < w_hi;
+            if (i0 + 64 + lane < w_hi) key_next = a[i0 + 64 + lane];
+            const int d = (int)((key >> shift) & (kBins - 1));
+            const unsigned long long m = digit_peers(d, valid);
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (valid) {
+                const int base = whist[cur][wid][d];           // all peers read ...
+                if (rank == 0) whist[cur][wid][d] = base + __popcll(m);  // ... before their leader moves the offset
+                const int off = base + rank;
+                b[off] = key;
+                if (pass < 3) atomicAdd(&whist[nxt][off / quarter][(int)((key >> (shift + kDigitBits)) & (kBins - 1))], 1);
+            }
+        }
+        cur = nxt;
         unsigned long long *tmp = a; a = b; b = tmp;
     }
+    __syncthreads();
     // ---- ties: keys with identical depth bits are still in scatter order; order each run by Gaussian index ----
     for (int i = tid; i < n; i += 256) {
         const unsigned hi = (unsigned)(a[i] >> 32);
@@ -478,6 +648,25 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
     }
     __syncthreads();
     for (int k = tid; k < n; k += 256) point_list[rg.x + k] = (uint32_t)a[k];
+}
+
+// One wave per published run (<= 256 keys of one tile's bucketized list in `scratch`): register bitonic sort on the full
+// (depth, index) key, index list written coalesced.
+__global__ void __launch_bounds__(256)
+segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned long long *__restrict__ scratch,
+                    uint32_t *__restrict__ point_list) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= nslots) return;
+    const int2 sg = segs[slot];
+    if (sg.y <= 0) return;
+    unsigned long long v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (r * 64 + lane) < sg.y ? scratch[(size_t)sg.x + r * 64 + lane] : ~0ull;
+    wave_bitonic256(v, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r * 64 + lane < sg.y) point_list[(size_t)sg.x + r * 64 + lane] = (uint32_t)v[r];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -649,12 +838,22 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     unsigned long long *keys = (unsigned long long *)get(VS_BUF_KEYS, (size_t)R * 8);
     uint32_t *point_list = (uint32_t *)get(VS_BUF_POINT_LIST, (size_t)R * 4);
     unsigned long long *scratch = nullptr;
-    if (max_tile > kSortLds) scratch = (unsigned long long *)get(VS_BUF_SORT_SCRATCH, (size_t)R * 8);
+    // large tiles: [R] u64 bucketized keys followed by the segment table: tile t owns slots (x_t >> 7) + t .. (y_t >> 7) + t,
+    // which tile the table exactly ((R >> 7) + tiles * C slots of {start, length}) because the ranges are contiguous
+    const long long nslots = (R >> 7) + (long long)tiles * C;
+    int2 *segs = nullptr;
+    if (max_tile > kSortLds) {
+        scratch = (unsigned long long *)get(VS_BUF_SORT_SCRATCH, (size_t)R * 8 + (size_t)nslots * sizeof(int2));
+        segs = scratch ? reinterpret_cast<int2 *>(scratch + R) : nullptr;
+    }
     VS_CHECK(keys && point_list && (max_tile <= kSortLds || scratch), "vs_raster_forward: allocator returned null");
     if (R > 0) {
         dim3 grid(vs::cdiv(P, 256), C);
         hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, geom, rect, out->radii, ranges, cursor, keys);
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch, segs);
+        if (segs)
+            hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)vs::cdiv64(nslots, 4)), dim3(256), 0, stream, segs, (int)nslots,
+                               scratch, point_list);
     }
     const bool count = (in->flags & VS_RASTER_COUNT_TOUCHED) && out->n_touched;
     dim3 rgrid(tiles, C);
