@@ -51,7 +51,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) patch[(crow + r) * PR + j * 16 + ccol] = acc[i][j][r] + bv[j];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 

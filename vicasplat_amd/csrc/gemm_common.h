@@ -99,6 +99,14 @@ __device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
 }
 
+// The epilogue patches are private to a wave: ordering its own LDS writes before its own reads needs no workgroup
+// barrier (LDS operations of one wave execute in order) -- only a compiler/memory-model fence at wavefront scope.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- epilogue shared by the tile kernels.  A lane's accumulators are 4 rows x 1 column per fragment: storing them
 // directly means 2-byte (or 4-byte) scattered stores.  Instead every wave transposes one 16 x 64 slab at a time through
 // a private LDS patch (`scratch`: the operand tiles, dead after the last barrier; 16*68*4 B per wave) and writes /
@@ -125,6 +133,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
             rope_on = nbase < 2 * g.rope_C && nbase + 64 <= g.N;
             inv2d = __builtin_amdgcn_exp2f(-(float)ccol * (1.0f / 16.0f) * g.rope_l2base);
         }
+        [[maybe_unused]] int2 rope_p[4] = {};
+        [[maybe_unused]] int rope_k[4] = {};
+        [[maybe_unused]] auto rope_fetch = [&](int i_) {  // pos / kind of the 4 output rows this lane holds in slab i_
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(mw0 + i_ * 16 + crow + r, g.M - 1);
+                const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+                rope_p[r] = *reinterpret_cast<const int2 *>(g.rope_pos + 2 * orow);
+                rope_k[r] = g.rope_kind ? (int)g.rope_kind[orow] : 0;
+            }
+        };
+        if constexpr (EPI == 4) {
+            if (rope_on) rope_fetch(0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             float vv[4][4];
@@ -137,12 +159,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                 }
             if constexpr (EPI == 4) {
                 if (rope_on) {
+                    // this slab's row table entries were fetched while the previous slab was processed
+                    int2 pcur[4]; int kcur[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pcur[r] = rope_p[r]; kcur[r] = rope_k[r]; }
+                    if (i + 1 < MI) rope_fetch(i + 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int m = min(mw0 + i * 16 + crow + r, g.M - 1);
-                        const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                        const int kd = g.rope_kind ? (int)g.rope_kind[orow] : 0;
-                        const float p0 = (float)g.rope_pos[2 * orow], p1 = (float)g.rope_pos[2 * orow + 1];
+                        const int kd = kcur[r];
+                        const float p0 = (float)pcur[r].x, p1 = (float)pcur[r].y;
                         if (kd == 0) {
                             float s0, c0, s1, c1;
                             sincos_hw(p0 * inv2d, s0, c0);
@@ -170,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(vv[j][r]);
-            __syncthreads();
+            wave_lds_sync();
             // 16 rows x 8 chunks of 8 halfs = 128 chunks, 2 per lane
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -190,7 +215,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                     }
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     } else {
         constexpr int PR = 64 + 4;  // floats per patch row (272 B)
@@ -211,7 +236,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                     patch[(crow + r) * PR + j * 16 + ccol] = v;
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
             // 16 rows x 16 chunks of 4 floats = 256 chunks, 4 per lane
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -239,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                     }
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 }
