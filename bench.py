@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenes-per-gpu", type=int, default=8)
+    ap.add_argument("--scenes-per-gpu", type=int, default=24)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--targets", type=int, default=12)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])

@@ -284,7 +284,11 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // leftover of <= half a tile as a tail launch whenever the partial row would open a new round.
     // 256x256 tiles (one 8-wave workgroup per CU): for K-tile-aligned shapes whose full tile rows fill the 256 CUs evenly.
     if (g.K % 128 == 0 && g.M >= 256) {
-        const int tn = vs::cdiv(g.N, 256), rem = g.M % 256, tail = (rem > 0 && rem <= 128) ? rem : 0;
+        const int tn = vs::cdiv(g.N, 256), rem = g.M % 256;
+        const long long full = (long long)(g.M / 256) * tn;
+        // leftover rows go to a tail launch when they are at most half a tile, or when their partial tile row would open a
+        // new round of workgroups (one 8-wave workgroup per CU: 256 slots)
+        const int tail = (rem > 0 && full > 0 && (rem <= 128 || (full + tn + 255) / 256 > (full + 255) / 256)) ? rem : 0;
         const long long tiles = (long long)vs::cdiv(g.M - tail, 256) * tn;
         const long long rounds = (tiles + 255) / 256;
         if (force == 16 || tiles * 100 >= rounds * 256 * 85) {
