@@ -188,14 +188,16 @@ def main():
         gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         # dominant hand-written kernel family of the step: the MFMA GEMM (ViT encoder/decoder linears, 1x1 convolutions)
         traffic = {}
-        try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null when the file is absent
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))["kernels"]
-            traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm.items()}
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null unless they cover this workload
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            if pm.get("workload", {}).get("scenes_per_gpu") == B and V == 8 and Vt == 12:
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm["kernels"].items()}
+                traffic["rasterizer"] = pm["kernels"]["rasterizer"]["hbm_bytes_per_step"]  # one forward = 6 kernels
         except Exception:
             pass
         roofline = dict(kernel="gemm256_kernel/gemm_kernel<f16> (vs_gemm_bias_act, vs_gemm_qkv_rope)", bound="mfma",
                         achieved=round(gemm_tf, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s",
-                        frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4), traffic=traffic.get("gemm_kernel"),
+                        frac=round(gemm_tf / PEAK_MFMA_16BIT_TFLOPS, 4), traffic=traffic.get("gemm"),
                         launches=gm["calls"], avg_launch_us=round(gm["ms"] * 1e3 / gm["calls"], 2))
         known = gm["ms"] + at["ms"] + ln["ms"] + rs["ms"] + cv["ms"] + up["ms"] + ad["ms"] + stem["ms"]
         mfma_flops = gm["flops"] + at["flops"] + cv["flops"] + stem["flops"]
@@ -209,7 +211,8 @@ def main():
                                unit="TFLOP/s", frac=round(cv["flops"] / (cv["ms"] * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4)),
             roofline_attention=dict(bound="mfma", achieved=round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s"),
             roofline_rasterizer=dict(bound="hbm", achieved=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                     frac=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), num_rendered=int(R),
+                                     frac=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                     traffic=traffic.get("rasterizer"), algorithmic_bytes=int(rs["bytes"]), num_rendered=int(R),
                                      gaussians=P * B, views=B * Vt),
             mfma_util_step=round(mfma_flops / (mfma_ms * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4))
 
