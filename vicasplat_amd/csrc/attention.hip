@@ -271,6 +271,169 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
     }
 }
 
+// ---- resident variant for short key sets (the frame encoder: 257 x 257 per (frame, head), no mask, no segments).
+// The tiled kernel re-stages every K/V tile once per 64-query workgroup (5 x for 257 queries) with two barriers per
+// tile, and pays full tiles for the 257th key and the 257th query.  Here ONE workgroup of 8 waves owns a (frame, head):
+// all keys and values go to LDS once (K row-major, V transposed, 75 KiB for 272 padded keys -> two workgroups per CU),
+// one barrier, then every wave walks its 16-query groups over the key tiles with no further synchronisation; a partial
+// last tile only runs the 16-key sub-blocks that hold keys. ----
+constexpr int kResMaxKeys = 320;
+
+template <bool BF16>
+__global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_res[];
+    const int Lk = a.Lk;
+    const int Lkp = (Lk + 15) & ~15;      // keys padded to the 16-key MFMA sub-block
+    const int vrow = Lkp + 8;             // halfs per V^T row
+    unsigned short *sK = smem_res;                  // [Lkp][KROW]
+    unsigned short *sVT = smem_res + Lkp * KROW;    // [HD][vrow]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const long long kbase = b * a.k_batch_rows;
+
+    // ---- stage all keys / values: thread -> (key, 16-half chunk) for K, (key pair, 8-dim chunk) for V.  Every global
+    // load of the workgroup is issued before the first LDS store (up to 3 rounds x 4 x 16 B per thread in flight). ----
+    constexpr int NR = (kResMaxKeys * 4 + 511) / 512;  // rounds of 512 threads over (key, chunk) / (pair, chunk) items
+    uint4 rk[NR][2], rv[NR][2];
+    const int nK = Lkp * 4, nV = (Lkp / 2) * 8, halfp = Lkp / 2;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int idx = tid + r * 512;
+        rk[r][0] = rk[r][1] = rv[r][0] = rv[r][1] = make_uint4(0, 0, 0, 0);
+        if (idx < nK) {
+            const int key = idx >> 2, ch = (idx & 3) * 16;
+            if (key < Lk) {
+                const unsigned short *kp = a.k + (kbase + key) * a.ldk + h * HD + ch;
+                rk[r][0] = *reinterpret_cast<const uint4 *>(kp);
+                rk[r][1] = *reinterpret_cast<const uint4 *>(kp + 8);
+            }
+        }
+        if (idx < nV) {
+            const int kp2 = idx % halfp, vc = idx / halfp;
+            if (2 * kp2 < Lk) rv[r][0] = *reinterpret_cast<const uint4 *>(a.v + (kbase + 2 * kp2) * a.ldv + h * HD + vc * 8);
+            if (2 * kp2 + 1 < Lk) rv[r][1] = *reinterpret_cast<const uint4 *>(a.v + (kbase + 2 * kp2 + 1) * a.ldv + h * HD + vc * 8);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int idx = tid + r * 512;
+        if (idx < nK) {
+            const int key = idx >> 2, ch = (idx & 3) * 16;
+            *reinterpret_cast<uint4 *>(&sK[key * KROW + ch]) = rk[r][0];
+            *reinterpret_cast<uint4 *>(&sK[key * KROW + ch + 8]) = rk[r][1];
+        }
+        if (idx < nV) {
+            const int kp2 = idx % halfp, vc = idx / halfp;
+            const unsigned wa[4] = {rv[r][0].x, rv[r][0].y, rv[r][0].z, rv[r][0].w}, wb[4] = {rv[r][1].x, rv[r][1].y, rv[r][1].z, rv[r][1].w};
+            unsigned *vt = reinterpret_cast<unsigned *>(sVT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vt[((vc * 8 + 2 * i) * vrow) / 2 + kp2] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
+                vt[((vc * 8 + 2 * i + 1) * vrow) / 2 + kp2] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int ngroups = (a.Lq + 15) >> 4;
+    for (int grp = wid; grp < ngroups; grp += 8) {
+        const int qi = grp * 16 + c16;
+        const bool qvalid = qi < a.Lq;
+        const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+        const unsigned short *qp = a.q + qrow * a.ldq + h * HD + g * 8;
+        const uint4 qf0 = *reinterpret_cast<const uint4 *>(qp), qf1 = *reinterpret_cast<const uint4 *>(qp + 32);
+        f4 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int kt = 0; kt < Lk; kt += KB) {
+            const int nbmax = min(4, (Lk - kt + 15) >> 4);  // 16-key sub-blocks of this tile that hold keys (wave-uniform)
+            f4 st[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                st[nb] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (nb < nbmax) {
+                    const unsigned short *kr = &sK[(kt + nb * 16 + c16) * KROW + g * 8];
+                    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+                    acc = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr), qf0, acc);
+                    acc = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr + 32), qf1, acc);
+                    st[nb] = acc;
+                }
+            }
+            if (kt + KB > Lk) {  // straddling tile: keys past Lk are padding
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt + nb * 16 + g * 4 + r >= Lk) st[nb][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+            for (int nb = 1; nb < 4; ++nb) mx = fmaxf(fmaxf(mx, fmaxf(st[nb][0], st[nb][1])), fmaxf(st[nb][2], st[nb][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * a.scale_log2e);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[nb][r], a.scale_log2e, -m_use));
+                    st[nb][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ar = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) o[db][r] *= ar;
+                }
+                m_run = m_new;
+            }
+            l_run += rs;
+            uint4 pf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                pf[ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
+                pf[ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
+                pf[ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+                pf[ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+            }
+            const int ksmax = (nbmax + 1) >> 1;  // 32-key MFMA steps that hold keys (V^T padding beyond is zero)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks < ksmax) {
+                        const unsigned short *vr = &sVT[(db * 16 + c16) * vrow + kt + g * 4];
+                        uint2 lo = *reinterpret_cast<const uint2 *>(vr + (2 * ks) * 16);
+                        uint2 hi = make_uint2(0, 0);
+                        if (2 * ks + 1 < nbmax) hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
+                        o[db] = mfma<BF16>(pf[ks], make_uint4(lo.x, lo.y, hi.x, hi.y), o[db]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lr = __shfl(l_run, g * 4 + r, 64);
+            const int qo = grp * 16 + g * 4 + r;
+            if (qo >= a.Lq) continue;
+            const float inv = lr > 0.f ? 1.0f / lr : 0.f;
+            unsigned short *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[db][r] * inv);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vs_attention(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq,
@@ -295,6 +458,21 @@ extern "C" int vs_attention(const void *q, const void *k, const void *v, void *o
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; else 64
     static const int force_qg = [] { const char *e = getenv("VS_ATTN_QG"); return e ? atoi(e) : 0; }();
     static const int force_wpe = [] { const char *e = getenv("VS_ATTN_WPE"); return e ? atoi(e) : 0; }();
+    static const int force_res = [] { const char *e = getenv("VS_ATTN_RES"); return e ? atoi(e) : -1; }();
+    if (!kv_seg && !q_kvlen && Lk <= kResMaxKeys && Lq <= 3 * 8 * 16 && force_res != 0) {
+        const int Lkp = (Lk + 15) & ~15;
+        const size_t lds = (size_t)(Lkp * KROW + HD * (Lkp + 8)) * sizeof(unsigned short);
+        dim3 grid(1, H, nbatch);
+        if (dtype == 2) {
+            VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((attention_res_kernel<true>), grid, dim3(512), lds, stream, a);
+        } else {
+            VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((attention_res_kernel<false>), grid, dim3(512), lds, stream, a);
+        }
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     // 128 queries per workgroup only for long key sequences (more MFMAs per staged tile); the 257/516-key shapes are
     // latency bound and run faster with 64-query workgroups at higher occupancy
     const int Lk_eff = kv_seg ? 2 * Lk : Lk;
