@@ -11,7 +11,7 @@ def bench(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e-3
 # encoder: 64 frames x 16 heads x 257
-for name, nb, H, Lq, Lk, seg in [("encoder", 64, 16, 257, 257, False), ("video", 8, 12, 2064, 2064, False), ("neighbor", 64, 12, 257, 514, True)]:
+for name, nb, H, Lq, Lk, seg in [("encoder", 64, 16, 257, 257, False), ("encoder192", 192, 16, 257, 257, False), ("video", 8, 12, 2064, 2064, False), ("neighbor", 64, 12, 257, 514, True)]:
     C = H * 64
     rows = nb * Lq
     qkv = torch.randn(rows, 3 * C, device=d).half()

@@ -279,24 +279,27 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     if (g.M <= 64 && force == 0 && epi != 4) return launch_smallm<BF16>(g, epi, stream);
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
-    // M = frames * 257 tokens is never a multiple of the tile height, and one partial row of tiles past a full wave of
-    // workgroups costs a whole extra round.  Every path below therefore runs the full tile rows as one launch and a
-    // leftover of <= half a tile as a tail launch whenever the partial row would open a new round.
-    // 256x256 tiles (one 8-wave workgroup per CU): for K-tile-aligned shapes whose full tile rows fill the 256 CUs evenly.
+    // 256x256 tiles run one 8-wave workgroup per CU, i.e. in rounds of 256 tiles, and a partly filled round costs as much
+    // as a full one (M = frames * 257 tokens never divides).  So the big tiles only get as many rows as fill whole rounds;
+    // the remaining rows are finished by a launch of small tiles (128x128, 3 workgroups per CU) or, for <= 64 rows, the
+    // weight-streaming kernel -- a short round instead of a mostly idle long one.
     if (g.K % 128 == 0 && g.M >= 256) {
-        const int tn = vs::cdiv(g.N, 256), rem = g.M % 256;
-        const long long full = (long long)(g.M / 256) * tn;
-        // leftover rows go to a tail launch when they are at most half a tile, or when their partial tile row would open a
-        // new round of workgroups (one 8-wave workgroup per CU: 256 slots)
-        const int tail = (rem > 0 && full > 0 && (rem <= 128 || (full + tn + 255) / 256 > (full + 255) / 256)) ? rem : 0;
-        const long long tiles = (long long)vs::cdiv(g.M - tail, 256) * tn;
-        const long long rounds = (tiles + 255) / 256;
-        if (force == 16 || tiles * 100 >= rounds * 256 * 85) {
+        const int tn = vs::cdiv(g.N, 256), mt = g.M / 256;
+        const long long full = (long long)mt * tn, rounds_all = (vs::cdiv(g.M, 256) * (long long)tn + 255) / 256;
+        int mt_main = mt;
+        if (full > 256 && full % 256 != 0) mt_main = (int)((full / 256) * 256 / tn);  // whole rounds only
+        const int rows_main = mt_main * 256, rem = g.M - rows_main;
+        // cost in units of one 256x256 round; a 128x128 round (768 tiles) is about 0.31 of it
+        const long long tiles4 = (long long)vs::cdiv(rem, 128) * vs::cdiv(g.N, 128);
+        const double cost_split = (double)(((long long)mt_main * tn + 255) / 256) + (rem > 0 ? 0.31 * (double)((tiles4 + 767) / 768) : 0.0);
+        const bool split = rem > 0 && mt_main > 0 && cost_split < (double)rounds_all - 0.05;
+        const long long tiles_one = vs::cdiv(g.M, 256) * (long long)tn;
+        if (force == 16 || split || tiles_one * 100 >= rounds_all * 256 * 85) {
             GemmArgs main_g = g;
-            main_g.M = g.M - tail;
+            if (split) main_g.M = rows_main;
             int rc = launch_256<BF16>(main_g, epi, stream);
-            if (rc || !tail) return rc;
-            return launch_tail<BF16>(g, tail, epi, stream);
+            if (rc || !split) return rc;
+            return launch_tail<BF16>(g, rem, epi, stream);
         }
     }
     // 256x128 tiles (half the W-panel traffic and LDS-DMA issue per flop of 128x128) whenever there are enough of them
