@@ -390,3 +390,25 @@ def test_upsample2x_nhwc(dt):
         assert (out - (ref + add.float())).abs().max() <= tol * (ref + add.float()).abs().max()
         out = ops.upsample2x_nhwc(x.permute(0, 2, 3, 1).contiguous(), add.permute(0, 2, 3, 1).contiguous(), relu_add=True).permute(0, 3, 1, 2).float()
         assert (out - (ref + F.relu(add.float()))).abs().max() <= tol * (ref + add.float()).abs().max()
+
+
+def test_abi_rejects_bad_arguments_loudly():
+    """Error behaviour at the boundary: negative return + vs_last_error message -> RuntimeError (mirrors TORCH_CHECK in
+    curope.cpp:54-59); nothing is silently rounded, padded or sent to a slow path."""
+    from vicasplat_amd import ops
+    d = _dev()
+    a = torch.zeros(64, 96, dtype=torch.float16, device=d)
+    w = torch.zeros(32, 96, dtype=torch.float16, device=d)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(a, w, None, torch.empty(64, 32, dtype=torch.float16, device=d), ops.EPI_STORE16)
+    x = torch.zeros(1, 8, 8, 48, dtype=torch.float16, device=d)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.conv3x3_nhwc(x, torch.zeros(64, 3, 3, 48, dtype=torch.float16, device=d))
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        ops.upsample2x_nhwc(torch.zeros(1, 4, 4, 12, dtype=torch.float16, device=d))
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm(a.cpu(), w, None, torch.empty(64, 32, dtype=torch.float16, device=d), ops.EPI_STORE16)  # host tensor
+    q = torch.zeros(16, 3 * 64, dtype=torch.float16, device=d)
+    with pytest.raises(RuntimeError, match="C % 64"):
+        ops.gemm_qkv_rope(torch.zeros(16, 64, dtype=torch.float16, device=d), torch.zeros(192, 64, dtype=torch.float16, device=d), None, q,
+                          48, torch.zeros(16, 2, dtype=torch.int32, device=d))

@@ -159,6 +159,44 @@ def test_large_tile_sort_paths(P, tied):
     _compare(o, g, 0, color_atol=1e-4)
 
 
+def test_full_size_scene_invariants():
+    """BASELINE config-4 size (8 views -> 524 288 Gaussians, 256x256 targets): size-independent properties of the forward
+    state, checked on the device -- per-tile lists sorted by (depth, index), every listed Gaussian overlaps its tile,
+    populations add up to R, opacity = 1 - final_T, n_contrib <= tile population."""
+    d = _dev()
+    sc = rr.synthetic_scene(V=8, res=256, Vt=4, seed=3)
+    cams = rr.make_cameras(sc["extrinsics"], sc["intrinsics"], sc["near"], sc["far"])
+    shs = np.ascontiguousarray(np.transpose(sc["harmonics"], (0, 2, 1)))
+    g = _run_gpu(sc["means"], rr.cov6(sc["covariances"]), shs, sc["opacities"], cams, 256, 256, np.zeros(3, np.float32))
+    C, P = len(cams), sc["means"].shape[0]
+    assert P == 524288
+    rg = g["ranges"].long()                       # [C, tiles, 2]
+    pop = rg[..., 1] - rg[..., 0]
+    assert int(pop.sum()) == g["R"] == g["point_list"].numel()
+    assert torch.equal(rg[..., 0].flatten()[1:], rg[..., 1].flatten()[:-1]), "ranges tile the list without gaps"
+    pl = g["point_list"].long()
+    tile_of = torch.repeat_interleave(torch.arange(C * 256, device=d), pop.flatten())
+    cam_of, t_in = tile_of // 256, tile_of % 256
+    depth = g["geom"][cam_of, pl, 11]
+    same_tile = tile_of[1:] == tile_of[:-1]
+    dd = depth[1:] - depth[:-1]
+    assert bool((dd[same_tile] >= 0).all()), "depth-sorted inside every tile"
+    tie = same_tile & (dd == 0)
+    assert bool((pl[1:][tie] > pl[:-1][tie]).all()), "ties broken by Gaussian index"
+    rect = g["rect"][cam_of, pl].long()           # min.x min.y max.x max.y (exclusive max)
+    tx, ty = t_in % 16, t_in // 16
+    assert bool(((tx >= rect[:, 0]) & (tx < rect[:, 2]) & (ty >= rect[:, 1]) & (ty < rect[:, 3])).all())
+    assert bool((g["radii"][cam_of, pl] > 0).all())
+    # every (visible Gaussian, covered tile) pair is listed exactly once
+    r_all = g["rect"].long()
+    want = ((r_all[..., 2] - r_all[..., 0]) * (r_all[..., 3] - r_all[..., 1]))[g["radii"] > 0].sum()
+    assert int(want) == g["R"]
+    assert torch.allclose(g["opacity"], 1.0 - g["final_T"], atol=1e-6)
+    tile_pop_px = pop.view(C, 16, 16).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    assert bool((g["n_contrib"] <= tile_pop_px).all()) and bool((g["n_contrib"] >= 0).all())
+    assert bool(torch.isfinite(g["color"]).all()) and float(g["final_T"].min()) >= 0.0 and float(g["final_T"].max()) <= 1.0
+
+
 def test_empty_and_culled():
     d = _dev()
     cams = _two_cams()
