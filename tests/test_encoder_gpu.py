@@ -1,4 +1,4 @@
-"""End-to-end parity of the MI355X encoder (HIP ViT blocks + MIOpen heads) against golden vectors produced by the REAL
+"""End-to-end parity of the MI355X encoder (hand-written HIP kernels end to end) against golden vectors produced by the REAL
 reference on CPU in float64 (tests/golden/encoder_*.npz).  -m gpu.
 
 Precision policy: GEMM/attention operands f16 with f32 accumulation and f32 residual stream -- the
@@ -84,6 +84,24 @@ def test_encoder_full_vitl_8view_matches_reference():
 
 def test_encoder_bf16_path_runs():
     _check("tiny_v2", torch.bfloat16, 3e-2, 2e-1)
+
+
+def test_scenes_are_independent_so_sharding_is_exact():
+    """The multi-GPU path shards the scene batch with no collective: a scene must come out the same
+    (to operand-rounding noise) whether it is encoded alone or inside a larger batch."""
+    m = _model("full")
+    img, K = er.synthetic_input(3, 2, 256, 11)
+    both = m(dict(image=img.cuda(), intrinsics=K.cuda()), compute_viewspace_depth=False)
+    for i in (0, 2):
+        one = m(dict(image=img[i:i + 1].cuda(), intrinsics=K[i:i + 1].cuda()), compute_viewspace_depth=False)
+        e = (_rel(one["pred_extrins"].cpu(), both["pred_extrins"][i:i + 1].cpu()),
+             _rel(one["raw_gaussians"].cpu(), both["raw_gaussians"][i:i + 1].cpu()),
+             _rel(one["gaussians"].means.cpu(), both["gaussians"].means[i:i + 1].cpu()))
+        print("scene", i, "alone vs in batch:", ["%.2e" % v for v in e])
+        # not bitwise: batch size picks different GEMM kernels (tile vs small-M / tail) whose f32 sums are ordered
+        # differently, and a last-bit difference can flip a 16-bit operand rounding that 36 blocks then amplify; the result
+        # stays inside the 16-bit-operand noise floor measured against the reference goldens (pose 1e-3, raw 5e-3)
+        assert e[0] <= 1e-3 and e[1] <= 1e-2 and e[2] <= 1e-2, e
 
 
 def test_no_cpu_fallback():
