@@ -80,3 +80,26 @@ def test_transforms_json(tmp_path):
     frames = json.load(open(tmp_path / "s" / "transforms.json"))
     assert [f["file_path"] for f in frames] == ["context/000000.png", "context/000001.png", "context/000002.png"]
     assert frames[2]["transform_matrix"][0][3] == 2.0
+
+
+def test_load_images_resize_crop_normalise(tmp_path):
+    from PIL import Image
+    # 400 x 300 landscape: left half red, right half blue, a green band over the top 30 rows
+    a = np.zeros((300, 400, 3), np.uint8)
+    a[:, :200, 0] = 255; a[:, 200:, 2] = 255; a[:30, :, 1] = 255
+    Image.fromarray(a).save(tmp_path / "b.png")
+    Image.fromarray(np.full((100, 60, 3), 128, np.uint8)).save(tmp_path / "a.png")   # small portrait: enlarged (bicubic)
+    (tmp_path / "notes.txt").write_text("ignored")
+    x = callers.load_images(str(tmp_path), size=256)
+    assert x.shape == (2, 3, 256, 256) and x.dtype == torch.float32
+    assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0
+    assert torch.allclose(x[0], torch.full_like(x[0], 128 / 255 * 2 - 1), atol=1e-6)    # name order: a.png first
+    img = x[1]                                                                           # 400x300 -> 341x256 -> centre 256x256
+    assert float(img[0, 128, 10]) > 0.9 and float(img[2, 128, 10]) < -0.9                # left: red
+    assert float(img[2, 128, 245]) > 0.9 and float(img[0, 128, 245]) < -0.9              # right: blue
+    assert float(img[1, 5, 128]) > 0.9 and float(img[1, 200, 128]) < -0.9                # green band survives at the top
+    # the crop is centred: the red/blue boundary sits in the middle column
+    assert abs(int((img[0, 128] > 0).sum()) - 128) <= 2
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        callers.load_images([str(tmp_path / "notes.txt")])

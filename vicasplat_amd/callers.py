@@ -8,6 +8,7 @@ scripts do around the encoder/decoder:
   * `align_poses`             — ModelWrapper.test_step_align, src/model/model_wrapper.py:442-513
   * `export_ply`              — src/model/ply_export.py:31-90 (own binary writer, no plyfile dependency)
   * `export_transforms`       — src/model/model_wrapper.py:390-400 (transforms.json)
+  * `load_images`             — demo.py:75-132 (resize short side to 256, centre crop, normalise to [-1, 1])
 The encoder's training step (backward through the transformer) is not built; see DESIGN.md §7.
 """
 from __future__ import annotations
@@ -152,3 +153,38 @@ def export_transforms(extrinsics: Tensor, path, file_names: list[str] | None = N
     path.parent.mkdir(exist_ok=True, parents=True)
     with open(path, "w") as f:
         json.dump(frames, f, indent=4)
+
+
+_IMAGE_EXT = (".jpg", ".jpeg", ".png")
+
+
+def load_images(folder_or_list, size: int = 256) -> Tensor:
+    """Demo pre-processing (demo.py:75-132): EXIF-upright RGB, short side resized to `size` (Lanczos when shrinking,
+    bicubic when enlarging), centre square crop, then (x/255 - 0.5) / 0.5.  Returns [V, 3, size, size] f32, files in
+    name order.  Host-side (PIL); the frames go to the GPU with the batch."""
+    import os
+    from PIL import Image, ImageOps
+    if isinstance(folder_or_list, (str, os.PathLike)):
+        root = os.fspath(folder_or_list)
+        paths = [os.path.join(root, f) for f in sorted(os.listdir(root))]
+    else:
+        paths = sorted((os.fspath(f) for f in folder_or_list), key=lambda f: f.split("/")[-1])
+    frames = []
+    for path in paths:
+        if not path.lower().endswith(_IMAGE_EXT):
+            continue
+        img = ImageOps.exif_transpose(Image.open(path)).convert("RGB")
+        w, h = img.size
+        long_edge = round(size * max(w / h, h / w))   # short side -> size
+        big = max(w, h)
+        interp = Image.LANCZOS if big > long_edge else Image.BICUBIC
+        img = img.resize((int(round(w * long_edge / big)), int(round(h * long_edge / big))), interp)
+        w, h = img.size
+        cx, cy = w // 2, h // 2
+        half = min(cx, cy)
+        img = img.crop((cx - half, cy - half, cx + half, cy + half))
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        frames.append((x - 0.5) / 0.5)
+    if not frames:
+        raise FileNotFoundError(f"no .jpg/.jpeg/.png images in {folder_or_list!r}")
+    return torch.stack(frames, 0)
