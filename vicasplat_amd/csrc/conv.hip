@@ -28,69 +28,56 @@ struct ConvArgs {
     int Hin, Win, stride;
 };
 
-// epilogue shared by the conv kernels: every wave transposes one 16 x 64 f32 slab (acc + bias) at a time through a
-// private LDS patch, then each lane finishes two 8-channel row chunks: + residual (16-byte load, added in f32), ReLU,
-// round to 16 bit, one 16-byte store.  mw0 / nbase = first output pixel / channel of the wave's tile.
+// epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
+// channels of one pixel per fragment): + bias, + residual (8-byte load, added in f32), ReLU, round to 16 bit, one 8-byte
+// store per fragment -- no LDS round trip.  mw0 / nbase = first output pixel / channel of the wave's tile.
 template <bool BF16, int MI>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, int M, void *scratch,
-                                              int wid, int lane) {
-    const int ccol = lane & 15, crow = (lane >> 4) * 4;
-    float bv[4];
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, int M, void *, int, int lane) {
+    const int mrow = lane & 15, c4 = (lane >> 4) * 4;
+    float bv[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nbase + j * 16 + ccol;
-        bv[j] = (g.bias && n < g.Cout) ? g.bias[n] : 0.0f;
-    }
-    constexpr int PR = 64 + 4;  // floats per patch row (272 B)
-    float *patch = reinterpret_cast<float *>(scratch) + wid * (16 * PR);
-    const bool vec_ok = (g.Cout % 8 == 0) && (nbase + 64 <= g.Cout) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) &&
-                        (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nbase + j * 16 + c4 + r;
+            bv[j][r] = (g.bias && n < g.Cout) ? g.bias[n] : 0.0f;
+        }
+    const bool vec_ok = (g.Cout % 4 == 0) && (nbase + 64 <= g.Cout) && ((reinterpret_cast<uintptr_t>(g.out) & 7) == 0) &&
+                        (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 7) == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        const int m = mw0 + i * 16 + mrow;
+        if (m >= M) continue;
+        const size_t o = (size_t)m * g.Cout + nbase + c4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) patch[(crow + r) * PR + j * 16 + ccol] = acc[i][j][r] + bv[j];
-        wave_lds_sync();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
-            const int m = mw0 + i * 16 + prow;
-            if (m < M) {
-                const float4 lo = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 8]);
-                const float4 hi = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 8 + 4]);
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const size_t o = (size_t)m * g.Cout + nbase + pch * 8;
-                if (vec_ok) {
-                    if (g.res) {
-                        const uint4 rv = *reinterpret_cast<const uint4 *>(g.res + o);
-                        const unsigned rr[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[2 * e] += from16<BF16>((unsigned short)(rr[e] & 0xffffu));
-                            v[2 * e + 1] += from16<BF16>((unsigned short)(rr[e] >> 16));
-                        }
-                    }
-                    unsigned pk[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a0 = g.relu_out ? fmaxf(v[2 * e], 0.0f) : v[2 * e];
-                        const float a1 = g.relu_out ? fmaxf(v[2 * e + 1], 0.0f) : v[2 * e + 1];
-                        pk[e] = (unsigned)to16<BF16>(a0) | ((unsigned)to16<BF16>(a1) << 16);
-                    }
-                    *reinterpret_cast<uint4 *>(g.out + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (nbase + pch * 8 + e < g.Cout) {
-                            float a = v[e] + (g.res ? from16<BF16>(g.res[o + e]) : 0.0f);
-                            if (g.relu_out) a = fmaxf(a, 0.0f);
-                            g.out[o + e] = to16<BF16>(a);
-                        }
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+            if (vec_ok) {
+                if (g.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2 *>(g.res + o + j * 16);
+                    v[0] += from16<BF16>((unsigned short)(rv.x & 0xffffu)); v[1] += from16<BF16>((unsigned short)(rv.x >> 16));
+                    v[2] += from16<BF16>((unsigned short)(rv.y & 0xffffu)); v[3] += from16<BF16>((unsigned short)(rv.y >> 16));
                 }
+                if (g.relu_out) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
+                pk.y = (unsigned)to16<BF16>(v[2]) | ((unsigned)to16<BF16>(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(g.out + o + j * 16) = pk;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nbase + j * 16 + c4 + r < g.Cout) {
+                        float x = v[r] + (g.res ? from16<BF16>(g.res[o + j * 16 + r]) : 0.0f);
+                        if (g.relu_out) x = fmaxf(x, 0.0f);
+                        g.out[o + j * 16 + r] = to16<BF16>(x);
+                    }
             }
         }
-        wave_lds_sync();
     }
 }
 
@@ -265,7 +252,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
             const int ra_ = wr * (16 * MI) + i * 16 + frow;                                                 \
             uint4 fa = *reinterpret_cast<const uint4 *>(&cA[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);           \
             if (g.relu_in) { fa.x = relu2(fa.x); fa.y = relu2(fa.y); fa.z = relu2(fa.z); fa.w = relu2(fa.w); } \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fb[j], fa, acc[i][j]);     \
         }                                                                                                   \
     }
     VS_STAGE(0)

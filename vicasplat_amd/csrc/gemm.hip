@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                    \
             const int ra_ = wr * (16 * MI) + i * 16 + frow;                                                 \
             const uint4 fa = *reinterpret_cast<const uint4 *>(&cA[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);     \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fa, fb[j], acc[i][j]);     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fb[j], fa, acc[i][j]);     \
         }                                                                                                   \
     }
     VS_STAGE(0, 0)

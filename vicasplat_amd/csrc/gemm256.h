@@ -76,8 +76,8 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
 #define VS_MM(ha_, hb_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fa[i][0], fb[hb_][j][0], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
-            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fa[i][1], fb[hb_][j][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fb[hb_][j][0], fa[i][0], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fb[hb_][j][1], fa[i][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
         }
 #define VS_BAR()                                  \
     {                                             \

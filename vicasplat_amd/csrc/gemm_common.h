@@ -99,172 +99,129 @@ __device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
 }
 
-// The epilogue patches are private to a wave: ordering its own LDS writes before its own reads needs no workgroup
-// barrier (LDS operations of one wave execute in order) -- only a compiler/memory-model fence at wavefront scope.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---- epilogue shared by the tile kernels.  A lane's accumulators are 4 rows x 1 column per fragment: storing them
-// directly means 2-byte (or 4-byte) scattered stores.  Instead every wave transposes one 16 x 64 slab at a time through
-// a private LDS patch (`scratch`: the operand tiles, dead after the last barrier; 16*68*4 B per wave) and writes /
-// updates full 16-byte row chunks.  mw0 / nbase = first output row / column of the wave's (16*MI) x 64 tile. ----
+// ---- epilogue shared by the tile kernels.  The main loops issue mfma(W fragment, A fragment): the accumulator tile is
+// C^T, so a lane holds FOUR CONSECUTIVE OUTPUT COLUMNS of one row per fragment (row m = lane & 15, columns
+// (lane >> 4) * 4 + 0..3) -- an 8-byte (16-bit) or 16-byte (f32) store per fragment straight from registers, no LDS
+// transpose and no barrier; RoPE pairs (c, c+16) are fragments j / j+1 of the same lane, interleaved pairs (2p, 2p+1) are
+// neighbouring registers.  mw0 / nbase = first output row / column of the wave's (16*MI) x 64 tile. ----
 template <bool BF16, int EPI, int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *scratch, int wid,
-                                              int lane) {
-    const int ccol = lane & 15, crow = (lane >> 4) * 4;
-    float bv[4];
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *, int, int lane) {
+    const int mrow = lane & 15, c4 = (lane >> 4) * 4;
+    const bool full_n = nbase + 64 <= g.N;
+    float bv[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nbase + j * 16 + ccol;
-        bv[j] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
-    }
-    if constexpr (EPI == 0 || EPI == 1 || EPI == 4) {
-        constexpr int PR = 64 + 8;  // halfs per patch row (144 B: 16-byte aligned, conflict-light)
-        unsigned short *patch = reinterpret_cast<unsigned short *>(scratch) + wid * (16 * PR);
-        const bool vec_ok = (g.ldo % 8 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
-        // RoPE (EPI 4): a wave's 64 columns are one head; in the accumulator layout the 2-D pair (c, c+16) of a 32-half is
-        // (fragment 2h, fragment 2h+1) of the SAME lane, the 1-D pair (2p, 2p+1) is the neighbouring lane.
-        [[maybe_unused]] bool rope_on = false;
-        [[maybe_unused]] float inv2d = 0.f;
-        if constexpr (EPI == 4) {
-            rope_on = nbase < 2 * g.rope_C && nbase + 64 <= g.N;
-            inv2d = __builtin_amdgcn_exp2f(-(float)ccol * (1.0f / 16.0f) * g.rope_l2base);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nbase + j * 16 + c4 + r;
+            bv[j][r] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
         }
-        [[maybe_unused]] int2 rope_p[4] = {};
-        [[maybe_unused]] int rope_k[4] = {};
-        [[maybe_unused]] auto rope_fetch = [&](int i_) {  // pos / kind of the 4 output rows this lane holds in slab i_
+    [[maybe_unused]] float inv2d[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] bool rope_on = false;
+    if constexpr (EPI == 4) {
+        rope_on = nbase < 2 * g.rope_C && full_n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) inv2d[r] = __builtin_amdgcn_exp2f(-(float)(c4 + r) * (1.0f / 16.0f) * g.rope_l2base);
+    }
+    constexpr bool OUT16 = EPI == 0 || EPI == 1 || EPI == 4;
+    const bool vec_ok = full_n && (OUT16 ? (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 7) == 0)
+                                         : (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0));
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mw0 + i * 16 + mrow;
+        const bool valid = m < g.M;
+        const int mc = valid ? m : g.M - 1;
+        const size_t orow = (size_t)(mc / g.grp_in) * g.grp_out + g.grp_off + (mc % g.grp_in);
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = min(mw0 + i_ * 16 + crow + r, g.M - 1);
-                const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                rope_p[r] = *reinterpret_cast<const int2 *>(g.rope_pos + 2 * orow);
-                rope_k[r] = g.rope_kind ? (int)g.rope_kind[orow] : 0;
+                v[j][r] = acc[i][j][r] + bv[j][r];
+                if constexpr (EPI == 1) v[j][r] = gelu_erf(v[j][r]);
             }
-        };
         if constexpr (EPI == 4) {
-            if (rope_on) rope_fetch(0);
-        }
+            if (rope_on) {
+                const int kd = g.rope_kind ? (int)g.rope_kind[orow] : 0;
+                const int2 pp = *reinterpret_cast<const int2 *>(g.rope_pos + 2 * orow);
+                if (kd == 0) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            float vv[4][4];
+                    for (int h = 0; h < 2; ++h) {
+                        const float p = (float)(h == 0 ? pp.x : pp.y);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                        for (int r = 0; r < 4; ++r) {
+                            float sn, cs;
+                            sincos_hw(p * inv2d[r], sn, cs);
+                            const float u = v[2 * h][r], w = v[2 * h + 1][r];
+                            v[2 * h][r] = u * cs - w * sn;
+                            v[2 * h + 1][r] = w * cs + u * sn;
+                        }
+                    }
+                } else if (kd == 1) {  // temporal rope of a camera-token row: interleaved pairs (2p, 2p+1) = registers (r, r+1)
+                    const float p = (float)pp.x;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    vv[j][r] = acc[i][j][r] + bv[j];
-                    if constexpr (EPI == 1) vv[j][r] = gelu_erf(vv[j][r]);
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            float sn, cs;
+                            sincos_hw(p * __builtin_amdgcn_exp2f(-(float)((j * 16 + c4 + r) >> 1) * (1.0f / 32.0f) * g.rope_l2theta), sn, cs);
+                            const float u = v[j][r], w = v[j][r + 1];
+                            v[j][r] = u * cs - w * sn;
+                            v[j][r + 1] = w * cs + u * sn;
+                        }
                 }
-            if constexpr (EPI == 4) {
-                if (rope_on) {
-                    // this slab's row table entries were fetched while the previous slab was processed
-                    int2 pcur[4]; int kcur[4];
+            }
+        }
+        if (!valid) continue;
+        if constexpr (OUT16) {
+            unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + c4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pcur[r] = rope_p[r]; kcur[r] = rope_k[r]; }
-                    if (i + 1 < MI) rope_fetch(i + 1);
+            for (int j = 0; j < 4; ++j) {
+                if (vec_ok) {
+                    uint2 pk;
+                    pk.x = (unsigned)to16<BF16>(v[j][0]) | ((unsigned)to16<BF16>(v[j][1]) << 16);
+                    pk.y = (unsigned)to16<BF16>(v[j][2]) | ((unsigned)to16<BF16>(v[j][3]) << 16);
+                    *reinterpret_cast<uint2 *>(dst + j * 16) = pk;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nbase + j * 16 + c4 + r < g.N) dst[j * 16 + r] = to16<BF16>(v[j][r]);
+                }
+            }
+        } else {
+            float *dst = reinterpret_cast<float *>(g.out) + orow * g.ldo + nbase + c4;
+            const float *gp = nullptr;
+            if (EPI == 2 && g.gate) gp = g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nbase + c4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (vec_ok) {
+                    float4 val = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    if constexpr (EPI == 2) {
+                        if (gp) {
+                            const bool g_ok = (reinterpret_cast<uintptr_t>(gp + j * 16) & 15) == 0;
+                            float gt[4];
+                            if (g_ok) { const float4 t = *reinterpret_cast<const float4 *>(gp + j * 16); gt[0] = t.x; gt[1] = t.y; gt[2] = t.z; gt[3] = t.w; }
+                            else { gt[0] = gp[j * 16]; gt[1] = gp[j * 16 + 1]; gt[2] = gp[j * 16 + 2]; gt[3] = gp[j * 16 + 3]; }
+                            val.x *= 1.0f + gt[0]; val.y *= 1.0f + gt[1]; val.z *= 1.0f + gt[2]; val.w *= 1.0f + gt[3];
+                        }
+                        float4 o = *reinterpret_cast<float4 *>(dst + j * 16);
+                        o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
+                        *reinterpret_cast<float4 *>(dst + j * 16) = o;
+                    } else {
+                        *reinterpret_cast<float4 *>(dst + j * 16) = val;
+                    }
+                } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int kd = kcur[r];
-                        const float p0 = (float)pcur[r].x, p1 = (float)pcur[r].y;
-                        if (kd == 0) {
-                            float s0, c0, s1, c1;
-                            sincos_hw(p0 * inv2d, s0, c0);
-                            sincos_hw(p1 * inv2d, s1, c1);
-                            const float u0 = vv[0][r], w0 = vv[1][r], u1 = vv[2][r], w1 = vv[3][r];
-                            vv[0][r] = u0 * c0 - w0 * s0; vv[1][r] = w0 * c0 + u0 * s0;
-                            vv[2][r] = u1 * c1 - w1 * s1; vv[3][r] = w1 * c1 + u1 * s1;
-                        }
-                        // camera-token rows (1 in 258): interleaved pairs live in lanes (2p, 2p+1); whole wave joins the swap
-                        if (__builtin_amdgcn_ballot_w64(kd == 1) != 0) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float other = __shfl_xor(vv[j][r], 1, 64);
-                                if (kd == 1) {
-                                    float sn, cs;
-                                    sincos_hw(p0 * __builtin_amdgcn_exp2f(-(float)((j * 16 + ccol) >> 1) * (1.0f / 32.0f) * g.rope_l2theta), sn, cs);
-                                    vv[j][r] = (ccol & 1) ? vv[j][r] * cs + other * sn : vv[j][r] * cs - other * sn;
-                                }
-                            }
+                        const int n = nbase + j * 16 + c4 + r;
+                        if (n < g.N) {
+                            float x = v[j][r];
+                            if (EPI == 2 && gp) x *= 1.0f + gp[j * 16 + r];
+                            if constexpr (EPI == 2) dst[j * 16 + r] += x; else dst[j * 16 + r] = x;
                         }
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) patch[(crow + r) * PR + j * 16 + ccol] = to16<BF16>(vv[j][r]);
-            wave_lds_sync();
-            // 16 rows x 8 chunks of 8 halfs = 128 chunks, 2 per lane
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int q = lane + 64 * c, prow = q >> 3, pch = q & 7;
-                const int m = mw0 + i * 16 + prow;
-                if (m < g.M) {
-                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                    unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + pch * 8;
-                    const uint4 val = *reinterpret_cast<const uint4 *>(&patch[prow * PR + pch * 8]);
-                    if (vec_ok) {
-                        *reinterpret_cast<uint4 *>(dst) = val;
-                    } else {
-                        const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (nbase + pch * 8 + e < g.N) dst[e] = hv[e];
-                    }
-                }
-            }
-            wave_lds_sync();
-        }
-    } else {
-        constexpr int PR = 64 + 4;  // floats per patch row (272 B)
-        float *patch = reinterpret_cast<float *>(scratch) + wid * (16 * PR);
-        const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (nbase + 64 <= g.N);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mw0 + i * 16 + crow + r;
-                const float *gp = nullptr;
-                if (EPI == 2 && g.gate && m < g.M) gp = g.gate + (size_t)(m / g.gate_rows) * g.gate_ld;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = nbase + j * 16 + ccol;
-                    float v = acc[i][j][r] + bv[j];
-                    if (gp && n < g.N) v *= 1.0f + gp[n];
-                    patch[(crow + r) * PR + j * 16 + ccol] = v;
-                }
-            }
-            wave_lds_sync();
-            // 16 rows x 16 chunks of 4 floats = 256 chunks, 4 per lane
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int q = lane + 64 * c, prow = q >> 4, pch = q & 15;
-                const int m = mw0 + i * 16 + prow;
-                if (m < g.M) {
-                    const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-                    float *dst = reinterpret_cast<float *>(g.out) + orow * g.ldo + nbase + pch * 4;
-                    const float4 val = *reinterpret_cast<const float4 *>(&patch[prow * PR + pch * 4]);
-                    if (vec_ok) {
-                        if constexpr (EPI == 2) {
-                            float4 o = *reinterpret_cast<float4 *>(dst);
-                            o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
-                            *reinterpret_cast<float4 *>(dst) = o;
-                        } else {
-                            *reinterpret_cast<float4 *>(dst) = val;
-                        }
-                    } else {
-                        const float *fv = reinterpret_cast<const float *>(&val);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nbase + pch * 4 + e < g.N) {
-                                if constexpr (EPI == 2) dst[e] += fv[e]; else dst[e] = fv[e];
-                            }
-                    }
-                }
-            }
-            wave_lds_sync();
         }
     }
 }
