@@ -27,7 +27,10 @@
 namespace {
 
 template <bool BF16, int EPI, int MI>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g) {
+__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g_in) {
+    GemmArgs g = g_in;
+    const int ksp = (EPI == 2 && g.ksplit > 1) ? (int)blockIdx.y : 0;  // split-K slice (tail launches of the f32 residual epilogue)
+    if (ksp > 0) g.bias = nullptr;                                      // the bias belongs to slice 0
     constexpr int BM = 32 * MI;
     constexpr int NS = 3;                       // LDS ring depth
     constexpr int GL = MI / 2 + 2;              // global_load_lds per wave per stage (A: BM/16/4, W: 128/16/4)
@@ -82,7 +85,13 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    const int nk = g.K / 32;
+    const int nk = (EPI == 2 && g.ksplit > 1) ? g.K / 32 / g.ksplit : g.K / 32;
+    if (ksp > 0) {
+#pragma unroll
+        for (int i = 0; i < MI / 2; ++i) pa[i] += (long long)ksp * nk * g.a_kstride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pw[i] += ksp * nk * 32;
+    }
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wid * (MI / 2)) * 1024u);
     const unsigned ldsW = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(NS * BM * 32 * 2) + (unsigned)(wid * 2) * 1024u);
@@ -236,7 +245,7 @@ int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
 template <bool BF16, int MI>
 int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M - g.m_lo, 32 * MI) * vs::cdiv(g.N, BN);
-    dim3 grid(nwg), block(256);
+    dim3 grid(nwg, epi == 2 && g.ksplit > 1 ? g.ksplit : 1), block(256);
     switch (epi) {
         case 0: hipLaunchKernelGGL((gemm_kernel<BF16, 0, MI>), grid, block, 0, stream, g); break;
         case 1: hipLaunchKernelGGL((gemm_kernel<BF16, 1, MI>), grid, block, 0, stream, g); break;
@@ -268,6 +277,15 @@ template <bool BF16>
 int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     GemmArgs t = g;
     t.m_lo = g.M - rem;
+    // a tail is a handful of tiles walking all of K serially: for the f32 residual epilogue split K over up to 8 workgroups
+    // per tile (>= 8 k-steps each) and let the partial sums meet through f32 atomics
+    static const int no_ksplit = [] { const char *e = getenv("VS_GEMM_NO_KSPLIT"); return e ? atoi(e) : 0; }();
+    if (epi == 2 && rem > 64 && !no_ksplit) {
+        const int tiles = vs::cdiv(rem, 128) * vs::cdiv(g.N, BN);
+        int ks = 1;
+        while (ks < 8 && (g.K / 32) % (ks * 2) == 0 && g.K / 32 / (ks * 2) >= 8 && tiles * ks * 2 <= 512) ks *= 2;
+        t.ksplit = ks;
+    }
     // (the RoPE epilogue pairs columns 16 apart: only the tile kernels hold both in one workgroup)
     return rem <= 64 && epi != 4 ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
 }
@@ -344,7 +362,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
-    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1;
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
@@ -402,6 +420,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
+    g.ksplit = 1;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;

@@ -26,6 +26,7 @@ struct GemmArgs {
     // window-GEMM extras (7x7 RGB stem, gemm_kernel only): every a_sup_in row groups skip a_sup_extra more A rows (image
     // padding rows), and k-step kt reads its 32-wide slice at element offset kt * a_kstride (next image row), not kt * 32
     int a_sup_in, a_sup_extra, a_kstride;
+    int ksplit;  // > 1 (gemm_kernel, epilogue 2 only): blockIdx.y-th of ksplit equal K ranges, summed into out with f32 atomics
     // epilogue 4 (STORE16 + RoPE on the q and k column blocks of a packed qkv projection, head_dim 64): per OUTPUT row
     // pos[2] and kind (0: 2-D pairs (i, i+16) per 32-half with pos[0]/pos[1], 1: 1-D interleaved pairs with pos[0], 2: none)
     const int32_t *rope_pos;
@@ -204,9 +205,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                             else { gt[0] = gp[j * 16]; gt[1] = gp[j * 16 + 1]; gt[2] = gp[j * 16 + 2]; gt[3] = gp[j * 16 + 3]; }
                             val.x *= 1.0f + gt[0]; val.y *= 1.0f + gt[1]; val.z *= 1.0f + gt[2]; val.w *= 1.0f + gt[3];
                         }
-                        float4 o = *reinterpret_cast<float4 *>(dst + j * 16);
-                        o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
-                        *reinterpret_cast<float4 *>(dst + j * 16) = o;
+                        if (g.ksplit > 1) {  // partial sums of a split-K tail launch meet in memory
+                            unsafeAtomicAdd(dst + j * 16 + 0, val.x); unsafeAtomicAdd(dst + j * 16 + 1, val.y);
+                            unsafeAtomicAdd(dst + j * 16 + 2, val.z); unsafeAtomicAdd(dst + j * 16 + 3, val.w);
+                        } else {
+                            float4 o = *reinterpret_cast<float4 *>(dst + j * 16);
+                            o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
+                            *reinterpret_cast<float4 *>(dst + j * 16) = o;
+                        }
                     } else {
                         *reinterpret_cast<float4 *>(dst + j * 16) = val;
                     }
@@ -217,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                         if (n < g.N) {
                             float x = v[j][r];
                             if (EPI == 2 && gp) x *= 1.0f + gp[j * 16 + r];
-                            if constexpr (EPI == 2) dst[j * 16 + r] += x; else dst[j * 16 + r] = x;
+                            if constexpr (EPI == 2) { if (g.ksplit > 1) unsafeAtomicAdd(dst + j * 16 + r, x); else dst[j * 16 + r] += x; } else dst[j * 16 + r] = x;
                         }
                     }
                 }
