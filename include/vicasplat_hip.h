@@ -207,6 +207,27 @@ int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg,
 int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const float *bias, void *out, int32_t Nimg, int32_t H, int32_t W,
                         int32_t Hp, int32_t Wp, int32_t Cout, int32_t dtype, vs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Encoder backward building blocks (training_step, model_wrapper.py:184-321: the reference differentiates the encoder
+ * with torch autograd).  Groundwork: parity-tested operators, not yet assembled into a training step.
+ *   vs_transpose16        out[c, r] = in[r, c] for r < R (zero for R <= r < Rpad); 16-bit elements.  With it the NT GEMM
+ *                         (vs_gemm_bias_act) computes dX = dY W (A = dY, W-operand = W^T) and dW = dY^T X (A = dY^T,
+ *                         W-operand = X^T, epilogue 3) of nn.Linear; Rpad pads the reduction dimension to a multiple of 64.
+ *   vs_colsum             out[n] = sum_m x[m, n] (bias gradient); dtype 0 f32, 1 f16, 2 bf16; out is overwritten.
+ *   vs_gelu_backward      dz = dy * d/dz gelu_erf(z) on n 16-bit elements (n % 8 == 0).
+ *   vs_layernorm_backward backward of vs_layernorm_mod: out = (xhat w + b)(1 + scale[g]) + shift[g], g = row / mod_rows.
+ *                         dout is read at the forward's OUTPUT row (grp_* mapping) in dtype do_dtype (0 f32, 1 f16, 2 bf16);
+ *                         dx f32 [M,C] is written (accumulate_dx = 0) or added to (1); dw, db [C] and dscale, dshift
+ *                         [G, mod_ld] are ADDED to (f32 atomics): zero them before the first call of a step.
+ * ------------------------------------------------------------------------------------------------ */
+int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
+int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream);
+int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream);
+int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,
+                          const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx, int32_t accumulate_dx,
+                          float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in,
+                          int32_t grp_out, int32_t grp_off, vs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -412,3 +412,73 @@ def test_abi_rejects_bad_arguments_loudly():
     with pytest.raises(RuntimeError, match="C % 64"):
         ops.gemm_qkv_rope(torch.zeros(16, 64, dtype=torch.float16, device=d), torch.zeros(192, 64, dtype=torch.float16, device=d), None, q,
                           48, torch.zeros(16, 2, dtype=torch.int32, device=d))
+
+
+# ---- encoder backward building blocks (training groundwork) vs torch autograd ----
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(514, 768, 768), (16448, 1024, 1024), (100, 192, 64), (257, 3072, 768)])
+def test_linear_backward_matches_autograd(dt, M, N, K):
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dt).to(d)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dt).to(d)
+    dy = (torch.randn(M, N, generator=g) * 0.5).to(dt).to(d)
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    br = torch.zeros(N, device=d, requires_grad=True)
+    (F.linear(xr, wr, br) * dy.float()).sum().backward()
+    dx, dw, db = ops.linear_backward(dy, x, w)
+    rt = 3e-3 if dt == torch.float16 else 1.6e-2
+    assert (dx.float() - xr.grad).abs().max() <= rt * xr.grad.abs().max()
+    assert (dw - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max() + 1e-4  # f32 accumulation of exact 16-bit products
+    assert (db - br.grad).abs().max() <= 1e-4 * br.grad.abs().max() + 1e-3
+    # transpose16 pads with zeros
+    t = ops.transpose16(x, 64)
+    assert t.shape == (K, (M + 63) // 64 * 64) and torch.equal(t[:, :M], x.t()) and float(t[:, M:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gelu_backward_matches_autograd(dt):
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(3)
+    z = (torch.randn(1000, 64, device=d) * 2).to(dt)
+    dy = torch.randn(1000, 64, device=d).to(dt)
+    zr = z.float().requires_grad_()
+    (F.gelu(zr) * dy.float()).sum().backward()
+    dz = ops.gelu_backward(dy, z)
+    assert (dz.float() - zr.grad).abs().max() <= (2e-3 if dt == torch.float16 else 1.2e-2) * zr.grad.abs().max()
+
+
+@pytest.mark.parametrize("do_dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("M,C,gi", [(1028, 1024, 257), (600, 768, 200), (37, 192, 37)])
+def test_layernorm_backward_matches_autograd(do_dt, M, C, gi):
+    """LayerNorm + AdaLN modulation backward (dx, dw, db, dscale, dshift), incl. the remapped output rows."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(d)
+    w = (torch.randn(C, generator=g) * 0.2 + 1).to(d)
+    b = (torch.randn(C, generator=g) * 0.1).to(d)
+    G = (M + gi - 1) // gi
+    scale = (torch.randn(G, C, generator=g) * 0.3).to(d)
+    shift = (torch.randn(G, C, generator=g) * 0.3).to(d)
+    rows = torch.arange(M, device=d)
+    dout_full = torch.randn(G * (gi + 1), C, generator=g).to(d).to(do_dt)           # forward wrote rows g*(gi+1) + 1 + m%gi
+    orow = (rows // gi) * (gi + 1) + 1 + rows % gi
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    sr, hr = scale.clone().requires_grad_(), shift.clone().requires_grad_()
+    y = F.layer_norm(xr, (C,), wr, br, 1e-6) * (1 + sr[rows // gi]) + hr[rows // gi]
+    (y * dout_full[orow].float()).sum().backward()
+    dx, dw, db, dsc, dsh = ops.layernorm_backward(dout_full, x, w, b, scale=scale, mod_rows=gi, grp_in=gi, grp_out=gi + 1, grp_off=1)
+    tol = 2e-4 if do_dt == torch.float32 else 2e-3
+    for got, ref, nm in ((dx, xr.grad, "dx"), (dw, wr.grad, "dw"), (db, br.grad, "db"), (dsc, sr.grad, "dscale"), (dsh, hr.grad, "dshift")):
+        assert (got - ref).abs().max() <= tol * ref.abs().max() + 1e-5, nm
+    # plain LayerNorm (no modulation), accumulate into an existing dx
+    xr2 = x.clone().requires_grad_()
+    dplain = dout_full[:M].float()
+    (F.layer_norm(xr2, (C,), w, b, 1e-6) * dplain).sum().backward()
+    base = torch.ones(M, C, device=d)
+    dx2, _, _, n1, n2 = ops.layernorm_backward(dout_full[:M], x, w, b, dx=base.clone(), accumulate_dx=True)
+    assert n1 is None and n2 is None
+    assert (dx2 - base - xr2.grad).abs().max() <= tol * xr2.grad.abs().max() + 1e-5

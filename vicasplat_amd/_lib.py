@@ -91,6 +91,15 @@ def lib() -> C.CDLL:
             L.vs_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp]
             L.vs_gaussian_adapter.restype = C.c_int
             L.vs_gaussian_adapter.argtypes = [vp, i64, i64, vp, i64, i64, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.vs_transpose16.restype = C.c_int
+            L.vs_transpose16.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
+            L.vs_colsum.restype = C.c_int
+            L.vs_colsum.argtypes = [vp, i64, vp, i32, i32, i32, vp]
+            L.vs_gelu_backward.restype = C.c_int
+            L.vs_gelu_backward.argtypes = [vp, vp, vp, i64, i32, vp]
+            L.vs_layernorm_backward.restype = C.c_int
+            L.vs_layernorm_backward.argtypes = [vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp, i32, i32, f32,
+                                                i32, i32, i32, vp]
             L.vs_gemm_qkv_rope.restype = C.c_int
             L.vs_gemm_qkv_rope.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32,
                                            C.c_float, C.c_float, vp]

@@ -1,0 +1,305 @@
+// Building blocks of the ENCODER backward pass (training_step, model_wrapper.py:184-321, where the
+// reference relies on torch autograd).  Not yet wired into a training step -- see DESIGN.md 7 -- but each one is a complete,
+// parity-tested operator:
+//
+//   vs_transpose16        [R,C] -> [C,Rpad] 16-bit, zero padded: feeds the existing NT GEMM kernels for
+//                         dX = dY W   (A = dY [M,N], "W" = W^T [K,N])      and
+//                         dW = dY^T X (A = dY^T [N,M], "W" = X^T [K,M], f32 store) of nn.Linear (croco/blocks.py:60-112)
+//   vs_colsum             db[n] = sum_m dY[m,n]                                           (16-bit or f32 input, f32 output)
+//   vs_gelu_backward      dz = dy * gelu'(z), exact-erf GELU (nn.GELU(), blocks.py:60)
+//   vs_layernorm_backward nn.LayerNorm(eps) followed by the AdaLN modulation of backbone_vica.py:268-273:
+//                         out = (xhat * w + b) * (1 + scale[g]) + shift[g];  dx, dw, db, dscale, dshift
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+template <bool BF16>
+__device__ __forceinline__ float ld16(unsigned short h) {
+    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
+    else return (float)*reinterpret_cast<_Float16 *>(&h);
+}
+template <bool BF16>
+__device__ __forceinline__ unsigned short st16(float v) {
+    if constexpr (BF16) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    } else {
+        _Float16 h = (_Float16)v;
+        return *reinterpret_cast<unsigned short *>(&h);
+    }
+}
+
+// 64 x 64 tile through LDS (65-half rows: conflict-free both ways); rows >= R of the output padding are written as zeros
+__global__ void __launch_bounds__(256)
+transpose16_kernel(const unsigned short *__restrict__ in, long long ld_in, unsigned short *__restrict__ out, long long ld_out,
+                   int R, int C, int Rpad) {
+    __shared__ unsigned short tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(long long)r * ld_in + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rpad) out[(long long)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// column sums: block = 64 columns x 4 row lanes; rows strided over gridDim.y blocks; one f32 atomic per (block, column)
+template <int DT>  // 0 f32, 1 f16, 2 bf16
+__global__ void __launch_bounds__(256)
+colsum_kernel(const void *__restrict__ x, long long ld, float *__restrict__ out, int M, int N) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N) {
+        for (int m = blockIdx.y * 4 + ty; m < M; m += gridDim.y * 4) {
+            if constexpr (DT == 0) s += reinterpret_cast<const float *>(x)[(long long)m * ld + c];
+            else s += ld16<DT == 2>(reinterpret_cast<const unsigned short *>(x)[(long long)m * ld + c]);
+        }
+    }
+    part[ty][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) unsafeAtomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+gelu_backward_kernel(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ z, unsigned short *__restrict__ dz,
+                     long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint4 a = *reinterpret_cast<const uint4 *>(dy + i), b = *reinterpret_cast<const uint4 *>(z + i);
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float g = ld16<BF16>((unsigned short)(h ? aw[k] >> 16 : aw[k] & 0xffffu));
+            const float x = ld16<BF16>((unsigned short)(h ? bw[k] >> 16 : bw[k] & 0xffffu));
+            // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+            o[h] = g * (cdf + x * pdf);
+        }
+        r[k] = (unsigned)st16<BF16>(o[0]) | ((unsigned)st16<BF16>(o[1]) << 16);
+    }
+    *reinterpret_cast<uint4 *>(dz + i) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per row (rows strided over the grid), lane owns columns lane*4 + 256*k.  Per-row: recompute mean / rstd, then
+//   g  = dout * (1 + scale) * w,   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+// Column-wise sums (dw, db) and per-group sums (dscale, dshift) are kept in registers across the wave's rows and flushed
+// with f32 atomics at the end (dscale/dshift at every group change).
+constexpr int kLnVec = 8;  // C <= 64 * 4 * 8 = 2048
+template <int DT>  // dout dtype: 0 f32, 1 f16, 2 bf16
+__global__ void __launch_bounds__(256)
+layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const float *__restrict__ x, long long ldx,
+                          const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ scale, int mod_rows,
+                          int mod_ld, float *__restrict__ dx, long long ld_dx, int accumulate_dx, float *__restrict__ dw,
+                          float *__restrict__ db, float *__restrict__ dscale, float *__restrict__ dshift, int M, int C, float eps,
+                          int grp_in, int grp_out, int grp_off) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float4 wv[kLnVec], bvv[kLnVec], aw[kLnVec], ab[kLnVec];
+#pragma unroll
+    for (int k = 0; k < kLnVec; ++k) {
+        const int c = (lane + 64 * k) * 4;
+        wv[k] = c < C ? *reinterpret_cast<const float4 *>(w + c) : make_float4(0, 0, 0, 0);
+        bvv[k] = c < C ? *reinterpret_cast<const float4 *>(b + c) : make_float4(0, 0, 0, 0);
+        aw[k] = ab[k] = make_float4(0, 0, 0, 0);
+    }
+    // contiguous row range per wave so that per-group (dscale, dshift) partial sums flush rarely
+    const int per = (M + nwaves - 1) / nwaves;
+    const int m_lo = wave * per, m_hi = min(M, m_lo + per);
+    int cur_g = -1;
+    float4 as[kLnVec], ah[kLnVec];
+    auto flush_group = [&]() {
+        if (cur_g < 0 || !dscale) return;
+#pragma unroll
+        for (int k = 0; k < kLnVec; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < C) {
+                float *ps = dscale + (long long)cur_g * mod_ld + c, *ph = dshift + (long long)cur_g * mod_ld + c;
+                unsafeAtomicAdd(ps + 0, as[k].x); unsafeAtomicAdd(ps + 1, as[k].y); unsafeAtomicAdd(ps + 2, as[k].z); unsafeAtomicAdd(ps + 3, as[k].w);
+                unsafeAtomicAdd(ph + 0, ah[k].x); unsafeAtomicAdd(ph + 1, ah[k].y); unsafeAtomicAdd(ph + 2, ah[k].z); unsafeAtomicAdd(ph + 3, ah[k].w);
+            }
+        }
+    };
+    for (int m = m_lo; m < m_hi; ++m) {
+        const int gidx = scale ? m / mod_rows : 0;
+        if (scale && gidx != cur_g) {
+            flush_group();
+            cur_g = gidx;
+#pragma unroll
+            for (int k = 0; k < kLnVec; ++k) as[k] = ah[k] = make_float4(0, 0, 0, 0);
+        }
+        const float *xr = x + (long long)m * ldx;
+        const long long orow = (long long)(m / grp_in) * grp_out + grp_off + (m % grp_in);  // row of dout (the forward's output row)
+        float4 xv[kLnVec], gv[kLnVec];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLnVec; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            xv[k] = c < C ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0, 0, 0, 0);
+            s += xv[k].x + xv[k].y + xv[k].z + xv[k].w;
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLnVec; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < C) {
+                xv[k].x -= mean; xv[k].y -= mean; xv[k].z -= mean; xv[k].w -= mean;
+                q += xv[k].x * xv[k].x + xv[k].y * xv[k].y + xv[k].z * xv[k].z + xv[k].w * xv[k].w;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLnVec; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            gv[k] = make_float4(0, 0, 0, 0);
+            if (c < C) {
+                float d[4];
+                if constexpr (DT == 0) {
+                    const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dout) + orow * ld_do + c);
+                    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+                } else {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(dout) + orow * ld_do + c);
+                    d[0] = ld16<DT == 2>((unsigned short)(t.x & 0xffffu)); d[1] = ld16<DT == 2>((unsigned short)(t.x >> 16));
+                    d[2] = ld16<DT == 2>((unsigned short)(t.y & 0xffffu)); d[3] = ld16<DT == 2>((unsigned short)(t.y >> 16));
+                }
+                const float xh[4] = {xv[k].x * rstd, xv[k].y * rstd, xv[k].z * rstd, xv[k].w * rstd};
+                const float ww[4] = {wv[k].x, wv[k].y, wv[k].z, wv[k].w}, bb[4] = {bvv[k].x, bvv[k].y, bvv[k].z, bvv[k].w};
+                float sc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (scale) {
+                    const float4 t = *reinterpret_cast<const float4 *>(scale + (long long)gidx * mod_ld + c);
+                    sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
+                }
+                float gg[4];
+                float *pas = &as[k].x, *pah = &ah[k].x, *paw = &aw[k].x, *pab = &ab[k].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = xh[e] * ww[e] + bb[e];     // LN output before modulation
+                    const float dy = d[e] * (1.0f + sc[e]);     // gradient w.r.t. y
+                    if (scale) { pas[e] += d[e] * y; pah[e] += d[e]; }
+                    paw[e] += dy * xh[e];
+                    pab[e] += dy;
+                    gg[e] = dy * ww[e];
+                    sg += gg[e];
+                    sgx += gg[e] * xh[e];
+                }
+                gv[k] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+            }
+        }
+        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+        float *dxr = dx + (long long)m * ld_dx;
+#pragma unroll
+        for (int k = 0; k < kLnVec; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < C) {
+                float4 r;
+                r.x = rstd * (gv[k].x - mg - xv[k].x * rstd * mgx);
+                r.y = rstd * (gv[k].y - mg - xv[k].y * rstd * mgx);
+                r.z = rstd * (gv[k].z - mg - xv[k].z * rstd * mgx);
+                r.w = rstd * (gv[k].w - mg - xv[k].w * rstd * mgx);
+                if (accumulate_dx) {
+                    const float4 o = *reinterpret_cast<const float4 *>(dxr + c);
+                    r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+                }
+                *reinterpret_cast<float4 *>(dxr + c) = r;
+            }
+        }
+    }
+    flush_group();
+#pragma unroll
+    for (int k = 0; k < kLnVec; ++k) {
+        const int c = (lane + 64 * k) * 4;
+        if (c < C && m_lo < m_hi) {
+            unsafeAtomicAdd(dw + c + 0, aw[k].x); unsafeAtomicAdd(dw + c + 1, aw[k].y); unsafeAtomicAdd(dw + c + 2, aw[k].z); unsafeAtomicAdd(dw + c + 3, aw[k].w);
+            unsafeAtomicAdd(db + c + 0, ab[k].x); unsafeAtomicAdd(db + c + 1, ab[k].y); unsafeAtomicAdd(db + c + 2, ab[k].z); unsafeAtomicAdd(db + c + 3, ab[k].w);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad,
+                              vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && out, "vs_transpose16: null pointer");
+    VS_CHECK(R >= 0 && C >= 0 && Rpad >= R && ld_in >= C && ld_out >= Rpad, "vs_transpose16: bad sizes R=%d C=%d Rpad=%d", R, C, Rpad);
+    if (Rpad == 0 || C == 0) return 0;
+    dim3 grid(vs::cdiv(C, 64), vs::cdiv(Rpad, 64)), block(256);
+    hipLaunchKernelGGL(transpose16_kernel, grid, block, 0, stream, (const unsigned short *)in, (long long)ld_in, (unsigned short *)out,
+                       (long long)ld_out, R, C, Rpad);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && out, "vs_colsum: null pointer");
+    VS_CHECK(dtype >= 0 && dtype <= 2, "vs_colsum: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    VS_CHECK(M >= 0 && N > 0 && ld >= N, "vs_colsum: bad sizes");
+    VS_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream));
+    if (M == 0) return 0;
+    dim3 grid(vs::cdiv(N, 64), std::min(256, vs::cdiv(M, 64))), block(256);
+    if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, grid, block, 0, stream, x, (long long)ld, out, M, N);
+    else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<1>, grid, block, 0, stream, x, (long long)ld, out, M, N);
+    else hipLaunchKernelGGL(colsum_kernel<2>, grid, block, 0, stream, x, (long long)ld, out, M, N);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(dy && z && dz, "vs_gelu_backward: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gelu_backward: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(n >= 0 && n % 8 == 0, "vs_gelu_backward: n=%lld must be a multiple of 8", (long long)n);
+    VS_CHECK((((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz) & 15) == 0, "vs_gelu_backward: 16-byte alignment required");
+    if (n == 0) return 0;
+    dim3 grid((unsigned)vs::cdiv64(n / 8, 256)), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(gelu_backward_kernel<true>, grid, block, 0, stream, (const unsigned short *)dy, (const unsigned short *)z, (unsigned short *)dz, (long long)n);
+    else hipLaunchKernelGGL(gelu_backward_kernel<false>, grid, block, 0, stream, (const unsigned short *)dy, (const unsigned short *)z, (unsigned short *)dz, (long long)n);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w,
+                                     const float *b, const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx,
+                                     int32_t accumulate_dx, float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C,
+                                     float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(dout && x && w && b && dx && dw && db, "vs_layernorm_backward: null pointer");
+    VS_CHECK(C > 0 && C % 4 == 0 && C <= 64 * 4 * kLnVec, "vs_layernorm_backward: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * kLnVec);
+    VS_CHECK(do_dtype >= 0 && do_dtype <= 2, "vs_layernorm_backward: bad dout dtype %d", do_dtype);
+    VS_CHECK(ldx % 4 == 0 && ld_dx % 4 == 0 && ld_do % 4 == 0, "vs_layernorm_backward: row strides must be multiples of 4 elements");
+    VS_CHECK(!scale || (dscale && dshift), "vs_layernorm_backward: scale given without dscale/dshift");
+    if (M <= 0) return 0;
+    if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
+    if (mod_rows <= 0) mod_rows = M;
+    if (mod_ld <= 0) mod_ld = C;
+    dim3 grid(std::min(1024, vs::cdiv(M, 4))), block(256);
+#define VS_LNB(DT_) hipLaunchKernelGGL(layernorm_backward_kernel<DT_>, grid, block, 0, stream, dout, (long long)ld_do, x, (long long)ldx, w, b, \
+                                      scale, mod_rows, mod_ld, dx, (long long)ld_dx, accumulate_dx, dw, db, dscale, dshift, M, C, eps,    \
+                                      grp_in, grp_out, grp_off)
+    if (do_dtype == 0) VS_LNB(0); else if (do_dtype == 1) VS_LNB(1); else VS_LNB(2);
+#undef VS_LNB
+    VS_HIP(hipGetLastError());
+    return 0;
+}

@@ -213,3 +213,105 @@ def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_ad
         rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, int(relu_add), _DT[x.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_upsample2x_nhwc")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Encoder backward building blocks (groundwork for the training step): parity-tested against torch autograd,
+# not yet assembled into a torch.autograd.Function chain.
+# ---------------------------------------------------------------------------------------------------------------------
+_DT3 = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def transpose16(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
+    """x [R,C] 16-bit (row stride any) -> [C, Rpad] with Rpad = R rounded up to `pad_to`, padding columns zero."""
+    dev = L.require_device(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float16, torch.bfloat16)
+    R, Cc = x.shape
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, Rpad), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_transpose16(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, L.stream_ptr(dev))
+    L.check(rc, "vs_transpose16")
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """f32 column sums of x [M,N] (f32 / f16 / bf16)."""
+    dev = L.require_device(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_colsum(L.ptr(x), x.stride(0), L.ptr(out), x.shape[0], x.shape[1], _DT3[x.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_colsum")
+    return out
+
+
+def gelu_backward(dy: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """dz = dy * gelu_erf'(z); dy, z contiguous 16-bit of the same shape (numel % 8 == 0)."""
+    dev = L.require_device(dy, z)
+    assert dy.shape == z.shape and dy.dtype == z.dtype and dy.is_contiguous() and z.is_contiguous()
+    dz = torch.empty_like(dy)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gelu_backward(L.ptr(dy), L.ptr(z), L.ptr(dz), dy.numel(), _DT[dy.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_gelu_backward")
+    return dz
+
+
+def layernorm_backward(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, scale: Optional[torch.Tensor] = None,
+                       mod_rows: int = 0, eps: float = 1e-6, dx: Optional[torch.Tensor] = None, accumulate_dx: bool = False,
+                       grp_in: int = 0, grp_out: int = 0, grp_off: int = 0):
+    """Backward of layernorm_mod.  x f32 [M,C]; dout [rows,C] in the forward's output layout (f32 or 16-bit).
+    Returns (dx f32 [M,C], dw [C], db [C], dscale [G,C] | None, dshift [G,C] | None)."""
+    dev = L.require_device(dout, x, w, b, scale, dx)
+    M, Cc = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and dout.stride(-1) == 1
+    if dx is None:
+        assert not accumulate_dx
+        dx = torch.empty((M, Cc), dtype=torch.float32, device=dev)
+    dw = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    db = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    dscale = dshift = None
+    mod_ld = 0
+    if scale is not None:
+        assert scale.dtype == torch.float32 and scale.stride(-1) == 1
+        dscale = torch.zeros((scale.shape[0], Cc), dtype=torch.float32, device=dev)
+        dshift = torch.zeros_like(dscale)
+        mod_ld = scale.stride(0)
+        assert mod_ld == Cc or scale.shape[0] == 1 or True
+    with torch.cuda.device(dev):
+        # dscale / dshift are written with the row stride of `scale`; give them the same stride by allocating [G, mod_ld]
+        if scale is not None and mod_ld != Cc:
+            dscale = torch.zeros((scale.shape[0], mod_ld), dtype=torch.float32, device=dev)
+            dshift = torch.zeros_like(dscale)
+        rc = L.lib().vs_layernorm_backward(L.ptr(dout), dout.stride(-2), _DT3[dout.dtype], L.ptr(x), x.stride(0), L.ptr(w), L.ptr(b),
+                                           L.ptr(scale), mod_rows, mod_ld, L.ptr(dx), dx.stride(0), int(accumulate_dx), L.ptr(dw),
+                                           L.ptr(db), L.ptr(dscale), L.ptr(dshift), M, Cc, eps, grp_in, grp_out, grp_off,
+                                           L.stream_ptr(dev))
+    L.check(rc, "vs_layernorm_backward")
+    if dscale is not None and dscale.shape[1] != Cc:
+        dscale, dshift = dscale[:, :Cc], dshift[:, :Cc]
+    return dx, dw, db, dscale, dshift
+
+
+def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_dx: bool = True, need_dw: bool = True,
+                    need_db: bool = True, wT: Optional[torch.Tensor] = None):
+    """Backward of y = x @ w^T + b on the NT GEMM kernels: dy [M,N], x [M,K], w [N,K] 16-bit.
+    dx = dy @ w (16-bit), dw = dy^T @ x (f32, f32 accumulation over M), db = column sums of dy (f32).
+    `wT` = transpose16(w, 64) can be cached by the caller (weights change once per optimiser step)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dev = dy.device
+    dx = dw = db = None
+    if need_dx:
+        if wT is None:
+            wT = transpose16(w, 64)                       # [K, Npad]: reduction over N
+        dyp = dy if N % 64 == 0 else torch.nn.functional.pad(dy, (0, wT.shape[1] - N))
+        dx = torch.empty((M, K), dtype=dy.dtype, device=dev)
+        gemm(dyp, wT, None, dx, EPI_STORE16)
+    if need_dw:
+        dyT, xT = transpose16(dy, 64), transpose16(x, 64)   # [N, Mpad], [K, Mpad]: reduction over M, zero padded
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        gemm(dyT, xT, None, dw, EPI_STORE32)
+    if need_db:
+        db = colsum(dy)
+    return dx, dw, db
