@@ -207,6 +207,22 @@ int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg,
 int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const float *bias, void *out, int32_t Nimg, int32_t H, int32_t W,
                         int32_t Hp, int32_t Wp, int32_t Cout, int32_t dtype, vs_stream_t stream);
 
+/* vs_attention that also saves, per (row, head), the log2-domain logsumexp of the scaled scores (lse [rows, H] f32) --
+ * the only forward state the flash-style backward needs besides out. */
+int vs_attention_lse(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
+                     int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                     const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype, float *lse, vs_stream_t stream);
+
+/* Backward of vs_attention (same addressing, mask and key segments).  o = forward output, dout = its gradient (row stride
+ * lddo), lse from vs_attention_lse; delta [rows, H] f32 is scratch.  dq: 16-bit [rows, lddq] (written); dk, dv: f32 with row
+ * strides lddk / lddv, indexed by KEY row, ADDED to with f32 atomics (zero them first: with key segments one K/V row
+ * receives gradient from several batch items).  max_keys = largest len0 + len1 when kv_seg is used. */
+int vs_attention_backward(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse, float *delta,
+                          void *dq, float *dk, float *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk, int64_t q_batch_rows,
+                          int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int32_t lddo, int32_t lddq,
+                          int32_t lddk, int32_t lddv, const int32_t *kv_seg, const int32_t *q_kvlen, int32_t max_keys, float scale,
+                          int32_t dtype, vs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Encoder backward building blocks (training_step, model_wrapper.py:184-321: the reference differentiates the encoder
  * with torch autograd).  Groundwork: parity-tested operators, not yet assembled into a training step.

@@ -482,3 +482,74 @@ def test_layernorm_backward_matches_autograd(do_dt, M, C, gi):
     dx2, _, _, n1, n2 = ops.layernorm_backward(dout_full[:M], x, w, b, dx=base.clone(), accumulate_dx=True)
     assert n1 is None and n2 is None
     assert (dx2 - base - xr2.grad).abs().max() <= tol * xr2.grad.abs().max() + 1e-5
+
+
+def _attn_ref(q, k, v, keymask, scale):
+    """q [Lq,H,64], k/v [Lk,H,64] f32, keymask [Lq,Lk] bool -> out [Lq,H,64] (plain softmax attention)."""
+    s = torch.einsum("qhd,khd->hqk", q, k) * scale
+    s = s.masked_fill(~keymask[None], float("-inf"))
+    return torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["encoder", "video_prefix", "neighbour_segments"])
+def test_attention_backward_matches_autograd(dt, case):
+    """dq / dk / dv of the three attention shapes (plain, key-prefix mask, two gathered key segments) vs torch autograd."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(len(case))
+    H, C = 3, 192
+    if case == "encoder":
+        nb, Lq = 3, 257
+        rows = nb * Lq
+    elif case == "video_prefix":
+        nb, Lq = 2, 3 * 86          # 3 frames of 86 tokens per scene; token 0 of a frame sees the frames up to its own
+        rows = nb * Lq
+    else:
+        nb, Lq = 4, 100            # 4 frames; frame t attends to frames t-1 and t+1 (clamped like backbone_vica.py:172-186)
+        rows = nb * Lq
+    qkv = (torch.randn(rows, 3 * C, generator=g) * 0.7).to(dt).to(d)
+    dout = torch.randn(rows, C, generator=g).to(dt).to(d)
+    q2, k2, v2 = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    kw, kvlen, seg = dict(nbatch=nb, H=H, Lq=Lq, q_batch_rows=Lq), None, None
+    if case == "neighbour_segments":
+        nbr = [[1, 1], [0, 2], [1, 3], [2, 2]]
+        seg = torch.tensor([[a * Lq, Lq, b * Lq, Lq] for a, b in nbr], dtype=torch.int32, device=d)
+        kw.update(kv_seg=seg)
+    else:
+        kw.update(Lk=Lq, k_batch_rows=Lq)
+        if case == "video_prefix":
+            kvlen = torch.full((nb, Lq), Lq, dtype=torch.int32)
+            for t in range(3):
+                kvlen[:, t * 86] = (t + 1) * 86
+            kvlen = kvlen.reshape(-1).contiguous().to(d)
+            kw.update(q_kvlen=kvlen)
+    out = torch.empty(rows, C, dtype=dt, device=d)
+    lse = torch.empty(rows, H, dtype=torch.float32, device=d)
+    ops.attention(q2, k2, v2, out, lse=lse, **kw)
+    dq, dk, dv = ops.attention_backward(q2, k2, v2, out, dout, lse, max_keys=2 * Lq if seg is not None else 0, **kw)
+    # reference
+    qf = qkv.float().clone().requires_grad_()
+    outs = []
+    for b in range(nb):
+        qb = qf[b * Lq:(b + 1) * Lq, :C].reshape(Lq, H, 64)
+        if seg is None:
+            kb = qf[b * Lq:(b + 1) * Lq, C:2 * C].reshape(Lq, H, 64); vb = qf[b * Lq:(b + 1) * Lq, 2 * C:].reshape(Lq, H, 64)
+            mask = torch.ones(Lq, Lq, dtype=torch.bool, device=d)
+            if kvlen is not None:
+                mask = torch.arange(Lq, device=d)[None, :] < kvlen[b * Lq:(b + 1) * Lq, None]
+        else:
+            a0, b0 = nbr[b]
+            idx = torch.cat([torch.arange(a0 * Lq, (a0 + 1) * Lq), torch.arange(b0 * Lq, (b0 + 1) * Lq)]).to(d)
+            kb = qf[idx, C:2 * C].reshape(2 * Lq, H, 64); vb = qf[idx, 2 * C:].reshape(2 * Lq, H, 64)
+            mask = torch.ones(Lq, 2 * Lq, dtype=torch.bool, device=d)
+        outs.append(_attn_ref(qb, kb, vb, mask, 0.125).reshape(Lq, C))
+    ref_out = torch.cat(outs)
+    (ref_out * dout.float()).sum().backward()
+    gq, gk, gv = qf.grad[:, :C], qf.grad[:, C:2 * C], qf.grad[:, 2 * C:]
+    rt = 6e-3 if dt == torch.float16 else 3e-2
+    assert (out.float() - ref_out).abs().max() <= rt * ref_out.abs().max()
+    # lse: log2-domain logsumexp of the scaled scores
+    assert torch.isfinite(lse).all()
+    for got, ref, nm in ((dq.float(), gq, "dq"), (dk, gk, "dk"), (dv, gv, "dv")):
+        assert (got - ref).abs().max() <= rt * ref.abs().max(), (nm, float((got - ref).abs().max()), float(ref.abs().max()))

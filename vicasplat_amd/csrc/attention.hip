@@ -39,6 +39,7 @@ struct AttnArgs {
     long long q_batch_rows, k_batch_rows;
     int ldq, ldk, ldv, ldo;
     float scale_log2e;
+    float *lse;  // optional [rows, H] f32: log2-domain logsumexp of the scaled scores (saved for the backward pass)
 };
 
 template <bool BF16>
@@ -268,6 +269,10 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[u][db][r] * inv);
         }
+        if (a.lse && g == 0) {
+            const int qo = q0 + (wid * QG + u) * 16 + c16;
+            if (qo < a.Lq) a.lse[(b * a.q_batch_rows + qo) * a.H + h] = l_run[u] > 0.f ? m_run[u] + log2f(l_run[u]) : -INFINITY;
+        }
     }
 }
 
@@ -431,15 +436,29 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
 #pragma unroll
             for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[db][r] * inv);
         }
+        if (a.lse && g == 0 && qvalid) a.lse[(b * a.q_batch_rows + qi) * a.H + h] = l_run > 0.f ? m_run + log2f(l_run) : -INFINITY;
     }
 }
 
 }  // namespace
 
+extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq,
+                                int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv,
+                                int32_t ldo, const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype, float *lse,
+                                vs_stream_t stream_);
+
 extern "C" int vs_attention(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq,
                             int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv,
                             int32_t ldo, const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype,
                             vs_stream_t stream_) {
+    return vs_attention_lse(q, k, v, out, nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, ldq, ldk, ldv, ldo, kv_seg, q_kvlen, scale, dtype,
+                            nullptr, stream_);
+}
+
+extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq,
+                                int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv,
+                                int32_t ldo, const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype, float *lse,
+                                vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(q && k && v && out, "vs_attention: null pointer");
     VS_CHECK(nbatch >= 0 && H > 0 && Lq >= 0, "vs_attention: bad sizes");
@@ -455,6 +474,7 @@ extern "C" int vs_attention(const void *q, const void *k, const void *v, void *o
     a.nbatch = nbatch; a.H = H; a.Lq = Lq; a.Lk = Lk; a.q_batch_rows = q_batch_rows; a.k_batch_rows = k_batch_rows;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.scale_log2e = scale * 1.4426950408889634f;
+    a.lse = lse;
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; else 64
     static const int force_qg = [] { const char *e = getenv("VS_ATTN_QG"); return e ? atoi(e) : 0; }();
     static const int force_wpe = [] { const char *e = getenv("VS_ATTN_WPE"); return e ? atoi(e) : 0; }();

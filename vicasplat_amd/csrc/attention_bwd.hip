@@ -1,0 +1,326 @@
+// Attention backward (head dim 64) for the three attention shapes of attention.hip: same q | k | v addressing, key-prefix
+// mask and two-segment key gather.  Groundwork for the encoder training step, parity-tested against torch
+// autograd.  Flash-style: nothing of size Lq x Lk is stored; the forward saves the log2-domain logsumexp L (vs_attention_lse).
+//
+//   delta_i = sum_d dO_i O_i                                   attn_delta_kernel      (one wave per (row, head))
+//   P = exp2(S * scale*log2e - L),  dP = dO V^T,  dS = P o (dP - delta) * scale
+//   dQ_i = sum_j dS_ij K_j                                      attn_bwd_dq_kernel     (workgroup = 64 queries, loops key tiles;
+//                                                                                        lane = query, as in the forward)
+//   dV_j = sum_i P_ij dO_i,   dK_j = sum_i dS_ij Q_i            attn_bwd_dkv_kernel    (workgroup = 64 keys, loops query tiles;
+//                                                                                        lane = key); f32 atomics into dK / dV
+//                                                               because with key segments a K/V row serves several batch items
+// S and dP are recomputed in both kernels (7 instead of 5 MFMA products per (i, j) tile, no atomics on dQ).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64, TB = 64;
+constexpr int ROW = HD + 8;   // halfs per row-major tile row (144 B)
+constexpr int TROW = TB + 8;  // halfs per transposed tile row
+
+struct AttnBwdArgs {
+    const unsigned short *q, *k, *v, *o, *dout;
+    const float *lse;
+    float *delta;
+    unsigned short *dq;
+    float *dk, *dv;
+    const int32_t *kv_seg, *q_kvlen;
+    int nbatch, H, Lq, Lk;
+    long long q_batch_rows, k_batch_rows;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    float scale, scale_log2e;
+};
+
+template <bool BF16>
+__device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
+}
+template <bool BF16>
+__device__ __forceinline__ float ld16(unsigned short h) {
+    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
+    else return (float)*reinterpret_cast<_Float16 *>(&h);
+}
+template <bool BF16>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    if constexpr (BF16) {
+        unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        ua += 0x7FFFu + ((ua >> 16) & 1u);
+        ub += 0x7FFFu + ((ub >> 16) & 1u);
+        return (ua >> 16) | (ub & 0xFFFF0000u);
+    } else {
+        _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        return (unsigned)(*reinterpret_cast<unsigned short *>(&ha)) | ((unsigned)(*reinterpret_cast<unsigned short *>(&hb)) << 16);
+    }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+attn_delta_kernel(const AttnBwdArgs a, long long rows) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (row, head)
+    if (item >= rows * a.H) return;
+    const long long row = item / a.H;
+    const int h = (int)(item % a.H);
+    float v = ld16<BF16>(a.o[row * a.ldo + h * HD + lane]) * ld16<BF16>(a.dout[row * a.lddo + h * HD + lane]);
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) v += __shfl_xor(v, o_, 64);
+    if (lane == 0) a.delta[item] = v;
+}
+
+struct KeyList {
+    int base0, len0, base1, len1, Lk;
+    __device__ __forceinline__ long long row(int j) const {
+        j = min(j, Lk - 1);
+        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
+    }
+};
+__device__ __forceinline__ KeyList key_list(const AttnBwdArgs &a, int b) {
+    KeyList kl;
+    if (a.kv_seg) {
+        kl.base0 = a.kv_seg[4 * b + 0]; kl.len0 = a.kv_seg[4 * b + 1]; kl.base1 = a.kv_seg[4 * b + 2]; kl.len1 = a.kv_seg[4 * b + 3];
+    } else {
+        kl.base0 = (int)(b * a.k_batch_rows); kl.len0 = a.Lk; kl.base1 = 0; kl.len1 = 0;
+    }
+    kl.Lk = kl.len0 + kl.len1;
+    return kl;
+}
+
+// stage 64 rows x 64 halfs: row-major image (ROW stride) and, optionally, the transposed image (TROW stride); rows >= nvalid are
+// zero.  256 threads: thread -> (row pair rp = tid & 31, 8-half chunk c = tid >> 5).
+template <bool WANT_ROWMAJOR, bool WANT_T, class RowFn>
+__device__ __forceinline__ void stage_tile(const unsigned short *src, int ld, int col0, RowFn row_of, int nvalid, unsigned short *sR,
+                                           unsigned short *sT, int tid) {
+    const int rp = tid & 31, c = tid >> 5;
+    uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+    if (2 * rp < nvalid) va = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp) * ld + col0 + c * 8);
+    if (2 * rp + 1 < nvalid) vb = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp + 1) * ld + col0 + c * 8);
+    if constexpr (WANT_ROWMAJOR) {
+        *reinterpret_cast<uint4 *>(&sR[(2 * rp) * ROW + c * 8]) = va;
+        *reinterpret_cast<uint4 *>(&sR[(2 * rp + 1) * ROW + c * 8]) = vb;
+    }
+    if constexpr (WANT_T) {
+        const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        unsigned *vt = reinterpret_cast<unsigned *>(sT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vt[((c * 8 + 2 * i) * TROW) / 2 + rp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
+            vt[((c * 8 + 2 * i + 1) * TROW) / 2 + rp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
+        }
+    }
+}
+
+// ---- dQ: workgroup = 64 queries (4 waves x 16), lane = (query c16, key group g); loops over 64-key tiles ----
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[TB * ROW], sV[TB * ROW], sKT[HD * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const KeyList kl = key_list(a, b);
+    const int qi = q0 + wid * 16 + c16;
+    const bool qvalid = qi < a.Lq;
+    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+    int my_len = qvalid ? kl.Lk : 0;
+    if (a.q_kvlen && qvalid) my_len = min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+    // B-operand fragments (rows = queries): Q and dO
+    const unsigned short *qp = a.q + qrow * a.ldq + h * HD + g * 8, *dop = a.dout + qrow * a.lddo + h * HD + g * 8;
+    uint4 qf[2], dof[2];
+    qf[0] = *reinterpret_cast<const uint4 *>(qp); qf[1] = *reinterpret_cast<const uint4 *>(qp + 32);
+    dof[0] = *reinterpret_cast<const uint4 *>(dop); dof[1] = *reinterpret_cast<const uint4 *>(dop + 32);
+    if (!qvalid) dof[0] = dof[1] = make_uint4(0, 0, 0, 0);
+    const float L = qvalid ? a.lse[qrow * a.H + h] : INFINITY;
+    const float D = qvalid ? a.delta[qrow * a.H + h] : 0.f;
+    f4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    auto krow = [&](int j) { return kl.row(j); };
+    for (int kt = 0; kt < kl.Lk; kt += TB) {
+        __syncthreads();
+        auto rk = [&](int r) { return krow(kt + r); };
+        stage_tile<true, true>(a.k, a.ldk, h * HD, rk, kl.Lk - kt, sK, sKT, tid);
+        stage_tile<true, false>(a.v, a.ldv, h * HD, rk, kl.Lk - kt, sV, nullptr, tid);
+        __syncthreads();
+        uint4 dsf[2];
+        f4 ds[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[(nb * 16 + c16) * ROW + ks * 32 + g * 8]);
+                const uint4 vf = *reinterpret_cast<const uint4 *>(&sV[(nb * 16 + c16) * ROW + ks * 32 + g * 8]);
+                s = mfma<BF16>(kf, qf[ks], s);      // S^T[key][query]
+                dp = mfma<BF16>(vf, dof[ks], dp);   // dP^T[key][query]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + nb * 16 + g * 4 + r;
+                const float p = key < my_len ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) : 0.f;
+                ds[nb][r] = p * (dp[r] - D) * a.scale;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            dsf[ks].x = pack2<BF16>(ds[2 * ks][0], ds[2 * ks][1]);
+            dsf[ks].y = pack2<BF16>(ds[2 * ks][2], ds[2 * ks][3]);
+            dsf[ks].z = pack2<BF16>(ds[2 * ks + 1][0], ds[2 * ks + 1][1]);
+            dsf[ks].w = pack2<BF16>(ds[2 * ks + 1][2], ds[2 * ks + 1][3]);
+        }
+        // dQ += dS K : A = dS (rows = query, k = keys in the permuted order of dsf), B = K^T rows d
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short *kr = &sKT[(db * 16 + c16) * TROW + g * 4];
+                const uint2 lo = *reinterpret_cast<const uint2 *>(kr + (2 * ks) * 16);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(kr + (2 * ks + 1) * 16);
+                dq[db] = mfma<BF16>(dsf[ks], make_uint4(lo.x, lo.y, hi.x, hi.y), dq[db]);
+            }
+    }
+    // dQ rows q = g*4 + r, cols d = db*16 + c16
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qo = q0 + wid * 16 + g * 4 + r;
+        if (qo >= a.Lq) continue;
+        unsigned short *op = a.dq + (b * a.q_batch_rows + qo) * a.lddq + h * HD + c16;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) op[db * 16] = (unsigned short)(pack2<BF16>(dq[db][r], 0.f) & 0xFFFFu);
+    }
+}
+
+// ---- dK, dV: workgroup = 64 keys of the batch item's key list (4 waves x 16), lane = (key c16, query group g); loops over
+// 64-query tiles ----
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * ROW], sDO[TB * ROW], sQT[HD * TROW], sDOT[HD * TROW];
+    __shared__ float sL[TB], sD[TB];
+    __shared__ int sLen[TB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
+    const KeyList kl = key_list(a, b);
+    if (kt0 >= kl.Lk) return;
+    const int kj = kt0 + wid * 16 + c16;        // position of this lane's key in the key list
+    const bool kvalid = kj < kl.Lk;
+    const long long krow = kl.row(kj);
+    // B-operand fragments (rows = keys): K and V
+    const unsigned short *kp = a.k + krow * a.ldk + h * HD + g * 8, *vp = a.v + krow * a.ldv + h * HD + g * 8;
+    uint4 kf[2], vf[2];
+    kf[0] = *reinterpret_cast<const uint4 *>(kp); kf[1] = *reinterpret_cast<const uint4 *>(kp + 32);
+    vf[0] = *reinterpret_cast<const uint4 *>(vp); vf[1] = *reinterpret_cast<const uint4 *>(vp + 32);
+    f4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < a.Lq; qt += TB) {
+        __syncthreads();
+        auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
+        stage_tile<true, true>(a.q, a.ldq, h * HD, rq, a.Lq - qt, sQ, sQT, tid);
+        stage_tile<true, true>(a.dout, a.lddo, h * HD, rq, a.Lq - qt, sDO, sDOT, tid);
+        if (tid < TB) {
+            const int qi = qt + tid;
+            const bool ok = qi < a.Lq;
+            const long long row = b * a.q_batch_rows + (ok ? qi : a.Lq - 1);
+            sL[tid] = ok ? a.lse[row * a.H + h] : INFINITY;
+            sD[tid] = ok ? a.delta[row * a.H + h] : 0.f;
+            sLen[tid] = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
+        }
+        __syncthreads();
+        f4 p[4], ds[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 qa = *reinterpret_cast<const uint4 *>(&sQ[(qb * 16 + c16) * ROW + ks * 32 + g * 8]);
+                const uint4 da = *reinterpret_cast<const uint4 *>(&sDO[(qb * 16 + c16) * ROW + ks * 32 + g * 8]);
+                s = mfma<BF16>(qa, kf[ks], s);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
+                dp = mfma<BF16>(da, vf[ks], dp);   // dP[query][key]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = qb * 16 + g * 4 + r;
+                const float pv = (kvalid && kj < sLen[ql]) ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -sL[ql])) : 0.f;
+                p[qb][r] = pv;
+                ds[qb][r] = pv * (dp[r] - sD[ql]) * a.scale;
+            }
+        }
+        uint4 pf[2], dsf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            pf[ks].x = pack2<BF16>(p[2 * ks][0], p[2 * ks][1]);       pf[ks].y = pack2<BF16>(p[2 * ks][2], p[2 * ks][3]);
+            pf[ks].z = pack2<BF16>(p[2 * ks + 1][0], p[2 * ks + 1][1]); pf[ks].w = pack2<BF16>(p[2 * ks + 1][2], p[2 * ks + 1][3]);
+            dsf[ks].x = pack2<BF16>(ds[2 * ks][0], ds[2 * ks][1]);       dsf[ks].y = pack2<BF16>(ds[2 * ks][2], ds[2 * ks][3]);
+            dsf[ks].z = pack2<BF16>(ds[2 * ks + 1][0], ds[2 * ks + 1][1]); dsf[ks].w = pack2<BF16>(ds[2 * ks + 1][2], ds[2 * ks + 1][3]);
+        }
+        // dV += P^T dO, dK += dS^T Q : A = P^T / dS^T (rows = key, k = queries in the packed order), B = dO^T / Q^T rows d
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short *dr = &sDOT[(db * 16 + c16) * TROW + g * 4], *qr = &sQT[(db * 16 + c16) * TROW + g * 4];
+                const uint2 dlo = *reinterpret_cast<const uint2 *>(dr + (2 * ks) * 16), dhi = *reinterpret_cast<const uint2 *>(dr + (2 * ks + 1) * 16);
+                const uint2 qlo = *reinterpret_cast<const uint2 *>(qr + (2 * ks) * 16), qhi = *reinterpret_cast<const uint2 *>(qr + (2 * ks + 1) * 16);
+                dv[db] = mfma<BF16>(pf[ks], make_uint4(dlo.x, dlo.y, dhi.x, dhi.y), dv[db]);
+                dk[db] = mfma<BF16>(dsf[ks], make_uint4(qlo.x, qlo.y, qhi.x, qhi.y), dk[db]);
+            }
+    }
+    // dK / dV rows key = g*4 + r (of this wave's 16), cols d = db*16 + c16
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kpos = kt0 + wid * 16 + g * 4 + r;
+        if (kpos >= kl.Lk) continue;
+        const long long row = kl.row(kpos);
+        float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            unsafeAtomicAdd(pk + db * 16, dk[db][r]);
+            unsafeAtomicAdd(pv + db * 16, dv[db][r]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vs_attention_backward(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse,
+                                     float *delta, void *dq, float *dk, float *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
+                                     int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                     int32_t lddo, int32_t lddq, int32_t lddk, int32_t lddv, const int32_t *kv_seg,
+                                     const int32_t *q_kvlen, int32_t max_keys, float scale, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(q && k && v && o && dout && lse && delta && dq && dk && dv, "vs_attention_backward: null pointer");
+    VS_CHECK(nbatch >= 0 && H > 0 && Lq >= 0, "vs_attention_backward: bad sizes");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_attention_backward: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0, "vs_attention_backward: row strides must be multiples of 8 elements");
+    VS_CHECK(kv_seg ? max_keys > 0 : Lk > 0, "vs_attention_backward: Lk (or max_keys with kv_seg) must be positive");
+    if (nbatch == 0 || Lq == 0) return 0;
+    AttnBwdArgs a;
+    a.q = (const unsigned short *)q; a.k = (const unsigned short *)k; a.v = (const unsigned short *)v;
+    a.o = (const unsigned short *)o; a.dout = (const unsigned short *)dout; a.lse = lse; a.delta = delta;
+    a.dq = (unsigned short *)dq; a.dk = dk; a.dv = dv; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;
+    a.nbatch = nbatch; a.H = H; a.Lq = Lq; a.Lk = Lk; a.q_batch_rows = q_batch_rows; a.k_batch_rows = k_batch_rows;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    const long long rows = (long long)(nbatch - 1) * q_batch_rows + Lq;
+    const int keys = kv_seg ? max_keys : Lk;
+    dim3 block(256);
+    if (dtype == 2) {
+        hipLaunchKernelGGL(attn_delta_kernel<true>, dim3((unsigned)vs::cdiv64(rows * H, 4)), block, 0, stream, a, rows);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<false>, dim3((unsigned)vs::cdiv64(rows * H, 4)), block, 0, stream, a, rows);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}

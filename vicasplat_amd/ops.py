@@ -93,19 +93,45 @@ def rope_qk(buf: torch.Tensor, H: int, k_col: int, pos: torch.Tensor, kind: Opti
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, nbatch: int, H: int, Lq: int,
               Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0, kv_seg: Optional[torch.Tensor] = None,
-              q_kvlen: Optional[torch.Tensor] = None, scale: float = 0.125) -> torch.Tensor:
-    """q/k/v: 2-D views [rows, ld] whose column 0 is head 0 (e.g. slices of a packed q|k|v buffer); out [rows, H*64]."""
-    dev = L.require_device(q, k, v, out, kv_seg, q_kvlen)
+              q_kvlen: Optional[torch.Tensor] = None, scale: float = 0.125, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/k/v: 2-D views [rows, ld] whose column 0 is head 0 (e.g. slices of a packed q|k|v buffer); out [rows, H*64].
+    lse (optional, f32 [rows, H] contiguous) receives the log2-domain logsumexp for attention_backward."""
+    dev = L.require_device(q, k, v, out, kv_seg, q_kvlen, lse)
     for t in (q, k, v, out):
         assert t.dim() == 2 and t.stride(1) == 1
     assert kv_seg is None or (kv_seg.dtype == torch.int32 and kv_seg.is_contiguous())
     assert q_kvlen is None or (q_kvlen.dtype == torch.int32 and q_kvlen.is_contiguous())
+    assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (q.shape[0], H))
     with torch.cuda.device(dev):
-        rc = L.lib().vs_attention(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
-                                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
-                                  _DT[q.dtype], L.stream_ptr(dev))
+        rc = L.lib().vs_attention_lse(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
+                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
+                                      _DT[q.dtype], L.ptr(lse), L.stream_ptr(dev))
     L.check(rc, "vs_attention")
     return out
+
+
+def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, *,
+                       nbatch: int, H: int, Lq: int, Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0,
+                       kv_seg: Optional[torch.Tensor] = None, q_kvlen: Optional[torch.Tensor] = None, max_keys: int = 0,
+                       scale: float = 0.125):
+    """Backward of `attention` (groundwork for the training step).  Returns dq (16-bit [rows, H*64]) and dk, dv (f32
+    [key rows, H*64], accumulated with atomics from zero)."""
+    dev = L.require_device(q, k, v, out, dout, lse, kv_seg, q_kvlen)
+    for t in (q, k, v, out, dout):
+        assert t.dim() == 2 and t.stride(1) == 1
+    Cc = H * 64
+    dq = torch.empty((q.shape[0], Cc), dtype=q.dtype, device=dev)
+    dk = torch.zeros((k.shape[0], Cc), dtype=torch.float32, device=dev)
+    dv = torch.zeros((v.shape[0], Cc), dtype=torch.float32, device=dev)
+    delta = torch.empty((q.shape[0], H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_attention_backward(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dq),
+                                           L.ptr(dk), L.ptr(dv), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, q.stride(0),
+                                           k.stride(0), v.stride(0), out.stride(0), dout.stride(0), dq.stride(0), dk.stride(0),
+                                           dv.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), max_keys, scale, _DT[q.dtype],
+                                           L.stream_ptr(dev))
+    L.check(rc, "vs_attention_backward")
+    return dq, dk, dv
 
 
 def gaussian_adapter(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torch.Tensor, *, scale_act: str = "softplus",
