@@ -162,6 +162,9 @@ int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias, void *out,
  * 64.  pos int32 [rows,2] (y,x) or (t,-); kind uint8 [rows] (0 = 2-D, 1 = temporal 1-D interleaved, 2 = none) or NULL. */
 int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos, const uint8_t *kind,
                float base2d, float theta1d, int32_t dtype, vs_stream_t stream);
+/* Same with a direction: dir = +1 forward, -1 the inverse rotation (= the backward pass of the embedding on dq, dk). */
+int vs_rope_qk_dir(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos, const uint8_t *kind,
+                   float base2d, float theta1d, float dir, int32_t dtype, vs_stream_t stream);
 
 /* Fused attention, head dim 64.  Batch item b, head h: queries rows b*q_batch_rows + [0,Lq) of q (row stride ldq,
  * head h at column h*64); keys/values rows b*k_batch_rows + [0,Lk) of k / v -- or, when kv_seg != NULL, the two row
@@ -236,6 +239,12 @@ int vs_attention_backward(const void *q, const void *k, const void *v, const voi
  *                         dx f32 [M,C] is written (accumulate_dx = 0) or added to (1); dw, db [C] and dscale, dshift
  *                         [G, mod_ld] are ADDED to (f32 atomics): zero them before the first call of a step.
  * ------------------------------------------------------------------------------------------------ */
+/* dx = x > 0 ? dx : 0, in place, n 16-bit elements (f16 or bf16: same sign/zero encoding); backward of a ReLU on x. */
+int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream);
+/* out32[M,N] += A[M,K] W[N,K]^T, K cut into ksplit slices (separate workgroups, f32 atomics): long thin reductions such as
+ * weight gradients.  K % (32 * ksplit) == 0; A, W may start at any 2-byte aligned address (shifted views). */
+int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                              int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
 int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream);
 int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream);

@@ -193,6 +193,9 @@ def test_rope_qk_packed(dt):
         tol = 4e-3 if dt == torch.float16 else 3e-2
         assert (got[:, col:col + H * 64].reshape(rows, H, 64) - exp).abs().max() <= tol
     assert torch.equal(got[:, 2 * H * 64:], ref_in[:, 2 * H * 64:])  # v untouched
+    # the inverse rotation (backward of the embedding) undoes it
+    ops.rope_qk(buf, H, H * 64, pos, kind, 100.0, 30.0, inverse=True)
+    assert (buf.float() - ref_in).abs().max() <= (6e-3 if dt == torch.float16 else 5e-2)
 
 
 def test_curope_drop_in_matches_reference_math():
@@ -553,3 +556,27 @@ def test_attention_backward_matches_autograd(dt, case):
     assert torch.isfinite(lse).all()
     for got, ref, nm in ((dq.float(), gq, "dq"), (dk, gk, "dk"), (dv, gv, "dv")):
         assert (got - ref).abs().max() <= rt * ref.abs().max(), (nm, float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,relu_in", [(2, 16, 16, 64, 128, False), (1, 37, 21, 128, 256, True), (3, 64, 64, 256, 256, True)])
+def test_conv3x3_backward_matches_autograd(dt, N, H, W, Cin, Cout, relu_in):
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(N * H + Cin)
+    x = torch.randn(N, H, W, Cin, device=d).to(dt)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1).to(d)
+    wp = ops.pack_conv3x3_weight(conv.weight, dt)
+    dy = (torch.randn(N, H, W, Cout, device=d) * 0.5).to(dt)
+    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_()
+    wr = wp.float().permute(0, 3, 1, 2).clone().requires_grad_()   # [Cout,Cin,3,3] from the 16-bit packed weights
+    br = conv.bias.detach().clone().requires_grad_()
+    y = F.conv2d(F.relu(xr) if relu_in else xr, wr, br, padding=1)
+    (y * dy.float().permute(0, 3, 1, 2)).sum().backward()
+    dx, dw, db = ops.conv3x3_backward(dy, x, wp, relu_in=relu_in)
+    rt = 4e-3 if dt == torch.float16 else 2.5e-2
+    gx = xr.grad.permute(0, 2, 3, 1)
+    assert (dx.float() - gx).abs().max() <= rt * gx.abs().max()
+    gw = wr.grad.permute(0, 2, 3, 1)
+    assert (dw - gw).abs().max() <= 3e-3 * gw.abs().max() + 1e-3
+    assert (db - br.grad).abs().max() <= 1e-3 * br.grad.abs().max() + 1e-2

@@ -91,11 +91,17 @@ def lib() -> C.CDLL:
             L.vs_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp]
             L.vs_gaussian_adapter.restype = C.c_int
             L.vs_gaussian_adapter.argtypes = [vp, i64, i64, vp, i64, i64, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.vs_rope_qk_dir.restype = C.c_int
+            L.vs_rope_qk_dir.argtypes = [vp, i64, i32, i32, i32, vp, vp, f32, f32, f32, i32, vp]
             L.vs_attention_lse.restype = C.c_int
             L.vs_attention_lse.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]
             L.vs_attention_backward.restype = C.c_int
             L.vs_attention_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32,
                                                 i32, i32, i32, vp, vp, i32, f32, i32, vp]
+            L.vs_relu_mask16.restype = C.c_int
+            L.vs_relu_mask16.argtypes = [vp, vp, i64, vp]
+            L.vs_gemm_splitk_accumulate.restype = C.c_int
+            L.vs_gemm_splitk_accumulate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_transpose16.restype = C.c_int
             L.vs_transpose16.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
             L.vs_colsum.restype = C.c_int

@@ -94,6 +94,22 @@ gelu_backward_kernel(const unsigned short *__restrict__ dy, const unsigned short
     *reinterpret_cast<uint4 *>(dz + i) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+// dx = x > 0 ? dx : 0 on packed 16-bit pairs (backward of a ReLU whose INPUT x was saved), in place
+__global__ void __launch_bounds__(256)
+relu_mask16_kernel(unsigned short *__restrict__ dx, const unsigned short *__restrict__ x, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    uint4 d = *reinterpret_cast<uint4 *>(dx + i);
+    const uint4 v = *reinterpret_cast<const uint4 *>(x + i);
+    auto m = [](unsigned dd, unsigned xx) {  // keep a half iff x is positive: sign bit clear and not (+/-)zero
+        const unsigned lo = ((xx & 0x8000u) == 0 && (xx & 0x7fffu) != 0) ? 0xffffu : 0u;
+        const unsigned hi = ((xx & 0x80000000u) == 0 && (xx & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+        return dd & (lo | hi);
+    };
+    d.x = m(d.x, v.x); d.y = m(d.y, v.y); d.z = m(d.z, v.z); d.w = m(d.w, v.w);
+    *reinterpret_cast<uint4 *>(dx + i) = d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -300,6 +316,18 @@ extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do
                                       grp_in, grp_out, grp_off)
     if (do_dtype == 0) VS_LNB(0); else if (do_dtype == 1) VS_LNB(1); else VS_LNB(2);
 #undef VS_LNB
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(dx && x, "vs_relu_mask16: null pointer");
+    VS_CHECK(n >= 0 && n % 8 == 0, "vs_relu_mask16: n must be a multiple of 8");
+    VS_CHECK((((uintptr_t)dx | (uintptr_t)x) & 15) == 0, "vs_relu_mask16: 16-byte alignment required");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(relu_mask16_kernel, dim3((unsigned)vs::cdiv64(n / 8, 256)), dim3(256), 0, stream, (unsigned short *)dx,
+                       (const unsigned short *)x, (long long)n);
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -395,6 +395,32 @@ extern "C" int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias,
                       a_grp_in, a_grp_out, a_grp_off, pos, kind, C, base2d, theta1d, (hipStream_t)stream_);
 }
 
+// out32[M,N] += A[M,K] W[N,K]^T with the K range cut into `ksplit` slices that run as separate workgroups and meet through
+// f32 atomics: for reductions that are long and thin (weight gradients: M, N = channels, K = millions of pixels or tokens).
+// A and W may start at any 2-byte aligned address (LDS-DMA staging), which lets a caller pass shifted views.
+extern "C" int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
+                                         int32_t ldw, int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(A && W && out, "vs_gemm_splitk_accumulate: null pointer");
+    VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit > 0, "vs_gemm_splitk_accumulate: bad sizes");
+    VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_splitk_accumulate: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_splitk_accumulate: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(ksplit <= 65535, "vs_gemm_splitk_accumulate: ksplit too large");
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+    g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
+    g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.ksplit = ksplit > 1 ? ksplit : 2;  // the epilogue uses atomics whenever ksplit > 1; a single slice still accumulates
+    if (ksplit == 1) { VS_CHECK(K % 64 == 0, "vs_gemm_splitk_accumulate: K must be a multiple of 64 when ksplit == 1"); }
+    const int rc = dtype == 2 ? launch_mi<true, 4>(g, 2, stream) : launch_mi<false, 4>(g, 2, stream);
+    if (rc) return rc;
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
 // 7x7 stride-1 pad-3 convolution of an RGB image (the gs head's input_merger, heads/dpt_gs_head.py:112-118) as a window
 // GEMM on gemm_kernel: with a zero-padded NHWC image [Nimg, Hp, Wp, 3] the 7 horizontal taps x 3 channels of one kernel
 // row are 21 CONTIGUOUS halfs starting at padded pixel (y+dy, x), so k-step dy of output pixel (y, x) is the 32-half slice

@@ -116,7 +116,7 @@ __device__ __forceinline__ void st16(unsigned short *p, float v) {
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 rope_qk_kernel(unsigned short *__restrict__ buf, long long ld, int rows, int H, int k_col, const int32_t *__restrict__ pos,
-               const uint8_t *__restrict__ kind, float base2d, float theta1d) {
+               const uint8_t *__restrict__ kind, float base2d, float theta1d, float dir) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -134,7 +134,7 @@ rope_qk_kernel(unsigned short *__restrict__ buf, long long ld, int rows, int H, 
         ang = (float)pos[2 * row] / powf(theta1d, (float)(2 * p) / 64.0f);
     }
     float sn, cs;
-    sincosf(ang, &sn, &cs);
+    sincosf(ang * dir, &sn, &cs);  // dir = -1: the inverse rotation = the backward pass of the (orthogonal) embedding
     unsigned short *r = buf + (long long)row * ld + (sel ? k_col : 0);
     for (int h = 0; h < H; ++h) {
         unsigned short *pu = r + h * 64 + iu, *pv = r + h * 64 + iv;
@@ -169,15 +169,21 @@ extern "C" int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, con
     return 0;
 }
 
-extern "C" int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos,
-                          const uint8_t *kind, float base2d, float theta1d, int32_t dtype, vs_stream_t stream_) {
+extern "C" int vs_rope_qk_dir(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos,
+                              const uint8_t *kind, float base2d, float theta1d, float dir, int32_t dtype, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(buf && pos, "vs_rope_qk: null pointer");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_rope_qk: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(dir == 1.0f || dir == -1.0f, "vs_rope_qk_dir: dir must be +1 (forward) or -1 (inverse / backward)");
     if (rows <= 0 || H <= 0) return 0;
     dim3 grid(vs::cdiv(rows, 4)), block(256);
-    if (dtype == 2) hipLaunchKernelGGL(rope_qk_kernel<true>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d);
-    else hipLaunchKernelGGL(rope_qk_kernel<false>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d);
+    if (dtype == 2) hipLaunchKernelGGL(rope_qk_kernel<true>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
+    else hipLaunchKernelGGL(rope_qk_kernel<false>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
     VS_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int vs_rope_qk(void *buf, int64_t ld, int32_t rows, int32_t H, int32_t k_col, const int32_t *pos, const uint8_t *kind,
+                          float base2d, float theta1d, int32_t dtype, vs_stream_t stream_) {
+    return vs_rope_qk_dir(buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, 1.0f, dtype, stream_);
 }

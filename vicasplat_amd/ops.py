@@ -79,14 +79,15 @@ def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 
 
 def rope_qk(buf: torch.Tensor, H: int, k_col: int, pos: torch.Tensor, kind: Optional[torch.Tensor] = None,
-            base2d: float = 100.0, theta1d: float = 30.0) -> torch.Tensor:
-    """In-place RoPE on q (col 0) and k (col k_col) of buf [rows, ld]; pos int32 [rows,2]; kind uint8 [rows] or None."""
+            base2d: float = 100.0, theta1d: float = 30.0, inverse: bool = False) -> torch.Tensor:
+    """In-place RoPE on q (col 0) and k (col k_col) of buf [rows, ld]; pos int32 [rows,2]; kind uint8 [rows] or None.
+    inverse=True applies the inverse rotation (the backward pass of the embedding, on dq | dk)."""
     dev = L.require_device(buf, pos, kind)
     assert buf.dim() == 2 and buf.stride(1) == 1 and pos.dtype == torch.int32 and pos.is_contiguous()
     assert kind is None or (kind.dtype == torch.uint8 and kind.is_contiguous())
     with torch.cuda.device(dev):
-        rc = L.lib().vs_rope_qk(L.ptr(buf), buf.stride(0), buf.shape[0], H, k_col, L.ptr(pos), L.ptr(kind), base2d, theta1d,
-                                _DT[buf.dtype], L.stream_ptr(dev))
+        rc = L.lib().vs_rope_qk_dir(L.ptr(buf), buf.stride(0), buf.shape[0], H, k_col, L.ptr(pos), L.ptr(kind), base2d, theta1d,
+                                    -1.0 if inverse else 1.0, _DT[buf.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_rope_qk")
     return buf
 
@@ -340,4 +341,68 @@ def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_
         gemm(dyT, xT, None, dw, EPI_STORE32)
     if need_db:
         db = colsum(dy)
+    return dx, dw, db
+
+
+def relu_mask_(dx: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """In place dx = x > 0 ? dx : 0 (contiguous 16-bit, same shape): backward of a ReLU applied to x."""
+    dev = L.require_device(dx, x)
+    assert dx.shape == x.shape and dx.dtype == x.dtype and dx.is_contiguous() and x.is_contiguous()
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_relu_mask16(L.ptr(dx), L.ptr(x), dx.numel(), L.stream_ptr(dev))
+    L.check(rc, "vs_relu_mask16")
+    return dx
+
+
+def gemm_splitk_accumulate(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int, *, K: Optional[int] = None) -> torch.Tensor:
+    """out32 [M,N] += a[M,K] @ w[N,K]^T with K split over `ksplit` workgroups per tile.  a / w may be column-shifted views."""
+    dev = L.require_device(a, w, out)
+    assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and out.dtype == torch.float32
+    K = a.shape[1] if K is None else K
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_splitk_accumulate(L.ptr(a), L.ptr(w), L.ptr(out), a.shape[0], w.shape[0], K, a.stride(0), w.stride(0),
+                                               out.stride(0), ksplit, _DT[a.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_splitk_accumulate")
+    return out
+
+
+def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu_in: bool = False, need_dx: bool = True):
+    """Backward of conv3x3_nhwc(x, w, bias, relu_in=relu_in) (stride 1, pad 1) for the gradient dy of its pre-activation output.
+    dy [N,H,W,Cout], x [N,H,W,Cin] (the conv input, before the fused input ReLU), w [Cout,3,3,Cin], all 16-bit NHWC.
+    Returns dx [N,H,W,Cin] 16-bit, dw [Cout,3,3,Cin] f32, db [Cout] f32.
+      dx: the same implicit-GEMM kernel on dy with the spatially flipped, channel-transposed weights;
+      dw: per tap one split-K GEMM over the zero-bordered, transposed activations -- the tap shift is a column shift of the
+          [Cin, pixels] operand (LDS-DMA reads any 2-byte aligned address), so no im2col buffer exists here either."""
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    dev, dt = x.device, x.dtype
+    dx = None
+    if need_dx:
+        wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()          # [Cin, 3, 3, Cout]
+        dx = conv3x3_nhwc(dy.contiguous(), wd, None)
+        if relu_in:
+            relu_mask_(dx, x)
+    # weight gradient
+    xin = torch.relu(x) if relu_in else x
+    Hp, Wp = H + 2, W + 2
+    P = N * Hp * Wp
+    ksplit = max(1, min(256, P // 4096))
+    unit = 64 * ksplit
+    Ppad = (P + unit - 1) // unit * unit
+    slack = Wp + 2                                                  # largest |tap shift| + 1
+    xp = torch.zeros((N, Hp, Wp, Cin), dtype=dt, device=dev); xp[:, 1:-1, 1:-1] = xin
+    dyp = torch.zeros((N, Hp, Wp, Cout), dtype=dt, device=dev); dyp[:, 1:-1, 1:-1] = dy
+    xT = torch.zeros((Cin, slack + Ppad + slack), dtype=dt, device=dev)
+    xT[:, slack:slack + P] = transpose16(xp.view(P, Cin))[:, :P]
+    dyT = torch.zeros((Cout, Ppad), dtype=dt, device=dev)
+    dyT[:, :P] = transpose16(dyp.view(P, Cout))[:, :P]
+    dw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=dev)
+    tmp = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
+    for ty in range(3):
+        for tx in range(3):
+            shift = (ty - 1) * Wp + (tx - 1)
+            tmp.zero_()
+            gemm_splitk_accumulate(dyT, xT[:, slack + shift:slack + shift + Ppad], tmp, ksplit, K=Ppad)
+            dw[:, ty, tx] = tmp
+    db = colsum(dy.reshape(-1, Cout))
     return dx, dw, db
