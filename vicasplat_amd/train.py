@@ -1,0 +1,83 @@
+"""Training-step groundwork: the frame-encoder transformer block differentiated end to end
+on the HIP backward operators of `ops` -- LayerNorm -> packed qkv projection + RoPE -> attention -> projection (+residual)
+-> LayerNorm -> fc1 -> GELU -> fc2 (+residual), i.e. croco/blocks.py:114-130 as `VicaNet` runs it
+(backbone_vica.py:455-470).  Parity against torch autograd over the oracle's block: tests/test_train_gpu.py.
+
+What is NOT here yet: the decoder blocks (camera tokens, AdaLN), the DPT heads, the adapter, the optimiser and the
+gradient all-reduce -- so there is no training step; this module only proves the operators compose on the real block.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+@dataclass
+class EncBlockParams:
+    """One encoder block: 16-bit GEMM operands, f32 everything else (the layout VicaNet caches for inference)."""
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor      # [3C, C] 16-bit, [3C] f32
+    proj_w: torch.Tensor; proj_b: torch.Tensor    # [C, C], [C]
+    ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor      # [4C, C], [4C]
+    fc2_w: torch.Tensor; fc2_b: torch.Tensor      # [C, 4C], [C]
+
+
+def enc_block_forward_train(x: torch.Tensor, p: EncBlockParams, pos: torch.Tensor, *, frames: int, tokens: int, heads: int,
+                            rope_base: float = 100.0, eps: float = 1e-6):
+    """x f32 [frames*tokens, C] (residual stream) -> (x_out f32, tape).  Same kernels as inference; the tape keeps what
+    the backward needs: both residual inputs, both LayerNorm outputs, qkv (after RoPE), the attention output + its
+    logsumexp, and the fc1 pre-activation."""
+    M, C = x.shape
+    dt = p.qkv_w.dtype
+    dev = x.device
+    h1 = torch.empty(M, C, dtype=dt, device=dev)
+    ops.layernorm_mod(x, p.ln1_w, p.ln1_b, h1, eps=eps)
+    qkv = torch.empty(M, 3 * C, dtype=dt, device=dev)
+    ops.gemm_qkv_rope(h1, p.qkv_w, p.qkv_b, qkv, C, pos, None, rope_base, 1.0)
+    att = torch.empty(M, C, dtype=dt, device=dev)
+    lse = torch.empty(M, heads, dtype=torch.float32, device=dev)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], att, nbatch=frames, H=heads, Lq=tokens, Lk=tokens,
+                  q_batch_rows=tokens, k_batch_rows=tokens, lse=lse)
+    x_mid = x.clone()
+    ops.gemm(att, p.proj_w, p.proj_b, x_mid, ops.EPI_RESID32)
+    h2 = torch.empty(M, C, dtype=dt, device=dev)
+    ops.layernorm_mod(x_mid, p.ln2_w, p.ln2_b, h2, eps=eps)
+    z = torch.empty(M, p.fc1_w.shape[0], dtype=dt, device=dev)
+    ops.gemm(h2, p.fc1_w, p.fc1_b, z, ops.EPI_STORE16)       # pre-activation kept for the GELU backward
+    a = F.gelu(z.float()).to(dt)
+    x_out = x_mid.clone()
+    ops.gemm(a, p.fc2_w, p.fc2_b, x_out, ops.EPI_RESID32)
+    tape = dict(x=x, h1=h1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, h2=h2, z=z, a=a, pos=pos, frames=frames, tokens=tokens,
+                heads=heads, rope_base=rope_base, eps=eps)
+    return x_out, tape
+
+
+def enc_block_backward(dx_out: torch.Tensor, tape: dict, p: EncBlockParams):
+    """dx_out f32 [M,C] = dL/d(block output) -> (dx_in f32 [M,C], dict of parameter gradients, all f32)."""
+    t = tape
+    C = dx_out.shape[1]
+    dt = p.qkv_w.dtype
+    g = {}
+    dx_mid = dx_out.clone()                                   # residual branch
+    # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
+    da, g["fc2_w"], g["fc2_b"] = ops.linear_backward(dx_out.to(dt), t["a"], p.fc2_w)
+    dz = ops.gelu_backward(da, t["z"])
+    dh2, g["fc1_w"], g["fc1_b"] = ops.linear_backward(dz, t["h2"], p.fc1_w)
+    _, g["ln2_w"], g["ln2_b"], _, _ = ops.layernorm_backward(dh2, t["x_mid"], p.ln2_w, p.ln2_b, eps=t["eps"], dx=dx_mid, accumulate_dx=True)
+    # ---- attention: x_mid = x + proj(attn(rope(qkv(LN1(x))))) ----
+    dx_in = dx_mid.clone()
+    datt, g["proj_w"], g["proj_b"] = ops.linear_backward(dx_mid.to(dt), t["att"], p.proj_w)
+    qkv = t["qkv"]
+    dq, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], t["att"], datt, t["lse"], nbatch=t["frames"],
+                                        H=t["heads"], Lq=t["tokens"], Lk=t["tokens"], q_batch_rows=t["tokens"],
+                                        k_batch_rows=t["tokens"])
+    dqkv = torch.cat([dq, dk.to(dt), dv.to(dt)], dim=1)
+    ops.rope_qk(dqkv, t["heads"], C, t["pos"], None, t["rope_base"], 1.0, inverse=True)   # backward of the rotation on dq | dk
+    dh1, g["qkv_w"], g["qkv_b"] = ops.linear_backward(dqkv, t["h1"], p.qkv_w)
+    _, g["ln1_w"], g["ln1_b"], _, _ = ops.layernorm_backward(dh1, t["x"], p.ln1_w, p.ln1_b, eps=t["eps"], dx=dx_in, accumulate_dx=True)
+    return dx_in, g
