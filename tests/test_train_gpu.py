@@ -64,3 +64,99 @@ def test_encoder_block_backward_matches_oracle_autograd(dt):
         errs[ours] = rel(grads[ours], Wr[n + ref].grad)
     print(dt, {k: f"{v:.2e}" for k, v in errs.items()})
     assert max(errs.values()) <= gt, errs
+
+
+TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
+
+
+def _tiny_model(dt):
+    import json, os
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    shapes = json.load(open(os.path.join(G, "shapes_tiny.json")))
+    m, _ = get_encoder(default_cfg(**TINY))
+    W = er.golden_weights(shapes, seed=0)
+    m.load_state_dict(W, strict=True)
+    m = m.cuda().train()
+    m.set_compute_dtype(dt)
+    return m, W
+
+
+def test_training_forward_matches_reference_goldens():
+    """The differentiable forward (autograd Functions on the HIP kernels) reproduces the REAL reference's f64 outputs like
+    the inference forward does (same goldens, same tolerances as tests/test_encoder_gpu.py)."""
+    import os
+    import numpy as np
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_tiny_v3.npz"))
+    m, _ = _tiny_model(torch.float16)
+    B, V = int(z["cfg_B"]), int(z["cfg_V"])
+    img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    with torch.no_grad():
+        out = forward_train(m, img.cuda(), K.cuda(), torch.float16)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max() / (np.abs(b).max() + 1e-12))
+    LAT = slice(8, 256, 16)
+    e_pose = rel(out["pred_extrins"].cpu().numpy(), z["f64_pred_extrins"])
+    e_raw = rel(out["raw_gaussians"][:, :, LAT, LAT].cpu().numpy(), z["f64_raw"])
+    e_cov = rel(out["gaussians"]["covariances"][:, :, LAT, LAT].cpu().numpy(), z["f64_covariances"])
+    print("train forward vs reference f64:", e_pose, e_raw, e_cov)
+    assert e_pose <= 5e-3 and e_raw <= 3e-2 and e_cov <= 6e-2
+
+
+def test_training_backward_matches_oracle_autograd():
+    """End-to-end gradients of the whole encoder (2 + 12 transformer blocks, both DPT heads, adapter, pose head) for a
+    random linear functional of its outputs, HIP training path vs f32 torch autograd over the oracle (128 x 128 frames)."""
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    dt = torch.float16
+    m, W = _tiny_model(dt)
+    B, V, S = 1, 3, 128
+    img, K = er.synthetic_input(B, V, S, 7)
+    g = torch.Generator().manual_seed(1)
+    r_raw = torch.randn(B, V, S, S, 86, generator=g) * 1e-3
+    r_raw[..., :3] *= 0.1
+    r_pose = torch.randn(B, V - 1, 8, generator=g)
+    r_cov = torch.randn(B, V, S, S, 3, 3, generator=g) * 10.0
+    # ---- oracle (f32 CPU autograd) ----
+    Wr = {k: v.clone().float().requires_grad_() for k, v in W.items()}
+    cfg = er.default_cfg(**TINY)
+    o = er.forward.__wrapped__(Wr, cfg, img, K)
+    loss_r = (o["raw_gaussians"] * r_raw).sum() + (o["pred_extrins"] * r_pose).sum() + (o["gaussians"]["covariances"] * r_cov).sum()
+    loss_r.backward()
+    # ---- ours ----
+    out = forward_train(m, img.cuda(), K.cuda(), dt)
+    loss = (out["raw_gaussians"] * r_raw.cuda()).sum() + (out["pred_extrins"] * r_pose.cuda()).sum() + \
+        (out["gaussians"]["covariances"] * r_cov.cuda()).sum()
+    S = 1024.0                       # static loss scale: 16-bit activation gradients would underflow otherwise (torch.amp practice)
+    (loss * S).backward()
+    assert abs(float(loss.detach()) - float(loss_r.detach())) <= 2e-2 * abs(float(loss_r.detach())) + 1e-2, (float(loss.detach()), float(loss_r.detach()))
+    errs = {}
+    for name, p in m.named_parameters():
+        import re
+        ref = Wr[re.sub(r"layer(\d)_rn", lambda mm: f"layer_rn.{int(mm.group(1)) - 1}", name)].grad   # aliased keys
+        if ref is None:                      # unused by the model (e.g. refinenet4.resConfUnit1: no skip input)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        errs[name] = float((p.grad.cpu().float() / S - ref).abs().max() / (ref.abs().max() + 1e-20))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    vals = sorted(errs.values())
+    print("params", len(errs), "median rel err %.2e" % vals[len(vals) // 2], "p90 %.2e" % vals[int(len(vals) * 0.9)], "worst", worst)
+    # The residual error is the forward's 16-bit-operand noise (activations entering every weight gradient differ from the f32
+    # oracle's by the same ~1-3 % that the forward parity tests allow on this tiny random-weight model), not a backward defect:
+    # the backward operators alone are exact to 1e-6..7e-4 (tests/test_ops_gpu.py, the block test above).  What training
+    # needs is the gradient DIRECTION: cosine similarity of the whole gradient and of every parameter's gradient.
+    ours = torch.cat([p.grad.flatten().cpu().float() / S for n_, p in m.named_parameters() if n_ in errs])
+    import re as _re
+    refv = torch.cat([Wr[_re.sub(r"layer(\d)_rn", lambda mm: f"layer_rn.{int(mm.group(1)) - 1}", n_)].grad.flatten() for n_, p in m.named_parameters() if n_ in errs])
+    cos_all = float((ours.double() @ refv.double()) / (ours.double().norm() * refv.double().norm()))
+    cos_min, cos_arg = 1.0, None
+    for n_, p in m.named_parameters():
+        if n_ in errs:
+            r_ = Wr[_re.sub(r"layer(\d)_rn", lambda mm: f"layer_rn.{int(mm.group(1)) - 1}", n_)].grad.flatten()
+            o_ = p.grad.flatten().cpu().double()
+            c_ = float((o_ @ r_.double()) / (o_.norm() * r_.double().norm() + 1e-300))
+            if c_ < cos_min:
+                cos_min, cos_arg = c_, n_
+    print("cosine(all) %.6f  min per-parameter cosine %.5f (%s)" % (cos_all, cos_min, cos_arg))
+    assert cos_all >= 0.999 and cos_min >= 0.98, (cos_all, cos_min, cos_arg)
+    assert vals[len(vals) // 2] <= 4e-2 and vals[int(len(vals) * 0.9)] <= 8e-2 and vals[-1] <= 0.25, worst

@@ -1,0 +1,151 @@
+"""torch.autograd.Function wrappers of the HIP operators, forward AND backward on the hand-written kernels
+(`vicasplat_amd.ops`).  They are what the training forward (`model/encoder/train_forward.py`) is written in, so that the
+glue between the hot operators -- residual adds, reshapes, the tiny f32 camera-token math -- is differentiated by
+PyTorch while every GEMM, LayerNorm, attention, RoPE and 3x3 convolution runs on gfx950 in both directions.
+
+Reference: the training step differentiates the encoder with torch autograd (model_wrapper.py:184-321); these Functions
+are the MI355X replacements of the autograd nodes of nn.Linear, nn.LayerNorm (+AdaLN modulation), RoPE2D / temporal RoPE,
+scaled-dot-product attention and nn.Conv2d(k=3, s=1, p=1) on that path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class LinearFn(torch.autograd.Function):
+    """y16 = x @ w^T + b on the MFMA GEMM; backward = dgrad / wgrad on the same kernels (ops.linear_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dt):
+        K = x.shape[-1]
+        x16 = x.reshape(-1, K).to(dt).contiguous()
+        w16 = w.detach().to(dt).contiguous()
+        y = torch.empty((x16.shape[0], w16.shape[0]), dtype=dt, device=x.device)
+        ops.gemm(x16, w16, None if b is None else b.detach().float().contiguous(), y, ops.EPI_STORE16)
+        ctx.save_for_backward(x16, w16)
+        ctx.meta = (x.shape, x.dtype, b is not None)
+        return y.view(*x.shape[:-1], w16.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w16 = ctx.saved_tensors
+        xshape, xdtype, has_b = ctx.meta
+        dy16 = dy.reshape(-1, dy.shape[-1]).to(w16.dtype).contiguous()
+        dx, dw, db = ops.linear_backward(dy16, x16, w16, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
+                                         need_db=has_b and ctx.needs_input_grad[2])
+        return (None if dx is None else dx.view(xshape).to(xdtype)), dw, db, None
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype) -> torch.Tensor:
+    """nn.Linear in the operand dtype `dt`.  K must be a multiple of 64 for the MFMA kernels; tiny odd shapes (the 9 -> C
+    intrinsic embedding) stay on torch in f32."""
+    if x.shape[-1] % 64 != 0:
+        return torch.nn.functional.linear(x.float(), w, b).to(dt)
+    return LinearFn.apply(x, w, b, dt)
+
+
+class LayerNormModFn(torch.autograd.Function):
+    """out = LN(x; w, b) [* (1 + scale[row // mod_rows]) + shift[...]], x f32 [M,C] -> out in `out_dtype`."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale, shift, mod_rows, out_dtype, eps):
+        M, C = x.shape
+        xf = x.float().contiguous()
+        out = torch.empty((M, C), dtype=out_dtype, device=x.device)
+        sc = None if scale is None else scale.detach().float().contiguous()
+        sh = None if shift is None else shift.detach().float().contiguous()
+        ops.layernorm_mod(xf, w.detach().float().contiguous(), b.detach().float().contiguous(), out, eps=eps, scale=sc, shift=sh,
+                          mod_rows=mod_rows)
+        ctx.save_for_backward(xf, w.detach().float().contiguous(), b.detach().float().contiguous(), sc)
+        ctx.meta = (mod_rows, eps, x.dtype, scale is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xf, w, b, sc = ctx.saved_tensors
+        mod_rows, eps, xdtype, has_mod = ctx.meta
+        dx, dw, db, dsc, dsh = ops.layernorm_backward(dout.contiguous(), xf, w, b, scale=sc, mod_rows=mod_rows, eps=eps)
+        return dx.to(xdtype), dw, db, (dsc if has_mod else None), (dsh if has_mod else None), None, None, None
+
+
+def layernorm_mod(x, w, b, *, scale=None, shift=None, mod_rows=0, out_dtype=torch.float16, eps=1e-6):
+    """x [..., C] (any leading dims; scale/shift [G, C] apply to consecutive groups of mod_rows rows)."""
+    lead = x.shape[:-1]
+    y = LayerNormModFn.apply(x.reshape(-1, x.shape[-1]), w, b, scale, shift, mod_rows, out_dtype, eps)
+    return y.view(*lead, x.shape[-1])
+
+
+class RopeQKFn(torch.autograd.Function):
+    """Rotary embedding of the q | k blocks of a packed [rows, 3C] projection; backward = the inverse rotation."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos, kind, H, C, base2d, theta1d):
+        out = qkv.contiguous().clone()
+        ops.rope_qk(out, H, C, pos, kind, base2d, theta1d)
+        ctx.meta = (pos, kind, H, C, base2d, theta1d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        pos, kind, H, C, base2d, theta1d = ctx.meta
+        g = dy.contiguous().clone()
+        ops.rope_qk(g, H, C, pos, kind, base2d, theta1d, inverse=True)
+        return g, None, None, None, None, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / 8) v on packed q | k | v [rows, 3C] (head_dim 64) with the key-prefix mask / key segments of
+    ops.attention; backward = ops.attention_backward (flash style, logsumexp saved)."""
+
+    @staticmethod
+    def forward(ctx, qkv, nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, kv_seg, q_kvlen, max_keys):
+        C = H * 64
+        qkv = qkv.contiguous()
+        out = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((qkv.shape[0], H), dtype=torch.float32, device=qkv.device)
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, nbatch=nbatch, H=H, Lq=Lq, Lk=Lk, q_batch_rows=q_batch_rows,
+                      k_batch_rows=k_batch_rows, kv_seg=kv_seg, q_kvlen=q_kvlen, lse=lse)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.meta = (nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, kv_seg, q_kvlen, max_keys)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        nbatch, H, Lq, Lk, qbr, kbr, kv_seg, q_kvlen, max_keys = ctx.meta
+        C = H * 64
+        dq, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H,
+                                            Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, kv_seg=kv_seg, q_kvlen=q_kvlen,
+                                            max_keys=max_keys)
+        dqkv = torch.cat([dq, dk.to(dq.dtype), dv.to(dq.dtype)], dim=1)
+        return dqkv, None, None, None, None, None, None, None, None, None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """nn.Conv2d(k=3, s=1, p=1) on NHWC 16-bit activations with the ResidualConvUnit's activation-before-conv fused
+    (relu_in); w is the module's [Cout, Cin, 3, 3] f32 parameter.  Backward: ops.conv3x3_backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu_in):
+        dt = x.dtype
+        wp = ops.pack_conv3x3_weight(w, dt)
+        x = x.contiguous()
+        y = ops.conv3x3_nhwc(x, wp, None if b is None else b.detach().float().contiguous(), relu_in=relu_in)
+        ctx.save_for_backward(x, wp)
+        ctx.meta = (relu_in, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        relu_in, has_b = ctx.meta
+        dx, dw, db = ops.conv3x3_backward(dy.contiguous(), x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0])
+        return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None
+
+
+def conv3x3(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
+    return Conv3x3Fn.apply(x_nhwc, w, b, relu_in)

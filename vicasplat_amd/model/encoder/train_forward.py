@@ -1,0 +1,182 @@
+"""Differentiable (training) forward of the VicaSplat encoder, written over the module's parameters with the autograd
+Functions of `vicasplat_amd.autograd`: every nn.Linear / 1x1 conv / ConvTranspose(k=s) (MFMA GEMM), LayerNorm + AdaLN
+modulation, RoPE, attention and 3x3 stride-1 convolution runs on the HIP kernels forward AND backward; PyTorch autograd
+differentiates the glue (residual adds, gates, token (de)interleaving, the tiny f32 camera-token MLPs / pose head,
+bilinear x2, the 7x7 stem, the one stride-2 conv and the per-pixel Gaussian adapter -- together < 3 % of the FLOPs).
+
+Structure and names follow vicasplat.py:158-278 / backbone_vica.py:526-582 (state_dict keys of SURVEY Appendix C).
+First version of the training path: correct and kernel-backed, not yet tuned -- the inference path
+(`VicaSplat.forward`) keeps its own fused, buffer-reusing implementation.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from ... import autograd as A
+
+LN_EPS = 1e-6
+
+
+def _ln_f32(P, name, x):
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], LN_EPS)
+
+
+def _lin_f32(P, name, x):
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torch.dtype = torch.float16) -> dict:
+    """image [B,V,3,H,W] normalised to [-1,1], intrinsics [B,V,3,3] -> dict(raw_gaussians [B,V,H,W,86] f32, pred_extrins
+    [B,V-1,8], gaussian_camera_extrins [B,V,4,4], gaussians {means, covariances, harmonics, opacities})."""
+    P = dict(model.named_parameters())
+    cfg = model.backbone.config
+    dev = image.device
+    B, V, _, H, Wd = image.shape
+    p = cfg.patch_size
+    gh, gw = H // p, Wd // p
+    n = gh * gw
+    N1 = n + 1
+    BT = B * V
+    tabs = model.backbone._pos_tables(B, V, gh, gw, dev)
+    lin = lambda name, x: A.linear(x, P[name + ".weight"], P.get(name + ".bias"), dt)
+    lnm = lambda name, x, **k: A.layernorm_mod(x, P[name + ".weight"], P[name + ".bias"], eps=LN_EPS, **k)
+
+    # ---------------- frame encoder (backbone_vica.py:450-480) ----------------
+    frames = image.reshape(BT, 3, H, Wd)
+    cols = frames.reshape(BT, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(BT, n, 3 * p * p)   # conv(k=s=16) as a GEMM
+    Ce = cfg.enc_embed_dim
+    x = A.linear(cols, P["backbone.patch_embed.proj.weight"].flatten(1), P["backbone.patch_embed.proj.bias"], dt).float()
+    intr = _lin_f32(P, "backbone.intrinsic_encoder", intrinsics.reshape(BT, 1, 9).float())
+    x = torch.cat([x, intr], 1)                                                                     # [BT, N1, Ce] f32 stream
+    He = cfg.enc_num_heads
+    for i in range(cfg.enc_depth):
+        nm = f"backbone.enc_blocks.{i}"
+        h = lnm(nm + ".norm1", x, out_dtype=dt)
+        qkv = A.RopeQKFn.apply(lin(nm + ".attn.qkv", h).reshape(BT * N1, 3 * Ce), tabs["pos_img"], None, He, Ce, 100.0, 1.0)
+        att = A.AttentionFn.apply(qkv, BT, He, N1, N1, N1, N1, None, None, 0)
+        x = x + lin(nm + ".attn.proj", att).float().view(BT, N1, Ce)
+        h = lnm(nm + ".norm2", x, out_dtype=dt)
+        x = x + lin(nm + ".mlp.fc2", F.gelu(lin(nm + ".mlp.fc1", h).float()).to(dt)).float()
+    x = lnm("backbone.enc_norm", x, out_dtype=torch.float32)
+
+    # ---------------- video / camera decoder (backbone_vica.py:482-524, block :280-335) ----------------
+    T = V
+    inter = [x]
+    x = lin("backbone.decoder_embed", x).float().view(B, T, N1, -1)
+    C = x.shape[-1]
+    Hd = cfg.dec_num_heads
+    ti, te = P["backbone.camera_intrinsic_token"], P["backbone.camera_extrinsic_token"]
+    cam = torch.cat([ti.expand(B, 1, C), (ti + te).expand(B, T - 1, C)], 1)                          # [B,T,C] f32
+    theta = float(cfg.temporal_rope_theta)
+    M2 = N1 + 1
+    for i in range(cfg.dec_depth):
+        nm = f"backbone.dec_blocks.{i}"
+        cn = _ln_f32(P, nm + ".cam_norm1", cam)
+        s1, b1, g1 = _lin_f32(P, nm + ".modulation1.proj", F.silu(cn)).chunk(3, -1)                   # [B,T,C] each
+        himg = lnm(nm + ".norm1", x.reshape(BT * N1, C), scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        hmix = torch.cat([cn.to(dt).reshape(BT, 1, C), himg.view(BT, N1, C)], 1)                      # camera token first, as the keys are ordered
+        qkv = A.RopeQKFn.apply(lin(nm + ".attn.qkv", hmix).reshape(BT * M2, 3 * C), tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta)
+        att = A.AttentionFn.apply(qkv, B, Hd, T * M2, T * M2, T * M2, T * M2, None, tabs["kvlen"], 0)
+        o = lin(nm + ".attn.proj", att).float().view(B, T, M2, C)
+        x = x + (1 + g1[:, :, None]) * o[:, :, 1:]
+        cam = cam + o[:, :, 0]
+        cn = _ln_f32(P, nm + ".cam_norm2", cam)
+        s2, b2, g2, s3, b3, g3 = _lin_f32(P, nm + ".modulation2.proj", F.silu(cn)).chunk(6, -1)
+        # cross-neighbour attention (:152-191): q | k | v of frame t, keys gathered from frames t-1 / t+1 by row segments
+        himg = lnm(nm + ".norm2", x.reshape(BT * N1, C), scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        ca = nm + ".cross_attn"
+        qkv = torch.cat([lin(ca + ".projq", himg), lin(ca + ".projk", himg), lin(ca + ".projv", himg)], -1)
+        qkv = A.RopeQKFn.apply(qkv, tabs["pos_img"], None, Hd, C, 100.0, 1.0)
+        att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
+        x = x + (1 + g2[:, :, None]) * lin(ca + ".proj", att).float().view(B, T, N1, C)
+        himg = lnm(nm + ".norm3", x.reshape(BT * N1, C), scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        m = lin(nm + ".mlp.fc2", F.gelu(lin(nm + ".mlp.fc1", himg).float()).to(dt)).float().view(B, T, N1, C)
+        x = x + (1 + g3[:, :, None]) * m
+        cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
+        inter.append(x.reshape(BT, N1, C))
+    inter[-1] = lnm("backbone.dec_norm", inter[-1], out_dtype=torch.float32)
+    cam = _ln_f32(P, "backbone.camera_dec_norm", cam)
+    inter = [t[:, :-1] for t in inter]                                                                # drop the intrinsic token (:570-572)
+
+    # ---------------- pose head (vicasplat.py:179-199; misc/dq.py:224-262), f32 ----------------
+    d = _lin_f32(P, "camera_extrinsic_head.1", F.relu(cam[:, 1:]))
+    d = torch.cat([d[..., :3], d[..., 3:4] + 1.0, d[..., 4:]], -1)
+    d = d / d[..., :4].norm(dim=-1, keepdim=True)
+
+    # ---------------- DPT heads (heads/dpt_block.py, dpt_head.py:35-70, dpt_gs_head.py:120-157), NHWC 16-bit ----------------
+    def conv1x1(name, t):
+        return A.linear(t, P[name + ".weight"].flatten(1), P.get(name + ".bias"), dt)
+
+    def convT(name, t, k):                                       # ConvTranspose2d(kernel = stride = k): a GEMM + depth-to-space
+        w = P[name + ".weight"]                                  # [Cin, Cout, k, k]
+        Cout = w.shape[1]
+        y = A.linear(t, w.permute(2, 3, 1, 0).reshape(k * k * Cout, w.shape[0]), P[name + ".bias"].repeat(k * k), dt)
+        n_, h_, w_ = t.shape[:3]
+        return y.view(n_, h_, w_, k, k, Cout).permute(0, 1, 3, 2, 4, 5).reshape(n_, h_ * k, w_ * k, Cout)
+
+    def conv_torch(name, t, **kw):                               # NHWC in/out around torch's conv (stride-2 3x3 and the 7x7 stem)
+        y = F.conv2d(t.permute(0, 3, 1, 2).float(), P[name + ".weight"], P.get(name + ".bias"), **kw)
+        return y.permute(0, 2, 3, 1).to(dt).contiguous()
+
+    def up2(t):
+        y = F.interpolate(t.permute(0, 3, 1, 2).float(), scale_factor=2, mode="bilinear", align_corners=True)
+        return y.permute(0, 2, 3, 1).to(dt).contiguous()
+
+    def rcu(name, t):
+        y = A.conv3x3(t, P[name + ".conv1.weight"], P[name + ".conv1.bias"], relu_in=True)
+        y = A.conv3x3(y, P[name + ".conv2.weight"], P[name + ".conv2.bias"], relu_in=True)
+        return y + t
+
+    def fusion(name, t, skip=None):
+        if skip is not None:
+            t = t + rcu(name + ".resConfUnit1", skip)
+        return conv1x1(name + ".out_conv", up2(rcu(name + ".resConfUnit2", t)))
+
+    def trunk(pre):
+        L = cfg.dec_depth
+        hooks = [0, L * 2 // 4, L * 3 // 4, L]
+        maps = [inter[h].to(dt).reshape(BT, gh, gw, -1) for h in hooks]
+        a = pre + ".act_postprocess"
+        l0 = convT(a + ".0.1", conv1x1(a + ".0.0", maps[0]), 4)
+        l1 = convT(a + ".1.1", conv1x1(a + ".1.0", maps[1]), 2)
+        l2 = conv1x1(a + ".2.0", maps[2])
+        l3 = conv_torch(a + ".3.1", conv1x1(a + ".3.0", maps[3]), stride=2, padding=1)
+        s = pre + ".scratch"                      # (layer{j}_rn and layer_rn.{j-1} are one parameter under two state_dict keys)
+        l0, l1, l2, l3 = [A.conv3x3(l.contiguous(), P[f"{s}.layer{j + 1}_rn.weight"], None) for j, l in enumerate((l0, l1, l2, l3))]
+        p4 = fusion(s + ".refinenet4", l3)[:, :l2.shape[1], :l2.shape[2]]
+        p3 = fusion(s + ".refinenet3", p4, l2)
+        p2 = fusion(s + ".refinenet2", p3, l1)
+        return fusion(s + ".refinenet1", p2, l0)
+
+    pre = "downstream_head1.dpt"
+    t = trunk(pre)
+    t = A.conv3x3(t, P[pre + ".head.0.weight"], P[pre + ".head.0.bias"])
+    t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"])
+    xyz = conv1x1(pre + ".head.4", F.relu(t)).float()[..., :3]
+    dist = xyz.norm(dim=-1, keepdim=True)
+    centers = xyz / dist.clip(min=1e-8) * torch.expm1(dist)                                          # 'exp' depth mode, postprocess.py:46-56
+
+    pre = "gaussian_param_head.dpt"
+    t = up2(trunk(pre)) + F.relu(conv_torch(pre + ".input_merger.0", frames.permute(0, 2, 3, 1), padding=3))
+    t = F.relu(A.conv3x3(t, P[pre + ".head.0.weight"], None))
+    params = conv1x1(pre + ".head.4", t).float()
+    raw = torch.cat([centers, params], -1).view(B, V, H, Wd, -1)
+
+    # ---------------- Gaussian adapter (common/gaussian_adapter.py:168-212), per pixel, f32 ----------------
+    ga = model.gaussian_adapter
+    op, sc, rot = raw[..., 3:4], raw[..., 4:7], raw[..., 7:11]
+    sh = raw[..., 11:].reshape(*raw.shape[:-1], 3, -1) * ga.sh_mask.to(raw.dtype)
+    op = torch.sigmoid(op)
+    op = 0.5 * (1 - (1 - op) ** 1.0 + op ** 1.0)
+    sc = (0.001 * F.softplus(sc)).clamp_max(0.3)
+    rot = F.normalize(rot, dim=-1)
+    qi, qj, qk, qr = rot.unbind(-1)
+    two_s = 2 / ((rot * rot).sum(-1) + 1e-8)
+    R = torch.stack([1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+                     two_s * (qi * qj + qk * qr), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
+                     two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)], -1)
+    R = R.reshape(*rot.shape[:-1], 3, 3)
+    RS = R * sc[..., None, :]
+    gaussians = dict(means=raw[..., :3], covariances=RS @ RS.transpose(-1, -2), harmonics=sh, opacities=op[..., 0])
+    return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, camera_tokens=cam)
