@@ -9,7 +9,9 @@ scripts do around the encoder/decoder:
   * `export_ply`              — src/model/ply_export.py:31-90 (own binary writer, no plyfile dependency)
   * `export_transforms`       — src/model/model_wrapper.py:390-400 (transforms.json)
   * `load_images`             — demo.py:75-132 (resize short side to 256, centre crop, normalise to [-1, 1])
-The encoder's training step (backward through the transformer) is not built; see DESIGN.md §7.
+  * `configure_optimizer`, `training_step` — ModelWrapper.configure_optimizers / training_step (model_wrapper.py:884-951,
+    184-321): AdamW(lr, wd 0.05, betas 0.9/0.95) with the backbone-lr multiplier, encoder -> rasterizer -> MSE ->
+    backward on the HIP kernels (vicasplat_amd.autograd) -> optional gradient all-reduce -> clip 0.5 -> step.
 """
 from __future__ import annotations
 
@@ -188,3 +190,56 @@ def load_images(folder_or_list, size: int = 256) -> Tensor:
     if not frames:
         raise FileNotFoundError(f"no .jpg/.jpeg/.png images in {folder_or_list!r}")
     return torch.stack(frames, 0)
+
+
+def configure_optimizer(encoder, lr: float = 4e-5, backbone_lr_multiplier: float = 0.25, new_param_keywords=("camera", "mlp_cam", "cam_norm", "modulation"),
+                        weight_decay: float = 0.05, warm_up_steps: int = 0):
+    """AdamW with the reference's two learning-rate groups (model_wrapper.py:884-951): parameters whose name contains one of
+    `new_param_keywords` train at `lr`, the pretrained rest at `lr * backbone_lr_multiplier`; linear warm-up as the reference."""
+    new, old = [], []
+    for name, p in encoder.named_parameters():
+        if p.requires_grad:
+            (new if any(k in name for k in new_param_keywords) else old).append(p)
+    groups = [dict(params=new, lr=lr), dict(params=old, lr=lr * backbone_lr_multiplier)] if new else [dict(params=old, lr=lr)]
+    opt = torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.95))
+    sched = torch.optim.lr_scheduler.LinearLR(opt, 1 / warm_up_steps, 1, total_iters=warm_up_steps) if warm_up_steps > 0 else None
+    return opt, sched
+
+
+def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, compute_dtype: torch.dtype = torch.float16,
+                  loss_scale: float = 1024.0, clip: float = 0.5, mse_weight: float = 1.0, allreduce: bool = False) -> dict:
+    """One optimisation step of the reference's photometric objective (training_step, model_wrapper.py:184-321, with the MSE
+    loss of loss_mse.py; LPIPS / camera losses need external weights / ground-truth poses and are not part of this harness).
+
+    batch: {"context": {"image" [B,V,3,H,W] in [-1,1], "intrinsics" [B,V,3,3]},
+            "target":  {"image" [B,Vt,3,H,W] in [0,1], "extrinsics", "intrinsics", "near", "far"}}
+    The encoder runs its differentiable HIP forward (train_forward.forward_train), the Gaussians are rendered by the HIP
+    rasterizer, and the backward pass runs on the HIP backward kernels.  `loss_scale` keeps 16-bit activation gradients out
+    of the f16 underflow range (gradients are unscaled before clipping).  allreduce=True averages gradients over
+    torch.distributed ranks with vicasplat_amd.dist.bucketed_allreduce_grads (RCCL over xGMI on a node)."""
+    from .model.encoder.train_forward import forward_train
+    ctx, tgt = batch["context"], batch["target"]
+    optimizer.zero_grad(set_to_none=True)
+    out = forward_train(encoder, ctx["image"], ctx["intrinsics"], compute_dtype)
+    g = out["gaussians"]
+    gs = Gaussians(g["means"].flatten(1, 3), g["covariances"].flatten(1, 3), g["harmonics"].flatten(1, 3), g["opacities"].flatten(1))
+    h, w = tgt["image"].shape[-2:]
+    render = decoder.forward(gs, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
+    loss = mse_loss(render.color, tgt["image"], mse_weight)
+    (loss * loss_scale).backward()
+    params = [p for p in encoder.parameters() if p.grad is not None]
+    if allreduce:
+        from . import dist as vdist
+        vdist.bucketed_allreduce_grads(params)
+    inv = 1.0 / loss_scale
+    for p in params:
+        p.grad.mul_(inv)
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in params)
+    gnorm = torch.nn.utils.clip_grad_norm_(params, clip) if finite else torch.tensor(float("nan"))
+    if finite:                                   # a non-finite step is skipped, as torch.amp's GradScaler would
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+    with torch.no_grad():
+        psnr = compute_psnr(tgt["image"].flatten(0, 1), render.color.detach().flatten(0, 1)).mean()
+    return dict(loss=loss.detach(), psnr=psnr, grad_norm=gnorm, skipped=not finite, pred_extrins=out["pred_extrins"].detach())
