@@ -115,13 +115,21 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         n_, h_, w_ = t.shape[:3]
         return y.view(n_, h_, w_, k, k, Cout).permute(0, 1, 3, 2, 4, 5).reshape(n_, h_ * k, w_ * k, Cout)
 
+    def chunked(fn, t, out_elems_per_item):                      # torch's kernels index with int32: keep every call < 2^31 elements
+        step = max(1, (2 ** 31 - 1) // max(1, out_elems_per_item))
+        if t.shape[0] <= step:
+            return fn(t)
+        return torch.cat([fn(t[i:i + step]) for i in range(0, t.shape[0], step)], 0)
+
     def conv_torch(name, t, **kw):                               # NHWC in/out around torch's conv (stride-2 3x3 and the 7x7 stem)
-        y = F.conv2d(t.permute(0, 3, 1, 2).float(), P[name + ".weight"], P.get(name + ".bias"), **kw)
-        return y.permute(0, 2, 3, 1).to(dt).contiguous()
+        w = P[name + ".weight"]
+        f = lambda u: F.conv2d(u.permute(0, 3, 1, 2).to(dt), w.to(dt), None if P.get(name + ".bias") is None else P[name + ".bias"].to(dt),
+                               **kw).permute(0, 2, 3, 1).contiguous()
+        return chunked(f, t, t.shape[1] * t.shape[2] * w.shape[0])
 
     def up2(t):
-        y = F.interpolate(t.permute(0, 3, 1, 2).float(), scale_factor=2, mode="bilinear", align_corners=True)
-        return y.permute(0, 2, 3, 1).to(dt).contiguous()
+        f = lambda u: F.interpolate(u.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+        return chunked(f, t, 4 * t.shape[1] * t.shape[2] * t.shape[3])
 
     def rcu(name, t):
         y = A.conv3x3(t, P[name + ".conv1.weight"], P[name + ".conv1.bias"], relu_in=True)
