@@ -228,7 +228,8 @@ int vs_attention_backward(const void *q, const void *k, const void *v, const voi
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder backward building blocks (training_step, model_wrapper.py:184-321: the reference differentiates the encoder
- * with torch autograd).  Groundwork: parity-tested operators, not yet assembled into a training step.
+ * with torch autograd).  They are assembled into torch.autograd.Functions in vicasplat_amd/autograd.py and drive
+ * vicasplat_amd.callers.training_step.
  *   vs_transpose16        out[c, r] = in[r, c] for r < R (zero for R <= r < Rpad); 16-bit elements.  With it the NT GEMM
  *                         (vs_gemm_bias_act) computes dX = dY W (A = dY, W-operand = W^T) and dW = dY^T X (A = dY^T,
  *                         W-operand = X^T, epilogue 3) of nn.Linear; Rpad pads the reduction dimension to a multiple of 64.

@@ -1,5 +1,5 @@
 // Attention backward (head dim 64) for the three attention shapes of attention.hip: same q | k | v addressing, key-prefix
-// mask and two-segment key gather.  Groundwork for the encoder training step, parity-tested against torch
+// mask and two-segment key gather.  Backward of the encoder's attention in the training step (autograd.AttentionFn), parity-tested against torch
 // autograd.  Flash-style: nothing of size Lq x Lk is stored; the forward saves the log2-domain logsumexp L (vs_attention_lse).
 //
 //   delta_i = sum_d dO_i O_i                                   attn_delta_kernel      (one wave per (row, head))

@@ -1,5 +1,5 @@
 // Building blocks of the ENCODER backward pass (training_step, model_wrapper.py:184-321, where the
-// reference relies on torch autograd).  Not yet wired into a training step -- see DESIGN.md 7 -- but each one is a complete,
+// reference relies on torch autograd).  Wired into torch.autograd.Functions by vicasplat_amd/autograd.py; each one is a complete,
 // parity-tested operator:
 //
 //   vs_transpose16        [R,C] -> [C,Rpad] 16-bit, zero padded: feeds the existing NT GEMM kernels for

@@ -115,7 +115,7 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: t
                        nbatch: int, H: int, Lq: int, Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0,
                        kv_seg: Optional[torch.Tensor] = None, q_kvlen: Optional[torch.Tensor] = None, max_keys: int = 0,
                        scale: float = 0.125):
-    """Backward of `attention` (groundwork for the training step).  Returns dq (16-bit [rows, H*64]) and dk, dv (f32
+    """Backward of `attention` (used by autograd.AttentionFn).  Returns dq (16-bit [rows, H*64]) and dk, dv (f32
     [key rows, H*64], accumulated with atomics from zero)."""
     dev = L.require_device(q, k, v, out, dout, lse, kv_seg, q_kvlen)
     for t in (q, k, v, out, dout):
@@ -243,8 +243,8 @@ def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_ad
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Encoder backward building blocks (groundwork for the training step): parity-tested against torch autograd,
-# not yet assembled into a torch.autograd.Function chain.
+# Encoder backward building blocks: parity-tested against torch autograd (tests/test_ops_gpu.py), assembled into
+# torch.autograd.Functions in vicasplat_amd/autograd.py.
 # ---------------------------------------------------------------------------------------------------------------------
 _DT3 = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 

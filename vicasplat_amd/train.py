@@ -1,10 +1,8 @@
-"""Training-step groundwork: the frame-encoder transformer block differentiated end to end
-on the HIP backward operators of `ops` -- LayerNorm -> packed qkv projection + RoPE -> attention -> projection (+residual)
--> LayerNorm -> fc1 -> GELU -> fc2 (+residual), i.e. croco/blocks.py:114-130 as `VicaNet` runs it
-(backbone_vica.py:455-470).  Parity against torch autograd over the oracle's block: tests/test_train_gpu.py.
-
-What is NOT here yet: the decoder blocks (camera tokens, AdaLN), the DPT heads, the adapter, the optimiser and the
-gradient all-reduce -- so there is no training step; this module only proves the operators compose on the real block.
+"""One frame-encoder transformer block differentiated by hand on the HIP backward operators of `ops` -- LayerNorm -> packed
+qkv projection + RoPE -> attention -> projection (+residual) -> LayerNorm -> fc1 -> GELU -> fc2 (+residual), i.e.
+croco/blocks.py:114-130 as `VicaNet` runs it (backbone_vica.py:455-470) -- with an explicit tape instead of autograd.
+Kept as the operator-level reference composition (13 gradients vs the oracle's autograd to 7e-4 in f16:
+tests/test_train_gpu.py); the training step itself uses `vicasplat_amd.autograd` + `model/encoder/train_forward.py`.
 """
 from __future__ import annotations
 
