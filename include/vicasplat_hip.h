@@ -200,6 +200,9 @@ int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void
                     int32_t relu_out, int32_t dtype, vs_stream_t stream);
 int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg, int32_t H, int32_t W, int32_t C,
                        int32_t relu_add, int32_t dtype, vs_stream_t stream);
+/* Backward of vs_upsample2x_nhwc (without add): din [N,H,W,C] = bilinear-x2^T applied to dout [N,2H,2W,C]; H, W = INPUT size. */
+int vs_upsample2x_backward_nhwc(const void *dout, void *din, int32_t Nimg, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                vs_stream_t stream);
 
 /* 7x7, stride 1, pad 3 convolution of an RGB image (gs head input_merger, heads/dpt_gs_head.py:112-118; replaces the
  * nn.Conv2d(3, C, 7, 1, 3) call) as a window GEMM on MFMA without an im2col buffer.

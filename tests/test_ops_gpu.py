@@ -580,3 +580,17 @@ def test_conv3x3_backward_matches_autograd(dt, N, H, W, Cin, Cout, relu_in):
     gw = wr.grad.permute(0, 2, 3, 1)
     assert (dw - gw).abs().max() <= 3e-3 * gw.abs().max() + 1e-3
     assert (db - br.grad).abs().max() <= 1e-3 * br.grad.abs().max() + 1e-2
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_upsample2x_backward_matches_autograd(dt):
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(4)
+    for (N, H, W, C) in [(2, 8, 8, 64), (1, 5, 7, 16), (1, 1, 3, 8), (2, 64, 64, 256)]:
+        dy = torch.randn(N, 2 * H, 2 * W, C, device=d).to(dt)
+        x = torch.zeros(N, C, H, W, device=d, requires_grad=True)
+        (F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) * dy.float().permute(0, 3, 1, 2)).sum().backward()
+        got = ops.upsample2x_backward_nhwc(dy).permute(0, 3, 1, 2).float()
+        tol = 2e-3 if dt == torch.float16 else 1.6e-2
+        assert (got - x.grad).abs().max() <= tol * x.grad.abs().max()

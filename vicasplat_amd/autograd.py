@@ -149,3 +149,19 @@ class Conv3x3Fn(torch.autograd.Function):
 
 def conv3x3(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
     return Conv3x3Fn.apply(x_nhwc, w, b, relu_in)
+
+
+class Upsample2xFn(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC 16-bit; backward = its transpose (gather kernel)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_nhwc(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2x_backward_nhwc(dy.contiguous())
+
+
+def upsample2x(x_nhwc: torch.Tensor) -> torch.Tensor:
+    return Upsample2xFn.apply(x_nhwc)

@@ -321,6 +321,51 @@ upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *_
     *reinterpret_cast<uint4 *>(out + o) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+// ---- backward of the bilinear x2 (align_corners=True): gather form, one thread per (input pixel, 8 channels).  Input row y
+// receives from the output rows whose two source rows include y: sy = yo * (H-1)/(2H-1) in [y-1, y+1), i.e. yo within
+// [2y-3, 2y+3]; the weight of an output row for y is (y0 == y)(1 - ly) + (y1 == y) ly, which is what the forward used. ----
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+upsample2x_backward_kernel(const unsigned short *__restrict__ dout, unsigned short *__restrict__ din, int Nimg, int H, int W, int C) {
+    const int Ho = 2 * H, Wo = 2 * W, c8 = C >> 3;
+    const long long total = (long long)Nimg * H * W * c8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cc = (int)(idx % c8);
+    long long p = idx / c8;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int yo = max(0, 2 * y - 3); yo <= min(Ho - 1, 2 * y + 3); ++yo) {
+        const float sy = (float)yo * ry;
+        const int y0 = min((int)sy, H - 1), y1 = min(y0 + 1, H - 1);
+        const float ly = sy - (float)y0;
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int xo = max(0, 2 * x - 3); xo <= min(Wo - 1, 2 * x + 3); ++xo) {
+            const float sx = (float)xo * rx;
+            const int x0 = min((int)sx, W - 1), x1 = min(x0 + 1, W - 1);
+            const float lx = sx - (float)x0;
+            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            if (wx == 0.f) continue;
+            const float wgt = wy * wx;
+            const uint4 v = *reinterpret_cast<const uint4 *>(dout + ((((size_t)n * Ho + yo) * Wo + xo) * C + cc * 8));
+            const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[2 * k] += wgt * from16<BF16>((unsigned short)(vv[k] & 0xffffu));
+                acc[2 * k + 1] += wgt * from16<BF16>((unsigned short)(vv[k] >> 16));
+            }
+        }
+    }
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (unsigned)to16<BF16>(acc[2 * k]) | ((unsigned)to16<BF16>(acc[2 * k + 1]) << 16);
+    *reinterpret_cast<uint4 *>(din + ((((size_t)n * H + y) * W + x) * C + cc * 8)) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 }  // namespace
 
 extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg,
@@ -380,6 +425,21 @@ extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, in
     dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);
     if (dtype == 2) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C, relu_add);
     else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C, relu_add);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_upsample2x_backward_nhwc(const void *dout, void *din, int32_t Nimg, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                           vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(dout && din, "vs_upsample2x_backward_nhwc: null pointer");
+    VS_CHECK(C % 8 == 0, "vs_upsample2x_backward_nhwc: C=%d must be a multiple of 8", C);
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_upsample2x_backward_nhwc: dtype must be 1 (f16) or 2 (bf16)");
+    const long long total = (long long)Nimg * H * W * (C / 8);
+    if (total <= 0) return 0;
+    dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(upsample2x_backward_kernel<true>, grid, block, 0, stream, (const unsigned short *)dout, (unsigned short *)din, Nimg, H, W, C);
+    else hipLaunchKernelGGL(upsample2x_backward_kernel<false>, grid, block, 0, stream, (const unsigned short *)dout, (unsigned short *)din, Nimg, H, W, C);
     VS_HIP(hipGetLastError());
     return 0;
 }

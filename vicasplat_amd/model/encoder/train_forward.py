@@ -2,7 +2,8 @@
 Functions of `vicasplat_amd.autograd`: every nn.Linear / 1x1 conv / ConvTranspose(k=s) (MFMA GEMM), LayerNorm + AdaLN
 modulation, RoPE, attention and 3x3 stride-1 convolution runs on the HIP kernels forward AND backward; PyTorch autograd
 differentiates the glue (residual adds, gates, token (de)interleaving, the tiny f32 camera-token MLPs / pose head,
-bilinear x2, the 7x7 stem, the one stride-2 conv and the per-pixel Gaussian adapter -- together < 3 % of the FLOPs).
+the one stride-2 conv and the per-pixel Gaussian adapter -- together < 1 % of the FLOPs; bilinear x2 and the 7x7 stem (as
+im2col rows) are on the HIP kernels too).
 
 Structure and names follow vicasplat.py:158-278 / backbone_vica.py:526-582 (state_dict keys of SURVEY Appendix C).
 First version of the training path: correct and kernel-backed, not yet tuned -- the inference path
@@ -128,8 +129,16 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         return chunked(f, t, t.shape[1] * t.shape[2] * w.shape[0])
 
     def up2(t):
-        f = lambda u: F.interpolate(u.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
-        return chunked(f, t, 4 * t.shape[1] * t.shape[2] * t.shape[3])
+        return A.upsample2x(t)
+
+    def stem7x7(name, fr):                                       # 7x7, pad 3 conv on the RGB frames as im2col rows + the MFMA GEMM
+        w = P[name + ".weight"]                                  # [Cout, 3, 7, 7]
+        n_, _, h_, w_ = fr.shape
+        f = lambda u: F.unfold(u.to(dt), 7, padding=3).transpose(1, 2)          # [n, h*w, 147] in (c, ky, kx) order = weight.flatten(1)
+        cols = chunked(f, fr, h_ * w_ * 147)
+        cols = F.pad(cols, (0, 192 - 147))
+        wk = F.pad(w.flatten(1), (0, 192 - 147))
+        return A.linear(cols, wk, P.get(name + ".bias"), dt).view(n_, h_, w_, w.shape[0])
 
     def rcu(name, t):
         y = A.conv3x3(t, P[name + ".conv1.weight"], P[name + ".conv1.bias"], relu_in=True)
@@ -166,7 +175,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     centers = xyz / dist.clip(min=1e-8) * torch.expm1(dist)                                          # 'exp' depth mode, postprocess.py:46-56
 
     pre = "gaussian_param_head.dpt"
-    t = up2(trunk(pre)) + F.relu(conv_torch(pre + ".input_merger.0", frames.permute(0, 2, 3, 1), padding=3))
+    t = up2(trunk(pre)) + F.relu(stem7x7(pre + ".input_merger.0", frames))
     t = F.relu(A.conv3x3(t, P[pre + ".head.0.weight"], None))
     params = conv1x1(pre + ".head.4", t).float()
     raw = torch.cat([centers, params], -1).view(B, V, H, Wd, -1)

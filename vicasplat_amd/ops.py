@@ -336,9 +336,14 @@ def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_
         dx = torch.empty((M, K), dtype=dy.dtype, device=dev)
         gemm(dyp, wT, None, dx, EPI_STORE16)
     if need_dw:
-        dyT, xT = transpose16(dy, 64), transpose16(x, 64)   # [N, Mpad], [K, Mpad]: reduction over M, zero padded
-        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
-        gemm(dyT, xT, None, dw, EPI_STORE32)
+        # reduction over the M rows: few output tiles, a very long K -> split it over workgroups (f32 atomics into zeros)
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        ks = 1
+        while ks < 16 and tiles * ks * 2 <= 1024 and M // (64 * ks * 2) >= 8:
+            ks *= 2
+        dyT, xT = transpose16(dy, 64 * ks), transpose16(x, 64 * ks)   # [N, Mpad], [K, Mpad], zero padded
+        dw = torch.zeros((N, K), dtype=torch.float32, device=dev)
+        gemm_splitk_accumulate(dyT, xT, dw, ks)
     if need_db:
         db = colsum(dy)
     return dx, dw, db
@@ -406,3 +411,15 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
             dw[:, ty, tx] = tmp
     db = colsum(dy.reshape(-1, Cout))
     return dx, dw, db
+
+
+def upsample2x_backward_nhwc(dout: torch.Tensor) -> torch.Tensor:
+    """Backward of upsample2x_nhwc (no add): dout [N,2H,2W,C] contiguous 16-bit -> din [N,H,W,C]."""
+    dev = L.require_device(dout)
+    assert dout.dim() == 4 and dout.is_contiguous() and dout.dtype in (torch.float16, torch.bfloat16)
+    N, Ho, Wo, Cc = dout.shape
+    din = torch.empty((N, Ho // 2, Wo // 2, Cc), dtype=dout.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_upsample2x_backward_nhwc(L.ptr(dout), L.ptr(din), N, Ho // 2, Wo // 2, Cc, _DT[dout.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_upsample2x_backward_nhwc")
+    return din
