@@ -43,8 +43,12 @@ class LinearFn(torch.autograd.Function):
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype) -> torch.Tensor:
     """nn.Linear in the operand dtype `dt`.  K must be a multiple of 64 for the MFMA kernels; tiny odd shapes (the 9 -> C
     intrinsic embedding) stay on torch in f32."""
-    if x.shape[-1] % 64 != 0:
-        return torch.nn.functional.linear(x.float(), w, b).to(dt)
+    K = x.shape[-1]
+    if K % 64 != 0:
+        if K < 32:
+            return torch.nn.functional.linear(x.float(), w, b).to(dt)
+        pad = (K + 63) // 64 * 64 - K        # e.g. the 96-channel reassemble stage: zero-pad the reduction dimension
+        x, w = torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(w, (0, pad))
     return LinearFn.apply(x, w, b, dt)
 
 

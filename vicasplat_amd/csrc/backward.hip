@@ -310,7 +310,8 @@ extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do
     if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
     if (mod_rows <= 0) mod_rows = M;
     if (mod_ld <= 0) mod_ld = C;
-    dim3 grid(std::min(1024, vs::cdiv(M, 4))), block(256);
+    // few, long-running waves: every wave ends with 2 C f32 atomics (dw, db), so their number sets the atomic traffic
+    dim3 grid(std::min(256, vs::cdiv(M, 4))), block(256);
 #define VS_LNB(DT_) hipLaunchKernelGGL(layernorm_backward_kernel<DT_>, grid, block, 0, stream, dout, (long long)ld_do, x, (long long)ldx, w, b, \
                                       scale, mod_rows, mod_ld, dx, (long long)ld_dx, accumulate_dx, dw, db, dscale, dshift, M, C, eps,    \
                                       grp_in, grp_out, grp_off)

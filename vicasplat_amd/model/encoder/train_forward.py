@@ -195,5 +195,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
                      two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)], -1)
     R = R.reshape(*rot.shape[:-1], 3, 3)
     RS = R * sc[..., None, :]
-    gaussians = dict(means=raw[..., :3], covariances=RS @ RS.transpose(-1, -2), harmonics=sh, opacities=op[..., 0])
+    # cov = RS RS^T written out elementwise: a batched 3x3 matmul over millions of Gaussians lands on a (slow) vendor BLAS path
+    cov = (RS[..., :, None, :] * RS[..., None, :, :]).sum(-1)
+    gaussians = dict(means=raw[..., :3], covariances=cov, harmonics=sh, opacities=op[..., 0])
     return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, camera_tokens=cam)
