@@ -231,12 +231,11 @@ def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, c
     if allreduce:
         from . import dist as vdist
         vdist.bucketed_allreduce_grads(params)
-    inv = 1.0 / loss_scale
-    for p in params:
-        p.grad.mul_(inv)
-    finite = all(bool(torch.isfinite(p.grad).all()) for p in params)
-    gnorm = torch.nn.utils.clip_grad_norm_(params, clip) if finite else torch.tensor(float("nan"))
-    if finite:                                   # a non-finite step is skipped, as torch.amp's GradScaler would
+    grads = [p.grad for p in params]
+    torch._foreach_mul_(grads, 1.0 / loss_scale)              # unscale (one fused launch per dtype group, no per-parameter sync)
+    gnorm = torch.nn.utils.clip_grad_norm_(params, clip)      # a non-finite norm marks an overflowed step ...
+    finite = bool(torch.isfinite(gnorm))
+    if finite:                                                # ... which is skipped, as torch.amp's GradScaler would
         optimizer.step()
         if scheduler is not None:
             scheduler.step()
