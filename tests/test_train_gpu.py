@@ -162,13 +162,13 @@ def test_training_backward_matches_oracle_autograd():
     assert vals[len(vals) // 2] <= 4e-2 and vals[int(len(vals) * 0.9)] <= 8e-2 and vals[-1] <= 0.25, worst
 
 
-def test_training_step_reduces_the_photometric_loss():
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_training_step_reduces_the_photometric_loss(dt):
     """callers.training_step: encoder (HIP fwd+bwd) -> rasterizer (HIP fwd+bwd) -> MSE -> clip -> AdamW.  A few steps on one
     fixed batch must lower the loss; every parameter that the loss reaches gets a finite gradient."""
     from vicasplat_amd import callers
     from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
     import bench
-    dt = torch.float16
     m, _ = _tiny_model(dt)
     d = torch.device("cuda:0")
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
