@@ -249,6 +249,11 @@ int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream);
  * weight gradients.  K % (32 * ksplit) == 0; A, W may start at any 2-byte aligned address (shifted views). */
 int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
                               int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream);
+/* ntaps (<= 9) split-K GEMMs sharing A in one launch: out32[t] [M,N] (t-th block of tap_out_stride floats) += A (W + shifts[t])^T;
+ * shifts is a HOST array of element offsets.  The 3x3 convolution weight gradient (A = dY^T, W = zero-bordered X^T, shift = tap). */
+int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                            int32_t ldo, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps, int32_t ksplit, int32_t dtype,
+                            vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
 int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream);
 int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream);

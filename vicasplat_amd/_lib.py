@@ -104,6 +104,8 @@ def lib() -> C.CDLL:
             L.vs_relu_mask16.argtypes = [vp, vp, i64, vp]
             L.vs_gemm_splitk_accumulate.restype = C.c_int
             L.vs_gemm_splitk_accumulate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_gemm_taps_accumulate.restype = C.c_int
+            L.vs_gemm_taps_accumulate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, vp, i32, i32, i32, vp]
             L.vs_transpose16.restype = C.c_int
             L.vs_transpose16.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
             L.vs_colsum.restype = C.c_int

@@ -29,7 +29,17 @@ namespace {
 template <bool BF16, int EPI, int MI>
 __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g_in) {
     GemmArgs g = g_in;
-    const int ksp = (EPI == 2 && g.ksplit > 1) ? (int)blockIdx.y : 0;  // split-K slice (tail launches of the f32 residual epilogue)
+    int ksp = (EPI == 2 && g.ksplit > 1) ? (int)blockIdx.y : 0;  // split-K slice (tail launches of the f32 residual epilogue)
+    int tap = -1, lin_tile = -1;
+    if (EPI == 2 && g.ntaps > 0) {  // tap-fused weight gradient: blockIdx.x = (k-slice, tap, tile)
+        const int tiles = ((g.M - g.m_lo + 32 * MI - 1) / (32 * MI)) * ((g.N + BN - 1) / BN);
+        ksp = blockIdx.x / (tiles * g.ntaps);
+        const int rem = blockIdx.x - ksp * tiles * g.ntaps;
+        tap = rem / tiles;
+        lin_tile = rem - tap * tiles;
+        g.W = reinterpret_cast<const unsigned short *>(g.W) + g.tap_shift[tap];
+        g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
+    }
     if (ksp > 0) g.bias = nullptr;                                      // the bias belongs to slice 0
     constexpr int BM = 32 * MI;
     constexpr int NS = 3;                       // LDS ring depth
@@ -51,7 +61,9 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
     const int tiles_m = (g.M - g.m_lo + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
-    {
+    if (lin_tile >= 0) {
+        bid = lin_tile;
+    } else {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -246,6 +258,7 @@ template <bool BF16, int MI>
 int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M - g.m_lo, 32 * MI) * vs::cdiv(g.N, BN);
     dim3 grid(nwg, epi == 2 && g.ksplit > 1 ? g.ksplit : 1), block(256);
+    if (epi == 2 && g.ntaps > 0) grid = dim3((unsigned)nwg * g.ntaps * g.ksplit, 1);
     switch (epi) {
         case 0: hipLaunchKernelGGL((gemm_kernel<BF16, 0, MI>), grid, block, 0, stream, g); break;
         case 1: hipLaunchKernelGGL((gemm_kernel<BF16, 1, MI>), grid, block, 0, stream, g); break;
@@ -362,7 +375,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
-    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0;
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
@@ -413,8 +426,34 @@ extern "C" int vs_gemm_splitk_accumulate(const void *A, const void *W, float *ou
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.ntaps = 0; g.tap_out_stride = 0;
     g.ksplit = ksplit > 1 ? ksplit : 2;  // the epilogue uses atomics whenever ksplit > 1; a single slice still accumulates
     if (ksplit == 1) { VS_CHECK(K % 64 == 0, "vs_gemm_splitk_accumulate: K must be a multiple of 64 when ksplit == 1"); }
+    const int rc = dtype == 2 ? launch_mi<true, 4>(g, 2, stream) : launch_mi<false, 4>(g, 2, stream);
+    if (rc) return rc;
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ntaps split-K GEMMs in one launch: out32[t][M,N] += A[M,K] (W + shift[t])[N,K]^T for t < ntaps (<= 9).  The weight gradient of
+// a 3x3 convolution: A = dY^T [Cout, pixels], W = X^T [Cin, pixels] (zero-bordered), shift[t] = the tap's pixel offset.
+extern "C" int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
+                                       int32_t ldw, int32_t ldo, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps,
+                                       int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(A && W && out && shifts, "vs_gemm_taps_accumulate: null pointer");
+    VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit >= 2 && ntaps >= 1 && ntaps <= 9, "vs_gemm_taps_accumulate: bad sizes (ksplit >= 2, 1 <= ntaps <= 9)");
+    VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_taps_accumulate: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_taps_accumulate: dtype must be 1 (f16) or 2 (bf16)");
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+    g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
+    g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.ksplit = ksplit; g.ntaps = ntaps; g.tap_out_stride = tap_out_stride;
+    for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
     const int rc = dtype == 2 ? launch_mi<true, 4>(g, 2, stream) : launch_mi<false, 4>(g, 2, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
@@ -446,7 +485,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
-    g.ksplit = 1;
+    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;

@@ -26,6 +26,12 @@ struct GemmArgs {
     // window-GEMM extras (7x7 RGB stem, gemm_kernel only): every a_sup_in row groups skip a_sup_extra more A rows (image
     // padding rows), and k-step kt reads its 32-wide slice at element offset kt * a_kstride (next image row), not kt * 32
     int a_sup_in, a_sup_extra, a_kstride;
+    // tap-fused weight gradient (gemm_kernel, epilogue 2): ntaps > 0 -> the launch is ntaps GEMMs sharing A; tap t reads the
+    // W operand shifted by tap_shift[t] elements and adds into out + t * tap_out_stride; workgroup order is (k-slice, tap, tile)
+    // so that the taps of one K slice run together and their re-reads of A / X hit the caches instead of HBM
+    int ntaps;
+    long long tap_out_stride;
+    int tap_shift[9];
     int ksplit;  // > 1 (gemm_kernel, epilogue 2 only): blockIdx.y-th of ksplit equal K ranges, summed into out with f32 atomics
     // epilogue 4 (STORE16 + RoPE on the q and k column blocks of a packed qkv projection, head_dim 64): per OUTPUT row
     // pos[2] and kind (0: 2-D pairs (i, i+16) per 32-half with pos[0]/pos[1], 1: 1-D interleaved pairs with pos[0], 2: none)

@@ -391,7 +391,7 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
     xin = torch.relu(x) if relu_in else x
     Hp, Wp = H + 2, W + 2
     P = N * Hp * Wp
-    ksplit = max(1, min(256, P // 4096))
+    ksplit = max(2, min(256, P // 4096))
     unit = 64 * ksplit
     Ppad = (P + unit - 1) // unit * unit
     slack = Wp + 2                                                  # largest |tap shift| + 1
@@ -401,14 +401,18 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
     xT[:, slack:slack + P] = transpose16(xp.view(P, Cin))[:, :P]
     dyT = torch.zeros((Cout, Ppad), dtype=dt, device=dev)
     dyT[:, :P] = transpose16(dyp.view(P, Cout))[:, :P]
-    dw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=dev)
-    tmp = torch.zeros((Cout, Cin), dtype=torch.float32, device=dev)
-    for ty in range(3):
-        for tx in range(3):
-            shift = (ty - 1) * Wp + (tx - 1)
-            tmp.zero_()
-            gemm_splitk_accumulate(dyT, xT[:, slack + shift:slack + shift + Ppad], tmp, ksplit, K=Ppad)
-            dw[:, ty, tx] = tmp
+    # all 9 taps in ONE launch (workgroup order: k-slice, tap, tile): the taps of a K slice run together, so A and the nine
+    # overlapping shifted views of X^T are served from the caches instead of being streamed from HBM nine times
+    import ctypes
+    ksplit = max(2, ksplit)
+    dw9 = torch.zeros((9, Cout, Cin), dtype=torch.float32, device=dev)
+    shifts = (ctypes.c_int32 * 9)(*[(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)])
+    base = xT[:, slack:slack + Ppad]
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_taps_accumulate(L.ptr(dyT), L.ptr(base), L.ptr(dw9), Cout, Cin, Ppad, dyT.stride(0), xT.stride(0), Cin,
+                                             Cout * Cin, shifts, 9, ksplit, _DT[dt], L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_taps_accumulate")
+    dw = dw9.view(3, 3, Cout, Cin).permute(2, 0, 1, 3).contiguous()
     db = colsum(dy.reshape(-1, Cout))
     return dx, dw, db
 
