@@ -582,6 +582,36 @@ def test_conv3x3_backward_matches_autograd(dt, N, H, W, Cin, Cout, relu_in):
     assert (db - br.grad).abs().max() <= 1e-3 * br.grad.abs().max() + 1e-2
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 128, 128), (1, 7, 5, 64, 192), (3, 4, 4, 192, 64)])
+def test_conv3x3_stride2_function_matches_autograd(N, H, W, Cin, Cout):
+    """autograd.Conv3x3Fn(stride=2) (the reassemble conv of dpt_block.py act_postprocess[3]): forward on the HIP conv, backward
+    = the stride-1 backward of the zero-dilated gradient; both against torch's f32 conv on the 16-bit rounded operands."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    dt = torch.float16
+    torch.manual_seed(H * W + Cin)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 2, 1).to(d)
+    x = torch.randn(N, H, W, Cin, device=d).to(dt).requires_grad_()
+    w = conv.weight.detach().to(dt).float().requires_grad_()
+    b = conv.bias.detach().clone().requires_grad_()
+    y = A.conv3x3(x, w, b, stride=2)
+    xr = x.detach().float().permute(0, 3, 1, 2).clone().requires_grad_()
+    wr = w.detach().clone().requires_grad_()
+    br = b.detach().clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, stride=2, padding=1)
+    assert y.shape == (N, (H + 1) // 2, (W + 1) // 2, Cout)
+    assert (y.float() - yr.permute(0, 2, 3, 1)).abs().max() <= 4e-3 * yr.abs().max()
+    dy = (torch.randn_like(yr) * 0.5).to(dt)
+    (y.float() * dy.float().permute(0, 2, 3, 1)).sum().backward()
+    (yr * dy.float()).sum().backward()
+    gx = xr.grad.permute(0, 2, 3, 1)
+    assert (x.grad.float() - gx).abs().max() <= 4e-3 * gx.abs().max()
+    assert (w.grad - wr.grad).abs().max() <= 3e-3 * wr.grad.abs().max() + 1e-3
+    assert (b.grad - br.grad).abs().max() <= 1e-3 * br.grad.abs().max() + 1e-2
+    y2 = A.conv3x3(x.detach(), w.detach(), b.detach(), stride=2)
+    assert torch.equal(y2, y.detach())
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_upsample2x_backward_matches_autograd(dt):
     from vicasplat_amd import ops

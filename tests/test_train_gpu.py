@@ -190,3 +190,32 @@ def test_training_step_reduces_the_photometric_loss(dt):
     assert hist[-1] < hist[0] * 0.995 and float(r["grad_norm"]) > 0, hist
     changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in list(m.named_parameters())[:40])
     assert changed >= 30
+
+
+def test_training_step_with_gradient_allreduce_single_rank():
+    """The DDP leg of the training step (bucketed all-reduce over RCCL, `allreduce=True`) on a world of one: the collective
+    path executes on the GPU and leaves the step unchanged.  (World size 2 is covered on CPU/gloo in test_distributed_cpu.py.)"""
+    import torch.distributed as dist
+    from vicasplat_amd import callers
+    from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
+    import bench
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        dt = torch.float16
+        d = torch.device("cuda:0")
+        dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
+        B, V, Vt, S = 1, 2, 2, 64
+        img, K = er.synthetic_input(B, V, S, 3)
+        tE, tK, tn, tf = bench.target_cameras(B, Vt, d)
+        target = torch.rand(B, Vt, 3, S, S, device=d)
+        batch = dict(context=dict(image=img.to(d), intrinsics=K.to(d)), target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
+        res = []
+        for flag in (False, True):
+            m, _ = _tiny_model(dt)
+            opt, _ = callers.configure_optimizer(m, lr=4e-5)
+            r = callers.training_step(m, dec, batch, opt, compute_dtype=dt, allreduce=flag)
+            res.append((float(r["loss"]), float(r["grad_norm"])))
+        assert abs(res[0][0] - res[1][0]) <= 1e-6 and abs(res[0][1] - res[1][1]) <= 1e-3 * res[0][1], res
+    finally:
+        dist.destroy_process_group()

@@ -130,29 +130,34 @@ class AttentionFn(torch.autograd.Function):
 
 
 class Conv3x3Fn(torch.autograd.Function):
-    """nn.Conv2d(k=3, s=1, p=1) on NHWC 16-bit activations with the ResidualConvUnit's activation-before-conv fused
-    (relu_in); w is the module's [Cout, Cin, 3, 3] f32 parameter.  Backward: ops.conv3x3_backward."""
+    """nn.Conv2d(k=3, s=1|2, p=1) on NHWC 16-bit activations with the ResidualConvUnit's activation-before-conv fused
+    (relu_in); w is the module's [Cout, Cin, 3, 3] f32 parameter.  Backward: ops.conv3x3_backward.  The stride-2 conv is
+    the stride-1 conv sampled at even pixels, so its backward is the stride-1 backward of the zero-dilated gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu_in):
+    def forward(ctx, x, w, b, relu_in, stride):
         dt = x.dtype
         wp = ops.pack_conv3x3_weight(w, dt)
         x = x.contiguous()
-        y = ops.conv3x3_nhwc(x, wp, None if b is None else b.detach().float().contiguous(), relu_in=relu_in)
+        y = ops.conv3x3_nhwc(x, wp, None if b is None else b.detach().float().contiguous(), relu_in=relu_in, stride=stride)
         ctx.save_for_backward(x, wp)
-        ctx.meta = (relu_in, b is not None)
+        ctx.meta = (relu_in, b is not None, stride)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wp = ctx.saved_tensors
-        relu_in, has_b = ctx.meta
+        relu_in, has_b, stride = ctx.meta
+        if stride != 1:
+            full = torch.zeros(x.shape[:3] + (dy.shape[3],), dtype=dy.dtype, device=dy.device)
+            full[:, ::stride, ::stride] = dy
+            dy = full
         dx, dw, db = ops.conv3x3_backward(dy.contiguous(), x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0])
-        return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None
+        return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None, None
 
 
-def conv3x3(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
-    return Conv3x3Fn.apply(x_nhwc, w, b, relu_in)
+def conv3x3(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu_in: bool = False, stride: int = 1) -> torch.Tensor:
+    return Conv3x3Fn.apply(x_nhwc, w, b, relu_in, stride)
 
 
 class Upsample2xFn(torch.autograd.Function):

@@ -1,9 +1,9 @@
 """Differentiable (training) forward of the VicaSplat encoder, written over the module's parameters with the autograd
 Functions of `vicasplat_amd.autograd`: every nn.Linear / 1x1 conv / ConvTranspose(k=s) (MFMA GEMM), LayerNorm + AdaLN
-modulation, RoPE, attention and 3x3 stride-1 convolution runs on the HIP kernels forward AND backward; PyTorch autograd
-differentiates the glue (residual adds, gates, token (de)interleaving, the tiny f32 camera-token MLPs / pose head,
-the one stride-2 conv and the per-pixel Gaussian adapter -- together < 1 % of the FLOPs; bilinear x2 and the 7x7 stem (as
-im2col rows) are on the HIP kernels too).
+modulation, RoPE, attention and 3x3 convolution (stride 1 and the one stride-2 reassemble conv) runs on the HIP kernels
+forward AND backward; PyTorch autograd differentiates the glue (residual adds, gates, token (de)interleaving, the tiny f32
+camera-token MLPs / pose head and the per-pixel Gaussian adapter -- together < 1 % of the FLOPs; bilinear x2 and the 7x7
+stem (as im2col rows) are on the HIP kernels too).  Every kernel on this path is run-to-run deterministic in the forward.
 
 Structure and names follow vicasplat.py:158-278 / backbone_vica.py:526-582 (state_dict keys of SURVEY Appendix C).
 First version of the training path: correct and kernel-backed, not yet tuned -- the inference path
@@ -122,12 +122,6 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
             return fn(t)
         return torch.cat([fn(t[i:i + step]) for i in range(0, t.shape[0], step)], 0)
 
-    def conv_torch(name, t, **kw):                               # NHWC in/out around torch's conv (stride-2 3x3 and the 7x7 stem)
-        w = P[name + ".weight"]
-        f = lambda u: F.conv2d(u.permute(0, 3, 1, 2).to(dt), w.to(dt), None if P.get(name + ".bias") is None else P[name + ".bias"].to(dt),
-                               **kw).permute(0, 2, 3, 1).contiguous()
-        return chunked(f, t, t.shape[1] * t.shape[2] * w.shape[0])
-
     def up2(t):
         return A.upsample2x(t)
 
@@ -158,7 +152,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         l0 = convT(a + ".0.1", conv1x1(a + ".0.0", maps[0]), 4)
         l1 = convT(a + ".1.1", conv1x1(a + ".1.0", maps[1]), 2)
         l2 = conv1x1(a + ".2.0", maps[2])
-        l3 = conv_torch(a + ".3.1", conv1x1(a + ".3.0", maps[3]), stride=2, padding=1)
+        l3 = A.conv3x3(conv1x1(a + ".3.0", maps[3]).contiguous(), P[a + ".3.1.weight"], P.get(a + ".3.1.bias"), stride=2)
         s = pre + ".scratch"                      # (layer{j}_rn and layer_rn.{j-1} are one parameter under two state_dict keys)
         l0, l1, l2, l3 = [A.conv3x3(l.contiguous(), P[f"{s}.layer{j + 1}_rn.weight"], None) for j, l in enumerate((l0, l1, l2, l3))]
         p4 = fusion(s + ".refinenet4", l3)[:, :l2.shape[1], :l2.shape[2]]
