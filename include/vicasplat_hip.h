@@ -246,7 +246,9 @@ int vs_attention_backward(const void *q, const void *k, const void *v, const voi
 /* dx = x > 0 ? dx : 0, in place, n 16-bit elements (f16 or bf16: same sign/zero encoding); backward of a ReLU on x. */
 int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream);
 /* out32[M,N] += A[M,K] W[N,K]^T, K cut into ksplit slices (separate workgroups, f32 atomics): long thin reductions such as
- * weight gradients.  K % (32 * ksplit) == 0; A, W may start at any 2-byte aligned address (shifted views). */
+ * weight gradients.  K % (32 * ksplit) == 0; A, W may start at any 2-byte aligned address (shifted views).  Runs on 256x256 tiles
+ * (the phase-interleaved main loop of the forward GEMMs) when M % 256 == 0, N % 256 == 0 and K % (128 * ksplit) == 0, on 128x128
+ * tiles otherwise. */
 int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
                               int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream);
 /* ntaps (<= 9) split-K GEMMs sharing A in one launch: out32[t] [M,N] (t-th block of tap_out_stride floats) += A (W + shifts[t])^T;
@@ -254,7 +256,27 @@ int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t 
 int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
                             int32_t ldo, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps, int32_t ksplit, int32_t dtype,
                             vs_stream_t stream);
+/* General form of the two above: ntaps = 0 (plain) or 1..9 (taps), plus an optional workspace of >= slices * max(ntaps, 1) * M * N
+ * floats (slices = ksplit, or 2 when ksplit == 1 on the 128x128 tiling; 16-byte aligned).  With it the K slices store partial tiles
+ * and a second kernel sums them into out -- f32 atomics sustain ~0.3 TB/s on MI355X, plain stores ten times that -- without it
+ * they meet through atomics as above.  out is added to in both modes.
+ * a_slice_stride / w_slice_stride (elements): 0 = K slice s is columns [s K/ksplit, (s+1) K/ksplit) of A / W; > 0 = slice-blocked
+ * operands [slice][channel][K/ksplit (+ halo)] as vs_transpose16_ex writes them: slice s is columns [0, K/ksplit) of the matrix at
+ * A + s * a_slice_stride.  Blocking keeps the rows a workgroup walks KBs apart instead of the whole reduction length (MBs). */
+int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
+                  int64_t a_slice_stride, int64_t w_slice_stride, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps,
+                  int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
+/* vs_transpose16 with extras: colsum (nullable, f32 [C], overwritten) = column sums of the input, i.e. the bias gradient rides on
+ * the transpose of dY that the weight-gradient GEMM needs anyway (dtype 1 f16 / 2 bf16); border_h, border_w > 0: the R input rows
+ * are the pixels of zero-bordered (border_h + 2) x (border_w + 2) maps whose interior is read from the unpadded NHWC tensor `in`
+ * (the operands of the conv weight gradient without a padded copy); relu != 0 writes negative inputs as zero.
+ * nslices > 1: slice-blocked output [slice][C][SL + 2 halo], SL = Rpad / nslices: slice z = transposed rows [z SL - halo, (z+1) SL + halo)
+ * (zeros outside [0, R)) at out + z * slice_stride, row stride ld_out -- the operand layout of vs_gemm_wgrad; the halo columns are
+ * what the shifted tap views of a 3x3 weight gradient read beyond their own slice (colsum needs halo == 0). */
+int vs_transpose16_ex(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, float *colsum,
+                      int32_t dtype, int32_t border_h, int32_t border_w, int32_t relu, int32_t nslices, int32_t halo,
+                      int64_t slice_stride, vs_stream_t stream);
 int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream);
 int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream);
 int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,

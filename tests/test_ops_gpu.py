@@ -441,6 +441,99 @@ def test_linear_backward_matches_autograd(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_transpose16_border_relu_colsum(dt):
+    """vs_transpose16_ex: transposed zero-bordered pixel grid straight from NHWC, input ReLU and column sums in the same pass."""
+    from vicasplat_amd import ops
+    d = _dev()
+    torch.manual_seed(11)
+    for (N, H, W, C) in [(2, 5, 7, 96), (1, 16, 16, 64), (3, 1, 1, 8)]:
+        x = torch.randn(N, H, W, C, device=d).to(dt)
+        for relu in (False, True):
+            cs = torch.full((C,), 7.0, device=d)
+            P = N * (H + 2) * (W + 2)
+            buf = torch.full((C, 8 + (P + 127) // 128 * 128 + 8), 3.0, dtype=dt, device=d)
+            t = ops.transpose16(x.view(-1, C), 128, colsum_out=cs, out=buf[:, 8:-8], border_hw=(H, W), relu=relu)
+            xr = torch.relu(x) if relu else x
+            ref = F.pad(xr.permute(0, 3, 1, 2), (1, 1, 1, 1)).permute(1, 0, 2, 3).reshape(C, P)
+            assert torch.equal(t[:, :P], ref) and float(t[:, P:].abs().sum()) == 0
+            assert float((buf[:, :8] - 3).abs().sum()) == 0 and float((buf[:, -8:] - 3).abs().sum()) == 0   # outside the view: untouched
+            want = xr.float().sum((0, 1, 2))
+            assert (cs - want).abs().max() <= 1e-3 * want.abs().max() + 1e-3
+    # slice-blocked output with halos: slice z = padded pixels [z*SL - halo, (z+1)*SL + halo), zeros outside [0, P)
+    N, H, W, C = 2, 6, 5, 72
+    x = torch.randn(N, H, W, C, device=d).to(dt)
+    P = N * (H + 2) * (W + 2)
+    for (ks, halo) in [(4, 8), (7, 0), (2, 16)]:
+        cs = torch.zeros(C, device=d) if halo == 0 else None
+        t = ops.transpose16(x.view(-1, C), 64 * ks, border_hw=(H, W), slices=ks, halo=halo, colsum_out=cs)
+        Ppad = (P + 64 * ks - 1) // (64 * ks) * (64 * ks)
+        SL = Ppad // ks
+        assert t.shape == (ks, C, SL + 2 * halo)
+        ref = F.pad(F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1)).permute(1, 0, 2, 3).reshape(C, P), (halo, Ppad - P + halo))
+        for z in range(ks):
+            assert torch.equal(t[z], ref[:, z * SL:(z + 1) * SL + 2 * halo])
+        if cs is not None:
+            want = x.float().sum((0, 1, 2))
+            assert (cs - want).abs().max() <= 1e-3 * want.abs().max() + 1e-3
+    from vicasplat_amd import _lib as L
+    x = torch.zeros(10, 8, dtype=dt, device=d); o = torch.zeros(8, 64, dtype=dt, device=d)
+    with pytest.raises(RuntimeError, match="whole number"):
+        L.check(L.lib().vs_transpose16_ex(L.ptr(x), 8, L.ptr(o), 64, 10, 8, 64, None, 1, 2, 2, 0, 1, 0, 0, L.stream_ptr(d)), "vs_transpose16_ex")
+    with pytest.raises(RuntimeError, match="halo"):
+        L.check(L.lib().vs_transpose16_ex(L.ptr(x), 8, L.ptr(o), 64, 10, 8, 64, None, 1, 0, 0, 0, 1, 8, 0, L.stream_ptr(d)), "vs_transpose16_ex")
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,ks", [(256, 256, 128 * 3, 3), (512, 256, 128 * 28 * 2, 28), (256, 768, 128, 1), (1024, 256, 1280, 5),
+                                      (256, 256, 64 * 6, 6), (384, 256, 1024, 4)])
+@pytest.mark.parametrize("mode", ["workspace", "atomics", "legacy"])
+def test_gemm_splitk_accumulate_matches_matmul(dt, M, N, K, ks, mode):
+    """Weight-gradient GEMM on both tilings (256x256 when the output is whole 256-tiles and K % (128 ks) == 0, else 128x128) and
+    both ways of joining the K slices (partial tiles + reduce kernel / f32 atomics): out += A W^T onto a non-zero start."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) / math.sqrt(K)).to(dt).to(d)
+    w = torch.randn(N, K, generator=g).to(dt).to(d)
+    out = torch.randn(M, N, generator=g).to(d)
+    want = out.double() + a.double() @ w.double().t()
+    if mode == "legacy":
+        ops.gemm_splitk_accumulate(a, w, out, ks)
+    else:
+        ops.gemm_wgrad(a, w, out, ks, workspace=mode == "workspace")
+    assert (out.double() - want).abs().max() <= 2e-5 * want.abs().max() + 2e-5
+
+
+def test_gemm_wgrad_taps_and_errors():
+    """Tap-fused form: out[t] += A (W shifted by shifts[t])^T, incl. odd (2-byte aligned) shifts, with and without workspace."""
+    from vicasplat_amd import ops, _lib as L
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (M, N, K, ks) in [(256, 256, 1024, 4), (128, 192, 512, 2), (256, 512, 256, 1)]:
+        a = (torch.randn(M, K, generator=g) / 16).half().to(d)
+        wfull = torch.randn(N, K + 64, generator=g).half().to(d)
+        shifts = [-19, -1, 0, 1, 18]
+        for wsflag in (True, False):
+            out = torch.randn(len(shifts), M, N, generator=g).to(d)
+            want = torch.stack([out[t].double() + a.double() @ wfull[:, 32 + sh:32 + sh + K].double().t() for t, sh in enumerate(shifts)])
+            ops.gemm_wgrad(a, wfull[:, 32:32 + K], out, ks, shifts=shifts, workspace=wsflag)
+            assert (out.double() - want).abs().max() <= 2e-5 * want.abs().max() + 2e-5
+            if ks > 1:   # the same product from slice-blocked operands (halo 32 around every W slice)
+                SL = K // ks
+                a3 = a.view(M, ks, SL).permute(1, 0, 2).contiguous()
+                w3 = torch.stack([wfull[:, z * SL:(z + 1) * SL + 64] for z in range(ks)]).contiguous()
+                out2 = torch.zeros_like(out)
+                ops.gemm_wgrad(a3, w3[:, :, 32:32 + SL], out2, ks, shifts=shifts, workspace=wsflag)
+                want2 = torch.stack([a.double() @ wfull[:, 32 + sh:32 + sh + K].double().t() for sh in shifts])
+                assert (out2.double() - want2).abs().max() <= 2e-5 * want2.abs().max() + 2e-5
+    a = torch.zeros(256, 256, dtype=torch.float16, device=d); o = torch.zeros(256, 256, device=d); ws = torch.zeros(16, device=d)
+    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(a), L.ptr(o), 256, 256, 256, 256, 256, 256, 0, 0, 0, None, 0, 2, 1, L.ptr(ws), 64, L.stream_ptr(d))
+    assert rc != 0 and b"workspace" in L.lib().vs_last_error()
+    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(a), L.ptr(o), 256, 256, 256, 256, 256, 256, 0, 0, 0, None, 3, 2, 1, None, 0, L.stream_ptr(d))
+    assert rc != 0 and b"shifts" in L.lib().vs_last_error()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gelu_backward_matches_autograd(dt):
     from vicasplat_amd import ops
     d = _dev()

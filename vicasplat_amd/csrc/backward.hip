@@ -32,21 +32,99 @@ __device__ __forceinline__ unsigned short st16(float v) {
     }
 }
 
-// 64 x 64 tile through LDS (65-half rows: conflict-free both ways); rows >= R of the output padding are written as zeros
+// 64 x 64 tile through LDS (65-half rows: conflict-free both ways); rows >= R of the output padding are written as zeros.
+// CS = 1 / 2 (f16 / bf16): the column sums of the input (the bias gradient of the layer whose dY is being transposed for its
+// weight-gradient GEMM) are accumulated on the way through -- one f32 atomic per column and block, no second pass over dY.
+// bH > 0: the R input rows are the pixels of a ZERO-BORDERED NHWC map [n, bH+2, bW+2] whose interior is read from the
+// unpadded [n, bH, bW, C] tensor `in` (border rows read as zero): the conv weight gradient's operands are produced
+// straight from the activations, without a padded copy.  relu: negative inputs are written as zero (activation-before-conv).
+// Slice-blocked output (gridDim.z slices of SL rows + `halo` rows of the neighbouring slices on either side): slice z holds
+// the transposed rows [z SL - halo, (z+1) SL + halo) at out + z * slice_stride, i.e. out is [slice][C][SL + 2 halo] -- the
+// operand layout of vs_gemm_wgrad (one K slice per block; the halo is what the shifted tap views of a 3x3 weight gradient read
+// beyond their slice).
+template <int CS>
 __global__ void __launch_bounds__(256)
 transpose16_kernel(const unsigned short *__restrict__ in, long long ld_in, unsigned short *__restrict__ out, long long ld_out,
-                   int R, int C, int Rpad) {
-    __shared__ unsigned short tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? in[(long long)r * ld_in + c] : (unsigned short)0;
+                   int R, int C, int SL, int halo, long long slice_stride, float *__restrict__ colsum, int bH, int bW, int relu) {
+    // 64 x 64 tile; every thread moves 4 consecutive elements (8 bytes) per access in both directions: rows of 68 halfs keep the
+    // 8-byte LDS accesses aligned.  Pass p: thread (q = t & 15, rr = t >> 4) reads input row p*16 + rr, columns 4q..4q+3, and
+    // later writes output row (= input column) p*16 + rr, slice-local rows 4q..4q+3.
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][68];
+    [[maybe_unused]] __shared__ float part[16][64];
+    const int l0 = blockIdx.y * 64, c0 = blockIdx.x * 64;       // l0: first slice-local row of this block
+    const int r0 = (int)blockIdx.z * SL - halo + l0;            // ... and the input row it corresponds to (may be < 0)
+    const int Rpad = SL + 2 * halo;                              // slice-local rows to write
+    out += (long long)blockIdx.z * slice_stride;
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const bool vec_in = (ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0 && c0 + 64 <= C;
+    [[maybe_unused]] float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = p * 16 + rr, r = r0 + i, c = c0 + 4 * q;
+        long long src = r;
+        bool ok = r >= 0 && r < R;
+        if (bH > 0 && ok) {
+            const int Wp = bW + 2, Hp = bH + 2;
+            const int n = r / (Hp * Wp), rem = r - n * (Hp * Wp);
+            const int y = rem / Wp - 1, x = rem - (rem / Wp) * Wp - 1;
+            ok = y >= 0 && y < bH && x >= 0 && x < bW;
+            src = ((long long)n * bH + y) * bW + x;
+        }
+        unsigned short v[4] = {0, 0, 0, 0};
+        if (ok) {
+            const unsigned short *ip = in + src * ld_in + c;
+            if (vec_in) {
+                const uint2 u = *reinterpret_cast<const uint2 *>(ip);
+                v[0] = (unsigned short)(u.x & 0xffffu); v[1] = (unsigned short)(u.x >> 16);
+                v[2] = (unsigned short)(u.y & 0xffffu); v[3] = (unsigned short)(u.y >> 16);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) v[e] = ip[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (relu && (v[e] & 0x8000u)) v[e] = 0;
+            if constexpr (CS != 0) s[e] += ld16<CS == 2>(v[e]);
+        }
+        uint2 w;
+        w.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+        w.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+        *reinterpret_cast<uint2 *>(&tile[i][4 * q]) = w;
+    }
+    if constexpr (CS != 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[rr][4 * q + e] = s[e];
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < C && r < Rpad) out[(long long)c * ld_out + r] = tile[tx][i];
+    if constexpr (CS != 0) {
+        if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C && r0 < R && r0 + 64 > 0) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += part[k][threadIdx.x];
+            unsafeAtomicAdd(colsum + c0 + threadIdx.x, a);
+        }
+    }
+    const bool vec_out = (ld_out & 3) == 0 && (slice_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int cl = p * 16 + rr, c = c0 + cl, l = l0 + 4 * q;
+        if (c >= C || l >= Rpad) continue;
+        unsigned short v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[4 * q + e][cl];
+        unsigned short *op = out + (long long)c * ld_out + l;
+        if (vec_out && l + 3 < Rpad) {
+            uint2 w;
+            w.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+            w.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+            *reinterpret_cast<uint2 *>(op) = w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (l + e < Rpad) op[e] = v[e];
+        }
     }
 }
 
@@ -254,17 +332,48 @@ layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const 
 
 }  // namespace
 
-extern "C" int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad,
-                              vs_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK(in && out, "vs_transpose16: null pointer");
-    VS_CHECK(R >= 0 && C >= 0 && Rpad >= R && ld_in >= C && ld_out >= Rpad, "vs_transpose16: bad sizes R=%d C=%d Rpad=%d", R, C, Rpad);
-    if (Rpad == 0 || C == 0) return 0;
-    dim3 grid(vs::cdiv(C, 64), vs::cdiv(Rpad, 64)), block(256);
-    hipLaunchKernelGGL(transpose16_kernel, grid, block, 0, stream, (const unsigned short *)in, (long long)ld_in, (unsigned short *)out,
-                       (long long)ld_out, R, C, Rpad);
+namespace {
+int transpose_entry(const char *fn, const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad,
+                    float *colsum, int32_t dtype, int32_t bH, int32_t bW, int32_t relu, int32_t nslices, int32_t halo,
+                    int64_t slice_stride, hipStream_t stream) {
+    VS_CHECK(in && out, "%s: null pointer", fn);
+    VS_CHECK(R >= 0 && C >= 0 && Rpad >= R && ld_in >= C, "%s: bad sizes R=%d C=%d Rpad=%d", fn, R, C, Rpad);
+    VS_CHECK((bH == 0 && bW == 0) || (bH > 0 && bW > 0 && R % ((bH + 2) * (bW + 2)) == 0),
+             "%s: with a border, R=%d must be a whole number of (H+2) x (W+2) maps (H=%d W=%d)", fn, R, bH, bW);
+    if (nslices < 1) nslices = 1;
+    VS_CHECK(nslices <= 65535 && Rpad % nslices == 0 && halo >= 0, "%s: Rpad=%d must be a multiple of nslices=%d (<= 65535), halo >= 0", fn, Rpad, nslices);
+    VS_CHECK(nslices > 1 || halo == 0, "%s: a halo needs nslices > 1", fn);
+    const int SL = Rpad / nslices;
+    VS_CHECK(ld_out >= SL + 2 * halo, "%s: ld_out=%lld < slice length + 2 halo = %d", fn, (long long)ld_out, SL + 2 * halo);
+    VS_CHECK(!(colsum && halo), "%s: column sums need halo == 0 (rows would be counted twice)", fn);
+    if (C == 0) return 0;
+    if (colsum) {
+        VS_CHECK(dtype == 1 || dtype == 2, "%s: dtype must be 1 (f16) or 2 (bf16)", fn);
+        VS_HIP(hipMemsetAsync(colsum, 0, (size_t)C * sizeof(float), stream));
+    }
+    if (Rpad == 0) return 0;
+    dim3 grid(vs::cdiv(C, 64), vs::cdiv(SL + 2 * halo, 64), nslices), block(256);
+    VS_CHECK(grid.y <= 65535u, "%s: too many rows per slice", fn);
+    const unsigned short *ip = (const unsigned short *)in;
+    unsigned short *op = (unsigned short *)out;
+    if (!colsum) hipLaunchKernelGGL(transpose16_kernel<0>, grid, block, 0, stream, ip, (long long)ld_in, op, (long long)ld_out, R, C, SL, halo, (long long)slice_stride, colsum, bH, bW, relu);
+    else if (dtype == 2) hipLaunchKernelGGL(transpose16_kernel<2>, grid, block, 0, stream, ip, (long long)ld_in, op, (long long)ld_out, R, C, SL, halo, (long long)slice_stride, colsum, bH, bW, relu);
+    else hipLaunchKernelGGL(transpose16_kernel<1>, grid, block, 0, stream, ip, (long long)ld_in, op, (long long)ld_out, R, C, SL, halo, (long long)slice_stride, colsum, bH, bW, relu);
     VS_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad,
+                              vs_stream_t stream_) {
+    return transpose_entry("vs_transpose16", in, ld_in, out, ld_out, R, C, Rpad, nullptr, 0, 0, 0, 0, 1, 0, 0, (hipStream_t)stream_);
+}
+
+extern "C" int vs_transpose16_ex(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad,
+                                 float *colsum, int32_t dtype, int32_t border_h, int32_t border_w, int32_t relu, int32_t nslices,
+                                 int32_t halo, int64_t slice_stride, vs_stream_t stream_) {
+    return transpose_entry("vs_transpose16_ex", in, ld_in, out, ld_out, R, C, Rpad, colsum, dtype, border_h, border_w, relu, nslices, halo,
+                           slice_stride, (hipStream_t)stream_);
 }
 
 extern "C" int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream_) {
@@ -274,7 +383,7 @@ extern "C" int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32
     VS_CHECK(M >= 0 && N > 0 && ld >= N, "vs_colsum: bad sizes");
     VS_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream));
     if (M == 0) return 0;
-    dim3 grid(vs::cdiv(N, 64), std::min(256, vs::cdiv(M, 64))), block(256);
+    dim3 grid(vs::cdiv(N, 64), std::min(std::max(256, 2048 / vs::cdiv(N, 64)), vs::cdiv(M, 64))), block(256);
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, grid, block, 0, stream, x, (long long)ld, out, M, N);
     else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<1>, grid, block, 0, stream, x, (long long)ld, out, M, N);
     else hipLaunchKernelGGL(colsum_kernel<2>, grid, block, 0, stream, x, (long long)ld, out, M, N);

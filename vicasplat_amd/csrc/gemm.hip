@@ -37,10 +37,18 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         const int rem = blockIdx.x - ksp * tiles * g.ntaps;
         tap = rem / tiles;
         lin_tile = rem - tap * tiles;
-        g.W = reinterpret_cast<const unsigned short *>(g.W) + g.tap_shift[tap];
+        g.W = reinterpret_cast<const unsigned short *>(g.W) + g_in.tap_shift[tap];  // (indexing the kernarg, not the copy: a
+                                                                                     //  dynamically indexed local struct lives in scratch)
         g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
     }
     if (ksp > 0) g.bias = nullptr;                                      // the bias belongs to slice 0
+    const int ksplit_n = g.ksplit;
+    if (EPI == 2 && g.partials) {  // weight-gradient slice: store the partial tile to the workspace (see GemmArgs::partials)
+        const int nt = g.ntaps > 0 ? g.ntaps : 1;
+        g.out = g.partials + ((long long)(ksp * nt + (tap > 0 ? tap : 0)) * g.M) * g.N;
+        g.ldo = g.N;
+        g.ksplit = -1;
+    }
     constexpr int BM = 32 * MI;
     constexpr int NS = 3;                       // LDS ring depth
     constexpr int GL = MI / 2 + 2;              // global_load_lds per wave per stage (A: BM/16/4, W: 128/16/4)
@@ -97,12 +105,12 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fg = lane >> 4;
-    const int nk = (EPI == 2 && g.ksplit > 1) ? g.K / 32 / g.ksplit : g.K / 32;
+    const int nk = (EPI == 2 && ksplit_n > 1) ? g.K / 32 / ksplit_n : g.K / 32;
     if (ksp > 0) {
 #pragma unroll
-        for (int i = 0; i < MI / 2; ++i) pa[i] += (long long)ksp * nk * g.a_kstride;
+        for (int i = 0; i < MI / 2; ++i) pa[i] += ksp * (g.a_slice_stride ? g.a_slice_stride : (long long)nk * g.a_kstride);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pw[i] += ksp * nk * 32;
+        for (int i = 0; i < 2; ++i) pw[i] += ksp * (g.w_slice_stride ? g.w_slice_stride : (long long)nk * 32);
     }
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wid * (MI / 2)) * 1024u);
@@ -348,6 +356,75 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     return launch_tail<BF16>(g, rem, epi, stream);
 }
 
+// out[t][m, n] += sum_s partials[((s * ntaps + t) * M + m) * N + n]: second stage of a weight-gradient GEMM with a workspace.
+template <int VEC>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out, int M, int N, int ntaps,
+                                                            int ks, long long ldo, long long tap_out_stride) {
+    const int Nv = N / VEC;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per_tap = (long long)M * Nv;
+    if (idx >= per_tap * ntaps) return;
+    const int t = (int)(idx / per_tap);
+    const long long r = idx - t * per_tap;
+    const int m = (int)(r / Nv), n = (int)(r - (long long)m * Nv) * VEC;
+    const long long slice = (long long)ntaps * M * N;
+    const float *p = ws + ((long long)t * M + m) * N + n;
+    float *o = out + t * tap_out_stride + (long long)m * ldo + n;
+    if constexpr (VEC == 4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int s = 0; s < ks; ++s) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + s * slice);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float4 c = *reinterpret_cast<float4 *>(o);
+        c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+        *reinterpret_cast<float4 *>(o) = c;
+    } else {
+        float a = 0.f;
+        for (int s = 0; s < ks; ++s) a += p[s * slice];
+        *o += a;
+    }
+}
+
+// Weight-gradient launches (split-K, optionally tap-fused): 256x256 tiles on the phase-interleaved main loop when the
+// output is made of whole 256-tiles and every K slice is an even number (>= 2) of 64-wide K tiles; 128x128 tiles otherwise.
+// With a workspace of ksplit * ntaps * M * N floats the slices store partial tiles and a second kernel sums them; without
+// one they meet through f32 atomics.
+template <bool BF16>
+int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, hipStream_t stream) {
+    static const int no256 = [] { const char *e = getenv("VS_WGRAD_NO256"); return e ? atoi(e) : 0; }();
+    const int ntaps = g.ntaps > 0 ? g.ntaps : 1;
+    const bool big = !no256 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % (128 * ksplit) == 0;
+    const int slices = big ? ksplit : (ksplit > 1 ? ksplit : 2);  // gemm_kernel always runs >= 2 slices in this mode
+    const long long need = (long long)slices * ntaps * g.M * g.N * (long long)sizeof(float);
+    g.partials = nullptr;
+    if (ws) {
+        if (ws_bytes < need) { vs::set_error("weight-gradient GEMM: workspace of %lld bytes given, %lld needed", ws_bytes, need); return -1; }
+        if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) { vs::set_error("weight-gradient GEMM: workspace must be 16-byte aligned"); return -1; }
+        g.partials = ws;
+    }
+    int rc = 0;
+    if (big) {
+        g.ksplit = ksplit;
+        const long long nwg = (long long)(g.M / 256) * (g.N / 256) * ntaps * ksplit;
+        if (nwg > 0x7fffffffLL) { vs::set_error("weight-gradient GEMM: grid too large"); return -1; }
+        hipLaunchKernelGGL((gemm256_splitk_kernel<BF16>), dim3((unsigned)nwg), dim3(512), 0, stream, g);
+    } else {
+        g.ksplit = slices;
+        if (slices != ksplit && (g.a_slice_stride || g.w_slice_stride)) { vs::set_error("weight-gradient GEMM: slice-blocked operands need ksplit >= 2 on the 128x128 tiling"); return -1; }
+        if (g.K % (32 * slices) != 0) { vs::set_error("weight-gradient GEMM: K=%d must be a multiple of %d", g.K, 32 * slices); return -1; }
+        rc = launch_mi<BF16, 4>(g, 2, stream);
+    }
+    if (rc || !ws) return rc;
+    const bool v4 = g.N % 4 == 0 && g.ldo % 4 == 0 && g.tap_out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0;
+    const long long items = (long long)ntaps * g.M * (v4 ? g.N / 4 : g.N);
+    const dim3 grid((unsigned)((items + 255) / 256));
+    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, ws, (float *)g.out, g.M, g.N, ntaps, slices, (long long)g.ldo, g.tap_out_stride);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, ws, (float *)g.out, g.M, g.N, ntaps, slices, (long long)g.ldo, g.tap_out_stride);
+    return 0;
+}
+
 }  // namespace
 
 namespace {
@@ -375,7 +452,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
-    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
@@ -408,17 +485,23 @@ extern "C" int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias,
                       a_grp_in, a_grp_out, a_grp_off, pos, kind, C, base2d, theta1d, (hipStream_t)stream_);
 }
 
-// out32[M,N] += A[M,K] W[N,K]^T with the K range cut into `ksplit` slices that run as separate workgroups and meet through
-// f32 atomics: for reductions that are long and thin (weight gradients: M, N = channels, K = millions of pixels or tokens).
-// A and W may start at any 2-byte aligned address (LDS-DMA staging), which lets a caller pass shifted views.
-extern "C" int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
-                                         int32_t ldw, int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
+// Weight-gradient GEMM: out32[t][M,N] += A[M,K] (W + shift[t])[N,K]^T for t < max(ntaps, 1), the K range cut into `ksplit` slices
+// that run as separate workgroups: long thin reductions (M, N = channels, K = millions of pixels or tokens).  ntaps = 0: one
+// plain GEMM (shifts ignored); 1..9: the taps of a 3x3 convolution -- A = dY^T [Cout, pixels], W = X^T [Cin, pixels]
+// (zero-bordered), shift[t] = the tap's pixel offset, out + t * tap_out_stride = that tap's [M, N] gradient.  A and W may start
+// at any 2-byte aligned address (LDS-DMA staging), which is what lets the taps be shifted views.  workspace: null (slices meet
+// through f32 atomics) or >= slices * max(ntaps, 1) * M * N floats (slices store partial tiles, a second kernel sums them).
+// a_slice_stride / w_slice_stride: 0 = K slice s is columns [s K/ksplit, (s+1) K/ksplit) of A / W; > 0 = slice-blocked operands,
+// slice s is columns [0, K/ksplit) of the matrix at A + s * a_slice_stride (elements), see vs_transpose16_ex.
+extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                             int32_t ldo, int64_t a_slice_stride, int64_t w_slice_stride, int64_t tap_out_stride, const int32_t *shifts,
+                             int32_t ntaps, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK(A && W && out, "vs_gemm_splitk_accumulate: null pointer");
-    VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit > 0, "vs_gemm_splitk_accumulate: bad sizes");
-    VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_splitk_accumulate: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_splitk_accumulate: dtype must be 1 (f16) or 2 (bf16)");
-    VS_CHECK(ksplit <= 65535, "vs_gemm_splitk_accumulate: ksplit too large");
+    VS_CHECK(A && W && out, "vs_gemm_wgrad: null pointer");
+    VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit >= 1 && ksplit <= 65535, "vs_gemm_wgrad: bad sizes M=%d N=%d K=%d ksplit=%d", M, N, K, ksplit);
+    VS_CHECK(ntaps >= 0 && ntaps <= 9 && (ntaps == 0 || shifts), "vs_gemm_wgrad: 0 <= ntaps <= 9, and shifts when ntaps > 0");
+    VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_wgrad: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_wgrad: dtype must be 1 (f16) or 2 (bf16)");
     GemmArgs g;
     g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
@@ -426,38 +509,28 @@ extern "C" int vs_gemm_splitk_accumulate(const void *A, const void *W, float *ou
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
-    g.ntaps = 0; g.tap_out_stride = 0;
-    g.ksplit = ksplit > 1 ? ksplit : 2;  // the epilogue uses atomics whenever ksplit > 1; a single slice still accumulates
-    if (ksplit == 1) { VS_CHECK(K % 64 == 0, "vs_gemm_splitk_accumulate: K must be a multiple of 64 when ksplit == 1"); }
-    const int rc = dtype == 2 ? launch_mi<true, 4>(g, 2, stream) : launch_mi<false, 4>(g, 2, stream);
+    g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
+    g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride;
+    VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
+    for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
+    const int rc = dtype == 2 ? launch_wgrad<true>(g, ksplit, (float *)workspace, workspace_bytes, stream)
+                              : launch_wgrad<false>(g, ksplit, (float *)workspace, workspace_bytes, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;
 }
 
-// ntaps split-K GEMMs in one launch: out32[t][M,N] += A[M,K] (W + shift[t])[N,K]^T for t < ntaps (<= 9).  The weight gradient of
-// a 3x3 convolution: A = dY^T [Cout, pixels], W = X^T [Cin, pixels] (zero-bordered), shift[t] = the tap's pixel offset.
+// The two atomics-only forms of vs_gemm_wgrad (no workspace).
+extern "C" int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
+                                         int32_t ldw, int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
+    return vs_gemm_wgrad(A, W, out, M, N, K, lda, ldw, ldo, 0, 0, 0, nullptr, 0, ksplit, dtype, nullptr, 0, stream_);
+}
+
 extern "C" int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
                                        int32_t ldw, int32_t ldo, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps,
                                        int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK(A && W && out && shifts, "vs_gemm_taps_accumulate: null pointer");
-    VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit >= 2 && ntaps >= 1 && ntaps <= 9, "vs_gemm_taps_accumulate: bad sizes (ksplit >= 2, 1 <= ntaps <= 9)");
-    VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_taps_accumulate: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_taps_accumulate: dtype must be 1 (f16) or 2 (bf16)");
-    GemmArgs g;
-    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
-    g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
-    g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
-    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
-    g.ksplit = ksplit; g.ntaps = ntaps; g.tap_out_stride = tap_out_stride;
-    for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
-    const int rc = dtype == 2 ? launch_mi<true, 4>(g, 2, stream) : launch_mi<false, 4>(g, 2, stream);
-    if (rc) return rc;
-    VS_HIP(hipGetLastError());
-    return 0;
+    VS_CHECK(ntaps >= 1, "vs_gemm_taps_accumulate: ntaps must be >= 1");
+    return vs_gemm_wgrad(A, W, out, M, N, K, lda, ldw, ldo, 0, 0, tap_out_stride, shifts, ntaps, ksplit, dtype, nullptr, 0, stream_);
 }
 
 // 7x7 stride-1 pad-3 convolution of an RGB image (the gs head's input_merger, heads/dpt_gs_head.py:112-118) as a window
@@ -485,7 +558,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
-    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0;
+    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;

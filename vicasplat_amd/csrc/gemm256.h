@@ -183,4 +183,58 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
     gemm_epilogue<BF16, EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 
+// Split-K / tap-fused variant for weight gradients: out32[tap][M,N] += A[M, Kslice] (W + shift[tap])[N, Kslice]^T through f32
+// atomics, or (g.partials) per-slice partial tiles for splitk_reduce_kernel.  blockIdx.x = (k-slice, tap, tile), tile fastest: the workgroups of one K slice run together, so A and the (up to
+// nine, overlapping) shifted views of W of that slice are shared through L2.  K / 64 / ksplit must be even and >= 2.
+template <bool BF16>
+__global__ void __launch_bounds__(512, 1) gemm256_splitk_kernel(const GemmArgs g_in) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    GemmArgs g = g_in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
+    const int ntaps = g.ntaps > 0 ? g.ntaps : 1;
+    const int ksp = blockIdx.x / (tiles * ntaps);
+    const int rem = blockIdx.x - ksp * tiles * ntaps;
+    const int tap = rem / tiles, bid = rem - tap * tiles;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int KT = g.K / 64 / g.ksplit;
+
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A) + ksp * (g.a_slice_stride ? g.a_slice_stride : (long long)KT * 64);
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + ksp * (g.w_slice_stride ? g.w_slice_stride : (long long)KT * 64);
+    if (g.ntaps > 0) {
+        W += g_in.tap_shift[tap];  // index the kernarg: a dynamically indexed local copy would live in scratch
+        g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
+    }
+    g.ksplit = 2;  // epilogue: "partial sums meet through atomics" ...
+    if (g.partials) {  // ... or are stored to the workspace for splitk_reduce_kernel
+        g.out = g.partials + ((long long)(ksp * ntaps + tap) * g.M) * g.N;
+        g.ldo = g.N;
+        g.ksplit = -1;
+    }
+    GemmStager256 st;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = unit_row256(wid, j, lane);
+        const int src_chunk = unit_src_chunk256(q, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ra_ = min(m0 + unit_a_tile_row256(q, h), g.M - 1);
+            st.pu[h][j] = A + (size_t)ra_ * g.lda + src_chunk * 8;
+            const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.N - 1);
+            st.pu[2 + h][j] = W + (size_t)rw_ * g.ldw + src_chunk * 8;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256<BF16, false>(st, KT, acc, smem, lane, wid);
+    g.bias = nullptr;
+    g.gate = nullptr;
+    gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
 }  // namespace

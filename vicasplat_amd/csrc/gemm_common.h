@@ -32,7 +32,17 @@ struct GemmArgs {
     int ntaps;
     long long tap_out_stride;
     int tap_shift[9];
-    int ksplit;  // > 1 (gemm_kernel, epilogue 2 only): blockIdx.y-th of ksplit equal K ranges, summed into out with f32 atomics
+    int ksplit;  // > 1 (epilogue 2 only): blockIdx.y-th of ksplit equal K ranges, summed into out with f32 atomics
+    // weight-gradient launches with a workspace: K slice s (tap t) STORES its partial tile to partials[((s * ntaps + t) * M + m) * N + n]
+    // (plain coalesced stores; splitk_reduce_kernel sums the slices) instead of meeting the other slices through atomics --
+    // f32 atomics sustain only ~0.3 TB/s on this part, a tenth of the plain store rate.  The kernels then run the epilogue with
+    // ksplit = -1 ("store").
+    float *partials;
+    // element offset of K slice s within A / W: s * a_slice_stride (0: the slices are consecutive column ranges of one matrix,
+    // i.e. K / ksplit).  Weight-gradient operands are stored slice-blocked, [slice][channel][slice length], so that the rows a
+    // workgroup walks are a few KB apart instead of the whole reduction length (4 M pixels = 8 MB: one TLB entry per row and
+    // K step otherwise)
+    long long a_slice_stride, w_slice_stride;
     // epilogue 4 (STORE16 + RoPE on the q and k column blocks of a packed qkv projection, head_dim 64): per OUTPUT row
     // pos[2] and kind (0: 2-D pairs (i, i+16) per 32-half with pos[0]/pos[1], 1: 1-D interleaved pairs with pos[0], 2: none)
     const int32_t *rope_pos;
@@ -211,7 +221,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                             else { gt[0] = gp[j * 16]; gt[1] = gp[j * 16 + 1]; gt[2] = gp[j * 16 + 2]; gt[3] = gp[j * 16 + 3]; }
                             val.x *= 1.0f + gt[0]; val.y *= 1.0f + gt[1]; val.z *= 1.0f + gt[2]; val.w *= 1.0f + gt[3];
                         }
-                        if (g.ksplit > 1) {  // partial sums of a split-K tail launch meet in memory
+                        if (g.ksplit < 0) {  // partial tile of a weight-gradient K slice: plain store into the workspace
+                            *reinterpret_cast<float4 *>(dst + j * 16) = val;
+                        } else if (g.ksplit > 1) {  // partial sums of a split-K tail launch meet in memory
                             unsafeAtomicAdd(dst + j * 16 + 0, val.x); unsafeAtomicAdd(dst + j * 16 + 1, val.y);
                             unsafeAtomicAdd(dst + j * 16 + 2, val.z); unsafeAtomicAdd(dst + j * 16 + 3, val.w);
                         } else {
@@ -229,7 +241,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                         if (n < g.N) {
                             float x = v[j][r];
                             if (EPI == 2 && gp) x *= 1.0f + gp[j * 16 + r];
-                            if constexpr (EPI == 2) { if (g.ksplit > 1) unsafeAtomicAdd(dst + j * 16 + r, x); else dst[j * 16 + r] += x; } else dst[j * 16 + r] = x;
+                            if constexpr (EPI == 2) {
+                                if (g.ksplit < 0) dst[j * 16 + r] = x;
+                                else if (g.ksplit > 1) unsafeAtomicAdd(dst + j * 16 + r, x);
+                                else dst[j * 16 + r] += x;
+                            } else {
+                                dst[j * 16 + r] = x;
+                            }
                         }
                     }
                 }

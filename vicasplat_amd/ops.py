@@ -249,17 +249,54 @@ def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_ad
 _DT3 = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def transpose16(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
-    """x [R,C] 16-bit (row stride any) -> [C, Rpad] with Rpad = R rounded up to `pad_to`, padding columns zero."""
-    dev = L.require_device(x)
+def transpose16(x: torch.Tensor, pad_to: int = 1, *, colsum_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                border_hw: Optional[tuple] = None, relu: bool = False, slices: int = 1, halo: int = 0) -> torch.Tensor:
+    """x [R,C] 16-bit (row stride any) -> [C, Rpad] with Rpad = R rounded up to `pad_to`, padding columns zero.
+    colsum_out (f32 [C]) additionally receives the column sums of x (overwritten) from the same pass.
+    border_hw = (H, W): x is [n*H*W, C] (NHWC pixels) and the transposed rows are the pixels of the zero-bordered
+    [n, H+2, W+2] maps (R = n*(H+2)*(W+2)); relu zeroes negative inputs.  `out` [C, >= Rpad] may be a column-offset view.
+    slices > 1: slice-blocked result [slices, C, Rpad/slices + 2*halo] (slice z = rows [z*SL - halo, (z+1)*SL + halo), zeros
+    outside [0, R)): the operand layout of gemm_wgrad."""
+    dev = L.require_device(x, colsum_out, out)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float16, torch.bfloat16)
     R, Cc = x.shape
+    bh = bw = 0
+    if border_hw is not None:
+        bh, bw = border_hw
+        assert R % (bh * bw) == 0
+        R = R // (bh * bw) * (bh + 2) * (bw + 2)
     Rpad = (R + pad_to - 1) // pad_to * pad_to
-    out = torch.empty((Cc, Rpad), dtype=x.dtype, device=dev)
+    if slices > 1:
+        assert out is None and Rpad % slices == 0
+        out = torch.empty((slices, Cc, Rpad // slices + 2 * halo), dtype=x.dtype, device=dev)
+        ld_out, sstride = out.stride(1), out.stride(0)
+    else:
+        assert halo == 0
+        if out is None:
+            out = torch.empty((Cc, Rpad), dtype=x.dtype, device=dev)
+        else:
+            assert out.dtype == x.dtype and out.shape[0] == Cc and out.stride(1) == 1 and out.shape[1] >= Rpad
+        ld_out, sstride = out.stride(0), 0
+    if colsum_out is not None:
+        assert colsum_out.dtype == torch.float32 and colsum_out.is_contiguous() and colsum_out.numel() == Cc
     with torch.cuda.device(dev):
-        rc = L.lib().vs_transpose16(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, L.stream_ptr(dev))
-    L.check(rc, "vs_transpose16")
+        rc = L.lib().vs_transpose16_ex(L.ptr(x), x.stride(0), L.ptr(out), ld_out, R, Cc, Rpad, L.ptr(colsum_out), _DT[x.dtype],
+                                       bh, bw, int(relu), slices, halo, sstride, L.stream_ptr(dev))
+    L.check(rc, "vs_transpose16_ex")
     return out
+
+
+def wgrad_ksplit(out_rows: int, out_cols: int, red: int, ntaps: int = 1) -> tuple[int, int]:
+    """(ksplit, reduction padding unit) of a weight-gradient GEMM out[out_rows, out_cols] = sum over `red` rows.  Mirrors the
+    dispatch of vs_gemm_splitk_accumulate: whole 256x256 output tiles run on the 8-wave kernel, one workgroup per CU (aim at
+    ~256 workgroups, K slices of an even number of 64-wide tiles); anything else on 128x128 tiles, 3 per CU (~768)."""
+    if out_rows % 256 == 0 and out_cols % 256 == 0:
+        tiles = (out_rows // 256) * (out_cols // 256) * ntaps
+        ks = max(1, min((256 + tiles // 2) // tiles, red // 512))
+        return ks, 128 * ks
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128) * ntaps
+    ks = max(2, min(768 // tiles, red // 512, 1024))
+    return ks, 64 * ks
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
@@ -337,14 +374,14 @@ def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_
         gemm(dyp, wT, None, dx, EPI_STORE16)
     if need_dw:
         # reduction over the M rows: few output tiles, a very long K -> split it over workgroups (f32 atomics into zeros)
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        ks = 1
-        while ks < 16 and tiles * ks * 2 <= 1024 and M // (64 * ks * 2) >= 8:
-            ks *= 2
-        dyT, xT = transpose16(dy, 64 * ks), transpose16(x, 64 * ks)   # [N, Mpad], [K, Mpad], zero padded
+        ks, unit = wgrad_ksplit(N, K, M)
+        if need_db:
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+        # slice-blocked [ks, N, Mpad/ks], [ks, K, Mpad/ks], zero padded
+        dyT, xT = transpose16(dy, unit, colsum_out=db, slices=ks), transpose16(x, unit, slices=ks)
         dw = torch.zeros((N, K), dtype=torch.float32, device=dev)
-        gemm_splitk_accumulate(dyT, xT, dw, ks)
-    if need_db:
+        gemm_wgrad(dyT, xT, dw, ks)
+    elif need_db:
         db = colsum(dy)
     return dx, dw, db
 
@@ -359,8 +396,43 @@ def relu_mask_(dx: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+def gemm_wgrad(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int, *, shifts=None, K: Optional[int] = None,
+               workspace: bool = True) -> torch.Tensor:
+    """out32[t][M,N] += a[M,K] @ (w shifted by shifts[t])[N,K]^T, K split over `ksplit` workgroups per tile (vs_gemm_wgrad).
+    a, w: 2-D [rows, K] (slice s = columns [s K/ksplit, ...)) or slice-blocked 3-D [ksplit, rows, K/ksplit] as transpose16(slices=)
+    writes them (w may be a column-offset view into a wider halo'd buffer; K = ksplit * slice length then).
+    out is [M,N] (shifts None) or [len(shifts),M,N] contiguous.  workspace: the K slices store partial tiles that a second
+    kernel sums (default); False: they meet through f32 atomics."""
+    dev = L.require_device(a, w, out)
+    assert a.dtype == w.dtype and a.stride(-1) == 1 and w.stride(-1) == 1 and out.dtype == torch.float32 and out.is_contiguous()
+    assert a.dim() == w.dim()
+    asl = wsl = 0
+    if a.dim() == 3:
+        assert a.shape[0] == ksplit and w.shape[0] == ksplit and a.shape[2] == w.shape[2]
+        if ksplit == 1:
+            a, w = a[0], w[0]
+        else:
+            asl, wsl = a.stride(0), w.stride(0)
+            K = ksplit * a.shape[2] if K is None else K
+    K = a.shape[-1] if K is None else K
+    M, N = a.shape[-2], w.shape[-2]
+    ntaps = 0 if shifts is None else len(shifts)
+    assert out.shape == ((M, N) if shifts is None else (ntaps, M, N))
+    import ctypes
+    sh = None if shifts is None else (ctypes.c_int32 * ntaps)(*shifts)
+    ws, ws_bytes = None, 0
+    if workspace:
+        ws = torch.empty(max(2, ksplit) * max(1, ntaps) * M * N, dtype=torch.float32, device=dev)
+        ws_bytes = ws.numel() * 4
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(w), L.ptr(out), M, N, K, a.stride(-2), w.stride(-2), N, asl, wsl, M * N, sh, ntaps,
+                                   ksplit, _DT[a.dtype], L.ptr(ws), ws_bytes, L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_wgrad")
+    return out
+
+
 def gemm_splitk_accumulate(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int, *, K: Optional[int] = None) -> torch.Tensor:
-    """out32 [M,N] += a[M,K] @ w[N,K]^T with K split over `ksplit` workgroups per tile.  a / w may be column-shifted views."""
+    """out32 [M,N] += a[M,K] @ w[N,K]^T with K split over `ksplit` workgroups per tile, f32 atomics (vs_gemm_splitk_accumulate)."""
     dev = L.require_device(a, w, out)
     assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and out.dtype == torch.float32
     K = a.shape[1] if K is None else K
@@ -387,33 +459,26 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
         dx = conv3x3_nhwc(dy.contiguous(), wd, None)
         if relu_in:
             relu_mask_(dx, x)
-    # weight gradient
-    xin = torch.relu(x) if relu_in else x
+    # weight gradient: dY^T [Cout, pixels] and X^T [Cin, pixels] over the zero-bordered pixel grid, produced straight from the
+    # NHWC tensors by the transposing kernel (border, input ReLU and the bias gradient folded into that one pass)
     Hp, Wp = H + 2, W + 2
     P = N * Hp * Wp
-    ksplit = max(2, min(256, P // 4096))
-    unit = 64 * ksplit
+    ksplit, unit = wgrad_ksplit(Cout, Cin, P, 9)
     Ppad = (P + unit - 1) // unit * unit
-    slack = Wp + 2                                                  # largest |tap shift| + 1
-    xp = torch.zeros((N, Hp, Wp, Cin), dtype=dt, device=dev); xp[:, 1:-1, 1:-1] = xin
-    dyp = torch.zeros((N, Hp, Wp, Cout), dtype=dt, device=dev); dyp[:, 1:-1, 1:-1] = dy
-    xT = torch.zeros((Cin, slack + Ppad + slack), dtype=dt, device=dev)
-    xT[:, slack:slack + P] = transpose16(xp.view(P, Cin))[:, :P]
-    dyT = torch.zeros((Cout, Ppad), dtype=dt, device=dev)
-    dyT[:, :P] = transpose16(dyp.view(P, Cout))[:, :P]
+    halo = (Wp + 2 + 7) // 8 * 8                                    # >= largest |tap shift| + 1; keeps the rows 16-byte aligned
+    xT = transpose16(x.view(N * H * W, Cin), unit, border_hw=(H, W), relu=relu_in, slices=ksplit, halo=halo if ksplit > 1 else 0)
+    if ksplit == 1:                                                 # one slice: the shifted views need zero columns on either side
+        xT = torch.nn.functional.pad(xT, (halo, halo)).unsqueeze(0)
+    db = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dyT = transpose16(dy.contiguous().view(N * H * W, Cout), unit, colsum_out=db, border_hw=(H, W), slices=ksplit)
+    if ksplit == 1:
+        dyT = dyT.unsqueeze(0)
     # all 9 taps in ONE launch (workgroup order: k-slice, tap, tile): the taps of a K slice run together, so A and the nine
     # overlapping shifted views of X^T are served from the caches instead of being streamed from HBM nine times
-    import ctypes
-    ksplit = max(2, ksplit)
     dw9 = torch.zeros((9, Cout, Cin), dtype=torch.float32, device=dev)
-    shifts = (ctypes.c_int32 * 9)(*[(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)])
-    base = xT[:, slack:slack + Ppad]
-    with torch.cuda.device(dev):
-        rc = L.lib().vs_gemm_taps_accumulate(L.ptr(dyT), L.ptr(base), L.ptr(dw9), Cout, Cin, Ppad, dyT.stride(0), xT.stride(0), Cin,
-                                             Cout * Cin, shifts, 9, ksplit, _DT[dt], L.stream_ptr(dev))
-    L.check(rc, "vs_gemm_taps_accumulate")
+    shifts = [(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)]
+    gemm_wgrad(dyT, xT[:, :, halo:halo + Ppad // ksplit], dw9, ksplit, shifts=shifts)
     dw = dw9.view(3, 3, Cout, Cin).permute(2, 0, 1, 3).contiguous()
-    db = colsum(dy.reshape(-1, Cout))
     return dx, dw, db
 
 
