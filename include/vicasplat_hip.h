@@ -278,6 +278,8 @@ int vs_transpose16_ex(const void *in, int64_t ld_in, void *out, int64_t ld_out, 
                       int32_t dtype, int32_t border_h, int32_t border_w, int32_t relu, int32_t nslices, int32_t halo,
                       int64_t slice_stride, vs_stream_t stream);
 int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32_t dtype, vs_stream_t stream);
+/* out = gelu_erf(z) on n 16-bit elements (n % 8 == 0): the training forward's activation pass (z is kept for vs_gelu_backward). */
+int vs_gelu16(const void *z, void *out, int64_t n, int32_t dtype, vs_stream_t stream);
 int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream);
 int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,
                           const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx, int32_t accumulate_dx,

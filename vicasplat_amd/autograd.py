@@ -174,3 +174,45 @@ class Upsample2xFn(torch.autograd.Function):
 
 def upsample2x(x_nhwc: torch.Tensor) -> torch.Tensor:
     return Upsample2xFn.apply(x_nhwc)
+
+
+class GeluFn(torch.autograd.Function):
+    """Exact (erf) GELU on a 16-bit tensor; the pre-activation is kept for ops.gelu_backward."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous()
+        ctx.save_for_backward(z)
+        return ops.gelu16(z)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        return ops.gelu_backward(dy.to(z.dtype).contiguous(), z)
+
+
+def gelu(z: torch.Tensor) -> torch.Tensor:
+    return GeluFn.apply(z)
+
+
+class EncBlockFn(torch.autograd.Function):
+    """One frame-encoder block (croco/blocks.py:114-130) as a single autograd node on the hand-differentiated pair of
+    vicasplat_amd.train: x f32 [M,C] -> x_out f32 [M,C].  params = (norm1.w, norm1.b, qkv.w, qkv.b, proj.w, proj.b, norm2.w,
+    norm2.b, fc1.w, fc1.b, fc2.w, fc2.b), the module's f32 parameters."""
+
+    @staticmethod
+    def forward(ctx, x, pos, frames, tokens, heads, dt, *params):
+        from .train import EncBlockParams, enc_block_forward_train
+        f = [t.detach().float().contiguous() for t in params]
+        p = EncBlockParams(f[0], f[1], f[2].to(dt), f[3], f[4].to(dt), f[5], f[6], f[7], f[8].to(dt), f[9], f[10].to(dt), f[11])
+        x_out, tape = enc_block_forward_train(x.detach().contiguous(), p, pos, frames=frames, tokens=tokens, heads=heads)
+        ctx.tape, ctx.p = tape, p
+        return x_out
+
+    @staticmethod
+    def backward(ctx, dx_out):
+        from .train import enc_block_backward
+        dx, g = enc_block_backward(dx_out.contiguous(), ctx.tape, ctx.p)
+        ctx.tape = ctx.p = None
+        return (dx, None, None, None, None, None, g["ln1_w"], g["ln1_b"], g["qkv_w"], g["qkv_b"], g["proj_w"], g["proj_b"],
+                g["ln2_w"], g["ln2_b"], g["fc1_w"], g["fc1_b"], g["fc2_w"], g["fc2_b"])

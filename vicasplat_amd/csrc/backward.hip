@@ -172,6 +172,26 @@ gelu_backward_kernel(const unsigned short *__restrict__ dy, const unsigned short
     *reinterpret_cast<uint4 *>(dz + i) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+// a = gelu_erf(z) (exact GELU, croco/blocks.py:60) on 16-bit elements: the training forward keeps the pre-activation z for the
+// backward, so the activation is its own pass here instead of the GEMM epilogue
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+gelu16_kernel(const unsigned short *__restrict__ z, unsigned short *__restrict__ out, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint4 b = *reinterpret_cast<const uint4 *>(z + i);
+    const unsigned bw[4] = {b.x, b.y, b.z, b.w};
+    unsigned r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = ld16<BF16>((unsigned short)(bw[k] & 0xffffu)), x1 = ld16<BF16>((unsigned short)(bw[k] >> 16));
+        const float o0 = 0.5f * x0 * (1.0f + erff(x0 * 0.70710678118654752440f));
+        const float o1 = 0.5f * x1 * (1.0f + erff(x1 * 0.70710678118654752440f));
+        r[k] = (unsigned)st16<BF16>(o0) | ((unsigned)st16<BF16>(o1) << 16);
+    }
+    *reinterpret_cast<uint4 *>(out + i) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 // dx = x > 0 ? dx : 0 on packed 16-bit pairs (backward of a ReLU whose INPUT x was saved), in place
 __global__ void __launch_bounds__(256)
 relu_mask16_kernel(unsigned short *__restrict__ dx, const unsigned short *__restrict__ x, long long n) {
@@ -401,6 +421,20 @@ extern "C" int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t
     dim3 grid((unsigned)vs::cdiv64(n / 8, 256)), block(256);
     if (dtype == 2) hipLaunchKernelGGL(gelu_backward_kernel<true>, grid, block, 0, stream, (const unsigned short *)dy, (const unsigned short *)z, (unsigned short *)dz, (long long)n);
     else hipLaunchKernelGGL(gelu_backward_kernel<false>, grid, block, 0, stream, (const unsigned short *)dy, (const unsigned short *)z, (unsigned short *)dz, (long long)n);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_gelu16(const void *z, void *out, int64_t n, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(z && out, "vs_gelu16: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gelu16: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(n >= 0 && n % 8 == 0, "vs_gelu16: n=%lld must be a multiple of 8", (long long)n);
+    VS_CHECK((((uintptr_t)z | (uintptr_t)out) & 15) == 0, "vs_gelu16: 16-byte alignment required");
+    if (n == 0) return 0;
+    dim3 grid((unsigned)vs::cdiv64(n / 8, 256)), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(gelu16_kernel<true>, grid, block, 0, stream, (const unsigned short *)z, (unsigned short *)out, (long long)n);
+    else hipLaunchKernelGGL(gelu16_kernel<false>, grid, block, 0, stream, (const unsigned short *)z, (unsigned short *)out, (long long)n);
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -51,15 +51,13 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     intr = _lin_f32(P, "backbone.intrinsic_encoder", intrinsics.reshape(BT, 1, 9).float())
     x = torch.cat([x, intr], 1)                                                                     # [BT, N1, Ce] f32 stream
     He = cfg.enc_num_heads
-    for i in range(cfg.enc_depth):
+    x = x.reshape(BT * N1, Ce)
+    for i in range(cfg.enc_depth):          # one autograd node per block: LN / qkv+RoPE / attention / proj / LN / fc1 / GELU / fc2
         nm = f"backbone.enc_blocks.{i}"
-        h = lnm(nm + ".norm1", x, out_dtype=dt)
-        qkv = A.RopeQKFn.apply(lin(nm + ".attn.qkv", h).reshape(BT * N1, 3 * Ce), tabs["pos_img"], None, He, Ce, 100.0, 1.0)
-        att = A.AttentionFn.apply(qkv, BT, He, N1, N1, N1, N1, None, None, 0)
-        x = x + lin(nm + ".attn.proj", att).float().view(BT, N1, Ce)
-        h = lnm(nm + ".norm2", x, out_dtype=dt)
-        x = x + lin(nm + ".mlp.fc2", F.gelu(lin(nm + ".mlp.fc1", h).float()).to(dt)).float()
-    x = lnm("backbone.enc_norm", x, out_dtype=torch.float32)
+        names = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                 "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+        x = A.EncBlockFn.apply(x, tabs["pos_img"], BT, N1, He, dt, *[P[f"{nm}.{k}"] for k in names])
+    x = lnm("backbone.enc_norm", x.view(BT, N1, Ce), out_dtype=torch.float32)
 
     # ---------------- video / camera decoder (backbone_vica.py:482-524, block :280-335) ----------------
     T = V
@@ -92,7 +90,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
         x = x + (1 + g2[:, :, None]) * lin(ca + ".proj", att).float().view(B, T, N1, C)
         himg = lnm(nm + ".norm3", x.reshape(BT * N1, C), scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
-        m = lin(nm + ".mlp.fc2", F.gelu(lin(nm + ".mlp.fc1", himg).float()).to(dt)).float().view(B, T, N1, C)
+        m = lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", himg))).float().view(B, T, N1, C)
         x = x + (1 + g3[:, :, None]) * m
         cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
         inter.append(x.reshape(BT, N1, C))

@@ -310,6 +310,17 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gelu16(z: torch.Tensor) -> torch.Tensor:
+    """gelu_erf(z) on a contiguous 16-bit tensor (numel % 8 == 0)."""
+    dev = L.require_device(z)
+    assert z.is_contiguous() and z.dtype in (torch.float16, torch.bfloat16)
+    out = torch.empty_like(z)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gelu16(L.ptr(z), L.ptr(out), z.numel(), _DT[z.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_gelu16")
+    return out
+
+
 def gelu_backward(dy: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     """dz = dy * gelu_erf'(z); dy, z contiguous 16-bit of the same shape (numel % 8 == 0)."""
     dev = L.require_device(dy, z)

@@ -1,8 +1,9 @@
 """One frame-encoder transformer block differentiated by hand on the HIP backward operators of `ops` -- LayerNorm -> packed
 qkv projection + RoPE -> attention -> projection (+residual) -> LayerNorm -> fc1 -> GELU -> fc2 (+residual), i.e.
 croco/blocks.py:114-130 as `VicaNet` runs it (backbone_vica.py:455-470) -- with an explicit tape instead of autograd.
-Kept as the operator-level reference composition (13 gradients vs the oracle's autograd to 7e-4 in f16:
-tests/test_train_gpu.py); the training step itself uses `vicasplat_amd.autograd` + `model/encoder/train_forward.py`.
+13 gradients vs the oracle's autograd to 7e-4 in f16 (tests/test_train_gpu.py).  `autograd.EncBlockFn` wraps the pair as ONE
+autograd node per encoder block for the training forward (`model/encoder/train_forward.py`): the residual adds live in the GEMM
+epilogues and the LayerNorm backward's accumulate, so no elementwise PyTorch kernel runs inside a block in either direction.
 """
 from __future__ import annotations
 
@@ -47,7 +48,7 @@ def enc_block_forward_train(x: torch.Tensor, p: EncBlockParams, pos: torch.Tenso
     ops.layernorm_mod(x_mid, p.ln2_w, p.ln2_b, h2, eps=eps)
     z = torch.empty(M, p.fc1_w.shape[0], dtype=dt, device=dev)
     ops.gemm(h2, p.fc1_w, p.fc1_b, z, ops.EPI_STORE16)       # pre-activation kept for the GELU backward
-    a = F.gelu(z.float()).to(dt)
+    a = ops.gelu16(z)
     x_out = x_mid.clone()
     ops.gemm(a, p.fc2_w, p.fc2_b, x_out, ops.EPI_RESID32)
     tape = dict(x=x, h1=h1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, h2=h2, z=z, a=a, pos=pos, frames=frames, tokens=tokens,
@@ -61,14 +62,14 @@ def enc_block_backward(dx_out: torch.Tensor, tape: dict, p: EncBlockParams):
     C = dx_out.shape[1]
     dt = p.qkv_w.dtype
     g = {}
-    dx_mid = dx_out.clone()                                   # residual branch
+    dx_mid = dx_out.clone()                                   # residual branch; ONE f32 buffer collects dx_out + both LayerNorm backwards
     # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
     da, g["fc2_w"], g["fc2_b"] = ops.linear_backward(dx_out.to(dt), t["a"], p.fc2_w)
     dz = ops.gelu_backward(da, t["z"])
     dh2, g["fc1_w"], g["fc1_b"] = ops.linear_backward(dz, t["h2"], p.fc1_w)
     _, g["ln2_w"], g["ln2_b"], _, _ = ops.layernorm_backward(dh2, t["x_mid"], p.ln2_w, p.ln2_b, eps=t["eps"], dx=dx_mid, accumulate_dx=True)
     # ---- attention: x_mid = x + proj(attn(rope(qkv(LN1(x))))) ----
-    dx_in = dx_mid.clone()
+    dx_in = dx_mid
     datt, g["proj_w"], g["proj_b"] = ops.linear_backward(dx_mid.to(dt), t["att"], p.proj_w)
     qkv = t["qkv"]
     dq, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], t["att"], datt, t["lse"], nbatch=t["frames"],
