@@ -25,10 +25,15 @@ batch = dict(context=dict(image=img.to(d), intrinsics=K.to(d)), target=dict(imag
 opt, _ = callers.configure_optimizer(enc, lr=1e-12)   # timing only: random-init weights + real learning rates throw the scene off screen
 for _ in range(a.warmup):
     r = callers.training_step(enc, dec, batch, opt)
+st0 = dict(torch.cuda.memory_stats())
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     r = callers.training_step(enc, dec, batch, opt)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps(dict(config="re10k_8view training step fwd+bwd+AdamW", scenes=B, views=V, targets=Vt, ms_per_step=round(dt * 1e3, 1),
                       scenes_per_s=round(B / dt, 3), loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
-                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
+                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                      reserved_gb=round(torch.cuda.memory_stats()["reserved_bytes.all.peak"] / 2**30, 1),
+                      device_mallocs_in_timed_steps=torch.cuda.memory_stats()["num_device_alloc"] - st0["num_device_alloc"],
+                      device_frees_in_timed_steps=torch.cuda.memory_stats()["num_device_free"] - st0["num_device_free"],
+                      alloc_retries=torch.cuda.memory_stats()["num_alloc_retries"])))
