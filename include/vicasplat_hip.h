@@ -281,6 +281,16 @@ int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32_t N, int32
 /* out = gelu_erf(z) on n 16-bit elements (n % 8 == 0): the training forward's activation pass (z is kept for vs_gelu_backward). */
 int vs_gelu16(const void *z, void *out, int64_t n, int32_t dtype, vs_stream_t stream);
 int vs_gelu_backward(const void *dy, const void *z, void *dz, int64_t n, int32_t dtype, vs_stream_t stream);
+/* Gated residual update of the decoder image stream: out[m,c] = x[m,c] + (1 + gate[m / gate_rows, c]) * y[yrow(m), c] with
+ * yrow(m) = (m / grp_in) * grp_out + grp_off + m % grp_in (grp_in <= 0: identity); x, out f32 [M,C] (may alias), y 16-bit with row
+ * stride ldy, gate f32 [G,C] or null (plain residual).  backbone_vica.py:274-278,302,327,331 in one pass. */
+int vs_gated_resid(const float *x, const void *y, int64_t ldy, const float *gate, int32_t gate_rows, float *out, int32_t M, int32_t C,
+                   int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t dtype, vs_stream_t stream);
+/* Its backward on the branch side: dy[yrow(m), c] = dout[m,c] * (1 + gate) (16-bit, row stride lddy; rows outside the map are not
+ * written) and dgate[g, c] += sum over the group's rows of dout * y (f32 atomics: zero dgate first); dx = dout needs no kernel. */
+int vs_gated_resid_backward(const float *dout, const void *y, int64_t ldy, const float *gate, int32_t gate_rows, void *dy, int64_t lddy,
+                            float *dgate, int32_t M, int32_t C, int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t dtype,
+                            vs_stream_t stream);
 int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,
                           const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx, int32_t accumulate_dx,
                           float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in,

@@ -534,6 +534,57 @@ def test_gemm_wgrad_taps_and_errors():
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gated_resid_and_lead_layernorm_match_autograd(dt):
+    """autograd.gated_resid (x + (1 + gate) * branch with the camera-token row split off), autograd.gelu and layernorm_mod(lead=)
+    against the same expressions in plain torch, forward and backward."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    torch.manual_seed(21)
+    BT, N1, C = 6, 37, 192
+    M2 = N1 + 1
+    x = torch.randn(BT * N1, C, device=d, requires_grad=True)
+    y = torch.randn(BT * M2, C, device=d).to(dt).requires_grad_()
+    gate = (torch.randn(BT, C, device=d) * 0.3).requires_grad_()
+    out, extra = A.gated_resid(x, y, gate, N1, N1, M2, 1)
+    yv = y.float().view(BT, M2, C)
+    ref = x.view(BT, N1, C) + (1 + gate[:, None]) * yv[:, 1:]
+    tol = 2e-3 if dt == torch.float16 else 1.6e-2
+    assert (out.view(BT, N1, C) - ref).abs().max() <= 1e-5 * ref.abs().max() and torch.equal(extra.view(BT, C), yv[:, 0])
+    go, ge = torch.randn_like(out), torch.randn_like(extra)
+    gx, gy, gg = torch.autograd.grad((out * go).sum() + (extra * ge).sum(), (x, y, gate))
+    rx, ry, rg = torch.autograd.grad((ref.reshape(-1, C) * go).sum() + (yv[:, :1] * ge).sum(), (x, y, gate))
+    assert torch.equal(gx, rx) and (gy.float() - ry.float()).abs().max() <= tol * ry.float().abs().max()
+    assert (gg - rg).abs().max() <= 1e-4 * rg.abs().max() + 1e-4
+    # no gate, identity row map
+    y2 = torch.randn(BT * N1, C, device=d).to(dt).requires_grad_()
+    o2 = A.gated_resid(x, y2)
+    assert (o2 - (x + y2.float())).abs().max() <= 1e-5 * o2.abs().max()
+    g2 = torch.autograd.grad((o2 * go).sum(), y2)[0]
+    assert (g2.float() - go).abs().max() <= tol * go.abs().max()
+    # GELU
+    z = (torch.randn(64, 256, device=d) * 2).to(dt).requires_grad_()
+    a = A.gelu(z)
+    zr = z.detach().float().requires_grad_()
+    ar = F.gelu(zr)
+    assert (a.float() - ar).abs().max() <= tol * ar.abs().max()
+    da = torch.randn_like(ar)
+    assert (torch.autograd.grad((a.float() * da).sum(), z)[0].float() - torch.autograd.grad((ar * da).sum(), zr)[0]).abs().max() <= 2 * tol * da.abs().max()
+    # LayerNorm + modulation written behind a leading row per frame
+    w = (torch.randn(C, device=d) * 0.2 + 1).requires_grad_(); b = (torch.randn(C, device=d) * 0.1).requires_grad_()
+    sc = (torch.randn(BT, C, device=d) * 0.3).requires_grad_(); sh = (torch.randn(BT, C, device=d) * 0.3).requires_grad_()
+    lead = torch.randn(BT, C, device=d).to(dt).requires_grad_()
+    h = A.layernorm_mod(x, w, b, scale=sc, shift=sh, mod_rows=N1, out_dtype=dt, lead=lead, lead_rows=N1)
+    ln = F.layer_norm(x, (C,), w, b, 1e-6).view(BT, N1, C) * (1 + sc[:, None]) + sh[:, None]
+    href = torch.cat([lead.float()[:, None], ln], 1).reshape(BT * M2, C)
+    assert h.shape == (BT * M2, C) and (h.float() - href).abs().max() <= tol * href.abs().max()
+    gh = torch.randn_like(href)
+    got = torch.autograd.grad((h.float() * gh).sum(), (x, w, b, sc, sh, lead))
+    want = torch.autograd.grad((href * gh).sum(), (x, w, b, sc, sh, lead))
+    for gname, u, v in zip(("x", "w", "b", "scale", "shift", "lead"), got, want):
+        assert (u.float() - v.float()).abs().max() <= 2 * tol * v.float().abs().max() + 1e-4, gname
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gelu_backward_matches_autograd(dt):
     from vicasplat_amd import ops
     d = _dev()

@@ -114,6 +114,10 @@ def lib() -> C.CDLL:
             L.vs_transpose16_ex.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i64, vp]
             L.vs_colsum.restype = C.c_int
             L.vs_colsum.argtypes = [vp, i64, vp, i32, i32, i32, vp]
+            L.vs_gated_resid.restype = C.c_int
+            L.vs_gated_resid.argtypes = [vp, vp, i64, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_gated_resid_backward.restype = C.c_int
+            L.vs_gated_resid_backward.argtypes = [vp, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]
             L.vs_gelu16.restype = C.c_int
             L.vs_gelu16.argtypes = [vp, vp, i64, i32, vp]
             L.vs_gelu_backward.restype = C.c_int

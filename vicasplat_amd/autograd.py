@@ -53,34 +53,50 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torc
 
 
 class LayerNormModFn(torch.autograd.Function):
-    """out = LN(x; w, b) [* (1 + scale[row // mod_rows]) + shift[...]], x f32 [M,C] -> out in `out_dtype`."""
+    """out = LN(x; w, b) [* (1 + scale[row // mod_rows]) + shift[...]], x f32 [M,C] -> out in `out_dtype`.
+    lead (optional, [M // lead_rows, C]): the output gets one extra row in FRONT of every lead_rows rows holding lead (the
+    decoder's camera token in front of each frame's image tokens, backbone_vica.py:95-118) -- the kernel writes the LayerNorm
+    rows straight into that interleaved buffer, so no concatenation pass exists."""
 
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, mod_rows, out_dtype, eps):
+    def forward(ctx, x, w, b, scale, shift, mod_rows, out_dtype, eps, lead, lead_rows):
         M, C = x.shape
         xf = x.float().contiguous()
-        out = torch.empty((M, C), dtype=out_dtype, device=x.device)
         sc = None if scale is None else scale.detach().float().contiguous()
         sh = None if shift is None else shift.detach().float().contiguous()
-        ops.layernorm_mod(xf, w.detach().float().contiguous(), b.detach().float().contiguous(), out, eps=eps, scale=sc, shift=sh,
-                          mod_rows=mod_rows)
-        ctx.save_for_backward(xf, w.detach().float().contiguous(), b.detach().float().contiguous(), sc)
-        ctx.meta = (mod_rows, eps, x.dtype, scale is not None)
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        grp = (0, 0, 0)
+        if lead is None:
+            out = torch.empty((M, C), dtype=out_dtype, device=x.device)
+        else:
+            nf = M // lead_rows
+            out = torch.empty((nf * (lead_rows + 1), C), dtype=out_dtype, device=x.device)
+            out.view(nf, lead_rows + 1, C)[:, 0] = lead.detach().reshape(nf, C)
+            grp = (lead_rows, lead_rows + 1, 1)
+        ops.layernorm_mod(xf, wf, bf, out, eps=eps, scale=sc, shift=sh, mod_rows=mod_rows, grp_in=grp[0], grp_out=grp[1], grp_off=grp[2])
+        ctx.save_for_backward(xf, wf, bf, sc)
+        ctx.meta = (mod_rows, eps, x.dtype, scale is not None, grp, None if lead is None else (lead.shape, lead.dtype))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         xf, w, b, sc = ctx.saved_tensors
-        mod_rows, eps, xdtype, has_mod = ctx.meta
-        dx, dw, db, dsc, dsh = ops.layernorm_backward(dout.contiguous(), xf, w, b, scale=sc, mod_rows=mod_rows, eps=eps)
-        return dx.to(xdtype), dw, db, (dsc if has_mod else None), (dsh if has_mod else None), None, None, None
+        mod_rows, eps, xdtype, has_mod, grp, lead_meta = ctx.meta
+        dout = dout.contiguous()
+        dx, dw, db, dsc, dsh = ops.layernorm_backward(dout, xf, w, b, scale=sc, mod_rows=mod_rows, eps=eps, grp_in=grp[0], grp_out=grp[1],
+                                                      grp_off=grp[2])
+        dlead = None
+        if lead_meta is not None:
+            dlead = dout.view(-1, grp[1], dout.shape[1])[:, 0].to(lead_meta[1]).reshape(lead_meta[0])
+        return dx.to(xdtype), dw, db, (dsc if has_mod else None), (dsh if has_mod else None), None, None, None, dlead, None
 
 
-def layernorm_mod(x, w, b, *, scale=None, shift=None, mod_rows=0, out_dtype=torch.float16, eps=1e-6):
-    """x [..., C] (any leading dims; scale/shift [G, C] apply to consecutive groups of mod_rows rows)."""
-    lead = x.shape[:-1]
-    y = LayerNormModFn.apply(x.reshape(-1, x.shape[-1]), w, b, scale, shift, mod_rows, out_dtype, eps)
-    return y.view(*lead, x.shape[-1])
+def layernorm_mod(x, w, b, *, scale=None, shift=None, mod_rows=0, out_dtype=torch.float16, eps=1e-6, lead=None, lead_rows=0):
+    """x [..., C] (any leading dims; scale/shift [G, C] apply to consecutive groups of mod_rows rows).  With `lead` the result is
+    2-D [rows + rows // lead_rows, C] (see LayerNormModFn)."""
+    lead_shape = x.shape[:-1]
+    y = LayerNormModFn.apply(x.reshape(-1, x.shape[-1]), w, b, scale, shift, mod_rows, out_dtype, eps, lead, lead_rows)
+    return y if lead is not None else y.view(*lead_shape, x.shape[-1])
 
 
 class RopeQKFn(torch.autograd.Function):
@@ -125,7 +141,10 @@ class AttentionFn(torch.autograd.Function):
         dq, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H,
                                             Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, kv_seg=kv_seg, q_kvlen=q_kvlen,
                                             max_keys=max_keys)
-        dqkv = torch.cat([dq, dk.to(dq.dtype), dv.to(dq.dtype)], dim=1)
+        dqkv = torch.empty((dq.shape[0], 3 * C), dtype=dq.dtype, device=dq.device)   # (one cast-copy per block instead of casts + cat)
+        dqkv[:, :C] = dq
+        dqkv[:, C:2 * C] = dk
+        dqkv[:, 2 * C:] = dv
         return dqkv, None, None, None, None, None, None, None, None, None
 
 
@@ -216,3 +235,37 @@ class EncBlockFn(torch.autograd.Function):
         ctx.tape = ctx.p = None
         return (dx, None, None, None, None, None, g["ln1_w"], g["ln1_b"], g["qkv_w"], g["qkv_b"], g["proj_w"], g["proj_b"],
                 g["ln2_w"], g["ln2_b"], g["fc1_w"], g["fc1_b"], g["fc2_w"], g["fc2_b"])
+
+
+class GatedResidFn(torch.autograd.Function):
+    """x32 [M,C] + (1 + gate[row // gate_rows]) * y16[yrow(row)] in one pass (ops.gated_resid); y's rows outside the map (the
+    camera-token row in front of each frame's image tokens, grp_off) are returned as a second f32 output so that the camera
+    stream can consume them.  Backward: dx = dout, dy rows / dgate from ops.gated_resid_backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, gate, gate_rows, grp_in, grp_out, grp_off):
+        y = y.contiguous()
+        g = None if gate is None else gate.detach().float().contiguous()
+        out = ops.gated_resid(x.detach().contiguous(), y, g, gate_rows, grp_in=grp_in, grp_out=grp_out, grp_off=grp_off)
+        ctx.save_for_backward(y, g)
+        ctx.meta = (gate_rows, grp_in, grp_out, grp_off, gate is not None and gate.dtype)
+        extra = y.view(-1, grp_out, y.shape[1])[:, :grp_off].float() if grp_off > 0 else None
+        return (out, extra) if grp_off > 0 else out
+
+    @staticmethod
+    def backward(ctx, dout, dextra=None):
+        y, g = ctx.saved_tensors
+        gate_rows, grp_in, grp_out, grp_off, gdt = ctx.meta
+        dy = torch.empty_like(y)
+        if grp_off > 0:
+            v = dy.view(-1, grp_out, y.shape[1])
+            if dextra is None:
+                v[:, :grp_off] = 0
+            else:
+                v[:, :grp_off] = dextra
+        dgate = ops.gated_resid_backward(dout.contiguous().float(), y, g, gate_rows, dy, grp_in=grp_in, grp_out=grp_out, grp_off=grp_off)
+        return dout, dy, (None if dgate is None else dgate.to(gdt)), None, None, None, None
+
+
+def gated_resid(x, y, gate=None, gate_rows=0, grp_in=0, grp_out=0, grp_off=0):
+    return GatedResidFn.apply(x, y, gate, gate_rows, grp_in, grp_out, grp_off)

@@ -214,67 +214,67 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per row (rows strided over the grid), lane owns columns lane*4 + 256*k.  Per-row: recompute mean / rstd, then
+// One wave per row, lane owns columns lane*4 + 256*k (k < NV).  Per row: recompute mean / rstd, then
 //   g  = dout * (1 + scale) * w,   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
-// Column-wise sums (dw, db) and per-group sums (dscale, dshift) are kept in registers across the wave's rows and flushed
-// with f32 atomics at the end (dscale/dshift at every group change).
+// Work split: blockIdx.y = modulation group (rows [g*mod_rows, (g+1)*mod_rows); one group = all rows without modulation),
+// blockIdx.x = chunk of that group; the block's 4 waves interleave the chunk's rows.  Column sums (dw, db) and the group's
+// (dscale, dshift) stay in registers across the wave's rows, are summed over the block's waves through LDS and leave the block
+// as ONE f32 atomic per column -- the host picks ~512 blocks, so the atomic traffic stays at a few MB per call.
 constexpr int kLnVec = 8;  // C <= 64 * 4 * 8 = 2048
-template <int DT>  // dout dtype: 0 f32, 1 f16, 2 bf16
+template <int DT, int NV, bool MOD>  // dout dtype: 0 f32, 1 f16, 2 bf16; NV * 256 >= C; MOD: scale / shift modulation present
 __global__ void __launch_bounds__(256)
 layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const float *__restrict__ x, long long ldx,
                           const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ scale, int mod_rows,
                           int mod_ld, float *__restrict__ dx, long long ld_dx, int accumulate_dx, float *__restrict__ dw,
                           float *__restrict__ db, float *__restrict__ dscale, float *__restrict__ dshift, int M, int C, float eps,
-                          int grp_in, int grp_out, int grp_off) {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    float4 wv[kLnVec], bvv[kLnVec], aw[kLnVec], ab[kLnVec];
+                          int grp_in, int grp_out, int grp_off, int rows_per_chunk) {
+    __shared__ float red[4][NV * 256];
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    const int gidx = blockIdx.y;
+    const int g_lo = gidx * mod_rows, g_hi = min(M, g_lo + mod_rows);
+    const int m_lo = g_lo + blockIdx.x * rows_per_chunk, m_hi = min(g_hi, m_lo + rows_per_chunk);
+    if (m_lo >= m_hi) return;
+    float4 wv[NV], bvv[NV], sc[NV], aw[NV], ab[NV];
+    [[maybe_unused]] float4 as[NV], ah[NV];
 #pragma unroll
-    for (int k = 0; k < kLnVec; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int c = (lane + 64 * k) * 4;
         wv[k] = c < C ? *reinterpret_cast<const float4 *>(w + c) : make_float4(0, 0, 0, 0);
         bvv[k] = c < C ? *reinterpret_cast<const float4 *>(b + c) : make_float4(0, 0, 0, 0);
+        sc[k] = make_float4(0, 0, 0, 0);
+        if constexpr (MOD) {
+            if (c < C) sc[k] = *reinterpret_cast<const float4 *>(scale + (long long)gidx * mod_ld + c);
+            as[k] = ah[k] = make_float4(0, 0, 0, 0);
+        }
         aw[k] = ab[k] = make_float4(0, 0, 0, 0);
     }
-    // contiguous row range per wave so that per-group (dscale, dshift) partial sums flush rarely
-    const int per = (M + nwaves - 1) / nwaves;
-    const int m_lo = wave * per, m_hi = min(M, m_lo + per);
-    int cur_g = -1;
-    float4 as[kLnVec], ah[kLnVec];
-    auto flush_group = [&]() {
-        if (cur_g < 0 || !dscale) return;
-#pragma unroll
-        for (int k = 0; k < kLnVec; ++k) {
-            const int c = (lane + 64 * k) * 4;
-            if (c < C) {
-                float *ps = dscale + (long long)cur_g * mod_ld + c, *ph = dshift + (long long)cur_g * mod_ld + c;
-                unsafeAtomicAdd(ps + 0, as[k].x); unsafeAtomicAdd(ps + 1, as[k].y); unsafeAtomicAdd(ps + 2, as[k].z); unsafeAtomicAdd(ps + 3, as[k].w);
-                unsafeAtomicAdd(ph + 0, ah[k].x); unsafeAtomicAdd(ph + 1, ah[k].y); unsafeAtomicAdd(ph + 2, ah[k].z); unsafeAtomicAdd(ph + 3, ah[k].w);
-            }
-        }
-    };
-    for (int m = m_lo; m < m_hi; ++m) {
-        const int gidx = scale ? m / mod_rows : 0;
-        if (scale && gidx != cur_g) {
-            flush_group();
-            cur_g = gidx;
-#pragma unroll
-            for (int k = 0; k < kLnVec; ++k) as[k] = ah[k] = make_float4(0, 0, 0, 0);
-        }
+    for (int m = m_lo + wv_id; m < m_hi; m += 4) {
         const float *xr = x + (long long)m * ldx;
         const long long orow = (long long)(m / grp_in) * grp_out + grp_off + (m % grp_in);  // row of dout (the forward's output row)
-        float4 xv[kLnVec], gv[kLnVec];
+        float4 xv[NV], gv[NV];
+        float d[NV][4];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < kLnVec; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = (lane + 64 * k) * 4;
             xv[k] = c < C ? *reinterpret_cast<const float4 *>(xr + c) : make_float4(0, 0, 0, 0);
             s += xv[k].x + xv[k].y + xv[k].z + xv[k].w;
+            d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.f;
+            if (c < C) {  // issue the dout loads before the first reduction: they do not depend on it
+                if constexpr (DT == 0) {
+                    const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dout) + orow * ld_do + c);
+                    d[k][0] = t.x; d[k][1] = t.y; d[k][2] = t.z; d[k][3] = t.w;
+                } else {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(dout) + orow * ld_do + c);
+                    d[k][0] = ld16<DT == 2>((unsigned short)(t.x & 0xffffu)); d[k][1] = ld16<DT == 2>((unsigned short)(t.x >> 16));
+                    d[k][2] = ld16<DT == 2>((unsigned short)(t.y & 0xffffu)); d[k][3] = ld16<DT == 2>((unsigned short)(t.y >> 16));
+                }
+            }
         }
         const float mean = wave_sum(s) / (float)C;
         float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < kLnVec; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = (lane + 64 * k) * 4;
             if (c < C) {
                 xv[k].x -= mean; xv[k].y -= mean; xv[k].z -= mean; xv[k].w -= mean;
@@ -284,33 +284,22 @@ layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const 
         const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int k = 0; k < kLnVec; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = (lane + 64 * k) * 4;
             gv[k] = make_float4(0, 0, 0, 0);
             if (c < C) {
-                float d[4];
-                if constexpr (DT == 0) {
-                    const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dout) + orow * ld_do + c);
-                    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
-                } else {
-                    const uint2 t = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(dout) + orow * ld_do + c);
-                    d[0] = ld16<DT == 2>((unsigned short)(t.x & 0xffffu)); d[1] = ld16<DT == 2>((unsigned short)(t.x >> 16));
-                    d[2] = ld16<DT == 2>((unsigned short)(t.y & 0xffffu)); d[3] = ld16<DT == 2>((unsigned short)(t.y >> 16));
-                }
                 const float xh[4] = {xv[k].x * rstd, xv[k].y * rstd, xv[k].z * rstd, xv[k].w * rstd};
                 const float ww[4] = {wv[k].x, wv[k].y, wv[k].z, wv[k].w}, bb[4] = {bvv[k].x, bvv[k].y, bvv[k].z, bvv[k].w};
-                float sc[4] = {0.f, 0.f, 0.f, 0.f};
-                if (scale) {
-                    const float4 t = *reinterpret_cast<const float4 *>(scale + (long long)gidx * mod_ld + c);
-                    sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
-                }
+                const float ss[4] = {sc[k].x, sc[k].y, sc[k].z, sc[k].w};
                 float gg[4];
-                float *pas = &as[k].x, *pah = &ah[k].x, *paw = &aw[k].x, *pab = &ab[k].x;
+                float *paw = &aw[k].x, *pab = &ab[k].x;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float y = xh[e] * ww[e] + bb[e];     // LN output before modulation
-                    const float dy = d[e] * (1.0f + sc[e]);     // gradient w.r.t. y
-                    if (scale) { pas[e] += d[e] * y; pah[e] += d[e]; }
+                    const float dy = d[k][e] * (1.0f + ss[e]);     // gradient w.r.t. the LN output before modulation
+                    if constexpr (MOD) {
+                        (&as[k].x)[e] += d[k][e] * (xh[e] * ww[e] + bb[e]);
+                        (&ah[k].x)[e] += d[k][e];
+                    }
                     paw[e] += dy * xh[e];
                     pab[e] += dy;
                     gg[e] = dy * ww[e];
@@ -323,7 +312,7 @@ layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const 
         const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
         float *dxr = dx + (long long)m * ld_dx;
 #pragma unroll
-        for (int k = 0; k < kLnVec; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int c = (lane + 64 * k) * 4;
             if (c < C) {
                 float4 r;
@@ -339,15 +328,91 @@ layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const 
             }
         }
     }
-    flush_group();
+    // block reduction of the column sums, then one atomic per column
+    auto flush = [&](float4 (&acc)[NV], float *dst) {
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kLnVec; ++k) {
+        for (int k = 0; k < NV; ++k) *reinterpret_cast<float4 *>(&red[wv_id][(lane + 64 * k) * 4]) = acc[k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) unsafeAtomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    };
+    flush(aw, dw);
+    flush(ab, db);
+    if constexpr (MOD) {
+        flush(as, dscale + (long long)gidx * mod_ld);
+        flush(ah, dshift + (long long)gidx * mod_ld);
+    }
+}
+
+// Gated residual update of the decoder's image stream (backbone_vica.py:274-278,302,327,331):
+//   out[m, c] = x[m, c] + (1 + gate[m / gate_rows, c]) * y[yrow(m), c],   yrow(m) = (m / grp_in) * grp_out + grp_off + m % grp_in
+// x, out f32 (may alias), y 16-bit (the branch output, possibly interleaved with other rows: the camera token in front of each
+// frame's image tokens), gate f32 [G, C] or null.  One pass instead of cast + multiply + add.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+gated_resid_kernel(const float *__restrict__ x, const unsigned short *__restrict__ y, long long ldy, const float *__restrict__ gate,
+                   int gate_rows, float *__restrict__ out, int M, int C, int grp_in, int grp_out, int grp_off) {
+    const int C4 = C >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * C4) return;
+    const int m = (int)(idx / C4), c = (int)(idx - (long long)m * C4) * 4;
+    const long long yr = (long long)(m / grp_in) * grp_out + grp_off + (m % grp_in);
+    const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)m * C + c);
+    const uint2 t = *reinterpret_cast<const uint2 *>(y + yr * ldy + c);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gate) g = *reinterpret_cast<const float4 *>(gate + (long long)(m / gate_rows) * C + c);
+    float4 o;
+    o.x = xv.x + (1.0f + g.x) * ld16<BF16>((unsigned short)(t.x & 0xffffu));
+    o.y = xv.y + (1.0f + g.y) * ld16<BF16>((unsigned short)(t.x >> 16));
+    o.z = xv.z + (1.0f + g.z) * ld16<BF16>((unsigned short)(t.y & 0xffffu));
+    o.w = xv.w + (1.0f + g.w) * ld16<BF16>((unsigned short)(t.y >> 16));
+    *reinterpret_cast<float4 *>(out + (long long)m * C + c) = o;
+}
+
+// Backward of the branch side: dy[yrow(m), c] = dout[m, c] * (1 + gate) in 16 bits and dgate[g, c] += sum_m dout[m, c] * y[yrow(m), c]
+// (dx = dout needs no kernel).  blockIdx.y = gate group, blockIdx.x = chunk of its rows; wave per row, lane owns columns
+// lane*4 + 256 k; the group sums leave the block as one f32 atomic per column (as in layernorm_backward_kernel).
+template <bool BF16, int NV>
+__global__ void __launch_bounds__(256)
+gated_resid_backward_kernel(const float *__restrict__ dout, const unsigned short *__restrict__ y, long long ldy,
+                            const float *__restrict__ gate, int gate_rows, unsigned short *__restrict__ dy, long long lddy,
+                            float *__restrict__ dgate, int M, int C, int grp_in, int grp_out, int grp_off, int rows_per_chunk) {
+    __shared__ float red[4][NV * 256];
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    const int gidx = blockIdx.y;
+    const int g_lo = gidx * gate_rows, g_hi = min(M, g_lo + gate_rows);
+    const int m_lo = g_lo + blockIdx.x * rows_per_chunk, m_hi = min(g_hi, m_lo + rows_per_chunk);
+    if (m_lo >= m_hi) return;
+    float4 gt[NV], acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
         const int c = (lane + 64 * k) * 4;
-        if (c < C && m_lo < m_hi) {
-            unsafeAtomicAdd(dw + c + 0, aw[k].x); unsafeAtomicAdd(dw + c + 1, aw[k].y); unsafeAtomicAdd(dw + c + 2, aw[k].z); unsafeAtomicAdd(dw + c + 3, aw[k].w);
-            unsafeAtomicAdd(db + c + 0, ab[k].x); unsafeAtomicAdd(db + c + 1, ab[k].y); unsafeAtomicAdd(db + c + 2, ab[k].z); unsafeAtomicAdd(db + c + 3, ab[k].w);
+        gt[k] = (gate && c < C) ? *reinterpret_cast<const float4 *>(gate + (long long)gidx * C + c) : make_float4(0, 0, 0, 0);
+        acc[k] = make_float4(0, 0, 0, 0);
+    }
+    for (int m = m_lo + wv_id; m < m_hi; m += 4) {
+        const long long yr = (long long)(m / grp_in) * grp_out + grp_off + (m % grp_in);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c >= C) continue;
+            const float4 d = *reinterpret_cast<const float4 *>(dout + (long long)m * C + c);
+            if (gate) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(y + yr * ldy + c);
+                acc[k].x += d.x * ld16<BF16>((unsigned short)(t.x & 0xffffu)); acc[k].y += d.y * ld16<BF16>((unsigned short)(t.x >> 16));
+                acc[k].z += d.z * ld16<BF16>((unsigned short)(t.y & 0xffffu)); acc[k].w += d.w * ld16<BF16>((unsigned short)(t.y >> 16));
+            }
+            uint2 o;
+            o.x = (unsigned)st16<BF16>(d.x * (1.0f + gt[k].x)) | ((unsigned)st16<BF16>(d.y * (1.0f + gt[k].y)) << 16);
+            o.y = (unsigned)st16<BF16>(d.z * (1.0f + gt[k].z)) | ((unsigned)st16<BF16>(d.w * (1.0f + gt[k].w)) << 16);
+            *reinterpret_cast<uint2 *>(dy + yr * lddy + c) = o;
         }
     }
+    if (!gate) return;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) *reinterpret_cast<float4 *>(&red[wv_id][(lane + 64 * k) * 4]) = acc[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) unsafeAtomicAdd(dgate + (long long)gidx * C + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
 }  // namespace
@@ -453,13 +518,69 @@ extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do
     if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
     if (mod_rows <= 0) mod_rows = M;
     if (mod_ld <= 0) mod_ld = C;
-    // few, long-running waves: every wave ends with 2 C f32 atomics (dw, db), so their number sets the atomic traffic
-    dim3 grid(std::min(256, vs::cdiv(M, 4))), block(256);
-#define VS_LNB(DT_) hipLaunchKernelGGL(layernorm_backward_kernel<DT_>, grid, block, 0, stream, dout, (long long)ld_do, x, (long long)ldx, w, b, \
-                                      scale, mod_rows, mod_ld, dx, (long long)ld_dx, accumulate_dx, dw, db, dscale, dshift, M, C, eps,    \
-                                      grp_in, grp_out, grp_off)
-    if (do_dtype == 0) VS_LNB(0); else if (do_dtype == 1) VS_LNB(1); else VS_LNB(2);
+    // ~512 blocks of 4 waves (2 resident blocks per CU): enough waves to hide the row reductions' latency, few enough that the
+    // per-block column-sum atomics stay a few MB.  One grid row per modulation group.
+    const int G = scale ? vs::cdiv(M, mod_rows) : 1;
+    const int group_rows = scale ? mod_rows : M;
+    if (!scale) mod_rows = M;
+    const int chunks = std::max(1, std::min(512 / G, vs::cdiv(group_rows, 4)));
+    const int rows_per_chunk = vs::cdiv(group_rows, chunks);
+    VS_CHECK(G <= 65535, "vs_layernorm_backward: too many modulation groups (%d)", G);
+    dim3 grid(vs::cdiv(group_rows, rows_per_chunk), G), block(256);
+#define VS_LNB3(DT_, NV_, MOD_) hipLaunchKernelGGL((layernorm_backward_kernel<DT_, NV_, MOD_>), grid, block, 0, stream, dout, (long long)ld_do, x, \
+                                      (long long)ldx, w, b, scale, mod_rows, mod_ld, dx, (long long)ld_dx, accumulate_dx, dw, db, dscale, dshift, M, C, eps, \
+                                      grp_in, grp_out, grp_off, rows_per_chunk)
+#define VS_LNB2(DT_, NV_) { if (scale) VS_LNB3(DT_, NV_, true); else VS_LNB3(DT_, NV_, false); }
+#define VS_LNB(DT_) { if (C <= 256) VS_LNB2(DT_, 1) else if (C <= 512) VS_LNB2(DT_, 2) else if (C <= 768) VS_LNB2(DT_, 3) \
+                      else if (C <= 1024) VS_LNB2(DT_, 4) else VS_LNB2(DT_, 8) }
+    if (do_dtype == 0) VS_LNB(0) else if (do_dtype == 1) VS_LNB(1) else VS_LNB(2)
+#undef VS_LNB3
+#undef VS_LNB2
 #undef VS_LNB
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_gated_resid(const float *x, const void *y, int64_t ldy, const float *gate, int32_t gate_rows, float *out, int32_t M,
+                              int32_t C, int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && y && out, "vs_gated_resid: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gated_resid: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(M >= 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0, "vs_gated_resid: C and ldy must be multiples of 4");
+    VS_CHECK((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gate) & 15) == 0 && ((uintptr_t)y & 7) == 0, "vs_gated_resid: misaligned pointer");
+    if (M == 0) return 0;
+    if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
+    if (gate_rows <= 0) gate_rows = M;
+    dim3 grid((unsigned)vs::cdiv64((long long)M * (C / 4), 256)), block(256);
+    if (dtype == 2) hipLaunchKernelGGL(gated_resid_kernel<true>, grid, block, 0, stream, x, (const unsigned short *)y, (long long)ldy, gate, gate_rows, out, M, C, grp_in, grp_out, grp_off);
+    else hipLaunchKernelGGL(gated_resid_kernel<false>, grid, block, 0, stream, x, (const unsigned short *)y, (long long)ldy, gate, gate_rows, out, M, C, grp_in, grp_out, grp_off);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_gated_resid_backward(const float *dout, const void *y, int64_t ldy, const float *gate, int32_t gate_rows, void *dy,
+                                       int64_t lddy, float *dgate, int32_t M, int32_t C, int32_t grp_in, int32_t grp_out,
+                                       int32_t grp_off, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(dout && dy && (!gate || (y && dgate)), "vs_gated_resid_backward: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gated_resid_backward: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(M >= 0 && C > 0 && C % 4 == 0 && C <= 2048 && ldy % 4 == 0 && lddy % 4 == 0, "vs_gated_resid_backward: C (<= 2048), ldy, lddy must be multiples of 4");
+    VS_CHECK((((uintptr_t)dout | (uintptr_t)gate | (uintptr_t)dgate) & 15) == 0 && (((uintptr_t)y | (uintptr_t)dy) & 7) == 0, "vs_gated_resid_backward: misaligned pointer");
+    if (M == 0) return 0;
+    if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
+    if (!gate || gate_rows <= 0) gate_rows = M;
+    const int G = vs::cdiv(M, gate_rows);
+    VS_CHECK(G <= 65535, "vs_gated_resid_backward: too many gate groups (%d)", G);
+    const int chunks = std::max(1, std::min(1024 / G, vs::cdiv(gate_rows, 4)));
+    const int rows_per_chunk = vs::cdiv(gate_rows, chunks);
+    dim3 grid(vs::cdiv(gate_rows, rows_per_chunk), G), block(256);
+#define VS_GRB2(BF_, NV_) hipLaunchKernelGGL((gated_resid_backward_kernel<BF_, NV_>), grid, block, 0, stream, dout, (const unsigned short *)y, (long long)ldy, \
+                                          gate, gate_rows, (unsigned short *)dy, (long long)lddy, dgate, M, C, grp_in, grp_out, grp_off, rows_per_chunk)
+#define VS_GRB(BF_) { if (C <= 256) VS_GRB2(BF_, 1); else if (C <= 512) VS_GRB2(BF_, 2); else if (C <= 768) VS_GRB2(BF_, 3); \
+                      else if (C <= 1024) VS_GRB2(BF_, 4); else VS_GRB2(BF_, 8); }
+    if (dtype == 2) VS_GRB(true) else VS_GRB(false)
+#undef VS_GRB
+#undef VS_GRB2
     VS_HIP(hipGetLastError());
     return 0;
 }

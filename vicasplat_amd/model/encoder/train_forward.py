@@ -62,7 +62,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     # ---------------- video / camera decoder (backbone_vica.py:482-524, block :280-335) ----------------
     T = V
     inter = [x]
-    x = lin("backbone.decoder_embed", x).float().view(B, T, N1, -1)
+    x = lin("backbone.decoder_embed", x).float().view(BT * N1, -1)                                    # image stream, f32 [BT*N1, C]
     C = x.shape[-1]
     Hd = cfg.dec_num_heads
     ti, te = P["backbone.camera_intrinsic_token"], P["backbone.camera_extrinsic_token"]
@@ -70,30 +70,32 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     theta = float(cfg.temporal_rope_theta)
     M2 = N1 + 1
     for i in range(cfg.dec_depth):
+        # the elementwise work of the image stream lives in the HIP kernels: LayerNorm + AdaLN writes its rows straight behind
+        # each frame's camera-token row, and every residual update x + (1 + gate) * branch is one gated_resid pass
         nm = f"backbone.dec_blocks.{i}"
         cn = _ln_f32(P, nm + ".cam_norm1", cam)
         s1, b1, g1 = _lin_f32(P, nm + ".modulation1.proj", F.silu(cn)).chunk(3, -1)                   # [B,T,C] each
-        himg = lnm(nm + ".norm1", x.reshape(BT * N1, C), scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=dt)
-        hmix = torch.cat([cn.to(dt).reshape(BT, 1, C), himg.view(BT, N1, C)], 1)                      # camera token first, as the keys are ordered
-        qkv = A.RopeQKFn.apply(lin(nm + ".attn.qkv", hmix).reshape(BT * M2, 3 * C), tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta)
+        hmix = lnm(nm + ".norm1", x, scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=dt,
+                   lead=cn.to(dt).reshape(BT, C), lead_rows=N1)                                       # [BT*M2, C]: camera token first
+        qkv = A.RopeQKFn.apply(lin(nm + ".attn.qkv", hmix), tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta)
         att = A.AttentionFn.apply(qkv, B, Hd, T * M2, T * M2, T * M2, T * M2, None, tabs["kvlen"], 0)
-        o = lin(nm + ".attn.proj", att).float().view(B, T, M2, C)
-        x = x + (1 + g1[:, :, None]) * o[:, :, 1:]
-        cam = cam + o[:, :, 0]
+        x, o_cam = A.gated_resid(x, lin(nm + ".attn.proj", att), g1.reshape(BT, C), N1, N1, M2, 1)
+        cam = cam + o_cam.view(B, T, C)
         cn = _ln_f32(P, nm + ".cam_norm2", cam)
         s2, b2, g2, s3, b3, g3 = _lin_f32(P, nm + ".modulation2.proj", F.silu(cn)).chunk(6, -1)
-        # cross-neighbour attention (:152-191): q | k | v of frame t, keys gathered from frames t-1 / t+1 by row segments
-        himg = lnm(nm + ".norm2", x.reshape(BT * N1, C), scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        # cross-neighbour attention (:152-191): q | k | v of frame t (one GEMM over the stacked projq / projk / projv weights),
+        # keys gathered from frames t-1 / t+1 by row segments
+        himg = lnm(nm + ".norm2", x, scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=dt)
         ca = nm + ".cross_attn"
-        qkv = torch.cat([lin(ca + ".projq", himg), lin(ca + ".projk", himg), lin(ca + ".projv", himg)], -1)
-        qkv = A.RopeQKFn.apply(qkv, tabs["pos_img"], None, Hd, C, 100.0, 1.0)
+        wqkv = torch.cat([P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]], 0)
+        bqkv = torch.cat([P[ca + ".projq.bias"], P[ca + ".projk.bias"], P[ca + ".projv.bias"]], 0)
+        qkv = A.RopeQKFn.apply(A.linear(himg, wqkv, bqkv, dt), tabs["pos_img"], None, Hd, C, 100.0, 1.0)
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
-        x = x + (1 + g2[:, :, None]) * lin(ca + ".proj", att).float().view(B, T, N1, C)
-        himg = lnm(nm + ".norm3", x.reshape(BT * N1, C), scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
-        m = lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", himg))).float().view(B, T, N1, C)
-        x = x + (1 + g3[:, :, None]) * m
+        x = A.gated_resid(x, lin(ca + ".proj", att), g2.reshape(BT, C), N1)
+        himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        x = A.gated_resid(x, lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", himg))), g3.reshape(BT, C), N1)
         cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
-        inter.append(x.reshape(BT, N1, C))
+        inter.append(x.view(BT, N1, C))
     inter[-1] = lnm("backbone.dec_norm", inter[-1], out_dtype=torch.float32)
     cam = _ln_f32(P, "backbone.camera_dec_norm", cam)
     inter = [t[:, :-1] for t in inter]                                                                # drop the intrinsic token (:570-572)

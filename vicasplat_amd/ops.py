@@ -310,6 +310,37 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gated_resid(x: torch.Tensor, y: torch.Tensor, gate: Optional[torch.Tensor] = None, gate_rows: int = 0, *, grp_in: int = 0,
+                grp_out: int = 0, grp_off: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x + (1 + gate[row // gate_rows]) * y[yrow(row)]: x f32 [M,C] contiguous, y 16-bit [rows,C] (row stride any), gate f32
+    [G,C] or None; yrow(m) = (m // grp_in) * grp_out + grp_off + m % grp_in picks y's rows (identity by default)."""
+    dev = L.require_device(x, y, gate, out)
+    assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float32 and y.stride(1) == 1 and y.shape[1] == x.shape[1]
+    assert gate is None or (gate.is_contiguous() and gate.dtype == torch.float32 and gate.shape[1] == x.shape[1])
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gated_resid(L.ptr(x), L.ptr(y), y.stride(0), L.ptr(gate), gate_rows, L.ptr(out), x.shape[0], x.shape[1], grp_in,
+                                    grp_out, grp_off, _DT[y.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_gated_resid")
+    return out
+
+
+def gated_resid_backward(dout: torch.Tensor, y: torch.Tensor, gate: Optional[torch.Tensor], gate_rows: int, dy: torch.Tensor, *,
+                         grp_in: int = 0, grp_out: int = 0, grp_off: int = 0) -> Optional[torch.Tensor]:
+    """Branch-side backward of gated_resid: writes dy[yrow(m)] = dout[m] * (1 + gate) into the given 16-bit buffer (other rows are
+    left alone) and returns dgate [G,C] f32 (None without a gate)."""
+    dev = L.require_device(dout, y, gate, dy)
+    assert dout.dim() == 2 and dout.is_contiguous() and dout.dtype == torch.float32 and dy.stride(1) == 1 and dy.dtype == y.dtype
+    dgate = None if gate is None else torch.zeros_like(gate)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gated_resid_backward(L.ptr(dout), L.ptr(y), y.stride(0), L.ptr(gate), gate_rows, L.ptr(dy), dy.stride(0),
+                                             L.ptr(dgate), dout.shape[0], dout.shape[1], grp_in, grp_out, grp_off, _DT[y.dtype],
+                                             L.stream_ptr(dev))
+    L.check(rc, "vs_gated_resid_backward")
+    return dgate
+
+
 def gelu16(z: torch.Tensor) -> torch.Tensor:
     """gelu_erf(z) on a contiguous 16-bit tensor (numel % 8 == 0)."""
     dev = L.require_device(z)
