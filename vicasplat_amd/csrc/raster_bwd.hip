@@ -6,9 +6,10 @@
 //
 //   K1 render_backward_kernel : per (camera, tile) back-to-front replay from final_T / n_contrib; gradients w.r.t. the
 //        screen-space mean (NDC units), conic (true partials), opacity, colour and depth of every (camera, Gaussian)
-//        are accumulated with hardware f32 atomics.  Same 4-wave quadrant layout and wave-uniform footprint cull as
-//        the forward, so a wave only touches the Gaussians that can reach its 8x8 pixels; lanes that do not
-//        contribute issue no atomics.
+//        are summed over the wave's 8x8 pixels in registers (DPP row sums + 4 readlanes) and leave the wave as ONE f32
+//        atomic per component -- a pixel-sized Gaussian is seen by tens of lanes of a wave, and per-lane atomics (the
+//        upstream scheme) made this kernel 8x the forward.  Same 4-wave quadrant layout and wave-uniform footprint
+//        cull as the forward, so a wave only touches the Gaussians that can reach its pixels.
 //   K2 preprocess_backward_kernel : thread = Gaussian of a scene, loops over the scene's cameras and sums the
 //        per-camera contributions in registers -> ONE plain store per output element (no atomics over views), plus a
 //        block-reduced atomic for the per-camera twist gradient dL/dtau = (rho, theta), T_cw' = Exp(tau) T_cw.
@@ -29,6 +30,17 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 
 // per-(camera,Gaussian) gradient record written by K1: mean2D.xy | conic.xyz | opacity | rgb | depth
 constexpr int kG = 10;
+
+// sum over the 64 lanes of a wave, returned in every lane: quad / half-row / row DPP adds, then the 4 row totals by readlane
+__device__ __forceinline__ float wave_total(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    const int iv = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+}
 
 __global__ void __launch_bounds__(256)
 render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
@@ -96,38 +108,50 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
             if (posn >= wave_max) continue;
             const float4 q0 = sq0[j];
             if (fabsf(q0.x - qcx) > q0.z + 3.5f || fabsf(q0.y - qcy) > q0.w + 3.5f) continue;
-            if (posn >= last) continue;
+            // per-lane contribution test (the wave stays converged: the sums below run over all 64 lanes)
             const float4 q1 = sq1[j];
             const float dx = q0.x - pixfx, dy = q0.y - pixfy;
             const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float G = __expf(power);
+            const float G = __expf(fminf(power, 0.0f));
             const float alpha = fminf(0.99f, q1.w * G);
-            if (alpha < 1.0f / 255.0f) continue;
+            const bool act = posn < last && power <= 0.0f && alpha >= 1.0f / 255.0f;
+            if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
             const float4 q2 = sq2[j];
-            T = T / (1.0f - alpha);
-            const float dch = alpha * T;
-            float dL_dalpha = 0.f;
-            acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r; last_r = q2.x; dL_dalpha += (q2.x - acc_r) * dLr;
-            acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g; last_g = q2.y; dL_dalpha += (q2.y - acc_g) * dLg;
-            acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b; last_b = q2.z; dL_dalpha += (q2.z - acc_b) * dLb;
-            acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d; last_d = q2.w; dL_dalpha += (q2.w - acc_d) * dLd;
-            dL_dalpha *= T;
-            last_alpha = alpha;
-            dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
-            const float dL_dG = q1.w * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            float *r = gr + (size_t)sid[j] * kG;
-            atomicAdd(r + 0, dL_dG * (-gdx * q1.x - gdy * q1.y) * ddelx_dx);
-            atomicAdd(r + 1, dL_dG * (-gdy * q1.z - gdx * q1.y) * ddely_dy);
-            atomicAdd(r + 2, -0.5f * gdx * dx * dL_dG);
-            atomicAdd(r + 3, -1.0f * gdx * dy * dL_dG);
-            atomicAdd(r + 4, -0.5f * gdy * dy * dL_dG);
-            atomicAdd(r + 5, G * dL_dalpha);
-            atomicAdd(r + 6, dch * dLr);
-            atomicAdd(r + 7, dch * dLg);
-            atomicAdd(r + 8, dch * dLb);
-            atomicAdd(r + 9, dch * dLd);
+            float v[kG];
+#pragma unroll
+            for (int e = 0; e < kG; ++e) v[e] = 0.f;
+            if (act) {
+                T = T / (1.0f - alpha);
+                const float dch = alpha * T;
+                float dL_dalpha = 0.f;
+                acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r; last_r = q2.x; dL_dalpha += (q2.x - acc_r) * dLr;
+                acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g; last_g = q2.y; dL_dalpha += (q2.y - acc_g) * dLg;
+                acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b; last_b = q2.z; dL_dalpha += (q2.z - acc_b) * dLb;
+                acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d; last_d = q2.w; dL_dalpha += (q2.w - acc_d) * dLd;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
+                const float dL_dG = q1.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                v[0] = dL_dG * (-gdx * q1.x - gdy * q1.y) * ddelx_dx;
+                v[1] = dL_dG * (-gdy * q1.z - gdx * q1.y) * ddely_dy;
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -1.0f * gdx * dy * dL_dG;
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = G * dL_dalpha;
+                v[6] = dch * dLr;
+                v[7] = dch * dLg;
+                v[8] = dch * dLb;
+                v[9] = dch * dLd;
+            }
+#pragma unroll
+            for (int e = 0; e < kG; ++e) v[e] = wave_total(v[e]);
+            if (lane < kG) {  // lane e adds component e: one 10-lane atomic instruction per (wave, Gaussian)
+                float mine = v[0];
+#pragma unroll
+                for (int e = 1; e < kG; ++e) mine = lane == e ? v[e] : mine;
+                atomicAdd(gr + (size_t)sid[j] * kG + lane, mine);
+            }
         }
     }
 }
