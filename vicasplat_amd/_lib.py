@@ -13,7 +13,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libvicasplat_hip.so")
+_SO = os.environ.get("VICASPLAT_HIP_LIB") or os.path.join(_HERE, "libvicasplat_hip.so")   # (override: A/B runs of two builds)
 _lock = threading.Lock()
 _lib = None
 
