@@ -94,22 +94,13 @@ __device__ __forceinline__ KeyList key_list(const AttnBwdArgs &a, int b) {
 
 // stage 64 rows x 64 halfs: row-major image (ROW stride) and, optionally, the transposed image (TROW stride); rows >= nvalid are
 // zero.  256 threads: thread -> (row pair rp = tid & 31, 8-half chunk c = tid >> 5).
-// The global loads (tile_load) and the LDS writes (tile_store) are separate so that the K loops can fetch tile t+1 into registers
-// while the MFMAs of tile t run.
-struct TileRegs { uint4 va, vb; };
-template <class RowFn>
-__device__ __forceinline__ TileRegs tile_load(const unsigned short *src, int ld, int col0, RowFn row_of, int nvalid, int tid) {
+template <bool WANT_ROWMAJOR, bool WANT_T, class RowFn>
+__device__ __forceinline__ void stage_tile(const unsigned short *src, int ld, int col0, RowFn row_of, int nvalid, unsigned short *sR,
+                                           unsigned short *sT, int tid) {
     const int rp = tid & 31, c = tid >> 5;
-    TileRegs t;
-    t.va = t.vb = make_uint4(0, 0, 0, 0);
-    if (2 * rp < nvalid) t.va = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp) * ld + col0 + c * 8);
-    if (2 * rp + 1 < nvalid) t.vb = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp + 1) * ld + col0 + c * 8);
-    return t;
-}
-template <bool WANT_ROWMAJOR, bool WANT_T>
-__device__ __forceinline__ void tile_store(const TileRegs &t, unsigned short *sR, unsigned short *sT, int tid) {
-    const int rp = tid & 31, c = tid >> 5;
-    const uint4 va = t.va, vb = t.vb;
+    uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+    if (2 * rp < nvalid) va = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp) * ld + col0 + c * 8);
+    if (2 * rp + 1 < nvalid) vb = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp + 1) * ld + col0 + c * 8);
     if constexpr (WANT_ROWMAJOR) {
         *reinterpret_cast<uint4 *>(&sR[(2 * rp) * ROW + c * 8]) = va;
         *reinterpret_cast<uint4 *>(&sR[(2 * rp + 1) * ROW + c * 8]) = vb;
@@ -150,40 +141,17 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
     f4 dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = f4{0.f, 0.f, 0.f, 0.f};
-    auto fetch = [&](int kt, TileRegs &tk, TileRegs &tv) {
-        auto rk = [&](int r) { return kl.row(kt + r); };
-        tk = tile_load(a.k, a.ldk, h * HD, rk, kl.Lk - kt, tid);
-        tv = tile_load(a.v, a.ldv, h * HD, rk, kl.Lk - kt, tid);
-    };
-    // keys at positions >= the longest key prefix of the workgroup's queries are masked for all of them: stop there
-    // (the camera-blocked causal mask of the video attention hides, on average, half of the keys)
-    __shared__ int s_kmax;
-    if (tid == 0) s_kmax = 0;
-    __syncthreads();
-    {
-        int wm = my_len;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wm = max(wm, __shfl_xor(wm, o, 64));
-        if (lane == 0) atomicMax(&s_kmax, wm);
-    }
-    __syncthreads();
-    const int kmax = s_kmax;
-    const bool wave_live = q0 + wid * 16 < a.Lq;   // a wave whose 16 queries are all padding only helps with the staging
-    TileRegs tk, tv;
-    fetch(0, tk, tv);
-    for (int kt = 0; kt < kmax; kt += TB) {
+    auto krow = [&](int j) { return kl.row(j); };
+    for (int kt = 0; kt < kl.Lk; kt += TB) {
         __syncthreads();
-        tile_store<true, true>(tk, sK, sKT, tid);
-        tile_store<true, false>(tv, sV, nullptr, tid);
+        auto rk = [&](int r) { return krow(kt + r); };
+        stage_tile<true, true>(a.k, a.ldk, h * HD, rk, kl.Lk - kt, sK, sKT, tid);
+        stage_tile<true, false>(a.v, a.ldv, h * HD, rk, kl.Lk - kt, sV, nullptr, tid);
         __syncthreads();
-        if (kt + TB < kmax) fetch(kt + TB, tk, tv);   // in flight behind this tile's MFMAs
-        if (!wave_live) continue;
-        const int nbv = min(4, (kmax - kt + 15) >> 4);   // 16-key blocks of this tile that hold visible keys
         uint4 dsf[2];
         f4 ds[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            if (nb >= nbv) { ds[nb] = f4{0.f, 0.f, 0.f, 0.f}; continue; }
             f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -211,7 +179,6 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if (2 * ks >= nbv) continue;   // both 16-key blocks of this k-step are invisible
                 const unsigned short *kr = &sKT[(db * 16 + c16) * TROW + g * 4];
                 const uint2 lo = *reinterpret_cast<const uint2 *>(kr + (2 * ks) * 16);
                 const uint2 hi = *reinterpret_cast<const uint2 *>(kr + (2 * ks + 1) * 16);
@@ -253,52 +220,23 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     f4 dk[4], dv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f4{0.f, 0.f, 0.f, 0.f};
-    TileRegs tq, tdo;
-    float nL = INFINITY, nD = 0.f;
-    int nLen = 0;
-    auto fetch = [&](int qt) {
+    for (int qt = 0; qt < a.Lq; qt += TB) {
+        __syncthreads();
         auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
-        tq = tile_load(a.q, a.ldq, h * HD, rq, a.Lq - qt, tid);
-        tdo = tile_load(a.dout, a.lddo, h * HD, rq, a.Lq - qt, tid);
+        stage_tile<true, true>(a.q, a.ldq, h * HD, rq, a.Lq - qt, sQ, sQT, tid);
+        stage_tile<true, true>(a.dout, a.lddo, h * HD, rq, a.Lq - qt, sDO, sDOT, tid);
         if (tid < TB) {
             const int qi = qt + tid;
             const bool ok = qi < a.Lq;
             const long long row = b * a.q_batch_rows + (ok ? qi : a.Lq - 1);
-            nL = ok ? a.lse[row * a.H + h] : INFINITY;
-            nD = ok ? a.delta[row * a.H + h] : 0.f;
-            nLen = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
+            sL[tid] = ok ? a.lse[row * a.H + h] : INFINITY;
+            sD[tid] = ok ? a.delta[row * a.H + h] : 0.f;
+            sLen[tid] = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
         }
-    };
-    // queries whose key prefix ends at or before this workgroup's first key cannot see any of its keys: skip the leading
-    // query tiles that consist of such queries only (exact for the camera-blocked causal mask, conservative for any other)
-    __shared__ int s_qmin;
-    if (tid == 0) s_qmin = a.q_kvlen ? a.Lq : 0;
-    __syncthreads();
-    if (a.q_kvlen) {
-        int first = a.Lq;
-        for (int qi = tid; qi < a.Lq; qi += 256)
-            if (a.q_kvlen[(long long)b * a.Lq + qi] > kt0) { first = qi; break; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
-        if (lane == 0) atomicMin(&s_qmin, first);
-    }
-    __syncthreads();
-    const int qt_begin = (s_qmin / TB) * TB;
-    const bool wave_live = kt0 + wid * 16 < kl.Lk;   // a wave whose 16 keys are all padding only helps with the staging
-    if (qt_begin < a.Lq) fetch(qt_begin);
-    for (int qt = qt_begin; qt < a.Lq; qt += TB) {
         __syncthreads();
-        tile_store<true, true>(tq, sQ, sQT, tid);
-        tile_store<true, true>(tdo, sDO, sDOT, tid);
-        if (tid < TB) { sL[tid] = nL; sD[tid] = nD; sLen[tid] = nLen; }
-        __syncthreads();
-        if (qt + TB < a.Lq) fetch(qt + TB);   // in flight behind this tile's MFMAs
-        if (!wave_live) continue;
-        const int nqv = min(4, (a.Lq - qt + 15) >> 4);   // 16-query blocks of this tile that hold real queries
         f4 p[4], ds[4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-            if (qb >= nqv) { p[qb] = ds[qb] = f4{0.f, 0.f, 0.f, 0.f}; continue; }
             f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -328,7 +266,6 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if (2 * ks >= nqv) continue;   // both 16-query blocks of this k-step are padding
                 const unsigned short *dr = &sDOT[(db * 16 + c16) * TROW + g * 4], *qr = &sQT[(db * 16 + c16) * TROW + g * 4];
                 const uint2 dlo = *reinterpret_cast<const uint2 *>(dr + (2 * ks) * 16), dhi = *reinterpret_cast<const uint2 *>(dr + (2 * ks + 1) * 16);
                 const uint2 qlo = *reinterpret_cast<const uint2 *>(qr + (2 * ks) * 16), qhi = *reinterpret_cast<const uint2 *>(qr + (2 * ks + 1) * 16);
@@ -345,13 +282,8 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
         float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            if (a.kv_seg) {  // gathered key lists overlap between batch items (a frame is the neighbour of two others): accumulate
-                unsafeAtomicAdd(pk + db * 16, dk[db][r]);
-                unsafeAtomicAdd(pv + db * 16, dv[db][r]);
-            } else {         // every key row belongs to exactly one workgroup: plain stores (f32 atomics run at a tenth of their rate)
-                pk[db * 16] = dk[db][r];
-                pv[db * 16] = dv[db][r];
-            }
+            unsafeAtomicAdd(pk + db * 16, dk[db][r]);
+            unsafeAtomicAdd(pv + db * 16, dv[db][r]);
         }
     }
 }
