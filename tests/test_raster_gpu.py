@@ -362,3 +362,27 @@ def test_backward_through_render_cuda_native_layouts():
     assert np.allclose(g33, np.transpose(g33, (0, 2, 1)))  # symmetric spread
     g6 = np.stack([g33[:, 0, 0], 2 * g33[:, 0, 1], 2 * g33[:, 0, 2], g33[:, 1, 1], 2 * g33[:, 1, 2], g33[:, 2, 2]], -1)
     _close(g6, e_c, "covariances", 3e-3)
+
+
+@pytest.mark.gpu
+def test_differentiated_renders_do_not_accumulate_memory():
+    """Repeated render + backward (a training loop, or the 100-iteration pose alignment of evaluation) must not grow the live
+    device memory: the autograd node may not hold its own outputs (they hold it)."""
+    import gc
+    from vicasplat_amd.model.decoder.cuda_splatting import render_cuda
+    d = _dev()
+    sc = rr.synthetic_scene(V=1, res=64, Vt=2, seed=5)
+    T = lambda a, g=False: torch.tensor(a, dtype=torch.float32, device=d).requires_grad_(g)
+    base = (T(sc["means"]), T(sc["covariances"]), T(sc["harmonics"]), T(sc["opacities"]))
+    cam = (T(sc["extrinsics"]), T(sc["intrinsics"]), T(sc["near"]), T(sc["far"]))
+    live = []
+    for it in range(6):
+        m, cv, sh, op = [(b * 1.0).requires_grad_() for b in base]     # fresh graph leaves every iteration, as a model output would be
+        big = torch.zeros(1 << 22, device=d, requires_grad=True)      # 16 MB hanging off the graph of the means: leaks show up clearly
+        img, dep = render_cuda(*cam, (64, 64), torch.zeros(2, 3, device=d), m + big[:3].sum() * 0, cv, sh, op)
+        (img.sum() + dep.sum()).backward()
+        del m, cv, sh, op, big, img, dep
+        gc.collect()
+        torch.cuda.synchronize()
+        live.append(torch.cuda.memory_allocated(d))
+    assert live[-1] <= live[1], live

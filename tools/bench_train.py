@@ -27,9 +27,16 @@ for _ in range(a.warmup):
     r = callers.training_step(enc, dec, batch, opt)
 st0 = dict(torch.cuda.memory_stats())
 torch.cuda.synchronize(); t0 = time.perf_counter()
+per_step = []
 for _ in range(a.steps):
+    ts = time.perf_counter(); m0 = torch.cuda.memory_stats()["num_device_alloc"]
     r = callers.training_step(enc, dec, batch, opt)
+    if os.environ.get("VS_TRAIN_STEP_TIMES"):      # per-step wall time, device mallocs, live GB after the step (adds one sync per step)
+        torch.cuda.synchronize()
+        per_step.append((round((time.perf_counter() - ts) * 1e3, 1), torch.cuda.memory_stats()["num_device_alloc"] - m0,
+                         round(torch.cuda.memory_allocated() / 2**30, 2)))
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+if per_step: print("per-step (ms, device mallocs, live GB):", per_step)
 print(json.dumps(dict(config="re10k_8view training step fwd+bwd+AdamW", scenes=B, views=V, targets=Vt, ms_per_step=round(dt * 1e3, 1),
                       scenes_per_s=round(B / dt, 3), loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),

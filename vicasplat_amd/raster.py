@@ -95,8 +95,13 @@ class _Rasterize(torch.autograd.Function):
                                  background, cam_scene, H, W, sh_degree, flags)
         color, radii, depth, opacity, n_touched = outs
         ctx.inp, ctx.out, ctx.alloc = st["inp"], st["out"], st["alloc"]
+        # inputs whose device pointers sit in ctx.inp.  NO output tensor may be stored on ctx directly: an output holds its
+        # grad_fn (this node) and the node would hold the output -- a cycle through C++ references that Python's collector never
+        # sees, i.e. one leaked copy of the scene's Gaussians (and of everything their graph saved) per differentiated render.
+        # The backward needs exactly one output, radii (ctx.out.radii): it goes through save_for_backward.
         ctx.keep = (means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
-                    cam_scene, projmatrix_raw, color, depth, opacity, radii)
+                    cam_scene, projmatrix_raw)
+        ctx.save_for_backward(radii)
         ctx.want_tau = theta is not None or rho is not None
         ctx.dims = st["dims"]
         ctx.num_rendered = st["num_rendered"]
@@ -109,7 +114,9 @@ class _Rasterize(torch.autograd.Function):
         if not hasattr(lib, "vs_raster_backward"):
             raise RuntimeError("libvicasplat_hip.so was built without vs_raster_backward")
         (means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background, cam_scene,
-         projmatrix_raw, *_rest) = ctx.keep
+         projmatrix_raw) = ctx.keep
+        (radii,) = ctx.saved_tensors               # keeps the buffer behind ctx.out.radii alive
+        ctx.out.radii = L.ptr(radii)
         S, P, Cn, M, H, W, cov33 = ctx.dims
         dev = means3D.device
         g_color = _f32c(g_color) if g_color is not None else torch.zeros((Cn, 3, H, W), dtype=torch.float32, device=dev)
