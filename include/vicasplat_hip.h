@@ -259,13 +259,13 @@ int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M,
 /* General form of the two above: ntaps = 0 (plain) or 1..9 (taps), plus an optional workspace of >= slices * max(ntaps, 1) * M * N
  * floats (slices = ksplit, or 2 when ksplit == 1 on the 128x128 tiling; 16-byte aligned).  With it the K slices store partial tiles
  * and a second kernel sums them into out -- f32 atomics sustain ~0.3 TB/s on MI355X, plain stores ten times that -- without it
- * they meet through atomics as above.  out is added to in both modes.
+ * they meet through atomics as above.  out is added to (accumulate != 0) or, workspace mode only, overwritten (accumulate == 0).
  * a_slice_stride / w_slice_stride (elements): 0 = K slice s is columns [s K/ksplit, (s+1) K/ksplit) of A / W; > 0 = slice-blocked
  * operands [slice][channel][K/ksplit (+ halo)] as vs_transpose16_ex writes them: slice s is columns [0, K/ksplit) of the matrix at
  * A + s * a_slice_stride.  Blocking keeps the rows a workgroup walks KBs apart instead of the whole reduction length (MBs). */
 int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
                   int64_t a_slice_stride, int64_t w_slice_stride, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps,
-                  int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, vs_stream_t stream);
+                  int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
 /* vs_transpose16 with extras: colsum (nullable, f32 [C], overwritten) = column sums of the input, i.e. the bias gradient rides on
  * the transpose of dY that the weight-gradient GEMM needs anyway (dtype 1 f16 / 2 bf16); border_h, border_w > 0: the R input rows

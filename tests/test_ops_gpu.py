@@ -527,10 +527,18 @@ def test_gemm_wgrad_taps_and_errors():
                 want2 = torch.stack([a.double() @ wfull[:, 32 + sh:32 + sh + K].double().t() for sh in shifts])
                 assert (out2.double() - want2).abs().max() <= 2e-5 * want2.abs().max() + 2e-5
     a = torch.zeros(256, 256, dtype=torch.float16, device=d); o = torch.zeros(256, 256, device=d); ws = torch.zeros(16, device=d)
-    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(a), L.ptr(o), 256, 256, 256, 256, 256, 256, 0, 0, 0, None, 0, 2, 1, L.ptr(ws), 64, L.stream_ptr(d))
+    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(a), L.ptr(o), 256, 256, 256, 256, 256, 256, 0, 0, 0, None, 0, 2, 1, L.ptr(ws), 64, 1, L.stream_ptr(d))
     assert rc != 0 and b"workspace" in L.lib().vs_last_error()
-    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(a), L.ptr(o), 256, 256, 256, 256, 256, 256, 0, 0, 0, None, 3, 2, 1, None, 0, L.stream_ptr(d))
+    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(a), L.ptr(o), 256, 256, 256, 256, 256, 256, 0, 0, 0, None, 3, 2, 1, None, 0, 1, L.stream_ptr(d))
     assert rc != 0 and b"shifts" in L.lib().vs_last_error()
+    # accumulate = 0 overwrites (workspace mode only)
+    a = (torch.randn(256, 512, generator=g) / 16).half().to(d); w = torch.randn(256, 512, generator=g).half().to(d)
+    o = torch.full((256, 256), 1e9, device=d)
+    ops.gemm_wgrad(a, w, o, 2, accumulate=False)
+    want = a.double() @ w.double().t()
+    assert (o.double() - want).abs().max() <= 2e-5 * want.abs().max() + 2e-5
+    rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(w), L.ptr(o), 256, 256, 512, 512, 512, 256, 0, 0, 0, None, 0, 2, 1, None, 0, 0, L.stream_ptr(d))
+    assert rc != 0 and b"accumulate" in L.lib().vs_last_error()
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

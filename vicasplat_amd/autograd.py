@@ -17,39 +17,51 @@ from . import ops
 
 
 class LinearFn(torch.autograd.Function):
-    """y16 = x @ w^T + b on the MFMA GEMM; backward = dgrad / wgrad on the same kernels (ops.linear_backward)."""
+    """y16 = x @ w^T + b on the MFMA GEMM; backward = dgrad / wgrad on the same kernels (ops.linear_backward).
+    rope = (pos, kind, H, C, base2d, theta1d): w is a packed q | k | v projection and the rotary embedding of q and k runs in the
+    GEMM epilogue (vs_gemm_qkv_rope); the backward applies the inverse rotation to dq | dk IN PLACE on the incoming gradient
+    (that tensor is produced by AttentionFn.backward for this node alone) before the usual dgrad / wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, b, dt):
+    def forward(ctx, x, w, b, dt, rope):
         K = x.shape[-1]
         x16 = x.reshape(-1, K).to(dt).contiguous()
         w16 = w.detach().to(dt).contiguous()
+        bf = None if b is None else b.detach().float().contiguous()
         y = torch.empty((x16.shape[0], w16.shape[0]), dtype=dt, device=x.device)
-        ops.gemm(x16, w16, None if b is None else b.detach().float().contiguous(), y, ops.EPI_STORE16)
+        if rope is None:
+            ops.gemm(x16, w16, bf, y, ops.EPI_STORE16)
+        else:
+            pos, kind, H, C, base2d, theta1d = rope
+            ops.gemm_qkv_rope(x16, w16, bf, y, C, pos, kind, base2d, theta1d)
         ctx.save_for_backward(x16, w16)
-        ctx.meta = (x.shape, x.dtype, b is not None)
+        ctx.meta = (x.shape, x.dtype, b is not None, rope)
         return y.view(*x.shape[:-1], w16.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x16, w16 = ctx.saved_tensors
-        xshape, xdtype, has_b = ctx.meta
+        xshape, xdtype, has_b, rope = ctx.meta
         dy16 = dy.reshape(-1, dy.shape[-1]).to(w16.dtype).contiguous()
+        if rope is not None:
+            pos, kind, H, C, base2d, theta1d = rope
+            ops.rope_qk(dy16, H, C, pos, kind, base2d, theta1d, inverse=True)
         dx, dw, db = ops.linear_backward(dy16, x16, w16, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
                                          need_db=has_b and ctx.needs_input_grad[2])
-        return (None if dx is None else dx.view(xshape).to(xdtype)), dw, db, None
+        return (None if dx is None else dx.view(xshape).to(xdtype)), dw, db, None, None
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype, rope=None) -> torch.Tensor:
     """nn.Linear in the operand dtype `dt`.  K must be a multiple of 64 for the MFMA kernels; tiny odd shapes (the 9 -> C
     intrinsic embedding) stay on torch in f32."""
     K = x.shape[-1]
     if K % 64 != 0:
+        assert rope is None
         if K < 32:
             return torch.nn.functional.linear(x.float(), w, b).to(dt)
         pad = (K + 63) // 64 * 64 - K        # e.g. the 96-channel reassemble stage: zero-pad the reduction dimension
         x, w = torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(w, (0, pad))
-    return LinearFn.apply(x, w, b, dt)
+    return LinearFn.apply(x, w, b, dt, rope)
 
 
 class LayerNormModFn(torch.autograd.Function):
@@ -149,34 +161,42 @@ class AttentionFn(torch.autograd.Function):
 
 
 class Conv3x3Fn(torch.autograd.Function):
-    """nn.Conv2d(k=3, s=1|2, p=1) on NHWC 16-bit activations with the ResidualConvUnit's activation-before-conv fused
-    (relu_in); w is the module's [Cout, Cin, 3, 3] f32 parameter.  Backward: ops.conv3x3_backward.  The stride-2 conv is
-    the stride-1 conv sampled at even pixels, so its backward is the stride-1 backward of the zero-dilated gradient."""
+    """nn.Conv2d(k=3, s=1|2, p=1) on NHWC 16-bit activations with the ResidualConvUnit's activation-before-conv (relu_in), the
+    unit's skip connection (residual, added to the output) and a trailing ReLU (relu_out) fused into the kernel; w is the module's
+    [Cout, Cin, 3, 3] f32 parameter.  Backward: ops.conv3x3_backward.  The stride-2 conv is the stride-1 conv sampled at even
+    pixels, so its backward is the stride-1 backward of the zero-dilated gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu_in, stride):
+    def forward(ctx, x, w, b, relu_in, stride, residual, relu_out):
         dt = x.dtype
         wp = ops.pack_conv3x3_weight(w, dt)
         x = x.contiguous()
-        y = ops.conv3x3_nhwc(x, wp, None if b is None else b.detach().float().contiguous(), relu_in=relu_in, stride=stride)
-        ctx.save_for_backward(x, wp)
-        ctx.meta = (relu_in, b is not None, stride)
+        res = None if residual is None else residual.contiguous()
+        y = ops.conv3x3_nhwc(x, wp, None if b is None else b.detach().float().contiguous(), residual=res, relu_in=relu_in,
+                             relu_out=relu_out, stride=stride)
+        ctx.save_for_backward(x, wp, y if relu_out else None)
+        ctx.meta = (relu_in, b is not None, stride, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wp = ctx.saved_tensors
-        relu_in, has_b, stride = ctx.meta
+        x, wp, y = ctx.saved_tensors
+        relu_in, has_b, stride, has_res = ctx.meta
+        dy = dy.contiguous()
+        if y is not None:                                  # trailing ReLU: gradient only where the output is positive
+            dy = ops.relu_mask_(dy.clone(), y)
+        dres = dy if has_res else None
         if stride != 1:
             full = torch.zeros(x.shape[:3] + (dy.shape[3],), dtype=dy.dtype, device=dy.device)
             full[:, ::stride, ::stride] = dy
             dy = full
-        dx, dw, db = ops.conv3x3_backward(dy.contiguous(), x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0])
-        return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None, None
+        dx, dw, db = ops.conv3x3_backward(dy, x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0])
+        return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None, None, dres, None
 
 
-def conv3x3(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu_in: bool = False, stride: int = 1) -> torch.Tensor:
-    return Conv3x3Fn.apply(x_nhwc, w, b, relu_in, stride)
+def conv3x3(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], relu_in: bool = False, stride: int = 1,
+            residual: Optional[torch.Tensor] = None, relu_out: bool = False) -> torch.Tensor:
+    return Conv3x3Fn.apply(x_nhwc, w, b, relu_in, stride, residual, relu_out)
 
 
 class Upsample2xFn(torch.autograd.Function):

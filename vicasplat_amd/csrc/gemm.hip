@@ -359,7 +359,7 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
 // out[t][m, n] += sum_s partials[((s * ntaps + t) * M + m) * N + n]: second stage of a weight-gradient GEMM with a workspace.
 template <int VEC>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out, int M, int N, int ntaps,
-                                                            int ks, long long ldo, long long tap_out_stride) {
+                                                            int ks, long long ldo, long long tap_out_stride, int accumulate) {
     const int Nv = N / VEC;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long per_tap = (long long)M * Nv;
@@ -377,13 +377,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restr
             const float4 v = *reinterpret_cast<const float4 *>(p + s * slice);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        float4 c = *reinterpret_cast<float4 *>(o);
-        c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
-        *reinterpret_cast<float4 *>(o) = c;
+        if (accumulate) {
+            const float4 c = *reinterpret_cast<float4 *>(o);
+            a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        }
+        *reinterpret_cast<float4 *>(o) = a;
     } else {
-        float a = 0.f;
+        float a = accumulate ? *o : 0.f;
         for (int s = 0; s < ks; ++s) a += p[s * slice];
-        *o += a;
+        *o = a;
     }
 }
 
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restr
 // With a workspace of ksplit * ntaps * M * N floats the slices store partial tiles and a second kernel sums them; without
 // one they meet through f32 atomics.
 template <bool BF16>
-int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, hipStream_t stream) {
+int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, int accumulate, hipStream_t stream) {
     static const int no256 = [] { const char *e = getenv("VS_WGRAD_NO256"); return e ? atoi(e) : 0; }();
     const int ntaps = g.ntaps > 0 ? g.ntaps : 1;
     const bool big = !no256 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % (128 * ksplit) == 0;
@@ -420,8 +422,8 @@ int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, hipStre
     const bool v4 = g.N % 4 == 0 && g.ldo % 4 == 0 && g.tap_out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0;
     const long long items = (long long)ntaps * g.M * (v4 ? g.N / 4 : g.N);
     const dim3 grid((unsigned)((items + 255) / 256));
-    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, ws, (float *)g.out, g.M, g.N, ntaps, slices, (long long)g.ldo, g.tap_out_stride);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, ws, (float *)g.out, g.M, g.N, ntaps, slices, (long long)g.ldo, g.tap_out_stride);
+    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, ws, (float *)g.out, g.M, g.N, ntaps, slices, (long long)g.ldo, g.tap_out_stride, accumulate);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, ws, (float *)g.out, g.M, g.N, ntaps, slices, (long long)g.ldo, g.tap_out_stride, accumulate);
     return 0;
 }
 
@@ -490,12 +492,14 @@ extern "C" int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias,
 // plain GEMM (shifts ignored); 1..9: the taps of a 3x3 convolution -- A = dY^T [Cout, pixels], W = X^T [Cin, pixels]
 // (zero-bordered), shift[t] = the tap's pixel offset, out + t * tap_out_stride = that tap's [M, N] gradient.  A and W may start
 // at any 2-byte aligned address (LDS-DMA staging), which is what lets the taps be shifted views.  workspace: null (slices meet
-// through f32 atomics) or >= slices * max(ntaps, 1) * M * N floats (slices store partial tiles, a second kernel sums them).
+// through f32 atomics) or >= slices * max(ntaps, 1) * M * N floats (slices store partial tiles, a second kernel sums them and,
+// with accumulate == 0, overwrites out instead of adding to it).
 // a_slice_stride / w_slice_stride: 0 = K slice s is columns [s K/ksplit, (s+1) K/ksplit) of A / W; > 0 = slice-blocked operands,
 // slice s is columns [0, K/ksplit) of the matrix at A + s * a_slice_stride (elements), see vs_transpose16_ex.
 extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
                              int32_t ldo, int64_t a_slice_stride, int64_t w_slice_stride, int64_t tap_out_stride, const int32_t *shifts,
-                             int32_t ntaps, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, vs_stream_t stream_) {
+                             int32_t ntaps, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate,
+                             vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(A && W && out, "vs_gemm_wgrad: null pointer");
     VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit >= 1 && ksplit <= 65535, "vs_gemm_wgrad: bad sizes M=%d N=%d K=%d ksplit=%d", M, N, K, ksplit);
@@ -513,8 +517,9 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
     for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
-    const int rc = dtype == 2 ? launch_wgrad<true>(g, ksplit, (float *)workspace, workspace_bytes, stream)
-                              : launch_wgrad<false>(g, ksplit, (float *)workspace, workspace_bytes, stream);
+    VS_CHECK(accumulate || workspace, "vs_gemm_wgrad: accumulate = 0 (overwrite out) needs a workspace; the atomics path can only add");
+    const int rc = dtype == 2 ? launch_wgrad<true>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
+                              : launch_wgrad<false>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;
@@ -523,14 +528,14 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
 // The two atomics-only forms of vs_gemm_wgrad (no workspace).
 extern "C" int vs_gemm_splitk_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
                                          int32_t ldw, int32_t ldo, int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
-    return vs_gemm_wgrad(A, W, out, M, N, K, lda, ldw, ldo, 0, 0, 0, nullptr, 0, ksplit, dtype, nullptr, 0, stream_);
+    return vs_gemm_wgrad(A, W, out, M, N, K, lda, ldw, ldo, 0, 0, 0, nullptr, 0, ksplit, dtype, nullptr, 0, 1, stream_);
 }
 
 extern "C" int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda,
                                        int32_t ldw, int32_t ldo, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps,
                                        int32_t ksplit, int32_t dtype, vs_stream_t stream_) {
     VS_CHECK(ntaps >= 1, "vs_gemm_taps_accumulate: ntaps must be >= 1");
-    return vs_gemm_wgrad(A, W, out, M, N, K, lda, ldw, ldo, 0, 0, tap_out_stride, shifts, ntaps, ksplit, dtype, nullptr, 0, stream_);
+    return vs_gemm_wgrad(A, W, out, M, N, K, lda, ldw, ldo, 0, 0, tap_out_stride, shifts, ntaps, ksplit, dtype, nullptr, 0, 1, stream_);
 }
 
 // 7x7 stride-1 pad-3 convolution of an RGB image (the gs head's input_merger, heads/dpt_gs_head.py:112-118) as a window

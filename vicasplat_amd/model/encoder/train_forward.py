@@ -77,7 +77,8 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         s1, b1, g1 = _lin_f32(P, nm + ".modulation1.proj", F.silu(cn)).chunk(3, -1)                   # [B,T,C] each
         hmix = lnm(nm + ".norm1", x, scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=dt,
                    lead=cn.to(dt).reshape(BT, C), lead_rows=N1)                                       # [BT*M2, C]: camera token first
-        qkv = A.RopeQKFn.apply(lin(nm + ".attn.qkv", hmix), tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta)
+        qkv = A.linear(hmix, P[nm + ".attn.qkv.weight"], P[nm + ".attn.qkv.bias"], dt,
+                       rope=(tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta))                 # RoPE in the GEMM epilogue
         att = A.AttentionFn.apply(qkv, B, Hd, T * M2, T * M2, T * M2, T * M2, None, tabs["kvlen"], 0)
         x, o_cam = A.gated_resid(x, lin(nm + ".attn.proj", att), g1.reshape(BT, C), N1, N1, M2, 1)
         cam = cam + o_cam.view(B, T, C)
@@ -89,7 +90,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         ca = nm + ".cross_attn"
         wqkv = torch.cat([P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]], 0)
         bqkv = torch.cat([P[ca + ".projq.bias"], P[ca + ".projk.bias"], P[ca + ".projv.bias"]], 0)
-        qkv = A.RopeQKFn.apply(A.linear(himg, wqkv, bqkv, dt), tabs["pos_img"], None, Hd, C, 100.0, 1.0)
+        qkv = A.linear(himg, wqkv, bqkv, dt, rope=(tabs["pos_img"], None, Hd, C, 100.0, 1.0))
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
         x = A.gated_resid(x, lin(ca + ".proj", att), g2.reshape(BT, C), N1)
         himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
@@ -136,8 +137,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
 
     def rcu(name, t):
         y = A.conv3x3(t, P[name + ".conv1.weight"], P[name + ".conv1.bias"], relu_in=True)
-        y = A.conv3x3(y, P[name + ".conv2.weight"], P[name + ".conv2.bias"], relu_in=True)
-        return y + t
+        return A.conv3x3(y, P[name + ".conv2.weight"], P[name + ".conv2.bias"], relu_in=True, residual=t)   # + t in the conv epilogue
 
     def fusion(name, t, skip=None):
         if skip is not None:
@@ -163,14 +163,14 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     pre = "downstream_head1.dpt"
     t = trunk(pre)
     t = A.conv3x3(t, P[pre + ".head.0.weight"], P[pre + ".head.0.bias"])
-    t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"])
-    xyz = conv1x1(pre + ".head.4", F.relu(t)).float()[..., :3]
+    t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"], relu_out=True)
+    xyz = conv1x1(pre + ".head.4", t).float()[..., :3]
     dist = xyz.norm(dim=-1, keepdim=True)
     centers = xyz / dist.clip(min=1e-8) * torch.expm1(dist)                                          # 'exp' depth mode, postprocess.py:46-56
 
     pre = "gaussian_param_head.dpt"
     t = up2(trunk(pre)) + F.relu(stem7x7(pre + ".input_merger.0", frames))
-    t = F.relu(A.conv3x3(t, P[pre + ".head.0.weight"], None))
+    t = A.conv3x3(t, P[pre + ".head.0.weight"], None, relu_out=True)
     params = conv1x1(pre + ".head.4", t).float()
     raw = torch.cat([centers, params], -1).view(B, V, H, Wd, -1)
 

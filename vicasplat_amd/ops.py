@@ -421,8 +421,8 @@ def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_
             db = torch.empty(N, dtype=torch.float32, device=dev)
         # slice-blocked [ks, N, Mpad/ks], [ks, K, Mpad/ks], zero padded
         dyT, xT = transpose16(dy, unit, colsum_out=db, slices=ks), transpose16(x, unit, slices=ks)
-        dw = torch.zeros((N, K), dtype=torch.float32, device=dev)
-        gemm_wgrad(dyT, xT, dw, ks)
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        gemm_wgrad(dyT, xT, dw, ks, accumulate=False)
     elif need_db:
         db = colsum(dy)
     return dx, dw, db
@@ -439,12 +439,12 @@ def relu_mask_(dx: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_wgrad(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int, *, shifts=None, K: Optional[int] = None,
-               workspace: bool = True) -> torch.Tensor:
+               workspace: bool = True, accumulate: bool = True) -> torch.Tensor:
     """out32[t][M,N] += a[M,K] @ (w shifted by shifts[t])[N,K]^T, K split over `ksplit` workgroups per tile (vs_gemm_wgrad).
     a, w: 2-D [rows, K] (slice s = columns [s K/ksplit, ...)) or slice-blocked 3-D [ksplit, rows, K/ksplit] as transpose16(slices=)
     writes them (w may be a column-offset view into a wider halo'd buffer; K = ksplit * slice length then).
     out is [M,N] (shifts None) or [len(shifts),M,N] contiguous.  workspace: the K slices store partial tiles that a second
-    kernel sums (default); False: they meet through f32 atomics."""
+    kernel sums (default); False: they meet through f32 atomics.  accumulate=False (workspace mode) overwrites out: no zero fill."""
     dev = L.require_device(a, w, out)
     assert a.dtype == w.dtype and a.stride(-1) == 1 and w.stride(-1) == 1 and out.dtype == torch.float32 and out.is_contiguous()
     assert a.dim() == w.dim()
@@ -468,7 +468,7 @@ def gemm_wgrad(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int,
         ws_bytes = ws.numel() * 4
     with torch.cuda.device(dev):
         rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(w), L.ptr(out), M, N, K, a.stride(-2), w.stride(-2), N, asl, wsl, M * N, sh, ntaps,
-                                   ksplit, _DT[a.dtype], L.ptr(ws), ws_bytes, L.stream_ptr(dev))
+                                   ksplit, _DT[a.dtype], L.ptr(ws), ws_bytes, int(accumulate), L.stream_ptr(dev))
     L.check(rc, "vs_gemm_wgrad")
     return out
 
@@ -517,9 +517,9 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
         dyT = dyT.unsqueeze(0)
     # all 9 taps in ONE launch (workgroup order: k-slice, tap, tile): the taps of a K slice run together, so A and the nine
     # overlapping shifted views of X^T are served from the caches instead of being streamed from HBM nine times
-    dw9 = torch.zeros((9, Cout, Cin), dtype=torch.float32, device=dev)
+    dw9 = torch.empty((9, Cout, Cin), dtype=torch.float32, device=dev)
     shifts = [(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)]
-    gemm_wgrad(dyT, xT[:, :, halo:halo + Ppad // ksplit], dw9, ksplit, shifts=shifts)
+    gemm_wgrad(dyT, xT[:, :, halo:halo + Ppad // ksplit], dw9, ksplit, shifts=shifts, accumulate=False)
     dw = dw9.view(3, 3, Cout, Cin).permute(2, 0, 1, 3).contiguous()
     return dx, dw, db
 
