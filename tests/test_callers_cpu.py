@@ -103,3 +103,24 @@ def test_load_images_resize_crop_normalise(tmp_path):
     import pytest
     with pytest.raises(FileNotFoundError):
         callers.load_images([str(tmp_path / "notes.txt")])
+
+
+def test_wgrad_split_heuristic_matches_the_kernel_contract():
+    """ops.wgrad_ksplit (host logic): the (ksplit, padding unit) it picks must satisfy what vs_gemm_wgrad checks -- whole 256-tiles
+    run on the 8-wave kernel with an even number (>= 2) of 64-wide K tiles per slice, everything else on 128x128 tiles with
+    32-wide K steps and at least two slices -- and keep the launch near one wave of workgroups."""
+    from vicasplat_amd.ops import wgrad_ksplit
+    for rows, cols, red, taps in [(4096, 1024, 49344, 1), (768, 768, 16448, 1), (256, 256, 4_260_000, 9), (128, 128, 4_194_304, 9),
+                                  (83, 128, 12_582_912, 1), (96, 1024, 514, 1), (1024, 1024, 100, 1), (256, 256, 130, 9), (3072, 1024, 514, 1)]:
+        ks, unit = wgrad_ksplit(rows, cols, red, taps)
+        assert ks >= 1 and unit >= 64
+        padded = (red + unit - 1) // unit * unit
+        slice_len = padded // ks
+        if rows % 256 == 0 and cols % 256 == 0:
+            assert unit == 128 * ks and slice_len % 128 == 0                       # even number of 64-wide K tiles per slice
+            assert (rows // 256) * (cols // 256) * taps * ks <= 384 or ks == 1     # about one workgroup per CU
+        else:
+            assert ks >= 2 and unit == 64 * ks and slice_len % 64 == 0
+            tiles = -(-rows // 128) * -(-cols // 128) * taps
+            assert tiles * ks <= 768 or ks == 2
+        assert padded - red < unit                                                 # never more than one unit of zero padding
