@@ -296,6 +296,15 @@ int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, con
                           float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in,
                           int32_t grp_out, int32_t grp_off, vs_stream_t stream);
 
+/* Backward of vs_gaussian_adapter for dense NHWC 16-bit head outputs (training): gradients of means [npix,3], covariances [npix,3,3],
+ * harmonics [npix,3,d_sh], opacities [npix] and (nullable) of the raw output [npix, 11 + 3 d_sh] -> d_pts [npix, pts_pix], d_gs
+ * [npix, 8 + 3 d_sh] in the inputs' dtype (1 f16, 2 bf16).  Backward of MyGaussianAdapter.forward + the 'exp' depth post-process
+ * (common/gaussian_adapter.py:168-212, heads/postprocess.py:46-56) in one pass. */
+int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *gs, int32_t in_dtype, int64_t npix, int32_t d_sh,
+                                 const float *sh_mask, int32_t scale_act, float scale_min, float scale_max, float opacity_exponent,
+                                 const float *d_means, const float *d_cov, const float *d_harmonics, const float *d_opacities,
+                                 const float *d_raw, void *d_pts, void *d_gs, vs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

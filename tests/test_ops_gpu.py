@@ -593,6 +593,63 @@ def test_gated_resid_and_lead_layernorm_match_autograd(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("act,exponent", [("softplus", 1.0), ("bounded", 2.0), ("exp", -1.0)])
+def test_gaussian_adapter_function_matches_autograd(dt, act, exponent):
+    """autograd.gaussian_adapter (fused HIP kernel forward and backward) against the per-pixel PyTorch formulation of
+    postprocess.py:46-56 + gaussian_adapter.py:168-212 differentiated by torch autograd, for all outputs incl. raw."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    torch.manual_seed(17)
+    N, H, W, nsh = 2, 9, 13, 25
+    pts = (torch.randn(N, H, W, 4, device=d) * 0.7).to(dt).requires_grad_()
+    gs = torch.randn(N, H, W, 8 + 3 * nsh, device=d).to(dt).requires_grad_()
+    with torch.no_grad():
+        gs[..., 1:4] *= 3                       # some scales past the clamp / softplus knee
+    mask = torch.linspace(1.0, 0.1, nsh, device=d)
+    smin, smax = 0.5, 15.0
+    means, cov, sh, op, raw = A.gaussian_adapter(pts, gs, mask, scale_act=act, scale_min=smin, scale_max=smax, opacity_exponent=exponent)
+
+    pr, gr = pts.detach().float().requires_grad_(), gs.detach().float().requires_grad_()
+    xyz = pr[..., :3]
+    dist = xyz.norm(dim=-1, keepdim=True)
+    centers = xyz / dist.clip(min=1e-8) * torch.expm1(dist)
+    o = torch.sigmoid(gr[..., 0])
+    if exponent > 0:
+        o = 0.5 * (1 - (1 - o) ** exponent + o ** (1 / exponent))
+    v = gr[..., 1:4]
+    sc = {"softplus": lambda: (0.001 * F.softplus(v)).clamp_max(0.3), "exp": lambda: torch.exp(v).clamp_max(0.3),
+          "bounded": lambda: smin + (smax - smin) * torch.sigmoid(v)}[act]()
+    rot = F.normalize(gr[..., 4:8], dim=-1)
+    qi, qj, qk, qr = rot.unbind(-1)
+    two_s = 2 / ((rot * rot).sum(-1) + 1e-8)
+    R = torch.stack([1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+                     two_s * (qi * qj + qk * qr), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
+                     two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)], -1).reshape(N, H, W, 3, 3)
+    RS = R * sc[..., None, :]
+    cov_r = RS @ RS.transpose(-1, -2)
+    sh_r = gr[..., 8:].reshape(N, H, W, 3, nsh) * mask
+    raw_r = torch.cat([centers, gr], -1)
+    tol = 2e-3 if dt == torch.float16 else 1.6e-2
+    for name, a_, b_ in (("means", means, centers), ("cov", cov, cov_r), ("sh", sh, sh_r), ("op", op, o), ("raw", raw, raw_r)):
+        assert (a_ - b_.detach()).abs().max() <= 2e-5 * b_.detach().abs().max() + 1e-6, name
+    ws = [torch.randn_like(t) for t in (centers, cov_r, sh_r, o, raw_r)]
+    ws[1] = ws[1] * 30.0                         # covariances are ~1e-5..1e-1: weight them up so that every path matters
+    loss = sum((a_ * w_).sum() for a_, w_ in zip((means, cov, sh, op, raw), ws))
+    loss_r = sum((a_ * w_).sum() for a_, w_ in zip((centers, cov_r, sh_r, o, raw_r), ws))
+    g_pts, g_gs = torch.autograd.grad(loss, (pts, gs), retain_graph=True)
+    r_pts, r_gs = torch.autograd.grad(loss_r, (pr, gr), retain_graph=True)
+    assert float(g_pts[..., 3].abs().max()) == 0
+    assert (g_pts.float() - r_pts).abs().max() <= tol * r_pts.abs().max()
+    for name, sl in (("opacity", slice(0, 1)), ("scales", slice(1, 4)), ("rotation", slice(4, 8)), ("harmonics", slice(8, None))):
+        e = (g_gs.float()[..., sl] - r_gs[..., sl]).abs().max()
+        assert e <= tol * r_gs[..., sl].abs().max() + 1e-6, (name, float(e), float(r_gs[..., sl].abs().max()))
+    # without a gradient for raw (the training step's case) and for only one output
+    g2 = torch.autograd.grad((cov * ws[1]).sum(), gs, retain_graph=True)[0]
+    r2 = torch.autograd.grad((cov_r * ws[1]).sum(), gr, retain_graph=True)[0]
+    assert (g2.float() - r2).abs().max() <= tol * r2.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gelu_backward_matches_autograd(dt):
     from vicasplat_amd import ops
     d = _dev()

@@ -289,3 +289,36 @@ class GatedResidFn(torch.autograd.Function):
 
 def gated_resid(x, y, gate=None, gate_rows=0, grp_in=0, grp_out=0, grp_off=0):
     return GatedResidFn.apply(x, y, gate, gate_rows, grp_in, grp_out, grp_off)
+
+
+class GaussianAdapterFn(torch.autograd.Function):
+    """'exp' depth post-process + raw_gaussians concat + MyGaussianAdapter (heads/postprocess.py:46-56, vicasplat.py:256,
+    common/gaussian_adapter.py:168-212) on the fused HIP kernel in both directions.  pts [N,H,W,>=3], gs [N,H,W,8+3*d_sh]: the
+    heads' 16-bit NHWC outputs -> (means [N,H,W,3], covariances [N,H,W,3,3], harmonics [N,H,W,3,d_sh], opacities [N,H,W], raw
+    [N,H,W,11+3*d_sh]), all f32."""
+
+    @staticmethod
+    def forward(ctx, pts, gs, sh_mask, scale_act, scale_min, scale_max, opacity_exponent):
+        pts, gs = pts.contiguous(), gs.contiguous()
+        mask = sh_mask.detach().float().contiguous()
+        o = ops.gaussian_adapter(pts.permute(0, 3, 1, 2)[:, :3], gs.permute(0, 3, 1, 2), mask, scale_act=scale_act, scale_min=scale_min,
+                                 scale_max=scale_max, opacity_exponent=opacity_exponent)
+        ctx.save_for_backward(pts, gs, mask)
+        ctx.meta = (scale_act, scale_min, scale_max, opacity_exponent)
+        return o["means"], o["covariances"], o["harmonics"], o["opacities"][..., 0], o["raw"]
+
+    @staticmethod
+    def backward(ctx, d_means, d_cov, d_harm, d_op, d_raw):
+        pts, gs, mask = ctx.saved_tensors
+        scale_act, scale_min, scale_max, opacity_exponent = ctx.meta
+        z = lambda g, ref_shape: torch.zeros(ref_shape, dtype=torch.float32, device=pts.device) if g is None else g
+        N, H, W = gs.shape[:3]
+        d_sh = (gs.shape[-1] - 8) // 3
+        d_pts, d_gs = ops.gaussian_adapter_backward(pts, gs, mask, z(d_means, (N, H, W, 3)), z(d_cov, (N, H, W, 3, 3)),
+                                                    z(d_harm, (N, H, W, 3, d_sh)), z(d_op, (N, H, W)), d_raw, scale_act=scale_act,
+                                                    scale_min=scale_min, scale_max=scale_max, opacity_exponent=opacity_exponent)
+        return d_pts, d_gs, None, None, None, None, None
+
+
+def gaussian_adapter(pts, gs, sh_mask, *, scale_act="softplus", scale_min=0.0, scale_max=0.0, opacity_exponent=1.0):
+    return GaussianAdapterFn.apply(pts, gs, sh_mask, scale_act, scale_min, scale_max, opacity_exponent)

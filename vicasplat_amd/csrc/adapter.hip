@@ -232,6 +232,176 @@ __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a)
     flush_block(s_op, a.opacities + p0, np, lane);
 }
 
+// ---- backward of the adapter (training): gradients of the Gaussian attributes -> gradients of the two heads' 16-bit NHWC
+// outputs.  One wave per 64 consecutive pixels; the wide per-pixel gradient rows (harmonics 3*d_sh floats, raw 11+3*d_sh
+// floats) and the 16-bit outputs move through LDS as contiguous blocks, the per-pixel chain rule runs in registers:
+//   means  m = x k(d), k = expm1(d)/d            dx = g k + (g.x) k'(d) x / d
+//   opacity p = sigmoid(o) [pdf->opacity map]     do = gp p (1-p) [* map']
+//   scale   s = min(0.001 softplus(v), 0.3) ...   dv = gs ds/dv
+//   cov     = (R S)(R S)^T                         dRS = (G + G^T) RS,  ds_c = sum_r dRS_rc R_rc,  dR_rc = dRS_rc s_c
+//   R(q), q = qr/|qr|, two_s = 2/(q.q + 1e-8)      dq from the 9 entries + the two_s term, then through the normalisation
+//   harmonics = sh * mask                           dsh = g * mask
+// plus d_raw (gradient of the raw_gaussians output: means | pre-activation channels), added where given. ----
+struct AdapterBwdArgs {
+    const void *pts, *gs;      // forward inputs, dense NHWC 16-bit: pts [npix, pts_pix] (3 used), gs [npix, 8 + 3 d_sh]
+    int pts_pix;
+    long long npix;
+    int d_sh;
+    const float *sh_mask;
+    int scale_act;
+    float scale_min, scale_max, opacity_exponent;
+    const float *d_means, *d_cov, *d_harm, *d_op, *d_raw;   // d_raw may be null
+    void *d_pts, *d_gs;        // outputs, same layouts / dtype as pts, gs
+};
+
+template <bool BF16>
+__device__ __forceinline__ unsigned short to16a(float v) {
+    if constexpr (BF16) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    } else {
+        _Float16 h = (_Float16)v;
+        return *reinterpret_cast<unsigned short *>(&h);
+    }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_harm[64 * (kMaxCh - 11)], s_raw[64 * kMaxCh];
+    __shared__ __attribute__((aligned(16))) unsigned short s_out[64 * (kMaxCh - 3) + 16];
+    const int lane = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int np = (int)min((long long)64, a.npix - p0);
+    const int nsh = a.d_sh, cg = 8 + 3 * nsh, craw = 11 + 3 * nsh, nh = 3 * nsh;
+    {   // coalesced loads of the block's harmonics / raw gradient rows
+        const float *gh = a.d_harm + p0 * nh;
+        for (int k = lane; k < np * nh; k += 64) s_harm[k] = gh[k];
+        if (a.d_raw) {
+            const float *gr = a.d_raw + p0 * craw;
+            for (int k = lane; k < np * craw; k += 64) s_raw[k] = gr[k];
+        }
+    }
+    __syncthreads();
+    const bool live = lane < np;
+    const long long i = p0 + lane;
+    float dpt[3] = {0.f, 0.f, 0.f}, dg8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const unsigned short *pp = reinterpret_cast<const unsigned short *>(a.pts) + i * a.pts_pix;
+        const unsigned short *gg = reinterpret_cast<const unsigned short *>(a.gs) + i * cg;
+        const float *rr = a.d_raw ? s_raw + lane * craw : nullptr;
+        // ---- means ----
+        const float x = cvt16<BF16>(pp[0]), y = cvt16<BF16>(pp[1]), z = cvt16<BF16>(pp[2]);
+        float gm[3] = {a.d_means[3 * i], a.d_means[3 * i + 1], a.d_means[3 * i + 2]};
+        if (rr) { gm[0] += rr[0]; gm[1] += rr[1]; gm[2] += rr[2]; }
+        const float d = sqrtf(x * x + y * y + z * z);
+        if (d > 1e-8f) {
+            const float em = expm1f(d), k = em / d, kp = ((em + 1.0f) * d - em) / (d * d);
+            const float gx = (gm[0] * x + gm[1] * y + gm[2] * z) * kp / d;
+            dpt[0] = gm[0] * k + gx * x; dpt[1] = gm[1] * k + gx * y; dpt[2] = gm[2] * k + gx * z;
+        } else {   // m = x * expm1(d) / 1e-8 in this branch of the forward's clamp
+            const float k = expm1f(d) / 1e-8f;
+            dpt[0] = gm[0] * k; dpt[1] = gm[1] * k; dpt[2] = gm[2] * k;
+        }
+        // ---- opacity ----
+        const float o_raw = cvt16<BF16>(gg[0]);
+        const float p = 1.0f / (1.0f + expf(-o_raw));
+        float dmap = 1.0f;
+        if (a.opacity_exponent > 0.0f && a.opacity_exponent != 1.0f) {
+            const float e = a.opacity_exponent;
+            dmap = 0.5f * (e * powf(1.0f - p, e - 1.0f) + (1.0f / e) * powf(p, 1.0f / e - 1.0f));
+        }
+        dg8[0] = a.d_op[i] * dmap * p * (1.0f - p) + (rr ? rr[3] : 0.f);
+        // ---- scales, rotation (forward recomputed) ----
+        float sr[3], qr[4], s[3], dsdv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sr[c] = cvt16<BF16>(gg[1 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qr[c] = cvt16<BF16>(gg[4 + c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = sr[c];
+            if (a.scale_act == 0) {
+                const float sg = 1.0f / (1.0f + expf(-v));
+                s[c] = a.scale_min + (a.scale_max - a.scale_min) * sg;
+                dsdv[c] = (a.scale_max - a.scale_min) * sg * (1.0f - sg);
+            } else if (a.scale_act == 1) {
+                const float e = expf(v);
+                s[c] = fminf(e, 0.3f);
+                dsdv[c] = e < 0.3f ? e : 0.f;
+            } else {
+                const float sp = 0.001f * (v > 20.0f ? v : log1pf(expf(v)));
+                s[c] = fminf(sp, 0.3f);
+                dsdv[c] = sp < 0.3f ? 0.001f * (v > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-v))) : 0.f;
+            }
+        }
+        const float qn = fmaxf(sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]), 1e-12f);
+        const float qi = qr[0] / qn, qj = qr[1] / qn, qk = qr[2] / qn, qw = qr[3] / qn;
+        const float t = 2.0f / (qi * qi + qj * qj + qk * qk + qw * qw + 1e-8f);
+        const float R[3][3] = {{1 - t * (qj * qj + qk * qk), t * (qi * qj - qk * qw), t * (qi * qk + qj * qw)},
+                               {t * (qi * qj + qk * qw), 1 - t * (qi * qi + qk * qk), t * (qj * qk - qi * qw)},
+                               {t * (qi * qk - qj * qw), t * (qj * qk + qi * qw), 1 - t * (qi * qi + qj * qj)}};
+        float G[3][3], RS[3][3], dRS[3][3], dR[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { G[r][c] = a.d_cov[9 * i + 3 * r + c]; RS[r][c] = R[r][c] * s[c]; }
+        float ds[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = 0.f;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) v += (G[r][m] + G[m][r]) * RS[m][c];
+                dRS[r][c] = v;
+                ds[c] += v * R[r][c];
+                dR[r][c] = v * s[c];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dg8[1 + c] = ds[c] * dsdv[c] + (rr ? rr[4 + c] : 0.f);
+        // dL/dt (entries are 1 - t*u or t*u) and the explicit q dependence at fixed t
+        const float dt_ = -dR[0][0] * (qj * qj + qk * qk) + dR[0][1] * (qi * qj - qk * qw) + dR[0][2] * (qi * qk + qj * qw)
+                          + dR[1][0] * (qi * qj + qk * qw) - dR[1][1] * (qi * qi + qk * qk) + dR[1][2] * (qj * qk - qi * qw)
+                          + dR[2][0] * (qi * qk - qj * qw) + dR[2][1] * (qj * qk + qi * qw) - dR[2][2] * (qi * qi + qj * qj);
+        float dq[4];
+        dq[0] = t * (dR[0][1] * qj + dR[0][2] * qk + dR[1][0] * qj - 2.0f * dR[1][1] * qi - dR[1][2] * qw + dR[2][0] * qk + dR[2][1] * qw - 2.0f * dR[2][2] * qi);
+        dq[1] = t * (-2.0f * dR[0][0] * qj + dR[0][1] * qi + dR[0][2] * qw + dR[1][0] * qi + dR[1][2] * qk - dR[2][0] * qw + dR[2][1] * qk - 2.0f * dR[2][2] * qj);
+        dq[2] = t * (-2.0f * dR[0][0] * qk - dR[0][1] * qw + dR[0][2] * qi + dR[1][0] * qw - 2.0f * dR[1][1] * qk + dR[1][2] * qj + dR[2][0] * qi + dR[2][1] * qj);
+        dq[3] = t * (-dR[0][1] * qk + dR[0][2] * qj + dR[1][0] * qk - dR[1][2] * qi - dR[2][0] * qj + dR[2][1] * qi);
+        const float q[4] = {qi, qj, qk, qw};
+        const float dtq = -t * t * dt_;            // dt/dq_c = -t^2 q_c
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dq[c] += dtq * q[c];
+        // through q = qr / max(|qr|, 1e-12)
+        const float qdq = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dg8[4 + c] = (dq[c] - q[c] * qdq) / qn + (rr ? rr[7 + c] : 0.f);
+    }
+    // ---- d_gs block [64][cg] 16-bit through LDS ----
+    if (live) {
+        unsigned short *o = s_out + lane * cg;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = to16a<BF16>(dg8[c]);
+        const float *hh = s_harm + lane * nh;
+        const float *rr = a.d_raw ? s_raw + lane * craw : nullptr;
+        for (int c = 0; c < nh; ++c) o[8 + c] = to16a<BF16>(hh[c] * a.sh_mask[c % nsh] + (rr ? rr[11 + c] : 0.f));
+    }
+    __syncthreads();
+    {
+        unsigned short *dst = reinterpret_cast<unsigned short *>(a.d_gs) + p0 * cg;
+        const int n = np * cg;
+        for (int k = lane; k < (n >> 3); k += 64) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(s_out)[k];
+        for (int k = ((n >> 3) << 3) + lane; k < n; k += 64) dst[k] = s_out[k];
+    }
+    if (live) {
+        unsigned short *dp = reinterpret_cast<unsigned short *>(a.d_pts) + i * a.pts_pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dp[c] = to16a<BF16>(dpt[c]);
+        for (int c = 3; c < a.pts_pix; ++c) dp[c] = 0;
+    }
+}
+
 }  // namespace
 
 extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts_ch, const void *gs, int64_t gs_pix,
@@ -258,6 +428,28 @@ extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts
     if (in_dtype == 0) hipLaunchKernelGGL(adapter_kernel<0>, grid, block, 0, stream, a);
     else if (in_dtype == 1) hipLaunchKernelGGL(adapter_kernel<1>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(adapter_kernel<2>, grid, block, 0, stream, a);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// Backward of vs_gaussian_adapter for dense NHWC 16-bit head outputs (the training path): gradients of means [npix,3],
+// covariances [npix,3,3], harmonics [npix,3,d_sh], opacities [npix] and, optionally, of the raw output [npix, 11+3 d_sh]
+// -> d_pts [npix, pts_pix] and d_gs [npix, 8+3 d_sh] in the inputs' 16-bit dtype (channels of pts beyond 3 get zero).
+extern "C" int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *gs, int32_t in_dtype, int64_t npix, int32_t d_sh,
+                                            const float *sh_mask, int32_t scale_act, float scale_min, float scale_max,
+                                            float opacity_exponent, const float *d_means, const float *d_cov, const float *d_harmonics,
+                                            const float *d_opacities, const float *d_raw, void *d_pts, void *d_gs, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(pts && gs && sh_mask && d_means && d_cov && d_harmonics && d_opacities && d_pts && d_gs, "vs_gaussian_adapter_backward: null pointer");
+    VS_CHECK((in_dtype == 1 || in_dtype == 2) && d_sh > 0 && 11 + 3 * d_sh <= kMaxCh && scale_act >= 0 && scale_act <= 2 && pts_pix >= 3,
+             "vs_gaussian_adapter_backward: bad argument (16-bit inputs, 11 + 3 d_sh <= %d)", kMaxCh);
+    VS_CHECK(((uintptr_t)d_gs & 15) == 0, "vs_gaussian_adapter_backward: d_gs must be 16-byte aligned");
+    if (npix <= 0) return 0;
+    AdapterBwdArgs a{pts, gs, pts_pix, npix, d_sh, sh_mask, scale_act, scale_min, scale_max, opacity_exponent, d_means, d_cov, d_harmonics,
+                     d_opacities, d_raw, d_pts, d_gs};
+    dim3 grid((unsigned)vs::cdiv64(npix, 64));
+    if (in_dtype == 2) hipLaunchKernelGGL(adapter_backward_kernel<true>, grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(adapter_backward_kernel<false>, grid, dim3(64), 0, stream, a);
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -27,7 +27,7 @@ def _lin_f32(P, name, x):
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
-def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torch.dtype = torch.float16) -> dict:
+def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torch.dtype = torch.float16, global_step: int = 0) -> dict:
     """image [B,V,3,H,W] normalised to [-1,1], intrinsics [B,V,3,3] -> dict(raw_gaussians [B,V,H,W,86] f32, pred_extrins
     [B,V-1,8], gaussian_camera_extrins [B,V,4,4], gaussians {means, covariances, harmonics, opacities})."""
     P = dict(model.named_parameters())
@@ -164,32 +164,21 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     t = trunk(pre)
     t = A.conv3x3(t, P[pre + ".head.0.weight"], P[pre + ".head.0.bias"])
     t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"], relu_out=True)
-    xyz = conv1x1(pre + ".head.4", t).float()[..., :3]
-    dist = xyz.norm(dim=-1, keepdim=True)
-    centers = xyz / dist.clip(min=1e-8) * torch.expm1(dist)                                          # 'exp' depth mode, postprocess.py:46-56
+    pts16 = conv1x1(pre + ".head.4", t)                                                              # [BT,H,W,4] 16-bit: xyz | confidence
 
     pre = "gaussian_param_head.dpt"
     t = up2(trunk(pre)) + F.relu(stem7x7(pre + ".input_merger.0", frames))
     t = A.conv3x3(t, P[pre + ".head.0.weight"], None, relu_out=True)
-    params = conv1x1(pre + ".head.4", t).float()
-    raw = torch.cat([centers, params], -1).view(B, V, H, Wd, -1)
+    gs16 = conv1x1(pre + ".head.4", t)                                                               # [BT,H,W,8+3*d_sh] 16-bit
 
-    # ---------------- Gaussian adapter (common/gaussian_adapter.py:168-212), per pixel, f32 ----------------
+    # ---------------- 'exp' depth post-process (postprocess.py:46-56) + raw_gaussians concat (vicasplat.py:256) + Gaussian adapter
+    # (common/gaussian_adapter.py:168-212): ONE fused HIP kernel per direction on the heads' 16-bit NHWC outputs ----------------
     ga = model.gaussian_adapter
-    op, sc, rot = raw[..., 3:4], raw[..., 4:7], raw[..., 7:11]
-    sh = raw[..., 11:].reshape(*raw.shape[:-1], 3, -1) * ga.sh_mask.to(raw.dtype)
-    op = torch.sigmoid(op)
-    op = 0.5 * (1 - (1 - op) ** 1.0 + op ** 1.0)
-    sc = (0.001 * F.softplus(sc)).clamp_max(0.3)
-    rot = F.normalize(rot, dim=-1)
-    qi, qj, qk, qr = rot.unbind(-1)
-    two_s = 2 / ((rot * rot).sum(-1) + 1e-8)
-    R = torch.stack([1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
-                     two_s * (qi * qj + qk * qr), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
-                     two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)], -1)
-    R = R.reshape(*rot.shape[:-1], 3, 3)
-    RS = R * sc[..., None, :]
-    # cov = RS RS^T written out elementwise: a batched 3x3 matmul over millions of Gaussians lands on a (slow) vendor BLAS path
-    cov = (RS[..., :, None, :] * RS[..., None, :, :]).sum(-1)
-    gaussians = dict(means=raw[..., :3], covariances=cov, harmonics=sh, opacities=op[..., 0])
+    c = model.cfg.opacity_mapping
+    exponent = -1.0 if model.cfg.predict_opacity else 2 ** (c.initial + min(global_step / c.warm_up, 1) * (c.final - c.initial))
+    means, cov, sh, op, raw = A.gaussian_adapter(pts16, gs16, ga.sh_mask, scale_act=ga.cfg.scale_act, scale_min=ga.cfg.gaussian_scale_min,
+                                                 scale_max=ga.cfg.gaussian_scale_max, opacity_exponent=float(exponent))
+    un = lambda u: u.unflatten(0, (B, V))
+    raw = un(raw)
+    gaussians = dict(means=un(means), covariances=un(cov), harmonics=un(sh), opacities=un(op))
     return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, camera_tokens=cam)

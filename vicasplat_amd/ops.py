@@ -166,6 +166,30 @@ def gaussian_adapter(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torch.Tensor,
     return out
 
 
+def gaussian_adapter_backward(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torch.Tensor, d_means: torch.Tensor, d_cov: torch.Tensor,
+                              d_harm: torch.Tensor, d_op: torch.Tensor, d_raw: Optional[torch.Tensor] = None, *, scale_act: str = "softplus",
+                              scale_min: float = 0.0, scale_max: float = 0.0, opacity_exponent: float = 1.0):
+    """Backward of gaussian_adapter for dense NHWC 16-bit head outputs pts [N,H,W,pts_pix>=3], gs [N,H,W,8+3*d_sh]: f32 gradients of
+    means [..,3], covariances [..,3,3], harmonics [..,3,d_sh], opacities [..] (and optionally raw [..,11+3*d_sh]) -> (d_pts, d_gs)
+    in the inputs' layout and dtype."""
+    dev = L.require_device(pts, gs, sh_mask, d_means, d_cov, d_harm, d_op, d_raw)
+    assert pts.is_contiguous() and gs.is_contiguous() and pts.dtype == gs.dtype and pts.dtype in (torch.float16, torch.bfloat16)
+    d_sh = (gs.shape[-1] - 8) // 3
+    npix = gs.numel() // gs.shape[-1]
+    f = lambda t: None if t is None else t.float().contiguous()
+    d_means, d_cov, d_harm, d_op, d_raw = f(d_means), f(d_cov), f(d_harm), f(d_op), f(d_raw)
+    assert d_means.numel() == npix * 3 and d_cov.numel() == npix * 9 and d_harm.numel() == npix * 3 * d_sh and d_op.numel() == npix
+    assert d_raw is None or d_raw.numel() == npix * (11 + 3 * d_sh)
+    d_pts, d_gs = torch.empty_like(pts), torch.empty_like(gs)
+    act = {"bounded": 0, "exp": 1, "softplus": 2}[scale_act]
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gaussian_adapter_backward(L.ptr(pts), pts.shape[-1], L.ptr(gs), _DT[pts.dtype], npix, d_sh, L.ptr(sh_mask), act,
+                                                  scale_min, scale_max, opacity_exponent, L.ptr(d_means), L.ptr(d_cov), L.ptr(d_harm),
+                                                  L.ptr(d_op), L.ptr(d_raw), L.ptr(d_pts), L.ptr(d_gs), L.stream_ptr(dev))
+    L.check(rc, "vs_gaussian_adapter_backward")
+    return d_pts, d_gs
+
+
 def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                  relu_in: bool = False, relu_out: bool = False, out: Optional[torch.Tensor] = None, stride: int = 1) -> torch.Tensor:
     """x [N,H,W,Cin] contiguous 16-bit, w [Cout,3,3,Cin] (see pack_conv3x3_weight) -> [N,Ho,Wo,Cout] (k=3, pad=1)."""
