@@ -193,6 +193,8 @@ int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts_ch, const 
  * F.interpolate(scale_factor=2, bilinear, align_corners=True) of heads/dpt_block.py:79-218,316-343).
  *   vs_conv3x3_nhwc : out = [relu](conv3x3([relu](in)) + bias [+ residual]); implicit GEMM on MFMA, no im2col buffer.
  *                     in [N,H,W,Cin], w [Cout,3,3,Cin] (tap-major, channel-minor), out/residual [N,H,W,Cout]; Cin % 64 == 0.
+ *                     relu_out == 2: `residual` is not added but used as a mask, out = residual > 0 ? conv : 0 -- the data gradient
+ *                     of a conv whose input went through a ReLU (the conv runs on dY with flipped weights, residual = that input).
  *   vs_upsample2x_nhwc : out [N,2H,2W,C] = bilinear(in [N,H,W,C]) [+ add | + relu(add)]; C % 8 == 0.
  * ------------------------------------------------------------------------------------------------ */
 int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg, int32_t Hin,

@@ -57,10 +57,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
             if (vec_ok) {
                 if (g.res) {
                     const uint2 rv = *reinterpret_cast<const uint2 *>(g.res + o + j * 16);
-                    v[0] += from16<BF16>((unsigned short)(rv.x & 0xffffu)); v[1] += from16<BF16>((unsigned short)(rv.x >> 16));
-                    v[2] += from16<BF16>((unsigned short)(rv.y & 0xffffu)); v[3] += from16<BF16>((unsigned short)(rv.y >> 16));
+                    const float r0 = from16<BF16>((unsigned short)(rv.x & 0xffffu)), r1 = from16<BF16>((unsigned short)(rv.x >> 16));
+                    const float r2 = from16<BF16>((unsigned short)(rv.y & 0xffffu)), r3 = from16<BF16>((unsigned short)(rv.y >> 16));
+                    if (g.relu_out == 2) {  // data gradient of a conv behind a ReLU: keep it where the ReLU's input was positive
+                        v[0] = r0 > 0.f ? v[0] : 0.f; v[1] = r1 > 0.f ? v[1] : 0.f; v[2] = r2 > 0.f ? v[2] : 0.f; v[3] = r3 > 0.f ? v[3] : 0.f;
+                    } else {
+                        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+                    }
                 }
-                if (g.relu_out) {
+                if (g.relu_out == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                 }
@@ -72,8 +77,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (nbase + j * 16 + c4 + r < g.Cout) {
-                        float x = v[r] + (g.res ? from16<BF16>(g.res[o + j * 16 + r]) : 0.0f);
-                        if (g.relu_out) x = fmaxf(x, 0.0f);
+                        float x = v[r];
+                        if (g.res) {
+                            const float rr = from16<BF16>(g.res[o + j * 16 + r]);
+                            x = g.relu_out == 2 ? (rr > 0.f ? x : 0.f) : x + rr;
+                        }
+                        if (g.relu_out == 1) x = fmaxf(x, 0.0f);
                         g.out[o + j * 16 + r] = to16<BF16>(x);
                     }
             }
@@ -378,6 +387,7 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     VS_CHECK(Cin % 32 == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of 32 (pad the channels)", Cin);
     VS_CHECK(Hin < 32767 && Win < 65536 && (long long)Nimg * Hin * Win < 2147483647LL, "vs_conv3x3_nhwc: image too large");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_conv3x3_nhwc: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(relu_out >= 0 && relu_out <= 2 && (relu_out != 2 || residual), "vs_conv3x3_nhwc: relu_out must be 0, 1 or 2 (2 = mask by `residual`, which must be given)");
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
     if (Nimg == 0) return 0;
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,

@@ -191,8 +191,13 @@ def gaussian_adapter_backward(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torc
 
 
 def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 relu_in: bool = False, relu_out: bool = False, out: Optional[torch.Tensor] = None, stride: int = 1) -> torch.Tensor:
-    """x [N,H,W,Cin] contiguous 16-bit, w [Cout,3,3,Cin] (see pack_conv3x3_weight) -> [N,Ho,Wo,Cout] (k=3, pad=1)."""
+                 relu_in: bool = False, relu_out: bool = False, out: Optional[torch.Tensor] = None, stride: int = 1,
+                 mask_by: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,H,W,Cin] contiguous 16-bit, w [Cout,3,3,Cin] (see pack_conv3x3_weight) -> [N,Ho,Wo,Cout] (k=3, pad=1).
+    mask_by [N,Ho,Wo,Cout]: the result is zeroed where mask_by <= 0 (ReLU backward fused into a data-gradient conv)."""
+    if mask_by is not None:
+        assert residual is None and not relu_out
+        residual, relu_out = mask_by, 2
     dev = L.require_device(x, w, bias, residual, out)
     assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dtype in (torch.float16, torch.bfloat16)
     N, H, W, Cin = x.shape
@@ -522,9 +527,7 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
     dx = None
     if need_dx:
         wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()          # [Cin, 3, 3, Cout]
-        dx = conv3x3_nhwc(dy.contiguous(), wd, None)
-        if relu_in:
-            relu_mask_(dx, x)
+        dx = conv3x3_nhwc(dy.contiguous(), wd, None, mask_by=x if relu_in else None)   # ReLU backward in the conv epilogue
     # weight gradient: dY^T [Cout, pixels] and X^T [Cin, pixels] over the zero-bordered pixel grid, produced straight from the
     # NHWC tensors by the transposing kernel (border, input ReLU and the bias gradient folded into that one pass)
     Hp, Wp = H + 2, W + 2
