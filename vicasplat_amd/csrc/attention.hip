@@ -52,15 +52,11 @@ __device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
 
 template <bool BF16>
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    if constexpr (BF16) {
-        unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-        ua += 0x7FFFu + ((ua >> 16) & 1u);
-        ub += 0x7FFFu + ((ub >> 16) & 1u);
-        return (ua >> 16) | (ub & 0xFFFF0000u);
-    } else {
-        _Float16 ha = (_Float16)a, hb = (_Float16)b;
-        return (unsigned)(*reinterpret_cast<unsigned short *>(&ha)) | ((unsigned)(*reinterpret_cast<unsigned short *>(&hb)) << 16);
-    }
+    // one packed convert (round to nearest even) instead of two converts + an OR: the softmax / dS path is VALU-bound
+    unsigned r;
+    if constexpr (BF16) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 template <bool BF16>
