@@ -150,12 +150,11 @@ class AttentionFn(torch.autograd.Function):
         qkv, out, lse = ctx.saved_tensors
         nbatch, H, Lq, Lk, qbr, kbr, kv_seg, q_kvlen, max_keys = ctx.meta
         C = H * 64
-        dq, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H,
-                                            Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, kv_seg=kv_seg, q_kvlen=q_kvlen,
-                                            max_keys=max_keys)
-        dqkv = torch.empty((dq.shape[0], 3 * C), dtype=dq.dtype, device=dq.device)   # (one cast-copy per block instead of casts + cat)
-        dqkv[:, :C] = dq
-        dqkv[:, C:2 * C] = dk
+        dqkv = torch.empty((qkv.shape[0], 3 * C), dtype=qkv.dtype, device=qkv.device)   # dq lands in its block directly; dk / dv are f32
+        _, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H,
+                                           Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, kv_seg=kv_seg, q_kvlen=q_kvlen,
+                                           max_keys=max_keys, dq_out=dqkv[:, :C])
+        dqkv[:, C:2 * C] = dk                                                            # (one cast-copy each)
         dqkv[:, 2 * C:] = dv
         return dqkv, None, None, None, None, None, None, None, None, None
 

@@ -114,14 +114,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, *,
                        nbatch: int, H: int, Lq: int, Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0,
                        kv_seg: Optional[torch.Tensor] = None, q_kvlen: Optional[torch.Tensor] = None, max_keys: int = 0,
-                       scale: float = 0.125):
-    """Backward of `attention` (used by autograd.AttentionFn).  Returns dq (16-bit [rows, H*64]) and dk, dv (f32
-    [key rows, H*64], accumulated with atomics from zero)."""
+                       scale: float = 0.125, dq_out: Optional[torch.Tensor] = None):
+    """Backward of `attention` (used by autograd.AttentionFn).  Returns dq (16-bit [rows, H*64]; written into dq_out, e.g. the q
+    block of a packed [rows, 3*H*64] gradient buffer, when given) and dk, dv (f32 [key rows, H*64], accumulated from zero)."""
     dev = L.require_device(q, k, v, out, dout, lse, kv_seg, q_kvlen)
     for t in (q, k, v, out, dout):
         assert t.dim() == 2 and t.stride(1) == 1
     Cc = H * 64
-    dq = torch.empty((q.shape[0], Cc), dtype=q.dtype, device=dev)
+    if dq_out is None:
+        dq = torch.empty((q.shape[0], Cc), dtype=q.dtype, device=dev)
+    else:
+        dq = dq_out
+        assert dq.shape == (q.shape[0], Cc) and dq.dtype == q.dtype and dq.stride(1) == 1
     dk = torch.zeros((k.shape[0], Cc), dtype=torch.float32, device=dev)
     dv = torch.zeros((v.shape[0], Cc), dtype=torch.float32, device=dev)
     delta = torch.empty((q.shape[0], H), dtype=torch.float32, device=dev)

@@ -72,10 +72,12 @@ def enc_block_backward(dx_out: torch.Tensor, tape: dict, p: EncBlockParams):
     dx_in = dx_mid
     datt, g["proj_w"], g["proj_b"] = ops.linear_backward(dx_mid.to(dt), t["att"], p.proj_w)
     qkv = t["qkv"]
-    dq, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], t["att"], datt, t["lse"], nbatch=t["frames"],
-                                        H=t["heads"], Lq=t["tokens"], Lk=t["tokens"], q_batch_rows=t["tokens"],
-                                        k_batch_rows=t["tokens"])
-    dqkv = torch.cat([dq, dk.to(dt), dv.to(dt)], dim=1)
+    dqkv = torch.empty_like(qkv)                              # dq lands in its block directly; dk / dv (f32) are cast into theirs
+    _, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], t["att"], datt, t["lse"], nbatch=t["frames"],
+                                       H=t["heads"], Lq=t["tokens"], Lk=t["tokens"], q_batch_rows=t["tokens"],
+                                       k_batch_rows=t["tokens"], dq_out=dqkv[:, :C])
+    dqkv[:, C:2 * C] = dk
+    dqkv[:, 2 * C:] = dv
     ops.rope_qk(dqkv, t["heads"], C, t["pos"], None, t["rope_base"], 1.0, inverse=True)   # backward of the rotation on dq | dk
     dh1, g["qkv_w"], g["qkv_b"] = ops.linear_backward(dqkv, t["h1"], p.qkv_w)
     _, g["ln1_w"], g["ln1_b"], _, _ = ops.layernorm_backward(dh1, t["x"], p.ln1_w, p.ln1_b, eps=t["eps"], dx=dx_in, accumulate_dx=True)
