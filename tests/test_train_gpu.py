@@ -104,6 +104,38 @@ def test_training_forward_matches_reference_goldens():
     assert e_pose <= 5e-3 and e_raw <= 3e-2 and e_cov <= 6e-2
 
 
+@pytest.mark.parametrize("name", ["full_v2", "full_v8"])
+def test_training_forward_full_vitl_matches_reference_goldens(name):
+    """The differentiable forward at FULL size (ViT-L, 2 and 8 context views = BASELINE's training configuration) against the real
+    reference's f64 goldens, same bounds as the inference forward (tests/test_encoder_gpu.py)."""
+    import json, os
+    import numpy as np
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(G, f"encoder_{name}.npz"))
+    m, _ = get_encoder(default_cfg())
+    m.load_state_dict(er.golden_weights(json.load(open(os.path.join(G, "shapes_full.json"))), seed=0), strict=True)
+    m = m.cuda().train()
+    B, V = int(z["cfg_B"]), int(z["cfg_V"])
+    img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    with torch.no_grad():
+        out = forward_train(m, img.cuda(), K.cuda(), torch.float16)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max() / (np.abs(b).max() + 1e-12))
+    LAT = slice(8, 256, 16)
+    errs = dict(pose=rel(out["pred_extrins"].cpu().numpy(), z["f64_pred_extrins"]))
+    raw = out["raw_gaussians"][:, :, LAT, LAT].cpu().numpy()
+    for nm, sl in (("xyz", slice(0, 3)), ("opacity", slice(3, 4)), ("scale", slice(4, 7)), ("quat", slice(7, 11)), ("sh", slice(11, 86))):
+        errs[nm] = rel(raw[..., sl], z["f64_raw"][..., sl])
+    g = out["gaussians"]
+    for k in ("means", "harmonics", "opacities"):
+        errs["g_" + k] = rel(g[k][:, :, LAT, LAT].cpu().numpy(), z[f"f64_{k}"])
+    print("training forward", name, {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["pose"] <= 5e-3, errs
+    assert max(v for k, v in errs.items() if k != "pose") <= 3e-2, errs
+    assert out["raw_gaussians"].shape == (B, V, 256, 256, 86) and g["covariances"].shape == (B, V, 256, 256, 3, 3)
+
+
 def test_training_backward_matches_oracle_autograd():
     """End-to-end gradients of the whole encoder (2 + 12 transformer blocks, both DPT heads, adapter, pose head) for a
     random linear functional of its outputs, HIP training path vs f32 torch autograd over the oracle (128 x 128 frames)."""
