@@ -6,7 +6,7 @@
 //
 //   K1 render_backward_kernel : per (camera, tile) back-to-front replay from final_T / n_contrib; gradients w.r.t. the
 //        screen-space mean (NDC units), conic (true partials), opacity, colour and depth of every (camera, Gaussian)
-//        are summed over the wave's 8x8 pixels in registers (DPP row sums + 4 readlanes) and leave the wave as ONE f32
+//        are summed over the wave's 8x8 pixels in registers (six DPP adds per component) and leave the wave as ONE f32
 //        atomic per component -- a pixel-sized Gaussian is seen by tens of lanes of a wave, and per-lane atomics (the
 //        upstream scheme) made this kernel 8x the forward.  Same 4-wave quadrant layout and wave-uniform footprint
 //        cull as the forward, so a wave only touches the Gaussians that can reach its pixels.
@@ -31,15 +31,19 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 // per-(camera,Gaussian) gradient record written by K1: mean2D.xy | conic.xyz | opacity | rgb | depth
 constexpr int kG = 10;
 
-// sum over the 64 lanes of a wave, returned in every lane: quad / half-row / row DPP adds, then the 4 row totals by readlane
-__device__ __forceinline__ float wave_total(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
-    const int iv = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+// sum over the 64 lanes of a wave, valid in lanes 48..63 (the last row): quad / half-row / row DPP adds give every lane its row's
+// sum, row_bcast:15 folds row 0 into row 1 and row 2 into row 3, row_bcast:31 folds rows 0+1 into row 3 -- six VALU adds, no
+// LDS crossbar traffic and no readlane
+__device__ __forceinline__ float wave_total_hi(float v) {
+#define VS_DPP_ADD(ctrl_, rmask_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, rmask_, 0xF, false));
+    VS_DPP_ADD(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    VS_DPP_ADD(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    VS_DPP_ADD(0x141, 0xF)   // row_half_mirror
+    VS_DPP_ADD(0x140, 0xF)   // row_mirror
+    VS_DPP_ADD(0x142, 0xA)   // row_bcast:15 into rows 1 and 3
+    VS_DPP_ADD(0x143, 0xC)   // row_bcast:31 into rows 2 and 3
+#undef VS_DPP_ADD
+    return v;
 }
 
 __global__ void __launch_bounds__(256)
@@ -145,12 +149,12 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
                 v[9] = dch * dLd;
             }
 #pragma unroll
-            for (int e = 0; e < kG; ++e) v[e] = wave_total(v[e]);
-            if (lane < kG) {  // lane e adds component e: one 10-lane atomic instruction per (wave, Gaussian)
+            for (int e = 0; e < kG; ++e) v[e] = wave_total_hi(v[e]);   // totals live in lanes 48..63
+            if (lane >= 48 && lane < 48 + kG) {  // lane 48 + e adds component e: one 10-lane atomic instruction per (wave, Gaussian)
                 float mine = v[0];
 #pragma unroll
-                for (int e = 1; e < kG; ++e) mine = lane == e ? v[e] : mine;
-                atomicAdd(gr + (size_t)sid[j] * kG + lane, mine);
+                for (int e = 1; e < kG; ++e) mine = lane == 48 + e ? v[e] : mine;
+                atomicAdd(gr + (size_t)sid[j] * kG + (lane - 48), mine);
             }
         }
     }
