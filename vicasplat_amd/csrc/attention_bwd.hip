@@ -2,7 +2,7 @@
 // mask and two-segment key gather.  Backward of the encoder's attention in the training step (autograd.AttentionFn), parity-tested against torch
 // autograd.  Flash-style: nothing of size Lq x Lk is stored; the forward saves the log2-domain logsumexp L (vs_attention_lse).
 //
-//   delta_i = sum_d dO_i O_i                                   attn_delta_kernel      (one wave per (row, head))
+//   delta_i = sum_d dO_i O_i                                   attn_delta_kernel      (8 lanes per (row, head))
 //   P = exp2(S * scale*log2e - L),  dP = dO V^T,  dS = P o (dP - delta) * scale
 //   dQ_i = sum_j dS_ij K_j                                      attn_bwd_dq_kernel     (workgroup = 64 queries, loops key tiles;
 //                                                                                        lane = query, as in the forward)
@@ -56,18 +56,29 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return r;
 }
 
+// 8 lanes per (row, head): each lane multiplies 8 elements (one 16-byte load of O and of dO), three DPP steps sum the 8 lanes.
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 attn_delta_kernel(const AttnBwdArgs a, long long rows) {
-    const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (row, head)
-    if (item >= rows * a.H) return;
-    const long long row = item / a.H;
-    const int h = (int)(item % a.H);
-    float v = ld16<BF16>(a.o[row * a.ldo + h * HD + lane]) * ld16<BF16>(a.dout[row * a.lddo + h * HD + lane]);
+    const long long item = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;  // (row, head)
+    const int sub = threadIdx.x & 7;
+    float v = 0.f;
+    const bool live = item < rows * a.H;
+    if (live) {
+        const long long row = item / a.H;
+        const int h = (int)(item % a.H);
+        const uint4 ov = *reinterpret_cast<const uint4 *>(a.o + row * a.ldo + h * HD + sub * 8);
+        const uint4 dv = *reinterpret_cast<const uint4 *>(a.dout + row * a.lddo + h * HD + sub * 8);
+        const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) v += __shfl_xor(v, o_, 64);
-    if (lane == 0) a.delta[item] = v;
+        for (int k = 0; k < 4; ++k)
+            v += ld16<BF16>((unsigned short)(ow[k] & 0xffffu)) * ld16<BF16>((unsigned short)(dw[k] & 0xffffu)) +
+                 ld16<BF16>((unsigned short)(ow[k] >> 16)) * ld16<BF16>((unsigned short)(dw[k] >> 16));
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (live && sub == 0) a.delta[item] = v;
 }
 
 struct KeyList {
@@ -295,7 +306,8 @@ extern "C" int vs_attention_backward(const void *q, const void *k, const void *v
     VS_CHECK(q && k && v && o && dout && lse && delta && dq && dk && dv, "vs_attention_backward: null pointer");
     VS_CHECK(nbatch >= 0 && H > 0 && Lq >= 0, "vs_attention_backward: bad sizes");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_attention_backward: dtype must be 1 (f16) or 2 (bf16)");
-    VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0, "vs_attention_backward: row strides must be multiples of 8 elements");
+    VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0, "vs_attention_backward: row strides must be multiples of 8 elements");
+    VS_CHECK((((uintptr_t)o | (uintptr_t)dout) & 15) == 0, "vs_attention_backward: o and dout must be 16-byte aligned");
     VS_CHECK(kv_seg ? max_keys > 0 : Lk > 0, "vs_attention_backward: Lk (or max_keys with kv_seg) must be positive");
     if (nbatch == 0 || Lq == 0) return 0;
     AttnBwdArgs a;
@@ -309,11 +321,11 @@ extern "C" int vs_attention_backward(const void *q, const void *k, const void *v
     const int keys = kv_seg ? max_keys : Lk;
     dim3 block(256);
     if (dtype == 2) {
-        hipLaunchKernelGGL(attn_delta_kernel<true>, dim3((unsigned)vs::cdiv64(rows * H, 4)), block, 0, stream, a, rows);
+        hipLaunchKernelGGL(attn_delta_kernel<true>, dim3((unsigned)vs::cdiv64(rows * H, 32)), block, 0, stream, a, rows);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
     } else {
-        hipLaunchKernelGGL(attn_delta_kernel<false>, dim3((unsigned)vs::cdiv64(rows * H, 4)), block, 0, stream, a, rows);
+        hipLaunchKernelGGL(attn_delta_kernel<false>, dim3((unsigned)vs::cdiv64(rows * H, 32)), block, 0, stream, a, rows);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
     }
