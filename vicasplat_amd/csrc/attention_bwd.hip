@@ -155,6 +155,7 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
         stage_tile<true, true>(a.k, a.ldk, h * HD, rk, kl.Lk - kt, sK, sKT, tid);
         stage_tile<true, false>(a.v, a.ldv, h * HD, rk, kl.Lk - kt, sV, nullptr, tid);
         __syncthreads();
+        const bool tile_full = __builtin_amdgcn_ballot_w64(my_len < kt + TB) == 0ull;
         uint4 dsf[2];
         f4 ds[4];
 #pragma unroll
@@ -167,11 +168,16 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
                 s = mfma<BF16>(kf, qf[ks], s);      // S^T[key][query]
                 dp = mfma<BF16>(vf, dof[ks], dp);   // dP^T[key][query]
             }
+            if (tile_full) {   // every key of the tile is visible to every query of the wave: no mask arithmetic
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + nb * 16 + g * 4 + r;
-                const float p = key < my_len ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) : 0.f;
-                ds[nb][r] = p * (dp[r] - D) * a.scale;
+                for (int r = 0; r < 4; ++r) ds[nb][r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) * (dp[r] - D) * a.scale;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt + nb * 16 + g * 4 + r;
+                    const float p = key < my_len ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) : 0.f;
+                    ds[nb][r] = p * (dp[r] - D) * a.scale;
+                }
             }
         }
 #pragma unroll
@@ -209,8 +215,9 @@ template <bool BF16>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * ROW], sDO[TB * ROW], sQT[HD * TROW], sDOT[HD * TROW];
-    __shared__ float sL[TB], sD[TB];
-    __shared__ int sLen[TB];
+    __shared__ __attribute__((aligned(16))) float sL[TB], sD[TB];
+    __shared__ __attribute__((aligned(16))) int sLen[TB];
+    __shared__ int s_minlen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
@@ -238,9 +245,16 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
             const long long row = b * a.q_batch_rows + (ok ? qi : a.Lq - 1);
             sL[tid] = ok ? a.lse[row * a.H + h] : INFINITY;
             sD[tid] = ok ? a.delta[row * a.H + h] : 0.f;
-            sLen[tid] = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
+            const int len = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
+            sLen[tid] = len;
+            int mn = len;                             // (tid < 64 is exactly wave 0)
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1) mn = min(mn, __shfl_xor(mn, o_, 64));
+            if (tid == 0) s_minlen = mn;
         }
         __syncthreads();
+        // all 16 keys of the wave are real and visible to all 64 queries of the tile: no mask arithmetic, no per-element length reads
+        const bool tile_full = kt0 + wid * 16 + 16 <= min(kl.Lk, s_minlen);
         f4 p[4], ds[4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
@@ -252,12 +266,24 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
                 s = mfma<BF16>(qa, kf[ks], s);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
                 dp = mfma<BF16>(da, vf[ks], dp);   // dP[query][key]
             }
+            const float4 L4 = *reinterpret_cast<const float4 *>(&sL[qb * 16 + g * 4]), D4 = *reinterpret_cast<const float4 *>(&sD[qb * 16 + g * 4]);
+            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+            if (tile_full) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qb * 16 + g * 4 + r;
-                const float pv = (kvalid && kj < sLen[ql]) ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -sL[ql])) : 0.f;
-                p[qb][r] = pv;
-                ds[qb][r] = pv * (dp[r] - sD[ql]) * a.scale;
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -Lr[r]));
+                    p[qb][r] = pv;
+                    ds[qb][r] = pv * (dp[r] - Dr[r]) * a.scale;
+                }
+            } else {
+                const int4 N4 = *reinterpret_cast<const int4 *>(&sLen[qb * 16 + g * 4]);
+                const int Nr[4] = {N4.x, N4.y, N4.z, N4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = (kvalid && kj < Nr[r]) ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -Lr[r])) : 0.f;
+                    p[qb][r] = pv;
+                    ds[qb][r] = pv * (dp[r] - Dr[r]) * a.scale;
+                }
             }
         }
         uint4 pf[2], dsf[2];
