@@ -23,7 +23,10 @@ def run(name, rows, H, nbatch, Lq, Lk, qbr, kbr, kvlen=None, seg=None, max_keys=
     print(f"{name:10s} fwd {res[0] * 1e6:8.1f} us   bwd {res[1] * 1e6:8.1f} us   ratio {res[1] / res[0]:.2f}")
 run("encoder", B * T * N1, 16, B * T, N1, N1, N1, N1)
 M2 = N1 + 1
-kv = (torch.arange(T, device=d).repeat_interleave(M2).add(1) * M2).repeat(B).int().contiguous()
+# the real table (backbone_vica._pos_tables): image queries see all T*M2 keys, only the camera token of frame t is limited to frames <= t
+kv = torch.full((B, T, M2), T * M2, dtype=torch.int32, device=d)
+kv[:, :, 0] = ((torch.arange(T, device=d) + 1) * M2).int()[None]
+kv = kv.reshape(-1).contiguous()
 run("video", B * T * M2, 12, B, T * M2, T * M2, T * M2, T * M2, kvlen=kv)
 seg = []
 for b in range(B):
