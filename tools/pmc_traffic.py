@@ -1,6 +1,7 @@
 """Aggregate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs) of bench.py into profiles/round1_pmc_traffic.json.
 
-usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_executed> <out.json>
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_executed> <out.json> [scenes_per_gpu=24]
+(bench.py only uses the file when its "workload" block matches the workload being benchmarked: the default 24 scenes x 8 views x 12 targets)
 HBM bytes per kernel family, gfx950 corrections as MI355X_MICROARCH.md prescribes: rocprofv3 reports FETCH_SIZE / WRITE_SIZE
 in KiB; FETCH_SIZE counts a wide coalesced read at half its size on gfx950 (x2); WRITE_SIZE is taken as reported.
 """
@@ -35,6 +36,7 @@ def load(path, counter):
 
 def main():
     fetch_csv, write_csv, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    scenes = int(sys.argv[5]) if len(sys.argv) > 5 else 24
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     kernels = {}
     for fam in sorted(set(f) | set(w)):
@@ -46,7 +48,7 @@ def main():
     json.dump(dict(command="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py "
                            "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline", steps=steps,
                    units="KiB as reported; fetch corrected x2 for gfx950 (MI355X_MICROARCH.md, HBM section); write as reported",
-                   kernels=kernels), open(out, "w"), indent=1)
+                   kernels=kernels, workload=dict(scenes_per_gpu=scenes, context_views=8, target_views=12)), open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:12s} launches {v['launches']:6d}  HBM/launch {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB   HBM/step {v['hbm_bytes_per_step'] / 1e9:8.2f} GB")
 
