@@ -268,6 +268,12 @@ int vs_gemm_taps_accumulate(const void *A, const void *W, float *out, int32_t M,
 int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
                   int64_t a_slice_stride, int64_t w_slice_stride, int64_t tap_out_stride, const int32_t *shifts, int32_t ntaps,
                   int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream);
+/* Weight gradient from REDUCTION-MAJOR operands (no transposed copies): out32[M,N] (+)= sum_{k < Kred} A[k,m] W[k,n], A [Kred,M] and
+ * W [Kred,N] row-major 16-bit, i.e. dW = dY^T X straight from dY [tokens, out features] and X [tokens, in features].  The kernel
+ * gathers its MFMA operands with the LDS transpose read ds_read_b64_tr_b16.  M, N multiples of 256; lda, ldw multiples of 8; A, W
+ * 16-byte aligned; ksplit slices of the reduction, zero-filled past Kred; workspace / accumulate as in vs_gemm_wgrad. */
+int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t Kred, int32_t lda, int32_t ldw, int32_t ldo,
+                     int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
 /* vs_transpose16 with extras: colsum (nullable, f32 [C], overwritten) = column sums of the input, i.e. the bias gradient rides on
  * the transpose of dY that the weight-gradient GEMM needs anyway (dtype 1 f16 / 2 bf16); border_h, border_w > 0: the R input rows

@@ -504,6 +504,31 @@ def test_gemm_splitk_accumulate_matches_matmul(dt, M, N, K, ks, mode):
     assert (out.double() - want).abs().max() <= 2e-5 * want.abs().max() + 2e-5
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Kred,M,N,ks", [(256, 256, 256, 1), (130, 256, 512, 1), (1000, 512, 256, 3), (16448, 768, 768, 28), (4099, 1024, 256, 5)])
+def test_gemm_wgrad_tn_matches_matmul(dt, Kred, M, N, ks):
+    """Weight gradient from reduction-major operands (LDS transpose reads): out = a^T w, incl. reduction lengths that are not a
+    multiple of the K tiling (zero-filled by the kernel), row strides larger than the row, accumulate and atomics modes."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(Kred + M + N)
+    abuf = (torch.randn(Kred, M + 24, generator=g) / math.sqrt(Kred)).to(dt).to(d)
+    wbuf = torch.randn(Kred, N + 8, generator=g).to(dt).to(d)
+    a, w = abuf[:, 8:8 + M], wbuf[:, :N]                      # 16-byte aligned column-offset views (ld > row length)
+    want = a.double().t() @ w.double()
+    out = torch.full((M, N), 1e9, device=d)
+    ops.gemm_wgrad_tn(a, w, out, ks, accumulate=False)
+    tol = 2e-5 * float(want.abs().max()) + 2e-5
+    assert float((out.double() - want).abs().max()) <= tol
+    out2 = torch.randn(M, N, generator=g).to(d)
+    want2 = out2.double() + want
+    ops.gemm_wgrad_tn(a, w, out2, ks, accumulate=True)
+    assert float((out2.double() - want2).abs().max()) <= tol
+    out3 = torch.zeros(M, N, device=d)
+    ops.gemm_wgrad_tn(a, w, out3, ks, workspace=False)
+    assert float((out3.double() - want).abs().max()) <= tol
+
+
 def test_gemm_wgrad_taps_and_errors():
     """Tap-fused form: out[t] += A (W shifted by shifts[t])^T, incl. odd (2-byte aligned) shifts, with and without workspace."""
     from vicasplat_amd import ops, _lib as L

@@ -26,7 +26,12 @@ for (m, N, K) in [(M, 3072, 1024), (M, 1024, 1024), (M, 4096, 1024), (M, 1024, 4
     tw = timeit(lambda: ops.gemm_wgrad(dyT, xT, dw, ks, workspace=WS))
     tt = timeit(lambda: (ops.transpose16(dy, unit, colsum_out=db, slices=ks), ops.transpose16(x, unit, slices=ks)))
     td = timeit(lambda: ops.linear_backward(dy, x, w, need_dw=False, need_db=False))
-    print(f"{str((m, N, K)):28s} {tw * 1e6:9.1f} {2 * m * N * K / tw / 1e12:7.1f} {ks:4d} | {tt * 1e6:13.1f} | {td * 1e6:9.1f}")
+    extra = ""
+    if N % 256 == 0 and K % 256 == 0:
+        ttn = timeit(lambda: ops.gemm_wgrad_tn(dy, x, dw, ks, accumulate=False))
+        tcs = timeit(lambda: ops.colsum(dy))
+        extra = f" | TN (no transposes) {ttn * 1e6:8.1f} us {2 * m * N * K / ttn / 1e12:7.1f} TF/s + colsum {tcs * 1e6:6.1f} us"
+    print(f"{str((m, N, K)):28s} {tw * 1e6:9.1f} {2 * m * N * K / tw / 1e12:7.1f} {ks:4d} | {tt * 1e6:13.1f} | {td * 1e6:9.1f}{extra}")
 for (n, H, C1, C2) in [(a.scenes * 8, 256, 128, 128), (a.scenes * 8, 128, 256, 256), (a.scenes * 8, 64, 256, 256), (a.scenes * 8, 256, 256, 128)]:
     x = torch.randn(n, H, H, C1, device=d).half(); dy = torch.randn(n, H, H, C2, device=d).half()
     wp = torch.randn(C2, 3, 3, C1, device=d).half()

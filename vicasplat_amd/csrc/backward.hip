@@ -146,6 +146,38 @@ colsum_kernel(const void *__restrict__ x, long long ld, float *__restrict__ out,
     if (ty == 0 && c < N) unsafeAtomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// 16-bit fast path (N % 8 == 0, 16-byte aligned rows): thread = 8 consecutive columns (one 16-byte load per row), block = 16 column
+// groups (128 columns, 256 contiguous bytes per row) x 16 row lanes; rows strided over gridDim.y blocks; LDS reduction over the row
+// lanes, one f32 atomic per (block, column).
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+colsum16_kernel(const unsigned short *__restrict__ x, long long ld, float *__restrict__ out, int M, int N) {
+    __shared__ float part[16][129];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 128 + cg * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        for (int m = blockIdx.y * 16 + rl; m < M; m += gridDim.y * 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + (long long)m * ld + c);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[2 * k] += ld16<BF16>((unsigned short)(w[k] & 0xffffu));
+                s[2 * k + 1] += ld16<BF16>((unsigned short)(w[k] >> 16));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[rl][cg * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < N) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += part[r][threadIdx.x];
+        unsafeAtomicAdd(out + blockIdx.x * 128 + threadIdx.x, a);
+    }
+}
+
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 gelu_backward_kernel(const unsigned short *__restrict__ dy, const unsigned short *__restrict__ z, unsigned short *__restrict__ dz,
@@ -468,6 +500,14 @@ extern "C" int vs_colsum(const void *x, int64_t ld, float *out, int32_t M, int32
     VS_CHECK(M >= 0 && N > 0 && ld >= N, "vs_colsum: bad sizes");
     VS_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream));
     if (M == 0) return 0;
+    if (dtype != 0 && N % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0) {   // 16-byte loads
+        const int gx = vs::cdiv(N, 128);
+        dim3 g16(gx, std::max(1, std::min(std::max(1, 2048 / gx), vs::cdiv(M, 64)))), block(256);
+        if (dtype == 2) hipLaunchKernelGGL(colsum16_kernel<true>, g16, block, 0, stream, (const unsigned short *)x, (long long)ld, out, M, N);
+        else hipLaunchKernelGGL(colsum16_kernel<false>, g16, block, 0, stream, (const unsigned short *)x, (long long)ld, out, M, N);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     dim3 grid(vs::cdiv(N, 64), std::min(std::max(256, 2048 / vs::cdiv(N, 64)), vs::cdiv(M, 64))), block(256);
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, grid, block, 0, stream, x, (long long)ld, out, M, N);
     else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<1>, grid, block, 0, stream, x, (long long)ld, out, M, N);

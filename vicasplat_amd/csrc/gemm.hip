@@ -454,7 +454,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
-    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0;
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
@@ -514,13 +514,62 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
-    g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride;
+    g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
     for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
     VS_CHECK(accumulate || workspace, "vs_gemm_wgrad: accumulate = 0 (overwrite out) needs a workspace; the atomics path can only add");
     const int rc = dtype == 2 ? launch_wgrad<true>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
                               : launch_wgrad<false>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream);
     if (rc) return rc;
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// Weight gradient from REDUCTION-MAJOR operands: out32[M, N] (+)= sum over k < Kred of A[k, m] W[k, n] with A [Kred, M] and
+// W [Kred, N] row-major 16-bit -- dW = dY^T X straight from dY [tokens, out features] and X [tokens, in features], without the
+// transposed copies vs_gemm_wgrad needs.  M and N must be multiples of 256 (whole tiles of the 8-wave kernel), lda / ldw
+// multiples of 8, A / W 16-byte aligned.  The reduction is cut into ksplit slices of an even number (>= 2) of 64-row K tiles
+// (the last slice is zero-filled past Kred by the kernel); workspace / accumulate as in vs_gemm_wgrad.
+extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t Kred, int32_t lda, int32_t ldw,
+                                int32_t ldo, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate,
+                                vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(A && W && out, "vs_gemm_wgrad_tn: null pointer");
+    VS_CHECK(M > 0 && N > 0 && Kred > 0 && ksplit >= 1 && ksplit <= 65535, "vs_gemm_wgrad_tn: bad sizes");
+    VS_CHECK(M % 256 == 0 && N % 256 == 0, "vs_gemm_wgrad_tn: M=%d and N=%d must be multiples of 256", M, N);
+    VS_CHECK(lda % 8 == 0 && ldw % 8 == 0 && lda >= M && ldw >= N, "vs_gemm_wgrad_tn: lda / ldw must be multiples of 8 and cover the rows");
+    VS_CHECK((((uintptr_t)A | (uintptr_t)W) & 15) == 0, "vs_gemm_wgrad_tn: A and W must be 16-byte aligned");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_wgrad_tn: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(accumulate || workspace, "vs_gemm_wgrad_tn: accumulate = 0 (overwrite out) needs a workspace");
+    const int unit = 128 * ksplit;
+    const long long Kpad = ((long long)Kred + unit - 1) / unit * unit;
+    VS_CHECK(Kpad < 2147483647LL, "vs_gemm_wgrad_tn: reduction too long");
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.M = M; g.N = N; g.K = (int)Kpad; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
+    g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
+    g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
+    g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr;
+    const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
+    if (workspace) {
+        VS_CHECK(workspace_bytes >= need, "vs_gemm_wgrad_tn: workspace of %lld bytes given, %lld needed", (long long)workspace_bytes, need);
+        VS_CHECK(((uintptr_t)workspace & 15) == 0, "vs_gemm_wgrad_tn: workspace must be 16-byte aligned");
+        g.partials = (float *)workspace;
+    }
+    const long long nwg = (long long)(M / 256) * (N / 256) * ksplit;
+    VS_CHECK(nwg <= 0x7fffffffLL, "vs_gemm_wgrad_tn: grid too large");
+    if (dtype == 2) hipLaunchKernelGGL((gemm256_tn_splitk_kernel<true>), dim3((unsigned)nwg), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((gemm256_tn_splitk_kernel<false>), dim3((unsigned)nwg), dim3(512), 0, stream, g);
+    if (workspace) {
+        const bool v4 = ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        const long long items = (long long)M * (v4 ? N / 4 : N);
+        const dim3 grid((unsigned)((items + 255) / 256));
+        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);
+    }
     VS_HIP(hipGetLastError());
     return 0;
 }
@@ -563,7 +612,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
-    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0;
+    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;

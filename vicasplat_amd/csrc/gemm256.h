@@ -34,7 +34,15 @@ __device__ __forceinline__ int unit_b_tile_row256(int q, int h) { return (q >> 5
 
 // The K loop.  `st.stage(u, kt, lds_byte_offset)` issues this wave's two global_load_lds_dwordx4 for unit u (0 A_0, 1 A_1,
 // 2 B_0, 3 B_1) of K-tile kt; RELU_A clamps the A fragments at zero on their way to the MFMA (conv: activation-before-conv).
-template <bool BF16, bool RELU_A, class Stager>
+//
+// TN = true: the operands are REDUCTION-MAJOR in memory (element (k, m) at k * ld + m: a weight gradient dW = dY^T X read
+// straight from dY [tokens, N] and X [tokens, K], no transposed copies).  A staged unit is then 64 reduction rows x 256 B (the
+// unit's 128 tile rows as two / four contiguous column segments per reduction row), and a fragment is gathered with the LDS
+// transpose read ds_read_b64_tr_b16: lane t of a 16-lane group supplies the address of B[t>>2][(t&3)*4 .. +3] of a
+// [4 reduction rows][16 tile rows] block and receives column t, i.e. 4 consecutive k of its tile row (probed on hardware:
+// tools/probe/tr_read.hip).  Two such reads are the 8 k-values of one MFMA operand.  The 16-byte chunk index is XORed with
+// (reduction row & 3) << 1, so that the four rows of a block land in four different 8-bank windows.
+template <bool BF16, bool RELU_A, class Stager, bool TN = false>
 __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[8][4], const unsigned char *smem, const int lane,
                                             const int wid) {
     constexpr unsigned UNITB = kUnitBytes256;
@@ -49,6 +57,24 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
     const unsigned rd1 = (unsigned)(frow * 128 + (((4 + fg) ^ (frow >> 1)) << 4));
     const unsigned char *rdA = smem + wr * (64 * 128);
     const unsigned char *rdB = smem + wc * (32 * 128);
+    // TN: per-lane byte offsets of the transpose reads inside a unit (see above); t = lane in its 16-lane group, kg = group
+    [[maybe_unused]] unsigned tnA[4], tnB[2];
+    if constexpr (TN) {
+        const int t = lane & 15, kg = lane >> 4, tq = t >> 2, c1 = (t & 3) >> 1;
+        const unsigned rowb = (unsigned)((kg * 8 + tq) * 256 + (t & 1) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tnA[i] = rowb + (unsigned)(((wr * 8 + i * 2 + c1) ^ (tq << 1)) << 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tnB[j] = rowb + (unsigned)(((wc * 4 + j * 2 + c1) ^ (tq << 1)) << 4);
+    }
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef tr4 __attribute__((address_space(3))) *trp_t;
+    auto tr8 = [&](const unsigned char *p) -> uint4 {   // 8 k-values of one tile row: reduction rows +0..3 and +4..7
+        const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned char *>(p)));
+        const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned char *>(p + 4 * 256)));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
     uint4 fa[4][2], fb[2][2][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -57,13 +83,23 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
 
 #define VS_RD_A(h_, d_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
-        fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd0);           \
-        fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd1);           \
+        if constexpr (TN) {                                                                                      \
+            fa[i][0] = tr8(smem + ((d_) * 4 + (h_)) * UNITB + tnA[i]);                                           \
+            fa[i][1] = tr8(smem + ((d_) * 4 + (h_)) * UNITB + tnA[i] + 32 * 256);                                \
+        } else {                                                                                                 \
+            fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd0);       \
+            fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd1);       \
+        }                                                                                                        \
     }
 #define VS_RD_B(h_, d_)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
-        fb[h_][j][0] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd0);   \
-        fb[h_][j][1] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd1);   \
+        if constexpr (TN) {                                                                                      \
+            fb[h_][j][0] = tr8(smem + ((d_) * 4 + 2 + (h_)) * UNITB + tnB[j]);                                   \
+            fb[h_][j][1] = tr8(smem + ((d_) * 4 + 2 + (h_)) * UNITB + tnB[j] + 32 * 256);                        \
+        } else {                                                                                                 \
+            fb[h_][j][0] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd0); \
+            fb[h_][j][1] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd1); \
+        }                                                                                                        \
     }
 #define VS_RELU_A()                                                                                              \
     if constexpr (RELU_A) {                                                                                      \
@@ -234,6 +270,69 @@ __global__ void __launch_bounds__(512, 1) gemm256_splitk_kernel(const GemmArgs g
     mainloop256<BF16, false>(st, KT, acc, smem, lane, wid);
     g.bias = nullptr;
     g.gate = nullptr;
+    gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
+// ---- reduction-major (TN) weight gradient: out32[M, N] (+)= sum_k A[k, m] W[k, n], A = dY [tokens, M], W = X [tokens, N] as they
+// are in memory.  Same tiling, K slicing and epilogue as gemm256_splitk_kernel; only the staging (column segments of 64
+// reduction rows, rows >= k_valid from a zero page) and the fragment reads (transpose reads) differ. ----
+__device__ __attribute__((aligned(256))) unsigned short vs_zero_row256[128] = {0};
+
+struct GemmStagerTN {
+    const unsigned short *pu[4][2];  // [A0 A1 B0 B1][round]: this lane's 16 bytes in reduction row rrow[round] of K-tile 0
+    long long kst[2];                // element stride of one K-tile (64 reduction rows) in A / W
+    int rrow[2], klim;               // the lane's reduction row inside a K-tile per round; rows >= klim (slice-relative) are zero
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
+        const unsigned short *z = vs_zero_row256;
+        const long long off = kt * kst[u >> 1];
+        glds16(kt * 64 + rrow[0] < klim ? pu[u][0] + off : z, lds);
+        glds16(kt * 64 + rrow[1] < klim ? pu[u][1] + off : z, lds + 1024u);
+    }
+};
+
+template <bool BF16>
+__global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArgs g_in) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    GemmArgs g = g_in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles_n = g.N / BN2;
+    const int tiles = (g.M / BM2) * tiles_n;
+    const int ksp = blockIdx.x / tiles;
+    const int bid = blockIdx.x - ksp * tiles;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int KT = g.K / 64 / g.ksplit;
+    const long long k0 = (long long)ksp * KT * 64;       // first reduction row of this slice
+
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A) + k0 * g.lda;
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + k0 * g.ldw;
+    GemmStagerTN st;
+    st.kst[0] = 64LL * g.lda; st.kst[1] = 64LL * g.ldw;
+    st.klim = (int)max(0LL, min((long long)KT * 64, (long long)g.k_valid - k0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wid * 2 + j) * 4 + (lane >> 4);       // reduction row inside the K-tile that this lane's 16 bytes belong to
+        const int c = (lane & 15) ^ ((r & 3) << 1);           // logical 16-byte chunk of the unit row that must land at slot lane & 15
+        st.rrow[j] = r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            st.pu[h][j] = A + (long long)r * g.lda + m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;       // A_h: tile rows wr*128 + h*64 + 0..63
+            st.pu[2 + h][j] = W + (long long)r * g.ldw + n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;   // B_h: tile cols wc*64 + h*32 + 0..31
+        }
+    }
+    f4 acc[8][4];
+    mainloop256<BF16, false, GemmStagerTN, true>(st, KT, acc, smem, lane, wid);
+    g.bias = nullptr;
+    g.gate = nullptr;
+    g.ksplit = 2;
+    if (g.partials) {
+        g.out = g.partials + ((long long)ksp * g.M) * g.N;
+        g.ldo = g.N;
+        g.ksplit = -1;
+    }
     gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 

@@ -448,14 +448,20 @@ def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_
         dx = torch.empty((M, K), dtype=dy.dtype, device=dev)
         gemm(dyp, wT, None, dx, EPI_STORE16)
     if need_dw:
-        # reduction over the M rows: few output tiles, a very long K -> split it over workgroups (f32 atomics into zeros)
+        # reduction over the M rows: few output tiles, a very long K -> split it over workgroups (partial tiles + reduce kernel)
         ks, unit = wgrad_ksplit(N, K, M)
-        if need_db:
-            db = torch.empty(N, dtype=torch.float32, device=dev)
-        # slice-blocked [ks, N, Mpad/ks], [ks, K, Mpad/ks], zero padded
-        dyT, xT = transpose16(dy, unit, colsum_out=db, slices=ks), transpose16(x, unit, slices=ks)
         dw = torch.empty((N, K), dtype=torch.float32, device=dev)
-        gemm_wgrad(dyT, xT, dw, ks, accumulate=False)
+        if N % 256 == 0 and K % 256 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+            # whole 256-tiles: the reduction-major kernel reads dY and X as they are (LDS transpose reads), no transposed copies
+            gemm_wgrad_tn(dy, x, dw, ks, accumulate=False)
+            if need_db:
+                db = colsum(dy)
+        else:
+            if need_db:
+                db = torch.empty(N, dtype=torch.float32, device=dev)
+            # slice-blocked [ks, N, Mpad/ks], [ks, K, Mpad/ks], zero padded
+            dyT, xT = transpose16(dy, unit, colsum_out=db, slices=ks), transpose16(x, unit, slices=ks)
+            gemm_wgrad(dyT, xT, dw, ks, accumulate=False)
     elif need_db:
         db = colsum(dy)
     return dx, dw, db
@@ -503,6 +509,24 @@ def gemm_wgrad(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int,
         rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(w), L.ptr(out), M, N, K, a.stride(-2), w.stride(-2), N, asl, wsl, M * N, sh, ntaps,
                                    ksplit, _DT[a.dtype], L.ptr(ws), ws_bytes, int(accumulate), L.stream_ptr(dev))
     L.check(rc, "vs_gemm_wgrad")
+    return out
+
+
+def gemm_wgrad_tn(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int, *, workspace: bool = True, accumulate: bool = True):
+    """out32[M,N] (+)= a^T @ w for reduction-major operands a [Kred, M], w [Kred, N] (16-bit, row stride any multiple of 8): the weight
+    gradient dW = dY^T X without transposed copies (vs_gemm_wgrad_tn; M, N multiples of 256)."""
+    dev = L.require_device(a, w, out)
+    assert a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[0] == w.shape[0]
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == (a.shape[1], w.shape[1])
+    M, N, Kred = a.shape[1], w.shape[1], a.shape[0]
+    ws, ws_bytes = None, 0
+    if workspace:
+        ws = torch.empty(ksplit * M * N, dtype=torch.float32, device=dev)
+        ws_bytes = ws.numel() * 4
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_wgrad_tn(L.ptr(a), L.ptr(w), L.ptr(out), M, N, Kred, a.stride(0), w.stride(0), N, ksplit, _DT[a.dtype],
+                                      L.ptr(ws), ws_bytes, int(accumulate), L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_wgrad_tn")
     return out
 
 
