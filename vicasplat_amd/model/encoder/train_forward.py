@@ -131,8 +131,8 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         n_, _, h_, w_ = fr.shape
         f = lambda u: F.unfold(u.to(dt), 7, padding=3).transpose(1, 2)          # [n, h*w, 147] in (c, ky, kx) order = weight.flatten(1)
         cols = chunked(f, fr, h_ * w_ * 147)
-        cols = F.pad(cols, (0, 192 - 147))
-        wk = F.pad(w.flatten(1), (0, 192 - 147))
+        cols = F.pad(cols, (0, 256 - 147))     # 256 columns: whole tiles for the reduction-major weight-gradient kernel (no transposes)
+        wk = F.pad(w.flatten(1), (0, 256 - 147))
         return A.linear(cols, wk, P.get(name + ".bias"), dt).view(n_, h_, w_, w.shape[0])
 
     def rcu(name, t):
