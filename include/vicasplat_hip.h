@@ -270,8 +270,8 @@ int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N
                   int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream);
 /* Weight gradient from REDUCTION-MAJOR operands (no transposed copies): out32[M,N] (+)= sum_{k < Kred} A[k,m] W[k,n], A [Kred,M] and
  * W [Kred,N] row-major 16-bit, i.e. dW = dY^T X straight from dY [tokens, out features] and X [tokens, in features].  The kernel
- * gathers its MFMA operands with the LDS transpose read ds_read_b64_tr_b16.  M, N multiples of 256; lda, ldw multiples of 8; A, W
- * 16-byte aligned; ksplit slices of the reduction, zero-filled past Kred; workspace / accumulate as in vs_gemm_wgrad. */
+ * gathers its MFMA operands with the LDS transpose read ds_read_b64_tr_b16.  lda, ldw multiples of 8 (padded rows allowed); A, W
+ * 16-byte aligned; M, N arbitrary (256 x 256 tiles, zero page beyond the row storage); ksplit slices of the reduction, zero-filled past Kred; workspace / accumulate as in vs_gemm_wgrad. */
 int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t Kred, int32_t lda, int32_t ldw, int32_t ldo,
                      int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
@@ -305,13 +305,13 @@ int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, con
                           int32_t grp_out, int32_t grp_off, vs_stream_t stream);
 
 /* Backward of vs_gaussian_adapter for dense NHWC 16-bit head outputs (training): gradients of means [npix,3], covariances [npix,3,3],
- * harmonics [npix,3,d_sh], opacities [npix] and (nullable) of the raw output [npix, 11 + 3 d_sh] -> d_pts [npix, pts_pix], d_gs
- * [npix, 8 + 3 d_sh] in the inputs' dtype (1 f16, 2 bf16).  Backward of MyGaussianAdapter.forward + the 'exp' depth post-process
+ * harmonics [npix,3,d_sh], opacities [npix] and (nullable) of the raw output [npix, 11 + 3 d_sh] -> d_pts [npix, d_pts_ld], d_gs
+ * [npix, d_gs_ld] in the inputs' dtype (1 f16, 2 bf16); the row strides may exceed the channel counts (padding columns are zeroed).  Backward of MyGaussianAdapter.forward + the 'exp' depth post-process
  * (common/gaussian_adapter.py:168-212, heads/postprocess.py:46-56) in one pass. */
 int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *gs, int32_t in_dtype, int64_t npix, int32_t d_sh,
                                  const float *sh_mask, int32_t scale_act, float scale_min, float scale_max, float opacity_exponent,
                                  const float *d_means, const float *d_cov, const float *d_harmonics, const float *d_opacities,
-                                 const float *d_raw, void *d_pts, void *d_gs, vs_stream_t stream);
+                                 const float *d_raw, void *d_pts, int32_t d_pts_ld, void *d_gs, int32_t d_gs_ld, vs_stream_t stream);
 
 #ifdef __cplusplus
 }

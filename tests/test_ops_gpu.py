@@ -505,15 +505,17 @@ def test_gemm_splitk_accumulate_matches_matmul(dt, M, N, K, ks, mode):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("Kred,M,N,ks", [(256, 256, 256, 1), (130, 256, 512, 1), (1000, 512, 256, 3), (16448, 768, 768, 28), (4099, 1024, 256, 5)])
+@pytest.mark.parametrize("Kred,M,N,ks", [(256, 256, 256, 1), (130, 256, 512, 1), (1000, 512, 256, 3), (16448, 768, 768, 28), (4099, 1024, 256, 5),
+                                         (70000, 83, 256, 16), (70000, 4, 128, 8), (3000, 96, 200, 2)])
 def test_gemm_wgrad_tn_matches_matmul(dt, Kred, M, N, ks):
     """Weight gradient from reduction-major operands (LDS transpose reads): out = a^T w, incl. reduction lengths that are not a
     multiple of the K tiling (zero-filled by the kernel), row strides larger than the row, accumulate and atomics modes."""
     from vicasplat_amd import ops
     d = _dev()
     g = torch.Generator(device="cpu").manual_seed(Kred + M + N)
-    abuf = (torch.randn(Kred, M + 24, generator=g) / math.sqrt(Kred)).to(dt).to(d)
-    wbuf = torch.randn(Kred, N + 8, generator=g).to(dt).to(d)
+    Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8               # rows padded to 16-byte multiples (any M, N: skinny layers)
+    abuf = (torch.randn(Kred, Mp + 24, generator=g) / math.sqrt(Kred)).to(dt).to(d)
+    wbuf = torch.randn(Kred, Np + 8, generator=g).to(dt).to(d)
     a, w = abuf[:, 8:8 + M], wbuf[:, :N]                      # 16-byte aligned column-offset views (ld > row length)
     want = a.double().t() @ w.double()
     out = torch.full((M, N), 1e9, device=d)

@@ -90,7 +90,7 @@ def lib() -> C.CDLL:
             L.vs_attention.restype = C.c_int
             L.vs_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp]
             L.vs_gaussian_adapter_backward.restype = C.c_int
-            L.vs_gaussian_adapter_backward.argtypes = [vp, i32, vp, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.vs_gaussian_adapter_backward.argtypes = [vp, i32, vp, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp]
             L.vs_gaussian_adapter.restype = C.c_int
             L.vs_gaussian_adapter.argtypes = [vp, i64, i64, vp, i64, i64, i32, i64, i32, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
             L.vs_rope_qk_dir.restype = C.c_int

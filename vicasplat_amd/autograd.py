@@ -42,7 +42,9 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x16, w16 = ctx.saved_tensors
         xshape, xdtype, has_b, rope = ctx.meta
-        dy16 = dy.reshape(-1, dy.shape[-1]).to(w16.dtype).contiguous()
+        dy16 = dy.reshape(-1, dy.shape[-1]).to(w16.dtype)
+        if dy16.stride(1) != 1 or dy16.stride(0) % 8 != 0 or dy16.data_ptr() % 16 != 0:
+            dy16 = dy16.contiguous()          # (row-padded gradients -- 16-byte aligned rows -- are consumed as they are)
         if rope is not None:
             pos, kind, H, C, base2d, theta1d = rope
             ops.rope_qk(dy16, H, C, pos, kind, base2d, theta1d, inverse=True)

@@ -251,7 +251,8 @@ struct AdapterBwdArgs {
     int scale_act;
     float scale_min, scale_max, opacity_exponent;
     const float *d_means, *d_cov, *d_harm, *d_op, *d_raw;   // d_raw may be null
-    void *d_pts, *d_gs;        // outputs, same layouts / dtype as pts, gs
+    void *d_pts, *d_gs;        // outputs in the inputs' dtype: d_pts [npix, d_pts_ld], d_gs [npix, d_gs_ld] (row strides >= channels;
+    int d_pts_ld, d_gs_ld;     // padding columns are written as zeros, so that the rows can be 16-byte aligned for the consumers)
 };
 
 template <bool BF16>
@@ -269,7 +270,7 @@ __device__ __forceinline__ unsigned short to16a(float v) {
 template <bool BF16>
 __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float s_harm[64 * (kMaxCh - 11)], s_raw[64 * kMaxCh];
-    __shared__ __attribute__((aligned(16))) unsigned short s_out[64 * (kMaxCh - 3) + 16];
+    __shared__ __attribute__((aligned(16))) unsigned short s_out[64 * kMaxCh + 16];
     const int lane = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * 64;
     const int np = (int)min((long long)64, a.npix - p0);
@@ -379,26 +380,28 @@ __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdAr
         for (int c = 0; c < 4; ++c) dg8[4 + c] = (dq[c] - q[c] * qdq) / qn + (rr ? rr[7 + c] : 0.f);
     }
     // ---- d_gs block [64][cg] 16-bit through LDS ----
+    const int gld = a.d_gs_ld;
     if (live) {
-        unsigned short *o = s_out + lane * cg;
+        unsigned short *o = s_out + lane * gld;
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[c] = to16a<BF16>(dg8[c]);
         const float *hh = s_harm + lane * nh;
         const float *rr = a.d_raw ? s_raw + lane * craw : nullptr;
         for (int c = 0; c < nh; ++c) o[8 + c] = to16a<BF16>(hh[c] * a.sh_mask[c % nsh] + (rr ? rr[11 + c] : 0.f));
+        for (int c = cg; c < gld; ++c) o[c] = 0;
     }
     __syncthreads();
     {
-        unsigned short *dst = reinterpret_cast<unsigned short *>(a.d_gs) + p0 * cg;
-        const int n = np * cg;
+        unsigned short *dst = reinterpret_cast<unsigned short *>(a.d_gs) + p0 * gld;
+        const int n = np * gld;
         for (int k = lane; k < (n >> 3); k += 64) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(s_out)[k];
         for (int k = ((n >> 3) << 3) + lane; k < n; k += 64) dst[k] = s_out[k];
     }
     if (live) {
-        unsigned short *dp = reinterpret_cast<unsigned short *>(a.d_pts) + i * a.pts_pix;
+        unsigned short *dp = reinterpret_cast<unsigned short *>(a.d_pts) + i * a.d_pts_ld;
 #pragma unroll
         for (int c = 0; c < 3; ++c) dp[c] = to16a<BF16>(dpt[c]);
-        for (int c = 3; c < a.pts_pix; ++c) dp[c] = 0;
+        for (int c = 3; c < a.d_pts_ld; ++c) dp[c] = 0;
     }
 }
 
@@ -434,19 +437,22 @@ extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts
 
 // Backward of vs_gaussian_adapter for dense NHWC 16-bit head outputs (the training path): gradients of means [npix,3],
 // covariances [npix,3,3], harmonics [npix,3,d_sh], opacities [npix] and, optionally, of the raw output [npix, 11+3 d_sh]
-// -> d_pts [npix, pts_pix] and d_gs [npix, 8+3 d_sh] in the inputs' 16-bit dtype (channels of pts beyond 3 get zero).
+// -> d_pts [npix, d_pts_ld] and d_gs [npix, d_gs_ld] in the inputs' 16-bit dtype (row strides >= the channel counts; channels of pts
+// beyond 3 and all padding columns get zero, so a consumer can read 16-byte aligned rows).
 extern "C" int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *gs, int32_t in_dtype, int64_t npix, int32_t d_sh,
                                             const float *sh_mask, int32_t scale_act, float scale_min, float scale_max,
                                             float opacity_exponent, const float *d_means, const float *d_cov, const float *d_harmonics,
-                                            const float *d_opacities, const float *d_raw, void *d_pts, void *d_gs, vs_stream_t stream_) {
+                                            const float *d_opacities, const float *d_raw, void *d_pts, int32_t d_pts_ld, void *d_gs,
+                                            int32_t d_gs_ld, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(pts && gs && sh_mask && d_means && d_cov && d_harmonics && d_opacities && d_pts && d_gs, "vs_gaussian_adapter_backward: null pointer");
     VS_CHECK((in_dtype == 1 || in_dtype == 2) && d_sh > 0 && 11 + 3 * d_sh <= kMaxCh && scale_act >= 0 && scale_act <= 2 && pts_pix >= 3,
              "vs_gaussian_adapter_backward: bad argument (16-bit inputs, 11 + 3 d_sh <= %d)", kMaxCh);
     VS_CHECK(((uintptr_t)d_gs & 15) == 0, "vs_gaussian_adapter_backward: d_gs must be 16-byte aligned");
+    VS_CHECK(d_pts_ld >= pts_pix && d_gs_ld >= 8 + 3 * d_sh && d_gs_ld <= kMaxCh, "vs_gaussian_adapter_backward: output row strides must cover the channels (d_gs_ld <= %d)", kMaxCh);
     if (npix <= 0) return 0;
     AdapterBwdArgs a{pts, gs, pts_pix, npix, d_sh, sh_mask, scale_act, scale_min, scale_max, opacity_exponent, d_means, d_cov, d_harmonics,
-                     d_opacities, d_raw, d_pts, d_gs};
+                     d_opacities, d_raw, d_pts, d_gs, d_pts_ld, d_gs_ld};
     dim3 grid((unsigned)vs::cdiv64(npix, 64));
     if (in_dtype == 2) hipLaunchKernelGGL(adapter_backward_kernel<true>, grid, dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(adapter_backward_kernel<false>, grid, dim3(64), 0, stream, a);

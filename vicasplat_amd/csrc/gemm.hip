@@ -527,8 +527,8 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
 
 // Weight gradient from REDUCTION-MAJOR operands: out32[M, N] (+)= sum over k < Kred of A[k, m] W[k, n] with A [Kred, M] and
 // W [Kred, N] row-major 16-bit -- dW = dY^T X straight from dY [tokens, out features] and X [tokens, in features], without the
-// transposed copies vs_gemm_wgrad needs.  M and N must be multiples of 256 (whole tiles of the 8-wave kernel), lda / ldw
-// multiples of 8, A / W 16-byte aligned.  The reduction is cut into ksplit slices of an even number (>= 2) of 64-row K tiles
+// transposed copies vs_gemm_wgrad needs.  lda / ldw multiples of 8 (rows may be padded: lda >= M), A / W 16-byte aligned; M and N
+// need not be tile multiples (256 x 256 tiles; columns beyond the row storage come from a zero page).  The reduction is cut into ksplit slices of an even number (>= 2) of 64-row K tiles
 // (the last slice is zero-filled past Kred by the kernel); workspace / accumulate as in vs_gemm_wgrad.
 extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t Kred, int32_t lda, int32_t ldw,
                                 int32_t ldo, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate,
@@ -536,7 +536,6 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(A && W && out, "vs_gemm_wgrad_tn: null pointer");
     VS_CHECK(M > 0 && N > 0 && Kred > 0 && ksplit >= 1 && ksplit <= 65535, "vs_gemm_wgrad_tn: bad sizes");
-    VS_CHECK(M % 256 == 0 && N % 256 == 0, "vs_gemm_wgrad_tn: M=%d and N=%d must be multiples of 256", M, N);
     VS_CHECK(lda % 8 == 0 && ldw % 8 == 0 && lda >= M && ldw >= N, "vs_gemm_wgrad_tn: lda / ldw must be multiples of 8 and cover the rows");
     VS_CHECK((((uintptr_t)A | (uintptr_t)W) & 15) == 0, "vs_gemm_wgrad_tn: A and W must be 16-byte aligned");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_wgrad_tn: dtype must be 1 (f16) or 2 (bf16)");
@@ -559,12 +558,12 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
         VS_CHECK(((uintptr_t)workspace & 15) == 0, "vs_gemm_wgrad_tn: workspace must be 16-byte aligned");
         g.partials = (float *)workspace;
     }
-    const long long nwg = (long long)(M / 256) * (N / 256) * ksplit;
+    const long long nwg = (long long)vs::cdiv(M, 256) * vs::cdiv(N, 256) * ksplit;
     VS_CHECK(nwg <= 0x7fffffffLL, "vs_gemm_wgrad_tn: grid too large");
     if (dtype == 2) hipLaunchKernelGGL((gemm256_tn_splitk_kernel<true>), dim3((unsigned)nwg), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((gemm256_tn_splitk_kernel<false>), dim3((unsigned)nwg), dim3(512), 0, stream, g);
     if (workspace) {
-        const bool v4 = ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        const bool v4 = N % 4 == 0 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
         const long long items = (long long)M * (v4 ? N / 4 : N);
         const dim3 grid((unsigned)((items + 255) / 256));
         if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);

@@ -285,8 +285,8 @@ struct GemmStagerTN {
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
         const unsigned short *z = vs_zero_row256;
         const long long off = kt * kst[u >> 1];
-        glds16(kt * 64 + rrow[0] < klim ? pu[u][0] + off : z, lds);
-        glds16(kt * 64 + rrow[1] < klim ? pu[u][1] + off : z, lds + 1024u);
+        glds16((kt * 64 + rrow[0] < klim && pu[u][0]) ? pu[u][0] + off : z, lds);
+        glds16((kt * 64 + rrow[1] < klim && pu[u][1]) ? pu[u][1] + off : z, lds + 1024u);
     }
 };
 
@@ -298,8 +298,8 @@ __global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    const int tiles_n = g.N / BN2;
-    const int tiles = (g.M / BM2) * tiles_n;
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
     const int ksp = blockIdx.x / tiles;
     const int bid = blockIdx.x - ksp * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
@@ -319,8 +319,12 @@ __global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArg
         st.rrow[j] = r;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            st.pu[h][j] = A + (long long)r * g.lda + m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;       // A_h: tile rows wr*128 + h*64 + 0..63
-            st.pu[2 + h][j] = W + (long long)r * g.ldw + n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;   // B_h: tile cols wc*64 + h*32 + 0..31
+            // 16-byte column chunks that start beyond the row's storage (outputs that are not whole 256-tiles: skinny layers) come
+            // from the zero page; chunks inside [M, lda) hold whatever pads the row -- their outputs are masked by the epilogue
+            const int ca = m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;       // A_h: tile rows wr*128 + h*64 + 0..63
+            const int cw = n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;        // B_h: tile cols wc*64 + h*32 + 0..31
+            st.pu[h][j] = ca + 8 <= g.lda ? A + (long long)r * g.lda + ca : nullptr;
+            st.pu[2 + h][j] = cw + 8 <= g.ldw ? W + (long long)r * g.ldw + cw : nullptr;
         }
     }
     f4 acc[8][4];

@@ -175,7 +175,8 @@ def gaussian_adapter_backward(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torc
                               scale_min: float = 0.0, scale_max: float = 0.0, opacity_exponent: float = 1.0):
     """Backward of gaussian_adapter for dense NHWC 16-bit head outputs pts [N,H,W,pts_pix>=3], gs [N,H,W,8+3*d_sh]: f32 gradients of
     means [..,3], covariances [..,3,3], harmonics [..,3,d_sh], opacities [..] (and optionally raw [..,11+3*d_sh]) -> (d_pts, d_gs)
-    in the inputs' layout and dtype."""
+    in the inputs' shape and dtype, as views of buffers whose rows are padded to a multiple of 8 channels (16-byte aligned rows with
+    zero padding: what the reduction-major weight-gradient kernel of the 1x1 convs in front of the adapter reads directly)."""
     dev = L.require_device(pts, gs, sh_mask, d_means, d_cov, d_harm, d_op, d_raw)
     assert pts.is_contiguous() and gs.is_contiguous() and pts.dtype == gs.dtype and pts.dtype in (torch.float16, torch.bfloat16)
     d_sh = (gs.shape[-1] - 8) // 3
@@ -184,14 +185,16 @@ def gaussian_adapter_backward(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torc
     d_means, d_cov, d_harm, d_op, d_raw = f(d_means), f(d_cov), f(d_harm), f(d_op), f(d_raw)
     assert d_means.numel() == npix * 3 and d_cov.numel() == npix * 9 and d_harm.numel() == npix * 3 * d_sh and d_op.numel() == npix
     assert d_raw is None or d_raw.numel() == npix * (11 + 3 * d_sh)
-    d_pts, d_gs = torch.empty_like(pts), torch.empty_like(gs)
+    pl, gl = (pts.shape[-1] + 7) // 8 * 8, (gs.shape[-1] + 7) // 8 * 8
+    d_pts = torch.empty(pts.shape[:-1] + (pl,), dtype=pts.dtype, device=dev)
+    d_gs = torch.empty(gs.shape[:-1] + (gl,), dtype=gs.dtype, device=dev)
     act = {"bounded": 0, "exp": 1, "softplus": 2}[scale_act]
     with torch.cuda.device(dev):
         rc = L.lib().vs_gaussian_adapter_backward(L.ptr(pts), pts.shape[-1], L.ptr(gs), _DT[pts.dtype], npix, d_sh, L.ptr(sh_mask), act,
                                                   scale_min, scale_max, opacity_exponent, L.ptr(d_means), L.ptr(d_cov), L.ptr(d_harm),
-                                                  L.ptr(d_op), L.ptr(d_raw), L.ptr(d_pts), L.ptr(d_gs), L.stream_ptr(dev))
+                                                  L.ptr(d_op), L.ptr(d_raw), L.ptr(d_pts), pl, L.ptr(d_gs), gl, L.stream_ptr(dev))
     L.check(rc, "vs_gaussian_adapter_backward")
-    return d_pts, d_gs
+    return d_pts[..., :pts.shape[-1]], d_gs[..., :gs.shape[-1]]
 
 
 def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -451,11 +454,17 @@ def linear_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_
         # reduction over the M rows: few output tiles, a very long K -> split it over workgroups (partial tiles + reduce kernel)
         ks, unit = wgrad_ksplit(N, K, M)
         dw = torch.empty((N, K), dtype=torch.float32, device=dev)
-        if N % 256 == 0 and K % 256 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
-            # whole 256-tiles: the reduction-major kernel reads dY and X as they are (LDS transpose reads), no transposed copies
-            gemm_wgrad_tn(dy, x, dw, ks, accumulate=False)
+        skinny = M >= 1 << 20                    # millions of rows: HBM-bound whatever the tile fill, and the transposes cost 3 passes
+        if (((N % 256 == 0 and K % 256 == 0) or skinny) and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+                and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dy.stride(0) >= (N + 7) // 8 * 8):
+            # the reduction-major kernel reads dY and X as they are (LDS transpose reads), no transposed copies
+            gemm_wgrad_tn(dy, x, dw, ks if (N % 256 == 0 and K % 256 == 0) else max(1, min(256, M // 512)), accumulate=False)
             if need_db:
-                db = colsum(dy)
+                if N % 8 == 0:
+                    db = colsum(dy)
+                else:                             # rows padded with zeros up to a multiple of 8 (gaussian_adapter_backward): 16-byte loads
+                    Np = (N + 7) // 8 * 8
+                    db = colsum(torch.as_strided(dy, (M, Np), (dy.stride(0), 1)))[:N].contiguous()
         else:
             if need_db:
                 db = torch.empty(N, dtype=torch.float32, device=dev)
