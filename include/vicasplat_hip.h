@@ -274,6 +274,14 @@ int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M, int32_t N
  * 16-byte aligned; M, N arbitrary (256 x 256 tiles, zero page beyond the row storage); ksplit slices of the reduction, zero-filled past Kred; workspace / accumulate as in vs_gemm_wgrad. */
 int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_t M, int32_t N, int32_t Kred, int32_t lda, int32_t ldw, int32_t ldo,
                      int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream);
+/* Weight gradient of nn.Conv2d(k=3, s=1, p=1) from the NHWC tensors as they are (reduction-major, LDS transpose reads, zero page
+ * outside the image -- no zero-bordered transposed copies): out32[tap][ci][co] (+)= sum over pixels of act(x)[pixel + tap][ci] *
+ * dy[pixel][co]; x [Nimg,H,W,Cin], dy [Nimg,H,W,Cout] contiguous 16-bit, out [9, Cin, Cout], tap = ky*3 + kx; relu_in = the
+ * ResidualConvUnit's activation-before-conv on x.  Cin, Cout multiples of 8 (256 x 256 tiles: efficient for multiples of 256).
+ * workspace >= ksplit * 9 * Cin * Cout floats or null (atomics); accumulate as in vs_gemm_wgrad. */
+int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                        int32_t relu_in, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate,
+                        vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
 /* vs_transpose16 with extras: colsum (nullable, f32 [C], overwritten) = column sums of the input, i.e. the bias gradient rides on
  * the transpose of dY that the weight-gradient GEMM needs anyway (dtype 1 f16 / 2 bf16); border_h, border_w > 0: the R input rows

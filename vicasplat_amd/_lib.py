@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
             L.vs_gemm_taps_accumulate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, vp, i32, i32, i32, vp]
             L.vs_gemm_wgrad.restype = C.c_int
             L.vs_gemm_wgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, vp, i32, i32, i32, vp, i64, i32, vp]
+            L.vs_conv3x3_wgrad_tn.restype = C.c_int
+            L.vs_conv3x3_wgrad_tn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]
             L.vs_gemm_wgrad_tn.restype = C.c_int
             L.vs_gemm_wgrad_tn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]
             L.vs_transpose16.restype = C.c_int

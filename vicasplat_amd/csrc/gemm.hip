@@ -454,7 +454,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.a_grp_out = a_grp_out > 0 ? a_grp_out : g.a_grp_in;
     g.a_grp_off = a_grp_off;
     g.m_lo = 0;
-    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
@@ -514,7 +514,7 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
-    g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0;
+    g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
     for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
     VS_CHECK(accumulate || workspace, "vs_gemm_wgrad: accumulate = 0 (overwrite out) needs a workspace; the atomics path can only add");
@@ -551,7 +551,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
-    g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr;
+    g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
     if (workspace) {
         VS_CHECK(workspace_bytes >= need, "vs_gemm_wgrad_tn: workspace of %lld bytes given, %lld needed", (long long)workspace_bytes, need);
@@ -568,6 +568,62 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
         const dim3 grid((unsigned)((items + 255) / 256));
         if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);
         else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// Weight gradient of nn.Conv2d(k=3, s=1, p=1) from the NHWC tensors as they are: out32[tap][ci][co] (+)= sum over pixels of
+// act(x)[pixel + tap offset][ci] * dy[pixel][co] (zero outside the image), x [Nimg,H,W,Cin], dy [Nimg,H,W,Cout] contiguous 16-bit,
+// out [9, Cin, Cout] (tap = ky*3 + kx; transpose the last two axes for the module's [Cout, Cin, ky, kx]).  relu_in applies the
+// ResidualConvUnit's activation-before-conv to x on the fly.  Cin, Cout multiples of 8; 256 x 256 tiles, so efficient for channel
+// counts that are multiples of 256.  ksplit slices of the pixel range; workspace (>= ksplit * 9 * Cin * Cout floats) / accumulate
+// as in vs_gemm_wgrad.
+extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, int32_t Nimg, int32_t H, int32_t W, int32_t Cin,
+                                   int32_t Cout, int32_t relu_in, int32_t ksplit, int32_t dtype, void *workspace,
+                                   int64_t workspace_bytes, int32_t accumulate, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && dy && out, "vs_conv3x3_wgrad_tn: null pointer");
+    VS_CHECK(Nimg > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ksplit >= 1 && ksplit <= 65535, "vs_conv3x3_wgrad_tn: bad sizes");
+    VS_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "vs_conv3x3_wgrad_tn: Cin=%d and Cout=%d must be multiples of 8", Cin, Cout);
+    VS_CHECK((((uintptr_t)x | (uintptr_t)dy) & 15) == 0, "vs_conv3x3_wgrad_tn: x and dy must be 16-byte aligned");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_conv3x3_wgrad_tn: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(accumulate || workspace, "vs_conv3x3_wgrad_tn: accumulate = 0 (overwrite out) needs a workspace");
+    const long long P = (long long)Nimg * H * W;
+    const int unit = 128 * ksplit;
+    const long long Kpad = (P + unit - 1) / unit * unit;
+    VS_CHECK(Kpad < 2147483647LL, "vs_conv3x3_wgrad_tn: too many pixels");
+    GemmArgs g;
+    g.A = x; g.W = dy; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.M = Cin; g.N = Cout; g.K = (int)Kpad; g.lda = Cin; g.ldw = Cout; g.ldo = Cout;
+    g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
+    g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
+    g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
+    const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
+    if (workspace) {
+        VS_CHECK(workspace_bytes >= need, "vs_conv3x3_wgrad_tn: workspace of %lld bytes given, %lld needed", (long long)workspace_bytes, need);
+        VS_CHECK(((uintptr_t)workspace & 15) == 0, "vs_conv3x3_wgrad_tn: workspace must be 16-byte aligned");
+        g.partials = (float *)workspace;
+    }
+    const long long nwg = (long long)vs::cdiv(Cin, 256) * vs::cdiv(Cout, 256) * 9 * ksplit;
+    VS_CHECK(nwg <= 0x7fffffffLL, "vs_conv3x3_wgrad_tn: grid too large");
+    const dim3 grid((unsigned)nwg), block(512);
+    if (dtype == 2) {
+        if (relu_in) hipLaunchKernelGGL((conv3x3_wgrad_tn_kernel<true, true>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_wgrad_tn_kernel<true, false>), grid, block, 0, stream, g);
+    } else {
+        if (relu_in) hipLaunchKernelGGL((conv3x3_wgrad_tn_kernel<false, true>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_wgrad_tn_kernel<false, false>), grid, block, 0, stream, g);
+    }
+    if (workspace) {
+        const bool v4 = Cout % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        const long long items = 9LL * Cin * (v4 ? Cout / 4 : Cout);
+        const dim3 rg((unsigned)((items + 255) / 256));
+        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, rg, dim3(256), 0, stream, (const float *)workspace, out, Cin, Cout, 9, ksplit, (long long)Cout, (long long)Cin * Cout, accumulate);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<1>, rg, dim3(256), 0, stream, (const float *)workspace, out, Cin, Cout, 9, ksplit, (long long)Cout, (long long)Cin * Cout, accumulate);
     }
     VS_HIP(hipGetLastError());
     return 0;
@@ -611,7 +667,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;  // pixel (row r, x) -> padded pixel r * Wp + x ...
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
-    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0;
+    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;

@@ -340,4 +340,93 @@ __global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArg
     gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 
+// ---- reduction-major weight gradient of a 3x3 convolution (stride 1, pad 1): out32[tap][ci][co] (+)= sum over pixels p of
+// act(X)[p + shift(tap)][ci] * dY[p][co], X [pixels, Cin] and dY [pixels, Cout] NHWC as they are -- no zero-bordered, transposed
+// copies.  The A operand (X) of tap (ty, tx) is the pixel row shifted by (ty-1)*W + (tx-1); where that pixel falls outside the
+// image the lane reads the zero page instead (the forward conv's scheme, conv.hip), tracked per lane with an incremental
+// (y, x) counter: every staging call of a unit advances its pixel by one K-tile of 64 rows.  ReLU on X = RELU_A of the main loop.
+struct ConvWgradStagerTN {
+    const unsigned short *pa[2][2], *pw[2][2];  // [unit h][round]: this lane's 16 bytes for K-tile 0 (A already tap-shifted)
+    long long kstA, kstW;
+    int rrow[2], klim;
+    int py[2][2], px[2][2];                      // [A unit h][round]: (y, x) of the lane's pixel at the unit's NEXT staging call
+    int H, W, q64, r64, dyy, dxx;                // 64 = q64 * W + r64; tap offset (dyy, dxx) in {-1, 0, 1}
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) {
+        const unsigned short *z = vs_zero_row256;
+        if (u < 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = py[u][j] + dyy, x = px[u][j] + dxx;
+                const bool ok = kt * 64 + rrow[j] < klim && pa[u][j] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                glds16(ok ? pa[u][j] + kt * kstA : z, lds + 1024u * j);
+                int nx = px[u][j] + r64, ny = py[u][j] + q64;   // advance this unit's pixel by 64
+                if (nx >= W) { nx -= W; ++ny; }
+                while (ny >= H) ny -= H;
+                px[u][j] = nx; py[u][j] = ny;
+            }
+        } else {
+            const long long off = kt * kstW;
+            glds16((kt * 64 + rrow[0] < klim && pw[u - 2][0]) ? pw[u - 2][0] + off : z, lds);
+            glds16((kt * 64 + rrow[1] < klim && pw[u - 2][1]) ? pw[u - 2][1] + off : z, lds + 1024u);
+        }
+    }
+};
+
+template <bool BF16, bool RELU_A>
+__global__ void __launch_bounds__(512, 1) conv3x3_wgrad_tn_kernel(const GemmArgs g_in) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    GemmArgs g = g_in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
+    const int ksp = blockIdx.x / (tiles * 9);              // (k-slice, tap, tile): the taps of a slice share X and dY through L2
+    const int rem = blockIdx.x - ksp * tiles * 9;
+    const int tap = rem / tiles, bid = rem - tap * tiles;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int KT = g.K / 64 / g.ksplit;
+    const long long k0 = (long long)ksp * KT * 64;
+    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
+    const long long shift = (long long)dyy * g.conv_W + dxx;
+
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A) + (k0 + shift) * g.lda;
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + k0 * g.ldw;
+    ConvWgradStagerTN st;
+    st.kstA = 64LL * g.lda; st.kstW = 64LL * g.ldw;
+    st.klim = (int)max(0LL, min((long long)KT * 64, (long long)g.k_valid - k0));
+    st.H = g.conv_H; st.W = g.conv_W; st.q64 = 64 / g.conv_W; st.r64 = 64 % g.conv_W; st.dyy = dyy; st.dxx = dxx;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wid * 2 + j) * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((r & 3) << 1);
+        st.rrow[j] = r;
+        const long long p = k0 + r;                          // the lane's pixel at K-tile 0
+        const int rem_p = (int)(p % ((long long)g.conv_H * g.conv_W));
+        const int y0 = rem_p / g.conv_W, x0 = rem_p - y0 * g.conv_W;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ca = m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;
+            const int cw = n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;
+            st.pa[h][j] = ca + 8 <= g.lda ? A + (long long)r * g.lda + ca : nullptr;
+            st.pw[h][j] = cw + 8 <= g.ldw ? W + (long long)r * g.ldw + cw : nullptr;
+            st.py[h][j] = y0; st.px[h][j] = x0;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256<BF16, RELU_A, ConvWgradStagerTN, true>(st, KT, acc, smem, lane, wid);
+    g.bias = nullptr;
+    g.gate = nullptr;
+    g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
+    g.ksplit = 2;
+    if (g.partials) {
+        g.out = g.partials + ((long long)(ksp * 9 + tap) * g.M) * g.N;
+        g.ldo = g.N;
+        g.ksplit = -1;
+    }
+    gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
 }  // namespace

@@ -44,6 +44,7 @@ struct GemmArgs {
     // K step otherwise)
     long long a_slice_stride, w_slice_stride;
     int k_valid;  // reduction-major (TN) weight gradient: real number of reduction rows; rows in [k_valid, K) read as zeros
+    int conv_H, conv_W;  // reduction-major 3x3-conv weight gradient: image size (reduction row = pixel n*H*W + y*W + x of an NHWC tensor)
     // epilogue 4 (STORE16 + RoPE on the q and k column blocks of a packed qkv projection, head_dim 64): per OUTPUT row
     // pos[2] and kind (0: 2-D pairs (i, i+16) per 32-half with pos[0]/pos[1], 1: 1-D interleaved pairs with pos[0], 2: none)
     const int32_t *rope_pos;

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -565,6 +567,20 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
     if need_dx:
         wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()          # [Cin, 3, 3, Cout]
         dx = conv3x3_nhwc(dy.contiguous(), wd, None, mask_by=x if relu_in else None)   # ReLU backward in the conv epilogue
+    r256 = lambda c: (c + 255) // 256 * 256
+    if Cin % 8 == 0 and Cout % 8 == 0 and r256(Cin) * r256(Cout) <= 2 * Cin * Cout and x.is_contiguous() and dy.is_contiguous():
+        # 256 x 256 tiles at least half full: the reduction-major kernel reads the NHWC tensors as they are (tap shift = pixel-row
+        # shift, zero page outside the image, input ReLU on the fragments) -- no zero-bordered transposed copies
+        P = N * H * W
+        ks, _ = wgrad_ksplit(r256(Cin), r256(Cout), P, 9)
+        dw9 = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
+        ws = torch.empty(ks * 9 * Cin * Cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv3x3_wgrad_tn(L.ptr(x), L.ptr(dy), L.ptr(dw9), N, H, W, Cin, Cout, int(relu_in), ks, _DT[dt], L.ptr(ws),
+                                             ws.numel() * 4, 0, L.stream_ptr(dev))
+        L.check(rc, "vs_conv3x3_wgrad_tn")
+        dw = dw9.view(3, 3, Cin, Cout).permute(3, 0, 1, 2).contiguous()            # [Cout, ky, kx, Cin]
+        return dx, dw, colsum(dy.view(P, Cout))
     # weight gradient: dY^T [Cout, pixels] and X^T [Cin, pixels] over the zero-bordered pixel grid, produced straight from the
     # NHWC tensors by the transposing kernel (border, input ReLU and the bias gradient folded into that one pass)
     Hp, Wp = H + 2, W + 2
