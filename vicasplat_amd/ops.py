@@ -7,8 +7,6 @@ from __future__ import annotations
 
 from typing import Optional
 
-import os
-
 import torch
 
 from . import _lib as L
