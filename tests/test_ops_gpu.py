@@ -797,7 +797,7 @@ def test_attention_backward_matches_autograd(dt, case):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("N,H,W,Cin,Cout,relu_in", [(2, 16, 16, 64, 128, False), (1, 37, 21, 128, 256, True), (3, 64, 64, 256, 256, True),
                                                     (2, 13, 7, 256, 256, False), (1, 5, 100, 256, 512, True), (5, 8, 8, 512, 256, False), (2, 20, 12, 256, 128, True),
-                                                    (1, 9, 33, 192, 256, False)])
+                                                    (1, 9, 33, 192, 256, False), (2, 11, 19, 128, 128, True), (1, 30, 8, 128, 256, False), (3, 6, 6, 64, 256, True)])
 def test_conv3x3_backward_matches_autograd(dt, N, H, W, Cin, Cout, relu_in):
     from vicasplat_amd import ops
     d = _dev()

@@ -608,7 +608,8 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
         VS_CHECK(((uintptr_t)workspace & 15) == 0, "vs_conv3x3_wgrad_tn: workspace must be 16-byte aligned");
         g.partials = (float *)workspace;
     }
-    const long long nwg = (long long)vs::cdiv(Cin, 256) * vs::cdiv(Cout, 256) * 9 * ksplit;
+    const int G = (Cin <= 128 && 256 % Cin == 0) ? 256 / Cin : 1;   // taps that share one 256-row tile (conv3x3_wgrad_tn_kernel)
+    const long long nwg = (long long)(G > 1 ? 1 : vs::cdiv(Cin, 256)) * vs::cdiv(Cout, 256) * vs::cdiv(9, G) * ksplit;
     VS_CHECK(nwg <= 0x7fffffffLL, "vs_conv3x3_wgrad_tn: grid too large");
     const dim3 grid((unsigned)nwg), block(512);
     if (dtype == 2) {

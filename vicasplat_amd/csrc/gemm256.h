@@ -350,13 +350,14 @@ struct ConvWgradStagerTN {
     long long kstA, kstW;
     int rrow[2], klim;
     int py[2][2], px[2][2];                      // [A unit h][round]: (y, x) of the lane's pixel at the unit's NEXT staging call
-    int H, W, q64, r64, dyy, dxx;                // 64 = q64 * W + r64; tap offset (dyy, dxx) in {-1, 0, 1}
+    int dyy[2][2], dxx[2][2];                    // [A unit h][round]: the tap offset in {-1, 0, 1}^2 of the lane's tile row (tap groups)
+    int H, W, q64, r64;                          // 64 = q64 * W + r64
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) {
         const unsigned short *z = vs_zero_row256;
         if (u < 2) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int y = py[u][j] + dyy, x = px[u][j] + dxx;
+                const int y = py[u][j] + dyy[u][j], x = px[u][j] + dxx[u][j];
                 const bool ok = kt * 64 + rrow[j] < klim && pa[u][j] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
                 glds16(ok ? pa[u][j] + kt * kstA : z, lds + 1024u * j);
                 int nx = px[u][j] + r64, ny = py[u][j] + q64;   // advance this unit's pixel by 64
@@ -380,24 +381,28 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_tn_kernel(const GemmArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    // tap groups: with Cin <= 128 (a divisor of 256) the 256 tile rows hold G = 256 / Cin taps side by side -- out[tap][ci][co] is
+    // contiguous over (tap, ci), so rows m = tap_in_group * Cin + ci of the tile ARE rows of out + group * G * Cin * Cout
+    const int Cin = g.M;
+    const int G = (Cin <= 128 && 256 % Cin == 0) ? 256 / Cin : 1;
+    const int ngroups = (9 + G - 1) / G;
     const int tiles_n = (g.N + BN2 - 1) / BN2;
-    const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
-    const int ksp = blockIdx.x / (tiles * 9);              // (k-slice, tap, tile): the taps of a slice share X and dY through L2
-    const int rem = blockIdx.x - ksp * tiles * 9;
-    const int tap = rem / tiles, bid = rem - tap * tiles;
+    const int tiles = (G > 1 ? 1 : (Cin + BM2 - 1) / BM2) * tiles_n;
+    const int ksp = blockIdx.x / (tiles * ngroups);        // (k-slice, tap group, tile): the taps of a slice share X and dY through L2
+    const int rem = blockIdx.x - ksp * tiles * ngroups;
+    const int grp = rem / tiles, bid = rem - grp * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM2, n0 = tn * BN2;
     const int KT = g.K / 64 / g.ksplit;
     const long long k0 = (long long)ksp * KT * 64;
-    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
-    const long long shift = (long long)dyy * g.conv_W + dxx;
+    const int taps_here = min(G, 9 - grp * G);
 
-    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A) + (k0 + shift) * g.lda;
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A) + k0 * g.lda;
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + k0 * g.ldw;
     ConvWgradStagerTN st;
     st.kstA = 64LL * g.lda; st.kstW = 64LL * g.ldw;
     st.klim = (int)max(0LL, min((long long)KT * 64, (long long)g.k_valid - k0));
-    st.H = g.conv_H; st.W = g.conv_W; st.q64 = 64 / g.conv_W; st.r64 = 64 % g.conv_W; st.dyy = dyy; st.dxx = dxx;
+    st.H = g.conv_H; st.W = g.conv_W; st.q64 = 64 / g.conv_W; st.r64 = 64 % g.conv_W;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = (wid * 2 + j) * 4 + (lane >> 4);
@@ -408,9 +413,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_tn_kernel(const GemmArgs
         const int y0 = rem_p / g.conv_W, x0 = rem_p - y0 * g.conv_W;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int ca = m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;
+            const int ca = m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;   // tile row = (tap in group, input channel)
             const int cw = n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;
-            st.pa[h][j] = ca + 8 <= g.lda ? A + (long long)r * g.lda + ca : nullptr;
+            const int tl = G > 1 ? ca / Cin : 0, ci = G > 1 ? ca - tl * Cin : ca;
+            const int tap = grp * G + tl;
+            const int ty = tap / 3 - 1, tx = tap - (tap / 3) * 3 - 1;
+            st.dyy[h][j] = ty; st.dxx[h][j] = tx;
+            const long long shift = (long long)ty * g.conv_W + tx;
+            st.pa[h][j] = (tl < taps_here && ci + 8 <= g.lda) ? A + (shift + r) * g.lda + ci : nullptr;
             st.pw[h][j] = cw + 8 <= g.ldw ? W + (long long)r * g.ldw + cw : nullptr;
             st.py[h][j] = y0; st.px[h][j] = x0;
         }
@@ -419,13 +429,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_tn_kernel(const GemmArgs
     mainloop256<BF16, RELU_A, ConvWgradStagerTN, true>(st, KT, acc, smem, lane, wid);
     g.bias = nullptr;
     g.gate = nullptr;
-    g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
+    g.out = reinterpret_cast<float *>(g.out) + (long long)grp * G * g.tap_out_stride;
     g.ksplit = 2;
     if (g.partials) {
-        g.out = g.partials + ((long long)(ksp * 9 + tap) * g.M) * g.N;
+        g.out = g.partials + ((long long)(ksp * 9 + grp * G) * Cin) * g.N;
         g.ldo = g.N;
         g.ksplit = -1;
     }
+    if (G > 1) { g.M = taps_here * Cin; g.grp_in = g.M; g.grp_out = g.M; }   // rows of the group's taps, contiguous in out
     gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 

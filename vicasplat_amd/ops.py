@@ -566,11 +566,14 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
         wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()          # [Cin, 3, 3, Cout]
         dx = conv3x3_nhwc(dy.contiguous(), wd, None, mask_by=x if relu_in else None)   # ReLU backward in the conv epilogue
     r256 = lambda c: (c + 255) // 256 * 256
-    if Cin % 8 == 0 and Cout % 8 == 0 and r256(Cin) * r256(Cout) <= 2 * Cin * Cout and x.is_contiguous() and dy.is_contiguous():
-        # 256 x 256 tiles at least half full: the reduction-major kernel reads the NHWC tensors as they are (tap shift = pixel-row
+    G = 256 // Cin if (Cin <= 128 and 256 % Cin == 0) else 1              # taps that share one 256-row tile (conv3x3_wgrad_tn_kernel)
+    groups = (9 + G - 1) // G
+    tile_rows = groups * 256 if G > 1 else 9 * r256(Cin)
+    if (Cin % 8 == 0 and Cout % 8 == 0 and 9 * Cin * Cout >= 0.4 * tile_rows * r256(Cout) and x.is_contiguous() and dy.is_contiguous()):
+        # 256 x 256 tiles at least 40 % full: the reduction-major kernel reads the NHWC tensors as they are (tap shift = pixel-row
         # shift, zero page outside the image, input ReLU on the fragments) -- no zero-bordered transposed copies
         P = N * H * W
-        ks, _ = wgrad_ksplit(r256(Cin), r256(Cout), P, 9)
+        ks, _ = wgrad_ksplit(256 if G > 1 else r256(Cin), r256(Cout), P, groups if G > 1 else 9)
         dw9 = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
         ws = torch.empty(ks * 9 * Cin * Cout, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
