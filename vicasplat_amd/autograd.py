@@ -191,7 +191,7 @@ class Conv3x3Fn(torch.autograd.Function):
             full = torch.zeros(x.shape[:3] + (dy.shape[3],), dtype=dy.dtype, device=dy.device)
             full[:, ::stride, ::stride] = dy
             dy = full
-        dx, dw, db = ops.conv3x3_backward(dy, x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0])
+        dx, dw, db = ops.conv3x3_backward(dy, x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0], need_db=has_b)
         return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None, None, dres, None
 
 

@@ -551,7 +551,8 @@ def gemm_splitk_accumulate(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, 
     return out
 
 
-def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu_in: bool = False, need_dx: bool = True):
+def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu_in: bool = False, need_dx: bool = True,
+                     need_db: bool = True):
     """Backward of conv3x3_nhwc(x, w, bias, relu_in=relu_in) (stride 1, pad 1) for the gradient dy of its pre-activation output.
     dy [N,H,W,Cout], x [N,H,W,Cin] (the conv input, before the fused input ReLU), w [Cout,3,3,Cin], all 16-bit NHWC.
     Returns dx [N,H,W,Cin] 16-bit, dw [Cout,3,3,Cin] f32, db [Cout] f32.
@@ -581,7 +582,7 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
                                              ws.numel() * 4, 0, L.stream_ptr(dev))
         L.check(rc, "vs_conv3x3_wgrad_tn")
         dw = dw9.view(3, 3, Cin, Cout).permute(3, 0, 1, 2).contiguous()            # [Cout, ky, kx, Cin]
-        return dx, dw, colsum(dy.view(P, Cout))
+        return dx, dw, (colsum(dy.view(P, Cout)) if need_db else None)
     # weight gradient: dY^T [Cout, pixels] and X^T [Cin, pixels] over the zero-bordered pixel grid, produced straight from the
     # NHWC tensors by the transposing kernel (border, input ReLU and the bias gradient folded into that one pass)
     Hp, Wp = H + 2, W + 2
