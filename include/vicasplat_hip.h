@@ -282,6 +282,10 @@ int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_t M, int32_
 int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                         int32_t relu_in, int32_t ksplit, int32_t dtype, void *workspace, int64_t workspace_bytes, int32_t accumulate,
                         vs_stream_t stream);
+/* Epilogue 2 of vs_gemm_bias_act with the residual read from a second buffer: out32 = resid + (1 + gate) * (A W^T + bias); resid and out
+ * share the layout (ldo).  For callers that must keep the old residual stream (training) without cloning it. */
+int vs_gemm_resid(const void *A, const void *W, const float *bias, const float *resid, float *out, const float *gate, int32_t M, int32_t N,
+                  int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t dtype, int32_t gate_rows, int32_t gate_ld, vs_stream_t stream);
 int vs_transpose16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, vs_stream_t stream);
 /* vs_transpose16 with extras: colsum (nullable, f32 [C], overwritten) = column sums of the input, i.e. the bias gradient rides on
  * the transpose of dY that the weight-gradient GEMM needs anyway (dtype 1 f16 / 2 bf16); border_h, border_w > 0: the R input rows

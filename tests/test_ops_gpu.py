@@ -531,6 +531,27 @@ def test_gemm_wgrad_tn_matches_matmul(dt, Kred, M, N, ks):
     assert float((out3.double() - want).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("M,N,K", [(49344 // 8, 1024, 1024), (6168 + 192, 1024, 4096), (200, 768, 768), (64, 1024, 1024), (1000, 768, 3072)])
+def test_gemm_resid_matches_inplace_update(M, N, K):
+    """vs_gemm_resid (residual read from a second buffer) == clone + vs_gemm_bias_act epilogue 2, bit for bit on the main tiles and to
+    f32 rounding on split-K tails (the in-place form splits K there), incl. the small-M and tail launches, with and without a gate."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) / math.sqrt(K)).half().to(d)
+    w = torch.randn(N, K, generator=g).half().to(d)
+    b = torch.randn(N, generator=g).to(d)
+    x = torch.randn(M, N, generator=g).to(d)
+    for gate_rows in (0, 257):
+        gate = None if gate_rows == 0 else (torch.randn((M + 256) // 257, N, generator=g) * 0.3).to(d)
+        ref = x.clone()
+        ops.gemm(a, w, b, ref, ops.EPI_RESID32, gate=gate, gate_rows=gate_rows)
+        x0 = x.clone()
+        out = ops.gemm_resid(a, w, b, x, gate=gate, gate_rows=gate_rows)
+        assert torch.equal(x, x0)                                  # the source stream is untouched
+        assert (out - ref).abs().max() <= 2e-6 * ref.abs().max() + 2e-6
+
+
 def test_gemm_wgrad_taps_and_errors():
     """Tap-fused form: out[t] += A (W shifted by shifts[t])^T, incl. odd (2-byte aligned) shifts, with and without workspace."""
     from vicasplat_amd import ops, _lib as L

@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
             L.vs_conv3x3_wgrad_tn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]
             L.vs_gemm_wgrad_tn.restype = C.c_int
             L.vs_gemm_wgrad_tn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]
+            L.vs_gemm_resid.restype = C.c_int
+            L.vs_gemm_resid.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_transpose16.restype = C.c_int
             L.vs_transpose16.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
             L.vs_transpose16_ex.restype = C.c_int

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
         } else if constexpr (EPI == 2) {
             float *o = reinterpret_cast<float *>(g.out) + orow * g.ldo + n;
             const float gt = g.gate ? g.gate[(size_t)(m / g.gate_rows) * g.gate_ld + n] : 0.0f;
-            *o = *o + (1.0f + gt) * v;
+            *o = (g.resid ? g.resid[orow * g.ldo + n] : *o) + (1.0f + gt) * v;
         } else {
             reinterpret_cast<float *>(g.out)[orow * g.ldo + n] = v;
         }
@@ -301,7 +301,7 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     // a tail is a handful of tiles walking all of K serially: for the f32 residual epilogue split K over up to 8 workgroups
     // per tile (>= 8 k-steps each) and let the partial sums meet through f32 atomics
     static const int no_ksplit = [] { const char *e = getenv("VS_GEMM_NO_KSPLIT"); return e ? atoi(e) : 0; }();
-    if (epi == 2 && rem > 64 && !no_ksplit) {
+    if (epi == 2 && rem > 64 && !no_ksplit && !g.resid) {   // (split-K partial sums meet in out: it must already hold the residual)
         const int tiles = vs::cdiv(rem, 128) * vs::cdiv(g.N, BN);
         int ks = 1;
         while (ks < 8 && (g.K / 32) % (ks * 2) == 0 && g.K / 32 / (ks * 2) >= 8 && tiles * ks * 2 <= 512) ks *= 2;
@@ -430,7 +430,7 @@ int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, int acc
 }  // namespace
 
 namespace {
-int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, void *out, const float *gate, int32_t M, int32_t N,
+int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, void *out, const float *gate, const float *resid, int32_t M, int32_t N,
                int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype, int32_t grp_in, int32_t grp_out,
                int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
                const int32_t *rope_pos, const uint8_t *rope_kind, int32_t rope_C, float base2d, float theta1d, hipStream_t stream) {
@@ -443,7 +443,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
              "%s: A and W must be 16-byte aligned", fn);
     if (M == 0) return 0;
     GemmArgs g;
-    g.A = A; g.W = W; g.bias = bias; g.out = out; g.gate = gate;
+    g.A = A; g.W = W; g.bias = bias; g.out = out; g.gate = gate; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
     g.grp_in = grp_in > 0 ? grp_in : (M > 0 ? M : 1);
     g.grp_out = grp_out > 0 ? grp_out : g.grp_in;
@@ -470,8 +470,19 @@ extern "C" int vs_gemm_bias_act(const void *A, const void *W, const float *bias,
                                 int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld,
                                 int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off, vs_stream_t stream_) {
     VS_CHECK(epilogue >= 0 && epilogue <= 3, "vs_gemm_bias_act: unknown epilogue %d", epilogue);
-    return gemm_entry("vs_gemm_bias_act", A, W, bias, out, gate, M, N, K, lda, ldw, ldo, epilogue, dtype, grp_in, grp_out, grp_off,
+    return gemm_entry("vs_gemm_bias_act", A, W, bias, out, gate, nullptr, M, N, K, lda, ldw, ldo, epilogue, dtype, grp_in, grp_out, grp_off,
                       gate_rows, gate_ld, a_grp_in, a_grp_out, a_grp_off, nullptr, nullptr, 0, 0.f, 0.f, (hipStream_t)stream_);
+}
+
+// out32[row(m), n] = resid[row(m), n] + (1 + gate[m / gate_rows, n]) * (A W^T + bias): epilogue 2 of vs_gemm_bias_act with the residual
+// stream read from a second buffer (same layout as out), so a caller that must keep the old stream (training: the LayerNorm input
+// is needed by the backward) does not clone it first.
+extern "C" int vs_gemm_resid(const void *A, const void *W, const float *bias, const float *resid, float *out, const float *gate, int32_t M,
+                             int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t dtype, int32_t gate_rows, int32_t gate_ld,
+                             vs_stream_t stream_) {
+    VS_CHECK(resid, "vs_gemm_resid: null resid");
+    return gemm_entry("vs_gemm_resid", A, W, bias, out, gate, resid, M, N, K, lda, ldw, ldo, 2, dtype, 0, 0, 0, gate_rows, gate_ld, 0, 0, 0,
+                      nullptr, nullptr, 0, 0.f, 0.f, (hipStream_t)stream_);
 }
 
 // Packed q|k|v projection with the rotary embedding of q and k applied in the epilogue (head_dim 64): replaces
@@ -483,7 +494,7 @@ extern "C" int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias,
     VS_CHECK(pos, "vs_gemm_qkv_rope: null pos");
     VS_CHECK(C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0, "vs_gemm_qkv_rope: need C %% 64 == 0, N %% 64 == 0, N >= 2C (C=%d N=%d)", C, N);
     VS_CHECK(base2d > 0.f && theta1d > 0.f, "vs_gemm_qkv_rope: base2d and theta1d must be positive");
-    return gemm_entry("vs_gemm_qkv_rope", A, W, bias, out, nullptr, M, N, K, lda, ldw, ldo, 4, dtype, grp_in, grp_out, grp_off, 0, 0,
+    return gemm_entry("vs_gemm_qkv_rope", A, W, bias, out, nullptr, nullptr, M, N, K, lda, ldw, ldo, 4, dtype, grp_in, grp_out, grp_off, 0, 0,
                       a_grp_in, a_grp_out, a_grp_off, pos, kind, C, base2d, theta1d, (hipStream_t)stream_);
 }
 
@@ -507,7 +518,7 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_wgrad: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
     VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_wgrad: dtype must be 1 (f16) or 2 (bf16)");
     GemmArgs g;
-    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr; g.resid = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
@@ -544,7 +555,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     const long long Kpad = ((long long)Kred + unit - 1) / unit * unit;
     VS_CHECK(Kpad < 2147483647LL, "vs_gemm_wgrad_tn: reduction too long");
     GemmArgs g;
-    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr; g.resid = nullptr;
     g.M = M; g.N = N; g.K = (int)Kpad; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
@@ -594,7 +605,7 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
     const long long Kpad = (P + unit - 1) / unit * unit;
     VS_CHECK(Kpad < 2147483647LL, "vs_conv3x3_wgrad_tn: too many pixels");
     GemmArgs g;
-    g.A = x; g.W = dy; g.bias = nullptr; g.out = out; g.gate = nullptr;
+    g.A = x; g.W = dy; g.bias = nullptr; g.out = out; g.gate = nullptr; g.resid = nullptr;
     g.M = Cin; g.N = Cout; g.K = (int)Kpad; g.lda = Cin; g.ldw = Cout; g.ldo = Cout;
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
@@ -659,7 +670,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     VS_CHECK((reinterpret_cast<uintptr_t>(w) & 15) == 0, "vs_conv7x7_rgb_nhwc: w must be 16-byte aligned");
     if (Nimg == 0) return 0;
     GemmArgs g;
-    g.A = in_padded; g.W = w; g.bias = bias; g.out = out; g.gate = nullptr;
+    g.A = in_padded; g.W = w; g.bias = bias; g.out = out; g.gate = nullptr; g.resid = nullptr;
     g.M = Nimg * H * W; g.N = Cout; g.K = 7 * 32;
     g.lda = 3; g.ldw = 7 * 32; g.ldo = Cout;
     g.grp_in = g.M; g.grp_out = g.M; g.grp_off = 0;

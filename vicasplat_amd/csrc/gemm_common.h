@@ -16,6 +16,7 @@ struct GemmArgs {
     const float *bias;
     void *out;
     const float *gate;
+    const float *resid;  // epilogue 2: source of the residual stream (same row layout as out); null = out itself (in-place update)
     int M, N, K;
     int lda, ldw, ldo;
     int grp_in, grp_out, grp_off;
@@ -229,7 +230,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                             unsafeAtomicAdd(dst + j * 16 + 0, val.x); unsafeAtomicAdd(dst + j * 16 + 1, val.y);
                             unsafeAtomicAdd(dst + j * 16 + 2, val.z); unsafeAtomicAdd(dst + j * 16 + 3, val.w);
                         } else {
-                            float4 o = *reinterpret_cast<float4 *>(dst + j * 16);
+                            const float *src = g.resid ? g.resid + (dst - reinterpret_cast<float *>(g.out)) : dst;
+                            float4 o = *reinterpret_cast<const float4 *>(src + j * 16);
                             o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
                             *reinterpret_cast<float4 *>(dst + j * 16) = o;
                         }
@@ -246,7 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                             if constexpr (EPI == 2) {
                                 if (g.ksplit < 0) dst[j * 16 + r] = x;
                                 else if (g.ksplit > 1) unsafeAtomicAdd(dst + j * 16 + r, x);
-                                else dst[j * 16 + r] += x;
+                                else dst[j * 16 + r] = (g.resid ? g.resid[(dst - reinterpret_cast<float *>(g.out)) + j * 16 + r] : dst[j * 16 + r]) + x;
                             } else {
                                 dst[j * 16 + r] = x;
                             }

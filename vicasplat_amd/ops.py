@@ -60,6 +60,22 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def gemm_resid(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor, *, gate: Optional[torch.Tensor] = None,
+               gate_rows: int = 0) -> torch.Tensor:
+    """resid [M,N] f32 + (1 + gate) * (a @ w^T + bias) into a NEW tensor (vs_gemm_resid): the residual update of gemm(..., EPI_RESID32)
+    without touching (or cloning) the old stream."""
+    dev = L.require_device(a, w, bias, resid, gate)
+    assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16) and a.stride(1) == 1 and w.stride(1) == 1
+    assert resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == (a.shape[0], w.shape[0])
+    out = torch.empty_like(resid)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_resid(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(out), L.ptr(gate), a.shape[0], w.shape[0], a.shape[1],
+                                   a.stride(0), w.stride(0), out.stride(0), _DT[a.dtype], gate_rows, gate.stride(0) if gate is not None else 0,
+                                   L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_resid")
+    return out
+
+
 def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, C: int, pos: torch.Tensor,
                   kind: Optional[torch.Tensor] = None, base2d: float = 100.0, theta1d: float = 30.0, *, grp_in: int = 0,
                   grp_out: int = 0, grp_off: int = 0, M: Optional[int] = None, a_grp_in: int = 0, a_grp_out: int = 0,

@@ -42,15 +42,13 @@ def enc_block_forward_train(x: torch.Tensor, p: EncBlockParams, pos: torch.Tenso
     lse = torch.empty(M, heads, dtype=torch.float32, device=dev)
     ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], att, nbatch=frames, H=heads, Lq=tokens, Lk=tokens,
                   q_batch_rows=tokens, k_batch_rows=tokens, lse=lse)
-    x_mid = x.clone()
-    ops.gemm(att, p.proj_w, p.proj_b, x_mid, ops.EPI_RESID32)
+    x_mid = ops.gemm_resid(att, p.proj_w, p.proj_b, x)      # x + proj(att) into a new buffer: x stays for the LayerNorm backward
     h2 = torch.empty(M, C, dtype=dt, device=dev)
     ops.layernorm_mod(x_mid, p.ln2_w, p.ln2_b, h2, eps=eps)
     z = torch.empty(M, p.fc1_w.shape[0], dtype=dt, device=dev)
     ops.gemm(h2, p.fc1_w, p.fc1_b, z, ops.EPI_STORE16)       # pre-activation kept for the GELU backward
     a = ops.gelu16(z)
-    x_out = x_mid.clone()
-    ops.gemm(a, p.fc2_w, p.fc2_b, x_out, ops.EPI_RESID32)
+    x_out = ops.gemm_resid(a, p.fc2_w, p.fc2_b, x_mid)
     tape = dict(x=x, h1=h1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, h2=h2, z=z, a=a, pos=pos, frames=frames, tokens=tokens,
                 heads=heads, rope_base=rope_base, eps=eps)
     return x_out, tape
