@@ -201,7 +201,15 @@ def configure_optimizer(encoder, lr: float = 4e-5, backbone_lr_multiplier: float
         if p.requires_grad:
             (new if any(k in name for k in new_param_keywords) else old).append(p)
     groups = [dict(params=new, lr=lr), dict(params=old, lr=lr * backbone_lr_multiplier)] if new else [dict(params=old, lr=lr)]
-    opt = torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.95))
+    kw = dict(lr=lr, weight_decay=weight_decay, betas=(0.9, 0.95))
+    opt = None
+    if old and old[0].is_cuda:
+        try:   # one multi-tensor kernel per step instead of ~10 foreach passes over the 578 M parameters
+            opt = torch.optim.AdamW(groups, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            opt = None
+    if opt is None:
+        opt = torch.optim.AdamW(groups, **kw)
     sched = torch.optim.lr_scheduler.LinearLR(opt, 1 / warm_up_steps, 1, total_iters=warm_up_steps) if warm_up_steps > 0 else None
     return opt, sched
 
@@ -232,8 +240,10 @@ def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, c
         from . import dist as vdist
         vdist.bucketed_allreduce_grads(params)
     grads = [p.grad for p in params]
-    torch._foreach_mul_(grads, 1.0 / loss_scale)              # unscale (one fused launch per dtype group, no per-parameter sync)
-    gnorm = torch.nn.utils.clip_grad_norm_(params, clip)      # a non-finite norm marks an overflowed step ...
+    # unscale and clip in ONE pass over the gradients: norm of the scaled gradients, then a single multiply by
+    # min(1, clip / (norm + 1e-6)) / loss_scale (= torch's clip_grad_norm_ on the unscaled gradients)
+    gnorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads))) / loss_scale
+    torch._foreach_mul_(grads, torch.clamp(clip / (gnorm + 1e-6), max=1.0) / loss_scale)   # a non-finite norm marks an overflowed step ...
     finite = bool(torch.isfinite(gnorm))
     if finite:                                                # ... which is skipped, as torch.amp's GradScaler would
         optimizer.step()
