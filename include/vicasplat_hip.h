@@ -311,6 +311,14 @@ int vs_gated_resid(const float *x, const void *y, int64_t ldy, const float *gate
 int vs_gated_resid_backward(const float *dout, const void *y, int64_t ldy, const float *gate, int32_t gate_rows, void *dy, int64_t lddy,
                             float *dgate, int32_t M, int32_t C, int32_t grp_in, int32_t grp_out, int32_t grp_off, int32_t dtype,
                             vs_stream_t stream);
+/* vs_layernorm_backward with the residual-path gradient read from its own buffer (dx = dx_add + LayerNorm gradient; dx_add null, another
+ * buffer, or dx itself) and an optional 16-bit copy of dx (dx16 with row stride ld16, dx16_dtype 1 f16 / 2 bf16) for the GEMMs that
+ * consume the gradient next: no clone of the incoming gradient and no separate cast pass. */
+int vs_layernorm_backward_ex(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,
+                             const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx, const float *dx_add,
+                             int64_t ld_add, void *dx16, int64_t ld16, int32_t dx16_dtype, float *dw, float *db, float *dscale,
+                             float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off,
+                             vs_stream_t stream);
 int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,
                           const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx, int32_t accumulate_dx,
                           float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in,

@@ -133,6 +133,9 @@ def lib() -> C.CDLL:
             L.vs_layernorm_backward.restype = C.c_int
             L.vs_layernorm_backward.argtypes = [vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, i64, i32, vp, vp, vp, vp, i32, i32, f32,
                                                 i32, i32, i32, vp]
+            L.vs_layernorm_backward_ex.restype = C.c_int
+            L.vs_layernorm_backward_ex.argtypes = [vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, vp,
+                                                   i32, i32, f32, i32, i32, i32, vp]
             L.vs_gemm_qkv_rope.restype = C.c_int
             L.vs_gemm_qkv_rope.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32,
                                            C.c_float, C.c_float, vp]

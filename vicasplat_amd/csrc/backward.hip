@@ -257,7 +257,8 @@ template <int DT, int NV, bool MOD>  // dout dtype: 0 f32, 1 f16, 2 bf16; NV * 2
 __global__ void __launch_bounds__(256)
 layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const float *__restrict__ x, long long ldx,
                           const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ scale, int mod_rows,
-                          int mod_ld, float *__restrict__ dx, long long ld_dx, int accumulate_dx, float *__restrict__ dw,
+                          int mod_ld, float *dx, long long ld_dx, const float *dx_add, long long ld_add,   // (dx_add may alias dx)
+                          unsigned short *__restrict__ dx16, long long ld_dx16, int dx16_bf16, float *__restrict__ dw,
                           float *__restrict__ db, float *__restrict__ dscale, float *__restrict__ dshift, int M, int C, float eps,
                           int grp_in, int grp_out, int grp_off, int rows_per_chunk) {
     __shared__ float red[4][NV * 256];
@@ -352,11 +353,22 @@ layernorm_backward_kernel(const void *__restrict__ dout, long long ld_do, const 
                 r.y = rstd * (gv[k].y - mg - xv[k].y * rstd * mgx);
                 r.z = rstd * (gv[k].z - mg - xv[k].z * rstd * mgx);
                 r.w = rstd * (gv[k].w - mg - xv[k].w * rstd * mgx);
-                if (accumulate_dx) {
-                    const float4 o = *reinterpret_cast<const float4 *>(dxr + c);
+                if (dx_add) {   // gradient arriving through the residual connection (dx_add may be dx itself: in-place accumulate)
+                    const float4 o = *reinterpret_cast<const float4 *>(dx_add + (long long)m * ld_add + c);
                     r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
                 }
                 *reinterpret_cast<float4 *>(dxr + c) = r;
+                if (dx16) {     // 16-bit copy for the GEMMs that consume this gradient next (no separate cast pass)
+                    uint2 pk;
+                    if (dx16_bf16) {
+                        pk.x = (unsigned)st16<true>(r.x) | ((unsigned)st16<true>(r.y) << 16);
+                        pk.y = (unsigned)st16<true>(r.z) | ((unsigned)st16<true>(r.w) << 16);
+                    } else {
+                        pk.x = (unsigned)st16<false>(r.x) | ((unsigned)st16<false>(r.y) << 16);
+                        pk.y = (unsigned)st16<false>(r.z) | ((unsigned)st16<false>(r.w) << 16);
+                    }
+                    *reinterpret_cast<uint2 *>(dx16 + (long long)m * ld_dx16 + c) = pk;
+                }
             }
         }
     }
@@ -544,10 +556,16 @@ extern "C" int vs_gelu16(const void *z, void *out, int64_t n, int32_t dtype, vs_
     return 0;
 }
 
-extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w,
-                                     const float *b, const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx,
-                                     int32_t accumulate_dx, float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C,
-                                     float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream_) {
+namespace {
+int layernorm_backward_entry(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w, const float *b,
+                             const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx, const float *dx_add,
+                             int64_t ld_add, void *dx16v, int64_t ld16, int32_t dx16_dtype, float *dw, float *db, float *dscale,
+                             float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off,
+                             vs_stream_t stream_) {
+    unsigned short *dx16 = (unsigned short *)dx16v;
+    const int dx16_bf16 = dx16_dtype == 2;
+    VS_CHECK(!dx16 || ((dx16_dtype == 1 || dx16_dtype == 2) && ld16 % 4 == 0 && ((uintptr_t)dx16 & 7) == 0), "vs_layernorm_backward: bad 16-bit gradient output");
+    VS_CHECK(!dx_add || ld_add % 4 == 0, "vs_layernorm_backward: ld_add must be a multiple of 4");
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(dout && x && w && b && dx && dw && db, "vs_layernorm_backward: null pointer");
     VS_CHECK(C > 0 && C % 4 == 0 && C <= 64 * 4 * kLnVec, "vs_layernorm_backward: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * kLnVec);
@@ -568,7 +586,7 @@ extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do
     VS_CHECK(G <= 65535, "vs_layernorm_backward: too many modulation groups (%d)", G);
     dim3 grid(vs::cdiv(group_rows, rows_per_chunk), G), block(256);
 #define VS_LNB3(DT_, NV_, MOD_) hipLaunchKernelGGL((layernorm_backward_kernel<DT_, NV_, MOD_>), grid, block, 0, stream, dout, (long long)ld_do, x, \
-                                      (long long)ldx, w, b, scale, mod_rows, mod_ld, dx, (long long)ld_dx, accumulate_dx, dw, db, dscale, dshift, M, C, eps, \
+                                      (long long)ldx, w, b, scale, mod_rows, mod_ld, dx, (long long)ld_dx, dx_add, (long long)ld_add, dx16, (long long)ld16, dx16_bf16, dw, db, dscale, dshift, M, C, eps, \
                                       grp_in, grp_out, grp_off, rows_per_chunk)
 #define VS_LNB2(DT_, NV_) { if (scale) VS_LNB3(DT_, NV_, true); else VS_LNB3(DT_, NV_, false); }
 #define VS_LNB(DT_) { if (C <= 256) VS_LNB2(DT_, 1) else if (C <= 512) VS_LNB2(DT_, 2) else if (C <= 768) VS_LNB2(DT_, 3) \
@@ -579,6 +597,26 @@ extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do
 #undef VS_LNB
     VS_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w,
+                                     const float *b, const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx,
+                                     int32_t accumulate_dx, float *dw, float *db, float *dscale, float *dshift, int32_t M, int32_t C,
+                                     float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream_) {
+    return layernorm_backward_entry(dout, ld_do, do_dtype, x, ldx, w, b, scale, mod_rows, mod_ld, dx, ld_dx, accumulate_dx ? dx : nullptr, ld_dx,
+                                    nullptr, 0, 0, dw, db, dscale, dshift, M, C, eps, grp_in, grp_out, grp_off, stream_);
+}
+
+// vs_layernorm_backward with the residual-path gradient read from its own buffer (dx = dx_add + LayerNorm gradient; dx_add may be
+// null or dx itself) and an optional 16-bit copy of dx (dx16, dtype 1 f16 / 2 bf16) for the GEMMs that consume it next.
+extern "C" int vs_layernorm_backward_ex(const void *dout, int64_t ld_do, int32_t do_dtype, const float *x, int64_t ldx, const float *w,
+                                        const float *b, const float *scale, int32_t mod_rows, int32_t mod_ld, float *dx, int64_t ld_dx,
+                                        const float *dx_add, int64_t ld_add, void *dx16, int64_t ld16, int32_t dx16_dtype, float *dw,
+                                        float *db, float *dscale, float *dshift, int32_t M, int32_t C, float eps, int32_t grp_in,
+                                        int32_t grp_out, int32_t grp_off, vs_stream_t stream_) {
+    return layernorm_backward_entry(dout, ld_do, do_dtype, x, ldx, w, b, scale, mod_rows, mod_ld, dx, ld_dx, dx_add, ld_add, dx16, ld16,
+                                    dx16_dtype, dw, db, dscale, dshift, M, C, eps, grp_in, grp_out, grp_off, stream_);
 }
 
 extern "C" int vs_gated_resid(const float *x, const void *y, int64_t ldy, const float *gate, int32_t gate_rows, float *out, int32_t M,

@@ -417,15 +417,22 @@ def gelu_backward(dy: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
 
 def layernorm_backward(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, *, scale: Optional[torch.Tensor] = None,
                        mod_rows: int = 0, eps: float = 1e-6, dx: Optional[torch.Tensor] = None, accumulate_dx: bool = False,
-                       grp_in: int = 0, grp_out: int = 0, grp_off: int = 0):
+                       grp_in: int = 0, grp_out: int = 0, grp_off: int = 0, dx_add: Optional[torch.Tensor] = None,
+                       dx16: Optional[torch.Tensor] = None):
     """Backward of layernorm_mod.  x f32 [M,C]; dout [rows,C] in the forward's output layout (f32 or 16-bit).
-    Returns (dx f32 [M,C], dw [C], db [C], dscale [G,C] | None, dshift [G,C] | None)."""
-    dev = L.require_device(dout, x, w, b, scale, dx)
+    Returns (dx f32 [M,C], dw [C], db [C], dscale [G,C] | None, dshift [G,C] | None).  dx_add [M,C] f32: gradient arriving through the
+    residual connection, added into dx (accumulate_dx=True is dx_add = dx); dx16 [M,C] 16-bit: receives a copy of dx for the next GEMMs."""
+    dev = L.require_device(dout, x, w, b, scale, dx, dx_add, dx16)
     M, Cc = x.shape
     assert x.dtype == torch.float32 and x.stride(1) == 1 and dout.stride(-1) == 1
     if dx is None:
         assert not accumulate_dx
         dx = torch.empty((M, Cc), dtype=torch.float32, device=dev)
+    if accumulate_dx:
+        assert dx_add is None
+        dx_add = dx
+    assert dx_add is None or (dx_add.dtype == torch.float32 and dx_add.stride(1) == 1 and dx_add.shape == (M, Cc))
+    assert dx16 is None or (dx16.dtype in (torch.float16, torch.bfloat16) and dx16.stride(1) == 1 and dx16.shape == (M, Cc))
     dw = torch.zeros(Cc, dtype=torch.float32, device=dev)
     db = torch.zeros(Cc, dtype=torch.float32, device=dev)
     dscale = dshift = None
@@ -441,10 +448,12 @@ def layernorm_backward(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, b: 
         if scale is not None and mod_ld != Cc:
             dscale = torch.zeros((scale.shape[0], mod_ld), dtype=torch.float32, device=dev)
             dshift = torch.zeros_like(dscale)
-        rc = L.lib().vs_layernorm_backward(L.ptr(dout), dout.stride(-2), _DT3[dout.dtype], L.ptr(x), x.stride(0), L.ptr(w), L.ptr(b),
-                                           L.ptr(scale), mod_rows, mod_ld, L.ptr(dx), dx.stride(0), int(accumulate_dx), L.ptr(dw),
-                                           L.ptr(db), L.ptr(dscale), L.ptr(dshift), M, Cc, eps, grp_in, grp_out, grp_off,
-                                           L.stream_ptr(dev))
+        rc = L.lib().vs_layernorm_backward_ex(L.ptr(dout), dout.stride(-2), _DT3[dout.dtype], L.ptr(x), x.stride(0), L.ptr(w), L.ptr(b),
+                                              L.ptr(scale), mod_rows, mod_ld, L.ptr(dx), dx.stride(0), L.ptr(dx_add),
+                                              dx_add.stride(0) if dx_add is not None else 0, L.ptr(dx16),
+                                              dx16.stride(0) if dx16 is not None else 0, _DT[dx16.dtype] if dx16 is not None else 0,
+                                              L.ptr(dw), L.ptr(db), L.ptr(dscale), L.ptr(dshift), M, Cc, eps, grp_in, grp_out, grp_off,
+                                              L.stream_ptr(dev))
     L.check(rc, "vs_layernorm_backward")
     if dscale is not None and dscale.shape[1] != Cc:
         dscale, dshift = dscale[:, :Cc], dshift[:, :Cc]

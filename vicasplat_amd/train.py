@@ -60,15 +60,19 @@ def enc_block_backward(dx_out: torch.Tensor, tape: dict, p: EncBlockParams):
     C = dx_out.shape[1]
     dt = p.qkv_w.dtype
     g = {}
-    dx_mid = dx_out.clone()                                   # residual branch; ONE f32 buffer collects dx_out + both LayerNorm backwards
     # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
     da, g["fc2_w"], g["fc2_b"] = ops.linear_backward(dx_out.to(dt), t["a"], p.fc2_w)
     dz = ops.gelu_backward(da, t["z"])
     dh2, g["fc1_w"], g["fc1_b"] = ops.linear_backward(dz, t["h2"], p.fc1_w)
-    _, g["ln2_w"], g["ln2_b"], _, _ = ops.layernorm_backward(dh2, t["x_mid"], p.ln2_w, p.ln2_b, eps=t["eps"], dx=dx_mid, accumulate_dx=True)
+    # dx_mid = dx_out (residual path, read from its own buffer: no clone) + LayerNorm-2 gradient; that ONE f32 buffer then collects
+    # the LayerNorm-1 gradient too, and the kernel also emits the 16-bit copy that the projection's backward GEMMs read (no cast pass)
+    dx_mid = torch.empty_like(dx_out)
+    dx_mid16 = torch.empty(dx_out.shape, dtype=dt, device=dx_out.device)
+    _, g["ln2_w"], g["ln2_b"], _, _ = ops.layernorm_backward(dh2, t["x_mid"], p.ln2_w, p.ln2_b, eps=t["eps"], dx=dx_mid, dx_add=dx_out,
+                                                             dx16=dx_mid16)
     # ---- attention: x_mid = x + proj(attn(rope(qkv(LN1(x))))) ----
     dx_in = dx_mid
-    datt, g["proj_w"], g["proj_b"] = ops.linear_backward(dx_mid.to(dt), t["att"], p.proj_w)
+    datt, g["proj_w"], g["proj_b"] = ops.linear_backward(dx_mid16, t["att"], p.proj_w)
     qkv = t["qkv"]
     dqkv = torch.empty_like(qkv)                              # dq lands in its block directly; dk / dv (f32) are cast into theirs
     _, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], t["att"], datt, t["lse"], nbatch=t["frames"],
