@@ -20,7 +20,19 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 64, TB = 64;
 constexpr int ROW = HD + 8;   // halfs per row-major tile row (144 B)
-constexpr int TROW = TB + 8;  // halfs per transposed tile row
+constexpr int TROW = TB + 8;  // halfs per transposed tile row (stage_tile's optional transposed image; unused by the kernels now)
+
+// 4 consecutive tile ROWS of one column through the LDS transpose read (ds_read_b64_tr_b16, tools/probe/tr_read.hip): lane t of a
+// 16-lane group supplies &tile[row0 + (t >> 2)][col0 + (t & 3) * 4] and receives tile[row0 .. row0 + 3][col0 + t].  With it the
+// "k along rows" MFMA operands (dO^T, Q^T, K^T) are gathered from the ROW-MAJOR tiles: no transposed LDS images, no packing pass.
+// (ROW = 72 halfs = 144 B: the four rows of a read fall into four different 8-bank windows.)
+typedef short tr4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 tr_rows4(const unsigned short *tile, int row0, int col0, int t) {
+    typedef tr4_t __attribute__((address_space(3))) *trp_t;
+    const unsigned short *p = tile + (row0 + (t >> 2)) * ROW + col0 + (t & 3) * 4;
+    const tr4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned short *>(p)));
+    return __builtin_bit_cast(uint2, v);
+}
 
 struct AttnBwdArgs {
     const unsigned short *q, *k, *v, *o, *dout;
@@ -127,7 +139,7 @@ __device__ __forceinline__ void stage_tile(const unsigned short *src, int ld, in
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(const AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sK[TB * ROW], sV[TB * ROW], sKT[HD * TROW];
+    __shared__ __attribute__((aligned(16))) unsigned short sK[TB * ROW], sV[TB * ROW];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -152,7 +164,7 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
     for (int kt = 0; kt < kl.Lk; kt += TB) {
         __syncthreads();
         auto rk = [&](int r) { return krow(kt + r); };
-        stage_tile<true, true>(a.k, a.ldk, h * HD, rk, kl.Lk - kt, sK, sKT, tid);
+        stage_tile<true, false>(a.k, a.ldk, h * HD, rk, kl.Lk - kt, sK, nullptr, tid);
         stage_tile<true, false>(a.v, a.ldv, h * HD, rk, kl.Lk - kt, sV, nullptr, tid);
         __syncthreads();
         const bool tile_full = __builtin_amdgcn_ballot_w64(my_len < kt + TB) == 0ull;
@@ -192,9 +204,8 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const unsigned short *kr = &sKT[(db * 16 + c16) * TROW + g * 4];
-                const uint2 lo = *reinterpret_cast<const uint2 *>(kr + (2 * ks) * 16);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(kr + (2 * ks + 1) * 16);
+                const uint2 lo = tr_rows4(sK, (2 * ks) * 16 + g * 4, db * 16, c16);        // K[keys g*4..+3 of block 2ks][d = db*16 + c16]
+                const uint2 hi = tr_rows4(sK, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 dq[db] = mfma<BF16>(dsf[ks], make_uint4(lo.x, lo.y, hi.x, hi.y), dq[db]);
             }
     }
@@ -214,7 +225,7 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(const AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * ROW], sDO[TB * ROW], sQT[HD * TROW], sDOT[HD * TROW];
+    __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * ROW], sDO[TB * ROW];
     __shared__ __attribute__((aligned(16))) float sL[TB], sD[TB];
     __shared__ __attribute__((aligned(16))) int sLen[TB];
     __shared__ int s_minlen;
@@ -237,8 +248,8 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     for (int qt = 0; qt < a.Lq; qt += TB) {
         __syncthreads();
         auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
-        stage_tile<true, true>(a.q, a.ldq, h * HD, rq, a.Lq - qt, sQ, sQT, tid);
-        stage_tile<true, true>(a.dout, a.lddo, h * HD, rq, a.Lq - qt, sDO, sDOT, tid);
+        stage_tile<true, false>(a.q, a.ldq, h * HD, rq, a.Lq - qt, sQ, nullptr, tid);
+        stage_tile<true, false>(a.dout, a.lddo, h * HD, rq, a.Lq - qt, sDO, nullptr, tid);
         if (tid < TB) {
             const int qi = qt + tid;
             const bool ok = qi < a.Lq;
@@ -299,9 +310,8 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const unsigned short *dr = &sDOT[(db * 16 + c16) * TROW + g * 4], *qr = &sQT[(db * 16 + c16) * TROW + g * 4];
-                const uint2 dlo = *reinterpret_cast<const uint2 *>(dr + (2 * ks) * 16), dhi = *reinterpret_cast<const uint2 *>(dr + (2 * ks + 1) * 16);
-                const uint2 qlo = *reinterpret_cast<const uint2 *>(qr + (2 * ks) * 16), qhi = *reinterpret_cast<const uint2 *>(qr + (2 * ks + 1) * 16);
+                const uint2 dlo = tr_rows4(sDO, (2 * ks) * 16 + g * 4, db * 16, c16), dhi = tr_rows4(sDO, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 qlo = tr_rows4(sQ, (2 * ks) * 16 + g * 4, db * 16, c16), qhi = tr_rows4(sQ, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 dv[db] = mfma<BF16>(pf[ks], make_uint4(dlo.x, dlo.y, dhi.x, dhi.y), dv[db]);
                 dk[db] = mfma<BF16>(dsf[ks], make_uint4(qlo.x, qlo.y, qhi.x, qhi.y), dk[db]);
             }
