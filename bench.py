@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--targets", type=int, default=12)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--mode", default="both", choices=["infer", "train", "both"],
+                    help="infer: the headline forward metric only; both (default): also time the full training step (BASELINE config 4/5) "
+                         "and report it in the `train` object of the same JSON line; train: `value` IS the training throughput")
+    ap.add_argument("--train-scenes-per-gpu", type=int, default=24)    # README.md:104 / distill.yaml: 24 scenes per GPU
+    ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -82,8 +87,64 @@ class KernelTimer:
         return out
 
 
+def train_leg(args, enc, dec, dev, rank, world, dist):
+    """BASELINE configs 4 / 5: the full training step -- encoder + decoder + rasterizer forward, MSE, backward on the HIP kernels,
+    gradient exchange (GradReducer: bucketed all-reduce over RCCL overlapped with backward; N > 1 only), clip 0.5, AdamW -- on
+    `--train-scenes-per-gpu` 8-view scenes with `--targets` target views each (re10k_8view.yaml:19-20).  Timed like the headline:
+    barrier + synchronize on both sides, max over ranks.  lr is 1e-12: random-init weights + a real learning rate throw the scene off
+    screen within a few steps, which would change the rasterizer's work between timed steps; every kernel of the step still runs."""
+    from vicasplat_amd import callers, synthetic
+    from vicasplat_amd import dist as vdist
+    B, V, Vt = args.train_scenes_per_gpu, args.views, args.targets
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    img, K = synthetic.synthetic_input(B, V, 256, seed=100 + rank)
+    tE, tK, tn, tf = target_cameras(B, Vt, dev)
+    gen = torch.Generator().manual_seed(7 + rank)
+    target = torch.rand(B, Vt, 3, 256, 256, generator=gen).to(dev)
+    batch = dict(context=dict(image=img.to(dev), intrinsics=K.to(dev)), target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
+    enc.train()
+    opt, _ = callers.configure_optimizer(enc, lr=1e-12)
+    reducer = vdist.GradReducer(enc.parameters()) if world > 1 else None
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    r = callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer)      # warm-up (allocator, optimizer state)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        r = callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms = el / args.train_steps * 1e3
+    # algorithmic FLOPs of the step (SURVEY 8d): 3 407 GFLOP forward per 8-view scene, backward = 2x forward
+    flops = 3.0 * 3407e9 * (V / 8.0) * B
+    tf_s = flops / (ms * 1e-3) / 1e12
+    enc.eval()
+    if reducer is not None:
+        reducer.remove()
+    for p in enc.parameters():
+        p.grad = None
+    return dict(metric="scenes/sec training step (fwd+bwd+clip+AdamW)", value=round(world * B / (ms * 1e-3), 3), unit="scenes/s",
+                ms_per_step=round(ms, 2), steps=args.train_steps, scenes_per_gpu=B, context_views=V, target_views=Vt, dtype=args.dtype,
+                loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
+                peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                gradient_exchange=("none (1 GPU)" if world == 1 else f"GradReducer: 64 MiB buckets all-reduced during backward, RCCL x{world}"),
+                roofline=dict(bound="mfma", achieved=round(tf_s, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s",
+                              frac=round(tf_s / PEAK_MFMA_16BIT_TFLOPS, 4),
+                              what="whole step: 3 x 3407 GFLOP per 8-view scene (fwd + 2x bwd, SURVEY 8d) / step time"))
+
+
 def main():
     args = parse()
+    if args.mode == "train":      # only the training leg is of interest: keep the forward part to one untimed-quality pass
+        args.steps, args.warmup, args.no_roofline, args.no_cpu_baseline = 1, 0, True, True
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
@@ -217,6 +278,7 @@ def main():
             mfma_util_step=round(mfma_flops / (mfma_ms * 1e-3) / 1e12 / PEAK_MFMA_16BIT_TFLOPS, 4))
 
     cpu_baseline = None
+    psnr_vs_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline leg: the oracle (a restatement of the reference, "port"), timed on the host cores ----
         from oracle import encoder_ref as er
@@ -249,8 +311,22 @@ def main():
                   extrinsics=tE[0, :nv].cpu().numpy(), intrinsics=tK[0, :nv].cpu().numpy(), near=tnear[0, :nv].cpu().numpy(),
                   far=tfar[0, :nv].cpu().numpy())
         t1 = time.perf_counter()
-        rr.render_views(sc, res=256)
+        o_views = rr.render_views(sc, res=256)
         t_ras = (time.perf_counter() - t1) / nv
+        # ---- render PSNR vs the oracle chain (BASELINE.json metric, second half): the SAME scene and target cameras through the
+        # product chain (HIP encoder -> HIP rasterizer, compute dtype of this run) against oracle encoder (f32) -> C rasterizer ----
+        from oracle import chain
+        h_out = enc(dict(image=img[:1, :Vs].to(dev), intrinsics=K[:1, :Vs].to(dev)), compute_viewspace_depth=False)
+        hg = h_out["gaussians"]
+        h_r = dec(Gaussians(hg.means, hg.covariances, hg.harmonics, hg.opacities), tE[:1, :nv], tK[:1, :nv], tnear[:1, :nv], tfar[:1, :nv],
+                  (256, 256))
+        torch.cuda.synchronize()
+        cm = chain.compare_renders(h_r.color[0].cpu().numpy(), o_views)
+        pose_err = float((h_out["gaussian_camera_extrins"][0].cpu() - o["gaussian_camera_extrins"][0]).abs().max())
+        psnr_vs_oracle = dict(value=round(min(cm["psnr_between"]), 2), unit="dB", per_view=[round(p, 2) for p in cm["psnr_between"]],
+                              dpsnr_common_target=[float(f"{p:.2e}") for p in cm["dpsnr_common_target"]], pose_max_abs_err=float(f"{pose_err:.2e}"),
+                              what=f"PSNR(HIP encoder[{args.dtype}] -> HIP rasterizer, oracle encoder[f32] -> C oracle rasterizer), scene 0, "
+                                   f"{Vs} context views, first {nv} of {Vt} target views; min over views")
         # extrapolation to one bench scene: encoder by FLOPs when only 2 views were run, rasterizer ~ Gaussians x views
         est = t_enc * enc_scale + t_ras * (V / Vs) * Vt
         cpu_baseline = dict(value=round(1.0 / est, 5), unit="scenes/s", cores=ncores, kind="port",
@@ -259,14 +335,32 @@ def main():
                                    f"({Vs * 65536 // 1000}k Gaussians, 1 thread, {nv} of {Vt} target views timed); scene time = encoder + "
                                    f"{Vt} views")
 
-    if rank == 0:
+    train = None
+    if args.mode in ("train", "both"):
+        del ctx
+        try:
+            train = train_leg(args, enc, dec, dev, rank, world, dist)
+        except Exception as e:      # the headline line must survive a failure of the optional training leg
+            if args.mode == "train":
+                raise
+            train = dict(error=repr(e)[:300])
+            if dist is not None:    # the ranks may have diverged inside a collective: nothing after this point may need them in step
+                dist = None
+    if rank == 0 and args.mode == "train":
+        print(json.dumps(dict(metric=train["metric"], value=train["value"], unit="scenes/s", n_gpus=world, steps=args.train_steps, warmup=1,
+                              ms_per_step=train["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype,
+                              data="synthetic", config=dict(workload="re10k_8view full pipeline fwd+bwd: one training step",
+                                                            scenes_per_gpu=train["scenes_per_gpu"], context_views=V, target_views=Vt,
+                                                            parallelism=f"data-parallel x{world}: " + train["gradient_exchange"]),
+                              roofline=train["roofline"], cpu_baseline=None, train=train)))
+    elif rank == 0:
         line = dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(value, 3), unit="scenes/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
                                          f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
                                 parallelism=f"scene-sharded x{world} (no collective)"),
-                    roofline=roofline, cpu_baseline=cpu_baseline, **extra)
+                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, train=train, **extra)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -98,16 +98,18 @@ def patch_positions(B, gh, gw):
 
 
 def encode_frames(W, cfg, frames, intr_tok):
-    """frames [BT,3,H,W] (already normalised), intr_tok [BT,1,C] -> tokens [BT,N+1,C], pos [BT,N+1,2]."""
+    """frames [BT,3,H,W] (already normalised), intr_tok [BT,1,C] -> tokens [BT,N+1,C], pos [BT,N+1,2]; intr_tok None
+    (use_intrinsic_embedding=false, the *_no_intrin checkpoints): N tokens, no extra position."""
     p = cfg["patch_size"]
     x = F.conv2d(frames, W["backbone.patch_embed.proj.weight"], W["backbone.patch_embed.proj.bias"], stride=p)
     BT, C, gh, gw = x.shape
     x = x.flatten(2).transpose(1, 2)
     pos = patch_positions(BT, gh, gw)
-    x = torch.cat([x, intr_tok], 1)
-    extra = pos[:, :1].clone()
-    extra[:, :, 0] += pos[:, -1:, 0] + 1  # (y,x) = (gh, 0): backbone_vica.py:455-459
-    pos = torch.cat([pos, extra], 1)
+    if intr_tok is not None:
+        x = torch.cat([x, intr_tok], 1)
+        extra = pos[:, :1].clone()
+        extra[:, :, 0] += pos[:, -1:, 0] + 1  # (y,x) = (gh, 0): backbone_vica.py:455-459
+        pos = torch.cat([pos, extra], 1)
     Hn = cfg["enc_num_heads"]
     for i in range(cfg["enc_depth"]):
         n = f"backbone.enc_blocks.{i}"
@@ -122,9 +124,12 @@ def encode_frames(W, cfg, frames, intr_tok):
 # ---------------------------------------------------------------------------------------------------------
 # video / camera decoder  (backbone_vica.py:57-335,482-524,585-593)
 # ---------------------------------------------------------------------------------------------------------
-def camera_mask(T, n_per_frame):
-    """[T, T*(1+n)] bool: camera query t sees every key of frames <= t (backbone_vica.py:585-593, intrinsic embedding on)."""
+def camera_mask(T, n_per_frame, first_token_full_attn=False):
+    """[T, T*(1+n)] bool: camera query t sees every key of frames <= t (backbone_vica.py:585-593); without the intrinsic
+    embedding camera token 0 (the intrinsic token) sees every frame (:589-590)."""
     m = torch.ones(T, T, dtype=torch.bool).tril()
+    if first_token_full_attn:
+        m[:1] = True
     return m[:, :, None].expand(T, T, 1 + n_per_frame).reshape(T, T * (1 + n_per_frame))
 
 
@@ -175,7 +180,7 @@ def decoder(W, cfg, x, pos):
     C = x.shape[-1]
     ti, te = W["backbone.camera_intrinsic_token"], W["backbone.camera_extrinsic_token"]
     cam = torch.cat([ti.expand(B, 1, C), (ti + te).expand(B, T - 1, C)], 1)
-    mask = camera_mask(T, N)
+    mask = camera_mask(T, N, first_token_full_attn=not cfg.get("use_intrinsic_embedding", True))
     for i in range(cfg["dec_depth"]):
         n = f"backbone.dec_blocks.{i}"
         cn = ln(W, n + ".cam_norm1", cam)
@@ -324,17 +329,25 @@ def forward(W: dict, cfg: dict, image: torch.Tensor, intrinsics: torch.Tensor, r
     p = cfg["patch_size"]
     gh, gw = H // p, Wd // p
     frames = image.reshape(B * V, 3, H, Wd)
-    intr_tok = lin(W, "backbone.intrinsic_encoder", intrinsics.reshape(B * V, 1, 9))
+    use_intr = cfg.get("use_intrinsic_embedding", True)
+    intr_tok = lin(W, "backbone.intrinsic_encoder", intrinsics.reshape(B * V, 1, 9)) if use_intr else None
     x, pos = encode_frames(W, cfg, frames, intr_tok)
     N1 = x.shape[1]
     inter, cam = decoder(W, cfg, x.reshape(B, V, N1, -1), pos.reshape(B, V, N1, 2))
-    inter = [t[:, :, :-1].reshape(B * V, N1 - 1, -1) for t in inter]  # drop the intrinsic token (:570-572)
+    n_img = N1 - 1 if use_intr else N1
+    inter = [t[:, :, :n_img].reshape(B * V, n_img, -1) for t in inter]  # drop the intrinsic token (:570-572)
     dq, c2w = pose_from_camera_tokens(W, cam[:, 1:])
     centers = pts3d_head(W, cfg, inter, gh, gw).reshape(B, V, H, Wd, 3)
     params = gs_head(W, cfg, inter, frames, gh, gw).reshape(B, V, -1, H, Wd).permute(0, 1, 3, 4, 2)
     raw = torch.cat([centers, params], -1)
     out = dict(pred_extrins=dq, gaussian_camera_extrins=c2w, raw_gaussians=raw, gaussian_centers=centers,
-               gaussians=gaussian_adapter(raw, cfg["sh_degree"]))
+               gaussians=gaussian_adapter(raw, cfg["sh_degree"]), pred_intrins=None, gaussian_camera_intrins=None)
+    if not use_intr:   # fov head on camera token 0 (vicasplat.py:129-138,201-205) -> pinhole K (cam_utils.py:220-234)
+        fov = lin(W, "camera_intrinsic_head.1", F.relu(cam[:, 0]))
+        Kp = torch.eye(3, dtype=fov.dtype).repeat(B, 1, 1)
+        Kp[:, 0, 0], Kp[:, 1, 1] = 0.5 / torch.tan(fov[:, 0] * 0.5), 0.5 / torch.tan(fov[:, 1] * 0.5)
+        Kp[:, 0, 2] = Kp[:, 1, 2] = 0.5
+        out["pred_intrins"], out["gaussian_camera_intrins"] = fov, Kp.float()[:, None].repeat(1, V, 1, 1)
     if return_intermediates:
         out["intermediates"] = inter
         out["camera_tokens"] = cam

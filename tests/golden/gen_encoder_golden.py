@@ -59,6 +59,9 @@ def run(model, image, K, dtype):
                raw=lat(out["raw_gaussians"]), means=lat(g.means), covariances=lat(g.covariances), harmonics=lat(g.harmonics),
                opacities=lat(g.opacities), scales=lat(g.scales), rotations=lat(g.rotations),
                blocks=np.stack([sums[k] for k in sorted(sums)]), block_names=np.array(sorted(sums)))
+    if out.get("pred_intrins") is not None:      # use_intrinsic_embedding=false: fov head + pinhole intrinsics
+        res["pred_intrins"] = out["pred_intrins"].double().numpy()
+        res["intrins_3x3"] = out["gaussian_camera_intrins"].double().numpy()
     return res
 
 
@@ -66,6 +69,9 @@ def make(name, overrides, B, V, seed=0, do_f64=True):
     t0 = time.time()
     model = ref_import.build_reference_encoder(overrides)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    if name.startswith("tiny_noint"):
+        import json
+        json.dump({k: list(v) for k, v in shapes.items()}, open(os.path.join(HERE, "shapes_tiny_noint.json"), "w"))
     W = er.golden_weights(shapes, seed=seed)
     missing, unexpected = model.load_state_dict(W, strict=True), None
     image, K = er.synthetic_input(B, V, 256, seed=seed)
@@ -87,7 +93,9 @@ def make(name, overrides, B, V, seed=0, do_f64=True):
 TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny_v3", "tiny_v2", "full_v2", "full_v8"]
+    which = sys.argv[1:] or ["tiny_v3", "tiny_v2", "full_v2", "full_v8", "tiny_noint_v3"]
+    if "tiny_noint_v3" in which:    # the *_no_intrin checkpoints' architecture (README.md:51-53): no intrinsic token, fov head
+        make("tiny_noint_v3", dict(TINY, use_intrinsic_embedding=False), B=2, V=3)
     if "tiny_v3" in which:
         make("tiny_v3", TINY, B=2, V=3)
     if "tiny_v2" in which:

@@ -44,3 +44,24 @@ def test_align_poses_recovers_perturbed_cameras():
     psnr0 = callers.compute_psnr(target[0], dec(g, E0, K, near, far, (64, 64)).color[0].detach())
     psnr1 = callers.compute_psnr(target[0], dec(g, E1, K, near, far, (64, 64)).color[0].detach())
     assert (psnr1 > psnr0 + 3).all(), (psnr0, psnr1)
+
+
+def test_render_video_interpolation_shares_one_gaussian_set():
+    """demo.py:204-243: 10 cameras per interval between the predicted key poses, rendered from ONE Gaussian set in a single batched
+    rasterizer call, forward path then its reverse; every frame equals the per-camera render_cuda of the same interpolated camera."""
+    from vicasplat_amd.model.decoder.cuda_splatting import render_cuda
+    from vicasplat_amd.model.types import Gaussians
+    d = torch.device("cuda:0")
+    sc = _smooth_scene(d, res=64, Vt=4)
+    g = Gaussians(sc["means"].view(2, 64, 64, 3), sc["covariances"].view(2, 64, 64, 3, 3), sc["harmonics"].view(2, 64, 64, 3, 25),
+                  sc["opacities"].view(2, 64, 64))
+    poses, K = sc["extrinsics"], sc["intrinsics"][:1]
+    frames = callers.render_video_interpolation(g, poses, K, n_interp_per_interv=10, image_shape=(64, 64))
+    assert frames.shape == (2 * 3 * 10, 3, 64, 64) and torch.equal(frames[:30].flip(0), frames[30:])
+    t = torch.linspace(0, 1, 10, device=d)
+    E = callers.interpolate_extrinsics(poses[:-1], poses[1:], t).reshape(-1, 4, 4)
+    for j in (0, 9, 17, 29):
+        one, _ = render_cuda(E[j:j + 1], K, sc["near"][:1], sc["far"][:1], (64, 64), torch.zeros(1, 3, device=d), sc["means"],
+                             sc["covariances"], sc["harmonics"], sc["opacities"])
+        assert torch.equal(one[0], frames[j])
+    assert float(frames.mean()) > 0.01

@@ -23,7 +23,10 @@ LAT = slice(8, 256, 16)
 def _model(kind, dt=torch.float16):
     from vicasplat_amd.model.encoder import default_cfg, get_encoder
     shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))
-    m, _ = get_encoder(default_cfg(**(TINY if kind == "tiny" else {})))
+    over = dict(TINY) if kind.startswith("tiny") else {}
+    if kind == "tiny_noint":
+        over["use_intrinsic_embedding"] = False
+    m, _ = get_encoder(default_cfg(**over))
     W = er.golden_weights(shapes, seed=0)
     missing = m.load_state_dict(W, strict=True)
     m = m.cuda().eval()
@@ -38,7 +41,7 @@ def _rel(a, b):
 
 def _check(name, dt, tol_pose, tol_raw):
     z = np.load(os.path.join(G, f"encoder_{name}.npz"))
-    kind = "tiny" if name.startswith("tiny") else "full"
+    kind = "tiny_noint" if name.startswith("tiny_noint") else "tiny" if name.startswith("tiny") else "full"
     m = _model(kind, dt)
     B, V = int(z["cfg_B"]), int(z["cfg_V"])
     img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
@@ -53,9 +56,16 @@ def _check(name, dt, tol_pose, tol_raw):
         errs["g_" + k] = _rel(getattr(g, k)[:, :, LAT, LAT].cpu().numpy(), z[f"f64_{k}"])
     print(name, dt, {k: f"{v:.2e}" for k, v in errs.items()})
     assert errs["pose"] <= tol_pose and errs["c2w"] <= tol_pose, errs
-    for k in ("xyz", "opacity", "scale", "quat", "sh", "g_means", "g_harmonics", "g_opacities"):
+    for k in ("xyz", "opacity", "scale", "quat", "sh", "g_means", "g_covariances", "g_harmonics", "g_opacities"):
         assert errs[k] <= tol_raw, (k, errs)
     assert out["raw_gaussians"].shape == (B, V, 256, 256, 86) and g.covariances.shape == (B, V, 256, 256, 3, 3)
+    if kind == "tiny_noint":
+        e_fov = _rel(out["pred_intrins"].cpu(), z["f64_pred_intrins"])
+        e_K = _rel(out["gaussian_camera_intrins"].cpu(), z["f64_intrins_3x3"])
+        print("fov", e_fov, "K", e_K)
+        assert e_fov <= tol_pose and e_K <= 10 * tol_pose, (e_fov, e_K)      # K = 0.5 / tan(fov / 2) amplifies a small fov's error
+    else:
+        assert out["pred_intrins"] is None and out["gaussian_camera_intrins"] is None
     return errs
 
 
@@ -71,6 +81,12 @@ def test_state_dict_is_the_reference_abi():
 @pytest.mark.parametrize("name", ["tiny_v2", "tiny_v3"])
 def test_encoder_tiny_matches_reference(name):
     _check(name, torch.float16, 5e-3, 3e-2)
+
+
+def test_encoder_without_intrinsic_embedding_matches_reference():
+    """use_intrinsic_embedding=false (the released *_no_intrin checkpoints, README.md:51-53): 256 tokens per frame, global scope for
+    camera token 0, fov head; goldens from the real reference built with that flag."""
+    _check("tiny_noint_v3", torch.float16, 5e-3, 3e-2)
 
 
 def test_encoder_full_vitl_2view_matches_reference():

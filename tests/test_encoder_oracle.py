@@ -19,9 +19,11 @@ LAT = slice(8, 256, 16)
 
 def _load(name):
     z = np.load(os.path.join(G, f"encoder_{name}.npz"))
-    kind = "tiny" if name.startswith("tiny") else "full"
+    kind = "tiny_noint" if name.startswith("tiny_noint") else "tiny" if name.startswith("tiny") else "full"
     shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))
-    cfg = er.default_cfg(**(TINY if kind == "tiny" else {}))
+    cfg = er.default_cfg(**(TINY if kind.startswith("tiny") else {}))
+    if kind == "tiny_noint":
+        cfg["use_intrinsic_embedding"] = False
     return z, shapes, cfg
 
 
@@ -53,6 +55,18 @@ def _check(z, out, tag, rtol):
 def test_oracle_matches_reference_f32(name):
     z, out = _run(name, torch.float32)
     _check(z, out, "f32", 1e-4)
+
+
+def test_oracle_matches_reference_without_intrinsic_embedding():
+    """use_intrinsic_embedding=false (the released *_no_intrin checkpoints, README.md:51-53): 256 tokens per frame, camera token 0
+    with global attention scope (backbone_vica.py:585-590), fov head -> pinhole intrinsics (vicasplat.py:129-138,201-205)."""
+    z, out = _run("tiny_noint_v3", torch.float32)
+    _check(z, out, "f32", 1e-4)
+    assert np.abs(out["pred_intrins"].double().numpy() - z["f32_pred_intrins"]).max() <= 1e-5
+    ref = z["f32_intrins_3x3"]
+    assert np.abs(out["gaussian_camera_intrins"].double().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    z, out = _run("tiny_noint_v3", torch.float64)
+    _check(z, out, "f64", 1e-6)
 
 
 def test_oracle_matches_reference_f64():
@@ -89,3 +103,5 @@ def test_pose_algebra_properties():
 def test_camera_mask_rows():
     m = er.camera_mask(8, 257)
     assert m.shape == (8, 8 * 258) and m.sum(1).tolist() == [258 * (t + 1) for t in range(8)]
+    m = er.camera_mask(4, 256, first_token_full_attn=True)
+    assert m.sum(1).tolist() == [257 * 4, 257 * 2, 257 * 3, 257 * 4]

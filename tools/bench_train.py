@@ -9,13 +9,14 @@ from vicasplat_amd.model.encoder import default_cfg, get_encoder
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--scenes", type=int, default=1); ap.add_argument("--views", type=int, default=8); ap.add_argument("--targets", type=int, default=4)
-ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--scenes", type=int, default=1); ap.add_argument("--views", type=int, default=8); ap.add_argument("--targets", type=int, default=12)   # re10k_8view.yaml:20
+ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--checkpoint", action="store_true")
 a = ap.parse_args()
 d = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "shapes_full.json")))
 enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).train()
 enc.set_compute_dtype(torch.float16)
+if a.checkpoint: enc.enable_gradient_checkpointing()
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
 B, V, Vt = a.scenes, a.views, a.targets
 img, K = synthetic.synthetic_input(B, V, 256, 0)
@@ -37,7 +38,7 @@ for _ in range(a.steps):
                          round(torch.cuda.memory_allocated() / 2**30, 2)))
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 if per_step: print("per-step (ms, device mallocs, live GB):", per_step)
-print(json.dumps(dict(config="re10k_8view training step fwd+bwd+AdamW", scenes=B, views=V, targets=Vt, ms_per_step=round(dt * 1e3, 1),
+print(json.dumps(dict(config="re10k_8view training step fwd+bwd+AdamW", checkpointing=bool(a.checkpoint), scenes=B, views=V, targets=Vt, ms_per_step=round(dt * 1e3, 1),
                       scenes_per_s=round(B / dt, 3), loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                       reserved_gb=round(torch.cuda.memory_stats()["reserved_bytes.all.peak"] / 2**30, 1),

@@ -19,8 +19,9 @@ from . import ops
 class LinearFn(torch.autograd.Function):
     """y16 = x @ w^T + b on the MFMA GEMM; backward = dgrad / wgrad on the same kernels (ops.linear_backward).
     rope = (pos, kind, H, C, base2d, theta1d): w is a packed q | k | v projection and the rotary embedding of q and k runs in the
-    GEMM epilogue (vs_gemm_qkv_rope); the backward applies the inverse rotation to dq | dk IN PLACE on the incoming gradient
-    (that tensor is produced by AttentionFn.backward for this node alone) before the usual dgrad / wgrad."""
+    GEMM epilogue (vs_gemm_qkv_rope); the backward applies the inverse rotation to dq | dk before the usual dgrad / wgrad -- in place
+    only when the incoming gradient is the fresh buffer AttentionFn.backward produced for this node alone (it tags it), on a
+    clone otherwise (retain_grad / tensor hooks / a second consumer must never observe a rotated gradient)."""
 
     @staticmethod
     def forward(ctx, x, w, b, dt, rope):
@@ -36,7 +37,7 @@ class LinearFn(torch.autograd.Function):
             ops.gemm_qkv_rope(x16, w16, bf, y, C, pos, kind, base2d, theta1d)
         ctx.save_for_backward(x16, w16)
         ctx.meta = (x.shape, x.dtype, b is not None, rope)
-        return y.view(*x.shape[:-1], w16.shape[0])
+        return y if x.dim() == 2 else y.view(*x.shape[:-1], w16.shape[0])   # (no view node in front of a 2-D result: see backward)
 
     @staticmethod
     def backward(ctx, dy):
@@ -47,6 +48,8 @@ class LinearFn(torch.autograd.Function):
             dy16 = dy16.contiguous()          # (row-padded gradients -- 16-byte aligned rows -- are consumed as they are)
         if rope is not None:
             pos, kind, H, C, base2d, theta1d = rope
+            if dy16.data_ptr() == dy.data_ptr() and not getattr(dy, "_vs_owned_grad", False):
+                dy16 = dy16.clone()       # never mutate a gradient autograd handed in, unless its producer marked it as ours alone
             ops.rope_qk(dy16, H, C, pos, kind, base2d, theta1d, inverse=True)
         dx, dw, db = ops.linear_backward(dy16, x16, w16, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
                                          need_db=has_b and ctx.needs_input_grad[2])
@@ -158,6 +161,7 @@ class AttentionFn(torch.autograd.Function):
                                            max_keys=max_keys, dq_out=dqkv[:, :C])
         dqkv[:, C:2 * C] = dk                                                            # (one cast-copy each)
         dqkv[:, 2 * C:] = dv
+        dqkv._vs_owned_grad = True     # fresh buffer with a single consumer: LinearFn.backward may un-rotate it in place
         return dqkv, None, None, None, None, None, None, None, None, None
 
 
@@ -238,23 +242,36 @@ def gelu(z: torch.Tensor) -> torch.Tensor:
 class EncBlockFn(torch.autograd.Function):
     """One frame-encoder block (croco/blocks.py:114-130) as a single autograd node on the hand-differentiated pair of
     vicasplat_amd.train: x f32 [M,C] -> x_out f32 [M,C].  params = (norm1.w, norm1.b, qkv.w, qkv.b, proj.w, proj.b, norm2.w,
-    norm2.b, fc1.w, fc1.b, fc2.w, fc2.b), the module's f32 parameters."""
+    norm2.b, fc1.w, fc1.b, fc2.w, fc2.b), the module's f32 parameters.
+    ckpt = True is the reference's per-block activation checkpointing (backbone_vica.py:464-474): only the block INPUT is kept and
+    the backward re-runs the block's forward kernels (run-to-run deterministic, so the recomputed tape is bit-identical) before
+    differentiating it -- 9 saved tensors (~26 B per token-channel) shrink to one f32 copy of x."""
 
     @staticmethod
-    def forward(ctx, x, pos, frames, tokens, heads, dt, *params):
+    def forward(ctx, x, pos, frames, tokens, heads, dt, ckpt, *params):
         from .train import EncBlockParams, enc_block_forward_train
         f = [t.detach().float().contiguous() for t in params]
         p = EncBlockParams(f[0], f[1], f[2].to(dt), f[3], f[4].to(dt), f[5], f[6], f[7], f[8].to(dt), f[9], f[10].to(dt), f[11])
-        x_out, tape = enc_block_forward_train(x.detach().contiguous(), p, pos, frames=frames, tokens=tokens, heads=heads)
-        ctx.tape, ctx.p = tape, p
+        xin = x.detach().contiguous()
+        x_out, tape = enc_block_forward_train(xin, p, pos, frames=frames, tokens=tokens, heads=heads)
+        ctx.tape, ctx.p, ctx.live = (None if ckpt else tape), p, True
+        ctx.recompute = (xin, pos, frames, tokens, heads) if ckpt else None
         return x_out
 
     @staticmethod
     def backward(ctx, dx_out):
-        from .train import enc_block_backward
-        dx, g = enc_block_backward(dx_out.contiguous(), ctx.tape, ctx.p)
-        ctx.tape = ctx.p = None
-        return (dx, None, None, None, None, None, g["ln1_w"], g["ln1_b"], g["qkv_w"], g["qkv_b"], g["proj_w"], g["proj_b"],
+        from .train import enc_block_backward, enc_block_forward_train
+        if not ctx.live:
+            raise RuntimeError("EncBlockFn.backward ran twice: the block's tape is released after the first backward "
+                               "(backward(retain_graph=True) twice is not supported on the hand-differentiated encoder blocks)")
+        tape = ctx.tape
+        if tape is None:
+            xin, pos, frames, tokens, heads = ctx.recompute
+            _, tape = enc_block_forward_train(xin, ctx.p, pos, frames=frames, tokens=tokens, heads=heads)
+        dx, g = enc_block_backward(dx_out.contiguous(), tape, ctx.p)
+        ctx.tape = ctx.p = ctx.recompute = None
+        ctx.live = False
+        return (dx, None, None, None, None, None, None, g["ln1_w"], g["ln1_b"], g["qkv_w"], g["qkv_b"], g["proj_w"], g["proj_b"],
                 g["ln2_w"], g["ln2_b"], g["fc1_w"], g["fc1_b"], g["fc2_w"], g["fc2_b"])
 
 

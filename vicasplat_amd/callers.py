@@ -9,6 +9,9 @@ scripts do around the encoder/decoder:
   * `export_ply`              — src/model/ply_export.py:31-90 (own binary writer, no plyfile dependency)
   * `export_transforms`       — src/model/model_wrapper.py:390-400 (transforms.json)
   * `load_images`             — demo.py:75-132 (resize short side to 256, centre crop, normalise to [-1, 1])
+  * `inference`, `interpolate_extrinsics`, `interpolate_intrinsics`, `render_video_interpolation` — demo.py:180-243 with
+    src/visualization/camera_trajectory/interpolation.py (the 70-view demo video: cameras share ONE Gaussian set)
+  * `camera_loss`, `camera_dq_loss` — src/loss/loss_camera.py:30-80 (dual-quaternion algebra of src/misc/dq.py restated)
   * `configure_optimizer`, `training_step` — ModelWrapper.configure_optimizers / training_step (model_wrapper.py:884-951,
     184-321): AdamW(lr, wd 0.05, betas 0.9/0.95) with the backbone-lr multiplier, encoder -> rasterizer -> MSE ->
     backward on the HIP kernels (vicasplat_amd.autograd) -> optional gradient all-reduce -> clip 0.5 -> step.
@@ -16,6 +19,7 @@ scripts do around the encoder/decoder:
 from __future__ import annotations
 
 import json
+import math
 from pathlib import Path
 
 import numpy as np
@@ -105,11 +109,16 @@ def _ply_attributes(num_rest: int) -> list[str]:
 def export_ply(means: Tensor, scales: Tensor, rotations: Tensor, harmonics: Tensor, opacities: Tensor, path,
                save_sh_dc_only: bool = False) -> int:
     """3DGS-compatible binary PLY: pruned at opacity < 0.005, sorted by opacity (descending), opacity as a logit, scales
-    as logs, rotation xyzw -> unit wxyz (ply_export.py:31-90). Returns the number of vertices written."""
+    as logs, rotation xyzw -> unit wxyz (ply_export.py:31-90; the vertex table is checked against the reference's own in
+    tests/test_callers_cpu.py). Returns the number of vertices written."""
     mask = opacities >= 0.005
     op, idx = torch.sort(opacities[mask], descending=True)
     means, scales, rotations, harmonics = (t[mask][idx] for t in (means, scales, rotations, harmonics))
     q = rotations / rotations.norm(dim=-1, keepdim=True)
+    # the reference round-trips the quaternion through a rotation matrix (scipy, ply_export.py:52-55), which fixes its sign: the
+    # component of largest magnitude comes back positive
+    lead = torch.gather(q, 1, q.abs().argmax(dim=1, keepdim=True))
+    q = q * torch.where(lead < 0, -torch.ones_like(lead), torch.ones_like(lead))
     q = torch.cat([q[:, 3:], q[:, :3]], dim=-1)
     f_dc = harmonics[..., 0]
     f_rest = harmonics[..., 1:].flatten(1)
@@ -192,14 +201,139 @@ def load_images(folder_or_list, size: int = 256) -> Tensor:
     return torch.stack(frames, 0)
 
 
-def configure_optimizer(encoder, lr: float = 4e-5, backbone_lr_multiplier: float = 0.25, new_param_keywords=("camera", "mlp_cam", "cam_norm", "modulation"),
-                        weight_decay: float = 0.05, warm_up_steps: int = 0):
+# ---------------------------------------------------------------------------------------------------------------------------
+# demo video path (demo.py:180-243): cameras interpolated between consecutive predicted poses, ALL of them rendered from the one
+# shared Gaussian set in a single batched rasterizer call (the rasterizer's shared-Gaussian mode, cam_scene = 0)
+# ---------------------------------------------------------------------------------------------------------------------------
+def interpolate_intrinsics(initial: Tensor, final: Tensor, t: Tensor) -> Tensor:
+    """[...,3,3] x2, t [S] -> [...,S,3,3] linear blend (visualization/camera_trajectory/interpolation.py:8-16)."""
+    return initial[..., None, :, :] + (final - initial)[..., None, :, :] * t[:, None, None]
+
+
+def _frame_yz(y: Tensor, z: Tensor) -> Tensor:
+    return torch.stack([torch.linalg.cross(y, z, dim=-1), y, z], dim=-1)   # columns (y x z, y, z)
+
+
+def _euler_yxz(R: Tensor):
+    """R = Ry(a) Rx(b) Rz(c) (intrinsic Y-X-Z, what scipy's as_euler('YXZ') returns) -> (a, b, c)."""
+    return torch.atan2(R[..., 0, 2], R[..., 2, 2]), torch.asin((-R[..., 1, 2]).clamp(-1, 1)), torch.atan2(R[..., 1, 0], R[..., 1, 1])
+
+
+def _blend_angle(a: Tensor, b: Tensor, t: Tensor) -> Tensor:
+    """Shortest-arc interpolation of angles taken mod 2 pi (interpolation.py:163-188)."""
+    tau = 2 * math.pi
+    a, b = a % tau, b % tau
+    d0, dl, dr = (b - a).abs(), (b - (a - tau)).abs(), (b - (a + tau)).abs()
+    use0 = (d0 < dl) & (d0 < dr)
+    usel = (dl < dr) & ~use0
+    a = torch.where(use0, a, torch.where(usel, a - tau, a + tau))
+    return a + (b - a) * t
+
+
+@torch.no_grad()
+def interpolate_extrinsics(initial: Tensor, final: Tensor, t: Tensor, eps: float = 1e-4) -> Tensor:
+    """c2w [N,4,4] x2, t [S] -> [N,S,4,4]: every pair is interpolated by rotating about its "focus point" -- the least-squares
+    intersection of the two look rays, or the midpoint of the origins when the look vectors are parallel -- in the 5-parameter
+    pivot form (3 offsets in the frame (pivot axis x look, pivot axis, look), in-plane angle, twist); the out-of-plane Euler angle
+    is dropped on the way back (interpolation.py:208-259, float64 inside like the reference)."""
+    A, B, t = initial.double(), final.double(), t.double()
+    la, lb = A[..., :3, 2], B[..., :3, 2]
+    oa, ob = A[..., :3, 3], B[..., :3, 3]
+    par = ((la * lb).sum(-1).abs() - 1).abs() < eps
+    eye = torch.eye(3, dtype=torch.float64, device=A.device)
+    Na, Nb = la[..., :, None] * la[..., None, :] - eye, lb[..., :, None] * lb[..., None, :] - eye
+    lhs, rhs = Na + Nb, (Na @ oa[..., None] + Nb @ ob[..., None])[..., 0]
+    lhs = torch.where(par[..., None, None], eye.expand_as(lhs), lhs)                # (unused rows: keep the solve well-posed)
+    pivot = torch.where(par[..., None], 0.5 * (oa + ob), torch.linalg.lstsq(lhs, rhs[..., None]).solution[..., 0])
+    # pivot frame: Y normal to the plane of the two look vectors; a look vector parallel to the other is replaced by z, then y
+    b2 = lb.clone()
+    for alt in ((0.0, 0.0, 1.0), (0.0, 1.0, 0.0)):
+        p_ = ((la * b2).sum(-1).abs() - 1).abs() < eps
+        b2 = torch.where(p_[..., None], b2.new_tensor(alt).expand_as(b2), b2)
+    n = torch.linalg.cross(la, b2, dim=-1)
+    F = _frame_yz(n / n.norm(dim=-1, keepdim=True), la)
+    axis = F[..., :, 1]
+
+    def to_params(E):
+        tf = _frame_yz(axis, E[..., :3, 2])
+        tr = (tf * (pivot - E[..., :3, 3])[..., :, None]).sum(-2)
+        y, _, z = _euler_yxz(torch.linalg.inv(F) @ E[..., :3, :3])
+        return tr, y, z
+
+    ta, ya, za = to_params(A)
+    tb, yb, zb = to_params(B)
+    tt = t[:, None]
+    tr = ta[..., None, :] + (tb - ta)[..., None, :] * tt
+    y, z = _blend_angle(ya[..., None], yb[..., None], t), _blend_angle(za[..., None], zb[..., None], t)
+    # back to matrices in float32 (the reference converts the parameters to f32 first)
+    tr, y, z, F32, piv = tr.float(), y.float(), z.float(), F.float()[..., None, :, :], pivot.float()[..., None, :]
+    cy, sy, cz, sz = y.cos(), y.sin(), z.cos(), z.sin()
+    o, l = torch.zeros_like(y), torch.ones_like(y)
+    Ry = torch.stack([cy, o, sy, o, l, o, -sy, o, cy], -1).unflatten(-1, (3, 3))
+    Rz = torch.stack([cz, -sz, o, sz, cz, o, o, o, l], -1).unflatten(-1, (3, 3))
+    Rm = F32 @ (Ry @ Rz)
+    tf = _frame_yz(F32[..., :, 1].expand_as(Rm[..., :, 2]), Rm[..., :, 2])
+    origin = piv - (tf @ tr[..., None])[..., 0]
+    out = torch.eye(4, dtype=torch.float32, device=A.device).repeat(*origin.shape[:-1], 1, 1)
+    out[..., :3, :3] = Rm
+    out[..., :3, 3] = origin
+    return out
+
+
+@torch.no_grad()
+def inference(model, imgs: Tensor, fovx_deg: float | None = None, fovy_deg: float | None = None) -> dict:
+    """demo.py:180-202: imgs [1,V,3,H,W] in [-1,1] (load_images) -> Gaussians, points, c2w poses, intrinsics; the intrinsic embedding is
+    fed the pinhole K of the given field of view (cam_utils.py:220-234) when the backbone uses it."""
+    inputs = {"image": imgs}
+    intr = None
+    if model.backbone.config.use_intrinsic_embedding:
+        assert (fovx_deg or 0) > 0 or (fovy_deg or 0) > 0, "need to provide valid fovx and fovy"
+        fx = math.radians(fovx_deg) if (fovx_deg or 0) > 0 else None
+        fy = math.radians(fovy_deg) if (fovy_deg or 0) > 0 else None
+        fov = (fx or fy, fy or fx)
+        intr = torch.eye(3, device=imgs.device)
+        intr[0, 0], intr[1, 1] = 0.5 / math.tan(0.5 * fov[0]), 0.5 / math.tan(0.5 * fov[1])
+        intr[0, 2] = intr[1, 2] = 0.5
+        intr = intr[None]
+        inputs["intrinsics"] = intr[None].expand(imgs.shape[0], imgs.shape[1], 3, 3).contiguous()
+    out = model(inputs, compute_viewspace_depth=False)
+    return dict(imgs=imgs * 0.5 + 0.5, gaussians=out["gaussians"], pts3d=out["gaussian_centers"], camera_poses=out["gaussian_camera_extrins"],
+                camera_intrins=out["gaussian_camera_intrins"] if intr is None else intr)
+
+
+@torch.no_grad()
+def render_video_interpolation(gaussians, camera_poses: Tensor, camera_intrins: Tensor, n_interp_per_interv: int = 10, near: float = 0.01,
+                               far: float = 100.0, image_shape=(256, 256)) -> Tensor:
+    """demo.py:204-243: camera_poses [V,4,4] c2w, camera_intrins [V,3,3] | [1,3,3] -> frames [2 * (V-1) * n, 3, H, W] (forward pass of
+    the path followed by its reverse).  The (V-1) * n cameras share ONE Gaussian set: one batched rasterizer call, no replication."""
+    from .model.decoder.cuda_splatting import render_cuda
+    dev = camera_poses.device
+    if camera_intrins.shape[0] == 1:
+        camera_intrins = camera_intrins.expand(camera_poses.shape[0], 3, 3)
+    t = torch.linspace(0, 1, n_interp_per_interv, dtype=torch.float32, device=dev)
+    E = interpolate_extrinsics(camera_poses[:-1], camera_poses[1:], t).reshape(-1, 4, 4)
+    K = interpolate_intrinsics(camera_intrins[:-1].float(), camera_intrins[1:].float(), t).reshape(-1, 3, 3)
+    v = E.shape[0]
+    images, _depth = render_cuda(E, K, torch.full((v,), near, device=dev), torch.full((v,), far, device=dev), image_shape,
+                                 torch.zeros(v, 3, device=dev), gaussians.means.reshape(-1, 3), gaussians.covariances.reshape(-1, 3, 3),
+                                 gaussians.harmonics.reshape(-1, *gaussians.harmonics.shape[-2:]), gaussians.opacities.reshape(-1),
+                                 scale_invariant=False)
+    return torch.cat([images, images.flip(dims=(0,))], dim=0)
+
+
+def configure_optimizer(encoder, lr: float = 4e-5, backbone_lr_multiplier: float = 0.25,
+                        new_param_keywords=("gaussian_param_head", "intrinsic_encoder"), weight_decay: float = 0.05, warm_up_steps: int = 0,
+                        lr_cosine_annealing: bool = False, max_steps: int | None = None):
     """AdamW with the reference's two learning-rate groups (model_wrapper.py:884-951): parameters whose name contains one of
-    `new_param_keywords` train at `lr`, the pretrained rest at `lr * backbone_lr_multiplier`; linear warm-up as the reference."""
+    `new_param_keywords` train at `lr`, the pretrained rest at `lr * backbone_lr_multiplier` (every released experiment sets
+    new_param_keywords = [gaussian_param_head, intrinsic_encoder]: config/experiment/re10k_*.yaml; distillation passes None -> one
+    group at `lr`).  Schedule: LinearLR warm-up (1/warm_up_steps -> 1), then -- `lr_cosine_annealing` (2- and 4-view configs) --
+    CosineAnnealingLR(T_max=max_steps, eta_min=0.1 * lr) chained with SequentialLR at the warm-up milestone (:930-935)."""
     new, old = [], []
+    kws = tuple(new_param_keywords or ())
     for name, p in encoder.named_parameters():
         if p.requires_grad:
-            (new if any(k in name for k in new_param_keywords) else old).append(p)
+            (new if any(k in name for k in kws) else old).append(p)
     groups = [dict(params=new, lr=lr), dict(params=old, lr=lr * backbone_lr_multiplier)] if new else [dict(params=old, lr=lr)]
     kw = dict(lr=lr, weight_decay=weight_decay, betas=(0.9, 0.95))
     opt = None
@@ -211,44 +345,157 @@ def configure_optimizer(encoder, lr: float = 4e-5, backbone_lr_multiplier: float
     if opt is None:
         opt = torch.optim.AdamW(groups, **kw)
     sched = torch.optim.lr_scheduler.LinearLR(opt, 1 / warm_up_steps, 1, total_iters=warm_up_steps) if warm_up_steps > 0 else None
+    if lr_cosine_annealing:
+        if max_steps is None:
+            raise ValueError("lr_cosine_annealing needs max_steps (trainer.max_steps of the experiment)")
+        cos = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max_steps, eta_min=lr * 0.1)
+        sched = cos if sched is None else torch.optim.lr_scheduler.SequentialLR(opt, schedulers=[sched, cos], milestones=[warm_up_steps])
     return opt, sched
 
 
-def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, compute_dtype: torch.dtype = torch.float16,
-                  loss_scale: float = 1024.0, clip: float = 0.5, mse_weight: float = 1.0, allreduce: bool = False) -> dict:
-    """One optimisation step of the reference's photometric objective (training_step, model_wrapper.py:184-321, with the MSE
-    loss of loss_mse.py; LPIPS / camera losses need external weights / ground-truth poses and are not part of this harness).
+# ---------------------------------------------------------------------------------------------------------------------------
+# camera (dual-quaternion) loss -- src/loss/loss_camera.py:30-80 with the quaternion algebra of src/misc/dq.py (pypose's SO3 product
+# / inverse restated on xyzw tensors) and pytorch3d's matrix_to_quaternion (restated: the best-conditioned of the four candidates)
+# ---------------------------------------------------------------------------------------------------------------------------
+def quat_mul_xyzw(a: Tensor, b: Tensor) -> Tensor:
+    x1, y1, z1, w1 = a.unbind(-1)
+    x2, y2, z2, w2 = b.unbind(-1)
+    return torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], -1)
 
-    batch: {"context": {"image" [B,V,3,H,W] in [-1,1], "intrinsics" [B,V,3,3]},
+
+def quat_conj_xyzw(q: Tensor) -> Tensor:
+    return q * q.new_tensor([-1.0, -1.0, -1.0, 1.0])
+
+
+def matrix_to_quaternion_wxyz(R: Tensor) -> Tensor:
+    """[...,3,3] rotation -> [...,4] quaternion (real part first), the candidate with the largest denominator of the four
+    square-root forms (what cam_utils.py:200-201 gets from pytorch3d.transforms.matrix_to_quaternion before normalising)."""
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = R.flatten(-2).unbind(-1)
+    q_abs = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], -1)
+    q_abs = torch.where(q_abs > 0, q_abs.clamp_min(0).sqrt(), torch.zeros_like(q_abs))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp_min(0.1))
+    best = q_abs.argmax(-1)
+    return torch.gather(cand, -2, best[..., None, None].expand(*best.shape, 1, 4))[..., 0, :]
+
+
+def camera_dq_array_from_Rt(R: Tensor, t: Tensor) -> Tensor:
+    """(R [...,3,3], t [...,3]) -> dual quaternion [...,8] = (q_r xyzw | q_d xyzw), q_d = 0.5 (t, 0) (x) q_r
+    (cam_utils.py:213-218, dq.py:114-129)."""
+    q = torch.nn.functional.normalize(matrix_to_quaternion_wxyz(R), dim=-1)[..., [1, 2, 3, 0]]
+    q = q / q.norm(dim=-1, keepdim=True)
+    qd = quat_mul_xyzw(0.5 * torch.cat([t, torch.zeros_like(t[..., :1])], -1), q)
+    return torch.cat([q, qd], -1)
+
+
+def dq_mul(a: Tensor, b: Tensor) -> Tensor:
+    """(r1 + e d1)(r2 + e d2) = r1 r2 + e (r1 d2 + d1 r2)   (dq.py:38-41)."""
+    return torch.cat([quat_mul_xyzw(a[..., :4], b[..., :4]),
+                      quat_mul_xyzw(a[..., :4], b[..., 4:]) + quat_mul_xyzw(a[..., 4:], b[..., :4])], -1)
+
+
+def dq_conj(a: Tensor) -> Tensor:
+    return torch.cat([quat_conj_xyzw(a[..., :4]), quat_conj_xyzw(a[..., 4:])], -1)
+
+
+def camera_dq_loss(prediction: Tensor, target: Tensor) -> Tensor:
+    """L1(pred (x) target*, identity) + L1(target (x) pred*, identity)   (loss_camera.py:30-45)."""
+    ident = torch.zeros_like(prediction)
+    ident[..., 3] = 1.0
+    return (dq_mul(prediction, dq_conj(target)) - ident).abs().mean() + (dq_mul(target, dq_conj(prediction)) - ident).abs().mean()
+
+
+def camera_loss(pred_extrins: Tensor, context_extrinsics: Tensor, weight: float = 1.0, use_dq_loss: bool = True) -> Tensor:
+    """LossCamera.forward for camera_type 'dq' without an intrinsics head (loss_camera.py:47-80): pred_extrins [B,V-1,8] against the
+    dual quaternions of the context cameras 1.. (c2w [B,V,4,4], already expressed in frame 0)."""
+    E = context_extrinsics[:, 1:]
+    tgt = camera_dq_array_from_Rt(E[..., :3, :3], E[..., :3, 3])
+    l1 = (pred_extrins - tgt).abs().mean()
+    return weight * ((camera_dq_loss(pred_extrins, tgt) + l1) if use_dq_loss else l1)
+
+
+class LossScaler:
+    """Dynamic loss scale for the 16-bit activation gradients (what torch.amp.GradScaler does for f16): halve on a non-finite
+    gradient norm (that step is skipped), double after `growth_interval` clean steps."""
+
+    def __init__(self, init_scale: float = 1024.0, growth_interval: int = 200, min_scale: float = 1.0, max_scale: float = 65536.0):
+        self.scale, self.growth_interval, self.min_scale, self.max_scale = float(init_scale), growth_interval, min_scale, max_scale
+        self.good = 0
+
+    def update(self, finite: bool) -> None:
+        if finite:
+            self.good += 1
+            if self.good >= self.growth_interval:
+                self.scale, self.good = min(self.scale * 2.0, self.max_scale), 0
+        else:
+            self.scale, self.good = max(self.scale * 0.5, self.min_scale), 0
+
+
+def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, compute_dtype: torch.dtype = torch.float16,
+                  loss_scale: float | LossScaler | None = None, clip: float = 0.5, mse_weight: float = 1.0, camera_weight: float = 0.0,
+                  extra_losses=(), allreduce: bool = False, reducer=None, global_step: int = 0) -> dict:
+    """One optimisation step of the reference's objective (training_step, model_wrapper.py:184-321): MSE (loss_mse.py) + camera
+    dual-quaternion loss (loss_camera.py, `camera_weight` > 0 and batch["context"]["extrinsics"] present) + `extra_losses`
+    (callables (render, batch, out) -> scalar; the reference's LPIPS term needs VGG weights that are not available offline and plugs
+    in here).
+
+    batch: {"context": {"image" [B,V,3,H,W] in [-1,1], "intrinsics" [B,V,3,3], ("extrinsics" [B,V,4,4])},
             "target":  {"image" [B,Vt,3,H,W] in [0,1], "extrinsics", "intrinsics", "near", "far"}}
-    The encoder runs its differentiable HIP forward (train_forward.forward_train), the Gaussians are rendered by the HIP
-    rasterizer, and the backward pass runs on the HIP backward kernels.  `loss_scale` keeps 16-bit activation gradients out
-    of the f16 underflow range (gradients are unscaled before clipping).  allreduce=True averages gradients over
-    torch.distributed ranks with vicasplat_amd.dist.bucketed_allreduce_grads (RCCL over xGMI on a node)."""
+    The encoder runs its differentiable HIP forward (train_forward.forward_train, `global_step` drives the opacity mapping as
+    model_wrapper.py:207), the Gaussians are rendered by the HIP rasterizer, and the backward pass runs on the HIP backward kernels.
+    `loss_scale`: a LossScaler (dynamic; default: one kept on the optimizer), or a fixed float.  f16 needs it for the 16-bit
+    activation gradients; gradients are unscaled before clipping; an overflowed step is skipped, its gradients dropped.
+    Gradient exchange: `reducer` (vicasplat_amd.dist.GradReducer: buckets all-reduced DURING backward, RCCL over xGMI) or
+    allreduce=True (bucketed all-reduce after backward)."""
     from .model.encoder.train_forward import forward_train
     ctx, tgt = batch["context"], batch["target"]
-    optimizer.zero_grad(set_to_none=True)
-    out = forward_train(encoder, ctx["image"], ctx["intrinsics"], compute_dtype)
+    if loss_scale is None:
+        loss_scale = getattr(optimizer, "_vs_loss_scaler", None)
+        if loss_scale is None:
+            loss_scale = optimizer._vs_loss_scaler = LossScaler(1024.0 if compute_dtype == torch.float16 else 1.0)
+    scale = loss_scale.scale if isinstance(loss_scale, LossScaler) else float(loss_scale)
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    out = forward_train(encoder, ctx["image"], ctx["intrinsics"], compute_dtype, global_step=global_step)
     g = out["gaussians"]
     gs = Gaussians(g["means"].flatten(1, 3), g["covariances"].flatten(1, 3), g["harmonics"].flatten(1, 3), g["opacities"].flatten(1))
     h, w = tgt["image"].shape[-2:]
     render = decoder.forward(gs, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
-    loss = mse_loss(render.color, tgt["image"], mse_weight)
-    (loss * loss_scale).backward()
-    params = [p for p in encoder.parameters() if p.grad is not None]
-    if allreduce:
+    parts = dict(mse=mse_loss(render.color, tgt["image"], mse_weight))
+    if camera_weight > 0 and "extrinsics" in ctx:
+        parts["camera"] = camera_loss(out["pred_extrins"], ctx["extrinsics"].float(), camera_weight)
+    for i, fn in enumerate(extra_losses):
+        parts[getattr(fn, "__name__", f"extra{i}")] = fn(render, batch, out)
+    loss = sum(parts.values())
+    (loss * scale).backward()
+    params = [p for p in encoder.parameters() if p.requires_grad]
+    if reducer is not None:
+        reducer.finish()
+    elif allreduce:
         from . import dist as vdist
-        vdist.bucketed_allreduce_grads(params)
-    grads = [p.grad for p in params]
+        vdist.bucketed_allreduce_grads(params)   # all trainable parameters: unused ones are zero-filled so every rank reduces identical buckets
+    grads = [p.grad for p in params if p.grad is not None]
     # unscale and clip in ONE pass over the gradients: norm of the scaled gradients, then a single multiply by
-    # min(1, clip / (norm + 1e-6)) / loss_scale (= torch's clip_grad_norm_ on the unscaled gradients)
-    gnorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads))) / loss_scale
-    torch._foreach_mul_(grads, torch.clamp(clip / (gnorm + 1e-6), max=1.0) / loss_scale)   # a non-finite norm marks an overflowed step ...
+    # min(1, clip / (norm + 1e-6)) / scale (= torch's clip_grad_norm_ on the unscaled gradients)
+    gnorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads))) / scale
     finite = bool(torch.isfinite(gnorm))
-    if finite:                                                # ... which is skipped, as torch.amp's GradScaler would
+    if finite:
+        torch._foreach_mul_(grads, torch.clamp(clip / (gnorm + 1e-6), max=1.0) / scale)
         optimizer.step()
         if scheduler is not None:
             scheduler.step()
+    elif reducer is None:                                     # overflowed step: skipped, as torch.amp's GradScaler would; drop the gradients
+        optimizer.zero_grad(set_to_none=True)
+    if isinstance(loss_scale, LossScaler):
+        loss_scale.update(finite)
     with torch.no_grad():
         psnr = compute_psnr(tgt["image"].flatten(0, 1), render.color.detach().flatten(0, 1)).mean()
-    return dict(loss=loss.detach(), psnr=psnr, grad_norm=gnorm, skipped=not finite, pred_extrins=out["pred_extrins"].detach())
+    return dict(loss=loss.detach(), psnr=psnr, grad_norm=gnorm, skipped=not finite, pred_extrins=out["pred_extrins"].detach(),
+                loss_scale=scale, **{"loss_" + k: v.detach() for k, v in parts.items()})

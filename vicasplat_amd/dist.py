@@ -82,3 +82,103 @@ def bucketed_allreduce_grads(params: Iterable[torch.nn.Parameter], bucket_bytes:
         size += b
     flush()
     return n_coll
+
+
+class GradReducer:
+    """Gradient exchange overlapped with the backward pass (what Lightning's DDP gives the reference, src/main.py:110-115).
+
+    The trainable parameters are laid out, in REVERSE registration order (the order in which backward produces their gradients),
+    in flat f32 buckets; every `p.grad` is a VIEW into its bucket, so autograd accumulates in place and nothing is concatenated
+    or copied back.  A post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its all-reduce is
+    issued asynchronously (RCCL over xGMI runs it on its own stream while the backward kernels continue).  `finish()` launches
+    the buckets that never completed (parameters without a gradient this step -- scratch.refinenet4.resConfUnit1 of both DPT
+    heads, SURVEY 2.2 -- contribute the zeros `zero_grad()` left there, so every rank reduces identical buckets) and waits.
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring collectives are per-link bound, so buckets are large (64 MiB
+    default -> ~36 collectives for the 2.31 GB gradient) rather than DDP's 25 MB.  `comm_dtype=torch.bfloat16` halves the bytes
+    on the links (1.16 GB): the bucket is cast into a staging buffer, reduced, and cast back.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True, group=None,
+                 comm_dtype: torch.dtype | None = None):
+        self.group, self.average, self.comm_dtype = group, average, comm_dtype
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        ps = [p for p in params if p.requires_grad]
+        self.params = ps[::-1]
+        self.buckets: List[dict] = []
+        cur, size = [], 0
+        for p in self.params:
+            b = p.numel() * 4
+            if cur and size + b > bucket_bytes:
+                self._close(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += b
+        if cur:
+            self._close(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._pending: List[tuple] = []
+        self.zero_grad()
+
+    def _close(self, plist):
+        dev = plist[0].device
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buckets.append(dict(params=plist, flat=flat, views=views, ready=0, launched=False,
+                                 stage=torch.empty(n, dtype=self.comm_dtype, device=dev) if self.comm_dtype else None))
+        for i, p in enumerate(plist):
+            p._vs_bucket, p._vs_slot = len(self.buckets) - 1, i
+
+    def zero_grad(self):
+        """Zero the flat buckets and (re)attach every p.grad as a view of its bucket."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["ready"], b["launched"] = 0, False
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+        self._pending = []
+
+    def _launch(self, b):
+        if b["launched"]:
+            return
+        b["launched"] = True
+        if self.world == 1:
+            return
+        buf = b["flat"]
+        if b["stage"] is not None:
+            b["stage"].copy_(buf)
+            buf = b["stage"]
+        self._pending.append((b, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+
+    def _on_grad(self, p):
+        b = self.buckets[p._vs_bucket]
+        v = b["views"][p._vs_slot]
+        if p.grad is not v:      # someone replaced .grad (zero_grad(set_to_none=True)): fold it back
+            v.copy_(p.grad)
+            p.grad = v
+        b["ready"] += 1
+        if b["ready"] == len(b["params"]):
+            self._launch(b)
+
+    def finish(self) -> int:
+        """Issue what is left, wait for every collective, finish the averaging.  Returns the number of collectives of the step."""
+        for b in self.buckets:
+            self._launch(b)
+        n = len(self._pending)
+        for b, work in self._pending:
+            work.wait()
+            if b["stage"] is not None:
+                b["flat"].copy_(b["stage"])
+            if self.average:
+                b["flat"] /= self.world
+        self._pending = []
+        return n
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

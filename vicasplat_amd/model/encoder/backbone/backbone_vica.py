@@ -102,9 +102,9 @@ class VicaNet(nn.Module):
                    use_cross_neighbor_attention=use_cross_neighbor_attention, use_intrinsic_embedding=use_intrinsic_embedding)
         self.config = SimpleNamespace(**cfg)
         if not (use_blocked_causal_attention and use_framewise_modulation and use_cross_neighbor_attention
-                and use_intrinsic_embedding and len(cfg["rope_dim_list"]) == 2):
+                and len(cfg["rope_dim_list"]) == 2):
             raise NotImplementedError("only the configuration of the released experiments is implemented "
-                                      "(config/model/encoder/backbone/vica.yaml + use_intrinsic_embedding=true)")
+                                      "(config/model/encoder/backbone/vica.yaml, use_intrinsic_embedding true or false)")
         if enc_embed_dim % 64 or dec_embed_dim % 64 or enc_embed_dim // enc_num_heads != 64 or dec_embed_dim // dec_num_heads != 64:
             raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
         # attribute fallbacks the heads rely on (dpt_head.py:105-110 reads net.dec_depth / enc_embed_dim / dec_embed_dim)
@@ -117,7 +117,7 @@ class VicaNet(nn.Module):
         self.dec_blocks = nn.ModuleList([_DecBlock(dec_embed_dim, dec_num_heads, mlp_ratio) for _ in range(dec_depth)])
         self.dec_norm = nn.LayerNorm(dec_embed_dim, eps=1e-6)
         self.camera_dec_norm = nn.LayerNorm(dec_embed_dim, eps=1e-6)
-        self.intrinsic_encoder = nn.Linear(9, enc_embed_dim)
+        self.intrinsic_encoder = nn.Linear(9, enc_embed_dim) if use_intrinsic_embedding else None   # backbone_vica.py:392-395
         self.camera_extrinsic_token = nn.Parameter(torch.empty(dec_embed_dim).normal_(std=0.02))
         self.camera_intrinsic_token = nn.Parameter(torch.empty(dec_embed_dim).normal_(std=0.02))
         self.gradient_checkpointing = False
@@ -127,6 +127,8 @@ class VicaNet(nn.Module):
         self._tables: dict = {}
 
     def enable_gradient_checkpointing(self):
+        """Per-block activation checkpointing of the TRAINING forward (train_forward.forward_train reads the flag); the
+        inference forward below keeps nothing, so there is nothing to checkpoint (backbone_vica.py:464-474,504-516)."""
         self.gradient_checkpointing = True
 
     def _init_weights(self):  # backbone_vica.py:427-448 (xavier on every Linear, incl. the AdaLN projections)
@@ -171,19 +173,25 @@ class VicaNet(nn.Module):
         key = (B, T, gh, gw, str(dev))
         if key in self._tables:
             return self._tables[key]
-        n = gh * gw
+        use_intr = self.config.use_intrinsic_embedding
         ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
-        frame = torch.cat([torch.stack([ys, xs], -1).reshape(n, 2), torch.tensor([[gh, 0]])], 0).int()  # intrinsic token at (gh, 0)
-        pos_img = frame.repeat(B * T, 1).contiguous()                              # [B*T*(n+1), 2]
+        frame = torch.stack([ys, xs], -1).reshape(gh * gw, 2)
+        if use_intr:
+            frame = torch.cat([frame, torch.tensor([[gh, 0]])], 0)                 # intrinsic token at (gh, 0) (backbone_vica.py:455-459)
+        frame = frame.int()
+        n1 = frame.shape[0]                                                        # tokens per frame: 257, or 256 without the intrinsic token
+        pos_img = frame.repeat(B * T, 1).contiguous()                              # [B*T*n1, 2]
         # interleaved buffer: row 0 of each frame = camera token (temporal position t), rows 1.. = image tokens
         t_idx = torch.arange(T).repeat(B)
         cam = torch.stack([t_idx, torch.zeros_like(t_idx)], -1).int()[:, None]     # [B*T,1,2]
         pos_mix = torch.cat([cam, frame[None].expand(B * T, -1, -1)], 1).reshape(-1, 2).contiguous()
-        kind = torch.zeros(B * T, n + 2, dtype=torch.uint8)
+        kind = torch.zeros(B * T, n1 + 1, dtype=torch.uint8)
         kind[:, 0] = 1
-        L = T * (n + 2)
-        kvlen = torch.full((B, T, n + 2), L, dtype=torch.int32)
-        kvlen[:, :, 0] = (torch.arange(T, dtype=torch.int32) + 1)[None] * (n + 2)  # camera query t sees frames <= t
+        L = T * (n1 + 1)
+        kvlen = torch.full((B, T, n1 + 1), L, dtype=torch.int32)
+        kvlen[:, :, 0] = (torch.arange(T, dtype=torch.int32) + 1)[None] * (n1 + 1)  # camera query t sees frames <= t
+        if not use_intr:
+            kvlen[:, 0, 0] = L     # without the intrinsic embedding camera token 0 has global scope (backbone_vica.py:589-590)
         if T == 2:
             nb = [[1], [0]]
         else:
@@ -191,7 +199,7 @@ class VicaNet(nn.Module):
         seg = []
         for b in range(B):
             for t in range(T):
-                s = [((b * T + j) * (n + 1), n + 1) for j in nb[t]]
+                s = [((b * T + j) * n1, n1) for j in nb[t]]
                 seg.append([s[0][0], s[0][1], s[1][0] if len(s) > 1 else 0, s[1][1] if len(s) > 1 else 0])
         tabs = dict(pos_img=pos_img.to(dev), pos_mix=pos_mix.to(dev), kind_mix=kind.reshape(-1).contiguous().to(dev),
                     kvlen=kvlen.reshape(-1).contiguous().to(dev), seg=torch.tensor(seg, dtype=torch.int32).to(dev))
@@ -206,12 +214,14 @@ class VicaNet(nn.Module):
         (only hooks 0, L/2, 3L/4, L -- the ones the DPT heads read -- are materialised; the others are None)."""
         if not x.is_cuda:
             raise RuntimeError("VicaNet.forward needs HIP device tensors: vicasplat_amd has no CPU fallback path")
-        assert intrinsics is not None, "use_intrinsic_embedding=True needs intrinsics"
         B, _, T, H, Wd = x.shape
         cfg, dt, dev = self.config, self.compute_dtype, x.device
+        use_intr = cfg.use_intrinsic_embedding
+        assert intrinsics is not None or not use_intr, "use_intrinsic_embedding=True needs intrinsics"
         p = cfg.patch_size
         gh, gw = H // p, Wd // p
-        n, N = gh * gw, gh * gw + 1
+        n = gh * gw
+        N = n + (1 if use_intr else 0)
         BT = B * T
         Ce, Cd, He, Hd = cfg.enc_embed_dim, cfg.dec_embed_dim, cfg.enc_num_heads, cfg.dec_num_heads
         W = self._weights16()
@@ -224,7 +234,8 @@ class VicaNet(nn.Module):
         cols = frames.permute(0, 2, 4, 1, 3, 5).reshape(BT * n, 3 * p * p).to(dt)
         xe = torch.empty(BT * N, Ce, **f32)
         ops.gemm(cols, W["patch"], self.patch_embed.proj.bias, xe, ops.EPI_STORE32, grp_in=n, grp_out=N, grp_off=0)
-        xe.view(BT, N, Ce)[:, n] = F.linear(intrinsics.reshape(BT, 9).float(), self.intrinsic_encoder.weight, self.intrinsic_encoder.bias)
+        if use_intr:
+            xe.view(BT, N, Ce)[:, n] = F.linear(intrinsics.reshape(BT, 9).float(), self.intrinsic_encoder.weight, self.intrinsic_encoder.bias)
 
         # ---- 24 encoder blocks (blocks.py:94-130) ----
         h = torch.empty(BT * N, Ce, **f16)
@@ -302,4 +313,4 @@ class VicaNet(nn.Module):
         camn = torch.empty(BT, Cd, **f32)
         ops.layernorm_mod(cam, self.camera_dec_norm.weight, self.camera_dec_norm.bias, camn)
         camera = camn.view(B, T, Cd)
-        return inter[-1], camera[:, 1:], None, inter
+        return inter[-1], camera[:, 1:], (None if use_intr else camera[:, 0]), inter

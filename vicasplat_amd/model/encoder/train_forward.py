@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
+import torch.utils.checkpoint
 
 from ... import autograd as A
 
@@ -37,9 +38,12 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     p = cfg.patch_size
     gh, gw = H // p, Wd // p
     n = gh * gw
-    N1 = n + 1
+    use_intr = cfg.use_intrinsic_embedding
+    N1 = n + (1 if use_intr else 0)          # tokens per frame (the intrinsic token rides behind the patches, backbone_vica.py:455-459)
     BT = B * V
     tabs = model.backbone._pos_tables(B, V, gh, gw, dev)
+    # per-block activation checkpointing (backbone_vica.py:464-474,504-516): enable_gradient_checkpointing() on the encoder
+    ckpt = bool(getattr(model.backbone, "gradient_checkpointing", False)) and torch.is_grad_enabled()
     lin = lambda name, x: A.linear(x, P[name + ".weight"], P.get(name + ".bias"), dt)
     lnm = lambda name, x, **k: A.layernorm_mod(x, P[name + ".weight"], P[name + ".bias"], eps=LN_EPS, **k)
 
@@ -48,15 +52,16 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     cols = frames.reshape(BT, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(BT, n, 3 * p * p)   # conv(k=s=16) as a GEMM
     Ce = cfg.enc_embed_dim
     x = A.linear(cols, P["backbone.patch_embed.proj.weight"].flatten(1), P["backbone.patch_embed.proj.bias"], dt).float()
-    intr = _lin_f32(P, "backbone.intrinsic_encoder", intrinsics.reshape(BT, 1, 9).float())
-    x = torch.cat([x, intr], 1)                                                                     # [BT, N1, Ce] f32 stream
+    if use_intr:
+        intr = _lin_f32(P, "backbone.intrinsic_encoder", intrinsics.reshape(BT, 1, 9).float())
+        x = torch.cat([x, intr], 1)                                                                 # [BT, N1, Ce] f32 stream
     He = cfg.enc_num_heads
     x = x.reshape(BT * N1, Ce)
     for i in range(cfg.enc_depth):          # one autograd node per block: LN / qkv+RoPE / attention / proj / LN / fc1 / GELU / fc2
         nm = f"backbone.enc_blocks.{i}"
         names = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                  "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
-        x = A.EncBlockFn.apply(x, tabs["pos_img"], BT, N1, He, dt, *[P[f"{nm}.{k}"] for k in names])
+        x = A.EncBlockFn.apply(x, tabs["pos_img"], BT, N1, He, dt, ckpt, *[P[f"{nm}.{k}"] for k in names])
     x = lnm("backbone.enc_norm", x.view(BT, N1, Ce), out_dtype=torch.float32)
 
     # ---------------- video / camera decoder (backbone_vica.py:482-524, block :280-335) ----------------
@@ -69,7 +74,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     cam = torch.cat([ti.expand(B, 1, C), (ti + te).expand(B, T - 1, C)], 1)                          # [B,T,C] f32
     theta = float(cfg.temporal_rope_theta)
     M2 = N1 + 1
-    for i in range(cfg.dec_depth):
+    def dec_block(i, x, cam):
         # the elementwise work of the image stream lives in the HIP kernels: LayerNorm + AdaLN writes its rows straight behind
         # each frame's camera-token row, and every residual update x + (1 + gate) * branch is one gated_resid pass
         nm = f"backbone.dec_blocks.{i}"
@@ -96,10 +101,17 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
         x = A.gated_resid(x, lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", himg))), g3.reshape(BT, C), N1)
         cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
+        return x, cam
+
+    for i in range(cfg.dec_depth):
+        if ckpt:      # keep only the block's inputs (x, cam); its Functions re-run in the backward (deterministic kernels)
+            x, cam = torch.utils.checkpoint.checkpoint(dec_block, i, x, cam, use_reentrant=False)
+        else:
+            x, cam = dec_block(i, x, cam)
         inter.append(x.view(BT, N1, C))
     inter[-1] = lnm("backbone.dec_norm", inter[-1], out_dtype=torch.float32)
     cam = _ln_f32(P, "backbone.camera_dec_norm", cam)
-    inter = [t[:, :-1] for t in inter]                                                                # drop the intrinsic token (:570-572)
+    inter = [t[:, :n] for t in inter]                                                                 # drop the intrinsic token (:570-572)
 
     # ---------------- pose head (vicasplat.py:179-199; misc/dq.py:224-262), f32 ----------------
     d = _lin_f32(P, "camera_extrinsic_head.1", F.relu(cam[:, 1:]))
@@ -181,4 +193,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     un = lambda u: u.unflatten(0, (B, V))
     raw = un(raw)
     gaussians = dict(means=un(means), covariances=un(cov), harmonics=un(sh), opacities=un(op))
-    return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, camera_tokens=cam)
+    pred_intrins = None
+    if not use_intr:
+        pred_intrins = _lin_f32(P, "camera_intrinsic_head.1", F.relu(cam[:, 0]))                      # fov head (vicasplat.py:201-205)
+    return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, camera_tokens=cam, pred_intrins=pred_intrins)

@@ -85,7 +85,12 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         self.camera_extrinsic_head = nn.Sequential(nn.ReLU(), nn.Linear(self.backbone.config.dec_embed_dim, 8))
         nn.init.zeros_(self.camera_extrinsic_head[1].weight)  # predicts the identity pose at init (vicasplat.py:126-127)
         nn.init.zeros_(self.camera_extrinsic_head[1].bias)
-        self.camera_intrinsic_head = None
+        if self.backbone.config.use_intrinsic_embedding:
+            self.camera_intrinsic_head = None
+        else:   # the *_no_intrin checkpoints: fov head on camera token 0, initialised to 50 degrees (vicasplat.py:79-82,129-138)
+            self.camera_intrinsic_head = nn.Sequential(nn.ReLU(), nn.Linear(self.backbone.config.dec_embed_dim, 2))
+            nn.init.zeros_(self.camera_intrinsic_head[1].weight)
+            nn.init.constant_(self.camera_intrinsic_head[1].bias, math.pi * 50 / 180)
         self.set_compute_dtype(compute_dtype)
         if device is not None or weight_dtype is not None:
             self.to(device=device, dtype=weight_dtype)
@@ -120,12 +125,19 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         pred_extrins = pred / pred[..., :4].norm(dim=-1, keepdim=True)
         eye = torch.eye(4, device=dev, dtype=pred_extrins.dtype).expand(B, 1, 4, 4)
         pred_extrinsics_4x4 = torch.cat([eye, camera_matrix_from_dq_array(pred_extrins)], dim=1)
+        pred_intrins = pred_K = None
+        if _global is not None:      # no intrinsic embedding: predict the field of view -> pinhole K (vicasplat.py:201-205, cam_utils.py:220-234)
+            pred_intrins = self.camera_intrinsic_head(_global)
+            pred_K = torch.eye(3, device=dev, dtype=torch.float32).repeat(B, 1, 1)
+            pred_K[:, 0, 0], pred_K[:, 1, 1] = 0.5 / torch.tan(pred_intrins[:, 0] * 0.5), 0.5 / torch.tan(pred_intrins[:, 1] * 0.5)
+            pred_K[:, 0, 2] = pred_K[:, 1, 2] = 0.5
+            pred_K = pred_K[:, None].repeat(1, T, 1, 1)
 
         tokens = [None if t is None else t.flatten(0, 1) for t in interms]
         if distill:
             gs_centers = self.downstream_head1.forward_pts3d(tokens, gh, gw).unflatten(0, (B, T))
-            return dict(pred_extrins=pred_extrins, pred_intrins=None, gaussian_camera_extrins=pred_extrinsics_4x4,
-                        gaussian_camera_intrins=None, gaussian_centers=gs_centers, confidence=None,
+            return dict(pred_extrins=pred_extrins, pred_intrins=pred_intrins, gaussian_camera_extrins=pred_extrinsics_4x4,
+                        gaussian_camera_intrins=pred_K, gaussian_centers=gs_centers, confidence=None,
                         context_view_depths=self._viewspace_depth(context, gs_centers) if compute_viewspace_depth else None)
         # heads -> ONE fused kernel: 'exp' depth post-process + raw_gaussians concat + Gaussian adapter
         pts_raw = self.downstream_head1.forward_pts3d_raw(tokens, gh, gw)
@@ -145,8 +157,8 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         viewspace_depth = self._viewspace_depth(context, gs_centers) if compute_viewspace_depth else None
         if visualization_dump is not None:
             visualization_dump["depth"] = gaussians.means[..., -1:]
-        return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=None, raw_gaussians=raw_gaussians,
-                    gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=None, gaussian_centers=gs_centers,
+        return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=pred_intrins, raw_gaussians=raw_gaussians,
+                    gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=pred_K, gaussian_centers=gs_centers,
                     confidence=None, context_view_depths=viewspace_depth)
 
     @staticmethod
