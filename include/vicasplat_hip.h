@@ -131,6 +131,12 @@ int vs_rope2d(void *tokens, const int64_t *pos, int32_t B, int32_t N, int32_t H,
  * ViT block operators (replace nn.LayerNorm / nn.Linear / softmax attention / F.scaled_dot_product_attention on the
  * encoder path: croco/blocks.py:73-130, backbone_vica.py:76-126,152-191,268-335).  dtype: 1 = f16, 2 = bf16 operands;
  * accumulation, LayerNorm, softmax and the residual stream are f32.
+ * dtype 3 = f32 operands -- the reference-precision path (the reference stores fp32 and multiplies in TF32,
+ * backbone_vica.py:9; gfx950 has no TF32, so the parity path is exact f32 on v_mfma_f32_16x16x4_f32 at 1/16 of the
+ * 16-bit matrix rate): accepted by vs_gemm_bias_act / vs_gemm_resid / vs_gemm_qkv_rope (K % 32 == 0, lda/ldw % 4 == 0),
+ * vs_attention(_lse), vs_conv3x3_nhwc (Cin % 16 == 0) and vs_upsample2x_nhwc.  A, W, activations and EVERY output that is
+ * "16-bit" for dtype 1/2 (epilogues 0, 1, the RoPE epilogue, attention / convolution / upsample outputs, residuals) are
+ * float arrays then; strides stay in elements.
  * ------------------------------------------------------------------------------------------------ */
 
 /* y = LN(x; w, b, eps) [* (1 + scale[row / mod_rows]) + shift[row / mod_rows]].  x f32 [M,C] (row stride ldx);

@@ -40,12 +40,18 @@ def scene_from_gaussians(g: dict, E, K, near, far, scene: int = 0) -> dict:
 
 
 def oracle_chain(W: dict, cfg: dict, image: torch.Tensor, intrinsics: torch.Tensor, E, K, near, far, res: int = 256,
-                 dtype=torch.float32):
-    """image [1,V,3,H,W], intrinsics [1,V,3,3] -> (encoder output dict, list of per-view rasterizer dicts)."""
+                 dtype=torch.float32, operand_mantissa_bits=None):
+    """image [1,V,3,H,W], intrinsics [1,V,3,3] -> (encoder output dict, list of per-view rasterizer dicts).
+    operand_mantissa_bits = 10 emulates the reference's CUDA precision (f32 storage, TF32 matmul / conv operands,
+    encoder_ref.operand_rounding); the rasterizer is f32 either way."""
     if dtype == torch.float64:
         W = {k: v.double() for k, v in W.items()}
         image, intrinsics = image.double(), intrinsics.double()
-    out = er.forward(W, cfg, image, intrinsics)
+    if operand_mantissa_bits is not None:
+        with er.operand_rounding(operand_mantissa_bits):
+            out = er.forward(W, cfg, image, intrinsics)
+    else:
+        out = er.forward(W, cfg, image, intrinsics)
     sc = scene_from_gaussians(out["gaussians"], E, K, near, far)
     return out, rr.render_views(sc, res=res), sc
 

@@ -30,8 +30,40 @@ def default_cfg(**over) -> dict:
 # ---------------------------------------------------------------------------------------------------------
 # primitives
 # ---------------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------------
+# operand-rounding emulation of the reference's CUDA precision (test infrastructure)
+# ---------------------------------------------------------------------------------------------------------
+# The reference runs fp32 storage with TF32 matmuls on its GPU (backbone_vica.py:9: torch.backends.cuda.matmul.allow_tf32 = True;
+# cudnn convolutions use TF32 by default): every matmul / convolution operand is rounded to a 10-bit mantissa, products accumulate
+# in f32.  `operand_rounding(10)` reproduces that on the CPU oracle by rounding the operands of every linear, convolution and
+# attention matmul (round-to-nearest-even on the f32 bit pattern), so the tests can state what the REFERENCE'S OWN CUDA PATH is
+# worth against its f32/f64 evaluation on the same scene -- the yardstick for the 16-bit-operand HIP path.
+_ROUND_BITS = None
+
+
+class operand_rounding:
+    def __init__(self, mantissa_bits):
+        self.bits = mantissa_bits
+
+    def __enter__(self):
+        global _ROUND_BITS
+        self.prev, _ROUND_BITS = _ROUND_BITS, self.bits
+
+    def __exit__(self, *a):
+        global _ROUND_BITS
+        _ROUND_BITS = self.prev
+
+
+def _r(x):
+    if _ROUND_BITS is None or x is None or x.dtype != torch.float32:
+        return x
+    sh = 23 - _ROUND_BITS
+    i = x.contiguous().view(torch.int32)
+    return ((i + (((i >> sh) & 1) + ((1 << (sh - 1)) - 1))) >> sh << sh).view(torch.float32)
+
+
 def lin(W, name, x):
-    return F.linear(x, W[name + ".weight"], W.get(name + ".bias"))
+    return F.linear(_r(x), _r(W[name + ".weight"]), W.get(name + ".bias"))
 
 
 def ln(W, name, x):
@@ -68,10 +100,10 @@ def rope1d_interleaved(x: torch.Tensor, theta: float) -> torch.Tensor:
 
 def sdpa(q, k, v, mask: Optional[torch.Tensor] = None):
     """softmax(q k^T / sqrt(d)) v, explicit (croco/blocks.py:106-110; F.scaled_dot_product_attention default scale)."""
-    att = (q @ k.transpose(-2, -1)) * (q.shape[-1] ** -0.5)
+    att = (_r(q) @ _r(k).transpose(-2, -1)) * (q.shape[-1] ** -0.5)
     if mask is not None:
         att = att.masked_fill(~mask, float("-inf"))
-    return att.softmax(-1) @ v
+    return _r(att.softmax(-1)) @ _r(v)
 
 
 def mlp(W, name, x):
@@ -101,7 +133,7 @@ def encode_frames(W, cfg, frames, intr_tok):
     """frames [BT,3,H,W] (already normalised), intr_tok [BT,1,C] -> tokens [BT,N+1,C], pos [BT,N+1,2]; intr_tok None
     (use_intrinsic_embedding=false, the *_no_intrin checkpoints): N tokens, no extra position."""
     p = cfg["patch_size"]
-    x = F.conv2d(frames, W["backbone.patch_embed.proj.weight"], W["backbone.patch_embed.proj.bias"], stride=p)
+    x = F.conv2d(_r(frames), _r(W["backbone.patch_embed.proj.weight"]), W["backbone.patch_embed.proj.bias"], stride=p)
     BT, C, gh, gw = x.shape
     x = x.flatten(2).transpose(1, 2)
     pos = patch_positions(BT, gh, gw)
@@ -202,7 +234,7 @@ def decoder(W, cfg, x, pos):
 # DPT heads  (heads/dpt_block.py:79-218,264-419; heads/dpt_head.py:35-70; heads/dpt_gs_head.py:120-157)
 # ---------------------------------------------------------------------------------------------------------
 def conv(W, name, x, stride=1, padding=0):
-    return F.conv2d(x, W[name + ".weight"], W.get(name + ".bias"), stride=stride, padding=padding)
+    return F.conv2d(_r(x), _r(W[name + ".weight"]), W.get(name + ".bias"), stride=stride, padding=padding)
 
 
 def up2(x):
@@ -228,12 +260,12 @@ def dpt_trunk(W, pre, cfg, inter, gh, gw):
     hooks = [0, L * 2 // 4, L * 3 // 4, L]
     maps = [inter[h].transpose(1, 2).reshape(inter[h].shape[0], -1, gh, gw) for h in hooks]
     a = pre + ".act_postprocess"
-    l0 = F.conv_transpose2d(conv(W, a + ".0.0", maps[0]), W[a + ".0.1.weight"], W[a + ".0.1.bias"], stride=4)
-    l1 = F.conv_transpose2d(conv(W, a + ".1.0", maps[1]), W[a + ".1.1.weight"], W[a + ".1.1.bias"], stride=2)
+    l0 = F.conv_transpose2d(_r(conv(W, a + ".0.0", maps[0])), _r(W[a + ".0.1.weight"]), W[a + ".0.1.bias"], stride=4)
+    l1 = F.conv_transpose2d(_r(conv(W, a + ".1.0", maps[1])), _r(W[a + ".1.1.weight"]), W[a + ".1.1.bias"], stride=2)
     l2 = conv(W, a + ".2.0", maps[2])
     l3 = conv(W, a + ".3.1", conv(W, a + ".3.0", maps[3]), stride=2, padding=1)
     s = pre + ".scratch"
-    l0, l1, l2, l3 = [F.conv2d(l, W[f"{s}.layer_rn.{i}.weight"], None, padding=1) for i, l in enumerate((l0, l1, l2, l3))]
+    l0, l1, l2, l3 = [F.conv2d(_r(l), _r(W[f"{s}.layer_rn.{i}.weight"]), None, padding=1) for i, l in enumerate((l0, l1, l2, l3))]
     p4 = fusion(W, s + ".refinenet4", l3)[:, :, :l2.shape[2], :l2.shape[3]]
     p3 = fusion(W, s + ".refinenet3", p4, l2)
     p2 = fusion(W, s + ".refinenet2", p3, l1)
@@ -255,7 +287,7 @@ def gs_head(W, cfg, inter, frames, gh, gw):
     """gaussian_param_head: trunk -> x2 -> + ReLU(conv7(image)) -> conv3 -> ReLU -> conv1.  -> [BT,83,H,W]."""
     pre = "gaussian_param_head.dpt"
     x = up2(dpt_trunk(W, pre, cfg, inter, gh, gw)) + F.relu(conv(W, pre + ".input_merger.0", frames, padding=3))
-    x = F.relu(F.conv2d(x, W[pre + ".head.0.weight"], None, padding=1))
+    x = F.relu(F.conv2d(_r(x), _r(W[pre + ".head.0.weight"]), None, padding=1))
     return conv(W, pre + ".head.4", x)
 
 

@@ -1,0 +1,246 @@
+"""The reference-precision path (compute dtype f32: fp32 weights AND activations on the exact-f32 MFMA) -- the fp32-class
+parity mode VERDICT r1 asked for (the reference stores fp32 and multiplies in TF32, backbone_vica.py:9; SURVEY 7-5: "parity path =
+fp32 MFMA ... report both").  -m gpu.
+
+  * operator level: GEMM (every epilogue, row maps, small-M and 128x128 routes), packed qkv + RoPE, attention (prefix mask, key
+    segments), 3x3 convolution (both kernels, ReLU-in / bias / residual / ReLU-out, stride 2) and bilinear x2 against float64 torch
+    on the SAME f32 inputs: only the f32 summation order differs (<= 2e-6 of the output scale);
+  * encoder level: against the real reference's float64 goldens <= 2e-4 (the reference's own f32 run differs from its f64 run by 4e-5);
+  * end to end: HIP encoder[f32] -> HIP rasterizer against the oracle chain (f32 and f64): PSNR >= 60 dB (f32 vs f64 oracle: 76 dB;
+    any TF32-class path, the reference's CUDA run included: 19-20 dB, tests/test_chain_cpu.py).
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import chain
+from oracle import encoder_ref as er
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(2056, 3072, 1024), (257, 1024, 4096), (100, 768, 768), (16, 2304, 768), (1, 128, 64), (300, 144, 160),
+                                   (513, 83, 256), (4112, 1024, 96)])
+def test_gemm_f32_epilogues(M, N, K):
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) + 0.1 * torch.arange(K).float() / K).to(d)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) + 0.05 * torch.arange(N).float()[:, None] / N).to(d)
+    bias = torch.randn(N, generator=g).to(d)
+    ref = a.double() @ w.double().t() + bias.double()
+    out = torch.empty(M, N, device=d)
+    ops.gemm(a, w, bias, out, ops.EPI_STORE16)
+    assert _rel(out, ref) <= 2e-6
+    ops.gemm(a, w, bias, out, ops.EPI_GELU16)
+    assert _rel(out, F.gelu(ref)) <= 2e-6
+    ops.gemm(a, w, None, out, ops.EPI_STORE32)
+    assert _rel(out, a.double() @ w.double().t()) <= 2e-6
+    x0 = torch.randn(M, N, generator=g).to(d)
+    gi = max(1, M // 3)
+    gate = torch.randn((M + gi - 1) // gi, N, generator=g).to(d) * 0.3
+    x = x0.clone()
+    ops.gemm(a, w, bias, x, ops.EPI_RESID32, gate=gate, gate_rows=gi)
+    rows = torch.arange(M, device=d)
+    assert _rel(x, x0.double() + (1 + gate.double()[rows // gi]) * ref) <= 2e-6
+    y = ops.gemm_resid(a, w, bias, x0)
+    assert _rel(y, x0.double() + ref) <= 2e-6
+    # row maps: read every gi rows out of gi + 1, write behind one extra row per group
+    if M >= 8:
+        G_ = M // gi
+        big = torch.randn(G_ * (gi + 1), K, generator=g).to(d)
+        out2 = torch.zeros(G_ * (gi + 2), N, device=d)
+        ops.gemm(big, w, bias, out2, ops.EPI_STORE16, M=G_ * gi, a_grp_in=gi, a_grp_out=gi + 1, a_grp_off=1, grp_in=gi, grp_out=gi + 2, grp_off=2)
+        r = torch.arange(G_ * gi, device=d)
+        src = big[(r // gi) * (gi + 1) + 1 + r % gi]
+        got = out2[(r // gi) * (gi + 2) + 2 + r % gi]
+        assert _rel(got, src.double() @ w.double().t() + bias.double()) <= 2e-6
+        assert float(out2[0].abs().max()) == 0 and float(out2[1].abs().max()) == 0
+
+
+def test_gemm_qkv_rope_f32():
+    """Packed q | k | v projection with the rotary embedding in the epilogue, f32 operands: 2-D image rows, 1-D temporal camera rows,
+    rows without a rotation, untouched v (same construction as tests/test_ops_gpu.py::test_gemm_qkv_rope_fused)."""
+    from tests.test_ops_gpu import _rope1d_ref, _rope2d_ref
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    frames, H, K = 5, 4, 256
+    rows, C = frames * 258, H * 64
+    a = torch.randn(rows, K, generator=g).to(d)
+    w = (torch.randn(3 * C, K, generator=g) / math.sqrt(K)).to(d)
+    bias = torch.randn(3 * C, generator=g).to(d)
+    kind = torch.zeros(rows, dtype=torch.uint8, device=d)
+    pos = torch.zeros(rows, 2, dtype=torch.int32, device=d)
+    n = torch.arange(rows, device=d) % 258
+    kind[n == 0] = 1
+    pos[n == 0, 0] = (torch.arange(rows, device=d) // 258)[n == 0].int() % 8
+    img = n > 0
+    pos[img, 0] = ((n[img] - 1) // 16).int()
+    pos[img, 1] = ((n[img] - 1) % 16).int()
+    pos[n == 257] = torch.tensor([16, 0], dtype=torch.int32, device=d)
+    kind[n == 5] = 2
+    ref = (a.double() @ w.double().t() + bias.double()).float().reshape(rows, 3, H, 64)
+    exp = ref.clone()
+    for blk in (0, 1):
+        x = ref[:, blk]
+        r2, r1 = _rope2d_ref(x, pos, 100.0), _rope1d_ref(x, pos[:, 0], 30.0)
+        exp[:, blk] = torch.where((kind == 1)[:, None, None], r1, torch.where((kind == 2)[:, None, None], x, r2))
+    out = torch.empty(rows, 3 * C, device=d)
+    ops.gemm_qkv_rope(a, w, bias, out, C, pos, kind, 100.0, 30.0)
+    # (the rotation uses the hardware v_sin / v_cos: ~1e-6 absolute on the unit circle)
+    assert float((out.reshape(rows, 3, H, 64) - exp).abs().max()) <= 2e-5 * float(exp.abs().max())
+
+
+def _attn_ref(q, k, v, lens=None):
+    s = (q.double() @ k.double().transpose(-1, -2)) * 0.125
+    if lens is not None:
+        j = torch.arange(k.shape[-2])
+        s = s.masked_fill(j[None, None, None, :] >= lens[:, None, :, None], float("-inf"))
+    return s.softmax(-1) @ v.double()
+
+
+def test_attention_f32_plain_prefix_mask_and_segments():
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(5)
+    nb, H, L = 3, 4, 257
+    C = H * 64
+    qkv = torch.randn(nb * L, 3 * C, generator=g).to(d)
+    out = torch.empty(nb * L, C, device=d)
+    lse = torch.empty(nb * L, H, device=d)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, nbatch=nb, H=H, Lq=L, Lk=L, q_batch_rows=L, k_batch_rows=L, lse=lse)
+    t = qkv.cpu().reshape(nb, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = _attn_ref(t[0], t[1], t[2]).permute(0, 2, 1, 3).reshape(nb * L, C)
+    assert _rel(out.cpu(), ref) <= 3e-6
+    s = (t[0].double() @ t[1].double().transpose(-1, -2)) * 0.125
+    lse_ref = (torch.logsumexp(s, -1) / math.log(2)).permute(0, 2, 1).reshape(nb * L, H)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) <= 1e-4
+    # per-query key-prefix lengths (the camera-token rows of the video attention)
+    lens = torch.randint(1, L + 1, (nb, L), generator=g)
+    lens[:, ::5] = L
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, nbatch=nb, H=H, Lq=L, Lk=L, q_batch_rows=L, k_batch_rows=L,
+                  q_kvlen=lens.int().reshape(-1).contiguous().to(d))
+    ref = _attn_ref(t[0], t[1], t[2], lens).permute(0, 2, 1, 3).reshape(nb * L, C)
+    assert _rel(out.cpu(), ref) <= 3e-6
+    # key segments: batch item b attends the rows of items (b-1, b+1) (cross-neighbour attention)
+    seg = torch.tensor([[L, L, L, L], [0, L, 2 * L, L], [L, L, L, L]], dtype=torch.int32).to(d)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, nbatch=nb, H=H, Lq=L, q_batch_rows=L, kv_seg=seg)
+    nbr = [[1, 1], [0, 2], [1, 1]]
+    kk = torch.stack([torch.cat([t[1][j] for j in nbr[b]], 1) for b in range(nb)])
+    vv = torch.stack([torch.cat([t[2][j] for j in nbr[b]], 1) for b in range(nb)])
+    ref = _attn_ref(t[0], kk, vv).permute(0, 2, 1, 3).reshape(nb * L, C)
+    assert _rel(out.cpu(), ref) <= 3e-6
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 64, 64, 256, 256, 1), (1, 32, 48, 128, 128, 1), (2, 16, 16, 192, 256, 1), (1, 33, 20, 768, 64, 2),
+                                                   (3, 40, 24, 64, 83, 1)])
+def test_conv3x3_f32(N, H, W, Cin, Cout, stride):
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(N + H + Cin + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(d)
+    b = torch.randn(Cout, generator=g).to(d)
+    wp = ops.pack_conv3x3_weight(w, torch.float32)
+    xn = x.permute(0, 3, 1, 2).double()
+    y = ops.conv3x3_nhwc(x, wp, b, stride=stride)
+    ref = F.conv2d(xn, w.double(), b.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    assert y.dtype == torch.float32 and _rel(y, ref) <= 2e-6
+    if stride == 1:
+        res = torch.randn(N, H, W, Cout, generator=g).to(d)
+        y = ops.conv3x3_nhwc(x, wp, b, residual=res, relu_in=True)
+        ref = F.conv2d(F.relu(xn), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+        assert _rel(y, ref) <= 2e-6
+        y = ops.conv3x3_nhwc(x, wp, None, relu_out=True)
+        assert _rel(y, F.relu(F.conv2d(xn, w.double(), None, padding=1)).permute(0, 2, 3, 1)) <= 2e-6
+
+
+def test_upsample2x_f32():
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 9, 13, 64, generator=g).to(d)
+    add = torch.randn(2, 18, 26, 64, generator=g).to(d)
+    ref = F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert _rel(ops.upsample2x_nhwc(x), ref) <= 2e-6
+    assert _rel(ops.upsample2x_nhwc(x, add=add, relu_add=True), ref + F.relu(add.double())) <= 2e-6
+
+
+def _model(kind):
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))
+    m, _ = get_encoder(default_cfg(**(TINY if kind == "tiny" else {})))
+    W = er.golden_weights(shapes, seed=0)
+    m.load_state_dict(W, strict=True)
+    m = m.cuda().eval()
+    m.set_compute_dtype("f32")
+    return m, W
+
+
+@pytest.mark.parametrize("name", ["tiny_v2", "tiny_v3", "full_v2", "full_v8"])
+def test_encoder_f32_matches_reference_f64_goldens(name):
+    """encoder vs the real reference's float64 outputs <= 2e-4 of each quantity's range (the reference's own f32
+    run sits at 4e-5)."""
+    z = np.load(os.path.join(G, f"encoder_{name}.npz"))
+    m, _ = _model("tiny" if name.startswith("tiny") else "full")
+    B, V = int(z["cfg_B"]), int(z["cfg_V"])
+    img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    out = m(dict(image=img.cuda(), intrinsics=K.cuda()), compute_viewspace_depth=False)
+    torch.cuda.synchronize()
+    LAT = slice(8, 256, 16)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max() / (np.abs(b).max() + 1e-12))
+    errs = dict(pose=rel(out["pred_extrins"].cpu(), z["f64_pred_extrins"]), c2w=rel(out["gaussian_camera_extrins"].cpu(), z["f64_c2w"]))
+    raw = out["raw_gaussians"][:, :, LAT, LAT].cpu().numpy()
+    for nm, sl in (("xyz", slice(0, 3)), ("opacity", slice(3, 4)), ("scale", slice(4, 7)), ("quat", slice(7, 11)), ("sh", slice(11, 86))):
+        errs[nm] = rel(raw[..., sl], z["f64_raw"][..., sl])
+    g = out["gaussians"]
+    for k in ("means", "covariances", "harmonics", "opacities"):
+        errs["g_" + k] = rel(getattr(g, k)[:, :, LAT, LAT].cpu().numpy(), z[f"f64_{k}"])
+    ref32 = float(np.abs(z["f32_raw"] - z["f64_raw"]).max() / np.abs(z["f64_raw"]).max())
+    print(name, "f32 path vs reference f64:", {k: f"{v:.1e}" for k, v in errs.items()}, f"[reference f32 vs f64 raw: {ref32:.1e}]")
+    assert max(errs.values()) <= 2e-4, errs
+
+
+@pytest.mark.parametrize("V,Vt", [(2, 4), (8, 12)])
+def test_end_to_end_f32_render_matches_the_oracle_chain(V, Vt):
+    from vicasplat_amd.model.decoder.cuda_splatting import camera_matrices
+    from vicasplat_amd.raster import forward_debug
+    d = _dev()
+    m, W = _model("full")
+    img, K = er.synthetic_input(1, V, 256, 0)
+    E, Kt, near, far = chain.config1_targets(Vt, 0.25 if Vt <= 4 else 0.05)
+    out = m(dict(image=img.to(d), intrinsics=K.to(d)), compute_viewspace_depth=False)
+    g = out["gaussians"]
+    T = lambda a: torch.as_tensor(a, dtype=torch.float32, device=d)
+    view_t, full_t, _p, campos, tanfov = camera_matrices(T(E), T(Kt), T(near), T(far))
+    r = forward_debug(g.means.flatten(1, 3)[:1], g.covariances.flatten(1, 3)[:1], g.opacities.flatten(1)[:1], view_t, full_t, campos, tanfov,
+                      torch.zeros(Vt, 3, device=d), 256, 256, shs=g.harmonics.flatten(1, 3)[:1], sh_degree=4, sh_rgb_major=True,
+                      cam_scene=torch.zeros(Vt, dtype=torch.int32, device=d))
+    torch.cuda.synchronize()
+    for odt in ((torch.float32, torch.float64) if V == 2 else (torch.float32,)):
+        o_out, views, _ = chain.oracle_chain(W, er.default_cfg(), img, K, E, Kt, near, far, dtype=odt)
+        c = chain.compare_renders(r["color"].cpu().numpy(), views)
+        tiles = chain.tile_assignment_diff(r["radii"].cpu().numpy(), r["rect"].cpu().numpy(), views)
+        pose = float((out["gaussian_camera_extrins"].cpu().double() - o_out["gaussian_camera_extrins"].double()).abs().max())
+        print(f"e2e f32 V={V} Vt={Vt} vs oracle {odt}: PSNR {['%.1f' % p for p in c['psnr_between']]} dB, |dPSNR| "
+              f"{['%.1e' % p for p in c['dpsnr_common_target']]}, tiles {tiles}, pose {pose:.1e}")
+        assert min(c["psnr_between"]) >= 60.0, c
+        assert max(c["dpsnr_common_target"]) <= 1e-4, c                                     # the north-star's 1e-4 dB bar
+        assert tiles["visibility_flips"] + tiles["rect_changes"] <= 2e-3 * tiles["gaussian_views"], tiles
+        assert pose <= 2e-5

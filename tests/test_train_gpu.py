@@ -324,27 +324,33 @@ def test_config4_full_size_training_step():
 
 def test_gradient_checkpointing_recomputes_the_same_step():
     """enable_gradient_checkpointing() (vicasplat.py:140, backbone_vica.py:464-474,504-516): per-block recomputation gives the same
-    loss and the same gradients (deterministic kernels), with a lower activation peak."""
-    from vicasplat_amd import callers
-    from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
+    outputs and bit-identical gradients (every encoder kernel is run-to-run deterministic), with a lower activation peak.  The loss
+    is taken on the encoder outputs directly: the rasterizer backward's float atomics would blur the comparison."""
+    from vicasplat_amd.model.encoder.train_forward import forward_train
     d = torch.device("cuda:0")
-    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
-    batch = _config4_batch(1, 3, 2, d)
+    img, K = er.synthetic_input(1, 3, 256, 0)
+    img, K = img.to(d), K.to(d)
+    g = torch.Generator().manual_seed(3)
+    cot = torch.randn(1, 3, 256, 256, 86, generator=g).to(d) * 1e-3
     out = []
     for ck in (False, True):
         m, _ = _tiny_model(torch.float16)
         if ck:
             m.enable_gradient_checkpointing()
-        opt, _ = callers.configure_optimizer(m, lr=1e-12)
+        torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         base = torch.cuda.memory_allocated()
-        r = callers.training_step(m, dec, batch, opt, loss_scale=1024.0)
+        o = forward_train(m, img, K, torch.float16)
+        loss = (o["raw_gaussians"] * cot).sum() * 64.0 + o["pred_extrins"].square().sum()
+        loss.backward()
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated() - base
-        grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None and "backbone" in n}
-        out.append((float(r["loss"]), grads, peak))
+        grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        out.append((float(loss), grads, peak))
+        del m, o, loss
     assert out[0][0] == out[1][0]
-    worst = max(float((out[0][1][n] - out[1][1][n]).abs().max() / (out[0][1][n].abs().max() + 1e-20)) for n in out[0][1])
-    print(f"checkpointing: worst backbone gradient difference {worst:.2e}; activation peak {out[0][2] / 2**20:.0f} MiB -> {out[1][2] / 2**20:.0f} MiB")
-    assert worst <= 1e-4            # encoder kernels recompute bit-identically; the rasterizer's atomics perturb the incoming gradient
+    assert set(out[0][1]) == set(out[1][1])
+    diff = [n for n in out[0][1] if not torch.equal(out[0][1][n], out[1][1][n])]
+    print(f"checkpointing: {len(out[0][1])} gradients, {len(diff)} differ; activation peak {out[0][2] / 2**20:.0f} MiB -> {out[1][2] / 2**20:.0f} MiB")
+    assert not diff, diff[:10]
     assert out[1][2] < out[0][2]

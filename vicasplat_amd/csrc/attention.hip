@@ -438,6 +438,147 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
 
 }  // namespace
 
+// ---- reference-precision attention (f32 q | k | v and output, exact f32 MFMA v_mfma_f32_16x16x4_f32; DESIGN 2 "f32 path") ----
+// Same semantics and indexing as attention_kernel (key segments, per-query key-prefix lengths, log2-domain logsumexp), a plain
+// structure: 4 waves x 16 queries per workgroup, 32-key tiles of K and V staged synchronously in LDS (rows padded to 68 floats:
+// conflict-free float4 / float fragment reads), S^T = K Q^T so that a lane owns one query column, online softmax in f32, O += P V
+// with the scores used as the A operand as they are.  Summation index maps: QK^T step (j, s) takes d = 16 j + 4 g + s for both
+// operands (g = lane >> 4); P V step (nb, r) takes key = 16 nb + 4 g + r.
+struct AttnArgsF32 {
+    const float *q, *k, *v;
+    float *out;
+    const int32_t *kv_seg, *q_kvlen;
+    int nbatch, H, Lq, Lk;
+    long long q_batch_rows, k_batch_rows;
+    int ldq, ldk, ldv, ldo;
+    float scale_log2e;
+    float *lse;
+};
+
+__global__ void __launch_bounds__(256) attention_f32_kernel(const AttnArgsF32 a) {
+    constexpr int TK = 32, ROW = HD + 4;
+    __shared__ __attribute__((aligned(16))) float sK[TK * ROW];
+    __shared__ __attribute__((aligned(16))) float sV[TK * ROW];
+    __shared__ int s_maxlen;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    int base0, len0, base1, len1;
+    if (a.kv_seg) {
+        base0 = a.kv_seg[4 * b + 0]; len0 = a.kv_seg[4 * b + 1]; base1 = a.kv_seg[4 * b + 2]; len1 = a.kv_seg[4 * b + 3];
+    } else {
+        base0 = (int)(b * a.k_batch_rows); len0 = a.Lk; base1 = 0; len1 = 0;
+    }
+    const int Lk = len0 + len1;
+    const int qi = q0 + wid * 16 + c16;
+    const bool qvalid = qi < a.Lq;
+    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+    int my_len = Lk;
+    if (a.q_kvlen && qvalid) my_len = min(Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+    if (!qvalid) my_len = 0;
+    float4 qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[j] = *reinterpret_cast<const float4 *>(a.q + qrow * a.ldq + h * HD + 16 * j + 4 * g);
+    int wave_len = my_len;
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) wave_len = max(wave_len, __shfl_xor(wave_len, o_, 64));
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_maxlen, wave_len);
+    __syncthreads();
+    const int maxlen = s_maxlen;
+
+    f4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    auto key_row = [&](int j) -> long long {
+        j = min(j, Lk - 1);
+        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
+    };
+    const int s_key = tid >> 3, s_c = (tid & 7) * 8;   // staging: one key row, 8 floats of K and of V per thread
+    for (int kt = 0; kt < maxlen; kt += TK) {
+        {
+            const long long r = key_row(kt + s_key);
+            const float *kp = a.k + r * a.ldk + h * HD + s_c, *vp = a.v + r * a.ldv + h * HD + s_c;
+            const float4 k0 = *reinterpret_cast<const float4 *>(kp), k1 = *reinterpret_cast<const float4 *>(kp + 4);
+            const float4 v0 = *reinterpret_cast<const float4 *>(vp), v1 = *reinterpret_cast<const float4 *>(vp + 4);
+            *reinterpret_cast<float4 *>(&sK[s_key * ROW + s_c]) = k0; *reinterpret_cast<float4 *>(&sK[s_key * ROW + s_c + 4]) = k1;
+            *reinterpret_cast<float4 *>(&sV[s_key * ROW + s_c]) = v0; *reinterpret_cast<float4 *>(&sV[s_key * ROW + s_c + 4]) = v1;
+        }
+        __syncthreads();
+        if (kt < wave_len) {
+            f4 st[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                st[nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 kf = *reinterpret_cast<const float4 *>(&sK[(nb * 16 + c16) * ROW + 16 * j + 4 * g]);
+                    st[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[j].x, st[nb], 0, 0, 0);
+                    st[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[j].y, st[nb], 0, 0, 0);
+                    st[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[j].z, st[nb], 0, 0, 0);
+                    st[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[j].w, st[nb], 0, 0, 0);
+                }
+            }
+            // lane holds S^T[key = kt + 16 nb + 4 g + r][query c16]; mask, then the online softmax of this query column
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = (kt + nb * 16 + g * 4 + r < my_len) ? st[nb][r] * a.scale_log2e : -INFINITY;
+                    st[nb][r] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = m_new == -INFINITY ? 1.f : exp2f(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = m_new == -INFINITY ? 0.f : exp2f(st[nb][r] - m_new);
+                    st[nb][r] = p;
+                    ps += p;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+            // O rows are queries g*4 + r: fetch their rescale factors from the lanes that own those query columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float al = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[db][r] *= al;
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float *vr = &sV[(nb * 16 + g * 4 + r) * ROW + c16];
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[nb][r], vr[db * 16], o[db], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lr = __shfl(l_run, g * 4 + r, 64);
+        const int qo = q0 + wid * 16 + g * 4 + r;
+        if (qo >= a.Lq) continue;
+        const float inv = lr > 0.f ? 1.0f / lr : 0.f;
+        float *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) op[db * 16] = o[db][r] * inv;
+    }
+    if (a.lse && g == 0 && qvalid) a.lse[(b * a.q_batch_rows + qi) * a.H + h] = l_run > 0.f ? m_run + log2f(l_run) : -INFINITY;
+}
+
 extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, void *out, int32_t nbatch, int32_t H, int32_t Lq,
                                 int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv,
                                 int32_t ldo, const int32_t *kv_seg, const int32_t *q_kvlen, float scale, int32_t dtype, float *lse,
@@ -461,9 +602,18 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
     VS_CHECK(kv_seg || Lk > 0, "vs_attention: Lk must be positive when kv_seg is null");
     VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "vs_attention: row strides must be multiples of 8 elements");
     VS_CHECK(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "vs_attention: 16-byte alignment required");
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_attention: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_attention: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
     VS_CHECK(H <= 65535 && nbatch <= 65535, "vs_attention: grid too large");
     if (nbatch == 0 || Lq == 0) return 0;
+    if (dtype == 3) {
+        AttnArgsF32 f;
+        f.q = (const float *)q; f.k = (const float *)k; f.v = (const float *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;
+        f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
+        f.ldq = ldq; f.ldk = ldk; f.ldv = ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse;
+        hipLaunchKernelGGL(attention_f32_kernel, dim3(vs::cdiv(Lq, 64), H, nbatch), dim3(256), 0, stream, f);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     AttnArgs a;
     a.q = (const unsigned short *)q; a.k = (const unsigned short *)k; a.v = (const unsigned short *)v;
     a.out = (unsigned short *)out; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;

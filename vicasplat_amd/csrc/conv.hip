@@ -31,7 +31,7 @@ struct ConvArgs {
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
 // channels of one pixel per fragment): + bias, + residual (8-byte load, added in f32), ReLU, round to 16 bit, one 8-byte
 // store per fragment -- no LDS round trip.  mw0 / nbase = first output pixel / channel of the wave's tile.
-template <bool BF16, int MI>
+template <int BF16, int MI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, int M, void *, int, int lane) {
     const int mrow = lane & 15, c4 = (lane >> 4) * 4;
     float bv[4][4];
@@ -54,11 +54,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+            if constexpr (BF16 == kDtF32) {   // f32 activations: residual / output are float arrays with the same element indices
+                const float *res32 = reinterpret_cast<const float *>(g.res);
+                float *out32 = reinterpret_cast<float *>(g.out);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nbase + j * 16 + c4 + r < g.Cout) {
+                        float x = v[r];
+                        if (res32) {
+                            const float rr = res32[o + j * 16 + r];
+                            x = g.relu_out == 2 ? (rr > 0.f ? x : 0.f) : x + rr;
+                        }
+                        if (g.relu_out == 1) x = fmaxf(x, 0.0f);
+                        v[r] = x;
+                    }
+                if (nbase + j * 16 + c4 + 3 < g.Cout && g.Cout % 4 == 0) {
+                    *reinterpret_cast<float4 *>(out32 + o + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nbase + j * 16 + c4 + r < g.Cout) out32[o + j * 16 + r] = v[r];
+                }
+                continue;
+            }
+            constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;
             if (vec_ok) {
                 if (g.res) {
                     const uint2 rv = *reinterpret_cast<const uint2 *>(g.res + o + j * 16);
-                    const float r0 = from16<BF16>((unsigned short)(rv.x & 0xffffu)), r1 = from16<BF16>((unsigned short)(rv.x >> 16));
-                    const float r2 = from16<BF16>((unsigned short)(rv.y & 0xffffu)), r3 = from16<BF16>((unsigned short)(rv.y >> 16));
+                    const float r0 = from16<D16>((unsigned short)(rv.x & 0xffffu)), r1 = from16<D16>((unsigned short)(rv.x >> 16));
+                    const float r2 = from16<D16>((unsigned short)(rv.y & 0xffffu)), r3 = from16<D16>((unsigned short)(rv.y >> 16));
                     if (g.relu_out == 2) {  // data gradient of a conv behind a ReLU: keep it where the ReLU's input was positive
                         v[0] = r0 > 0.f ? v[0] : 0.f; v[1] = r1 > 0.f ? v[1] : 0.f; v[2] = r2 > 0.f ? v[2] : 0.f; v[3] = r3 > 0.f ? v[3] : 0.f;
                     } else {
@@ -70,8 +94,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                 }
                 uint2 pk;
-                pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
-                pk.y = (unsigned)to16<BF16>(v[2]) | ((unsigned)to16<BF16>(v[3]) << 16);
+                pk.x = (unsigned)to16<D16>(v[0]) | ((unsigned)to16<D16>(v[1]) << 16);
+                pk.y = (unsigned)to16<D16>(v[2]) | ((unsigned)to16<D16>(v[3]) << 16);
                 *reinterpret_cast<uint2 *>(g.out + o + j * 16) = pk;
             } else {
 #pragma unroll
@@ -79,11 +103,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                     if (nbase + j * 16 + c4 + r < g.Cout) {
                         float x = v[r];
                         if (g.res) {
-                            const float rr = from16<BF16>(g.res[o + j * 16 + r]);
+                            const float rr = from16<D16>(g.res[o + j * 16 + r]);
                             x = g.relu_out == 2 ? (rr > 0.f ? x : 0.f) : x + rr;
                         }
                         if (g.relu_out == 1) x = fmaxf(x, 0.0f);
-                        g.out[o + j * 16 + r] = to16<BF16>(x);
+                        g.out[o + j * 16 + r] = to16<D16>(x);
                     }
             }
         }
@@ -120,7 +144,7 @@ struct ConvStager256 {
     }
 };
 
-template <bool BF16, bool RELU_IN>
+template <int BF16, bool RELU_IN>
 __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, const int cshift) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,7 +187,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
 }
 
-template <bool BF16, int MI>
+template <int BF16, int MI>
 __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
     constexpr int BM = 32 * MI;
     constexpr int NS = 3;
@@ -260,7 +284,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
         _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                    \
             const int ra_ = wr * (16 * MI) + i * 16 + frow;                                                 \
             uint4 fa = *reinterpret_cast<const uint4 *>(&cA[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);           \
-            if (g.relu_in) { fa.x = relu2(fa.x); fa.y = relu2(fa.y); fa.z = relu2(fa.z); fa.w = relu2(fa.w); } \
+            if (g.relu_in) { fa.x = relu_reg<BF16>(fa.x); fa.y = relu_reg<BF16>(fa.y); fa.z = relu_reg<BF16>(fa.z); fa.w = relu_reg<BF16>(fa.w); } \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fb[j], fa, acc[i][j]);     \
         }                                                                                                   \
     }
@@ -330,6 +354,43 @@ upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *_
     *reinterpret_cast<uint4 *>(out + o) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+// f32 variant (reference-precision path): one thread per (output pixel, 4 channels), same index math
+__global__ void __launch_bounds__(256)
+upsample2x_f32_kernel(const float *__restrict__ in, const float *__restrict__ add, float *__restrict__ out, int Nimg, int H, int W, int C,
+                      int relu_add) {
+    const int Ho = 2 * H, Wo = 2 * W, c4 = C >> 2;
+    const long long total = (long long)Nimg * Ho * Wo * c4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cc = (int)(idx % c4);
+    long long p = idx / c4;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float sy = Ho > 1 ? (float)yo * (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)xo * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const size_t base = (size_t)n * H * W;
+    const float4 v00 = *reinterpret_cast<const float4 *>(in + ((base + (size_t)y0 * W + x0) * C + cc * 4));
+    const float4 v01 = *reinterpret_cast<const float4 *>(in + ((base + (size_t)y0 * W + x1) * C + cc * 4));
+    const float4 v10 = *reinterpret_cast<const float4 *>(in + ((base + (size_t)y1 * W + x0) * C + cc * 4));
+    const float4 v11 = *reinterpret_cast<const float4 *>(in + ((base + (size_t)y1 * W + x1) * C + cc * 4));
+    const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * C + cc * 4;
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add) {
+        av = *reinterpret_cast<const float4 *>(add + o);
+        if (relu_add) { av.x = fmaxf(av.x, 0.f); av.y = fmaxf(av.y, 0.f); av.z = fmaxf(av.z, 0.f); av.w = fmaxf(av.w, 0.f); }
+    }
+    auto mix = [&](float a, float b, float c, float d, float e) {
+        const float t = a * (1.f - lx) + b * lx, bt = c * (1.f - lx) + d * lx;
+        return t * (1.f - ly) + bt * ly + e;
+    };
+    *reinterpret_cast<float4 *>(out + o) = make_float4(mix(v00.x, v01.x, v10.x, v11.x, av.x), mix(v00.y, v01.y, v10.y, v11.y, av.y),
+                                                       mix(v00.z, v01.z, v10.z, v11.z, av.z), mix(v00.w, v01.w, v10.w, v11.w, av.w));
+}
+
 // ---- backward of the bilinear x2 (align_corners=True): gather form, one thread per (input pixel, 8 channels).  Input row y
 // receives from the output rows whose two source rows include y: sy = yo * (H-1)/(2H-1) in [y-1, y+1), i.e. yo within
 // [2y-3, 2y+3]; the weight of an output row for y is (y0 == y)(1 - ly) + (y1 == y) ly, which is what the forward used. ----
@@ -384,9 +445,13 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && w && out, "vs_conv3x3_nhwc: null pointer");
     VS_CHECK(Nimg >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), "vs_conv3x3_nhwc: bad sizes");
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_conv3x3_nhwc: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
+    if (dtype == 3) {   // f32 activations / weights: the kernels address them in 2-byte units (gemm_common.h, kDtF32)
+        VS_CHECK(Cin % 16 == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of 16 for f32 (pad the channels)", Cin);
+        Cin *= 2;
+    }
     VS_CHECK(Cin % 32 == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of 32 (pad the channels)", Cin);
     VS_CHECK(Hin < 32767 && Win < 65536 && (long long)Nimg * Hin * Win < 2147483647LL, "vs_conv3x3_nhwc: image too large");
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_conv3x3_nhwc: dtype must be 1 (f16) or 2 (bf16)");
     VS_CHECK(relu_out >= 0 && relu_out <= 2 && (relu_out != 2 || residual), "vs_conv3x3_nhwc: relu_out must be 0, 1 or 2 (2 = mask by `residual`, which must be given)");
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
     if (Nimg == 0) return 0;
@@ -400,7 +465,10 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     const long long t256 = vs::cdiv64(M, 256) * vs::cdiv(Cout, 256);
     if (force != 8 && force != 4 && cshift >= 0 && Cout % 256 == 0 && (9 * Cin / 64) % 2 == 0 && t256 >= 224) {
         dim3 grid((unsigned)t256), block(512);
-        if (dtype == 2) {
+        if (dtype == 3) {
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, true>), grid, block, 0, stream, g, cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, false>), grid, block, 0, stream, g, cshift);
+        } else if (dtype == 2) {
             if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<true, true>), grid, block, 0, stream, g, cshift);
             else hipLaunchKernelGGL((conv3x3_256_kernel<true, false>), grid, block, 0, stream, g, cshift);
         } else {
@@ -411,7 +479,9 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
         return 0;
     }
     const long long big = vs::cdiv64(M, 256) * vs::cdiv(Cout, BN);
-    if ((big >= 256 || force == 8) && force != 4) {
+    if (dtype == 3) {
+        hipLaunchKernelGGL((conv3x3_kernel<kDtF32, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
+    } else if ((big >= 256 || force == 8) && force != 4) {
         dim3 grid((unsigned)big);
         if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<true, 8>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<false, 8>), grid, dim3(256), 0, stream, g);
@@ -428,8 +498,17 @@ extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, in
                                   int32_t relu_add, int32_t dtype, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && out, "vs_upsample2x_nhwc: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_upsample2x_nhwc: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
+    if (dtype == 3) {
+        VS_CHECK(C % 4 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 4", C);
+        const long long tot = (long long)Nimg * 4 * H * W * (C / 4);
+        if (tot <= 0) return 0;
+        hipLaunchKernelGGL(upsample2x_f32_kernel, dim3((unsigned)vs::cdiv64(tot, 256)), dim3(256), 0, stream, (const float *)in, (const float *)add,
+                           (float *)out, Nimg, H, W, C, relu_add);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     VS_CHECK(C % 8 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 8", C);
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_upsample2x_nhwc: dtype must be 1 (f16) or 2 (bf16)");
     const long long total = (long long)Nimg * 4 * H * W * (C / 8);
     if (total <= 0) return 0;
     dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);

@@ -26,7 +26,7 @@
 
 namespace {
 
-template <bool BF16, int EPI, int MI>
+template <int BF16, int EPI, int MI>
 __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g_in) {
     GemmArgs g = g_in;
     int ksp = (EPI == 2 && g.ksplit > 1) ? (int)blockIdx.y : 0;  // split-K slice (tail launches of the f32 residual epilogue)
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
 // one workgroup per 16 output columns, its NW waves split K into contiguous ranges and walk them 4 k-steps at a time
 // with all 20 fragment loads of a batch in flight (A is tiny and L2-resident, W is read exactly once per launch);
 // partial sums meet in LDS, then the same fused epilogues. ----
-template <bool BF16, int EPI, int NW, int MF>
+template <int BF16, int EPI, int NW, int MF>
 __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) {
     __shared__ float red[NW][MF][256];  // [wave][m-frag][16x16]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -226,11 +226,13 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][i][rc];
         const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-        if constexpr (EPI == 0) {
+        if constexpr (EPI == 0 && BF16 != kDtF32) {
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
-        } else if constexpr (EPI == 1) {
+        } else if constexpr (EPI == 1 && BF16 != kDtF32) {
             v = gelu_erf(v);
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
+        } else if constexpr (EPI == 1) {     // f32 operands: GELU, f32 store
+            reinterpret_cast<float *>(g.out)[orow * g.ldo + n] = gelu_erf(v);
         } else if constexpr (EPI == 2) {
             float *o = reinterpret_cast<float *>(g.out) + orow * g.ldo + n;
             const float gt = g.gate ? g.gate[(size_t)(m / g.gate_rows) * g.gate_ld + n] : 0.0f;
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
     }
 }
 
-template <bool BF16, int NW, int MF>
+template <int BF16, int NW, int MF>
 int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
     dim3 grid(vs::cdiv(g.N, 16)), block(64 * NW);
     switch (epi) {
@@ -254,7 +256,7 @@ int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
     return 0;
 }
 
-template <bool BF16>
+template <int BF16>
 int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
     // 16 waves split K when it is long (each walks <= 8 k-steps of 4096), 8 otherwise; 1 or 4 row fragments
     const bool one = g.M - g.m_lo <= 16, deep = g.K / 32 >= 64;
@@ -262,7 +264,7 @@ int launch_smallm(const GemmArgs &g, int epi, hipStream_t stream) {
     return deep ? launch_smallm_nw<BF16, 16, 4>(g, epi, stream) : launch_smallm_nw<BF16, 8, 4>(g, epi, stream);
 }
 
-template <bool BF16, int MI>
+template <int BF16, int MI>
 int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M - g.m_lo, 32 * MI) * vs::cdiv(g.N, BN);
     dim3 grid(nwg, epi == 2 && g.ksplit > 1 ? g.ksplit : 1), block(256);
@@ -278,7 +280,7 @@ int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
     return 0;
 }
 
-template <bool BF16>
+template <int BF16>
 int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M - g.m_lo, 256) * vs::cdiv(g.N, 256);
     dim3 grid(nwg), block(512);
@@ -294,7 +296,7 @@ int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
 }
 
 // Rows [g.M - rem, g.M) of a split GEMM: <= 64 rows on the weight-streaming kernel, <= 128 on one row of 128x128 tiles.
-template <bool BF16>
+template <int BF16>
 int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     GemmArgs t = g;
     t.m_lo = g.M - rem;
@@ -311,7 +313,16 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     return rem <= 64 && epi != 4 ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
 }
 
-template <bool BF16>
+// reference-precision path (exact f32 MFMA at 1/16 of the 16-bit rate): the matrix pipe, not the tile schedule, sets the time, so
+// there is one route per shape class and no tail splitting: 256x256 tiles when K allows (K in 2-byte units: a multiple of
+// 128 = 64 floats), 128x128 tiles otherwise, the weight-streaming kernel for the camera-token GEMMs
+int launch_f32(const GemmArgs &g, int epi, hipStream_t stream) {
+    if (g.M <= 64 && epi != 4) return launch_smallm<kDtF32>(g, epi, stream);
+    if (g.K % 128 == 0) return launch_256<kDtF32>(g, epi, stream);
+    return launch_mi<kDtF32, 4>(g, epi, stream);
+}
+
+template <int BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
@@ -393,7 +404,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restr
 // output is made of whole 256-tiles and every K slice is an even number (>= 2) of 64-wide K tiles; 128x128 tiles otherwise.
 // With a workspace of ksplit * ntaps * M * N floats the slices store partial tiles and a second kernel sums them; without
 // one they meet through f32 atomics.
-template <bool BF16>
+template <int BF16>
 int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, int accumulate, hipStream_t stream) {
     static const int no256 = [] { const char *e = getenv("VS_WGRAD_NO256"); return e ? atoi(e) : 0; }();
     const int ntaps = g.ntaps > 0 ? g.ntaps : 1;
@@ -436,9 +447,14 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
                const int32_t *rope_pos, const uint8_t *rope_kind, int32_t rope_C, float base2d, float theta1d, hipStream_t stream) {
     VS_CHECK(A && W && out, "%s: null pointer", fn);
     VS_CHECK(M >= 0 && N > 0 && K > 0, "%s: bad sizes M=%d N=%d K=%d", fn, M, N, K);
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "%s: dtype must be 1 (f16), 2 (bf16) or 3 (f32)", fn);
+    if (dtype == 3) {   // f32 operands are addressed in 2-byte units by the kernels (gemm_common.h, kDtF32): K, lda, ldw double
+        VS_CHECK(K % 32 == 0, "%s: K=%d must be a multiple of 32 for f32 operands", fn, K);
+        VS_CHECK(lda % 4 == 0 && ldw % 4 == 0, "%s: lda/ldw must be multiples of 4 floats (16-byte rows)", fn);
+        K *= 2; lda *= 2; ldw *= 2;
+    }
     VS_CHECK(K % 64 == 0, "%s: K=%d must be a multiple of 64", fn, K);
     VS_CHECK(lda % 8 == 0 && ldw % 8 == 0, "%s: lda/ldw must be multiples of 8 elements (16-byte rows)", fn);
-    VS_CHECK(dtype == 1 || dtype == 2, "%s: dtype must be 1 (f16) or 2 (bf16)", fn);
     VS_CHECK((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
              "%s: A and W must be 16-byte aligned", fn);
     if (M == 0) return 0;
@@ -458,7 +474,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
-    const int rc = dtype == 2 ? launch<true>(g, epilogue, stream) : launch<false>(g, epilogue, stream);
+    const int rc = dtype == 3 ? launch_f32(g, epilogue, stream) : dtype == 2 ? launch<1>(g, epilogue, stream) : launch<0>(g, epilogue, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;

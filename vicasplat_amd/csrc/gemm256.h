@@ -42,7 +42,7 @@ __device__ __forceinline__ int unit_b_tile_row256(int q, int h) { return (q >> 5
 // [4 reduction rows][16 tile rows] block and receives column t, i.e. 4 consecutive k of its tile row (probed on hardware:
 // tools/probe/tr_read.hip).  Two such reads are the 8 k-values of one MFMA operand.  The 16-byte chunk index is XORed with
 // (reduction row & 3) << 1, so that the four rows of a block land in four different 8-bank windows.
-template <bool BF16, bool RELU_A, class Stager, bool TN = false>
+template <int BF16, bool RELU_A, class Stager, bool TN = false>
 __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[8][4], const unsigned char *smem, const int lane,
                                             const int wid) {
     constexpr unsigned UNITB = kUnitBytes256;
@@ -105,8 +105,8 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
     if constexpr (RELU_A) {                                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                   \
-                fa[i][s_].x = relu2(fa[i][s_].x); fa[i][s_].y = relu2(fa[i][s_].y);                              \
-                fa[i][s_].z = relu2(fa[i][s_].z); fa[i][s_].w = relu2(fa[i][s_].w);                              \
+                fa[i][s_].x = relu_reg<BF16>(fa[i][s_].x); fa[i][s_].y = relu_reg<BF16>(fa[i][s_].y);            \
+                fa[i][s_].z = relu_reg<BF16>(fa[i][s_].z); fa[i][s_].w = relu_reg<BF16>(fa[i][s_].w);            \
             }                                                                                                    \
     }
 #define VS_MM(ha_, hb_)                                                                                          \
@@ -179,7 +179,7 @@ struct GemmStager256 {
     }
 };
 
-template <bool BF16, int EPI>
+template <int BF16, int EPI>
 __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
     constexpr int BM2 = 256, BN2 = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
 // Split-K / tap-fused variant for weight gradients: out32[tap][M,N] += A[M, Kslice] (W + shift[tap])[N, Kslice]^T through f32
 // atomics, or (g.partials) per-slice partial tiles for splitk_reduce_kernel.  blockIdx.x = (k-slice, tap, tile), tile fastest: the workgroups of one K slice run together, so A and the (up to
 // nine, overlapping) shifted views of W of that slice are shared through L2.  K / 64 / ksplit must be even and >= 2.
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(512, 1) gemm256_splitk_kernel(const GemmArgs g_in) {
     constexpr int BM2 = 256, BN2 = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
@@ -290,7 +290,7 @@ struct GemmStagerTN {
     }
 };
 
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArgs g_in) {
     constexpr int BM2 = 256, BN2 = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
@@ -373,7 +373,7 @@ struct ConvWgradStagerTN {
     }
 };
 
-template <bool BF16, bool RELU_A>
+template <int BF16, bool RELU_A>
 __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_tn_kernel(const GemmArgs g_in) {
     constexpr int BM2 = 256, BN2 = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];

@@ -54,18 +54,34 @@ struct GemmArgs {
     float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
 };
 
-template <bool BF16>
+// Operand dtype of the MFMA kernels (template parameter `BF16` of every kernel below: the name predates the third value).
+//   0 f16, 1 bf16: v_mfma_f32_16x16x32_{f16,bf16}, a fragment register quad = 8 consecutive k values of one tile row.
+//   2 f32 (kDtF32): the reference-precision path (fp32 weights and activations; gfx950 has no TF32 -- SURVEY 7-5 / DESIGN 2).
+//     The SAME kernels run it: an f32 operand array is addressed as an array of 2-byte units with doubled strides / K, so
+//     a staged 128-byte (64-byte) LDS row holds 32 (16) floats instead of 64 (32) halves, a fragment register quad is 4
+//     consecutive k, and one 16x16x32 MFMA becomes four v_mfma_f32_16x16x4_f32 (exact f32 products and sums == an fmaf chain;
+//     64 FLOP/clk/SIMD = 1/16 of the 16-bit rate).  Lane (row = l & 15, group = l >> 4) feeds float s of its quad to step s,
+//     i.e. k = 4 * group + s for BOTH operands -- any bijection of k onto (step, group) is a valid summation order.
+constexpr int kDtF32 = 2;
+
+template <int BF16>
 __device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
-    if constexpr (BF16) {
+    if constexpr (BF16 == kDtF32) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    } else if constexpr (BF16 == 1) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf8 *>(&a), *reinterpret_cast<const bf8 *>(&b), c, 0, 0, 0);
     } else {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8 *>(&a), *reinterpret_cast<const half8 *>(&b), c, 0, 0, 0);
     }
 }
 
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ unsigned short to16(float v) {
-    if constexpr (BF16) {
+    static_assert(BF16 != kDtF32, "f32 operands are stored as floats, not through to16");
+    if constexpr (BF16 == 1) {
         unsigned u = __float_as_uint(v);
         u += 0x7FFFu + ((u >> 16) & 1u);
         return (unsigned short)(u >> 16);
@@ -75,9 +91,10 @@ __device__ __forceinline__ unsigned short to16(float v) {
     }
 }
 
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ float from16(unsigned short h) {
-    if constexpr (BF16) return __uint_as_float(((unsigned)h) << 16);
+    static_assert(BF16 != kDtF32, "f32 operands are read as floats, not through from16");
+    if constexpr (BF16 == 1) return __uint_as_float(((unsigned)h) << 16);
     else return (float)*reinterpret_cast<_Float16 *>(&h);
 }
 
@@ -85,6 +102,12 @@ __device__ __forceinline__ float from16(unsigned short h) {
 __device__ __forceinline__ unsigned relu2(unsigned x) {
     const unsigned m = ((x >> 15) & 0x00010001u) * 0xFFFFu;
     return x & ~m;
+}
+// the same on one fragment register of operand dtype DT (f32: one float per register)
+template <int DT>
+__device__ __forceinline__ unsigned relu_reg(unsigned x) {
+    if constexpr (DT == kDtF32) return x & ~(unsigned)((int)x >> 31);
+    else return relu2(x);
 }
 
 // exact-erf GELU (croco/blocks.py:60,68 uses nn.GELU()): erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the
@@ -124,7 +147,7 @@ __device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
 // (lane >> 4) * 4 + 0..3) -- an 8-byte (16-bit) or 16-byte (f32) store per fragment straight from registers, no LDS
 // transpose and no barrier; RoPE pairs (c, c+16) are fragments j / j+1 of the same lane, interleaved pairs (2p, 2p+1) are
 // neighbouring registers.  mw0 / nbase = first output row / column of the wave's (16*MI) x 64 tile. ----
-template <bool BF16, int EPI, int MI>
+template <int BF16, int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *, int, int lane) {
     const int mrow = lane & 15, c4 = (lane >> 4) * 4;
     const bool full_n = nbase + 64 <= g.N;
@@ -143,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
         for (int r = 0; r < 4; ++r) inv2d[r] = __builtin_amdgcn_exp2f(-(float)(c4 + r) * (1.0f / 16.0f) * g.rope_l2base);
     }
-    constexpr bool OUT16 = EPI == 0 || EPI == 1 || EPI == 4;
+    constexpr bool OUT16 = (EPI == 0 || EPI == 1 || EPI == 4) && BF16 != kDtF32;   // f32 operands: every epilogue stores floats
     const bool vec_ok = full_n && (OUT16 ? (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 7) == 0)
                                          : (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0));
 #pragma unroll
@@ -194,18 +217,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
         }
         if (!valid) continue;
         if constexpr (OUT16) {
+            constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;   // (never instantiated for f32: keeps to16<> well-formed)
             unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + c4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (vec_ok) {
                     uint2 pk;
-                    pk.x = (unsigned)to16<BF16>(v[j][0]) | ((unsigned)to16<BF16>(v[j][1]) << 16);
-                    pk.y = (unsigned)to16<BF16>(v[j][2]) | ((unsigned)to16<BF16>(v[j][3]) << 16);
+                    pk.x = (unsigned)to16<D16>(v[j][0]) | ((unsigned)to16<D16>(v[j][1]) << 16);
+                    pk.y = (unsigned)to16<D16>(v[j][2]) | ((unsigned)to16<D16>(v[j][3]) << 16);
                     *reinterpret_cast<uint2 *>(dst + j * 16) = pk;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (nbase + j * 16 + c4 + r < g.N) dst[j * 16 + r] = to16<BF16>(v[j][r]);
+                        if (nbase + j * 16 + c4 + r < g.N) dst[j * 16 + r] = to16<D16>(v[j][r]);
                 }
             }
         } else {

@@ -306,7 +306,7 @@ class VicaNet(nn.Module):
             ops.gemm(cn16, W[f"d{i}.cfc1"], blk.mlp_cam.fc1.bias, chid, ops.EPI_GELU16)
             ops.gemm(chid, W[f"d{i}.cfc2"], blk.mlp_cam.fc2.bias, cam, ops.EPI_RESID32)
             if (i + 1) in hooks and (i + 1) != cfg.dec_depth:
-                inter[i + 1] = xd.view(B, T, N, Cd)[:, :, :n].to(dt)
+                inter[i + 1] = xd.view(B, T, N, Cd)[:, :, :n].to(dt, copy=True)   # (copy: xd keeps changing, and dt may be f32)
         last = torch.empty(BT * N, Cd, **f16)
         ops.layernorm_mod(xd, self.dec_norm.weight, self.dec_norm.bias, last)
         inter[cfg.dec_depth] = last.view(B, T, N, Cd)[:, :, :n]

@@ -178,6 +178,20 @@ class PixelwiseTaskWithDPT(nn.Module):
             P["stem.b"] = c.bias.detach().float().contiguous()
         return P["stem.w"], P["stem.b"]
 
+    def _stem_f32(self, frames: torch.Tensor) -> torch.Tensor:
+        """7x7 stem of the reference-precision (f32) path: im2col rows (c, ky, kx order = weight.flatten(1)), K padded 147 -> 160,
+        through the f32 MFMA GEMM; a few frames at a time (65 536 x 160 floats per frame)."""
+        c = self.dpt.input_merger[0]
+        N, _, H, W = frames.shape
+        wk = F.pad(c.weight.detach().float().flatten(1), (0, 160 - 147)).contiguous()
+        bias = c.bias.detach().float().contiguous()
+        out = torch.empty(N, H, W, wk.shape[0], dtype=torch.float32, device=frames.device)
+        step = 8
+        for i in range(0, N, step):
+            cols = F.pad(F.unfold(frames[i:i + step].float(), 7, padding=3).transpose(1, 2), (0, 160 - 147)).reshape(-1, 160).contiguous()
+            ops.gemm(cols, wk, bias, out[i:i + step].view(-1, wk.shape[0]), ops.EPI_STORE16)
+        return out
+
     @staticmethod
     def _gemm1x1(x, P, name, n_out=None):
         """x [..., K] NHWC 16-bit -> [..., N] via the GEMM kernel (1x1 convolution)."""
@@ -246,8 +260,11 @@ class PixelwiseTaskWithDPT(nn.Module):
         dt = self.compute_dtype
         # 7x7 stem on the RGB image (dpt_gs_head.py:112-118): window GEMM on the zero-bordered NHWC frames, bias fused; its
         # ReLU is fused into the upsample-add kernel below
-        P7 = self._stem_weights()
-        img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
+        if dt == torch.float32:
+            img = self._stem_f32(frames)
+        else:
+            P7 = self._stem_weights()
+            img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
         x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
         x = ops.conv3x3_nhwc(x, P["h0.w"], None, relu_out=True)  # Dropout(0.1) is the identity at inference
         y = self._gemm1x1(x, P, "h4")

@@ -12,6 +12,10 @@ import torch
 from . import _lib as L
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+# operand dtype codes of the MFMA kernels (GEMM / convolution / attention / upsample): 3 = f32, the reference-precision path --
+# fp32 weights AND activations on the exact f32 MFMA (csrc/gemm_common.h, kDtF32); every "16-bit" output is then f32 too
+_DTX = {torch.float32: 3, torch.float16: 1, torch.bfloat16: 2}
+_OPERAND_DTYPES = (torch.float16, torch.bfloat16, torch.float32)
 EPI_STORE16, EPI_GELU16, EPI_RESID32, EPI_STORE32 = 0, 1, 2, 3
 
 
@@ -42,7 +46,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w 16-bit; out 16-bit (epilogue 0/1) or f32 (2: in-place residual
     update with optional per-group gate [G,N]; 3: store)."""
     dev = L.require_device(a, w, bias, out, gate)
-    assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
+    assert a.dtype == w.dtype and a.dtype in _OPERAND_DTYPES
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
     K = a.shape[1]
     M = a.shape[0] if M is None else M  # with an input row map, M counts the rows actually consumed
@@ -54,7 +58,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     gate_ld = gate.stride(0) if gate is not None else 0
     with torch.cuda.device(dev):
         rc = L.lib().vs_gemm_bias_act(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(gate), M, N, K, a.stride(0),
-                                      w.stride(0), out.stride(-2), epilogue, _DT[a.dtype], grp_in, grp_out, grp_off,
+                                      w.stride(0), out.stride(-2), epilogue, _DTX[a.dtype], grp_in, grp_out, grp_off,
                                       gate_rows, gate_ld, a_grp_in, a_grp_out, a_grp_off, L.stream_ptr(dev))
     L.check(rc, "vs_gemm_bias_act")
     return out
@@ -65,12 +69,12 @@ def gemm_resid(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], r
     """resid [M,N] f32 + (1 + gate) * (a @ w^T + bias) into a NEW tensor (vs_gemm_resid): the residual update of gemm(..., EPI_RESID32)
     without touching (or cloning) the old stream."""
     dev = L.require_device(a, w, bias, resid, gate)
-    assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16) and a.stride(1) == 1 and w.stride(1) == 1
+    assert a.dtype == w.dtype and a.dtype in _OPERAND_DTYPES and a.stride(1) == 1 and w.stride(1) == 1
     assert resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == (a.shape[0], w.shape[0])
     out = torch.empty_like(resid)
     with torch.cuda.device(dev):
         rc = L.lib().vs_gemm_resid(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(resid), L.ptr(out), L.ptr(gate), a.shape[0], w.shape[0], a.shape[1],
-                                   a.stride(0), w.stride(0), out.stride(0), _DT[a.dtype], gate_rows, gate.stride(0) if gate is not None else 0,
+                                   a.stride(0), w.stride(0), out.stride(0), _DTX[a.dtype], gate_rows, gate.stride(0) if gate is not None else 0,
                                    L.stream_ptr(dev))
     L.check(rc, "vs_gemm_resid")
     return out
@@ -82,13 +86,13 @@ def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
                   a_grp_off: int = 0) -> torch.Tensor:
     """Packed q|k|v projection (w [N >= 2C, K]) with rope_qk(out, C // 64, C, pos, kind, ...) fused into the epilogue."""
     dev = L.require_device(a, w, bias, out, pos, kind)
-    assert a.dtype == w.dtype == out.dtype and a.dtype in (torch.float16, torch.bfloat16)
+    assert a.dtype == w.dtype == out.dtype and a.dtype in _OPERAND_DTYPES
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
     assert pos.dtype == torch.int32 and pos.is_contiguous() and (kind is None or (kind.dtype == torch.uint8 and kind.is_contiguous()))
     M = a.shape[0] if M is None else M
     with torch.cuda.device(dev):
         rc = L.lib().vs_gemm_qkv_rope(L.ptr(a), L.ptr(w), L.ptr(bias), L.ptr(out), M, w.shape[0], a.shape[1], a.stride(0), w.stride(0),
-                                      out.stride(-2), _DT[a.dtype], grp_in, grp_out, grp_off, a_grp_in, a_grp_out, a_grp_off,
+                                      out.stride(-2), _DTX[a.dtype], grp_in, grp_out, grp_off, a_grp_in, a_grp_out, a_grp_off,
                                       L.ptr(pos), L.ptr(kind), C, base2d, theta1d, L.stream_ptr(dev))
     L.check(rc, "vs_gemm_qkv_rope")
     return out
@@ -115,14 +119,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     lse (optional, f32 [rows, H] contiguous) receives the log2-domain logsumexp for attention_backward."""
     dev = L.require_device(q, k, v, out, kv_seg, q_kvlen, lse)
     for t in (q, k, v, out):
-        assert t.dim() == 2 and t.stride(1) == 1
+        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == q.dtype
     assert kv_seg is None or (kv_seg.dtype == torch.int32 and kv_seg.is_contiguous())
     assert q_kvlen is None or (q_kvlen.dtype == torch.int32 and q_kvlen.is_contiguous())
     assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (q.shape[0], H))
     with torch.cuda.device(dev):
         rc = L.lib().vs_attention_lse(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
                                       q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
-                                      _DT[q.dtype], L.ptr(lse), L.stream_ptr(dev))
+                                      _DTX[q.dtype], L.ptr(lse), L.stream_ptr(dev))
     L.check(rc, "vs_attention")
     return out
 
@@ -222,7 +226,7 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
         assert residual is None and not relu_out
         residual, relu_out = mask_by, 2
     dev = L.require_device(x, w, bias, residual, out)
-    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dtype in (torch.float16, torch.bfloat16)
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dtype in _OPERAND_DTYPES
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
     assert w.shape == (Cout, 3, 3, Cin)
@@ -232,7 +236,7 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     assert residual is None or (residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype)
     with torch.cuda.device(dev):
         rc = L.lib().vs_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(residual), L.ptr(out), N, H, W, Cin, Cout, stride,
-                                     int(relu_in), int(relu_out), _DT[x.dtype], L.stream_ptr(dev))
+                                     int(relu_in), int(relu_out), _DTX[x.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_conv3x3_nhwc")
     return out
 
@@ -284,12 +288,12 @@ def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[t
 def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_add: bool = False) -> torch.Tensor:
     """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit; optional fused `+ add` / `+ relu(add)`."""
     dev = L.require_device(x, add)
-    assert x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float16, torch.bfloat16)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype in _OPERAND_DTYPES
     N, H, W, Cc = x.shape
     out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=dev)
     assert add is None or (add.shape == out.shape and add.is_contiguous() and add.dtype == x.dtype)
     with torch.cuda.device(dev):
-        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, int(relu_add), _DT[x.dtype], L.stream_ptr(dev))
+        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, int(relu_add), _DTX[x.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_upsample2x_nhwc")
     return out
 
