@@ -227,6 +227,8 @@ def main():
         wrapped = [(ops, "gemm", gemm_meta), (ops, "gemm_qkv_rope", gemm_meta), (ops, "attention", attn_meta),
                    (ops, "layernorm_mod", lambda r, x, *a, **k: dict(bytes=x.numel() * 6.0)),
                    (ops, "conv3x3_nhwc", conv_meta),
+                   (ops, "conv3x3_head1x1_nhwc", lambda r, x, w, b, w2, b2, n_out, *a, **k: dict(
+                       flops=2.0 * x.shape[0] * x.shape[1] * x.shape[2] * (9.0 * w.shape[3] * w.shape[0] + w.shape[0] * n_out))),
                    (ops, "conv7x7_rgb_nhwc", lambda r, x, w, *a, **k: dict(flops=2.0 * r.numel() * 147)),
                    (ops, "upsample2x_nhwc", lambda r, x, *a, **k: dict(bytes=r.numel() * 2.0 * (2.25 if (len(a) or k.get("add") is not None) else 1.25))),
                    (ops, "gaussian_adapter", lambda r, *a, **k: dict()),
@@ -238,12 +240,14 @@ def main():
         for m, n, o in saved:
             setattr(m, n, o)
         zero = dict(ms=0.0, calls=0, flops=0.0, bytes=0.0)
-        for k_ in ("gemm", "gemm_qkv_rope", "conv3x3_nhwc", "conv7x7_rgb_nhwc", "upsample2x_nhwc", "gaussian_adapter"):
+        for k_ in ("gemm", "gemm_qkv_rope", "conv3x3_nhwc", "conv3x3_head1x1_nhwc", "conv7x7_rgb_nhwc", "upsample2x_nhwc", "gaussian_adapter"):
             summ.setdefault(k_, dict(zero))
         tot_ms = s.elapsed_time(e)
         # every vs_gemm_* launch: plain/fused-epilogue GEMMs and the qkv projections with RoPE in the epilogue
         gm = {k_: summ["gemm"][k_] + summ["gemm_qkv_rope"][k_] for k_ in ("ms", "calls", "flops")}
-        at, rs, cv, ln = summ["attention"], summ["_forward_impl"], summ["conv3x3_nhwc"], summ["layernorm_mod"]
+        at, rs, ln = summ["attention"], summ["_forward_impl"], summ["layernorm_mod"]
+        # 3x3 convolutions: the plain implicit-GEMM launches + the two fused conv3 -> ReLU -> conv1 head kernels
+        cv = {k_: summ["conv3x3_nhwc"][k_] + summ["conv3x3_head1x1_nhwc"][k_] for k_ in ("ms", "calls", "flops", "bytes")}
         up, ad, stem = summ["upsample2x_nhwc"], summ["gaussian_adapter"], summ["conv7x7_rgb_nhwc"]
         R = [m for n, _, _, m in kt.rec if n == "_forward_impl"][0]["R"]
         gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12

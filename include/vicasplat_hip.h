@@ -206,6 +206,14 @@ int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts_ch, const 
 int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg, int32_t Hin,
                     int32_t Win, int32_t Cin, int32_t Cout, int32_t stride /* 1 or 2; out = (in-1)/stride+1 */, int32_t relu_in,
                     int32_t relu_out, int32_t dtype, vs_stream_t stream);
+/* out2[pixel, 0..C2) = W2 * act(conv3x3(in) + bias) + bias2 in ONE kernel -- the last two layers of both DPT heads (conv3 -> ReLU ->
+ * conv1, heads/dpt_block.py:316-343): the 3x3 result never leaves the workgroup.  Form A (Gaussian-parameter head): Cout = 256,
+ * w2 [C2pad, 256] 16-bit (rows >= C2 zero), bias2 [C2pad] f32, C2pad a multiple of 16 <= 96, ld2 >= C2pad: second GEMM on the MFMA
+ * through LDS.  Form B (pts3d head): Cout = 128, C2 <= 4, w2 [C2, 128], bias2 [4], ld2 >= 4: VALU dot products.  stride 1, pad 1,
+ * N*H*W % 256 == 0, relu_out 0 | 1 applies to the 3x3 result, dtype 1 f16 / 2 bf16. */
+int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const float *bias, const void *w2, const float *bias2, void *out2, int32_t Nimg,
+                            int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t C2, int32_t C2pad, int32_t ld2, int32_t relu_in,
+                            int32_t relu_out, int32_t dtype, vs_stream_t stream);
 int vs_upsample2x_nhwc(const void *in, const void *add, void *out, int32_t Nimg, int32_t H, int32_t W, int32_t C,
                        int32_t relu_add, int32_t dtype, vs_stream_t stream);
 /* Backward of vs_upsample2x_nhwc (without add): din [N,H,W,C] = bilinear-x2^T applied to dout [N,2H,2W,C]; H, W = INPUT size. */

@@ -4,7 +4,7 @@ fp32 MFMA ... report both").  -m gpu.
 
   * operator level: GEMM (every epilogue, row maps, small-M and 128x128 routes), packed qkv + RoPE, attention (prefix mask, key
     segments), 3x3 convolution (both kernels, ReLU-in / bias / residual / ReLU-out, stride 2) and bilinear x2 against float64 torch
-    on the SAME f32 inputs: only the f32 summation order differs (<= 2e-6 of the output scale);
+    on the SAME f32 inputs: only the f32 summation order differs (<= 4e-6 of the output scale);
   * encoder level: against the real reference's float64 goldens <= 2e-4 (the reference's own f32 run differs from its f64 run by 4e-5);
   * end to end: HIP encoder[f32] -> HIP rasterizer against the oracle chain (f32 and f64): PSNR >= 60 dB (f32 vs f64 oracle: 76 dB;
     any TF32-class path, the reference's CUDA run included: 19-20 dB, tests/test_chain_cpu.py).
@@ -46,20 +46,20 @@ def test_gemm_f32_epilogues(M, N, K):
     ref = a.double() @ w.double().t() + bias.double()
     out = torch.empty(M, N, device=d)
     ops.gemm(a, w, bias, out, ops.EPI_STORE16)
-    assert _rel(out, ref) <= 2e-6
+    assert _rel(out, ref) <= 4e-6
     ops.gemm(a, w, bias, out, ops.EPI_GELU16)
-    assert _rel(out, F.gelu(ref)) <= 2e-6
+    assert _rel(out, F.gelu(ref)) <= 4e-6
     ops.gemm(a, w, None, out, ops.EPI_STORE32)
-    assert _rel(out, a.double() @ w.double().t()) <= 2e-6
+    assert _rel(out, a.double() @ w.double().t()) <= 4e-6
     x0 = torch.randn(M, N, generator=g).to(d)
     gi = max(1, M // 3)
     gate = torch.randn((M + gi - 1) // gi, N, generator=g).to(d) * 0.3
     x = x0.clone()
     ops.gemm(a, w, bias, x, ops.EPI_RESID32, gate=gate, gate_rows=gi)
     rows = torch.arange(M, device=d)
-    assert _rel(x, x0.double() + (1 + gate.double()[rows // gi]) * ref) <= 2e-6
+    assert _rel(x, x0.double() + (1 + gate.double()[rows // gi]) * ref) <= 4e-6
     y = ops.gemm_resid(a, w, bias, x0)
-    assert _rel(y, x0.double() + ref) <= 2e-6
+    assert _rel(y, x0.double() + ref) <= 4e-6
     # row maps: read every gi rows out of gi + 1, write behind one extra row per group
     if M >= 8:
         G_ = M // gi
@@ -69,7 +69,7 @@ def test_gemm_f32_epilogues(M, N, K):
         r = torch.arange(G_ * gi, device=d)
         src = big[(r // gi) * (gi + 1) + 1 + r % gi]
         got = out2[(r // gi) * (gi + 2) + 2 + r % gi]
-        assert _rel(got, src.double() @ w.double().t() + bias.double()) <= 2e-6
+        assert _rel(got, src.double() @ w.double().t() + bias.double()) <= 4e-6
         assert float(out2[0].abs().max()) == 0 and float(out2[1].abs().max()) == 0
 
 
@@ -161,14 +161,14 @@ def test_conv3x3_f32(N, H, W, Cin, Cout, stride):
     xn = x.permute(0, 3, 1, 2).double()
     y = ops.conv3x3_nhwc(x, wp, b, stride=stride)
     ref = F.conv2d(xn, w.double(), b.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
-    assert y.dtype == torch.float32 and _rel(y, ref) <= 2e-6
+    assert y.dtype == torch.float32 and _rel(y, ref) <= 4e-6
     if stride == 1:
         res = torch.randn(N, H, W, Cout, generator=g).to(d)
         y = ops.conv3x3_nhwc(x, wp, b, residual=res, relu_in=True)
         ref = F.conv2d(F.relu(xn), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
-        assert _rel(y, ref) <= 2e-6
+        assert _rel(y, ref) <= 4e-6
         y = ops.conv3x3_nhwc(x, wp, None, relu_out=True)
-        assert _rel(y, F.relu(F.conv2d(xn, w.double(), None, padding=1)).permute(0, 2, 3, 1)) <= 2e-6
+        assert _rel(y, F.relu(F.conv2d(xn, w.double(), None, padding=1)).permute(0, 2, 3, 1)) <= 4e-6
 
 
 def test_upsample2x_f32():
@@ -178,8 +178,8 @@ def test_upsample2x_f32():
     x = torch.randn(2, 9, 13, 64, generator=g).to(d)
     add = torch.randn(2, 18, 26, 64, generator=g).to(d)
     ref = F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
-    assert _rel(ops.upsample2x_nhwc(x), ref) <= 2e-6
-    assert _rel(ops.upsample2x_nhwc(x, add=add, relu_add=True), ref + F.relu(add.double())) <= 2e-6
+    assert _rel(ops.upsample2x_nhwc(x), ref) <= 4e-6
+    assert _rel(ops.upsample2x_nhwc(x, add=add, relu_add=True), ref + F.relu(add.double())) <= 4e-6
 
 
 def _model(kind):

@@ -883,3 +883,38 @@ def test_upsample2x_backward_matches_autograd(dt):
         got = ops.upsample2x_backward_nhwc(dy).permute(0, 3, 1, 2).float()
         tol = 2e-3 if dt == torch.float16 else 1.6e-2
         assert (got - x.grad).abs().max() <= tol * x.grad.abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Cin,Cout,C2", [(256, 256, 83), (128, 128, 3), (256, 256, 16), (64, 128, 4)])
+def test_conv3x3_head1x1_fused_matches_the_two_layer_path(dt, Cin, Cout, C2):
+    """conv3 -> ReLU -> conv1 of the DPT heads in one kernel (vs_conv3x3_head1x1_nhwc) against the unfused pair of HIP kernels
+    (same 16-bit rounding of the intermediate activation) and against fp32 torch."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + C2)
+    N, H, W = 2, 32, 48
+    x = torch.randn(N, H, W, Cin, generator=g).to(dt).to(d)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(d)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(d) if Cout == 128 else None
+    w2 = (torch.randn(C2, Cout, generator=g) / math.sqrt(Cout)).to(d)
+    b2 = torch.randn(C2, generator=g).to(d)
+    wp = ops.pack_conv3x3_weight(w, dt)
+    pad = (C2 + 15) // 16 * 16 if Cout == 256 else 4
+    w2p = torch.zeros(pad, Cout, dtype=dt, device=d); w2p[:C2] = w2.to(dt)
+    b2p = torch.zeros(pad, device=d); b2p[:C2] = b2
+    y = ops.conv3x3_head1x1_nhwc(x, wp, b, w2p, b2p, C2)
+    assert y.shape == (N, H, W, pad)
+    mid = ops.conv3x3_nhwc(x, wp, b, relu_out=True)
+    two = torch.empty(N * H * W, C2, dtype=dt, device=d)
+    if C2 % 8 == 0:
+        ops.gemm(mid.view(-1, Cout), w2p[:C2].contiguous(), b2, two, ops.EPI_STORE16)
+    else:
+        two = (mid.view(-1, Cout).float() @ w2p[:C2].float().t() + b2).to(dt)
+    tol = (2e-3 if dt == torch.float16 else 1.6e-2) * float(two.float().abs().max())
+    assert (y[..., :C2].reshape(-1, C2).float() - two.float()).abs().max() <= tol
+    if pad > C2 and Cout == 256:
+        assert float(y[..., C2:].abs().max()) == 0.0
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dt).float(), None if b is None else b, padding=1).relu().permute(0, 2, 3, 1)
+    ref = ref.reshape(-1, Cout) @ w2.to(dt).float().t() + b2
+    assert (y[..., :C2].reshape(-1, C2).float() - ref).abs().max() <= 4 * tol

@@ -324,8 +324,10 @@ def test_config4_full_size_training_step():
 
 def test_gradient_checkpointing_recomputes_the_same_step():
     """enable_gradient_checkpointing() (vicasplat.py:140, backbone_vica.py:464-474,504-516): per-block recomputation gives the same
-    outputs and bit-identical gradients (every encoder kernel is run-to-run deterministic), with a lower activation peak.  The loss
-    is taken on the encoder outputs directly: the rasterizer backward's float atomics would blur the comparison."""
+    outputs (bit-identical forward) and the same gradients, with a lower activation peak.  The backward kernels accumulate
+    LayerNorm / bias column sums and dk / dv with f32 atomics, so two IDENTICAL runs already differ in the last bits: the
+    checkpointed run must sit inside that run-to-run spread.  The loss is taken on the encoder outputs directly (the rasterizer
+    backward's atomics would only widen the spread)."""
     from vicasplat_amd.model.encoder.train_forward import forward_train
     d = torch.device("cuda:0")
     img, K = er.synthetic_input(1, 3, 256, 0)
@@ -333,7 +335,7 @@ def test_gradient_checkpointing_recomputes_the_same_step():
     g = torch.Generator().manual_seed(3)
     cot = torch.randn(1, 3, 256, 256, 86, generator=g).to(d) * 1e-3
     out = []
-    for ck in (False, True):
+    for ck in (False, False, True):
         m, _ = _tiny_model(torch.float16)
         if ck:
             m.enable_gradient_checkpointing()
@@ -348,9 +350,11 @@ def test_gradient_checkpointing_recomputes_the_same_step():
         grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
         out.append((float(loss), grads, peak))
         del m, o, loss
-    assert out[0][0] == out[1][0]
-    assert set(out[0][1]) == set(out[1][1])
-    diff = [n for n in out[0][1] if not torch.equal(out[0][1][n], out[1][1][n])]
-    print(f"checkpointing: {len(out[0][1])} gradients, {len(diff)} differ; activation peak {out[0][2] / 2**20:.0f} MiB -> {out[1][2] / 2**20:.0f} MiB")
-    assert not diff, diff[:10]
-    assert out[1][2] < out[0][2]
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert set(out[0][1]) == set(out[2][1])
+    spread = lambda a, b: max(float((a[n] - b[n]).abs().max() / (a[n].abs().max() + 1e-30)) for n in a)
+    s_base, s_ck = spread(out[0][1], out[1][1]), spread(out[0][1], out[2][1])
+    print(f"checkpointing: {len(out[0][1])} gradients; worst relative difference run-to-run {s_base:.2e}, checkpointed vs plain {s_ck:.2e}; "
+          f"activation peak {out[0][2] / 2**20:.0f} MiB -> {out[2][2] / 2**20:.0f} MiB")
+    assert s_ck <= max(3 * s_base, 1e-5), (s_base, s_ck)
+    assert out[2][2] < out[0][2]

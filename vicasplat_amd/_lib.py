@@ -143,6 +143,8 @@ def lib() -> C.CDLL:
             L.vs_conv7x7_rgb_nhwc.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_conv3x3_nhwc.restype = C.c_int
             L.vs_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_conv3x3_head1x1_nhwc.restype = C.c_int
+            L.vs_conv3x3_head1x1_nhwc.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 11 + [vp]
             L.vs_upsample2x_nhwc.restype = C.c_int
             L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             if hasattr(L, "vs_raster_backward"):

@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) adapter_kernel(const AdapterArgs a) {
 // 64 x (8+3*d_sh) input block and every output block are CONTIGUOUS in HBM, so they move as 16-byte coalesced
 // vectors through an LDS staging tile; the per-pixel math runs on LDS-resident values. ----
 constexpr int kMaxCh = 96;  // 11 + 3*d_sh <= 96  (d_sh <= 28)
+constexpr int kMaxPixStride = 96;  // largest pixel stride (channels incl. padding) of the gs input of the dense kernel
 
 template <bool BF16>
 __device__ __forceinline__ float cvt16(unsigned short h) {
@@ -125,17 +126,19 @@ __device__ __forceinline__ void flush_block(const float *__restrict__ sm, float 
 
 template <bool BF16>
 __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sin[64 * (kMaxCh - 3) + 64 * 3 + 16];
+    // pixel strides may exceed the channel counts (gs rows padded to a multiple of 16 channels, pts rows to 4: what the fused
+    // conv3 -> conv1 head kernel writes); the staged blocks keep the stride
+    __shared__ __attribute__((aligned(16))) unsigned short sin[64 * kMaxPixStride + 64 * 8 + 16];
     __shared__ __attribute__((aligned(16))) float sout[64 * kMaxCh];
     const int lane = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * 64;
     const int np = (int)min((long long)64, a.npix - p0);
-    const int nsh = a.d_sh, cg = 8 + 3 * nsh, craw = 11 + 3 * nsh;
-    unsigned short *sgs = sin, *spt = sin + 64 * cg;
+    const int nsh = a.d_sh, cg = (int)a.gs_pix, cp = (int)a.pts_pix, craw = 11 + 3 * nsh;
+    unsigned short *sgs = sin, *spt = sin + ((64 * cg + 7) & ~7);
     {   // coalesced 16-byte loads of the two input blocks
         const unsigned short *ggs = reinterpret_cast<const unsigned short *>(a.gs) + p0 * cg;
-        const unsigned short *gpt = reinterpret_cast<const unsigned short *>(a.pts) + p0 * 3;
-        const int n1 = np * cg, n2 = np * 3;
+        const unsigned short *gpt = reinterpret_cast<const unsigned short *>(a.pts) + p0 * cp;
+        const int n1 = np * cg, n2 = np * cp;
         for (int k = lane; k < (n1 >> 3); k += 64) reinterpret_cast<uint4 *>(sgs)[k] = reinterpret_cast<const uint4 *>(ggs)[k];
         for (int k = ((n1 >> 3) << 3) + lane; k < n1; k += 64) sgs[k] = ggs[k];
         for (int k = lane; k < (n2 >> 3); k += 64) reinterpret_cast<uint4 *>(spt)[k] = reinterpret_cast<const uint4 *>(gpt)[k];
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a)
     float mx = 0.f, my = 0.f, mz = 0.f, p = 0.f, s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 1.f}, cov[9];
     float o_raw = 0.f, sr[3] = {0.f, 0.f, 0.f}, qr[4] = {0.f, 0.f, 0.f, 1.f};
     if (live) {
-        const float x = cvt16<BF16>(spt[lane * 3]), y = cvt16<BF16>(spt[lane * 3 + 1]), z = cvt16<BF16>(spt[lane * 3 + 2]);
+        const float x = cvt16<BF16>(spt[lane * cp]), y = cvt16<BF16>(spt[lane * cp + 1]), z = cvt16<BF16>(spt[lane * cp + 2]);
         const float d = sqrtf(x * x + y * y + z * z);
         const float k = expm1f(d) / fmaxf(d, 1e-8f);
         mx = x * k; my = y * k; mz = z * k;
@@ -418,8 +421,9 @@ extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts
     if (npix <= 0) return 0;
     AdapterArgs a{pts, gs, pts_pix, pts_ch, gs_pix, gs_ch, in_dtype, npix, d_sh, sh_mask, scale_act, scale_min, scale_max,
                   opacity_exponent, means, cov, harmonics, opacities, scales, rotations, raw};
-    const bool dense16 = in_dtype != 0 && pts_ch == 1 && pts_pix == 3 && gs_ch == 1 && gs_pix == 8 + 3 * d_sh &&
-                         11 + 3 * d_sh <= kMaxCh && ((uintptr_t)pts & 15) == 0 && ((uintptr_t)gs & 15) == 0;
+    const bool dense16 = in_dtype != 0 && pts_ch == 1 && pts_pix >= 3 && pts_pix <= 8 && gs_ch == 1 && gs_pix >= 8 + 3 * d_sh &&
+                         gs_pix <= kMaxPixStride && 11 + 3 * d_sh <= kMaxCh && ((uintptr_t)pts & 15) == 0 && ((uintptr_t)gs & 15) == 0 &&
+                         ((64 * pts_pix) % 8 == 0) && ((64 * gs_pix) % 8 == 0);
     if (dense16) {
         dim3 g64((unsigned)vs::cdiv64(npix, 64));
         if (in_dtype == 1) hipLaunchKernelGGL(adapter_nhwc16_kernel<false>, g64, dim3(64), 0, stream, a);

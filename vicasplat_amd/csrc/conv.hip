@@ -26,6 +26,12 @@ struct ConvArgs {
     int Nimg, H, W, Cin, Cout;  // H, W: OUTPUT size
     int relu_in, relu_out;
     int Hin, Win, stride;
+    // fused head (vs_conv3x3_head1x1_nhwc): out2[pixel, 0..C2) = W2 relu(conv3x3(in) + bias) + bias2, the 3x3 result never leaves the
+    // workgroup.  w2: [C2pad, Cout] 16-bit (rows >= C2 zero), bias2: [C2pad] f32, out2 row stride ld2 (>= C2pad for the MFMA form)
+    const unsigned short *w2;
+    const float *bias2;
+    unsigned short *out2;
+    int C2, C2pad, ld2;
 };
 
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
@@ -114,6 +120,76 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
     }
 }
 
+// ---- fused 1x1 head behind a 3x3 convolution with Cout = 256 (the Gaussian-parameter head: conv3(256->256, no bias) -> ReLU ->
+// conv1(256->83), dpt_block.py:335-343).  The [256 pixels x 256 channels] tile of the 3x3 result goes to LDS as 16-bit values (the same
+// rounding the unfused path applies when it stores the activation), XOR-swizzled so that both the 8-byte writes from the C^T
+// accumulator layout and the 16-byte fragment reads are conflict-free, and is multiplied by W2 [C2pad <= 96, 256] on the MFMA: wave w
+// owns pixel rows 32 w .. 32 w + 31 (2 x NF fragments, K = 256 in 8 steps); W2 fragments come straight from L2 (48 KiB, shared by
+// every workgroup).  Saves the write + read of the 256-channel activation at full resolution (2 x 6.4 GB per 24-scene step).
+template <int BF16, int NF>
+__device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (&acc)[8][4], int m0, int wr, int wc, unsigned char *smem, int wid,
+                                                         int lane) {
+    const int mrow = lane & 15, grp = lane >> 4;
+    // stage relu(acc + bias) as 16-bit X[row][col], row stride 512 B, 16-byte chunk index XOR (row & 31)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wr * 128 + i * 16 + mrow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wc * 64 + j * 16 + grp * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] + (g.bias ? g.bias[col + r] : 0.0f);
+                if (g.relu_out == 1) v[r] = fmaxf(v[r], 0.0f);
+            }
+            uint2 pk;
+            pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
+            pk.y = (unsigned)to16<BF16>(v[2]) | ((unsigned)to16<BF16>(v[3]) << 16);
+            const int chunk = (col >> 3) ^ (row & 31);
+            *reinterpret_cast<uint2 *>(smem + row * 512 + chunk * 16 + (col & 7) * 2) = pk;
+        }
+    }
+    __syncthreads();
+    f4 acc2[2][NF];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc2[a_][n] = f4{0.f, 0.f, 0.f, 0.f};
+    const unsigned short *w2l = g.w2 + (size_t)mrow * g.Cout + grp * 8;   // row (n * 16 + mrow), k chunk grp of step ks
+    uint4 wf[2][NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) wf[0][n] = *reinterpret_cast<const uint4 *>(w2l + (size_t)n * 16 * g.Cout);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+#pragma unroll
+            for (int n = 0; n < NF; ++n) wf[(ks + 1) & 1][n] = *reinterpret_cast<const uint4 *>(w2l + (size_t)n * 16 * g.Cout + (ks + 1) * 32);
+        }
+#pragma unroll
+        for (int a_ = 0; a_ < 2; ++a_) {
+            const int row = wid * 32 + a_ * 16 + mrow;
+            const uint4 xf = *reinterpret_cast<const uint4 *>(smem + row * 512 + (((ks * 4 + grp) ^ (row & 31)) << 4));
+#pragma unroll
+            for (int n = 0; n < NF; ++n) acc2[a_][n] = mfma<BF16>(wf[ks & 1][n], xf, acc2[a_][n]);
+        }
+    }
+    // C^T layout again: lane holds 4 consecutive output channels (n * 16 + grp * 4 ..) of pixel row (wid * 32 + a * 16 + mrow)
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_) {
+        const size_t m = (size_t)m0 + wid * 32 + a_ * 16 + mrow;
+        unsigned short *dst = g.out2 + m * g.ld2 + grp * 4;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const float4 b2 = *reinterpret_cast<const float4 *>(g.bias2 + n * 16 + grp * 4);
+            uint2 pk;
+            pk.x = (unsigned)to16<BF16>(acc2[a_][n][0] + b2.x) | ((unsigned)to16<BF16>(acc2[a_][n][1] + b2.y) << 16);
+            pk.y = (unsigned)to16<BF16>(acc2[a_][n][2] + b2.z) | ((unsigned)to16<BF16>(acc2[a_][n][3] + b2.w) << 16);
+            *reinterpret_cast<uint2 *>(dst + n * 16) = pk;
+        }
+    }
+}
+
 // ---- 256 x 256 x 64 implicit-GEMM variant on the phase-interleaved main loop of gemm256.h (Cout tile 256, one tap x 64
 // input channels per K-tile; needs Cin = 64 << cshift).  Only the staging differs from the GEMM: per staged row the source
 // is the tap-shifted pixel's 128-byte channel slice, or the zero page outside the image. ----
@@ -144,7 +220,7 @@ struct ConvStager256 {
     }
 };
 
-template <int BF16, bool RELU_IN>
+template <int BF16, bool RELU_IN, int FUSE_NF = 0>
 __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, const int cshift) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -184,10 +260,66 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     }
     f4 acc[8][4];
     mainloop256<BF16, RELU_IN>(st, K / 64, acc, smem, lane, wid);
-    conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
+    if constexpr (FUSE_NF > 0) conv_head1x1_epilogue256<BF16, FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
+    else conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
 }
 
+// ---- fused 1x1 head with <= 4 outputs behind a 3x3 convolution whose Cout fits one 128-column tile (the pts3d head: conv3(128->128)
+// -> ReLU -> conv1(128->3), dpt_block.py:316-333): per pixel three 128-long dot products on the VALU.  A lane owns 16 channels of a pixel
+// row per fragment; partial sums are reduced over the 4 lane groups of the wave (xor 16 / 32) and over the two waves that share a row
+// (wc = 0 / 1) through LDS; the activation is rounded to 16 bit first, as the unfused path stores it.  Output [pixels, ld2 >= 4] 16-bit.
 template <int BF16, int MI>
+__device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int m0, int wr, int wc, float *red, int lane) {
+    const int mrow = lane & 15, grp = lane >> 4;
+    float w2v[4][4][4], bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = wc * 64 + j * 16 + grp * 4 + r;
+            bv[j][r] = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) w2v[o][j][r] = o < g.C2 ? from16<BF16>(g.w2[(size_t)o * g.Cout + col]) : 0.0f;
+        }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv[j][r];
+                if (g.relu_out == 1) v = fmaxf(v, 0.0f);
+                v = from16<BF16>(to16<BF16>(v));
+#pragma unroll
+                for (int o = 0; o < 4; ++o) p[o] = fmaf(v, w2v[o][j][r], p[o]);
+            }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            p[o] += __shfl_xor(p[o], 16, 64);
+            p[o] += __shfl_xor(p[o], 32, 64);
+        }
+        const int row = wr * (16 * MI) + i * 16 + mrow;
+        if (wc == 1 && grp == 0) *reinterpret_cast<float4 *>(red + row * 4) = make_float4(p[0], p[1], p[2], p[3]);
+        acc[i][0] = f4{p[0], p[1], p[2], p[3]};
+    }
+    __syncthreads();
+    if (wc == 0 && grp == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = wr * (16 * MI) + i * 16 + mrow;
+            const float4 q = *reinterpret_cast<const float4 *>(red + row * 4);
+            const float o0 = acc[i][0][0] + q.x + g.bias2[0], o1 = acc[i][0][1] + q.y + g.bias2[1];
+            const float o2 = acc[i][0][2] + q.z + g.bias2[2], o3 = acc[i][0][3] + q.w + g.bias2[3];
+            uint2 pk;
+            pk.x = (unsigned)to16<BF16>(o0) | ((unsigned)to16<BF16>(o1) << 16);
+            pk.y = (unsigned)to16<BF16>(o2) | ((unsigned)to16<BF16>(o3) << 16);
+            *reinterpret_cast<uint2 *>(g.out2 + ((size_t)m0 + row) * g.ld2) = pk;
+        }
+    }
+}
+
+template <int BF16, int MI, bool FUSE_DOT = false>
 __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
     constexpr int BM = 32 * MI;
     constexpr int NS = 3;
@@ -299,7 +431,8 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
 #undef VS_STAGE
     __syncthreads();
 
-    conv_epilogue<BF16, MI>(g, acc, m0 + wr * (16 * MI), n0 + wc * 64, M, smem, wid, lane);
+    if constexpr (FUSE_DOT) conv_head_dot_epilogue<BF16, MI>(g, acc, m0, wr, wc, reinterpret_cast<float *>(smem), lane);
+    else conv_epilogue<BF16, MI>(g, acc, m0 + wr * (16 * MI), n0 + wc * 64, M, smem, wid, lane);
 }
 
 // ---- bilinear x2, align_corners=True, NHWC 16-bit; optional fused "+ add" (gs head: up2(trunk) + image features) ----
@@ -456,7 +589,7 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
     if (Nimg == 0) return 0;
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
-               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride};
+               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0};
     const long long M = (long long)Nimg * H * W;
     static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
     int cshift = -1;
@@ -489,6 +622,55 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
         dim3 grid((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN)));
         if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<true, 4>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<false, 4>), grid, dim3(256), 0, stream, g);
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+/* out2[pixel, 0..C2) = W2 relu_out(conv3x3(in) + bias) + bias2 in ONE kernel (the 3x3 result stays on chip): the last two layers of
+ * both DPT heads (dpt_block.py:316-343).  Two forms: Cout = 256 and C2pad in {16,..,96} (multiple of 16; w2 [C2pad, 256], bias2 [C2pad],
+ * ld2 >= C2pad; MFMA through LDS), or Cout = 128 and C2 <= 4 (w2 [C2, 128], bias2 [4], ld2 >= 4; VALU dot products).  stride 1,
+ * N*H*W a multiple of 256, dtype 1 f16 / 2 bf16. */
+extern "C" int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const float *bias, const void *w2, const float *bias2, void *out2,
+                                       int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t C2, int32_t C2pad, int32_t ld2,
+                                       int32_t relu_in, int32_t relu_out, int32_t dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && w && w2 && bias2 && out2, "vs_conv3x3_head1x1_nhwc: null pointer");
+    VS_CHECK(dtype == 1 || dtype == 2, "vs_conv3x3_head1x1_nhwc: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(Nimg > 0 && H > 0 && W > 0 && H < 32767 && W < 65536, "vs_conv3x3_head1x1_nhwc: bad sizes");
+    const long long M = (long long)Nimg * H * W;
+    VS_CHECK(M % 256 == 0 && M < 2147483647LL, "vs_conv3x3_head1x1_nhwc: N*H*W must be a multiple of 256");
+    VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)out2 & 7) == 0 &&
+             ((uintptr_t)bias2 & 15) == 0, "vs_conv3x3_head1x1_nhwc: alignment");
+    VS_CHECK(relu_out == 0 || relu_out == 1, "vs_conv3x3_head1x1_nhwc: relu_out must be 0 or 1");
+    ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, nullptr, nullptr, Nimg, H, W, Cin, Cout, relu_in, relu_out, H, W, 1,
+               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2pad, ld2};
+    if (Cout == 256) {
+        int cshift = -1;
+        for (int sft = 0; sft < 4; ++sft)
+            if (Cin == (64 << sft)) cshift = sft;
+        VS_CHECK(cshift >= 0 && (9 * Cin / 64) % 2 == 0, "vs_conv3x3_head1x1_nhwc: Cin=%d not supported with Cout=256", Cin);
+        VS_CHECK(C2pad % 16 == 0 && C2pad >= 16 && C2pad <= 96 && C2 <= C2pad && ld2 >= C2pad && ld2 % 4 == 0 && !relu_in,
+                 "vs_conv3x3_head1x1_nhwc: need C2pad in 16..96 (multiple of 16), ld2 >= C2pad, no relu_in (C2pad=%d ld2=%d)", C2pad, ld2);
+        dim3 grid((unsigned)(M / 256)), block(512);
+#define VS_FUSE(NF_)                                                                                                        \
+        if (dtype == 2) hipLaunchKernelGGL((conv3x3_256_kernel<1, false, NF_>), grid, block, 0, stream, g, cshift);         \
+        else hipLaunchKernelGGL((conv3x3_256_kernel<0, false, NF_>), grid, block, 0, stream, g, cshift);
+        switch (C2pad / 16) {
+            case 1: VS_FUSE(1) break;
+            case 2: VS_FUSE(2) break;
+            case 3: VS_FUSE(3) break;
+            case 4: VS_FUSE(4) break;
+            case 5: VS_FUSE(5) break;
+            default: VS_FUSE(6) break;
+        }
+#undef VS_FUSE
+    } else {
+        VS_CHECK(Cout == 128 && C2 >= 1 && C2 <= 4 && ld2 >= 4 && ld2 % 4 == 0 && Cin % 32 == 0,
+                 "vs_conv3x3_head1x1_nhwc: the dot-product form needs Cout = 128, C2 <= 4, ld2 >= 4 (Cout=%d C2=%d)", Cout, C2);
+        dim3 grid((unsigned)(M / 256));
+        if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<1, 8, true>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_kernel<0, 8, true>), grid, dim3(256), 0, stream, g);
     }
     VS_HIP(hipGetLastError());
     return 0;

@@ -342,8 +342,11 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
         // cost in units of one 256x256 round; a 128x128 round (768 tiles) is about 0.31 of it
         const long long tiles4 = (long long)vs::cdiv(rem, 128) * vs::cdiv(g.N, 128);
         const double cost_split = (double)(((long long)mt_main * tn + 255) / 256) + (rem > 0 ? 0.31 * (double)((tiles4 + 767) / 768) : 0.0);
-        const bool split = rem > 0 && mt_main > 0 && cost_split < (double)rounds_all - 0.05;
         const long long tiles_one = vs::cdiv(g.M, 256) * (long long)tn;
+        // a last round that is >= 95 % full is not worth a second launch (e.g. 31 eight-view scenes: 249 row tiles -> 3.89 / 11.67 /
+        // 15.56 rounds): one launch, no tail
+        const bool nearly_full = tiles_one * 100 >= rounds_all * 256 * 95;
+        const bool split = !nearly_full && rem > 0 && mt_main > 0 && cost_split < (double)rounds_all - 0.05;
         if (force == 16 || split || tiles_one * 100 >= rounds_all * 256 * 85) {
             GemmArgs main_g = g;
             if (split) main_g.M = rows_main;
@@ -472,6 +475,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32; g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     g.rope_pos = rope_pos; g.rope_kind = rope_kind; g.rope_C = rope_C;
+    { static const int stg = [] { const char *e = getenv("VS_GEMM_STAGGER"); return e ? atoi(e) : 0; }(); g.stagger = stg; }
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
     const int rc = dtype == 3 ? launch_f32(g, epilogue, stream) : dtype == 2 ? launch<1>(g, epilogue, stream) : launch<0>(g, epilogue, stream);
@@ -539,7 +543,7 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
     g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
@@ -576,7 +580,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
@@ -626,7 +630,7 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
     g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
     const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
@@ -696,7 +700,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());

@@ -197,6 +197,10 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
     }
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = g.m_lo + tm * BM2, n0 = tn * BN2;
+    if (g.stagger > 0 && blockIdx.x < 256) {
+        const int n = (int)((blockIdx.x >> 3) & 7) * g.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);

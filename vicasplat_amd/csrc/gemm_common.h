@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -52,6 +54,7 @@ struct GemmArgs {
     const uint8_t *rope_kind;
     int rope_C;  // columns [0, C) = q, [C, 2C) = k, rest untouched
     float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
+    int stagger;  // experiment: first-round workgroups of gemm256_kernel sleep (bid % 8) * stagger * ~4 us before starting
 };
 
 // Operand dtype of the MFMA kernels (template parameter `BF16` of every kernel below: the name predates the third value).
@@ -106,8 +109,21 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {
 // the same on one fragment register of operand dtype DT (f32: one float per register)
 template <int DT>
 __device__ __forceinline__ unsigned relu_reg(unsigned x) {
-    if constexpr (DT == kDtF32) return x & ~(unsigned)((int)x >> 31);
-    else return relu2(x);
+    if constexpr (DT == kDtF32) {
+        return x & ~(unsigned)((int)x >> 31);
+    } else if constexpr (DT == 0) {
+        // f16: ONE packed max per register (relu2 is shift / and / quarter-rate 32-bit multiply / and-not: ~7 issue slots, and the
+        // implicit-GEMM main loop applies this to 32 A-fragment registers per K-tile beside 64 MFMAs of a one-wave-per-SIMD kernel).
+        // (-0.0 and NaN inputs: max(-0.0, +0.0) = +0.0 like the bit trick; a NaN activation is a NaN either way downstream.)
+        unsigned r;
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(x));
+        return r;
+    } else {
+        // bf16: sign masks of both halves with one packed arithmetic shift, then and-not
+        unsigned m;   // (the shift count comes from a register: a VOP3P inline constant only reaches the LOW half)
+        asm("v_pk_ashrrev_i16 %0, %2, %1" : "=v"(m) : "v"(x), "v"(0x000F000Fu));
+        return x & ~m;
+    }
 }
 
 // exact-erf GELU (croco/blocks.py:60,68 uses nn.GELU()): erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the
@@ -149,16 +165,27 @@ __device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
 // neighbouring registers.  mw0 / nbase = first output row / column of the wave's (16*MI) x 64 tile. ----
 template <int BF16, int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *, int, int lane) {
+    // (opaque copy of the lane id: keeps the compiler from hoisting the epilogue's per-lane constants -- bias, RoPE frequencies --
+    //  above the main loop, where they cost a spill that is reloaded inside it)
+    asm volatile("" : "+v"(lane));
     const int mrow = lane & 15, c4 = (lane >> 4) * 4;
     const bool full_n = nbase + 64 <= g.N;
     float bv[4][4];
+    if (g.bias && full_n && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) {   // (wave-uniform) 4 x 16-byte loads
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = nbase + j * 16 + c4 + r;
-            bv[j][r] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const float4 t = *reinterpret_cast<const float4 *>(g.bias + nbase + j * 16 + c4);
+            bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nbase + j * 16 + c4 + r;
+                bv[j][r] = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
+            }
+    }
     [[maybe_unused]] float inv2d[4] = {0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] bool rope_on = false;
     if constexpr (EPI == 4) {
@@ -169,6 +196,144 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
     constexpr bool OUT16 = (EPI == 0 || EPI == 1 || EPI == 4) && BF16 != kDtF32;   // f32 operands: every epilogue stores floats
     const bool vec_ok = full_n && (OUT16 ? (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 7) == 0)
                                          : (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0));
+    // ---- fast path: interior wave tile (every row and column valid, vector-aligned output).  All conditions are wave-uniform,
+    // so this is straight-line code: the generic path below branches per element and ends up as one load -> wait -> store chain
+    // per fragment (measured on the f32 residual epilogue: 17 us of a 52 us tile, 4 loads in flight per wave).  Here every
+    // residual / gate load of a batch of 4 row fragments is issued before the first use (16 x 16 B in flight per lane). ----
+    {
+        const bool plain_resid = EPI != 2 || (g.ksplit <= 1 && g.ksplit >= 0);
+        const bool res_ok = EPI != 2 || !g.resid || (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0;
+        const bool gate_ok = EPI != 2 || !g.gate || (g.gate_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(g.gate) & 15) == 0);
+        if (vec_ok && mw0 + 16 * MI <= g.M && plain_resid && res_ok && gate_ok) {
+            size_t orow[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mw0 + i * 16 + mrow;
+                orow[i] = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
+            }
+            [[maybe_unused]] int rk[MI];
+            [[maybe_unused]] int2 rp[MI];
+            if constexpr (EPI == 4) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    rk[i] = (rope_on && g.rope_kind) ? (int)g.rope_kind[orow[i]] : 0;
+                    rp[i] = rope_on ? *reinterpret_cast<const int2 *>(g.rope_pos + 2 * orow[i]) : make_int2(0, 0);
+                }
+            }
+            if constexpr (EPI == 2) {
+                float *const outp = reinterpret_cast<float *>(g.out);
+                const float *const srcp = g.resid ? g.resid : outp;
+                // The gate of a row depends on the row only through its group (frame) m / gate_rows.  With gate_rows >= 16 * MI the lane's
+                // MI rows (16 apart) fall into at most two groups: their gate vectors are loaded ONCE (8 x 16 B) and selected per row.
+                // (Per-row gate loads: every workgroup of the launch hammers the same few KB of the [groups, N] array -- measured +24 us
+                // on a 160 us GEMM.)  Fewer rows per group than that: per-row loads.
+                const int m_first = mw0 + mrow;
+                const bool two_groups = g.gate && g.gate_rows >= 16 * MI;
+                const int f0 = g.gate ? m_first / g.gate_rows : 0;
+                [[maybe_unused]] float4 gA[4], gB[4];
+                if (two_groups) {
+                    const int f1 = (m_first + 16 * (MI - 1)) / g.gate_rows;
+                    const float *pa_ = g.gate + (size_t)f0 * g.gate_ld + nbase + c4, *pb_ = g.gate + (size_t)f1 * g.gate_ld + nbase + c4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { gA[j] = *reinterpret_cast<const float4 *>(pa_ + j * 16); gB[j] = *reinterpret_cast<const float4 *>(pb_ + j * 16); }
+                }
+                // 2 row fragments per batch: 8 residual loads (32 registers) in flight beside the 128 accumulator and the 32 cached gate
+                // registers (4 per batch spills)
+                constexpr int IB = MI >= 2 ? 2 : 1;
+#pragma unroll
+                for (int i0 = 0; i0 < MI; i0 += IB) {
+                    float4 rs[IB][4];
+#pragma unroll
+                    for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rs[ii][j] = *reinterpret_cast<const float4 *>(srcp + orow[i0 + ii] * g.ldo + nbase + c4 + j * 16);
+#pragma unroll
+                    for (int ii = 0; ii < IB; ++ii) {
+                        const int m = m_first + (i0 + ii) * 16;
+                        const bool first = g.gate && (m / g.gate_rows == f0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float4 val = make_float4(acc[i0 + ii][j][0] + bv[j][0], acc[i0 + ii][j][1] + bv[j][1], acc[i0 + ii][j][2] + bv[j][2],
+                                                     acc[i0 + ii][j][3] + bv[j][3]);
+                            if (g.gate) {
+                                float4 gt;
+                                if (two_groups) {   // bitwise select (a ?: on the arrays makes hipcc index them through scratch memory)
+                                    const unsigned mk = first ? 0xffffffffu : 0u;
+                                    auto sel = [mk](float a_, float b_) { return __uint_as_float((__float_as_uint(a_) & mk) | (__float_as_uint(b_) & ~mk)); };
+                                    gt = make_float4(sel(gA[j].x, gB[j].x), sel(gA[j].y, gB[j].y), sel(gA[j].z, gB[j].z), sel(gA[j].w, gB[j].w));
+                                } else {
+                                    gt = *reinterpret_cast<const float4 *>(g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nbase + c4 + j * 16);
+                                }
+                                val.x *= 1.0f + gt.x; val.y *= 1.0f + gt.y; val.z *= 1.0f + gt.z; val.w *= 1.0f + gt.w;
+                            }
+                            float4 o = rs[ii][j];
+                            o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
+                            *reinterpret_cast<float4 *>(outp + orow[i0 + ii] * g.ldo + nbase + c4 + j * 16) = o;
+                        }
+                    }
+                }
+                return;
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    float v[4][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[j][r] = acc[i][j][r] + bv[j][r];
+                            if constexpr (EPI == 1) v[j][r] = gelu_erf(v[j][r]);
+                        }
+                    if constexpr (EPI == 4) {
+                        if (rope_on) {
+                            if (rk[i] == 0) {
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const float p = (float)(h == 0 ? rp[i].x : rp[i].y);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        float sn, cs;
+                                        sincos_hw(p * inv2d[r], sn, cs);
+                                        const float u = v[2 * h][r], w = v[2 * h + 1][r];
+                                        v[2 * h][r] = u * cs - w * sn;
+                                        v[2 * h + 1][r] = w * cs + u * sn;
+                                    }
+                                }
+                            } else if (rk[i] == 1) {
+                                const float p = (float)rp[i].x;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int r = 0; r < 4; r += 2) {
+                                        float sn, cs;
+                                        sincos_hw(p * __builtin_amdgcn_exp2f(-(float)((j * 16 + c4 + r) >> 1) * (1.0f / 32.0f) * g.rope_l2theta), sn, cs);
+                                        const float u = v[j][r], w = v[j][r + 1];
+                                        v[j][r] = u * cs - w * sn;
+                                        v[j][r + 1] = w * cs + u * sn;
+                                    }
+                            }
+                        }
+                    }
+                    if constexpr (OUT16) {
+                        constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;
+                        unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow[i] * g.ldo + nbase + c4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            uint2 pk;
+                            pk.x = (unsigned)to16<D16>(v[j][0]) | ((unsigned)to16<D16>(v[j][1]) << 16);
+                            pk.y = (unsigned)to16<D16>(v[j][2]) | ((unsigned)to16<D16>(v[j][3]) << 16);
+                            *reinterpret_cast<uint2 *>(dst + j * 16) = pk;
+                        }
+                    } else {
+                        float *dst = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo + nbase + c4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(dst + j * 16) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    }
+                }
+                return;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mw0 + i * 16 + mrow;

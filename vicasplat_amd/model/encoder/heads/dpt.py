@@ -165,8 +165,10 @@ class PixelwiseTaskWithDPT(nn.Module):
             lin(f"rf{r}.out", f.out_conv)
         if self.head_type == "regression":
             c3("h0", d.head[0]); c3("h2", d.head[2]); lin("h4", d.head[4])
+            lin("h4f", d.head[4], n_pad=4)                       # fused form: [4, 128] rows (row 3 zero), bias [4]
         else:
             c3("h0", d.head[0]); lin("h4", d.head[4])
+            lin("h4f", d.head[4], n_pad=_pad_to(self.num_channels, 16))   # fused form: channels padded to a multiple of 16
         self._pk, self._pk_key = P, key
         return P
 
@@ -242,7 +244,12 @@ class PixelwiseTaskWithDPT(nn.Module):
         """-> [BT,3,H,W] view (channels-last memory) of the head output in the compute dtype, BEFORE the 'exp' post-process."""
         x, P = self._trunk(tokens, gh, gw)
         x = ops.conv3x3_nhwc(x, P["h0.w"], P["h0.b"])
-        x = ops.conv3x3_nhwc(ops.upsample2x_nhwc(x), P["h2.w"], P["h2.b"], relu_out=True)
+        x = ops.upsample2x_nhwc(x)
+        if self.compute_dtype != torch.float32 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0:
+            # conv3(128->128) -> ReLU -> conv1(128->3) in one kernel: the 128-channel activation at full resolution never reaches HBM
+            y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f.w"], P["h4f.b"], 3)          # [BT,H,W,4]
+            return y[..., :3].permute(0, 3, 1, 2)
+        x = ops.conv3x3_nhwc(x, P["h2.w"], P["h2.b"], relu_out=True)
         y = self._gemm1x1(x, P, "h4")[..., :3]
         return y.contiguous().permute(0, 3, 1, 2)
 
@@ -266,6 +273,10 @@ class PixelwiseTaskWithDPT(nn.Module):
             P7 = self._stem_weights()
             img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
         x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
+        if dt != torch.float32 and self.num_channels <= 96 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0:
+            # conv3(256->256) -> ReLU -> conv1(256->83) in one kernel (dpt_block.py:335-343; Dropout(0.1) is the identity at inference)
+            y = ops.conv3x3_head1x1_nhwc(x, P["h0.w"], None, P["h4f.w"], P["h4f.b"], self.num_channels)   # [BT,H,W,96]
+            return y[..., :self.num_channels].permute(0, 3, 1, 2)
         x = ops.conv3x3_nhwc(x, P["h0.w"], None, relu_out=True)  # Dropout(0.1) is the identity at inference
         y = self._gemm1x1(x, P, "h4")
         return y.permute(0, 3, 1, 2)

@@ -241,6 +241,31 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     return out
 
 
+def conv3x3_head1x1_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], w2: torch.Tensor, bias2: torch.Tensor, n_out: int,
+                         relu_out: bool = True) -> torch.Tensor:
+    """[N,H,W,Cin] 16-bit -> [N,H,W,ld2] 16-bit = conv1x1(act(conv3x3(x) + bias)) + bias2 in one kernel (vs_conv3x3_head1x1_nhwc): the
+    last two layers of a DPT head.  w [Cout,3,3,Cin]; w2 [C2pad, Cout] (rows >= n_out zero) with bias2 [C2pad] for Cout = 256, or
+    w2 [<= 4, 128] with bias2 [4] for Cout = 128.  The result keeps its padded channel stride (ld2 = w2 rows, or 4): slice it."""
+    dev = L.require_device(x, w, bias, w2, bias2)
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and w2.is_contiguous() and x.dtype == w.dtype == w2.dtype
+    assert x.dtype in (torch.float16, torch.bfloat16) and bias2.dtype == torch.float32 and bias2.is_contiguous()
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape == (Cout, 3, 3, Cin) and w2.shape[1] == Cout
+    if Cout == 256:
+        c2pad = ld2 = w2.shape[0]
+        assert bias2.numel() == c2pad
+    else:
+        c2pad, ld2 = n_out, 4
+        assert w2.shape[0] >= n_out and bias2.numel() >= 4
+    out = torch.empty((N, H, W, ld2), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_conv3x3_head1x1_nhwc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(w2), L.ptr(bias2), L.ptr(out), N, H, W, Cin, Cout, n_out,
+                                             c2pad, ld2, 0, int(relu_out), _DT[x.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_conv3x3_head1x1_nhwc")
+    return out
+
+
 def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: int = 0) -> torch.Tensor:
     """nn.Conv2d weight [Cout,Cin,3,3] -> [Cout,3,3,Cin(+pad)] in the operand dtype (tap-major, channel-minor)."""
     wp = w.detach().permute(0, 2, 3, 1)
