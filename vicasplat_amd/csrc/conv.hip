@@ -194,24 +194,25 @@ __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (
 // input channels per K-tile; needs Cin = 64 << cshift).  Only the staging differs from the GEMM: per staged row the source
 // is the tap-shifted pixel's 128-byte channel slice, or the zero page outside the image. ----
 struct ConvStager256 {
-    const unsigned short *in;
+    // Per staged A row (this lane's 16 bytes of it): address of the CENTRE tap's channel slice and a 9-bit mask of the taps that fall
+    // inside the image, both fixed for the whole K loop; a stage call then needs one scalar offset (tap shift x Cin + channel block),
+    // one bit test and one select per row instead of re-deriving (y, x), the bounds and the 64-bit address from packed coordinates
+    // (the implicit-GEMM loop had 4x the VALU instructions of the plain GEMM loop between the same 64 MFMAs per K-tile).
+    const unsigned short *pa[2][2];  // [A_h][round]
+    const unsigned short *pz[2];     // [round] this lane's 16 bytes of the zero page
+    unsigned vmask[2][2];            // [A_h][round] bit t: tap t is inside the image (0 for rows past M)
     const unsigned short *pw[2][2];  // [B_h][round]
-    int pix[2][2];                   // [A_h][round] linear input pixel of the centre tap
-    unsigned yx[2][2];               // packed (y << 16 | x) of the centre tap in input coordinates; 0x7fff0000 = row past M
-    int chunk[2];                    // source 16-byte chunk per round
-    int Cin, Hin, Win, cshift;
+    int Cin, Win, cshift;
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
         if (u < 2) {
             const int tap = kt >> cshift, kc = kt & ((1 << cshift) - 1);
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const int shift = dy * Win + dx;
+            const int ty = (tap * 11) >> 5;                      // tap / 3 for tap in 0..8
+            const int dy = ty - 1, dx = tap - ty * 3 - 1;
+            const long long off = (long long)(dy * Win + dx) * Cin + kc * 64;   // wave-uniform
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int y = (int)(yx[u][j] >> 16) + dy, x = (int)(yx[u][j] & 0xffffu) + dx;
-                const bool ok = (unsigned)y < (unsigned)Hin && (unsigned)x < (unsigned)Win;
-                const unsigned short *src = ok ? in + ((size_t)(pix[u][j] + shift) * Cin + kc * 64 + chunk[j] * 8)
-                                               : vs_zero_page + chunk[j] * 8;
-                glds16(src, lds + j * 1024u);
+                const bool ok = (vmask[u][j] >> tap) & 1u;
+                glds16(ok ? pa[u][j] + off : pz[j], lds + j * 1024u);
             }
         } else {
             glds16(pw[u - 2][0] + kt * 64, lds);
@@ -241,21 +242,28 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     const int m0 = tm * 256, n0 = tn * 256;
 
     ConvStager256 st;
-    st.in = g.in; st.Cin = g.Cin; st.Hin = g.Hin; st.Win = g.Win; st.cshift = cshift;
+    st.Cin = g.Cin; st.Win = g.Win; st.cshift = cshift;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = unit_row256(wid, j, lane);
-        st.chunk[j] = unit_src_chunk256(q, lane);
+        const int chunk = unit_src_chunk256(q, lane);
+        st.pz[j] = vs_zero_page + chunk * 8;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int m = m0 + unit_a_tile_row256(q, h);
             const int p = m < M ? m : 0;
             const int nimg = p / HW, rem = p - nimg * HW;
             const int y = (rem / g.W) * g.stride, x = (rem % g.W) * g.stride;
-            st.pix[h][j] = (nimg * g.Hin + y) * g.Win + x;
-            st.yx[h][j] = m < M ? ((unsigned)y << 16) | (unsigned)x : 0x7fff0000u;
+            st.pa[h][j] = g.in + ((size_t)((nimg * g.Hin + y) * g.Win + x) * g.Cin + chunk * 8);
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (m < M && (unsigned)yy < (unsigned)g.Hin && (unsigned)xx < (unsigned)g.Win) vm |= 1u << t;
+            }
+            st.vmask[h][j] = vm;
             const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.Cout - 1);
-            st.pw[h][j] = g.w + (size_t)rw_ * K + st.chunk[j] * 8;
+            st.pw[h][j] = g.w + (size_t)rw_ * K + chunk * 8;
         }
     }
     f4 acc[8][4];

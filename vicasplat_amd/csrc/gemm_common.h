@@ -140,6 +140,27 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + copysignf(e, v));
 }
 
+// two at a time on the packed-f32 VALU forms (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of polynomial per issue slot; rcp / exp stay
+// scalar).  The GELU epilogue of a one-workgroup-per-CU kernel is pure exposed VALU time (measured: +10 us on a 35 us tile).
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v gelu_erf2(f2v v) {
+    f2v x;
+    x.x = fabsf(v.x); x.y = fabsf(v.y);
+    x = x * 0.70710678118654752440f;
+    f2v t = x * 0.3275911f + 1.0f;
+    t.x = __frcp_rn(t.x); t.y = __frcp_rn(t.y);
+    f2v p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f2v nx2 = x * x * (-1.4426950408889634f);     // -x^2 * log2(e): exp2 below
+    f2v e2;
+    e2.x = __builtin_amdgcn_exp2f(nx2.x); e2.y = __builtin_amdgcn_exp2f(nx2.y);
+    f2v e = 1.0f - p * t * e2;                           // erf(|v| / sqrt 2)
+    e.x = copysignf(e.x, v.x); e.y = copysignf(e.y, v.y);
+    return v * 0.5f * (e + 1.0f);
+}
+
 // cos/sin of an angle given in radians on the hardware v_cos/v_sin (argument in revolutions; |angle| stays < 2^8 rev)
 __device__ __forceinline__ void sincos_hw(float ang, float &sn, float &cs) {
     const float rev = ang * 0.15915494309189535f;
@@ -164,7 +185,7 @@ __device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {
 // transpose and no barrier; RoPE pairs (c, c+16) are fragments j / j+1 of the same lane, interleaved pairs (2p, 2p+1) are
 // neighbouring registers.  mw0 / nbase = first output row / column of the wave's (16*MI) x 64 tile. ----
 template <int BF16, int EPI, int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *, int, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, void *lds_scratch, int, int lane) {
     // (opaque copy of the lane id: keeps the compiler from hoisting the epilogue's per-lane constants -- bias, RoPE frequencies --
     //  above the main loop, where they cost a spill that is reloaded inside it)
     asm volatile("" : "+v"(lane));
@@ -188,10 +209,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
     }
     [[maybe_unused]] float inv2d[4] = {0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] bool rope_on = false;
+    // 2-D RoPE angles take few distinct values (position 0..gh x 16 frequencies): the workgroup tabulates (sin, cos) for positions
+    // 0..kRopeTabPos-1 once in the (now free) LDS ring -- 2 v_sin / v_cos per thread instead of 64 + 64 per lane in the interior-tile
+    // path -- with the SAME expression the direct evaluation uses, so the results are bit-identical; larger positions fall back to it.
+    constexpr int kRopeTabPos = 64;
+    [[maybe_unused]] float2 *const rtab = reinterpret_cast<float2 *>(lds_scratch);
     if constexpr (EPI == 4) {
         rope_on = nbase < 2 * g.rope_C && full_n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) inv2d[r] = __builtin_amdgcn_exp2f(-(float)(c4 + r) * (1.0f / 16.0f) * g.rope_l2base);
+        for (int e = threadIdx.x; e < kRopeTabPos * 16; e += blockDim.x) {
+            float sn, cs;
+            sincos_hw((float)(e >> 4) * __builtin_amdgcn_exp2f(-(float)(e & 15) * (1.0f / 16.0f) * g.rope_l2base), sn, cs);
+            rtab[e] = make_float2(sn, cs);
+        }
+        __syncthreads();
     }
     constexpr bool OUT16 = (EPI == 0 || EPI == 1 || EPI == 4) && BF16 != kDtF32;   // f32 operands: every epilogue stores floats
     const bool vec_ok = full_n && (OUT16 ? (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 7) == 0)
@@ -280,20 +312,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v[j][r] = acc[i][j][r] + bv[j][r];
-                            if constexpr (EPI == 1) v[j][r] = gelu_erf(v[j][r]);
+                        for (int r = 0; r < 4; r += 2) {
+                            if constexpr (EPI == 1) {
+                                const f2v gl = gelu_erf2(f2v{acc[i][j][r] + bv[j][r], acc[i][j][r + 1] + bv[j][r + 1]});
+                                v[j][r] = gl.x; v[j][r + 1] = gl.y;
+                            } else {
+                                v[j][r] = acc[i][j][r] + bv[j][r];
+                                v[j][r + 1] = acc[i][j][r + 1] + bv[j][r + 1];
+                            }
                         }
                     if constexpr (EPI == 4) {
                         if (rope_on) {
                             if (rk[i] == 0) {
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
-                                    const float p = (float)(h == 0 ? rp[i].x : rp[i].y);
+                                    const int pi = h == 0 ? rp[i].x : rp[i].y;
+                                    const float p = (float)pi;
+                                    float4 sc01, sc23;   // (sin, cos) of frequencies c4, c4+1 | c4+2, c4+3
+                                    const bool tab = (unsigned)pi < (unsigned)kRopeTabPos;
+                                    if (tab) {
+                                        sc01 = *reinterpret_cast<const float4 *>(rtab + pi * 16 + c4);
+                                        sc23 = *reinterpret_cast<const float4 *>(rtab + pi * 16 + c4 + 2);
+                                    }
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         float sn, cs;
-                                        sincos_hw(p * inv2d[r], sn, cs);
+                                        if (tab) {
+                                            sn = r == 0 ? sc01.x : r == 1 ? sc01.z : r == 2 ? sc23.x : sc23.z;
+                                            cs = r == 0 ? sc01.y : r == 1 ? sc01.w : r == 2 ? sc23.y : sc23.w;
+                                        } else {
+                                            sincos_hw(p * inv2d[r], sn, cs);
+                                        }
                                         const float u = v[2 * h][r], w = v[2 * h + 1][r];
                                         v[2 * h][r] = u * cs - w * sn;
                                         v[2 * h + 1][r] = w * cs + u * sn;
