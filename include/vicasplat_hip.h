@@ -146,6 +146,13 @@ int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, const float *b
                      int32_t mod_rows, int32_t mod_ld, void *out, int64_t ldo, int32_t out_dtype, int32_t M, int32_t C,
                      float eps, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream);
 
+/* Tiny f32 linear layers of the camera-token path (intrinsic embedding 9 -> 1024, backbone_vica.py:393,535-536; pose / fov heads
+ * ReLU -> Linear, vicasplat.py:118-138): out[m,n] = sum_k act(x[m,k]) w[n,k] + bias[n], relu_in 0 | 1; all f32, strides in elements. */
+int vs_linear_f32(const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias, float *out, int64_t ldo, int32_t M, int32_t N,
+                  int32_t K, int32_t relu_in, vs_stream_t stream);
+/* out[i] = silu(x[i]), x f32 -> out_dtype 0 f32 / 1 f16 / 2 bf16 (the SiLU in front of the AdaLN projections, backbone_vica.py:210-212); n % 4 == 0 */
+int vs_silu_cast(const float *x, void *out, int64_t n, int32_t out_dtype, vs_stream_t stream);
+
 /* out = epilogue(A[M,K] * W[N,K]^T + bias).  epilogue: 0 store 16-bit, 1 exact-erf GELU then store 16-bit,
  * 2 f32 residual update out += (1 + gate[row / gate_rows]) * (.), 3 store f32.  K % 64 == 0; lda/ldw % 8 == 0.
  * Output row mapping (grp_*) as in vs_layernorm_mod; a_grp_* is the same mapping applied to the rows of A that are

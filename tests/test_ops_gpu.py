@@ -918,3 +918,19 @@ def test_conv3x3_head1x1_fused_matches_the_two_layer_path(dt, Cin, Cout, C2):
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dt).float(), None if b is None else b, padding=1).relu().permute(0, 2, 3, 1)
     ref = ref.reshape(-1, Cout) @ w2.to(dt).float().t() + b2
     assert (y[..., :C2].reshape(-1, C2).float() - ref).abs().max() <= 4 * tol
+
+
+def test_linear_f32_and_silu_cast():
+    """The camera-token path's tiny f32 layers and the AdaLN SiLU on our own kernels (no vendor BLAS launch in the inference step)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for M, N, K, relu in ((192, 1024, 9, False), (168, 8, 768, True), (3, 2, 192, True), (1, 5, 70, False)):
+        x = torch.randn(M, K, generator=g).to(d); w = torch.randn(N, K, generator=g).to(d); b = torch.randn(N, generator=g).to(d)
+        ref = (x.relu() if relu else x).double() @ w.double().t() + b.double()
+        got = ops.linear_f32(x, w, b, relu_in=relu)
+        assert got.shape == (M, N) and (got.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    x = torch.randn(24, 768, generator=g).to(d) * 3
+    for dt, tol in ((torch.float32, 1e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+        y = ops.silu_cast(x, dt)
+        assert y.dtype == dt and (y.float() - F.silu(x)).abs().max() <= tol * F.silu(x).abs().max()

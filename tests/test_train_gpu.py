@@ -358,3 +358,83 @@ def test_gradient_checkpointing_recomputes_the_same_step():
           f"activation peak {out[0][2] / 2**20:.0f} MiB -> {out[2][2] / 2**20:.0f} MiB")
     assert s_ck <= max(3 * s_base, 1e-5), (s_base, s_ck)
     assert out[2][2] < out[0][2]
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose incoming gradient is rounded to the 16-bit operand dtype: mirrors a place where the HIP backward materialises
+    a gradient in 16 bit."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def test_encoder_block_backward_tight_against_rounding_matched_autograd():
+    """the loose bounds of the gradient tests above come from 16-bit rounding of the FORWARD activations, which
+    hides a few-% defect of one operator.  Here the float64 autograd reference rounds exactly where the HIP block does -- forward: LN
+    outputs, q|k|v after RoPE, softmax probabilities, attention output, fc1 pre-activation, GELU output; backward: every gradient the
+    kernels materialise in 16 bit -- with straight-through rounding, so that only summation order is left: all 13 gradients of a
+    ViT-L block must agree to 1.5e-3 of their scale (f16; measured <= 5.4e-4)."""
+    from vicasplat_amd import train
+    dt = torch.float16
+    d = torch.device("cuda:0")
+    frames, gh, C, H = 2, 16, 1024, 16
+    tokens = gh * gh + 1
+    M = frames * tokens
+    g = torch.Generator().manual_seed(5)
+    n = "backbone.enc_blocks.0"
+    W = {}
+    def mk(name, shape, std):
+        W[name] = torch.randn(*shape, generator=g) * std
+    mk(n + ".norm1.weight", (C,), 0.1); W[n + ".norm1.weight"] += 1
+    mk(n + ".norm1.bias", (C,), 0.1)
+    mk(n + ".norm2.weight", (C,), 0.1); W[n + ".norm2.weight"] += 1
+    mk(n + ".norm2.bias", (C,), 0.1)
+    for nm, shp in ((".attn.qkv", (3 * C, C)), (".attn.proj", (C, C)), (".mlp.fc1", (4 * C, C)), (".mlp.fc2", (C, 4 * C))):
+        mk(n + nm + ".weight", shp, 1.0 / math.sqrt(shp[1])); mk(n + nm + ".bias", (shp[0],), 0.1)
+    x0 = torch.randn(frames, tokens, C, generator=g)
+    dy = torch.randn(frames, tokens, C, generator=g) * 0.1
+    pos = er.patch_positions(frames, gh, gh)
+    extra = pos[:, :1].clone(); extra[:, :, 0] += pos[:, -1:, 0] + 1
+    pos = torch.cat([pos, extra], 1)
+
+    rt = lambda t: t + (t.to(dt).to(t.dtype) - t).detach()            # forward rounding, straight-through gradient
+    rg = lambda t: _RoundGrad.apply(t, dt)
+    f64 = torch.float64
+    Wr = {k: (v.to(dt) if k.endswith("weight") and v.dim() == 2 else v).to(f64).requires_grad_() for k, v in W.items()}
+    xr = x0.to(f64).requires_grad_()
+    h1 = rg(rt(er.ln(Wr, n + ".norm1", xr)))
+    qkv = er.lin(Wr, n + ".attn.qkv", h1).reshape(frames, -1, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    q, k, v = rg(rt(er.rope2d(qkv[0], pos, 100.0))), rg(rt(er.rope2d(qkv[1], pos, 100.0))), rg(rt(qkv[2]))
+    s = rg((q @ k.transpose(-2, -1)) * 0.125)
+    att = rg(rt(er.heads_merge(rt(s.softmax(-1)) @ v)))
+    xm = xr + rg(er.lin(Wr, n + ".attn.proj", att))
+    h2 = rg(rt(er.ln(Wr, n + ".norm2", xm)))
+    z = rg(rt(er.lin(Wr, n + ".mlp.fc1", h2)))
+    a = rg(rt(torch.nn.functional.gelu(z)))
+    xo = xm + rg(er.lin(Wr, n + ".mlp.fc2", a))
+    (xo * dy.to(f64)).sum().backward()
+
+    f = lambda name: W[name].to(d)
+    p = train.EncBlockParams(ln1_w=f(n + ".norm1.weight"), ln1_b=f(n + ".norm1.bias"), qkv_w=f(n + ".attn.qkv.weight").to(dt),
+                             qkv_b=f(n + ".attn.qkv.bias"), proj_w=f(n + ".attn.proj.weight").to(dt), proj_b=f(n + ".attn.proj.bias"),
+                             ln2_w=f(n + ".norm2.weight"), ln2_b=f(n + ".norm2.bias"), fc1_w=f(n + ".mlp.fc1.weight").to(dt),
+                             fc1_b=f(n + ".mlp.fc1.bias"), fc2_w=f(n + ".mlp.fc2.weight").to(dt), fc2_b=f(n + ".mlp.fc2.bias"))
+    pos_d = pos.reshape(M, 2).to(torch.int32).contiguous().to(d)
+    x_out, tape = train.enc_block_forward_train(x0.reshape(M, C).to(d), p, pos_d, frames=frames, tokens=tokens, heads=H)
+    rel = lambda a_, b_: float((a_.detach().cpu().double() - b_.detach()).abs().max() / (b_.detach().abs().max() + 1e-30))
+    e_fwd = rel(x_out, xo.reshape(M, C))
+    dx_in, grads = train.enc_block_backward(dy.reshape(M, C).to(d), tape, p)
+    errs = {"dx": rel(dx_in, xr.grad.reshape(M, C))}
+    for ours, ref in (("ln1_w", ".norm1.weight"), ("ln1_b", ".norm1.bias"), ("qkv_w", ".attn.qkv.weight"), ("qkv_b", ".attn.qkv.bias"),
+                      ("proj_w", ".attn.proj.weight"), ("proj_b", ".attn.proj.bias"), ("ln2_w", ".norm2.weight"), ("ln2_b", ".norm2.bias"),
+                      ("fc1_w", ".mlp.fc1.weight"), ("fc1_b", ".mlp.fc1.bias"), ("fc2_w", ".mlp.fc2.weight"), ("fc2_b", ".mlp.fc2.bias")):
+        errs[ours] = rel(grads[ours], Wr[n + ref].grad)
+    print("rounding-matched block: forward", f"{e_fwd:.2e}", {k_: f"{v_:.2e}" for k_, v_ in errs.items()})
+    assert e_fwd <= 5e-4
+    assert max(errs.values()) <= 1.5e-3, errs          # measured 2e-4 .. 5.4e-4

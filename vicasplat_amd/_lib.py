@@ -143,6 +143,10 @@ def lib() -> C.CDLL:
             L.vs_conv7x7_rgb_nhwc.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_conv3x3_nhwc.restype = C.c_int
             L.vs_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_linear_f32.restype = C.c_int
+            L.vs_linear_f32.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
+            L.vs_silu_cast.restype = C.c_int
+            L.vs_silu_cast.argtypes = [vp, vp, i64, i32, vp]
             L.vs_conv3x3_head1x1_nhwc.restype = C.c_int
             L.vs_conv3x3_head1x1_nhwc.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 11 + [vp]
             L.vs_upsample2x_nhwc.restype = C.c_int

@@ -144,7 +144,65 @@ rope_qk_kernel(unsigned short *__restrict__ buf, long long ld, int rows, int H, 
     }
 }
 
+// ---- tiny f32 linear layers of the camera-token path: out[m, n] = sum_k act(x[m, k]) w[n, k] + b[n] in f32 (the intrinsic embedding
+// 9 -> 1024, backbone_vica.py:393,535-536; the pose / fov heads ReLU -> Linear(768 -> 8 | 2), vicasplat.py:118-138,179-205; kept in f32
+// for pose accuracy).  Latency-bound work of a few thousand outputs: one wave per output, lanes stride K, wave reduction. ----
+__global__ void __launch_bounds__(256)
+linear_f32_kernel(const float *__restrict__ x, long long ldx, const float *__restrict__ w, long long ldw, const float *__restrict__ b,
+                  float *__restrict__ out, long long ldo, int M, int N, int K, int relu_in) {
+    const int lane = threadIdx.x & 63;
+    const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (long long)M * N) return;
+    const int m = (int)(o / N), n = (int)(o - (long long)m * N);
+    const float *xr = x + m * ldx, *wr = w + n * ldw;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float v = xr[k];
+        if (relu_in) v = fmaxf(v, 0.f);
+        s = fmaf(v, wr[k], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[m * ldo + n] = s + (b ? b[n] : 0.f);
+}
+
+// silu(x) (f32) -> 16-bit / f32: the AdaLN modulation input SiLU(cam_norm(camera token)) (backbone_vica.py:210-212) as the GEMM operand
+template <int DT>
+__global__ void __launch_bounds__(256) silu_cast_kernel(const float *__restrict__ x, typename Out<DT>::T *__restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    auto f = [](float a) { return a / (1.0f + __expf(-a)); };
+    Out<DT>::st4(out + 4 * i, f(v.x), f(v.y), f(v.z), f(v.w));
+}
+
 }  // namespace
+
+extern "C" int vs_linear_f32(const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias, float *out, int64_t ldo, int32_t M,
+                             int32_t N, int32_t K, int32_t relu_in, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && w && out, "vs_linear_f32: null pointer");
+    VS_CHECK(M >= 0 && N > 0 && K > 0, "vs_linear_f32: bad sizes");
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)vs::cdiv64((int64_t)M * N, 4)), dim3(256), 0, stream, x, (long long)ldx, w, (long long)ldw,
+                       bias, out, (long long)ldo, M, N, K, relu_in);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_silu_cast(const float *x, void *out, int64_t n, int32_t out_dtype, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && out, "vs_silu_cast: null pointer");
+    VS_CHECK(n % 4 == 0 && out_dtype >= 0 && out_dtype <= 2, "vs_silu_cast: n must be a multiple of 4, out_dtype 0 f32 / 1 f16 / 2 bf16");
+    if (n <= 0) return 0;
+    dim3 grid((unsigned)vs::cdiv64(n / 4, 256)), block(256);
+    switch (out_dtype) {
+        case 0: hipLaunchKernelGGL(silu_cast_kernel<0>, grid, block, 0, stream, x, (float *)out, (long long)(n / 4)); break;
+        case 1: hipLaunchKernelGGL(silu_cast_kernel<1>, grid, block, 0, stream, x, (unsigned short *)out, (long long)(n / 4)); break;
+        default: hipLaunchKernelGGL(silu_cast_kernel<2>, grid, block, 0, stream, x, (unsigned short *)out, (long long)(n / 4)); break;
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, const float *b, const float *scale,
                                 const float *shift, int32_t mod_rows, int32_t mod_ld, void *out, int64_t ldo,

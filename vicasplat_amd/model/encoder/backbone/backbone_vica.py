@@ -235,7 +235,7 @@ class VicaNet(nn.Module):
         xe = torch.empty(BT * N, Ce, **f32)
         ops.gemm(cols, W["patch"], self.patch_embed.proj.bias, xe, ops.EPI_STORE32, grp_in=n, grp_out=N, grp_off=0)
         if use_intr:
-            xe.view(BT, N, Ce)[:, n] = F.linear(intrinsics.reshape(BT, 9).float(), self.intrinsic_encoder.weight, self.intrinsic_encoder.bias)
+            xe.view(BT, N, Ce)[:, n] = ops.linear_f32(intrinsics.reshape(BT, 9), self.intrinsic_encoder.weight, self.intrinsic_encoder.bias)
 
         # ---- 24 encoder blocks (blocks.py:94-130) ----
         h = torch.empty(BT * N, Ce, **f16)
@@ -279,7 +279,7 @@ class VicaNet(nn.Module):
         for i, blk in enumerate(self.dec_blocks):
             # -- AdaLN parameters from the frame's camera token (:289-293, :194-212)
             ops.layernorm_mod(cam, blk.cam_norm1.weight, blk.cam_norm1.bias, cn)
-            ops.gemm(F.silu(cn).to(dt), W[f"d{i}.mod1"], blk.modulation1.proj.bias, mod1, ops.EPI_STORE32)
+            ops.gemm(ops.silu_cast(cn, dt), W[f"d{i}.mod1"], blk.modulation1.proj.bias, mod1, ops.EPI_STORE32)
             # -- video/camera self-attention over the interleaved [cam_t, img_t] sequence (:76-126)
             ops.layernorm_mod(xd, blk.norm1.weight, blk.norm1.bias, hmix, scale=mod1[:, :Cd], shift=mod1[:, Cd:2 * Cd],
                               mod_rows=N, grp_in=N, grp_out=M2, grp_off=1)
@@ -293,7 +293,7 @@ class VicaNet(nn.Module):
             # -- second modulation set (:306-318)
             ops.layernorm_mod(cam, blk.cam_norm2.weight, blk.cam_norm2.bias, cn)
             cn16.copy_(cn)
-            ops.gemm(F.silu(cn).to(dt), W[f"d{i}.mod2"], blk.modulation2.proj.bias, mod2, ops.EPI_STORE32)
+            ops.gemm(ops.silu_cast(cn, dt), W[f"d{i}.mod2"], blk.modulation2.proj.bias, mod2, ops.EPI_STORE32)
             # -- cross-neighbour attention (:152-191): keys/values of frames t-1, t+1 gathered by row segments
             ops.layernorm_mod(xd, blk.norm2.weight, blk.norm2.bias, h, scale=mod2[:, :Cd], shift=mod2[:, Cd:2 * Cd], mod_rows=N)
             ops.gemm_qkv_rope(h, W[f"d{i}.cqkv"], W[f"d{i}.cqkv_b"], qkv, Cd, tabs["pos_img"], None, 100.0, 1.0)

@@ -125,14 +125,15 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         video = image.permute(0, 2, 1, 3, 4)
         _, camera_embeds, _global, interms = self.backbone(video, context.get("intrinsics", None))
 
-        pred = self.camera_extrinsic_head(camera_embeds)
+        head = self.camera_extrinsic_head[1]                      # nn.Sequential(ReLU, Linear): ReLU fused into the f32 linear kernel
+        pred = ops.linear_f32(camera_embeds, head.weight, head.bias, relu_in=True)
         pred = torch.cat([pred[..., :3], pred[..., 3:4] + 1.0, pred[..., 4:]], -1)
         pred_extrins = pred / pred[..., :4].norm(dim=-1, keepdim=True)
         eye = torch.eye(4, device=dev, dtype=pred_extrins.dtype).expand(B, 1, 4, 4)
         pred_extrinsics_4x4 = torch.cat([eye, camera_matrix_from_dq_array(pred_extrins)], dim=1)
         pred_intrins = pred_K = None
         if _global is not None:      # no intrinsic embedding: predict the field of view -> pinhole K (vicasplat.py:201-205, cam_utils.py:220-234)
-            pred_intrins = self.camera_intrinsic_head(_global)
+            pred_intrins = ops.linear_f32(_global, self.camera_intrinsic_head[1].weight, self.camera_intrinsic_head[1].bias, relu_in=True)
             pred_K = torch.eye(3, device=dev, dtype=torch.float32).repeat(B, 1, 1)
             pred_K[:, 0, 0], pred_K[:, 1, 1] = 0.5 / torch.tan(pred_intrins[:, 0] * 0.5), 0.5 / torch.tan(pred_intrins[:, 1] * 0.5)
             pred_K[:, 0, 2] = pred_K[:, 1, 2] = 0.5

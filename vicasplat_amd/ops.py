@@ -40,6 +40,35 @@ def layernorm_mod(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out
     return out
 
 
+def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
+    """[..., K] f32 @ w[N, K]^T + bias in f32 (vs_linear_f32): the tiny camera-token layers (intrinsic embedding, pose / fov heads)."""
+    dev = L.require_device(x, w, bias)
+    x2 = x.reshape(-1, x.shape[-1]).float()
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    wf = w.detach().float()
+    if wf.stride(1) != 1:
+        wf = wf.contiguous()
+    bf = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty((x2.shape[0], wf.shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_linear_f32(L.ptr(x2), x2.stride(0), L.ptr(wf), wf.stride(0), L.ptr(bf), L.ptr(out), out.stride(0), x2.shape[0], wf.shape[0],
+                                   x2.shape[1], int(relu_in), L.stream_ptr(dev))
+    L.check(rc, "vs_linear_f32")
+    return out.view(*x.shape[:-1], wf.shape[0])
+
+
+def silu_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """silu(x) of an f32 tensor in `dtype` (one pass; the GEMM operand of the AdaLN projections)."""
+    dev = L.require_device(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0
+    out = torch.empty(x.shape, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_silu_cast(L.ptr(x), L.ptr(out), x.numel(), _DT[dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_silu_cast")
+    return out
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epilogue: int, *,
          gate: Optional[torch.Tensor] = None, gate_rows: int = 0, grp_in: int = 0, grp_out: int = 0, grp_off: int = 0,
          M: Optional[int] = None, a_grp_in: int = 0, a_grp_out: int = 0, a_grp_off: int = 0) -> torch.Tensor:
