@@ -227,3 +227,38 @@ def test_loss_scaler_backs_off_and_recovers():
     for _ in range(3):
         s.update(True)
     assert s.scale == 1024.0
+
+
+def _fake_lpips_state_dict(seed=0):
+    """Key names and shapes of lpips.LPIPS(net='vgg').state_dict() with seeded random values (structure test only: the real weights
+    are not available offline and LossLpips never substitutes them)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for s_, (idxs, ch) in enumerate(zip(callers.LossLpips._SLICES, callers.LossLpips._CHANNELS)):
+        for j, li in enumerate(idxs):
+            sd[f"net.slice{s_ + 1}.{li}.weight"] = torch.randn(ch[j + 1], ch[j], 3, 3, generator=g) * (2.0 / (9 * ch[j])) ** 0.5
+            sd[f"net.slice{s_ + 1}.{li}.bias"] = torch.randn(ch[j + 1], generator=g) * 0.01
+        sd[f"lin{s_}.model.1.weight"] = torch.rand(1, ch[-1], 1, 1, generator=g)
+    return sd
+
+
+def test_lpips_structure_and_properties():
+    """src/loss/loss_lpips.py:27-54 with the LPIPS-VGG algorithm restated: taps / channels of VGG-16, identity gives 0, symmetric,
+    non-negative (non-negative heads), differentiable, gated by apply_after_step, and refuses to run without weights."""
+    import pytest
+    with pytest.raises(RuntimeError):
+        callers.LossLpips(None)
+    loss = callers.LossLpips(_fake_lpips_state_dict(), weight=0.05, apply_after_step=3)
+    g = torch.Generator().manual_seed(1)
+    a = torch.rand(1, 2, 3, 64, 64, generator=g)
+    b = torch.rand(1, 2, 3, 64, 64, generator=g)
+    taps = loss.features(a.flatten(0, 1))
+    assert [t.shape[1] for t in taps] == [64, 128, 256, 512, 512] and [t.shape[-1] for t in taps] == [64, 32, 16, 8, 4]
+    assert float(loss(a, b, global_step=0)) == 0.0
+    d_ab, d_ba, d_aa = float(loss(a, b, 3)), float(loss(b, a, 3)), float(loss(a, a, 3))
+    assert d_aa == 0.0 and d_ab > 0 and abs(d_ab - d_ba) <= 1e-6 * d_ab
+    near = float(loss(a, (a + 0.01 * (b - a)).clamp(0, 1), 3))
+    assert near < 0.2 * d_ab
+    x = a.clone().requires_grad_()
+    loss(x, b, 3).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0

@@ -1,9 +1,13 @@
-"""Aggregate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs) of bench.py into profiles/round1_pmc_traffic.json.
+"""Aggregate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs) of bench.py into profiles/round2_pmc_traffic.json.
 
 usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_executed> <out.json> [scenes_per_gpu=24]
 (bench.py only uses the file when its "workload" block matches the workload being benchmarked: the default 24 scenes x 8 views x 12 targets)
 HBM bytes per kernel family, gfx950 corrections as MI355X_MICROARCH.md prescribes: rocprofv3 reports FETCH_SIZE / WRITE_SIZE
 in KiB; FETCH_SIZE counts a wide coalesced read at half its size on gfx950 (x2); WRITE_SIZE is taken as reported.
+Round 2: the x2 is NOT applied to render_kernel, whose reads are 16-byte gathers of 48-byte records: calibrated with
+tools/probe/fetch_calib.hip (profiles/round2_fetch_calibration.md) -- a streaming read of 1 GiB reports 512 MiB (x2 confirmed), a random
+gather of 16 M 48-byte records reports 1.66x the requested bytes, which is already the line-granular traffic (doubling it would exceed the
+HBM rate the kernel's duration allows).
 """
 import csv, json, sys, collections
 
@@ -20,8 +24,11 @@ def family(name):
     return "other"
 
 
+GATHER_KERNELS = ("render_kernel",)   # FETCH_SIZE taken as reported (calibrated), everything else x2
+
+
 def load(path, counter):
-    per = collections.defaultdict(lambda: [0, 0.0])  # family -> [dispatches, KiB]
+    per = collections.defaultdict(lambda: [0, 0.0])  # family -> [dispatches, KiB (fetch: already corrected)]
     seen = set()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -30,7 +37,15 @@ def load(path, counter):
         key = (r["Dispatch_Id"], fam)
         if key not in seen:
             seen.add(key); per[fam][0] += 1
-        per[fam][1] += float(r["Counter_Value"])
+        v = float(r["Counter_Value"])
+        if counter == "FETCH_SIZE" and not any(k in r["Kernel_Name"] for k in GATHER_KERNELS):
+            v *= 2.0
+        per[fam][1] += v
+        if fam == "rasterizer":     # per-kernel detail of the rasterizer
+            short = next(k for k in FAMILIES[3][1] if k in r["Kernel_Name"])
+            per["rasterizer/" + short][1] += v
+            if (r["Dispatch_Id"], short) not in seen:
+                seen.add((r["Dispatch_Id"], short)); per["rasterizer/" + short][0] += 1
     return per
 
 
@@ -41,13 +56,13 @@ def main():
     kernels = {}
     for fam in sorted(set(f) | set(w)):
         n = max(f[fam][0], w[fam][0], 1)
-        fb, wb = 2.0 * f[fam][1] * 1024.0, w[fam][1] * 1024.0
+        fb, wb = f[fam][1] * 1024.0, w[fam][1] * 1024.0
         kernels[fam] = dict(launches=n, fetch_kib_raw=f[fam][1], write_kib_raw=w[fam][1], fetch_bytes_corrected_per_launch=int(fb / n),
                             write_bytes_per_launch=int(wb / n), hbm_bytes_per_launch=int((fb + wb) / n),
                             hbm_bytes_per_step=int((fb + wb) / steps))
     json.dump(dict(command="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py "
-                           "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline", steps=steps,
-                   units="KiB as reported; fetch corrected x2 for gfx950 (MI355X_MICROARCH.md, HBM section); write as reported",
+                           "--mode infer --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-f32", steps=steps,
+                   units="KiB as reported; fetch corrected x2 for gfx950 (MI355X_MICROARCH.md, HBM section) except render_kernel (16-byte gathers: x1, calibrated); write as reported",
                    kernels=kernels, workload=dict(scenes_per_gpu=scenes, context_views=8, target_views=12)), open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:12s} launches {v['launches']:6d}  HBM/launch {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB   HBM/step {v['hbm_bytes_per_step'] / 1e9:8.2f} GB")

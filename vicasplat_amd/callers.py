@@ -12,6 +12,7 @@ scripts do around the encoder/decoder:
   * `inference`, `interpolate_extrinsics`, `interpolate_intrinsics`, `render_video_interpolation` — demo.py:180-243 with
     src/visualization/camera_trajectory/interpolation.py (the 70-view demo video: cameras share ONE Gaussian set)
   * `camera_loss`, `camera_dq_loss` — src/loss/loss_camera.py:30-80 (dual-quaternion algebra of src/misc/dq.py restated)
+  * `LossLpips` — src/loss/loss_lpips.py:27-54 (published LPIPS-VGG algorithm; the pretrained weights must be supplied, see the class)
   * `configure_optimizer`, `training_step` — ModelWrapper.configure_optimizers / training_step (model_wrapper.py:884-951,
     184-321): AdamW(lr, wd 0.05, betas 0.9/0.95) with the backbone-lr multiplier, encoder -> rasterizer -> MSE ->
     backward on the HIP kernels (vicasplat_amd.autograd) -> optional gradient all-reduce -> clip 0.5 -> step.
@@ -417,6 +418,68 @@ def camera_loss(pred_extrins: Tensor, context_extrinsics: Tensor, weight: float 
     tgt = camera_dq_array_from_Rt(E[..., :3, :3], E[..., :3, 3])
     l1 = (pred_extrins - tgt).abs().mean()
     return weight * ((camera_dq_loss(pred_extrins, tgt) + l1) if use_dq_loss else l1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# LPIPS(VGG) -- src/loss/loss_lpips.py:27-54.  The reference instantiates `lpips.LPIPS(net="vgg")` (un-vendored pip package, pretrained
+# VGG-16 + learned linear heads downloaded at construction): neither the package nor its weights exist offline, so the published
+# algorithm is restated here and the WEIGHTS must be supplied -- `torch.save(lpips.LPIPS(net="vgg").state_dict(), path)` on a machine that
+# has them.  Without weights the constructor raises; nothing is silently substituted.  The loss network runs on PyTorch convolutions (it
+# is not part of the encoder / rasterizer hot path and has no counterpart kernel in this library).
+# ---------------------------------------------------------------------------------------------------------------------------
+class LossLpips(torch.nn.Module):
+    """LPIPS with the VGG-16 backbone ("vgg" variant, v0.1): inputs in [0, 1] (`normalize=True` of loss_lpips.py:48-52), scaling layer,
+    the five ReLU taps relu1_2 / 2_2 / 3_3 / 4_3 / 5_3, channel-unit-normalised squared differences, non-negative 1x1 linear heads, spatial
+    mean, sum over the taps.  forward(prediction [b,v,3,h,w], target [b,v,3,h,w], global_step) -> weight * mean over images; zero before
+    `apply_after_step` (config/loss/lpips.yaml)."""
+    _SLICES = ((0, 2), (5, 7), (10, 12, 14), (17, 19, 21), (24, 26, 28))   # torchvision vgg16.features conv indices per slice
+    _CHANNELS = ((3, 64, 64), (64, 128, 128), (128, 256, 256, 256), (256, 512, 512, 512), (512, 512, 512, 512))
+
+    def __init__(self, weights, weight: float = 0.05, apply_after_step: int = 0):
+        super().__init__()
+        if weights is None:
+            raise RuntimeError("LossLpips needs the state_dict of lpips.LPIPS(net='vgg') (pretrained VGG-16 + linear heads); it is not "
+                               "available offline and is never replaced by random weights")
+        sd = torch.load(weights, map_location="cpu") if isinstance(weights, (str, Path)) else dict(weights)
+        self.weight, self.apply_after_step = weight, apply_after_step
+        self.register_buffer("shift", torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("scale", torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1), persistent=False)
+        for s_, idxs in enumerate(self._SLICES):
+            for j, li in enumerate(idxs):
+                w, b = sd[f"net.slice{s_ + 1}.{li}.weight"], sd[f"net.slice{s_ + 1}.{li}.bias"]
+                assert tuple(w.shape) == (self._CHANNELS[s_][j + 1], self._CHANNELS[s_][j], 3, 3), (s_, li, tuple(w.shape))
+                self.register_buffer(f"w{s_}_{j}", w.float().clone(), persistent=False)
+                self.register_buffer(f"b{s_}_{j}", b.float().clone(), persistent=False)
+            lin = sd.get(f"lin{s_}.model.1.weight", sd.get(f"lins.{s_}.model.1.weight"))
+            assert lin is not None and lin.shape[1] == self._CHANNELS[s_][-1]
+            self.register_buffer(f"lin{s_}", lin.float().clone(), persistent=False)
+
+    def features(self, x: Tensor):
+        import torch.nn.functional as F
+        x = (2 * x - 1 - self.shift) / self.scale
+        taps = []
+        for s_, idxs in enumerate(self._SLICES):
+            if s_ > 0:
+                x = F.max_pool2d(x, 2, 2)
+            for j in range(len(idxs)):
+                x = F.relu(F.conv2d(x, getattr(self, f"w{s_}_{j}"), getattr(self, f"b{s_}_{j}"), padding=1))
+            taps.append(x)
+        return taps
+
+    def distance(self, a: Tensor, b: Tensor) -> Tensor:
+        """[n,3,h,w] x2 in [0,1] -> [n] LPIPS distances."""
+        import torch.nn.functional as F
+        total = 0
+        for s_, (fa, fb) in enumerate(zip(self.features(a), self.features(b))):
+            na = fa / (fa.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            nb = fb / (fb.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            total = total + F.conv2d((na - nb) ** 2, getattr(self, f"lin{s_}")).mean(dim=(2, 3))[:, 0]
+        return total
+
+    def forward(self, prediction: Tensor, target: Tensor, global_step: int = 0) -> Tensor:
+        if global_step < self.apply_after_step:
+            return torch.zeros((), dtype=torch.float32, device=target.device)
+        return self.weight * self.distance(prediction.flatten(0, 1).float(), target.flatten(0, 1).float()).mean()
 
 
 class LossScaler:

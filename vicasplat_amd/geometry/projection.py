@@ -10,8 +10,8 @@ from torch import Tensor
 
 
 def _unit_rays(K_inv: Tensor, uv1: tuple[float, float, float]) -> Tensor:
-    v = torch.tensor(uv1, dtype=torch.float32, device=K_inv.device)
-    r = K_inv @ v  # [b,3]
+    # K_inv @ (u, v, 1) written out (3 multiply-adds per component in a fixed order): no vendor-BLAS GEMV launch for a 3x3 product
+    r = K_inv[..., 0] * uv1[0] + K_inv[..., 1] * uv1[1] + K_inv[..., 2] * uv1[2]  # [b,3]
     return r / r.norm(dim=-1, keepdim=True)
 
 

@@ -38,7 +38,8 @@ def camera_matrices(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: T
     tanfov = (0.5 * fov).tan()
     proj_t = get_projection_matrix(near.float(), far.float(), fov[:, 0], fov[:, 1]).transpose(1, 2)
     view_t = torch.linalg.inv(extrinsics.float()).transpose(1, 2)
-    full_t = view_t @ proj_t
+    # 4x4 product written out over k in a fixed order (288 tiny matrices: not worth a vendor-BLAS batched GEMM launch)
+    full_t = sum(view_t[:, :, k, None] * proj_t[:, k, None, :] for k in range(4))
     b = extrinsics.shape[0]
     return (view_t.reshape(b, 16).contiguous(), full_t.reshape(b, 16).contiguous(), proj_t.reshape(b, 16).contiguous(),
             extrinsics[:, :3, 3].float().contiguous(), tanfov.contiguous())
