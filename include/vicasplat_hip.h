@@ -83,7 +83,8 @@ enum {
     VS_BUF_FINAL_T = 8,   /* [C,H,W] f32 */
     VS_BUF_N_CONTRIB = 9, /* [C,H,W] i32 */
     VS_BUF_MISC = 10,     /* small control block */
-    VS_BUF_COUNT = 11
+    VS_BUF_DEPTH = 11,    /* [C,P] f32 view-space depth of the visible pairs (sort-key source; undefined where rect is all-zero) */
+    VS_BUF_COUNT = 12
 };
 typedef void *(*VsAllocFn)(void *ctx, int32_t tag, size_t bytes);
 

@@ -18,7 +18,7 @@ _lock = threading.Lock()
 _lib = None
 
 VS_BUF_GEOM, VS_BUF_RECT, VS_BUF_CLAMPED, VS_BUF_TILE_RANGES, VS_BUF_TILE_CURSOR, VS_BUF_KEYS, VS_BUF_POINT_LIST, \
-    VS_BUF_SORT_SCRATCH, VS_BUF_FINAL_T, VS_BUF_N_CONTRIB, VS_BUF_MISC, VS_BUF_COUNT = range(12)
+    VS_BUF_SORT_SCRATCH, VS_BUF_FINAL_T, VS_BUF_N_CONTRIB, VS_BUF_MISC, VS_BUF_DEPTH, VS_BUF_COUNT = range(13)
 VS_RASTER_COUNT_TOUCHED = 1
 VS_RASTER_SAVE_FOR_BACKWARD = 2
 VS_RASTER_SH_RGB_MAJOR = 4

@@ -39,20 +39,26 @@ __device__ __forceinline__ int f2i(float x) {
 
 // ---------------------------------------------------------------------------------------------------------
 // K1: preprocess.  grid = (ceil(P/256), S), block = 256.  A thread owns ONE Gaussian of scene s: it loads the
-// Gaussian's 58 input floats once into registers and then walks over every camera of that scene (the 232 input
-// bytes per Gaussian are read once per scene, not once per view).  Per camera the block bins its (Gaussian,tile)
-// instances in an LDS histogram and flushes one global atomic per non-empty bin, instead of one contended global
-// atomic per instance.
+// Gaussian's 58 input floats once and then walks over the cameras of that scene (the 232 input bytes per Gaussian
+// come from HBM once per scene, not once per view).  The scene's camera list is built once per block (wave 0, ballot
+// compaction, ascending) so that the loop only visits its own cameras.  Per camera the block bins its (Gaussian,tile)
+// instances in an LDS histogram and flushes one global atomic per non-empty bin, instead of one contended global atomic
+// per instance (measured: wave-aggregated global atomics are 2x slower here -- every block of a scene hits the same few
+// counters at the same time).  Two histograms alternate between cameras and the flush leaves its bins zeroed, so a camera
+// costs ONE barrier (accumulate | flush) instead of three (zero | accumulate | flush).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kHistTiles = 4096;  // LDS histogram capacity (16 KiB); larger tile grids use global atomics directly
+constexpr int kHistTiles = 4096;  // LDS histogram capacity (2 x 16 KiB in K1); larger tile grids use global atomics directly
+constexpr int kCamChunk = 2048;   // cameras scanned per list build (8 KiB of LDS)
 
 struct __attribute__((packed, aligned(4))) f3_t { float x, y, z; };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped,
-                  int32_t *__restrict__ radii, int32_t *__restrict__ tile_count) {
+                  int32_t *__restrict__ radii, float *__restrict__ depth, int32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
-    __shared__ int hist[kHistTiles];
+    __shared__ int cams[kCamChunk];
+    __shared__ int hist2[2][kHistTiles];
+    __shared__ int ncam_s;
     const int s = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int P = in.P;
@@ -61,7 +67,11 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
     const int W = in.width, H = in.height;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     const int tiles = gx * gy;
+    const int lane = threadIdx.x & 63;
     const bool use_lds = tiles <= kHistTiles;
+    if (use_lds)
+        for (int t = threadIdx.x; t < 2 * kHistTiles; t += 256) (&hist2[0][0])[t] = 0;   // (ordered by the camera-list barrier below)
+    int hb = 0;
 
     // ---- per-Gaussian inputs, loaded once ----
     float px = 0.f, py = 0.f, pz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f, opac = 0.f;
@@ -107,13 +117,25 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
     }
     const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
 
-    for (int c = 0; c < in.num_cameras; ++c) {
-        const int cs = in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes);
-        if (cs != s) continue;  // block-uniform
-        if (use_lds) {
-            for (int t = threadIdx.x; t < tiles; t += 256) hist[t] = 0;
-            __syncthreads();
-        }
+    for (int cbase = 0; cbase < in.num_cameras; cbase += kCamChunk) {
+      // cameras of this scene in [cbase, cbase + kCamChunk), ascending
+      if (cbase > 0) __syncthreads();
+      if (threadIdx.x < 64) {
+          int n = 0;
+          const int cend = min(in.num_cameras, cbase + kCamChunk);
+          for (int c0 = cbase; c0 < cend; c0 += 64) {
+              const int c = c0 + lane;
+              const bool mine = c < cend && (in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes)) == s;
+              const unsigned long long m = __ballot(mine);
+              if (mine) cams[n + __popcll(m & ((1ull << lane) - 1ull))] = c;
+              n += __popcll(m);
+          }
+          if (lane == 0) ncam_s = n;
+      }
+      __syncthreads();
+      const int ncam = ncam_s;
+      for (int k = 0; k < ncam; ++k) {
+        const int c = cams[k];
         const size_t ci = (size_t)c * P + i;
         bool visible = false;
         int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
@@ -219,6 +241,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                 g4[0] = make_float4(pixx, pixy, ext_x, ext_y);
                 g4[1] = make_float4(conx, cony, conz, opac);
                 g4[2] = make_float4(rgb[0], rgb[1], rgb[2], vz);
+                depth[ci] = vz;
                 radius_i = f2i(my_radius);
                 visible = true;
             } while (false);
@@ -228,6 +251,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
             clamped[ci] = (uint8_t)clamp_bits;
         }
         int32_t *tc = tile_count + (size_t)c * tiles;
+        int *hist = hist2[hb];
         if (visible) {
             for (int y = rminy; y < rmaxy; ++y)
                 for (int x = rminx; x < rmaxx; ++x) {
@@ -236,13 +260,14 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                 }
         }
         if (use_lds) {
-            __syncthreads();
+            __syncthreads();   // this camera's bins are complete; the other histogram (next camera) was zeroed by its last flush
             for (int t = threadIdx.x; t < tiles; t += 256) {
                 const int v = hist[t];
-                if (v) atomicAdd(&tc[t], v);
+                if (v) { atomicAdd(&tc[t], v); hist[t] = 0; }
             }
-            __syncthreads();
+            hb ^= 1;
         }
+      }
     }
 }
 
@@ -299,38 +324,49 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int32_t *__restrict__ c
 // K3: scatter (depth_bits<<32 | gaussian) keys into the per-(camera,tile) segments.  grid = (ceil(P/256), C).
 // Block-aggregated: instances are counted in an LDS histogram, one returning global atomic per non-empty bin
 // reserves the block's slots in the tile segment, then each instance takes an LDS-local slot.
+// Reads 12 bytes per (camera, Gaussian) pair: the tile rectangle (all-zero = not visible) and the view-space depth that K1
+// wrote to its own compact array (the 48-byte geom record holds it too, but at a 48-byte stride: 4x the bytes of this whole kernel).
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kScatterPer = 4;   // Gaussians per thread: the three block-wide steps (zero, reserve, slot) are paid once per 1024 pairs
+
 __global__ void __launch_bounds__(256)
-scatter_kernel(int P, int tiles, int gx, const float *__restrict__ geom, const ushort4 *__restrict__ rect,
-               const int32_t *__restrict__ radii, const int2 *__restrict__ ranges, int32_t *__restrict__ cursor,
-               unsigned long long *__restrict__ keys) {
+scatter_kernel(int P, int tiles, int gx, const float *__restrict__ depth, const ushort4 *__restrict__ rect,
+               const int2 *__restrict__ ranges, int32_t *__restrict__ cursor, unsigned long long *__restrict__ keys) {
     __shared__ int hist[kHistTiles];
     __shared__ int base[kHistTiles];
     const int c = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     const bool use_lds = tiles <= kHistTiles;
-    const size_t ci = (size_t)c * P + (i < P ? i : 0);
-    const bool visible = i < P && radii[ci] > 0;
-    ushort4 r = make_ushort4(0, 0, 0, 0);
-    unsigned long long key = 0;
-    if (visible) {
-        r = rect[ci];
-        key = ((unsigned long long)__float_as_uint(geom[ci * kGeomFloats + 11]) << 32) | (unsigned)i;
-    }
     const size_t t0 = (size_t)c * tiles;
+    ushort4 r[kScatterPer];
+    unsigned long long key[kScatterPer];
+#pragma unroll
+    for (int u = 0; u < kScatterPer; ++u) {
+        const int i = (blockIdx.x * kScatterPer + u) * 256 + threadIdx.x;
+        const size_t ci = (size_t)c * P + (i < P ? i : 0);
+        r[u] = make_ushort4(0, 0, 0, 0);
+        if (i < P) r[u] = rect[ci];
+        const bool visible = r[u].z > r[u].x && r[u].w > r[u].y;
+        if (!visible) r[u] = make_ushort4(0, 0, 0, 0);
+        key[u] = 0;
+        if (visible) key[u] = ((unsigned long long)__float_as_uint(depth[ci]) << 32) | (unsigned)i;
+    }
     if (!use_lds) {
-        for (int y = r.y; y < r.w; ++y)
-            for (int x = r.x; x < r.z; ++x) {
-                const size_t t = t0 + y * gx + x;
-                const int slot = atomicAdd(&cursor[t], 1);
-                keys[(size_t)ranges[t].x + slot] = key;
-            }
+#pragma unroll
+        for (int u = 0; u < kScatterPer; ++u)
+            for (int y = r[u].y; y < r[u].w; ++y)
+                for (int x = r[u].x; x < r[u].z; ++x) {
+                    const size_t t = t0 + y * gx + x;
+                    const int slot = atomicAdd(&cursor[t], 1);
+                    keys[(size_t)ranges[t].x + slot] = key[u];
+                }
         return;
     }
     for (int t = threadIdx.x; t < tiles; t += 256) hist[t] = 0;
     __syncthreads();
-    for (int y = r.y; y < r.w; ++y)
-        for (int x = r.x; x < r.z; ++x) atomicAdd(&hist[y * gx + x], 1);
+#pragma unroll
+    for (int u = 0; u < kScatterPer; ++u)
+        for (int y = r[u].y; y < r[u].w; ++y)
+            for (int x = r[u].x; x < r[u].z; ++x) atomicAdd(&hist[y * gx + x], 1);
     __syncthreads();
     for (int t = threadIdx.x; t < tiles; t += 256) {
         const int v = hist[t];
@@ -340,12 +376,14 @@ scatter_kernel(int P, int tiles, int gx, const float *__restrict__ geom, const u
         }
     }
     __syncthreads();
-    for (int y = r.y; y < r.w; ++y)
-        for (int x = r.x; x < r.z; ++x) {
-            const int t = y * gx + x;
-            const int slot = atomicAdd(&hist[t], 1);
-            keys[(size_t)base[t] + slot] = key;
-        }
+#pragma unroll
+    for (int u = 0; u < kScatterPer; ++u)
+        for (int y = r[u].y; y < r[u].w; ++y)
+            for (int x = r[u].x; x < r[u].z; ++x) {
+                const int t = y * gx + x;
+                const int slot = atomicAdd(&hist[t], 1);
+                keys[(size_t)base[t] + slot] = key[u];
+            }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -672,11 +710,15 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
 // ---------------------------------------------------------------------------------------------------------
 // K5: render.  One workgroup (4 waves) per (camera, 16x16 tile); wave w owns the 8x8 pixel quadrant (w&1, w>>1),
 // one pixel per lane.  The tile's sorted list is staged through LDS in batches of 256 records (coalesced id read,
-// 3 x 16-byte gathers of the packed record).  Per entry a wave first tests the Gaussian's conservative
-// {alpha >= 1/255} footprint against its quadrant -- a wave-uniform branch on broadcast LDS data -- so the
-// exp / blend body only runs for the quadrants a Gaussian can reach (for pixel-sized Gaussians ~1 of 4).
-// Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds, `contributor`
-// counts every list entry, so final_T / n_contrib match the oracle.
+// 3 x 16-byte gathers of the packed record).  The gather is software-pipelined through registers: while a batch is
+// blended out of LDS, the records of the next batch and the ids of the one after are already in flight, so the two
+// dependent memory round trips of a batch overlap with the previous batch's arithmetic instead of preceding it.
+// Per entry a wave first tests the Gaussian's conservative {alpha >= 1/255} footprint against its quadrant -- 64
+// entries per ballot -- so the exp / blend body only runs for the quadrants a Gaussian can reach (for pixel-sized
+// Gaussians ~1 of 4).  Survivors are taken two at a time: both alphas (LDS reads, quadratic form, exp) are evaluated
+// before either is blended -- they do not depend on T -- which doubles the independent work between the dependent
+// T updates.  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
+// `contributor` counts every list entry, so final_T / n_contrib match the oracle.
 // ---------------------------------------------------------------------------------------------------------
 template <bool COUNT_TOUCHED>
 __global__ void __launch_bounds__(256)
@@ -699,28 +741,75 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;  // quadrant centre; half size 3.5 px
     const int2 rg = ranges[(size_t)c * tiles + tile];
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
+    const uint32_t *__restrict__ plist = point_list + rg.x;
     const bool inside = pxi < W && pyi < H;
+    const int n = rg.y - rg.x;
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f;
     int last_contrib = 0;
     bool done = !inside;
 
-    int todo = rg.y - rg.x;
+    // pipeline registers: records (and id) of the batch that is staged next, id of the batch after it
+    uint32_t g_cur = 0, g_nxt = 0;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    if (tid < n) g_cur = plist[tid];
+    if (NT + tid < n) g_nxt = plist[NT + tid];
+    if (tid < n) {
+        r0 = g4[(size_t)g_cur * 3 + 0];
+        r1 = g4[(size_t)g_cur * 3 + 1];
+        r2 = g4[(size_t)g_cur * 3 + 2];
+    }
+
+    // alpha of staged entry j for this lane's pixel (0 = skipped by upstream's power > 0 test)
+    auto eval_alpha = [&](int j) -> float {
+        const float4 q0 = sq0[j];
+        const float4 q1 = sq1[j];
+        const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+        const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+        return power <= 0.0f ? fminf(0.99f, q1.w * __expf(power)) : 0.0f;
+    };
     int contributor = 0;
-    for (int base = rg.x; base < rg.y; base += NT, todo -= NT) {
+    auto blend = [&](int j, float alpha) {
+        bool touched = false;
+        if (!done && alpha >= 1.0f / 255.0f) {
+            const float test_T = T * (1.0f - alpha);
+            if (test_T < 0.0001f) {
+                done = true;
+            } else {
+                const float4 q2 = sq2[j];
+                const float w = alpha * T;
+                Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
+                Dd += q2.w * w;
+                touched = test_T > 0.5f;
+                T = test_T;
+                last_contrib = contributor + j + 1;
+            }
+        }
+        if (COUNT_TOUCHED) {
+            const int tot = __popcll(__ballot(touched));
+            if (lane == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+        }
+    };
+
+    for (int base = 0; base < n; base += NT) {
+        // (also orders the previous batch's LDS reads before this batch's stores)
         if (__syncthreads_count(done) == NT) break;
-        if (base + tid < rg.y) {
-            const uint32_t g = point_list[base + tid];
-            sq0[tid] = g4[(size_t)g * 3 + 0];
-            sq1[tid] = g4[(size_t)g * 3 + 1];
-            sq2[tid] = g4[(size_t)g * 3 + 2];
-            sid[tid] = g;
+        if (base + tid < n) {
+            sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2;
+            sid[tid] = g_cur;
         }
         __syncthreads();
-        const int cnt = min(NT, todo);
+        g_cur = g_nxt;
+        if (base + NT + tid < n) {
+            r0 = g4[(size_t)g_cur * 3 + 0];
+            r1 = g4[(size_t)g_cur * 3 + 1];
+            r2 = g4[(size_t)g_cur * 3 + 2];
+        }
+        if (base + 2 * NT + tid < n) g_nxt = plist[base + 2 * NT + tid];
+        const int cnt = min(NT, n - base);
         if (!__all(done)) {
             // The 64 lanes test 64 staged entries at once against this wave's quadrant (conservative {alpha >= 1/255}
-            // footprint); only the survivors are walked sequentially, in list order (ascending bit index).
+            // footprint); only the survivors are walked, in list order (ascending bit index), two per trip.
             for (int j0 = 0; j0 < cnt; j0 += 64) {
                 const int je = j0 + lane;
                 bool hit = false;
@@ -730,40 +819,22 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
                 }
                 unsigned long long mask = __ballot(hit);
                 while (mask) {
-                    const int j = j0 + __builtin_ctzll(mask);
+                    const int ja = j0 + __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const float4 q0 = sq0[j];
-                    const float4 q1 = sq1[j];
-                    const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-                    const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                    bool touched = false;
-                    if (!done && power <= 0.0f) {
-                        const float alpha = fminf(0.99f, q1.w * __expf(power));
-                        if (alpha >= 1.0f / 255.0f) {
-                            const float test_T = T * (1.0f - alpha);
-                            if (test_T < 0.0001f) {
-                                done = true;
-                            } else {
-                                const float4 q2 = sq2[j];
-                                const float w = alpha * T;
-                                Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
-                                Dd += q2.w * w;
-                                touched = test_T > 0.5f;
-                                T = test_T;
-                                last_contrib = contributor + j + 1;
-                            }
-                        }
-                    }
-                    if (COUNT_TOUCHED) {
-                        const int tot = __popcll(__ballot(touched));
-                        if (lane == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+                    if (mask) {
+                        const int jb = j0 + __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const float alpha_a = eval_alpha(ja), alpha_b = eval_alpha(jb);
+                        blend(ja, alpha_a);
+                        blend(jb, alpha_b);
+                    } else {
+                        blend(ja, eval_alpha(ja));
                     }
                 }
                 if (__all(done)) break;
             }
         }
         contributor += cnt;
-        __syncthreads();
     }
 
     if (inside) {
@@ -812,19 +883,20 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     float *geom = (float *)get(VS_BUF_GEOM, CP * kGeomFloats * sizeof(float));
     ushort4 *rect = (ushort4 *)get(VS_BUF_RECT, CP * sizeof(ushort4));
     uint8_t *clamped = (uint8_t *)get(VS_BUF_CLAMPED, CP);
+    float *depthkey = (float *)get(VS_BUF_DEPTH, CP * sizeof(float));
     int2 *ranges = (int2 *)get(VS_BUF_TILE_RANGES, (size_t)C * tiles * sizeof(int2));
     int32_t *cursor = (int32_t *)get(VS_BUF_TILE_CURSOR, (size_t)C * tiles * sizeof(int32_t));
     long long *misc = (long long *)get(VS_BUF_MISC, 4 * sizeof(long long));
     float *final_T = (float *)get(VS_BUF_FINAL_T, (size_t)C * H * W * sizeof(float));
     int32_t *n_contrib = (int32_t *)get(VS_BUF_N_CONTRIB, (size_t)C * H * W * sizeof(int32_t));
-    VS_CHECK(geom && rect && clamped && ranges && cursor && misc && final_T && n_contrib, "vs_raster_forward: allocator returned null");
+    VS_CHECK(geom && rect && clamped && depthkey && ranges && cursor && misc && final_T && n_contrib, "vs_raster_forward: allocator returned null");
 
     VS_HIP(hipMemsetAsync(cursor, 0, (size_t)C * tiles * sizeof(int32_t), stream));
     VS_HIP(hipMemsetAsync(misc, 0, 4 * sizeof(long long), stream));
     if (out->n_touched) VS_HIP(hipMemsetAsync(out->n_touched, 0, CP * sizeof(int32_t), stream));
     if (P > 0) {
         dim3 grid(vs::cdiv(P, 256), in->num_scenes);
-        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, stream, *in, geom, rect, clamped, out->radii, cursor);
+        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, stream, *in, geom, rect, clamped, out->radii, depthkey, cursor);
     }
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, cursor, ranges, C * tiles, misc);
     long long host_misc[2] = {0, 0};
@@ -848,8 +920,8 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     }
     VS_CHECK(keys && point_list && (max_tile <= kSortLds || scratch), "vs_raster_forward: allocator returned null");
     if (R > 0) {
-        dim3 grid(vs::cdiv(P, 256), C);
-        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, geom, rect, out->radii, ranges, cursor, keys);
+        dim3 grid(vs::cdiv(P, 256 * kScatterPer), C);
+        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, depthkey, rect, ranges, cursor, keys);
         hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch, segs);
         if (segs)
             hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)vs::cdiv64(nslots, 4)), dim3(256), 0, stream, segs, (int)nslots,

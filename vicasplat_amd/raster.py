@@ -94,6 +94,10 @@ class _Rasterize(torch.autograd.Function):
         outs, st = _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov,
                                  background, cam_scene, H, W, sh_degree, flags)
         color, radii, depth, opacity, n_touched = outs
+        # binning scratch the backward never reads (keys, sort ping-pong, depth keys, rectangles, cursors: ~25 bytes per instance)
+        # goes back to the caching allocator now; later work on this stream may reuse it
+        for tag in (L.VS_BUF_KEYS, L.VS_BUF_SORT_SCRATCH, L.VS_BUF_DEPTH, L.VS_BUF_RECT, L.VS_BUF_TILE_CURSOR):
+            st["alloc"].tensors.pop(tag, None)
         ctx.inp, ctx.out, ctx.alloc = st["inp"], st["out"], st["alloc"]
         # inputs whose device pointers sit in ctx.inp.  NO output tensor may be stored on ctx directly: an output holds its
         # grad_fn (this node) and the node would hold the output -- a cycle through C++ references that Python's collector never
