@@ -713,20 +713,23 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
 // 3 x 16-byte gathers of the packed record).  The gather is software-pipelined through registers: while a batch is
 // blended out of LDS, the records of the next batch and the ids of the one after are already in flight, so the two
 // dependent memory round trips of a batch overlap with the previous batch's arithmetic instead of preceding it.
-// Per entry a wave first tests the Gaussian's conservative {alpha >= 1/255} footprint against its quadrant -- 64
-// entries per ballot -- so the exp / blend body only runs for the quadrants a Gaussian can reach (for pixel-sized
-// Gaussians ~1 of 4).  Survivors are taken two at a time: both alphas (LDS reads, quadratic form, exp) are evaluated
-// before either is blended -- they do not depend on T -- which doubles the independent work between the dependent
-// T updates.  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
+// Culling is per 4x4 pixel block: the 16 lanes of a block walk their OWN survivor list.  Each lane tests one staged entry's
+// conservative {alpha >= 1/255} footprint against the wave's four blocks (64 entries per round, four ballots); a block then
+// steps through the set bits of its mask -- per-lane ctz, LDS reads at four different addresses per wave -- so one trip of
+// the loop blends up to four different Gaussians, one per block, and the trip count is the LONGEST of the four lists
+// instead of the union over the 8x8 quadrant (pixel-sized Gaussians reach 1-2 of the 4 blocks: about half the trips).
+// The blend uses selects, not nested branches.  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
 // `contributor` counts every list entry, so final_T / n_contrib match the oracle.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kRenderRecsPerThread = 1;   // (2 = 512-entry batches: measured 11 % slower, the LDS costs occupancy)
+
 template <bool COUNT_TOUCHED>
 __global__ void __launch_bounds__(256)
 render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ background, float *__restrict__ out_color,
               float *__restrict__ out_depth, float *__restrict__ out_opacity, float *__restrict__ final_T,
               int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched) {
-    constexpr int NT = 256;
+    constexpr int RPT = kRenderRecsPerThread, NT = 256 * RPT;   // staged batch: RPT records per thread
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
     __shared__ uint32_t sid[NT];
     const int c = blockIdx.y;
@@ -736,9 +739,10 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int sb = lane >> 4;                                    // this lane's 4x4 block inside the wave's 8x8 quadrant
+    const int pxi = qx0 + (sb & 1) * 4 + (lane & 3), pyi = qy0 + (sb >> 1) * 4 + ((lane >> 2) & 3);
     const float pixfx = (float)pxi, pixfy = (float)pyi;
-    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;  // quadrant centre; half size 3.5 px
+    const float bcx = (float)qx0 + 1.5f, bcy = (float)qy0 + 1.5f;  // centre of block 0; blocks are 4 px apart, half size 1.5 px
     const int2 rg = ranges[(size_t)c * tiles + tile];
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
     const uint32_t *__restrict__ plist = point_list + rg.x;
@@ -750,88 +754,105 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     bool done = !inside;
 
     // pipeline registers: records (and id) of the batch that is staged next, id of the batch after it
-    uint32_t g_cur = 0, g_nxt = 0;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    if (tid < n) g_cur = plist[tid];
-    if (NT + tid < n) g_nxt = plist[NT + tid];
-    if (tid < n) {
-        r0 = g4[(size_t)g_cur * 3 + 0];
-        r1 = g4[(size_t)g_cur * 3 + 1];
-        r2 = g4[(size_t)g_cur * 3 + 2];
+    uint32_t g_cur[RPT], g_nxt[RPT];
+    float4 r0[RPT], r1[RPT], r2[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int e = u * 256 + tid;
+        g_cur[u] = e < n ? plist[e] : 0u;
+        g_nxt[u] = NT + e < n ? plist[NT + e] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        r0[u] = r1[u] = r2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u * 256 + tid < n) {
+            r0[u] = g4[(size_t)g_cur[u] * 3 + 0];
+            r1[u] = g4[(size_t)g_cur[u] * 3 + 1];
+            r2[u] = g4[(size_t)g_cur[u] * 3 + 2];
+        }
     }
 
-    // alpha of staged entry j for this lane's pixel (0 = skipped by upstream's power > 0 test)
-    auto eval_alpha = [&](int j) -> float {
+    int contributor = 0;
+    // upstream's per-pixel step for staged entry j (lanes of a 4x4 block share j): skip / stop thresholds and operation order as in
+    // SURVEY.md B.3.  Divergent branches, not selects: the kernel is VALU-bound (SQ_ACTIVE_INST_VALU = its whole duration), exec
+    // masking costs scalar instructions only, and a select-based form measured 70 VALU per trip against ~40 for this one.
+    // One trip of a 4x4 block's lanes over staged entry j, as straight-line predicated code.  The kernel is VALU-bound
+    // (SQ_ACTIVE_INST_VALU = its whole duration) and hipcc turns divergent branches around loop-carried accumulators into register
+    // copies at every nesting level (70 VALU per trip measured; ~40 this way).
+    //   thr   alpha threshold of the pixel: 1/255 while live, +inf once done (saturated / outside the image): "live and
+    //         alpha >= 1/255" is one compare;
+    //   act   this lane's block has an entry in this trip (alpha forced to 0 otherwise);
+    //   the accumulators take w = 0 in lanes where upstream's three conditions do not all hold: x + c*0 == x for the finite
+    //   colours / depths preprocess writes, so those lanes are unchanged and the others see upstream's operations in its order.
+    float thr = done ? __builtin_inff() : 1.0f / 255.0f;
+    auto step = [&](int j, bool act) -> bool {
         const float4 q0 = sq0[j];
         const float4 q1 = sq1[j];
+        const float4 q2 = sq2[j];
         const float dx = q0.x - pixfx, dy = q0.y - pixfy;
         const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-        return power <= 0.0f ? fminf(0.99f, q1.w * __expf(power)) : 0.0f;
-    };
-    int contributor = 0;
-    auto blend = [&](int j, float alpha) {
-        bool touched = false;
-        if (!done && alpha >= 1.0f / 255.0f) {
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-            } else {
-                const float4 q2 = sq2[j];
-                const float w = alpha * T;
-                Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
-                Dd += q2.w * w;
-                touched = test_T > 0.5f;
-                T = test_T;
-                last_contrib = contributor + j + 1;
-            }
-        }
-        if (COUNT_TOUCHED) {
-            const int tot = __popcll(__ballot(touched));
-            if (lane == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
-        }
+        float alpha = fminf(0.99f, q1.w * __expf(fminf(power, 0.0f)));
+        alpha = (act && power <= 0.0f) ? alpha : 0.0f;   // upstream skips power > 0 (a NaN power compares false here too)
+        const bool pass = alpha >= thr;
+        const float test_T = T * (1.0f - alpha);
+        const bool go = pass && !(test_T < 0.0001f);
+        thr = (pass && !go) ? __builtin_inff() : thr;
+        const float w = go ? alpha * T : 0.0f;
+        Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
+        Dd += q2.w * w;
+        T = go ? test_T : T;
+        last_contrib = go ? contributor + j + 1 : last_contrib;
+        return go && test_T > 0.5f;
     };
 
     for (int base = 0; base < n; base += NT) {
         // (also orders the previous batch's LDS reads before this batch's stores)
-        if (__syncthreads_count(done) == NT) break;
-        if (base + tid < n) {
-            sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2;
-            sid[tid] = g_cur;
+        if (__syncthreads_count(thr > 1.0f) == NT) break;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int e = u * 256 + tid;
+            if (base + e < n) {
+                sq0[e] = r0[u]; sq1[e] = r1[u]; sq2[e] = r2[u];
+                if (COUNT_TOUCHED) sid[e] = g_cur[u];
+            }
         }
         __syncthreads();
-        g_cur = g_nxt;
-        if (base + NT + tid < n) {
-            r0 = g4[(size_t)g_cur * 3 + 0];
-            r1 = g4[(size_t)g_cur * 3 + 1];
-            r2 = g4[(size_t)g_cur * 3 + 2];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int e = u * 256 + tid;
+            g_cur[u] = g_nxt[u];
+            if (base + NT + e < n) {
+                r0[u] = g4[(size_t)g_cur[u] * 3 + 0];
+                r1[u] = g4[(size_t)g_cur[u] * 3 + 1];
+                r2[u] = g4[(size_t)g_cur[u] * 3 + 2];
+            }
+            if (base + 2 * NT + e < n) g_nxt[u] = plist[base + 2 * NT + e];
         }
-        if (base + 2 * NT + tid < n) g_nxt = plist[base + 2 * NT + tid];
         const int cnt = min(NT, n - base);
-        if (!__all(done)) {
-            // The 64 lanes test 64 staged entries at once against this wave's quadrant (conservative {alpha >= 1/255}
-            // footprint); only the survivors are walked, in list order (ascending bit index), two per trip.
+        if (!__all(thr > 1.0f)) {
             for (int j0 = 0; j0 < cnt; j0 += 64) {
                 const int je = j0 + lane;
-                bool hit = false;
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
                 if (je < cnt) {
                     const float4 t = sq0[je];
-                    hit = fabsf(t.x - qcx) <= t.z + 3.5f && fabsf(t.y - qcy) <= t.w + 3.5f;
+                    const float ex = t.z + 1.5f, ey = t.w + 1.5f;
+                    const bool x0 = fabsf(t.x - bcx) <= ex, x1 = fabsf(t.x - (bcx + 4.0f)) <= ex;
+                    const bool y0 = fabsf(t.y - bcy) <= ey, y1 = fabsf(t.y - (bcy + 4.0f)) <= ey;
+                    h0 = x0 && y0; h1 = x1 && y0; h2 = x0 && y1; h3 = x1 && y1;
                 }
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int ja = j0 + __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    if (mask) {
-                        const int jb = j0 + __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        const float alpha_a = eval_alpha(ja), alpha_b = eval_alpha(jb);
-                        blend(ja, alpha_a);
-                        blend(jb, alpha_b);
-                    } else {
-                        blend(ja, eval_alpha(ja));
+                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+                unsigned long long mine = (sb & 2) ? ((sb & 1) ? m3 : m2) : ((sb & 1) ? m1 : m0);
+                while (__any(mine != 0ull)) {
+                    const bool act = mine != 0ull;
+                    const int j = j0 + (act ? __builtin_ctzll(mine) : 0);
+                    mine &= mine - 1ull;
+                    const bool touched = step(j, act);
+                    if (COUNT_TOUCHED) {   // the four blocks blend four different entries: one count per block
+                        const int tot = __popcll(__ballot(touched) & (0xFFFFull << (sb * 16)));
+                        if ((lane & 15) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
                     }
                 }
-                if (__all(done)) break;
+                if (__all(thr > 1.0f)) break;
             }
         }
         contributor += cnt;
