@@ -713,12 +713,13 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
 // 3 x 16-byte gathers of the packed record).  The gather is software-pipelined through registers: while a batch is
 // blended out of LDS, the records of the next batch and the ids of the one after are already in flight, so the two
 // dependent memory round trips of a batch overlap with the previous batch's arithmetic instead of preceding it.
-// Culling is per 4x4 pixel block: the 16 lanes of a block walk their OWN survivor list.  Each lane tests one staged entry's
-// conservative {alpha >= 1/255} footprint against the wave's four blocks (64 entries per round, four ballots); a block then
-// steps through the set bits of its mask -- per-lane ctz, LDS reads at four different addresses per wave -- so one trip of
-// the loop blends up to four different Gaussians, one per block, and the trip count is the LONGEST of the four lists
-// instead of the union over the 8x8 quadrant (pixel-sized Gaussians reach 1-2 of the 4 blocks: about half the trips).
-// The blend uses selects, not nested branches.  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
+// Culling is per 2x2 pixel block: the 4 lanes of a block walk their OWN survivor list.  Per round of 64 staged entries each
+// lane tests one entry's conservative {alpha >= 1/255} footprint against the quadrant's four block columns and four block rows
+// (eight compares whose lane masks ARE the ballots; a block's list is column-mask & row-mask); a block then steps through the
+// set bits of its mask -- per-lane ctz, LDS reads at up to sixteen different addresses per wave -- so one trip of the loop
+// blends up to sixteen different Gaussians and the trip count is the LONGEST block list instead of the union over the 8x8
+// quadrant (a 3-4 px footprint reaches ~8 of 64 entries per block against ~34 per quadrant).
+// The trip is straight-line predicated code, not nested branches.  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
 // `contributor` counts every list entry, so final_T / n_contrib match the oracle.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRenderRecsPerThread = 1;   // (2 = 512-entry batches: measured 11 % slower, the LDS costs occupancy)
@@ -739,10 +740,11 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
-    const int sb = lane >> 4;                                    // this lane's 4x4 block inside the wave's 8x8 quadrant
-    const int pxi = qx0 + (sb & 1) * 4 + (lane & 3), pyi = qy0 + (sb >> 1) * 4 + ((lane >> 2) & 3);
+    const int sb = lane >> 2;                                    // this lane's 2x2 pixel block inside the wave's 8x8 quadrant (4 x 4 blocks)
+    const int bxi = sb & 3, byi = sb >> 2;
+    const int pxi = qx0 + bxi * 2 + (lane & 1), pyi = qy0 + byi * 2 + ((lane >> 1) & 1);
     const float pixfx = (float)pxi, pixfy = (float)pyi;
-    const float bcx = (float)qx0 + 1.5f, bcy = (float)qy0 + 1.5f;  // centre of block 0; blocks are 4 px apart, half size 1.5 px
+    const float bcx = (float)qx0 + 0.5f, bcy = (float)qy0 + 0.5f;  // centre of block column / row 0; 2 px apart, half size 0.5 px
     const int2 rg = ranges[(size_t)c * tiles + tile];
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
     const uint32_t *__restrict__ plist = point_list + rg.x;
@@ -773,10 +775,8 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     }
 
     int contributor = 0;
-    // upstream's per-pixel step for staged entry j (lanes of a 4x4 block share j): skip / stop thresholds and operation order as in
-    // SURVEY.md B.3.  Divergent branches, not selects: the kernel is VALU-bound (SQ_ACTIVE_INST_VALU = its whole duration), exec
-    // masking costs scalar instructions only, and a select-based form measured 70 VALU per trip against ~40 for this one.
-    // One trip of a 4x4 block's lanes over staged entry j, as straight-line predicated code.  The kernel is VALU-bound
+    // Upstream's per-pixel step (skip / stop thresholds, operation order) for staged entry j.
+    // One trip of a 2x2 block's lanes over staged entry j, as straight-line predicated code.  The kernel is VALU-bound
     // (SQ_ACTIVE_INST_VALU = its whole duration) and hipcc turns divergent branches around loop-carried accumulators into register
     // copies at every nesting level (70 VALU per trip measured; ~40 this way).
     //   thr   alpha threshold of the pixel: 1/255 while live, +inf once done (saturated / outside the image): "live and
@@ -832,24 +832,26 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
         if (!__all(thr > 1.0f)) {
             for (int j0 = 0; j0 < cnt; j0 += 64) {
                 const int je = j0 + lane;
-                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                // entry je against the four block columns and the four block rows: a block's mask is column-mask & row-mask
+                float tx = 0.f, ty = 0.f, ex = -1.f, ey = -1.f;
                 if (je < cnt) {
                     const float4 t = sq0[je];
-                    const float ex = t.z + 1.5f, ey = t.w + 1.5f;
-                    const bool x0 = fabsf(t.x - bcx) <= ex, x1 = fabsf(t.x - (bcx + 4.0f)) <= ex;
-                    const bool y0 = fabsf(t.y - bcy) <= ey, y1 = fabsf(t.y - (bcy + 4.0f)) <= ey;
-                    h0 = x0 && y0; h1 = x1 && y0; h2 = x0 && y1; h3 = x1 && y1;
+                    tx = t.x - bcx; ty = t.y - bcy; ex = t.z + 0.5f; ey = t.w + 0.5f;
                 }
-                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-                unsigned long long mine = (sb & 2) ? ((sb & 1) ? m3 : m2) : ((sb & 1) ? m1 : m0);
+                const unsigned long long mx0 = __ballot(fabsf(tx) <= ex), mx1 = __ballot(fabsf(tx - 2.0f) <= ex),
+                                         mx2 = __ballot(fabsf(tx - 4.0f) <= ex), mx3 = __ballot(fabsf(tx - 6.0f) <= ex);
+                const unsigned long long my0 = __ballot(fabsf(ty) <= ey), my1 = __ballot(fabsf(ty - 2.0f) <= ey),
+                                         my2 = __ballot(fabsf(ty - 4.0f) <= ey), my3 = __ballot(fabsf(ty - 6.0f) <= ey);
+                unsigned long long mine = ((bxi & 2) ? ((bxi & 1) ? mx3 : mx2) : ((bxi & 1) ? mx1 : mx0)) &
+                                          ((byi & 2) ? ((byi & 1) ? my3 : my2) : ((byi & 1) ? my1 : my0));
                 while (__any(mine != 0ull)) {
                     const bool act = mine != 0ull;
                     const int j = j0 + (act ? __builtin_ctzll(mine) : 0);
                     mine &= mine - 1ull;
                     const bool touched = step(j, act);
-                    if (COUNT_TOUCHED) {   // the four blocks blend four different entries: one count per block
-                        const int tot = __popcll(__ballot(touched) & (0xFFFFull << (sb * 16)));
-                        if ((lane & 15) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+                    if (COUNT_TOUCHED) {   // the sixteen blocks blend different entries: one count per block
+                        const int tot = __popcll(__ballot(touched) & (0xFull << (sb * 4)));
+                        if ((lane & 3) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
                     }
                 }
                 if (__all(thr > 1.0f)) break;
