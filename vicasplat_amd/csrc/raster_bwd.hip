@@ -31,21 +31,20 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 // per-(camera,Gaussian) gradient record written by K1: mean2D.xy | conic.xyz | opacity | rgb | depth
 constexpr int kG = 10;
 
-// sum over the 64 lanes of a wave, valid in lanes 48..63 (the last row): quad / half-row / row DPP adds give every lane its row's
-// sum, row_bcast:15 folds row 0 into row 1 and row 2 into row 3, row_bcast:31 folds rows 0+1 into row 3 -- six VALU adds, no
-// LDS crossbar traffic and no readlane
-__device__ __forceinline__ float wave_total_hi(float v) {
-#define VS_DPP_ADD(ctrl_, rmask_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl_, rmask_, 0xF, false));
-    VS_DPP_ADD(0xB1, 0xF)    // quad_perm [1,0,3,2]
-    VS_DPP_ADD(0x4E, 0xF)    // quad_perm [2,3,0,1]
-    VS_DPP_ADD(0x141, 0xF)   // row_half_mirror
-    VS_DPP_ADD(0x140, 0xF)   // row_mirror
-    VS_DPP_ADD(0x142, 0xA)   // row_bcast:15 into rows 1 and 3
-    VS_DPP_ADD(0x143, 0xC)   // row_bcast:31 into rows 2 and 3
-#undef VS_DPP_ADD
+// sum over the 4 lanes of a 2x2 pixel block (lanes 4k .. 4k+3), valid in all four: two quad-permute DPP adds
+__device__ __forceinline__ float quad_total(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
     return v;
 }
 
+// Same tile / quadrant / 2x2-block layout as the forward's render_kernel (raster_fwd.hip K5): per round of 64 staged entries every
+// lane tests one entry's footprint against the quadrant's four block columns and rows, a block's list is column-mask & row-mask,
+// and the block's 4 lanes walk it from the BACK (per-lane clz) -- one trip of the loop replays up to sixteen different Gaussians.
+// Gradients of a (tile, entry) are accumulated in LDS (per batch of 256 entries: [10][256] floats; a block adds its 4-lane sums with
+// ds_add_f32) and leave the workgroup once per batch as plain global atomics on the non-zero components: a pixel-sized Gaussian is
+// seen by several blocks of several waves, and the per-(wave, entry) 64-lane reductions + global atomics of the previous version
+// (and the per-entry scalar loop around them) were VALU time -- this kernel was 62 ms of the 24-scene training step.
 __global__ void __launch_bounds__(256)
 render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
                        const float *__restrict__ geom, const float *__restrict__ background, const float *__restrict__ final_T,
@@ -54,6 +53,7 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
     constexpr int NT = 256;
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
     __shared__ uint32_t sid[NT];
+    __shared__ float sgr[kG][NT];
     __shared__ int s_max;
     const int c = blockIdx.y;
     const int gx = (W + kTile - 1) / kTile;
@@ -62,11 +62,13 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int sb = lane >> 2, bxi = sb & 3, byi = sb >> 2;     // 2x2 pixel block of this lane inside the wave's 8x8 quadrant
+    const int pxi = qx0 + bxi * 2 + (lane & 1), pyi = qy0 + byi * 2 + ((lane >> 1) & 1);
     const float pixfx = (float)pxi, pixfy = (float)pyi;
-    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
+    const float bcx = (float)qx0 + 0.5f, bcy = (float)qy0 + 0.5f;  // centre of block column / row 0; 2 px apart, half size 0.5 px
     const int2 rg = ranges[(size_t)c * tiles + tile];
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
+    const uint32_t *__restrict__ plist = point_list + rg.x;
     const bool inside = pxi < W && pyi < H;
     const size_t HW = (size_t)H * W;
     const size_t pix = (size_t)pyi * W + pxi;
@@ -93,68 +95,107 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
     for (int o = 32; o > 0; o >>= 1) wave_max = max(wave_max, __shfl_xor(wave_max, o, 64));
 
     float *__restrict__ gr = grec + (size_t)c * P * kG;
+    const int nb = (nmax + NT - 1) / NT;
+    // register pipeline of the gather: records of the batch staged next, ids of the one after (batches run back to front)
+    uint32_t g_cur = 0, g_nxt = 0;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    if (nb > 0 && (nb - 1) * NT + tid < nmax) g_cur = plist[(nb - 1) * NT + tid];
+    if (nb > 1) g_nxt = plist[(nb - 2) * NT + tid];
+    if (nb > 0 && (nb - 1) * NT + tid < nmax) {
+        r0 = g4[(size_t)g_cur * 3 + 0]; r1 = g4[(size_t)g_cur * 3 + 1]; r2 = g4[(size_t)g_cur * 3 + 2];
+    }
     // walk the list back to front in batches of NT: batch b covers positions [b*NT, min((b+1)*NT, nmax))
-    for (int b = (nmax + NT - 1) / NT - 1; b >= 0; --b) {
+    for (int b = nb - 1; b >= 0; --b) {
         const int p0 = b * NT;
         const int cnt = min(NT, nmax - p0);
-        __syncthreads();
+        __syncthreads();   // the previous batch's flush has read sgr / sid
         if (tid < cnt) {
-            const uint32_t g = point_list[rg.x + p0 + tid];
-            sq0[tid] = g4[(size_t)g * 3 + 0];
-            sq1[tid] = g4[(size_t)g * 3 + 1];
-            sq2[tid] = g4[(size_t)g * 3 + 2];
-            sid[tid] = g;
+            sq0[tid] = r0; sq1[tid] = r1; sq2[tid] = r2;
+            sid[tid] = g_cur;
         }
+#pragma unroll
+        for (int e = 0; e < kG; ++e) sgr[e][tid] = 0.f;
         __syncthreads();
-        if (p0 >= wave_max) continue;  // nothing in this batch reaches the wave's pixels
-        for (int j = cnt - 1; j >= 0; --j) {
-            const int posn = p0 + j;  // 0-based position; upstream's `contributor` = posn + 1
-            if (posn >= wave_max) continue;
-            const float4 q0 = sq0[j];
-            if (fabsf(q0.x - qcx) > q0.z + 3.5f || fabsf(q0.y - qcy) > q0.w + 3.5f) continue;
-            // per-lane contribution test (the wave stays converged: the sums below run over all 64 lanes)
-            const float4 q1 = sq1[j];
-            const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-            const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-            const float G = __expf(fminf(power, 0.0f));
-            const float alpha = fminf(0.99f, q1.w * G);
-            const bool act = posn < last && power <= 0.0f && alpha >= 1.0f / 255.0f;
-            if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
-            const float4 q2 = sq2[j];
-            float v[kG];
+        g_cur = g_nxt;
+        if (b > 0) {   // (batches below the last one are full)
+            r0 = g4[(size_t)g_cur * 3 + 0]; r1 = g4[(size_t)g_cur * 3 + 1]; r2 = g4[(size_t)g_cur * 3 + 2];
+        }
+        if (b > 1) g_nxt = plist[(b - 2) * NT + tid];
+        if (p0 < wave_max) {   // something in this batch can reach the wave's pixels
+            for (int j0 = (cnt - 1) & ~63; j0 >= 0; j0 -= 64) {
+                if (p0 + j0 >= wave_max) continue;
+                const int je = j0 + lane;
+                float tx = 0.f, ty = 0.f, ex = -1.f, ey = -1.f;
+                if (je < cnt && p0 + je < wave_max) {
+                    const float4 t = sq0[je];
+                    tx = t.x - bcx; ty = t.y - bcy; ex = t.z + 0.5f; ey = t.w + 0.5f;
+                }
+                const unsigned long long mx0 = __ballot(fabsf(tx) <= ex), mx1 = __ballot(fabsf(tx - 2.0f) <= ex),
+                                         mx2 = __ballot(fabsf(tx - 4.0f) <= ex), mx3 = __ballot(fabsf(tx - 6.0f) <= ex);
+                const unsigned long long my0 = __ballot(fabsf(ty) <= ey), my1 = __ballot(fabsf(ty - 2.0f) <= ey),
+                                         my2 = __ballot(fabsf(ty - 4.0f) <= ey), my3 = __ballot(fabsf(ty - 6.0f) <= ey);
+                unsigned long long mine = ((bxi & 2) ? ((bxi & 1) ? mx3 : mx2) : ((bxi & 1) ? mx1 : mx0)) &
+                                          ((byi & 2) ? ((byi & 1) ? my3 : my2) : ((byi & 1) ? my1 : my0));
+                while (__any(mine != 0ull)) {
+                    const bool blk = mine != 0ull;
+                    const int jj = blk ? 63 - __builtin_clzll(mine) : 0;
+                    mine &= ~(1ull << jj);
+                    const int j = j0 + jj;
+                    const int posn = p0 + j;  // 0-based position; upstream's `contributor` = posn + 1
+                    const float4 q0 = sq0[j];
+                    const float4 q1 = sq1[j];
+                    const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                    const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+                    const float G = __expf(fminf(power, 0.0f));
+                    const float alpha = fminf(0.99f, q1.w * G);
+                    const bool act = blk && posn < last && power <= 0.0f && alpha >= 1.0f / 255.0f;
+                    const unsigned long long am = __ballot(act);
+                    if (am == 0ull) continue;
+                    const float4 q2 = sq2[j];
+                    float v[kG];
 #pragma unroll
-            for (int e = 0; e < kG; ++e) v[e] = 0.f;
-            if (act) {
-                T = T / (1.0f - alpha);
-                const float dch = alpha * T;
-                float dL_dalpha = 0.f;
-                acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r; last_r = q2.x; dL_dalpha += (q2.x - acc_r) * dLr;
-                acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g; last_g = q2.y; dL_dalpha += (q2.y - acc_g) * dLg;
-                acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b; last_b = q2.z; dL_dalpha += (q2.z - acc_b) * dLb;
-                acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d; last_d = q2.w; dL_dalpha += (q2.w - acc_d) * dLd;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
-                const float dL_dG = q1.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                v[0] = dL_dG * (-gdx * q1.x - gdy * q1.y) * ddelx_dx;
-                v[1] = dL_dG * (-gdy * q1.z - gdx * q1.y) * ddely_dy;
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -1.0f * gdx * dy * dL_dG;
-                v[4] = -0.5f * gdy * dy * dL_dG;
-                v[5] = G * dL_dalpha;
-                v[6] = dch * dLr;
-                v[7] = dch * dLg;
-                v[8] = dch * dLb;
-                v[9] = dch * dLd;
+                    for (int e = 0; e < kG; ++e) v[e] = 0.f;
+                    if (act) {
+                        T = T / (1.0f - alpha);
+                        const float dch = alpha * T;
+                        float dL_dalpha = 0.f;
+                        acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r; last_r = q2.x; dL_dalpha += (q2.x - acc_r) * dLr;
+                        acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g; last_g = q2.y; dL_dalpha += (q2.y - acc_g) * dLg;
+                        acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b; last_b = q2.z; dL_dalpha += (q2.z - acc_b) * dLb;
+                        acc_d = last_alpha * last_d + (1.0f - last_alpha) * acc_d; last_d = q2.w; dL_dalpha += (q2.w - acc_d) * dLd;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
+                        const float dL_dG = q1.w * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        v[0] = dL_dG * (-gdx * q1.x - gdy * q1.y) * ddelx_dx;
+                        v[1] = dL_dG * (-gdy * q1.z - gdx * q1.y) * ddely_dy;
+                        v[2] = -0.5f * gdx * dx * dL_dG;
+                        v[3] = -1.0f * gdx * dy * dL_dG;
+                        v[4] = -0.5f * gdy * dy * dL_dG;
+                        v[5] = G * dL_dalpha;
+                        v[6] = dch * dLr;
+                        v[7] = dch * dLg;
+                        v[8] = dch * dLb;
+                        v[9] = dch * dLd;
+                    }
+#pragma unroll
+                    for (int e = 0; e < kG; ++e) v[e] = quad_total(v[e]);
+                    // one lane per block that has an active pixel adds the block's sums to the batch record of ITS entry
+                    if ((lane & 3) == 0 && ((am >> (lane & 60)) & 0xFull) != 0ull) {
+#pragma unroll
+                        for (int e = 0; e < kG; ++e) atomicAdd(&sgr[e][j], v[e]);
+                    }
+                }
             }
+        }
+        __syncthreads();   // every wave's LDS adds of this batch are done
+        if (tid < cnt) {
+            float *o = gr + (size_t)sid[tid] * kG;
 #pragma unroll
-            for (int e = 0; e < kG; ++e) v[e] = wave_total_hi(v[e]);   // totals live in lanes 48..63
-            if (lane >= 48 && lane < 48 + kG) {  // lane 48 + e adds component e: one 10-lane atomic instruction per (wave, Gaussian)
-                float mine = v[0];
-#pragma unroll
-                for (int e = 1; e < kG; ++e) mine = lane == 48 + e ? v[e] : mine;
-                atomicAdd(gr + (size_t)sid[j] * kG + (lane - 48), mine);
+            for (int e = 0; e < kG; ++e) {
+                const float x = sgr[e][tid];
+                if (x != 0.0f) atomicAdd(o + e, x);
             }
         }
     }
