@@ -41,7 +41,7 @@ __device__ __forceinline__ float quad_total(float v) {
 // Same tile / quadrant / 2x2-block layout as the forward's render_kernel (raster_fwd.hip K5): per round of 64 staged entries every
 // lane tests one entry's footprint against the quadrant's four block columns and rows, a block's list is column-mask & row-mask,
 // and the block's 4 lanes walk it from the BACK (per-lane clz) -- one trip of the loop replays up to sixteen different Gaussians.
-// Gradients of a (tile, entry) are accumulated in LDS (per batch of 256 entries: [10][256] floats; a block adds its 4-lane sums with
+// Gradients of a (tile, entry) are accumulated in LDS (per batch of 256 entries: [256][10+1] floats; a block adds its 4-lane sums with
 // ds_add_f32) and leave the workgroup once per batch as plain global atomics on the non-zero components: a pixel-sized Gaussian is
 // seen by several blocks of several waves, and the per-(wave, entry) 64-lane reductions + global atomics of the previous version
 // (and the per-entry scalar loop around them) were VALU time -- this kernel was 62 ms of the 24-scene training step.
@@ -53,7 +53,7 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
     constexpr int NT = 256;
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
     __shared__ uint32_t sid[NT];
-    __shared__ float sgr[kG][NT];
+    __shared__ float sgr[NT][kG + 1];   // [entry][component], 11-float rows: block adds and the flush below both spread over the banks
     __shared__ int s_max;
     const int c = blockIdx.y;
     const int gx = (W + kTile - 1) / kTile;
@@ -114,7 +114,7 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
             sid[tid] = g_cur;
         }
 #pragma unroll
-        for (int e = 0; e < kG; ++e) sgr[e][tid] = 0.f;
+        for (int e = 0; e < kG; ++e) sgr[tid][e] = 0.f;
         __syncthreads();
         g_cur = g_nxt;
         if (b > 0) {   // (batches below the last one are full)
@@ -184,18 +184,22 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
                     // one lane per block that has an active pixel adds the block's sums to the batch record of ITS entry
                     if ((lane & 3) == 0 && ((am >> (lane & 60)) & 0xFull) != 0ull) {
 #pragma unroll
-                        for (int e = 0; e < kG; ++e) atomicAdd(&sgr[e][j], v[e]);
+                        for (int e = 0; e < kG; ++e) atomicAdd(&sgr[j][e], v[e]);
                     }
                 }
             }
         }
         __syncthreads();   // every wave's LDS adds of this batch are done
-        if (tid < cnt) {
-            float *o = gr + (size_t)sid[tid] * kG;
-#pragma unroll
-            for (int e = 0; e < kG; ++e) {
-                const float x = sgr[e][tid];
-                if (x != 0.0f) atomicAdd(o + e, x);
+        // flush: lane = (entry slot 0..5, component 0..9), so the ten atomics of one record are ten adjacent lanes of one instruction
+        // on ten adjacent addresses (one or two cache lines per record), zeros skipped
+        {
+            const int sub = lane / kG, e = lane - sub * kG;
+            for (int k = 0; k < 64; k += 6) {
+                const int j = wid * 64 + k + sub;
+                if (lane < 6 * kG && k + sub < 64 && j < cnt) {
+                    const float x = sgr[j][e];
+                    if (x != 0.0f) atomicAdd(gr + (size_t)sid[j] * kG + e, x);
+                }
             }
         }
     }
