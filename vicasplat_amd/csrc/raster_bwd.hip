@@ -262,9 +262,29 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
 #pragma unroll
     for (int k = 0; k < 16; ++k) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
 
-    for (int c = 0; c < in.num_cameras; ++c) {
-        const int cs = in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes);
-        if (cs != s) continue;  // block-uniform
+    // the scene's cameras, ascending (built once per block by wave 0 with ballot compaction, as in the forward's preprocess_kernel)
+    constexpr int kCamChunk = 2048;
+    __shared__ int cams[kCamChunk];
+    __shared__ int ncam_s;
+    for (int cbase = 0; cbase < in.num_cameras; cbase += kCamChunk) {
+      __syncthreads();
+      if (threadIdx.x < 64) {
+          const int lane = threadIdx.x;
+          int n = 0;
+          const int cend = min(in.num_cameras, cbase + kCamChunk);
+          for (int c0 = cbase; c0 < cend; c0 += 64) {
+              const int c = c0 + lane;
+              const bool mine = c < cend && (in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes)) == s;
+              const unsigned long long m = __ballot(mine);
+              if (mine) cams[n + __popcll(m & ((1ull << lane) - 1ull))] = c;
+              n += __popcll(m);
+          }
+          if (lane == 0) ncam_s = n;
+      }
+      __syncthreads();
+      const int ncam = ncam_s;
+      for (int kc = 0; kc < ncam; ++kc) {
+        const int c = cams[kc];
         const size_t ci = (size_t)c * P + (live ? i : 0);
         float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live && radii[ci] > 0) {
@@ -439,6 +459,7 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
                 if (threadIdx.x == 0 && tsum != 0.f) atomicAdd(&dL_dtau[6 * c + k], tsum);
             }
         }
+      }
     }
     if (!live) return;
     dL_dmeans3D[3 * gi] = g_mean[0]; dL_dmeans3D[3 * gi + 1] = g_mean[1]; dL_dmeans3D[3 * gi + 2] = g_mean[2];
