@@ -107,7 +107,7 @@ typedef struct VsRasterGrads {
     const float *dL_ddepth; /* [C,H,W] or NULL */
     /* outgoing; each is accumulated over the cameras of a scene */
     float *dL_dmeans3D;   /* [S,P,3] */
-    float *dL_dcov3D;     /* [S,P,6] */
+    float *dL_dcov3D;     /* [S,P,6], or [S,P,3,3] under VS_RASTER_COV_3X3 (off-diagonal partials split in halves over the two symmetric entries) */
     float *dL_dshs;       /* [S,P,M,3] or NULL */
     float *dL_dcolors_precomp; /* [S,P,3] or NULL */
     float *dL_dopacities; /* [S,P] */

@@ -496,3 +496,54 @@ def test_camera_twist_gradient_finite_differences_at_full_size():
     assert cos >= 0.9, (cos, ana, fd)
     assert 0.5 <= np.linalg.norm(ana) / np.linalg.norm(fd) <= 2.0
     assert (np.sign(ana) == np.sign(fd)).all()
+
+
+def test_camera_lists_many_cameras_two_scenes():
+    """preprocess / preprocess_backward build each scene's camera list per block in chunks of 2048 cameras: 2200 cameras over two scenes
+    with an irregular camera -> scene map (every camera rendered against the oracle's per-view result for ITS scene), forward state
+    bit-identical, and the Gaussian gradients of the batched backward equal to the sum of the per-camera oracle gradients."""
+    from vicasplat_amd.raster import forward_debug, rasterize
+    d = _dev()
+    W = H = 32
+    P, C = 48, 2200
+    rng = np.random.default_rng(5)
+    sc = [_random_small(P, seed=70 + s, spread=0.5) for s in range(2)]
+    cam_scene = (rng.uniform(size=C) < 0.35).astype(np.int32)        # irregular: ~35 % of the cameras look at scene 1
+    cam_scene[:3] = [1, 0, 1]
+    Es = np.tile(np.eye(4, dtype=np.float32)[None], (C, 1, 1))
+    Es[:, :3, 3] = rng.uniform(-0.05, 0.05, (C, 3)).astype(np.float32)
+    cams = rr.make_cameras(Es, np.tile(K09[None], (C, 1, 1)), np.full(C, 0.01, np.float32), np.full(C, 100.0, np.float32))
+    g = _gpu_cams(cams)
+    T = lambda k: torch.tensor(np.stack([s[k] for s in sc]), dtype=torch.float32, device=d)
+    means, cov6, shs, op = T(0), torch.tensor(np.stack([rr.cov6(s[1]) for s in sc]), device=d), T(2), T(3)
+    bg = np.array([0.05, 0.1, 0.15], np.float32)
+    bgt = torch.tensor(bg, device=d).expand(C, 3).contiguous()
+    cs = torch.tensor(cam_scene, device=d)
+    out = forward_debug(means, cov6, op, g["viewmatrix"], g["projmatrix"], g["campos"], g["tanfov"], bgt, H, W, shs=shs, sh_degree=4,
+                        cam_scene=cs)
+    check = [0, 1, 2, 2047, 2048, 2049, C - 1] + list(rng.integers(3, C, 6))
+    tot_checked = 0
+    for c in check:
+        s = int(cam_scene[c])
+        o = rr.rasterize_forward(cams[c], W, H, bg, sc[s][0], rr.cov6(sc[s][1]), sc[s][2], sc[s][3])
+        assert np.array_equal(out["radii"][c].cpu().numpy(), o["radii"]), f"camera {c}"
+        rg = out["ranges"][c].cpu().numpy()
+        assert np.array_equal(rg[:, 1] - rg[:, 0], o["ranges"][:, 1] - o["ranges"][:, 0])
+        assert np.array_equal(out["point_list"].cpu().numpy().astype(np.uint32)[rg[:, 0].min():rg[:, 1].max()], o["point_list"])
+        assert np.abs(out["color"][c].cpu().numpy() - o["color"]).max() < 5e-4
+        tot_checked += o["R"]
+    assert tot_checked > 0 and out["R"] > 0
+    # backward: d(sum of all renders * w) / d(means, opacities) of scene s only sees the cameras mapped to s
+    wts = torch.tensor(rng.standard_normal((C, 3, H, W)), dtype=torch.float32, device=d)
+    m_, o_ = means.clone().requires_grad_(True), op.clone().requires_grad_(True)
+    color, *_ = rasterize(m_, cov6, o_, g["viewmatrix"], g["projmatrix"], g["campos"], g["tanfov"], bgt, H, W, shs=shs, sh_degree=4,
+                          cam_scene=cs)
+    (color * wts).sum().backward()
+    for s in range(2):
+        idx = torch.tensor(np.nonzero(cam_scene == s)[0], device=d)
+        m1, o1 = means[s:s + 1].clone().requires_grad_(True), op[s:s + 1].clone().requires_grad_(True)
+        col1, *_ = rasterize(m1, cov6[s:s + 1], o1, g["viewmatrix"][idx], g["projmatrix"][idx], g["campos"][idx], g["tanfov"][idx],
+                             bgt[idx].contiguous(), H, W, shs=shs[s:s + 1], sh_degree=4)
+        (col1 * wts[idx]).sum().backward()
+        for a, b in ((m_.grad[s], m1.grad[0]), (o_.grad[s], o1.grad[0])):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), s

@@ -463,8 +463,14 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
     }
     if (!live) return;
     dL_dmeans3D[3 * gi] = g_mean[0]; dL_dmeans3D[3 * gi + 1] = g_mean[1]; dL_dmeans3D[3 * gi + 2] = g_mean[2];
+    if (in.flags & VS_RASTER_COV_3X3) {   // the caller differentiates the symmetric 3x3 layout: off-diagonal partials split in halves
+        float *o = dL_dcov3D + 9 * gi;
+        o[0] = g_cov[0]; o[4] = g_cov[3]; o[8] = g_cov[5];
+        o[1] = o[3] = 0.5f * g_cov[1]; o[2] = o[6] = 0.5f * g_cov[2]; o[5] = o[7] = 0.5f * g_cov[4];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * gi + k] = g_cov[k];
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * gi + k] = g_cov[k];
+    }
     dL_dopac[gi] = g_op;
     if (has_sh) {
         if (dL_dshs) {

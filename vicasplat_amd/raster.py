@@ -126,12 +126,13 @@ class _Rasterize(torch.autograd.Function):
         g_color = _f32c(g_color) if g_color is not None else torch.zeros((Cn, 3, H, W), dtype=torch.float32, device=dev)
         g_depth = _f32c(g_depth)
         g = L.VsRasterGrads()
-        d_means = torch.zeros_like(means3D)
-        d_cov = torch.zeros((S, P, 6), dtype=torch.float32, device=dev)
-        d_shs = torch.zeros_like(shs) if shs is not None else None
-        d_cp = torch.zeros_like(colors_precomp) if colors_precomp is not None else None
-        d_op = torch.zeros_like(opacities)
-        d_m2d = torch.zeros((Cn, P, 2), dtype=torch.float32, device=dev)
+        # every element of these is stored by preprocess_backward_kernel (one thread per Gaussian); dL_dmeans2D is cleared by the C side
+        d_means = torch.empty_like(means3D)
+        d_cov = torch.empty((S, P, 3, 3) if cov33 else (S, P, 6), dtype=torch.float32, device=dev)   # layout of the input covariances
+        d_shs = torch.empty_like(shs) if shs is not None else None
+        d_cp = torch.empty_like(colors_precomp) if colors_precomp is not None else None
+        d_op = torch.empty_like(opacities)
+        d_m2d = torch.empty((Cn, P, 2), dtype=torch.float32, device=dev)
         d_tau = torch.zeros((Cn, 6), dtype=torch.float32, device=dev) if ctx.want_tau else None
         g.dL_dcolor, g.dL_ddepth = L.ptr(g_color), L.ptr(g_depth)
         g.dL_dmeans3D, g.dL_dcov3D, g.dL_dshs, g.dL_dcolors_precomp = L.ptr(d_means), L.ptr(d_cov), L.ptr(d_shs), L.ptr(d_cp)
@@ -141,13 +142,6 @@ class _Rasterize(torch.autograd.Function):
             rc = lib.vs_raster_backward(C.byref(ctx.inp), C.byref(ctx.out), C.byref(g), alloc.fn, None, L.stream_ptr(dev))
         alloc.fn = None
         L.check(rc, "vs_raster_backward")
-        if cov33:  # spread the 6 unique partials back onto the symmetric 3x3 layout the caller differentiates
-            d33 = torch.empty((S, P, 3, 3), dtype=torch.float32, device=dev)
-            d33[..., 0, 0] = d_cov[..., 0]; d33[..., 1, 1] = d_cov[..., 3]; d33[..., 2, 2] = d_cov[..., 5]
-            d33[..., 0, 1] = d33[..., 1, 0] = 0.5 * d_cov[..., 1]
-            d33[..., 0, 2] = d33[..., 2, 0] = 0.5 * d_cov[..., 2]
-            d33[..., 1, 2] = d33[..., 2, 1] = 0.5 * d_cov[..., 4]
-            d_cov = d33
         d_theta = d_tau[:, 3:] if d_tau is not None else None
         d_rho = d_tau[:, :3] if d_tau is not None else None
         return (d_means, d_cov, d_shs, d_cp, d_op, None, None, None, None, None, None, d_theta, d_rho, None, None, None,
