@@ -98,6 +98,32 @@ def test_encoder_full_vitl_8view_matches_reference():
     _check("full_v8", torch.float16, 5e-3, 3e-2)
 
 
+def test_encoder_full_vitl_2view_batch16_matches_reference():
+    """BASELINE.json config 2 at the configuration's batch size (re10k_2view: 16 scenes per step): the golden scene rides in slot 5 of
+    a 16-scene batch (15 other seeds around it) and must match the reference's float64 outputs at the same bounds as alone -- the
+    batched launches (other GEMM tile routes, 32 frames per attention launch) may not leak between scenes."""
+    z = np.load(os.path.join(G, "encoder_full_v2.npz"))
+    assert int(z["cfg_B"]) == 1 and int(z["cfg_V"]) == 2
+    m = _model("full")
+    img0, K0 = er.synthetic_input(1, 2, 256, int(z["cfg_seed"]))
+    img, K = er.synthetic_input(16, 2, 256, 1234)
+    img[5], K[5] = img0[0], K0[0]
+    out = m(dict(image=img.cuda(), intrinsics=K.cuda()), compute_viewspace_depth=False)
+    torch.cuda.synchronize()
+    assert out["raw_gaussians"].shape == (16, 2, 256, 256, 86)
+    errs = dict(pose=_rel(out["pred_extrins"][5:6].cpu(), z["f64_pred_extrins"]))
+    raw = out["raw_gaussians"][5:6, :, LAT, LAT].cpu().numpy()
+    for nm, sl in (("xyz", slice(0, 3)), ("opacity", slice(3, 4)), ("scale", slice(4, 7)), ("quat", slice(7, 11)), ("sh", slice(11, 86))):
+        errs[nm] = _rel(raw[..., sl], z["f64_raw"][..., sl])
+    g = out["gaussians"]
+    for k in ("means", "covariances", "harmonics", "opacities"):
+        errs["g_" + k] = _rel(getattr(g, k)[5:6, :, LAT, LAT].cpu().numpy(), z[f"f64_{k}"])
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["pose"] <= 5e-3, errs
+    assert all(errs[k] <= 3e-2 for k in errs if k != "pose"), errs
+    assert bool(torch.isfinite(out["raw_gaussians"]).all()) and bool(torch.isfinite(out["pred_extrins"]).all())
+
+
 def test_encoder_bf16_path_runs():
     _check("tiny_v2", torch.bfloat16, 3e-2, 2e-1)
 
