@@ -444,21 +444,23 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
 }
 
 // ---- bilinear x2, align_corners=True, NHWC 16-bit; optional fused "+ add" (gs head: up2(trunk) + image features) ----
+// grid = (ceil(Wo * C/8 / 256), Nimg * Ho): the row quantities (image, source rows, ly) are block-uniform and the per-thread index math
+// is 32-bit (one thread per (output pixel, 8 channels); the flat 64-bit div/mod chain of the first version was ~200 VALU per 16 bytes
+// of output -- the kernel ran VALU-bound at 3.6 TB/s).  Source index = dst * (in-1)/(out-1) with the ratio formed once in f32, as
+// PyTorch's area_pixel_compute_source_index does for align_corners=True (and as the backward kernel below does).
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *__restrict__ add, unsigned short *__restrict__ out,
                   int Nimg, int H, int W, int C, int relu_add) {
     const int Ho = 2 * H, Wo = 2 * W, c8 = C >> 3;
-    const long long total = (long long)Nimg * Ho * Wo * c8;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cc = (int)(idx % c8);
-    long long p = idx / c8;
-    const int xo = (int)(p % Wo); p /= Wo;
-    const int yo = (int)(p % Ho);
-    const int n = (int)(p / Ho);
-    const float sy = Ho > 1 ? (float)yo * (float)(H - 1) / (float)(Ho - 1) : 0.f;
-    const float sx = Wo > 1 ? (float)xo * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Wo * c8) return;
+    const int xo = e / c8, cc = e - xo * c8;
+    const int row = blockIdx.z * gridDim.y + blockIdx.y;   // (grid.y is capped at 32768 rows; larger batches spill into grid.z)
+    if (row >= Nimg * Ho) return;
+    const int n = row / Ho, yo = row - n * Ho;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float sy = (float)yo * ry, sx = (float)xo * rx;
     const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = sy - (float)y0, lx = sx - (float)x0;
@@ -495,21 +497,19 @@ upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *_
     *reinterpret_cast<uint4 *>(out + o) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
-// f32 variant (reference-precision path): one thread per (output pixel, 4 channels), same index math
+// f32 variant (reference-precision path): one thread per (output pixel, 4 channels), same grid and index math
 __global__ void __launch_bounds__(256)
 upsample2x_f32_kernel(const float *__restrict__ in, const float *__restrict__ add, float *__restrict__ out, int Nimg, int H, int W, int C,
                       int relu_add) {
     const int Ho = 2 * H, Wo = 2 * W, c4 = C >> 2;
-    const long long total = (long long)Nimg * Ho * Wo * c4;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cc = (int)(idx % c4);
-    long long p = idx / c4;
-    const int xo = (int)(p % Wo); p /= Wo;
-    const int yo = (int)(p % Ho);
-    const int n = (int)(p / Ho);
-    const float sy = Ho > 1 ? (float)yo * (float)(H - 1) / (float)(Ho - 1) : 0.f;
-    const float sx = Wo > 1 ? (float)xo * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Wo * c4) return;
+    const int xo = e / c4, cc = e - xo * c4;
+    const int row = blockIdx.z * gridDim.y + blockIdx.y;   // (grid.y is capped at 32768 rows; larger batches spill into grid.z)
+    if (row >= Nimg * Ho) return;
+    const int n = row / Ho, yo = row - n * Ho;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float sy = (float)yo * ry, sx = (float)xo * rx;
     const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = sy - (float)y0, lx = sx - (float)x0;
@@ -539,14 +539,12 @@ template <bool BF16>
 __global__ void __launch_bounds__(256)
 upsample2x_backward_kernel(const unsigned short *__restrict__ dout, unsigned short *__restrict__ din, int Nimg, int H, int W, int C) {
     const int Ho = 2 * H, Wo = 2 * W, c8 = C >> 3;
-    const long long total = (long long)Nimg * H * W * c8;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cc = (int)(idx % c8);
-    long long p = idx / c8;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int n = (int)(p / H);
+    const int e = blockIdx.x * 256 + threadIdx.x;          // grid = (ceil(W * C/8 / 256), rows of din), as the forward
+    if (e >= W * c8) return;
+    const int x = e / c8, cc = e - x * c8;
+    const int row = blockIdx.z * gridDim.y + blockIdx.y;
+    if (row >= Nimg * H) return;
+    const int n = row / H, y = row - n * H;
     const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int yo = max(0, 2 * y - 3); yo <= min(Ho - 1, 2 * y + 3); ++yo) {
@@ -691,17 +689,17 @@ extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, in
     VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_upsample2x_nhwc: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
     if (dtype == 3) {
         VS_CHECK(C % 4 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 4", C);
-        const long long tot = (long long)Nimg * 4 * H * W * (C / 4);
-        if (tot <= 0) return 0;
-        hipLaunchKernelGGL(upsample2x_f32_kernel, dim3((unsigned)vs::cdiv64(tot, 256)), dim3(256), 0, stream, (const float *)in, (const float *)add,
-                           (float *)out, Nimg, H, W, C, relu_add);
+        if ((long long)Nimg * H * W * C <= 0) return 0;
+        const int rows = Nimg * 2 * H, gy = rows < 32768 ? rows : 32768;
+        hipLaunchKernelGGL(upsample2x_f32_kernel, dim3((unsigned)vs::cdiv(2 * W * (C / 4), 256), gy, vs::cdiv(rows, gy)), dim3(256), 0, stream,
+                           (const float *)in, (const float *)add, (float *)out, Nimg, H, W, C, relu_add);
         VS_HIP(hipGetLastError());
         return 0;
     }
     VS_CHECK(C % 8 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 8", C);
-    const long long total = (long long)Nimg * 4 * H * W * (C / 8);
-    if (total <= 0) return 0;
-    dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);
+    if ((long long)Nimg * H * W * C <= 0) return 0;
+    const int rows = Nimg * 2 * H, gy = rows < 32768 ? rows : 32768;
+    dim3 grid((unsigned)vs::cdiv(2 * W * (C / 8), 256), gy, vs::cdiv(rows, gy)), block(256);
     if (dtype == 2) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C, relu_add);
     else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, block, 0, stream, (const unsigned short *)in, (const unsigned short *)add, (unsigned short *)out, Nimg, H, W, C, relu_add);
     VS_HIP(hipGetLastError());
@@ -714,9 +712,9 @@ extern "C" int vs_upsample2x_backward_nhwc(const void *dout, void *din, int32_t 
     VS_CHECK(dout && din, "vs_upsample2x_backward_nhwc: null pointer");
     VS_CHECK(C % 8 == 0, "vs_upsample2x_backward_nhwc: C=%d must be a multiple of 8", C);
     VS_CHECK(dtype == 1 || dtype == 2, "vs_upsample2x_backward_nhwc: dtype must be 1 (f16) or 2 (bf16)");
-    const long long total = (long long)Nimg * H * W * (C / 8);
-    if (total <= 0) return 0;
-    dim3 grid((unsigned)vs::cdiv64(total, 256)), block(256);
+    if ((long long)Nimg * H * W * C <= 0) return 0;
+    const int rows = Nimg * H, gy = rows < 32768 ? rows : 32768;
+    dim3 grid((unsigned)vs::cdiv(W * (C / 8), 256), gy, vs::cdiv(rows, gy)), block(256);
     if (dtype == 2) hipLaunchKernelGGL(upsample2x_backward_kernel<true>, grid, block, 0, stream, (const unsigned short *)dout, (unsigned short *)din, Nimg, H, W, C);
     else hipLaunchKernelGGL(upsample2x_backward_kernel<false>, grid, block, 0, stream, (const unsigned short *)dout, (unsigned short *)din, Nimg, H, W, C);
     VS_HIP(hipGetLastError());
