@@ -42,6 +42,7 @@ def parse():
                          "and report it in the `train` object of the same JSON line; train: `value` IS the training throughput")
     ap.add_argument("--train-scenes-per-gpu", type=int, default=24)    # README.md:104 / distill.yaml: 24 scenes per GPU
     ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-timeout", type=float, default=240.0, help="seconds after which a stalled training leg is abandoned and the headline line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the reference-precision (f32) leg")
@@ -392,9 +393,30 @@ def main():
         enc.set_compute_dtype(dt)
         torch.cuda.empty_cache()
 
+    def headline(train):
+        return dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(value, 3), unit="scenes/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype=args.dtype, data="synthetic",
+                    config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
+                                         f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
+                                parallelism=f"scene-sharded x{world} (no collective)"),
+                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, f32_path=f32_path, train=train, **extra)
+
     train = None
     if args.mode in ("train", "both"):
         del ctx
+        # The training leg is the only part of this file with collectives in its data path.  If it stalls (a rank lost inside an
+        # all-reduce), the already-measured headline must still be reported: a watchdog prints it from rank 0 and ends every rank.
+        import threading
+
+        def give_up():
+            if rank == 0 and args.mode != "train":
+                print(json.dumps(headline(dict(error=f"training leg did not finish within {args.train_timeout} s"))), flush=True)
+            os._exit(0 if args.mode != "train" else 3)
+
+        dog = threading.Timer(args.train_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             train = train_leg(args, enc, dec, dev, rank, world, dist)
         except Exception as e:      # the headline line must survive a failure of the optional training leg
@@ -403,6 +425,8 @@ def main():
             train = dict(error=repr(e)[:300])
             if dist is not None:    # the ranks may have diverged inside a collective: nothing after this point may need them in step
                 dist = None
+        finally:
+            dog.cancel()
     if rank == 0 and args.mode == "train":
         print(json.dumps(dict(metric=train["metric"], value=train["value"], unit="scenes/s", n_gpus=world, steps=args.train_steps, warmup=1,
                               ms_per_step=train["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype,
@@ -411,13 +435,7 @@ def main():
                                                             parallelism=f"data-parallel x{world}: " + train["gradient_exchange"]),
                               roofline=train["roofline"], cpu_baseline=None, train=train)))
     elif rank == 0:
-        line = dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(value, 3), unit="scenes/s", n_gpus=world,
-                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype=args.dtype, data="synthetic",
-                    config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
-                                         f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
-                                parallelism=f"scene-sharded x{world} (no collective)"),
-                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, f32_path=f32_path, train=train, **extra)
+        line = headline(train)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
