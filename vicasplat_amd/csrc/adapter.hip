@@ -117,19 +117,39 @@ __device__ __forceinline__ float cvt16(unsigned short h) {
     else { _Float16 f = *reinterpret_cast<_Float16 *>(&h); return (float)f; }
 }
 
-__device__ __forceinline__ void flush_block(const float *__restrict__ sm, float *__restrict__ dst, int nfloat, int lane) {
-    // dst is 16-byte aligned (block start * per-pixel floats * 64 pixels); nfloat % 4 == 0 for full blocks
-    const int nv = nfloat >> 2;
-    for (int k = lane; k < nv; k += 64) reinterpret_cast<float4 *>(dst)[k] = reinterpret_cast<const float4 *>(sm)[k];
-    for (int k = (nv << 2) + lane; k < nfloat; k += 64) dst[k] = sm[k];
+// x / d == umulhi(x, div_magic(d)) for every index used here (x < 64 * 96, 2 <= d <= 96): the error x * (m d - 2^32) stays below 2^32
+__device__ __forceinline__ unsigned div_magic(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }   // d >= 2
+
+// One block of `per` floats per pixel for np pixels, written as 16-byte vectors straight to HBM (dst is 16-byte aligned: block start
+// * per * 64 pixels); element (px, c) comes from f(px, c).  No LDS image of the output: the wide rows (raw 86 floats, harmonics 75)
+// are conversions of the staged 16-bit input row, and an output tile in LDS (24.6 KiB) held this kernel to 4 waves per CU.
+template <class F>
+__device__ __forceinline__ void write_rows(float *__restrict__ dst, int np, int per, int lane, F f) {
+    const unsigned m = div_magic((unsigned)per);
+    const int n = np * per, nv = n >> 2;
+    for (int k4 = lane; k4 < nv; k4 += 64) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned k = (unsigned)(4 * k4 + j), px = __umulhi(k, m);
+            v[j] = f((int)px, (int)(k - px * (unsigned)per));
+        }
+        reinterpret_cast<float4 *>(dst)[k4] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (int k = (nv << 2) + lane; k < n; k += 64) {
+        const unsigned px = __umulhi((unsigned)k, m);
+        dst[k] = f((int)px, (int)((unsigned)k - px * (unsigned)per));
+    }
 }
 
 template <bool BF16>
 __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a) {
     // pixel strides may exceed the channel counts (gs rows padded to a multiple of 16 channels, pts rows to 4: what the fused
     // conv3 -> conv1 head kernel writes); the staged blocks keep the stride
+    constexpr int kPx = 28;   // per-pixel results: means 3 | raw opacity 1 | raw scale 3 | raw quat 4 | cov 9 | scale 3 | quat 4 | opacity 1
     __shared__ __attribute__((aligned(16))) unsigned short sin[64 * kMaxPixStride + 64 * 8 + 16];
-    __shared__ __attribute__((aligned(16))) float sout[64 * kMaxCh];
+    __shared__ float spx[64][kPx + 1];
+    __shared__ float smask[kMaxCh];
     const int lane = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * 64;
     const int np = (int)min((long long)64, a.npix - p0);
@@ -143,12 +163,15 @@ __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a)
         for (int k = ((n1 >> 3) << 3) + lane; k < n1; k += 64) sgs[k] = ggs[k];
         for (int k = lane; k < (n2 >> 3); k += 64) reinterpret_cast<uint4 *>(spt)[k] = reinterpret_cast<const uint4 *>(gpt)[k];
         for (int k = ((n2 >> 3) << 3) + lane; k < n2; k += 64) spt[k] = gpt[k];
+        for (int c = lane; c < 3 * nsh; c += 64) smask[c] = a.sh_mask[c % nsh];   // mask per (channel, coefficient) column
     }
     __syncthreads();
     const bool live = lane < np;
     const unsigned short *mg = sgs + lane * cg;
     float mx = 0.f, my = 0.f, mz = 0.f, p = 0.f, s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 1.f}, cov[9];
     float o_raw = 0.f, sr[3] = {0.f, 0.f, 0.f}, qr[4] = {0.f, 0.f, 0.f, 1.f};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) cov[c] = 0.f;
     if (live) {
         const float x = cvt16<BF16>(spt[lane * cp]), y = cvt16<BF16>(spt[lane * cp + 1]), z = cvt16<BF16>(spt[lane * cp + 2]);
         const float d = sqrtf(x * x + y * y + z * z);
@@ -192,47 +215,32 @@ __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a)
 #pragma unroll
             for (int c = 0; c < 3; ++c) cov[3 * r + c] = RS[r][0] * RS[c][0] + RS[r][1] * RS[c][1] + RS[r][2] * RS[c][2];
     }
-    // ---- raw [px][craw] ----
-    if (a.raw) {
-        if (live) {
-            float *r = sout + lane * craw;
-            r[0] = mx; r[1] = my; r[2] = mz; r[3] = o_raw;
+    {   // per-pixel results -> LDS rows (29-float stride: conflict-free for the row-per-lane stores), read back by the block writers
+        float *r = spx[lane];
+        r[0] = mx; r[1] = my; r[2] = mz; r[3] = o_raw;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) r[4 + c] = sr[c];
+        for (int c = 0; c < 3; ++c) r[4 + c] = sr[c];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) r[7 + c] = qr[c];
-            for (int c = 0; c < 3 * nsh; ++c) r[11 + c] = cvt16<BF16>(mg[8 + c]);
-        }
-        __syncthreads();
-        flush_block(sout, a.raw + p0 * craw, np * craw, lane);
-        __syncthreads();
-    }
-    // ---- harmonics [px][3*nsh] ----
-    if (live) {
-        float *r = sout + lane * 3 * nsh;
-        for (int c = 0; c < 3 * nsh; ++c) r[c] = cvt16<BF16>(mg[8 + c]) * a.sh_mask[c % nsh];
+        for (int c = 0; c < 4; ++c) r[7 + c] = qr[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) r[11 + c] = cov[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[20 + c] = s[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[23 + c] = q[c];
+        r[27] = p;
     }
     __syncthreads();
-    flush_block(sout, a.harmonics + p0 * 3 * nsh, np * 3 * nsh, lane);
-    __syncthreads();
-    // ---- covariances [px][9] | means [px][3] | scales [px][3] | rotations [px][4] | opacities [px] packed in one LDS tile ----
-    float *s_cov = sout, *s_mean = sout + 64 * 9, *s_scale = s_mean + 64 * 3, *s_rot = s_scale + 64 * 3, *s_op = s_rot + 64 * 4;
-    if (live) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) s_cov[lane * 9 + c] = cov[c];
-        s_mean[lane * 3] = mx; s_mean[lane * 3 + 1] = my; s_mean[lane * 3 + 2] = mz;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s_scale[lane * 3 + c] = s[c];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s_rot[lane * 4 + c] = q[c];
-        s_op[lane] = p;
-    }
-    __syncthreads();
-    flush_block(s_cov, a.cov + p0 * 9, np * 9, lane);
-    flush_block(s_mean, a.means + p0 * 3, np * 3, lane);
-    flush_block(s_scale, a.scales + p0 * 3, np * 3, lane);
-    flush_block(s_rot, a.rotations + p0 * 4, np * 4, lane);
-    flush_block(s_op, a.opacities + p0, np, lane);
+    // raw [px][11 + 3 d_sh] = means | pre-activation opacity, scale, quaternion | SH as the head wrote them
+    if (a.raw)
+        write_rows(a.raw + p0 * craw, np, craw, lane, [&](int px, int c) { return c < 11 ? spx[px][c] : cvt16<BF16>(sgs[px * cg + c - 3]); });
+    // harmonics [px][3][d_sh] = SH * sh_mask
+    write_rows(a.harmonics + p0 * 3 * nsh, np, 3 * nsh, lane, [&](int px, int c) { return cvt16<BF16>(sgs[px * cg + 8 + c]) * smask[c]; });
+    write_rows(a.cov + p0 * 9, np, 9, lane, [&](int px, int c) { return spx[px][11 + c]; });
+    write_rows(a.means + p0 * 3, np, 3, lane, [&](int px, int c) { return spx[px][c]; });
+    write_rows(a.scales + p0 * 3, np, 3, lane, [&](int px, int c) { return spx[px][20 + c]; });
+    write_rows(a.rotations + p0 * 4, np, 4, lane, [&](int px, int c) { return spx[px][23 + c]; });
+    if (live) a.opacities[p0 + lane] = p;
 }
 
 // ---- backward of the adapter (training): gradients of the Gaussian attributes -> gradients of the two heads' 16-bit NHWC
