@@ -280,28 +280,23 @@ __device__ __forceinline__ unsigned short to16a(float v) {
 
 template <bool BF16>
 __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_harm[64 * (kMaxCh - 11)], s_raw[64 * kMaxCh];
-    __shared__ __attribute__((aligned(16))) unsigned short s_out[64 * kMaxCh + 16];
+    // per-pixel results (8 leading d_gs channels) and the mask per SH column are all that goes through LDS: the wide rows (d_harm, d_raw
+    // -> d_gs) are an element-wise map written straight from global to global as 16-byte vectors (the [64][75] + [64][86] float tiles
+    // plus the 16-bit output tile of the first version were 58 KiB: two waves per CU)
+    __shared__ float s_dg8[64][9];
+    __shared__ float smask[kMaxCh];
     const int lane = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * 64;
     const int np = (int)min((long long)64, a.npix - p0);
     const int nsh = a.d_sh, cg = 8 + 3 * nsh, craw = 11 + 3 * nsh, nh = 3 * nsh;
-    {   // coalesced loads of the block's harmonics / raw gradient rows
-        const float *gh = a.d_harm + p0 * nh;
-        for (int k = lane; k < np * nh; k += 64) s_harm[k] = gh[k];
-        if (a.d_raw) {
-            const float *gr = a.d_raw + p0 * craw;
-            for (int k = lane; k < np * craw; k += 64) s_raw[k] = gr[k];
-        }
-    }
-    __syncthreads();
+    for (int c = lane; c < nh; c += 64) smask[c] = a.sh_mask[c % nsh];
     const bool live = lane < np;
     const long long i = p0 + lane;
     float dpt[3] = {0.f, 0.f, 0.f}, dg8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
         const unsigned short *pp = reinterpret_cast<const unsigned short *>(a.pts) + i * a.pts_pix;
         const unsigned short *gg = reinterpret_cast<const unsigned short *>(a.gs) + i * cg;
-        const float *rr = a.d_raw ? s_raw + lane * craw : nullptr;
+        const float *rr = a.d_raw ? a.d_raw + i * craw : nullptr;   // the 11 leading columns of this pixel's raw-gradient row
         // ---- means ----
         const float x = cvt16<BF16>(pp[0]), y = cvt16<BF16>(pp[1]), z = cvt16<BF16>(pp[2]);
         float gm[3] = {a.d_means[3 * i], a.d_means[3 * i + 1], a.d_means[3 * i + 2]};
@@ -390,23 +385,31 @@ __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdAr
 #pragma unroll
         for (int c = 0; c < 4; ++c) dg8[4 + c] = (dq[c] - q[c] * qdq) / qn + (rr ? rr[7 + c] : 0.f);
     }
-    // ---- d_gs block [64][cg] 16-bit through LDS ----
+    // ---- d_gs block [np][gld] 16-bit: columns 0..7 from the per-pixel chain rule, 8.. = d_harm * mask (+ d_raw), padding zero ----
     const int gld = a.d_gs_ld;
-    if (live) {
-        unsigned short *o = s_out + lane * gld;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = to16a<BF16>(dg8[c]);
-        const float *hh = s_harm + lane * nh;
-        const float *rr = a.d_raw ? s_raw + lane * craw : nullptr;
-        for (int c = 0; c < nh; ++c) o[8 + c] = to16a<BF16>(hh[c] * a.sh_mask[c % nsh] + (rr ? rr[11 + c] : 0.f));
-        for (int c = cg; c < gld; ++c) o[c] = 0;
-    }
+    for (int c = 0; c < 8; ++c) s_dg8[lane][c] = dg8[c];
     __syncthreads();
     {
         unsigned short *dst = reinterpret_cast<unsigned short *>(a.d_gs) + p0 * gld;
-        const int n = np * gld;
-        for (int k = lane; k < (n >> 3); k += 64) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(s_out)[k];
-        for (int k = ((n >> 3) << 3) + lane; k < n; k += 64) dst[k] = s_out[k];
+        const float *gh = a.d_harm + p0 * nh;
+        const float *gr = a.d_raw ? a.d_raw + p0 * craw : nullptr;
+        const unsigned m = div_magic((unsigned)gld);
+        auto elem = [&](unsigned k) -> unsigned short {
+            const unsigned px = __umulhi(k, m), c = k - px * (unsigned)gld;
+            float v = 0.f;
+            if (c < 8u) v = s_dg8[px][c];
+            else if (c < (unsigned)cg) v = gh[px * nh + (c - 8)] * smask[c - 8] + (gr ? gr[px * craw + 3 + c] : 0.f);
+            return to16a<BF16>(v);
+        };
+        const int n = np * gld, nv = n >> 3;
+        for (int k8 = lane; k8 < nv; k8 += 64) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (unsigned)elem((unsigned)(8 * k8 + 2 * j)) | ((unsigned)elem((unsigned)(8 * k8 + 2 * j + 1)) << 16);
+            reinterpret_cast<uint4 *>(dst)[k8] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        for (int k = (nv << 3) + lane; k < n; k += 64) dst[k] = elem((unsigned)k);
     }
     if (live) {
         unsigned short *dp = reinterpret_cast<unsigned short *>(a.d_pts) + i * a.d_pts_ld;
