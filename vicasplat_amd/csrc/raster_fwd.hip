@@ -719,7 +719,8 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
 // set bits of its mask -- per-lane ctz, LDS reads at up to sixteen different addresses per wave -- so one trip of the loop
 // blends up to sixteen different Gaussians and the trip count is the LONGEST block list instead of the union over the 8x8
 // quadrant (a 3-4 px footprint reaches ~8 of 64 entries per block against ~34 per quadrant).
-// The trip is straight-line predicated code, not nested branches.  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
+// The trip is straight-line predicated code, not nested branches.  (Per-PIXEL lists -- 8 + 8 masks, 64 different LDS addresses per read --
+// were measured at 18 ms against 7.0 for the blocks: the broadcast reads turn into bank-conflicted gathers.)  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
 // `contributor` counts every list entry, so final_T / n_contrib match the oracle.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRenderRecsPerThread = 1;   // (2 = 512-entry batches: measured 11 % slower, the LDS costs occupancy)
