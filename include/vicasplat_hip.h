@@ -57,6 +57,12 @@ typedef struct VsRasterIn {
     const float *campos;         /* [C,3] */
     const float *tanfov;         /* [C,2] (x,y) -- on the DEVICE: no .item() host sync (cuda_splatting.py:210-211) */
     const float *background;     /* [C,3] */
+    int64_t capacity;            /* 0: exact mode -- the instance count R is copied back to the host to size the key / list buffers (ONE
+                                    stream synchronisation per call, as upstream's rasterize_gaussians does per view).
+                                    > 0: no host synchronisation; the buffers are sized for `capacity` (Gaussian, tile) instances.  If the
+                                    call produces more, nothing is rendered (background only), buffers[VS_BUF_MISC] int64[2] is set to 1 and
+                                    int64[0] holds the R that was needed: the caller checks the flag whenever it next synchronises and
+                                    repeats the call with a larger capacity. */
 } VsRasterIn;
 
 enum {
@@ -82,7 +88,7 @@ enum {
     VS_BUF_SORT_SCRATCH = 7, /* [R] u64 bucketized / ping-pong keys of the large-tile sort + its segment table */
     VS_BUF_FINAL_T = 8,   /* [C,H,W] f32 */
     VS_BUF_N_CONTRIB = 9, /* [C,H,W] i32 */
-    VS_BUF_MISC = 10,     /* small control block */
+    VS_BUF_MISC = 10,     /* int64[4] control block: [0] R, [1] largest tile population, [2] capacity overflow flag */
     VS_BUF_DEPTH = 11,    /* [C,P] f32 view-space depth of the visible pairs (sort-key source; undefined where rect is all-zero) */
     VS_BUF_COUNT = 12
 };
@@ -98,7 +104,7 @@ typedef struct VsRasterOut {
     void *buffers[VS_BUF_COUNT]; /* filled on return with what the allocator handed out */
 } VsRasterOut;
 
-/* returns R (>= 0) or < 0 */
+/* returns R (>= 0; `capacity` in the capacity mode, where R itself stays on the device: buffers[VS_BUF_MISC] int64[0]) or < 0 */
 int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsAllocFn alloc, void *alloc_ctx, vs_stream_t stream);
 
 typedef struct VsRasterGrads {

@@ -547,3 +547,39 @@ def test_camera_lists_many_cameras_two_scenes():
         (col1 * wts[idx]).sum().backward()
         for a, b in ((m_.grad[s], m1.grad[0]), (o_.grad[s], o1.grad[0])):
             assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), s
+
+
+def test_capacity_mode_renders_without_host_sync_and_flags_overflow():
+    """vs_raster_forward's capacity mode (VsRasterIn.capacity > 0): identical outputs and gradients to the exact mode when the capacity
+    covers the instances; with a capacity that is too small the render is background only and the device-side flag is raised."""
+    from vicasplat_amd import raster
+    from vicasplat_amd.raster import rasterize
+    d = _dev()
+    W = H = 64
+    means, cov, sh, op = _random_small(800, seed=3)
+    cams = _two_cams()
+    g = _gpu_cams(cams)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=d).expand(2, 3).contiguous()
+    T = lambda a: torch.tensor(a, dtype=torch.float32, device=d)[None]
+    args = lambda m, o: (m, torch.tensor(rr.cov6(cov), device=d)[None], o, g["viewmatrix"], g["projmatrix"], g["campos"], g["tanfov"], bg, H, W)
+    wts = torch.randn(2, 3, H, W, device=d)
+
+    def run(cap):
+        m, o = T(means).requires_grad_(True), T(op).requires_grad_(True)
+        with raster.instance_capacity(cap):
+            color, radii, depth, *_ = rasterize(*args(m, o), shs=T(sh), sh_degree=4)
+        info = raster.last_call()
+        (color * wts).sum().backward()
+        return color.detach(), depth.detach(), m.grad, o.grad, info
+
+    c0, d0, gm0, go0, i0 = run(None)
+    R = i0["num_rendered"]
+    assert R > 1500 and int(i0["misc"][0]) == R and int(i0["misc"][2]) == 0
+    c1, d1, gm1, go1, i1 = run(R + 1000)
+    assert i1["num_rendered"] == R + 1000 and int(i1["misc"][0]) == R and int(i1["misc"][2]) == 0
+    assert torch.equal(c0, c1) and torch.equal(d0, d1)
+    assert float((gm0 - gm1).abs().max()) <= 1e-5 * max(1.0, float(gm0.abs().max())) and float((go0 - go1).abs().max()) <= 1e-5 * max(1.0, float(go0.abs().max()))
+    c2, d2, gm2, go2, i2 = run(R // 2)
+    assert int(i2["misc"][2]) == 1 and int(i2["misc"][0]) == R
+    assert torch.allclose(c2, bg[:, :, None, None].expand(2, 3, H, W)) and float(d2.abs().max()) == 0
+    assert float(gm2.abs().max()) == 0 and float(go2.abs().max()) == 0

@@ -33,7 +33,7 @@ class VsRasterIn(C.Structure):
         ("sh_coeffs", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("flags", C.c_int32),
         ("means3D", C.c_void_p), ("cov3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("cam_scene", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
-        ("campos", C.c_void_p), ("tanfov", C.c_void_p), ("background", C.c_void_p),
+        ("campos", C.c_void_p), ("tanfov", C.c_void_p), ("background", C.c_void_p), ("capacity", C.c_int64),
     ]
 
 

@@ -82,21 +82,41 @@ def align_poses(decoder, gaussians, target_image: Tensor, extrinsics: Tensor, in
                           gaussians.opacities.detach())
     rot = torch.nn.Parameter(torch.zeros(b, v, 3, device=dev))
     trans = torch.nn.Parameter(torch.zeros(b, v, 3, device=dev))
-    opt = torch.optim.Adam([{"params": [rot], "lr": rot_lr}, {"params": [trans], "lr": trans_lr}])
-    extrinsics = extrinsics.clone()
-    history = []
-    with torch.enable_grad():
-        for _ in range(steps):
-            opt.zero_grad()
-            out = decoder.forward(gaussians, extrinsics, intrinsics, near, far, (h, w), cam_rot_delta=rot, cam_trans_delta=trans)
-            loss = mse_loss(out.color, target_image, mse_weight)
-            loss.backward()
-            history.append(loss.detach())
-            with torch.no_grad():
-                opt.step()
-                extrinsics = update_pose(trans.flatten(0, 1), rot.flatten(0, 1), extrinsics.flatten(0, 1)).unflatten(0, (b, v))
-                rot.zero_()
-                trans.zero_()
+    from . import raster
+    ext0 = extrinsics.clone()
+
+    def run(sync_free: bool):
+        extr = ext0.clone()
+        history, overflow, cap = [], None, None
+        with torch.no_grad():
+            rot.zero_(); trans.zero_()
+        opt_ = torch.optim.Adam([{"params": [rot], "lr": rot_lr}, {"params": [trans], "lr": trans_lr}])
+        with torch.enable_grad():
+            for it in range(steps):
+                opt_.zero_grad()
+                # the first render runs in the exact mode and tells how many (Gaussian, tile) instances these cameras produce; the other
+                # 99 run without the per-call host synchronisation, in buffers 1.5x that size (the poses move by millimetres per step)
+                with raster.instance_capacity(cap if (sync_free and it > 0) else None):
+                    out = decoder.forward(gaussians, extr, intrinsics, near, far, (h, w), cam_rot_delta=rot, cam_trans_delta=trans)
+                info = raster.last_call()
+                if sync_free and info is not None:
+                    if it == 0:
+                        cap = int(info["num_rendered"] * 1.5) + 65536
+                    else:
+                        overflow = info["misc"][2] if overflow is None else torch.maximum(overflow, info["misc"][2])
+                loss = mse_loss(out.color, target_image, mse_weight)
+                loss.backward()
+                history.append(loss.detach())
+                with torch.no_grad():
+                    opt_.step()
+                    extr = update_pose(trans.flatten(0, 1), rot.flatten(0, 1), extr.flatten(0, 1)).unflatten(0, (b, v))
+                    rot.zero_()
+                    trans.zero_()
+        return extr, history, (overflow is not None and bool(overflow.item() != 0))
+
+    extrinsics, history, overflowed = run(True)
+    if overflowed:      # some step outgrew the buffers (its render was empty): repeat with exact sizing
+        extrinsics, history, _ = run(False)
     return (extrinsics, torch.stack(history)) if return_history else extrinsics
 
 

@@ -276,7 +276,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
 // Single workgroup (n is a few thousand).  misc[0] = R (int64), misc[1] = max tile population.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int32_t *__restrict__ count, int2 *__restrict__ ranges, int n,
-                                                          long long *__restrict__ misc) {
+                                                          long long *__restrict__ misc, long long capacity) {
     __shared__ long long wave_tot[16];
     __shared__ long long carry_s;
     __shared__ int max_s[16];
@@ -317,7 +317,12 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int32_t *__restrict__ c
         for (int w = 0; w < 16; ++w) m = max(m, max_s[w]);
         misc[0] = carry_s;
         misc[1] = m;
+        misc[2] = (capacity > 0 && carry_s > capacity) ? 1 : 0;
     }
+    // capacity mode (no host round trip sized the buffers): more instances than the buffers hold -> every tile list becomes empty,
+    // the scatter / sort / render kernels then touch nothing and the caller finds misc[2] set
+    if (capacity > 0 && carry_s > capacity)
+        for (int idx = tid; idx < n; idx += 1024) ranges[idx] = make_int2(0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -331,9 +336,11 @@ constexpr int kScatterPer = 4;   // Gaussians per thread: the three block-wide s
 
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int tiles, int gx, const float *__restrict__ depth, const ushort4 *__restrict__ rect,
-               const int2 *__restrict__ ranges, int32_t *__restrict__ cursor, unsigned long long *__restrict__ keys) {
+               const int2 *__restrict__ ranges, int32_t *__restrict__ cursor, unsigned long long *__restrict__ keys,
+               const long long *__restrict__ misc) {
     __shared__ int hist[kHistTiles];
     __shared__ int base[kHistTiles];
+    if (misc[2] != 0) return;   // capacity mode, more instances than `keys` holds: the scan emptied every tile list, nothing to place
     const int c = blockIdx.y;
     const bool use_lds = tiles <= kHistTiles;
     const size_t t0 = (size_t)c * tiles;
@@ -922,13 +929,22 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
         dim3 grid(vs::cdiv(P, 256), in->num_scenes);
         hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, stream, *in, geom, rect, clamped, out->radii, depthkey, cursor);
     }
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, cursor, ranges, C * tiles, misc);
-    long long host_misc[2] = {0, 0};
-    VS_HIP(hipMemcpyAsync(host_misc, misc, sizeof(host_misc), hipMemcpyDeviceToHost, stream));
-    VS_HIP(hipStreamSynchronize(stream));
-    const long long R = host_misc[0];
-    const long long max_tile = host_misc[1];
-    VS_CHECK(R >= 0 && R < 2147483647LL, "vs_raster_forward: %lld (Gaussian,tile) instances overflow int32 ranges", R);
+    VS_CHECK(in->capacity >= 0 && in->capacity < 2147483647LL, "vs_raster_forward: capacity %lld out of range", (long long)in->capacity);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, cursor, ranges, C * tiles, misc, (long long)in->capacity);
+    long long R, max_tile;
+    if (in->capacity > 0) {
+        // capacity mode: nothing comes back to the host; every buffer is sized for `capacity` instances and the large-tile sort
+        // scratch is always provided (the largest tile is not known here)
+        R = in->capacity;
+        max_tile = R;
+    } else {
+        long long host_misc[2] = {0, 0};
+        VS_HIP(hipMemcpyAsync(host_misc, misc, sizeof(host_misc), hipMemcpyDeviceToHost, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        R = host_misc[0];
+        max_tile = host_misc[1];
+        VS_CHECK(R >= 0 && R < 2147483647LL, "vs_raster_forward: %lld (Gaussian,tile) instances overflow int32 ranges", R);
+    }
     out->num_rendered = R;
 
     unsigned long long *keys = (unsigned long long *)get(VS_BUF_KEYS, (size_t)R * 8);
@@ -943,9 +959,11 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
         segs = scratch ? reinterpret_cast<int2 *>(scratch + R) : nullptr;
     }
     VS_CHECK(keys && point_list && (max_tile <= kSortLds || scratch), "vs_raster_forward: allocator returned null");
+    // capacity mode: the table is sized for `capacity` instances but tile_sort_kernel only clears the slots of the instances that exist
+    if (segs && in->capacity > 0) VS_HIP(hipMemsetAsync(segs, 0, (size_t)nslots * sizeof(int2), stream));
     if (R > 0) {
         dim3 grid(vs::cdiv(P, 256 * kScatterPer), C);
-        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, depthkey, rect, ranges, cursor, keys);
+        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, depthkey, rect, ranges, cursor, keys, misc);
         hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch, segs);
         if (segs)
             hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)vs::cdiv64(nslots, 4)), dim3(256), 0, stream, segs, (int)nslots,

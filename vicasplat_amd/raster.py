@@ -6,7 +6,9 @@ Python, cuda_splatting.py:199-238).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -20,6 +22,29 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+_hint = threading.local()
+
+
+@contextlib.contextmanager
+def instance_capacity(n: Optional[int]):
+    """Inside this context every rasterizer call runs in the CAPACITY mode of vs_raster_forward (include/vicasplat_hip.h): buffers sized
+    for `n` (Gaussian, tile) instances, NO host synchronisation per call (the exact mode copies the instance count back, as upstream's
+    extension does per view).  A call that needs more than `n` renders nothing and raises the device-side flag that `overflow_flag()`
+    returns; the caller checks it whenever it next synchronises and repeats with a larger capacity (callers.align_poses does)."""
+    prev = getattr(_hint, "n", None)
+    _hint.n = None if n is None else int(n)
+    try:
+        yield
+    finally:
+        _hint.n = prev
+
+
+def last_call() -> Optional[dict]:
+    """{'num_rendered': host int (== capacity in the capacity mode), 'misc': device int64[4] = [R, largest tile, overflow flag, 0]} of
+    this thread's most recent rasterizer call."""
+    return getattr(_hint, "last", None)
 
 
 def _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
@@ -42,6 +67,7 @@ def _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, pr
     inp.opacities, inp.cam_scene = L.ptr(opacities), L.ptr(cam_scene)
     inp.viewmatrix, inp.projmatrix, inp.campos = L.ptr(viewmatrix), L.ptr(projmatrix), L.ptr(campos)
     inp.tanfov, inp.background = L.ptr(tanfov), L.ptr(background)
+    inp.capacity = getattr(_hint, "n", None) or 0
 
     color = torch.empty((Cn, 3, H, W), dtype=torch.float32, device=dev)
     depth = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
@@ -57,6 +83,7 @@ def _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, pr
     L.check(R, "vs_raster_forward")
     if n_touched is None:
         n_touched = torch.zeros((Cn, P), dtype=torch.int32, device=dev)
+    _hint.last = dict(num_rendered=int(R), misc=alloc.tensors[L.VS_BUF_MISC].view(torch.int64)[:4])
     state = dict(inp=inp, out=out, alloc=alloc, dims=(S, P, Cn, M, H, W, cov33), num_rendered=int(R),
                  keep=(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
                        cam_scene, color, depth, opacity, radii))
