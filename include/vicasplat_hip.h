@@ -237,8 +237,8 @@ int vs_upsample2x_backward_nhwc(const void *dout, void *din, int32_t Nimg, int32
 /* 7x7, stride 1, pad 3 convolution of an RGB image (gs head input_merger, heads/dpt_gs_head.py:112-118; replaces the
  * nn.Conv2d(3, C, 7, 1, 3) call) as a window GEMM on MFMA without an im2col buffer.
  *   in_padded [Nimg, Hp, Wp, 3] 16-bit NHWC, zero border: 3 rows/cols before the image, >= 3 after (Hp >= H+6, Wp >= W+6),
- *             plus >= 16 readable halfs after the last element;
- *   w         [Cout, 7, 32]: w[co, dy, dx*3 + c] = weight[co, c, dy, dx], entries 21..31 of every row zero;
+ *             plus >= Wp*3 + 64 readable halfs after the last element (the 256-tile route's zero-weight eighth kernel row);
+ *   w         [Cout, 8, 32]: w[co, dy, dx*3 + c] = weight[co, c, dy, dx], entries 21..31 of every row and the whole row dy = 7 zero;
  *   out       [Nimg, H, W, Cout] 16-bit (+ bias[Cout] f32 or NULL). */
 int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const float *bias, void *out, int32_t Nimg, int32_t H, int32_t W,
                         int32_t Hp, int32_t Wp, int32_t Cout, int32_t dtype, vs_stream_t stream);

@@ -280,6 +280,62 @@ int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
     return 0;
 }
 
+// 7x7 RGB stem as a window GEMM on the 256x256 kernel's main loop: a K-tile (64) is TWO kernel rows of 32 halfs (21 used), i.e. the
+// two 64-byte halves of a staged A row come from two consecutive padded image rows; K = 8 rows x 32 (the eighth row of the packed
+// weights is zero -- its image data is finite and costs nothing).  Same staging units, swizzle and epilogue as gemm256_kernel.
+struct WindowStager256 {
+    const unsigned short *pa[2][2], *pw[2][2];
+    long long kstep;   // A elements per K-tile = 2 padded image rows
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
+        if (u < 2) {
+            glds16(pa[u][0] + kt * kstep, lds);
+            glds16(pa[u][1] + kt * kstep, lds + 1024u);
+        } else {
+            glds16(pw[u - 2][0] + kt * 64, lds);
+            glds16(pw[u - 2][1] + kt * 64, lds + 1024u);
+        }
+    }
+};
+
+template <int BF16>
+__global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int nwg = ((g.M + BM2 - 1) / BM2) * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
+    WindowStager256 st;
+    st.kstep = 2ll * g.a_kstride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = unit_row256(wid, j, lane);
+        const int c = unit_src_chunk256(q, lane);   // 16-byte chunk of the 128-byte staged row: 0..3 kernel row 2kt, 4..7 kernel row 2kt + 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ra_ = min(m0 + unit_a_tile_row256(q, h), g.M - 1);
+            const int rg_ = ra_ / g.a_grp_in;
+            const size_t arow = (size_t)rg_ * g.a_grp_out + (ra_ % g.a_grp_in) + (size_t)(rg_ / g.a_sup_in) * g.a_sup_extra;
+            st.pa[h][j] = A + arow * g.lda + (size_t)(c >> 2) * g.a_kstride + (c & 3) * 8;
+            const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.N - 1);
+            st.pw[h][j] = W + (size_t)rw_ * g.ldw + c * 8;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256<BF16, false>(st, 4, acc, smem, lane, wid);
+    gemm_epilogue<BF16, 0, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
 template <int BF16>
 int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M - g.m_lo, 256) * vs::cdiv(g.N, 256);
@@ -678,7 +734,9 @@ extern "C" int vs_gemm_taps_accumulate(const void *A, const void *W, float *out,
 // GEMM on gemm_kernel: with a zero-padded NHWC image [Nimg, Hp, Wp, 3] the 7 horizontal taps x 3 channels of one kernel
 // row are 21 CONTIGUOUS halfs starting at padded pixel (y+dy, x), so k-step dy of output pixel (y, x) is the 32-half slice
 // at that address (LDS-DMA takes any 2-byte-aligned source; the 11 trailing halfs are finite image data multiplied by zero
-// weights).  M = Nimg*H*W pixels, N = Cout, K = 7 x 32; no im2col buffer, bias fused.
+// weights).  M = Nimg*H*W pixels, N = Cout, K = 7 x 32 (the packed weights carry an eighth, all-zero kernel row: Cout >= 256 runs on
+// the 256x256 main loop with K = 8 x 32, whose last row reads padded image row y + 7: the image buffer must extend one padded row
+// + 64 halfs behind its last pixel); no im2col buffer, bias fused.
 extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const float *bias, void *out, int32_t Nimg, int32_t H,
                                    int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, int32_t dtype, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -692,7 +750,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     GemmArgs g;
     g.A = in_padded; g.W = w; g.bias = bias; g.out = out; g.gate = nullptr; g.resid = nullptr;
     g.M = Nimg * H * W; g.N = Cout; g.K = 7 * 32;
-    g.lda = 3; g.ldw = 7 * 32; g.ldo = Cout;
+    g.lda = 3; g.ldw = 8 * 32; g.ldo = Cout;
     g.grp_in = g.M; g.grp_out = g.M; g.grp_off = 0;
     g.gate_rows = g.M; g.gate_ld = Cout;
     g.m_lo = 0;
@@ -701,6 +759,14 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
+    static const int no256 = [] { const char *e = getenv("VS_STEM_NO256"); return e ? atoi(e) : 0; }();
+    if (Cout % 256 == 0 && g.M >= 256 && !no256) {
+        const int nwg = vs::cdiv(g.M, 256) * (Cout / 256);
+        if (dtype == 2) hipLaunchKernelGGL(conv7x7_256_kernel<1>, dim3(nwg), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL(conv7x7_256_kernel<0>, dim3(nwg), dim3(512), 0, stream, g);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());

@@ -304,21 +304,23 @@ def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: int = 0) -
 
 
 def pack_conv7x7_rgb_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """nn.Conv2d(3, Cout, 7) weight [Cout,3,7,7] -> [Cout, 7, 32] with w[co, dy, dx*3 + c] and zeros in 21..31."""
+    """nn.Conv2d(3, Cout, 7) weight [Cout,3,7,7] -> [Cout, 8, 32] with w[co, dy, dx*3 + c], zeros in columns 21..31 and in the eighth row
+    (K = 256 for the 256x256 tile kernel; the 7-row route reads the same buffer with a row stride of 256)."""
     Cout = w.shape[0]
     assert w.shape == (Cout, 3, 7, 7)
-    wp = torch.zeros(Cout, 7, 32, dtype=dtype, device=w.device)
-    wp[:, :, :21] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 7, 21).to(dtype)
+    wp = torch.zeros(Cout, 8, 32, dtype=dtype, device=w.device)
+    wp[:, :7, :21] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 7, 21).to(dtype)
     return wp.contiguous()
 
 
 def pad_rgb_nhwc(frames: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """frames [N,3,H,W] -> zero-bordered NHWC 16-bit image [N, H+6, W+8, 3] (3 before, 3/5 after) for conv7x7_rgb_nhwc;
-    the storage carries 64 spare halfs behind the last pixel (the last window slices read past it)."""
+    the storage carries one padded row + 64 spare halfs behind the last pixel (the last window slices -- and the zero-weight eighth
+    kernel row of the 256-tile route -- read past it)."""
     N, C, H, W = frames.shape
     assert C == 3
     Hp, Wp = H + 6, W + 8
-    flat = torch.zeros(N * Hp * Wp * 3 + 64, dtype=dtype, device=frames.device)
+    flat = torch.zeros(N * Hp * Wp * 3 + Wp * 3 + 64, dtype=dtype, device=frames.device)
     img = flat[:N * Hp * Wp * 3].view(N, Hp, Wp, 3)
     img[:, 3:3 + H, 3:3 + W] = frames.permute(0, 2, 3, 1)
     return img
@@ -329,8 +331,8 @@ def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[t
     dev = L.require_device(img_padded, w, bias)
     N, Hp, Wp, C = img_padded.shape
     Cout = w.shape[0]
-    assert C == 3 and img_padded.is_contiguous() and w.shape == (Cout, 7, 32) and w.is_contiguous() and img_padded.dtype == w.dtype
-    assert img_padded.untyped_storage().nbytes() >= (img_padded.storage_offset() + img_padded.numel() + 16) * 2
+    assert C == 3 and img_padded.is_contiguous() and w.shape == (Cout, 8, 32) and w.is_contiguous() and img_padded.dtype == w.dtype
+    assert img_padded.untyped_storage().nbytes() >= (img_padded.storage_offset() + img_padded.numel() + Wp * 3 + 64) * 2
     out = torch.empty((N, H, W, Cout), dtype=w.dtype, device=dev)
     with torch.cuda.device(dev):
         rc = L.lib().vs_conv7x7_rgb_nhwc(L.ptr(img_padded), L.ptr(w), L.ptr(bias), L.ptr(out), N, H, W, Hp, Wp, Cout,
