@@ -275,6 +275,8 @@ int vs_attention_backward(const void *q, const void *k, const void *v, const voi
  * ------------------------------------------------------------------------------------------------ */
 /* dx = x > 0 ? dx : 0, in place, n 16-bit elements (f16 or bf16: same sign/zero encoding); backward of a ReLU on x. */
 int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream);
+/* out = x > 0 ? dy : 0 (out may be dy): the same without a copy when the incoming gradient must stay intact. */
+int vs_relu_mask16_to(const void *dy, const void *x, void *out, int64_t n, vs_stream_t stream);
 /* out32[M,N] += A[M,K] W[N,K]^T, K cut into ksplit slices (separate workgroups, f32 atomics): long thin reductions such as
  * weight gradients.  K % (32 * ksplit) == 0; A, W may start at any 2-byte aligned address (shifted views).  Runs on 256x256 tiles
  * (the phase-interleaved main loop of the forward GEMMs) when M % 256 == 0, N % 256 == 0 and K % (128 * ksplit) == 0, on 128x128

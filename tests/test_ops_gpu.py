@@ -934,3 +934,20 @@ def test_linear_f32_and_silu_cast():
     for dt, tol in ((torch.float32, 1e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
         y = ops.silu_cast(x, dt)
         assert y.dtype == dt and (y.float() - F.silu(x)).abs().max() <= tol * F.silu(x).abs().max()
+
+
+def test_upsample2x_add_relu_function_matches_autograd():
+    from vicasplat_amd import autograd as A
+    d = torch.device("cuda:0")
+    torch.manual_seed(3)
+    x = torch.randn(2, 12, 10, 16, device=d).half().requires_grad_(True)
+    s = torch.randn(2, 24, 20, 16, device=d).half().requires_grad_(True)
+    y = A.upsample2x_add_relu(x, s)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr, sr = x.detach().float().requires_grad_(True), s.detach().float().requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1) + torch.relu(sr)
+    yr.backward(g.float())
+    assert float((y.float() - yr).abs().max()) <= 4e-3
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 2e-2 * max(1.0, float(xr.grad.abs().max()))
+    assert torch.equal(s.grad.float(), sr.grad.half().float())

@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
             L.vs_upsample2x_backward_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
             L.vs_relu_mask16.restype = C.c_int
             L.vs_relu_mask16.argtypes = [vp, vp, i64, vp]
+            L.vs_relu_mask16_to.restype = C.c_int
+            L.vs_relu_mask16_to.argtypes = [vp, vp, vp, i64, vp]
             L.vs_gemm_splitk_accumulate.restype = C.c_int
             L.vs_gemm_splitk_accumulate.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_gemm_taps_accumulate.restype = C.c_int

@@ -189,7 +189,7 @@ class Conv3x3Fn(torch.autograd.Function):
         relu_in, has_b, stride, has_res = ctx.meta
         dy = dy.contiguous()
         if y is not None:                                  # trailing ReLU: gradient only where the output is positive
-            dy = ops.relu_mask_(dy.clone(), y)
+            dy = ops.relu_mask(dy, y)
         dres = dy if has_res else None
         if stride != 1:
             full = torch.zeros(x.shape[:3] + (dy.shape[3],), dtype=dy.dtype, device=dy.device)
@@ -218,6 +218,30 @@ class Upsample2xFn(torch.autograd.Function):
 
 def upsample2x(x_nhwc: torch.Tensor) -> torch.Tensor:
     return Upsample2xFn.apply(x_nhwc)
+
+
+class Upsample2xAddReluFn(torch.autograd.Function):
+    """up2(x) + relu(s) in ONE kernel (the gs head's merge of the trunk with the 7x7 image features, dpt_gs_head.py:112-124; the inference
+    path's fused launch): replaces a bilinear kernel, a ReLU and an add over the 256 x 256 x C tensor and their three backward passes.
+    Backward: dx = up2^T(dy), ds = dy where s > 0."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        s = s.contiguous()
+        ctx.save_for_backward(s)
+        return ops.upsample2x_nhwc(x.contiguous(), add=s, relu_add=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.upsample2x_backward_nhwc(dy) if ctx.needs_input_grad[0] else None
+        ds = ops.relu_mask(dy, s) if ctx.needs_input_grad[1] else None
+        return dx, ds
+
+
+def upsample2x_add_relu(x_nhwc: torch.Tensor, s_nhwc: torch.Tensor) -> torch.Tensor:
+    return Upsample2xAddReluFn.apply(x_nhwc, s_nhwc)
 
 
 class GeluFn(torch.autograd.Function):

@@ -224,12 +224,12 @@ gelu16_kernel(const unsigned short *__restrict__ z, unsigned short *__restrict__
     *reinterpret_cast<uint4 *>(out + i) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
-// dx = x > 0 ? dx : 0 on packed 16-bit pairs (backward of a ReLU whose INPUT x was saved), in place
+// out = x > 0 ? dy : 0 on packed 16-bit pairs (backward of a ReLU whose INPUT x was saved); out may be dy (in place)
 __global__ void __launch_bounds__(256)
-relu_mask16_kernel(unsigned short *__restrict__ dx, const unsigned short *__restrict__ x, long long n) {
+relu_mask16_kernel(const unsigned short *dy, const unsigned short *__restrict__ x, unsigned short *dx, long long n) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= n) return;
-    uint4 d = *reinterpret_cast<uint4 *>(dx + i);
+    uint4 d = *reinterpret_cast<const uint4 *>(dy + i);
     const uint4 v = *reinterpret_cast<const uint4 *>(x + i);
     auto m = [](unsigned dd, unsigned xx) {  // keep a half iff x is positive: sign bit clear and not (+/-)zero
         const unsigned lo = ((xx & 0x8000u) == 0 && (xx & 0x7fffu) != 0) ? 0xffffu : 0u;
@@ -663,14 +663,16 @@ extern "C" int vs_gated_resid_backward(const float *dout, const void *y, int64_t
     return 0;
 }
 
-extern "C" int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream_) {
+extern "C" int vs_relu_mask16_to(const void *dy, const void *x, void *out, int64_t n, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK(dx && x, "vs_relu_mask16: null pointer");
+    VS_CHECK(dy && x && out, "vs_relu_mask16: null pointer");
     VS_CHECK(n >= 0 && n % 8 == 0, "vs_relu_mask16: n must be a multiple of 8");
-    VS_CHECK((((uintptr_t)dx | (uintptr_t)x) & 15) == 0, "vs_relu_mask16: 16-byte alignment required");
+    VS_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)out) & 15) == 0, "vs_relu_mask16: 16-byte alignment required");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(relu_mask16_kernel, dim3((unsigned)vs::cdiv64(n / 8, 256)), dim3(256), 0, stream, (unsigned short *)dx,
-                       (const unsigned short *)x, (long long)n);
+    hipLaunchKernelGGL(relu_mask16_kernel, dim3((unsigned)vs::cdiv64(n / 8, 256)), dim3(256), 0, stream, (const unsigned short *)dy,
+                       (const unsigned short *)x, (unsigned short *)out, (long long)n);
     VS_HIP(hipGetLastError());
     return 0;
 }
+
+extern "C" int vs_relu_mask16(void *dx, const void *x, int64_t n, vs_stream_t stream_) { return vs_relu_mask16_to(dx, x, dx, n, stream_); }

@@ -179,7 +179,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     pts16 = conv1x1(pre + ".head.4", t)                                                              # [BT,H,W,4] 16-bit: xyz | confidence
 
     pre = "gaussian_param_head.dpt"
-    t = up2(trunk(pre)) + F.relu(stem7x7(pre + ".input_merger.0", frames))
+    t = A.upsample2x_add_relu(trunk(pre), stem7x7(pre + ".input_merger.0", frames))             # up2(trunk) + relu(stem), one launch
     t = A.conv3x3(t, P[pre + ".head.0.weight"], None, relu_out=True)
     gs16 = conv1x1(pre + ".head.4", t)                                                               # [BT,H,W,8+3*d_sh] 16-bit
 

@@ -571,6 +571,17 @@ def relu_mask_(dx: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+def relu_mask(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """x > 0 ? dy : 0 into a new tensor (contiguous 16-bit, same shape): ReLU backward that leaves the incoming gradient intact."""
+    dev = L.require_device(dy, x)
+    assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous() and x.is_contiguous()
+    out = torch.empty_like(dy)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_relu_mask16_to(L.ptr(dy), L.ptr(x), L.ptr(out), dy.numel(), L.stream_ptr(dev))
+    L.check(rc, "vs_relu_mask16_to")
+    return out
+
+
 def gemm_wgrad(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int, *, shifts=None, K: Optional[int] = None,
                workspace: bool = True, accumulate: bool = True) -> torch.Tensor:
     """out32[t][M,N] += a[M,K] @ (w shifted by shifts[t])[N,K]^T, K split over `ksplit` workgroups per tile (vs_gemm_wgrad).
