@@ -234,9 +234,12 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
     const int ncoef = deg >= 3 ? 16 : (deg + 1) * (deg + 1);
 
     float px = 0.f, py = 0.f, pz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
-    float sh[16][3];
+    // the Gaussian's SH coefficients (bands 1..3, read 45 times per camera by the view-direction gradient) live in LDS, one column per
+    // thread: 48 registers less than a register copy -- with it and the 48 SH gradients the kernel needed 308 registers (one wave per SIMD)
+    __shared__ float s_sh[45][256];
+#define SHV(k_, ch_) s_sh[((k_) - 1) * 3 + (ch_)][threadIdx.x]
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sh[k][0] = sh[k][1] = sh[k][2] = 0.f;
+    for (int k = 0; k < 45; ++k) s_sh[k][threadIdx.x] = 0.f;
     if (live) {
         px = in.means3D[3 * gi]; py = in.means3D[3 * gi + 1]; pz = in.means3D[3 * gi + 2];
         if (in.flags & VS_RASTER_COV_3X3) {
@@ -249,10 +252,10 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
         if (has_sh) {
             const float *shp = in.shs + gi * (size_t)M * 3;
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
+            for (int k = 1; k < 16; ++k)
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch)
-                    if (k < ncoef) sh[k][ch] = rgb_major ? shp[ch * M + k] : shp[3 * k + ch];
+                    if (k < ncoef) SHV(k, ch) = rgb_major ? shp[ch * M + k] : shp[3 * k + ch];
         }
     }
     const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
@@ -399,16 +402,16 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
                         g_sh[1][ch] += -SH_C1 * y * g[ch];
                         g_sh[2][ch] += SH_C1 * z * g[ch];
                         g_sh[3][ch] += -SH_C1 * x * g[ch];
-                        dRx = -SH_C1 * sh[3][ch]; dRy = -SH_C1 * sh[1][ch]; dRz = SH_C1 * sh[2][ch];
+                        dRx = -SH_C1 * SHV(3, ch); dRy = -SH_C1 * SHV(1, ch); dRz = SH_C1 * SHV(2, ch);
                         if (deg > 1) {
                             g_sh[4][ch] += SH_C2[0] * xy * g[ch];
                             g_sh[5][ch] += SH_C2[1] * yz * g[ch];
                             g_sh[6][ch] += SH_C2[2] * (2.0f * zz - xx - yy) * g[ch];
                             g_sh[7][ch] += SH_C2[3] * xz * g[ch];
                             g_sh[8][ch] += SH_C2[4] * (xx - yy) * g[ch];
-                            dRx += SH_C2[0] * y * sh[4][ch] + SH_C2[2] * 2.0f * -x * sh[6][ch] + SH_C2[3] * z * sh[7][ch] + SH_C2[4] * 2.0f * x * sh[8][ch];
-                            dRy += SH_C2[0] * x * sh[4][ch] + SH_C2[1] * z * sh[5][ch] + SH_C2[2] * 2.0f * -y * sh[6][ch] + SH_C2[4] * 2.0f * -y * sh[8][ch];
-                            dRz += SH_C2[1] * y * sh[5][ch] + SH_C2[2] * 4.0f * z * sh[6][ch] + SH_C2[3] * x * sh[7][ch];
+                            dRx += SH_C2[0] * y * SHV(4, ch) + SH_C2[2] * 2.0f * -x * SHV(6, ch) + SH_C2[3] * z * SHV(7, ch) + SH_C2[4] * 2.0f * x * SHV(8, ch);
+                            dRy += SH_C2[0] * x * SHV(4, ch) + SH_C2[1] * z * SHV(5, ch) + SH_C2[2] * 2.0f * -y * SHV(6, ch) + SH_C2[4] * 2.0f * -y * SHV(8, ch);
+                            dRz += SH_C2[1] * y * SHV(5, ch) + SH_C2[2] * 4.0f * z * SHV(6, ch) + SH_C2[3] * x * SHV(7, ch);
                             if (deg > 2) {
                                 g_sh[9][ch] += SH_C3[0] * y * (3.0f * xx - yy) * g[ch];
                                 g_sh[10][ch] += SH_C3[1] * xy * z * g[ch];
@@ -417,15 +420,15 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
                                 g_sh[13][ch] += SH_C3[4] * x * (4.0f * zz - xx - yy) * g[ch];
                                 g_sh[14][ch] += SH_C3[5] * z * (xx - yy) * g[ch];
                                 g_sh[15][ch] += SH_C3[6] * x * (xx - 3.0f * yy) * g[ch];
-                                dRx += SH_C3[0] * sh[9][ch] * 6.0f * xy + SH_C3[1] * sh[10][ch] * yz + SH_C3[2] * sh[11][ch] * -2.0f * xy +
-                                       SH_C3[3] * sh[12][ch] * -6.0f * xz + SH_C3[4] * sh[13][ch] * (-3.0f * xx + 4.0f * zz - yy) +
-                                       SH_C3[5] * sh[14][ch] * 2.0f * xz + SH_C3[6] * sh[15][ch] * 3.0f * (xx - yy);
-                                dRy += SH_C3[0] * sh[9][ch] * 3.0f * (xx - yy) + SH_C3[1] * sh[10][ch] * xz +
-                                       SH_C3[2] * sh[11][ch] * (-3.0f * yy + 4.0f * zz - xx) + SH_C3[3] * sh[12][ch] * -6.0f * yz +
-                                       SH_C3[4] * sh[13][ch] * -2.0f * xy + SH_C3[5] * sh[14][ch] * -2.0f * yz + SH_C3[6] * sh[15][ch] * -6.0f * xy;
-                                dRz += SH_C3[1] * sh[10][ch] * xy + SH_C3[2] * sh[11][ch] * 8.0f * yz +
-                                       SH_C3[3] * sh[12][ch] * 3.0f * (2.0f * zz - xx - yy) + SH_C3[4] * sh[13][ch] * 8.0f * xz +
-                                       SH_C3[5] * sh[14][ch] * (xx - yy);
+                                dRx += SH_C3[0] * SHV(9, ch) * 6.0f * xy + SH_C3[1] * SHV(10, ch) * yz + SH_C3[2] * SHV(11, ch) * -2.0f * xy +
+                                       SH_C3[3] * SHV(12, ch) * -6.0f * xz + SH_C3[4] * SHV(13, ch) * (-3.0f * xx + 4.0f * zz - yy) +
+                                       SH_C3[5] * SHV(14, ch) * 2.0f * xz + SH_C3[6] * SHV(15, ch) * 3.0f * (xx - yy);
+                                dRy += SH_C3[0] * SHV(9, ch) * 3.0f * (xx - yy) + SH_C3[1] * SHV(10, ch) * xz +
+                                       SH_C3[2] * SHV(11, ch) * (-3.0f * yy + 4.0f * zz - xx) + SH_C3[3] * SHV(12, ch) * -6.0f * yz +
+                                       SH_C3[4] * SHV(13, ch) * -2.0f * xy + SH_C3[5] * SHV(14, ch) * -2.0f * yz + SH_C3[6] * SHV(15, ch) * -6.0f * xy;
+                                dRz += SH_C3[1] * SHV(10, ch) * xy + SH_C3[2] * SHV(11, ch) * 8.0f * yz +
+                                       SH_C3[3] * SHV(12, ch) * 3.0f * (2.0f * zz - xx - yy) + SH_C3[4] * SHV(13, ch) * 8.0f * xz +
+                                       SH_C3[5] * SHV(14, ch) * (xx - yy);
                             }
                         }
                     }
