@@ -109,7 +109,8 @@ def _reducer_worker(rank, world, port, q, comm_bf16):
             loss.backward()
             ncoll = red.finish()
             assert ncoll == len(red.buckets)
-        q.put((rank, {n: p.grad.clone() for n, p in m.named_parameters()}))
+        # numpy arrays travel by value; tensors would travel as shared-memory handles that die with this process (the parent may read late)
+        q.put((rank, {n: p.grad.detach().numpy().copy() for n, p in m.named_parameters()}))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
     finally:
@@ -127,6 +128,7 @@ def _run_reducer(comm_bf16):
     for p in procs:
         p.join(timeout=60)
     assert all(isinstance(v, dict) for v in out.values()), out
+    out = {r: {n: torch.from_numpy(a) for n, a in v.items()} for r, v in out.items()}
     m = _toy_model()
     x, y = _toy_batch()
     ((m(x) - y) ** 2).mean().backward()
