@@ -223,12 +223,14 @@ def test_training_step_reduces_the_photometric_loss(dt):
     opt, _ = callers.configure_optimizer(m, lr=4e-5, backbone_lr_multiplier=0.25)      # the reference's learning rates
     before = {n: p.detach().clone() for n, p in list(m.named_parameters())[:40]}
     hist = []
-    for it in range(8):
+    # (Adam's first updates are sign steps of size lr on every weight: the loss jumps up by ~20 % after step 1 and then comes down along
+    # a trajectory that differs run to run -- f32 atomics in the rasterizer backward -- so the check looks at the best of the last steps)
+    for it in range(16):
         r = callers.training_step(m, dec, batch, opt, compute_dtype=dt)
         assert not r["skipped"] and torch.isfinite(r["loss"]) and torch.isfinite(r["grad_norm"]), r
         hist.append(float(r["loss"]))
     print("loss", ["%.5f" % v for v in hist], "grad_norm", float(r["grad_norm"]), "psnr", float(r["psnr"]))
-    assert hist[-1] < hist[0] * 0.995 and float(r["grad_norm"]) > 0, hist
+    assert min(hist[-6:]) < hist[0] * 0.95 and float(r["grad_norm"]) > 0, hist
     changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in list(m.named_parameters())[:40])
     assert changed >= 30
 
