@@ -5,6 +5,7 @@
 #include <type_traits>
 
 namespace {
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -306,6 +307,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                 }
                 return;
             } else {
+                [[maybe_unused]] uint2 pkprev[4];
+                [[maybe_unused]] const bool wide16 = OUT16 && MI % 2 == 0 && g.ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     float v[4][4];
@@ -365,13 +368,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                     }
                     if constexpr (OUT16) {
                         constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;
-                        unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow[i] * g.ldo + nbase + c4;
+                        uint2 pk[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            uint2 pk;
-                            pk.x = (unsigned)to16<D16>(v[j][0]) | ((unsigned)to16<D16>(v[j][1]) << 16);
-                            pk.y = (unsigned)to16<D16>(v[j][2]) | ((unsigned)to16<D16>(v[j][3]) << 16);
-                            *reinterpret_cast<uint2 *>(dst + j * 16) = pk;
+                            pk[j].x = (unsigned)to16<D16>(v[j][0]) | ((unsigned)to16<D16>(v[j][1]) << 16);
+                            pk[j].y = (unsigned)to16<D16>(v[j][2]) | ((unsigned)to16<D16>(v[j][3]) << 16);
+                        }
+                        if (wide16) {
+                            // 16-byte stores: the epilogue is store-ISSUE-bound (4.4 us of a 24 us K = 1024 tile with 8-byte stores, measured
+                            // with cycle stamps), and a lane's 4 columns are 8 bytes.  Row fragments are taken in pairs: v_permlane16_swap
+                            // exchanges the odd 16-lane rows of fragment i with the even rows of fragment i + 1, after which an even-row lane
+                            // holds 8 consecutive columns of fragment i and an odd-row lane 8 consecutive columns of fragment i + 1.
+                            if ((i & 1) == 0) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) pkprev[j] = pk[j];
+                            } else {
+                                const bool odd = (lane >> 4) & 1;
+                                unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + (odd ? orow[i] : orow[i - 1]) * g.ldo + nbase + (c4 & ~4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const u2v sx = __builtin_amdgcn_permlane16_swap(pkprev[j].x, pk[j].x, false, false);
+                                    const u2v sy = __builtin_amdgcn_permlane16_swap(pkprev[j].y, pk[j].y, false, false);
+                                    *reinterpret_cast<uint4 *>(dst + j * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
+                                }
+                            }
+                        } else {
+                            unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow[i] * g.ldo + nbase + c4;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2 *>(dst + j * 16) = pk[j];
                         }
                     } else {
                         float *dst = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo + nbase + c4;
