@@ -50,6 +50,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
         }
     const bool vec_ok = (g.Cout % 4 == 0) && (nbase + 64 <= g.Cout) && ((reinterpret_cast<uintptr_t>(g.out) & 7) == 0) &&
                         (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 7) == 0);
+    // interior wave tile, 16-bit output: 16-byte stores -- row fragments in pairs, v_permlane16_swap gives an even-row lane 8 consecutive
+    // columns of fragment i and an odd-row lane 8 consecutive columns of fragment i + 1 (as in gemm_epilogue: the tile's store tail is
+    // issue-bound, 8-byte stores cost twice the instructions)
+    if constexpr (BF16 != kDtF32 && MI % 2 == 0) {
+        if (vec_ok && g.Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0 && mw0 + 16 * MI <= M) {
+            constexpr int D16 = BF16;
+            typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+            const bool odd = (lane >> 4) & 1;
+            uint2 prev[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const size_t o = (size_t)(mw0 + i * 16 + mrow) * g.Cout + nbase + c4;
+                uint2 pk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (g.res) {
+                        const uint2 rv = *reinterpret_cast<const uint2 *>(g.res + o + j * 16);
+                        const float r0 = from16<D16>((unsigned short)(rv.x & 0xffffu)), r1 = from16<D16>((unsigned short)(rv.x >> 16));
+                        const float r2 = from16<D16>((unsigned short)(rv.y & 0xffffu)), r3 = from16<D16>((unsigned short)(rv.y >> 16));
+                        if (g.relu_out == 2) {
+                            v[0] = r0 > 0.f ? v[0] : 0.f; v[1] = r1 > 0.f ? v[1] : 0.f; v[2] = r2 > 0.f ? v[2] : 0.f; v[3] = r3 > 0.f ? v[3] : 0.f;
+                        } else {
+                            v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+                        }
+                    }
+                    if (g.relu_out == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                    }
+                    pk[j].x = (unsigned)to16<D16>(v[0]) | ((unsigned)to16<D16>(v[1]) << 16);
+                    pk[j].y = (unsigned)to16<D16>(v[2]) | ((unsigned)to16<D16>(v[3]) << 16);
+                }
+                if ((i & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) prev[j] = pk[j];
+                } else {
+                    unsigned short *dst = g.out + (size_t)(mw0 + (odd ? i : i - 1) * 16 + mrow) * g.Cout + nbase + (c4 & ~4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u2v_ sx = __builtin_amdgcn_permlane16_swap(prev[j].x, pk[j].x, false, false);
+                        const u2v_ sy = __builtin_amdgcn_permlane16_swap(prev[j].y, pk[j].y, false, false);
+                        *reinterpret_cast<uint4 *>(dst + j * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mw0 + i * 16 + mrow;
