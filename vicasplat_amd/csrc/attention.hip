@@ -65,6 +65,30 @@ __device__ __forceinline__ unsigned short to16(float v) {
 }
 
 // QG = 16-query MFMA groups per wave (1 -> 64 queries per workgroup, 2 -> 128): more MFMAs per staged K/V tile.
+// O is accumulated TRANSPOSED (O^T = V^T P^T: the MFMA's operands swapped), so a lane holds its own query's output: registers
+// o[db][r] = O[query][db*16 + g*4 + r].  The running-max rescale and the final 1/l then need no cross-lane traffic, and the row leaves
+// as 16-byte stores: v_permlane16_swap gives an even-g lane 8 consecutive d of block db and an odd-g lane 8 of block db + 1 (the
+// first version stored 2 bytes per lane and instruction: 16 store instructions per 16 queries, issue-bound).
+template <bool BF16>
+__device__ __forceinline__ void store_o_rows(const f4 (&o)[4], float l, int q, int Lq, unsigned short *out, long long row0, int ldo, int col0, int g) {
+    typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    uint2 pk[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        pk[db].x = pack2<BF16>(o[db][0] * inv, o[db][1] * inv);
+        pk[db].y = pack2<BF16>(o[db][2] * inv, o[db][3] * inv);
+    }
+    unsigned short *op = out + (row0 + min(q, Lq - 1)) * ldo + col0 + (g & ~1) * 4;
+    const bool odd = g & 1;
+#pragma unroll
+    for (int d2 = 0; d2 < 4; d2 += 2) {
+        const u2v_ sx = __builtin_amdgcn_permlane16_swap(pk[d2].x, pk[d2 + 1].x, false, false);
+        const u2v_ sy = __builtin_amdgcn_permlane16_swap(pk[d2].y, pk[d2 + 1].y, false, false);
+        if (q < Lq) *reinterpret_cast<uint4 *>(op + (d2 + (odd ? 1 : 0)) * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
+    }
+}
+
 template <bool BF16, int QG, int WPE>
 __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
     constexpr int QBLK = 64 * QG;
@@ -220,11 +244,9 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
                 l_run[u] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ar = __shfl(alpha, g * 4 + r, 64);
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int db = 0; db < 4; ++db) o[u][db][r] *= ar;
-                }
+                    for (int db = 0; db < 4; ++db) o[u][db][r] *= alpha;   // (O is held transposed: this lane's registers are all its own query's)
                 m_run[u] = m_new;
             }
             l_run[u] += rs;
@@ -246,25 +268,16 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
                 const uint2 hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
                 const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
-                for (int u = 0; u < QG; ++u) o[u][db] = mfma<BF16>(pf[u][ks], vf, o[u][db]);
+                for (int u = 0; u < QG; ++u) o[u][db] = mfma<BF16>(vf, pf[u][ks], o[u][db]);   // O^T += V^T P^T: lane = query, registers = 4 consecutive d
             }
         }
         __syncthreads();
     }
 
-    // ---- epilogue: O rows q = g*4 + r, cols d = db*16 + c16 ----
+    // ---- epilogue: O^T: query = this lane's c16, d = db*16 + g*4 + r ----
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float lr = __shfl(l_run[u], g * 4 + r, 64);
-            const int qo = q0 + (wid * QG + u) * 16 + g * 4 + r;
-            if (qo >= a.Lq) continue;
-            const float inv = lr > 0.f ? 1.0f / lr : 0.f;
-            unsigned short *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[u][db][r] * inv);
-        }
+        store_o_rows<BF16>(o[u], l_run[u], q0 + (wid * QG + u) * 16 + c16, a.Lq, a.out, b * a.q_batch_rows, a.ldo, h * HD, g);
         if (a.lse && g == 0) {
             const int qo = q0 + (wid * QG + u) * 16 + c16;
             if (qo < a.Lq) a.lse[(b * a.q_batch_rows + qo) * a.H + h] = l_run[u] > 0.f ? m_run[u] + log2f(l_run[u]) : -INFINITY;
@@ -391,11 +404,9 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
                 l_run *= alpha;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ar = __shfl(alpha, g * 4 + r, 64);
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int db = 0; db < 4; ++db) o[db][r] *= ar;
-                }
+                    for (int db = 0; db < 4; ++db) o[db][r] *= alpha;
                 m_run = m_new;
             }
             l_run += rs;
@@ -417,21 +428,12 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
                         uint2 lo = *reinterpret_cast<const uint2 *>(vr + (2 * ks) * 16);
                         uint2 hi = make_uint2(0, 0);
                         if (2 * ks + 1 < nbmax) hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
-                        o[db] = mfma<BF16>(pf[ks], make_uint4(lo.x, lo.y, hi.x, hi.y), o[db]);
+                        o[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[ks], o[db]);   // O^T += V^T P^T
                     }
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float lr = __shfl(l_run, g * 4 + r, 64);
-            const int qo = grp * 16 + g * 4 + r;
-            if (qo >= a.Lq) continue;
-            const float inv = lr > 0.f ? 1.0f / lr : 0.f;
-            unsigned short *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + c16;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) op[db * 16] = to16<BF16>(o[db][r] * inv);
-        }
+        store_o_rows<BF16>(o, l_run, qi, a.Lq, a.out, b * a.q_batch_rows, a.ldo, h * HD, g);
         if (a.lse && g == 0 && qvalid) a.lse[(b * a.q_batch_rows + qi) * a.H + h] = l_run > 0.f ? m_run + log2f(l_run) : -INFINITY;
     }
 }
