@@ -206,17 +206,24 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
             for (int ks = 0; ks < 2; ++ks) {
                 const uint2 lo = tr_rows4(sK, (2 * ks) * 16 + g * 4, db * 16, c16);        // K[keys g*4..+3 of block 2ks][d = db*16 + c16]
                 const uint2 hi = tr_rows4(sK, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                dq[db] = mfma<BF16>(dsf[ks], make_uint4(lo.x, lo.y, hi.x, hi.y), dq[db]);
+                dq[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), dsf[ks], dq[db]);   // dQ^T += K^T dS^T: lane = query, registers = 4 consecutive d
             }
     }
-    // dQ rows q = g*4 + r, cols d = db*16 + c16
+    // dQ^T: query = this lane's c16, d = db*16 + g*4 + r; 16-byte stores (v_permlane16_swap: an even-g lane takes 8 consecutive d of
+    // block db, an odd-g lane 8 of block db + 1), as the forward's store_o_rows
+    {
+        typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+        uint2 pk[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qo = q0 + wid * 16 + g * 4 + r;
-        if (qo >= a.Lq) continue;
-        unsigned short *op = a.dq + (b * a.q_batch_rows + qo) * a.lddq + h * HD + c16;
+        for (int db = 0; db < 4; ++db) { pk[db].x = pack2<BF16>(dq[db][0], dq[db][1]); pk[db].y = pack2<BF16>(dq[db][2], dq[db][3]); }
+        unsigned short *op = a.dq + qrow * a.lddq + h * HD + (g & ~1) * 4;
+        const bool odd = g & 1;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) op[db * 16] = (unsigned short)(pack2<BF16>(dq[db][r], 0.f) & 0xFFFFu);
+        for (int d2 = 0; d2 < 4; d2 += 2) {
+            const u2v_ sx = __builtin_amdgcn_permlane16_swap(pk[d2].x, pk[d2 + 1].x, false, false);
+            const u2v_ sy = __builtin_amdgcn_permlane16_swap(pk[d2].y, pk[d2 + 1].y, false, false);
+            if (qvalid) *reinterpret_cast<uint4 *>(op + (d2 + (odd ? 1 : 0)) * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
+        }
     }
 }
 
