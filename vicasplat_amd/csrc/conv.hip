@@ -172,71 +172,107 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
 }
 
 // ---- fused 1x1 head behind a 3x3 convolution with Cout = 256 (the Gaussian-parameter head: conv3(256->256, no bias) -> ReLU ->
-// conv1(256->83), dpt_block.py:335-343).  The [256 pixels x 256 channels] tile of the 3x3 result goes to LDS as 16-bit values (the same
-// rounding the unfused path applies when it stores the activation), XOR-swizzled so that both the 8-byte writes from the C^T
-// accumulator layout and the 16-byte fragment reads are conflict-free, and is multiplied by W2 [C2pad <= 96, 256] on the MFMA: wave w
-// owns pixel rows 32 w .. 32 w + 31 (2 x NF fragments, K = 256 in 8 steps); W2 fragments come straight from L2 (48 KiB, shared by
-// every workgroup).  Saves the write + read of the 256-channel activation at full resolution (2 x 6.4 GB per 24-scene step).
+// conv1(256->83), dpt_block.py:335-343).  The [256 pixels x 256 channels] tile of the 3x3 result is multiplied by W2 [C2pad <= 96, 256]
+// on the MFMA inside the workgroup: it saves the write + read of the 256-channel activation at full resolution (2 x 6.4 GB per
+// 24-scene step).  Round 2, after cycle stamps (tools notes in profiles/round2_pmc_gemm256.md: of a 63 us tile the second GEMM took 11.8 us
+// and the staging 5.7 -- the W2 fragments came from L2 one k-step ahead of their use, a latency per step):
+//   * W2 (48 KiB) is brought into LDS ONCE per workgroup by LDS-DMA, issued right after the K loop so that it lands under the staging
+//     arithmetic; rows of 512 B, 16-byte chunk index XOR (row & 31) applied on the source side (LDS-DMA writes lanes linearly);
+//   * the 3x3 result goes to LDS as 16-bit values (the rounding the unfused path applies when it stores the activation) in TWO channel
+//     halves of 64 KiB (rows of 256 B, chunk XOR (row & 15)): the waves that own channels 0..127 stage, all eight waves run k-steps
+//     0..3 of the second GEMM (wave w: pixel rows 32 w .. 32 w + 31, 2 x NF fragments), then the other half -- W2 and a half tile
+//     fit the 160 KiB together, a full tile (128 KiB) did not;
+//   * the [256 x C2pad] result leaves as 16-byte stores (v_permlane16_swap pairs the two row fragments of a wave).
 template <int BF16, int NF>
 __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (&acc)[8][4], int m0, int wr, int wc, unsigned char *smem, int wid,
                                                          int lane) {
+    typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
     const int mrow = lane & 15, grp = lane >> 4;
-    // stage relu(acc + bias) as 16-bit X[row][col], row stride 512 B, 16-byte chunk index XOR (row & 31)
+    unsigned char *sX = smem;                 // [256 rows][256 B]
+    unsigned char *sW = smem + 64 * 1024;     // [NF * 16 rows][512 B]
+    {   // W2 -> LDS: 16-byte piece p = round * 512 + tid holds (row p >> 5, LDS slot p & 31) = global chunk (slot ^ (row & 31))
+        typedef void __attribute__((address_space(3))) *lptr_t;
+        const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)sW + (unsigned)wid * 1024u);
+        constexpr int kRounds = (NF * 16 * 32 + 511) / 512;   // NF * 16 rows x 32 pieces, 512 lanes per round
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wr * 128 + i * 16 + mrow;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = wc * 64 + j * 16 + grp * 4;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] + (g.bias ? g.bias[col + r] : 0.0f);
-                if (g.relu_out == 1) v[r] = fmaxf(v[r], 0.0f);
-            }
-            uint2 pk;
-            pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
-            pk.y = (unsigned)to16<BF16>(v[2]) | ((unsigned)to16<BF16>(v[3]) << 16);
-            const int chunk = (col >> 3) ^ (row & 31);
-            *reinterpret_cast<uint2 *>(smem + row * 512 + chunk * 16 + (col & 7) * 2) = pk;
+        for (int r = 0; r < kRounds; ++r) {
+            const int p = r * 512 + wid * 64 + lane;
+            const int row = min(p >> 5, NF * 16 - 1), slot = p & 31;
+            if (r * 512 + wid * 64 < NF * 16 * 32)   // (wave-uniform: NF * 16 * 32 is a multiple of 64)
+                glds16(g.w2 + (size_t)row * g.Cout + ((slot ^ (row & 31)) << 3), lds_w + (unsigned)r * 8192u);
         }
     }
-    __syncthreads();
     f4 acc2[2][NF];
 #pragma unroll
     for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
         for (int n = 0; n < NF; ++n) acc2[a_][n] = f4{0.f, 0.f, 0.f, 0.f};
-    const unsigned short *w2l = g.w2 + (size_t)mrow * g.Cout + grp * 8;   // row (n * 16 + mrow), k chunk grp of step ks
-    uint4 wf[2][NF];
 #pragma unroll
-    for (int n = 0; n < NF; ++n) wf[0][n] = *reinterpret_cast<const uint4 *>(w2l + (size_t)n * 16 * g.Cout);
+    for (int half = 0; half < 2; ++half) {
+        if (half == 1) __syncthreads();   // every wave is done reading the first half of X
+        if ((wc >> 1) == half) {          // this wave's 64 channels belong to the half: relu(acc + bias) -> 16 bit -> LDS
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) {
+            for (int i = 0; i < 8; ++i) {
+                const int row = wr * 128 + i * 16 + mrow;
 #pragma unroll
-            for (int n = 0; n < NF; ++n) wf[(ks + 1) & 1][n] = *reinterpret_cast<const uint4 *>(w2l + (size_t)n * 16 * g.Cout + (ks + 1) * 32);
+                for (int j = 0; j < 4; ++j) {
+                    const int col = wc * 64 + j * 16 + grp * 4, lc = col & 127;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[i][j][r] + (g.bias ? g.bias[col + r] : 0.0f);
+                        if (g.relu_out == 1) v[r] = fmaxf(v[r], 0.0f);
+                    }
+                    uint2 pk;
+                    pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
+                    pk.y = (unsigned)to16<BF16>(v[2]) | ((unsigned)to16<BF16>(v[3]) << 16);
+                    const int chunk = (lc >> 3) ^ (row & 15);
+                    *reinterpret_cast<uint2 *>(sX + row * 256 + chunk * 16 + (lc & 7) * 2) = pk;
+                }
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W2 pieces have landed (first half: under the staging above)
+        __syncthreads();
 #pragma unroll
-        for (int a_ = 0; a_ < 2; ++a_) {
-            const int row = wid * 32 + a_ * 16 + mrow;
-            const uint4 xf = *reinterpret_cast<const uint4 *>(smem + row * 512 + (((ks * 4 + grp) ^ (row & 31)) << 4));
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 wf[NF];
 #pragma unroll
-            for (int n = 0; n < NF; ++n) acc2[a_][n] = mfma<BF16>(wf[ks & 1][n], xf, acc2[a_][n]);
+            for (int n = 0; n < NF; ++n) {
+                const int row = n * 16 + mrow;
+                wf[n] = *reinterpret_cast<const uint4 *>(sW + row * 512 + ((((half * 4 + ks) * 4 + grp) ^ (row & 31)) << 4));
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_) {
+                const int row = wid * 32 + a_ * 16 + mrow;
+                const uint4 xf = *reinterpret_cast<const uint4 *>(sX + row * 256 + (((ks * 4 + grp) ^ (row & 15)) << 4));
+#pragma unroll
+                for (int n = 0; n < NF; ++n) acc2[a_][n] = mfma<BF16>(wf[n], xf, acc2[a_][n]);
+            }
         }
     }
-    // C^T layout again: lane holds 4 consecutive output channels (n * 16 + grp * 4 ..) of pixel row (wid * 32 + a * 16 + mrow)
+    // C^T layout again: lane holds 4 consecutive output channels (n * 16 + grp * 4 ..) of pixel row (wid * 32 + a * 16 + mrow); the two
+    // row fragments are paired so that an even-grp lane stores 8 channels of fragment 0 and an odd-grp lane 8 of fragment 1
+    const bool odd = grp & 1;
+    const size_t m = (size_t)m0 + wid * 32 + (odd ? 16 : 0) + mrow;
+    unsigned short *dst = g.out2 + m * g.ld2 + (grp & ~1) * 4;
+    const bool wide = g.ld2 % 8 == 0 && (reinterpret_cast<uintptr_t>(g.out2) & 15) == 0;
 #pragma unroll
-    for (int a_ = 0; a_ < 2; ++a_) {
-        const size_t m = (size_t)m0 + wid * 32 + a_ * 16 + mrow;
-        unsigned short *dst = g.out2 + m * g.ld2 + grp * 4;
+    for (int n = 0; n < NF; ++n) {
+        const float4 b2 = *reinterpret_cast<const float4 *>(g.bias2 + n * 16 + grp * 4);
+        uint2 pk[2];
 #pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const float4 b2 = *reinterpret_cast<const float4 *>(g.bias2 + n * 16 + grp * 4);
-            uint2 pk;
-            pk.x = (unsigned)to16<BF16>(acc2[a_][n][0] + b2.x) | ((unsigned)to16<BF16>(acc2[a_][n][1] + b2.y) << 16);
-            pk.y = (unsigned)to16<BF16>(acc2[a_][n][2] + b2.z) | ((unsigned)to16<BF16>(acc2[a_][n][3] + b2.w) << 16);
-            *reinterpret_cast<uint2 *>(dst + n * 16) = pk;
+        for (int a_ = 0; a_ < 2; ++a_) {
+            pk[a_].x = (unsigned)to16<BF16>(acc2[a_][n][0] + b2.x) | ((unsigned)to16<BF16>(acc2[a_][n][1] + b2.y) << 16);
+            pk[a_].y = (unsigned)to16<BF16>(acc2[a_][n][2] + b2.z) | ((unsigned)to16<BF16>(acc2[a_][n][3] + b2.w) << 16);
+        }
+        if (wide) {
+            const u2v_ sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+            const u2v_ sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+            *reinterpret_cast<uint4 *>(dst + n * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
+        } else {
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_)
+                *reinterpret_cast<uint2 *>(g.out2 + ((size_t)m0 + wid * 32 + a_ * 16 + mrow) * g.ld2 + grp * 4 + n * 16) = pk[a_];
         }
     }
 }
