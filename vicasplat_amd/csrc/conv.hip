@@ -211,17 +211,20 @@ __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (
     for (int half = 0; half < 2; ++half) {
         if (half == 1) __syncthreads();   // every wave is done reading the first half of X
         if ((wc >> 1) == half) {          // this wave's 64 channels belong to the half: relu(acc + bias) -> 16 bit -> LDS
+            float4 bv[4];                 // the lane's 16 bias values, loaded once (they do not depend on the row fragment)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bv[j] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + wc * 64 + j * 16 + grp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = wr * 128 + i * 16 + mrow;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = wc * 64 + j * 16 + grp * 4, lc = col & 127;
-                    float v[4];
+                    float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+                    if (g.relu_out == 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[i][j][r] + (g.bias ? g.bias[col + r] : 0.0f);
-                        if (g.relu_out == 1) v[r] = fmaxf(v[r], 0.0f);
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                     }
                     uint2 pk;
                     pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
