@@ -82,8 +82,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                     }
-                    pk[j].x = (unsigned)to16<D16>(v[0]) | ((unsigned)to16<D16>(v[1]) << 16);
-                    pk[j].y = (unsigned)to16<D16>(v[2]) | ((unsigned)to16<D16>(v[3]) << 16);
+                    pk[j].x = pack16x2<D16>(v[0], v[1]);
+                    pk[j].y = pack16x2<D16>(v[2], v[3]);
                 }
                 if ((i & 1) == 0) {
 #pragma unroll
@@ -151,8 +151,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                 }
                 uint2 pk;
-                pk.x = (unsigned)to16<D16>(v[0]) | ((unsigned)to16<D16>(v[1]) << 16);
-                pk.y = (unsigned)to16<D16>(v[2]) | ((unsigned)to16<D16>(v[3]) << 16);
+                pk.x = pack16x2<D16>(v[0], v[1]);
+                pk.y = pack16x2<D16>(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(g.out + o + j * 16) = pk;
             } else {
 #pragma unroll
@@ -211,6 +211,7 @@ __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (
     for (int half = 0; half < 2; ++half) {
         if (half == 1) __syncthreads();   // every wave is done reading the first half of X
         if ((wc >> 1) == half) {          // this wave's 64 channels belong to the half: relu(acc + bias) -> 16 bit -> LDS
+            const bool relu = g.relu_out == 1;
             float4 bv[4];                 // the lane's 16 bias values, loaded once (they do not depend on the row fragment)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -221,14 +222,10 @@ __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = wc * 64 + j * 16 + grp * 4, lc = col & 127;
-                    float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
-                    if (g.relu_out == 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-                    }
-                    uint2 pk;
-                    pk.x = (unsigned)to16<BF16>(v[0]) | ((unsigned)to16<BF16>(v[1]) << 16);
-                    pk.y = (unsigned)to16<BF16>(v[2]) | ((unsigned)to16<BF16>(v[3]) << 16);
+                    uint2 pk;   // (+ bias) -> 16 bit -> ReLU on the packed pairs (max(round(x), 0) == round(max(x, 0)))
+                    pk.x = pack16x2<BF16>(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y);
+                    pk.y = pack16x2<BF16>(acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+                    if (relu) { pk.x = relu_reg<BF16>(pk.x); pk.y = relu_reg<BF16>(pk.y); }
                     const int chunk = (lc >> 3) ^ (row & 15);
                     *reinterpret_cast<uint2 *>(sX + row * 256 + chunk * 16 + (lc & 7) * 2) = pk;
                 }
@@ -265,8 +262,8 @@ __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (
         uint2 pk[2];
 #pragma unroll
         for (int a_ = 0; a_ < 2; ++a_) {
-            pk[a_].x = (unsigned)to16<BF16>(acc2[a_][n][0] + b2.x) | ((unsigned)to16<BF16>(acc2[a_][n][1] + b2.y) << 16);
-            pk[a_].y = (unsigned)to16<BF16>(acc2[a_][n][2] + b2.z) | ((unsigned)to16<BF16>(acc2[a_][n][3] + b2.w) << 16);
+            pk[a_].x = pack16x2<BF16>(acc2[a_][n][0] + b2.x, acc2[a_][n][1] + b2.y);
+            pk[a_].y = pack16x2<BF16>(acc2[a_][n][2] + b2.z, acc2[a_][n][3] + b2.w);
         }
         if (wide) {
             const u2v_ sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
@@ -410,8 +407,8 @@ __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&a
             const float o0 = acc[i][0][0] + q.x + g.bias2[0], o1 = acc[i][0][1] + q.y + g.bias2[1];
             const float o2 = acc[i][0][2] + q.z + g.bias2[2], o3 = acc[i][0][3] + q.w + g.bias2[3];
             uint2 pk;
-            pk.x = (unsigned)to16<BF16>(o0) | ((unsigned)to16<BF16>(o1) << 16);
-            pk.y = (unsigned)to16<BF16>(o2) | ((unsigned)to16<BF16>(o3) << 16);
+            pk.x = pack16x2<BF16>(o0, o1);
+            pk.y = pack16x2<BF16>(o2, o3);
             *reinterpret_cast<uint2 *>(g.out2 + ((size_t)m0 + row) * g.ld2) = pk;
         }
     }
@@ -582,7 +579,7 @@ upsample2x_kernel(const unsigned short *__restrict__ in, const unsigned short *_
             const float b = from16<BF16>((unsigned short)(a10[k] >> 16)) * (1.f - lx) + from16<BF16>((unsigned short)(a11[k] >> 16)) * lx;
             hi = t * (1.f - ly) + b * ly + (add ? from16<BF16>((unsigned short)(aa[k] >> 16)) : 0.f);
         }
-        r[k] = (unsigned)to16<BF16>(lo) | ((unsigned)to16<BF16>(hi) << 16);
+        r[k] = pack16x2<BF16>(lo, hi);
     }
     *reinterpret_cast<uint4 *>(out + o) = make_uint4(r[0], r[1], r[2], r[3]);
 }
@@ -661,7 +658,7 @@ upsample2x_backward_kernel(const unsigned short *__restrict__ dout, unsigned sho
     }
     unsigned r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = (unsigned)to16<BF16>(acc[2 * k]) | ((unsigned)to16<BF16>(acc[2 * k + 1]) << 16);
+    for (int k = 0; k < 4; ++k) r[k] = pack16x2<BF16>(acc[2 * k], acc[2 * k + 1]);
     *reinterpret_cast<uint4 *>(din + ((((size_t)n * H + y) * W + x) * C + cc * 8)) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 

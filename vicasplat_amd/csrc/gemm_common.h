@@ -82,6 +82,17 @@ __device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
     }
 }
 
+// two floats -> one packed pair of 16-bit values (low half = a), round to nearest even: ONE instruction on gfx950 (v_cvt_pk_f16_f32 /
+// v_cvt_pk_bf16_f32) where two scalar converts plus the shift / or (and, for bf16, the integer rounding sequence) were 4-10
+template <int BF16>
+__device__ __forceinline__ unsigned pack16x2(float a, float b) {
+    static_assert(BF16 != kDtF32, "f32 operands are stored as floats");
+    unsigned r;
+    if constexpr (BF16 == 1) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int BF16>
 __device__ __forceinline__ unsigned short to16(float v) {
     static_assert(BF16 != kDtF32, "f32 operands are stored as floats, not through to16");
@@ -371,8 +382,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                         uint2 pk[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            pk[j].x = (unsigned)to16<D16>(v[j][0]) | ((unsigned)to16<D16>(v[j][1]) << 16);
-                            pk[j].y = (unsigned)to16<D16>(v[j][2]) | ((unsigned)to16<D16>(v[j][3]) << 16);
+                            pk[j].x = pack16x2<D16>(v[j][0], v[j][1]);
+                            pk[j].y = pack16x2<D16>(v[j][2], v[j][3]);
                         }
                         if (wide16) {
                             // 16-byte stores: the epilogue is store-ISSUE-bound (4.4 us of a 24 us K = 1024 tile with 8-byte stores, measured
@@ -461,8 +472,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
             for (int j = 0; j < 4; ++j) {
                 if (vec_ok) {
                     uint2 pk;
-                    pk.x = (unsigned)to16<D16>(v[j][0]) | ((unsigned)to16<D16>(v[j][1]) << 16);
-                    pk.y = (unsigned)to16<D16>(v[j][2]) | ((unsigned)to16<D16>(v[j][3]) << 16);
+                    pk.x = pack16x2<D16>(v[j][0], v[j][1]);
+                    pk.y = pack16x2<D16>(v[j][2], v[j][3]);
                     *reinterpret_cast<uint2 *>(dst + j * 16) = pk;
                 } else {
 #pragma unroll
