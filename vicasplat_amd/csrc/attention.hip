@@ -28,7 +28,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int HD = 64;       // head dim
 constexpr int KB = 64;       // keys per tile
 constexpr int KROW = HD + 8; // halfs, K tile row stride (144 B)
-constexpr int VROW = KB + 8; // halfs, V^T tile row stride (144 B)
 
 struct AttnArgs {
     const unsigned short *q, *k, *v;
@@ -65,6 +64,19 @@ __device__ __forceinline__ unsigned short to16(float v) {
 }
 
 // QG = 16-query MFMA groups per wave (1 -> 64 queries per workgroup, 2 -> 128): more MFMAs per staged K/V tile.
+// 4 consecutive ROWS (keys) of one column (d) of a row-major [keys][KROW] LDS tile through the transpose read ds_read_b64_tr_b16
+// (semantics probed in tools/probe/tr_read.hip, as in attention_bwd.hip): lane t of a 16-lane group supplies
+// &tile[row0 + (t >> 2)][col0 + (t & 3) * 4] and receives tile[row0 .. row0 + 3][col0 + t].  With it the P V product reads V as it is
+// staged (16-byte row copies): no transposed V image, whose staging cost eight 4-byte LDS stores and ~16 bit operations per thread and
+// tile (cycle stamps: 24 % of a frame-encoder workgroup's time was K/V staging).
+typedef short tr4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 v_rows4(const unsigned short *tile, int row0, int col0, int t) {
+    typedef tr4v_t __attribute__((address_space(3))) *trp_t;
+    const unsigned short *p = tile + (row0 + (t >> 2)) * KROW + col0 + (t & 3) * 4;
+    const tr4v_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned short *>(p)));
+    return __builtin_bit_cast(uint2, v);
+}
+
 // O is accumulated TRANSPOSED (O^T = V^T P^T: the MFMA's operands swapped), so a lane holds its own query's output: registers
 // o[db][r] = O[query][db*16 + g*4 + r].  The running-max rescale and the final 1/l then need no cross-lane traffic, and the row leaves
 // as 16-byte stores: v_permlane16_swap gives an even-g lane 8 consecutive d of block db and an odd-g lane 8 of block db + 1 (the
@@ -93,7 +105,7 @@ template <bool BF16, int QG, int WPE>
 __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
     constexpr int QBLK = 64 * QG;
     __shared__ __attribute__((aligned(16))) unsigned short sK2[2][KB * KROW];   // two-tile ring: one barrier per tile
-    __shared__ __attribute__((aligned(16))) unsigned short sVT2[2][HD * VROW];
+    __shared__ __attribute__((aligned(16))) unsigned short sV2[2][KB * KROW];    // row-major, read through ds_read_b64_tr_b16
     __shared__ int s_maxlen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
@@ -151,8 +163,7 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
     }
 
     // staging roles
-    const int k_key = tid >> 2, k_chunk = (tid & 3) * 16;  // K: one key row, 2 x 16B
-    const int v_kp = tid & 31, v_c = tid >> 5;              // V: key pair (2kp, 2kp+1), d chunk v_c*8
+    const int k_key = tid >> 2, k_chunk = (tid & 3) * 16;  // K and V: one key row, 2 x 16B of it
 
     auto key_row = [&](int j) -> long long {
         j = min(j, Lk - 1);
@@ -163,20 +174,16 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
         const unsigned short *kp = a.k + key_row(kt + k_key) * a.ldk + h * HD + k_chunk;
         pk0 = *reinterpret_cast<const uint4 *>(kp);
         pk1 = *reinterpret_cast<const uint4 *>(kp + 8);
-        pva = *reinterpret_cast<const uint4 *>(a.v + key_row(kt + 2 * v_kp) * a.ldv + h * HD + v_c * 8);
-        pvb = *reinterpret_cast<const uint4 *>(a.v + key_row(kt + 2 * v_kp + 1) * a.ldv + h * HD + v_c * 8);
+        const unsigned short *vp = a.v + key_row(kt + k_key) * a.ldv + h * HD + k_chunk;
+        pva = *reinterpret_cast<const uint4 *>(vp);
+        pvb = *reinterpret_cast<const uint4 *>(vp + 8);
     };
-    auto lds_store = [&](int buf) {  // K tile row-major, V tile transposed, from the prefetched registers
-        unsigned short *sK = sK2[buf];
+    auto lds_store = [&](int buf) {  // K and V tiles row-major, from the prefetched registers
+        unsigned short *sK = sK2[buf], *sV = sV2[buf];
         *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk]) = pk0;
         *reinterpret_cast<uint4 *>(&sK[k_key * KROW + k_chunk + 8]) = pk1;
-        const unsigned wa[4] = {pva.x, pva.y, pva.z, pva.w}, wb[4] = {pvb.x, pvb.y, pvb.z, pvb.w};
-        unsigned *vt = reinterpret_cast<unsigned *>(sVT2[buf]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vt[((v_c * 8 + 2 * i) * VROW) / 2 + v_kp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
-            vt[((v_c * 8 + 2 * i + 1) * VROW) / 2 + v_kp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
-        }
+        *reinterpret_cast<uint4 *>(&sV[k_key * KROW + k_chunk]) = pva;
+        *reinterpret_cast<uint4 *>(&sV[k_key * KROW + k_chunk + 8]) = pvb;
     };
     if (maxlen > 0) {
         gload(0);
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
     __syncthreads();
 
     for (int kt = 0, it = 0; kt < maxlen; kt += KB, ++it) {
-        const unsigned short *sK = sK2[it & 1], *sVT = sVT2[it & 1];
+        const unsigned short *sK = sK2[it & 1], *sV = sV2[it & 1];
         // tile kt is in ring slot it&1 (ordered by the barrier that closed the previous iteration); the other slot was
         // last read during iteration it-1, so tile kt+KB can be written into it now and the loads for kt+2KB issued.
         if (kt + KB < maxlen) {
@@ -263,9 +270,8 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const unsigned short *vr = &sVT[(db * 16 + c16) * VROW + g * 4];
-                const uint2 lo = *reinterpret_cast<const uint2 *>(vr + (2 * ks) * 16);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
+                const uint2 lo = v_rows4(sV, (2 * ks) * 16 + g * 4, db * 16, c16);      // V[keys g*4..+3 of sub-block 2ks][d = db*16 + c16]
+                const uint2 hi = v_rows4(sV, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
                 for (int u = 0; u < QG; ++u) o[u][db] = mfma<BF16>(vf, pf[u][ks], o[u][db]);   // O^T += V^T P^T: lane = query, registers = 4 consecutive d
@@ -288,7 +294,7 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
 // ---- resident variant for short key sets (the frame encoder: 257 x 257 per (frame, head), no mask, no segments).
 // The tiled kernel re-stages every K/V tile once per 64-query workgroup (5 x for 257 queries) with two barriers per
 // tile, and pays full tiles for the 257th key and the 257th query.  Here ONE workgroup of 8 waves owns a (frame, head):
-// all keys and values go to LDS once (K row-major, V transposed, 75 KiB for 272 padded keys -> two workgroups per CU),
+// all keys and values go to LDS once (both row-major, 76.5 KiB for 272 padded keys -> two workgroups per CU),
 // one barrier, then every wave walks its 16-query groups over the key tiles with no further synchronisation; a partial
 // last tile only runs the 16-key sub-blocks that hold keys. ----
 constexpr int kResMaxKeys = 320;
@@ -298,9 +304,8 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_res[];
     const int Lk = a.Lk;
     const int Lkp = (Lk + 15) & ~15;      // keys padded to the 16-key MFMA sub-block
-    const int vrow = Lkp + 8;             // halfs per V^T row
     unsigned short *sK = smem_res;                  // [Lkp][KROW]
-    unsigned short *sVT = smem_res + Lkp * KROW;    // [HD][vrow]
+    unsigned short *sV = smem_res + Lkp * KROW;     // [Lkp][KROW], row-major (rows >= Lk zero)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -308,9 +313,9 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
 
     // ---- stage all keys / values: thread -> (key, 16-half chunk) for K, (key pair, 8-dim chunk) for V.  Every global
     // load of the workgroup is issued before the first LDS store (up to 3 rounds x 4 x 16 B per thread in flight). ----
-    constexpr int NR = (kResMaxKeys * 4 + 511) / 512;  // rounds of 512 threads over (key, chunk) / (pair, chunk) items
+    constexpr int NR = (kResMaxKeys * 4 + 511) / 512;  // rounds of 512 threads over (key, 16-half chunk) items
     uint4 rk[NR][2], rv[NR][2];
-    const int nK = Lkp * 4, nV = (Lkp / 2) * 8, halfp = Lkp / 2;
+    const int nK = Lkp * 4;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int idx = tid + r * 512;
@@ -319,14 +324,12 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
             const int key = idx >> 2, ch = (idx & 3) * 16;
             if (key < Lk) {
                 const unsigned short *kp = a.k + (kbase + key) * a.ldk + h * HD + ch;
+                const unsigned short *vp = a.v + (kbase + key) * a.ldv + h * HD + ch;
                 rk[r][0] = *reinterpret_cast<const uint4 *>(kp);
                 rk[r][1] = *reinterpret_cast<const uint4 *>(kp + 8);
+                rv[r][0] = *reinterpret_cast<const uint4 *>(vp);
+                rv[r][1] = *reinterpret_cast<const uint4 *>(vp + 8);
             }
-        }
-        if (idx < nV) {
-            const int kp2 = idx % halfp, vc = idx / halfp;
-            if (2 * kp2 < Lk) rv[r][0] = *reinterpret_cast<const uint4 *>(a.v + (kbase + 2 * kp2) * a.ldv + h * HD + vc * 8);
-            if (2 * kp2 + 1 < Lk) rv[r][1] = *reinterpret_cast<const uint4 *>(a.v + (kbase + 2 * kp2 + 1) * a.ldv + h * HD + vc * 8);
         }
     }
 #pragma unroll
@@ -336,16 +339,8 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
             const int key = idx >> 2, ch = (idx & 3) * 16;
             *reinterpret_cast<uint4 *>(&sK[key * KROW + ch]) = rk[r][0];
             *reinterpret_cast<uint4 *>(&sK[key * KROW + ch + 8]) = rk[r][1];
-        }
-        if (idx < nV) {
-            const int kp2 = idx % halfp, vc = idx / halfp;
-            const unsigned wa[4] = {rv[r][0].x, rv[r][0].y, rv[r][0].z, rv[r][0].w}, wb[4] = {rv[r][1].x, rv[r][1].y, rv[r][1].z, rv[r][1].w};
-            unsigned *vt = reinterpret_cast<unsigned *>(sVT);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vt[((vc * 8 + 2 * i) * vrow) / 2 + kp2] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
-                vt[((vc * 8 + 2 * i + 1) * vrow) / 2 + kp2] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
-            }
+            *reinterpret_cast<uint4 *>(&sV[key * KROW + ch]) = rv[r][0];
+            *reinterpret_cast<uint4 *>(&sV[key * KROW + ch + 8]) = rv[r][1];
         }
     }
     __syncthreads();
@@ -424,10 +419,9 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     if (ks < ksmax) {
-                        const unsigned short *vr = &sVT[(db * 16 + c16) * vrow + kt + g * 4];
-                        uint2 lo = *reinterpret_cast<const uint2 *>(vr + (2 * ks) * 16);
+                        const uint2 lo = v_rows4(sV, kt + (2 * ks) * 16 + g * 4, db * 16, c16);
                         uint2 hi = make_uint2(0, 0);
-                        if (2 * ks + 1 < nbmax) hi = *reinterpret_cast<const uint2 *>(vr + (2 * ks + 1) * 16);
+                        if (2 * ks + 1 < nbmax) hi = v_rows4(sV, kt + (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                         o[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[ks], o[db]);   // O^T += V^T P^T
                     }
                 }
@@ -629,7 +623,7 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
     static const int force_res = [] { const char *e = getenv("VS_ATTN_RES"); return e ? atoi(e) : -1; }();
     if (!kv_seg && !q_kvlen && Lk <= kResMaxKeys && Lq <= 3 * 8 * 16 && force_res != 0) {
         const int Lkp = (Lk + 15) & ~15;
-        const size_t lds = (size_t)(Lkp * KROW + HD * (Lkp + 8)) * sizeof(unsigned short);
+        const size_t lds = (size_t)(2 * Lkp * KROW) * sizeof(unsigned short);   // K and V, row-major
         dim3 grid(1, H, nbatch);
         if (dtype == 2) {
             VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
