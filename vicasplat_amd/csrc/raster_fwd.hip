@@ -52,7 +52,7 @@ constexpr int kCamChunk = 2048;   // cameras scanned per list build (8 KiB of LD
 
 struct __attribute__((packed, aligned(4))) f3_t { float x, y, z; };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ void __launch_bounds__(256)
 preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped,
                   int32_t *__restrict__ radii, float *__restrict__ depth, int32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
