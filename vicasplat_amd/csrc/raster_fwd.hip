@@ -47,7 +47,7 @@ __device__ __forceinline__ int f2i(float x) {
 // counters at the same time).  Two histograms alternate between cameras and the flush leaves its bins zeroed, so a camera
 // costs ONE barrier (accumulate | flush) instead of three (zero | accumulate | flush).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kHistTiles = 4096;  // LDS histogram capacity (2 x 16 KiB in K1); larger tile grids use global atomics directly
+constexpr int kHistTiles = 4096;  // LDS histogram capacity (bins are launch-sized, up to 2 x 16 KiB in K1); larger tile grids use global atomics directly
 constexpr int kCamChunk = 2048;   // cameras scanned per list build (8 KiB of LDS)
 
 struct __attribute__((packed, aligned(4))) f3_t { float x, y, z; };
@@ -57,7 +57,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                   int32_t *__restrict__ radii, float *__restrict__ depth, int32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
     __shared__ int cams[kCamChunk];
-    __shared__ int hist2[2][kHistTiles];
+    extern __shared__ int hist_dyn[];   // 2 x tiles bins (launch-sized: 2 KiB for a 256 x 256 image instead of 2 x 16 KiB for the 4096-tile capacity)
     __shared__ int ncam_s;
     const int s = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -70,7 +70,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
     const int lane = threadIdx.x & 63;
     const bool use_lds = tiles <= kHistTiles;
     if (use_lds)
-        for (int t = threadIdx.x; t < 2 * kHistTiles; t += 256) (&hist2[0][0])[t] = 0;   // (ordered by the camera-list barrier below)
+        for (int t = threadIdx.x; t < 2 * tiles; t += 256) hist_dyn[t] = 0;   // (ordered by the camera-list barrier below)
     int hb = 0;
 
     // ---- per-Gaussian inputs, loaded once ----
@@ -251,7 +251,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
             clamped[ci] = (uint8_t)clamp_bits;
         }
         int32_t *tc = tile_count + (size_t)c * tiles;
-        int *hist = hist2[hb];
+        int *hist = hist_dyn + hb * tiles;
         if (visible) {
             for (int y = rminy; y < rmaxy; ++y)
                 for (int x = rminx; x < rmaxx; ++x) {
@@ -338,8 +338,8 @@ __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int tiles, int gx, const float *__restrict__ depth, const ushort4 *__restrict__ rect,
                const int2 *__restrict__ ranges, int32_t *__restrict__ cursor, unsigned long long *__restrict__ keys,
                const long long *__restrict__ misc) {
-    __shared__ int hist[kHistTiles];
-    __shared__ int base[kHistTiles];
+    extern __shared__ int hist_dyn[];   // tiles bins + tiles segment bases (launch-sized)
+    int *hist = hist_dyn, *base = hist_dyn + tiles;
     if (misc[2] != 0) return;   // capacity mode, more instances than `keys` holds: the scan emptied every tile list, nothing to place
     const int c = blockIdx.y;
     const bool use_lds = tiles <= kHistTiles;
@@ -927,7 +927,7 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     if (out->n_touched) VS_HIP(hipMemsetAsync(out->n_touched, 0, CP * sizeof(int32_t), stream));
     if (P > 0) {
         dim3 grid(vs::cdiv(P, 256), in->num_scenes);
-        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, stream, *in, geom, rect, clamped, out->radii, depthkey, cursor);
+        hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), tiles <= kHistTiles ? (size_t)2 * tiles * sizeof(int) : 0, stream, *in, geom, rect, clamped, out->radii, depthkey, cursor);
     }
     VS_CHECK(in->capacity >= 0 && in->capacity < 2147483647LL, "vs_raster_forward: capacity %lld out of range", (long long)in->capacity);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, cursor, ranges, C * tiles, misc, (long long)in->capacity);
@@ -963,7 +963,7 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     if (segs && in->capacity > 0) VS_HIP(hipMemsetAsync(segs, 0, (size_t)nslots * sizeof(int2), stream));
     if (R > 0) {
         dim3 grid(vs::cdiv(P, 256 * kScatterPer), C);
-        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), 0, stream, P, tiles, gx, depthkey, rect, ranges, cursor, keys, misc);
+        hipLaunchKernelGGL(scatter_kernel, grid, dim3(256), tiles <= kHistTiles ? (size_t)2 * tiles * sizeof(int) : 0, stream, P, tiles, gx, depthkey, rect, ranges, cursor, keys, misc);
         hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles, C), dim3(256), 0, stream, ranges, keys, point_list, scratch, segs);
         if (segs)
             hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)vs::cdiv64(nslots, 4)), dim3(256), 0, stream, segs, (int)nslots,
