@@ -63,6 +63,91 @@ __device__ __forceinline__ unsigned short to16(float v) {
     return (unsigned short)(pack2<BF16>(v, 0.f) & 0xFFFFu);
 }
 
+// ---- online-softmax step of one 16-query group over one 64-key tile.  The softmax is the VALU bottleneck of both kernels (16 scores
+// per lane and group against 16 MFMAs = 256 matrix cycles; v_exp_f32 is quarter rate, 16 of them are 256 issue cycles on their own), so
+// everything around the exponentials is kept to the fewest issue slots: bare v_max3_f32 (fmaxf() on raw MFMA outputs canonicalises
+// both operands under IEEE mode: 16 extra v_max per tile in the compiled code), the two cross-row reductions through v_permlane16_swap /
+// v_permlane32_swap (VALU, no ds_bpermute round trip through the LDS queue and its lgkmcnt(0) drain), scale, subtract and the row
+// sum on the packed-f32 forms (v_pk_mul_f32 / v_pk_add_f32: two scores per slot).  Scores are finite or -inf, never NaN. ----
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the value of the lane 16 (32) positions away, i.e. in the neighbouring 16-lane row (32-lane half): a swap of two copies of x hands
+// every lane its own value and its partner's, in either order (tools/probe/permlane_swap.hip).  Written as inline asm on two distinct
+// registers: the builtin called with the same value twice compiles to code that reads ONE of the two results twice (ROCm 7.2), and the
+// s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see inside an asm block.
+__device__ __forceinline__ void swap16(float &a, float &b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float &a, float &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows_max(float x) {
+    float a = x, b = x;
+    swap16(a, b);
+    a = vmax2(a, b); b = a;
+    swap32(a, b);
+    return vmax2(a, b);
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    float a = x, b = x;
+    swap16(a, b);
+    a += b; b = a;
+    swap32(a, b);
+    return a + b;
+}
+
+// st: S^T fragments (keys nb*16 + g*4 + r of this lane's query), masked entries -inf.  Updates the running max / sum, rescales the
+// transposed O accumulator when some query's maximum moved, and returns P in the A-operand layout of the P V MFMA.
+template <bool BF16>
+__device__ __forceinline__ void softmax_tile(f4 (&st)[4], float scale_log2e, float &m_run, float &l_run, f4 (&o)[4], uint4 (&pf)[2]) {
+    // scores to the log2 domain first (packed multiplies).  It also makes the MFMA results' first reader an instruction the compiler's
+    // hazard recogniser sees (an inline-asm v_max3 reading them directly gets no MFMA -> VALU wait states: NaNs from in-flight
+    // registers), and lets fmaxf() compile to bare v_max3_f32: arithmetic results are known canonical, MFMA outputs are not.
+    const f2v sc = f2v{scale_log2e, scale_log2e};
+    f2v t[4][2];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        t[nb][0] = f2v{st[nb][0], st[nb][1]} * sc;
+        t[nb][1] = f2v{st[nb][2], st[nb][3]} * sc;
+    }
+    float mx = fmaxf(fmaxf(t[0][0].x, t[0][0].y), t[0][1].x);
+    mx = fmaxf(fmaxf(mx, t[0][1].y), t[1][0].x);
+    mx = fmaxf(fmaxf(mx, t[1][0].y), t[1][1].x);
+    mx = fmaxf(fmaxf(mx, t[1][1].y), t[2][0].x);
+    mx = fmaxf(fmaxf(mx, t[2][0].y), t[2][1].x);
+    mx = fmaxf(fmaxf(mx, t[2][1].y), t[3][0].x);
+    mx = fmaxf(fmaxf(mx, t[3][0].y), t[3][1].x);
+    mx = fmaxf(mx, t[3][1].y);
+    mx = rows_max(mx);
+    const float m_new = vmax2(m_run, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const f2v neg_m = f2v{-m_use, -m_use};
+    f2v acc = f2v{0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f2v x = t[nb][h] + neg_m;
+            f2v p;
+            p.x = __builtin_amdgcn_exp2f(x.x);   // raw hardware exp2: inputs are <= 0 or -inf, no denormal fix-up needed
+            p.y = __builtin_amdgcn_exp2f(x.y);
+            st[nb][2 * h] = p.x; st[nb][2 * h + 1] = p.y;
+            acc += p;
+        }
+    const float rs = rows_sum(acc.x + acc.y);
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {  // wave-uniform: some query's running max moved
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] *= alpha;   // (O is held transposed: this lane's registers are all its own query's)
+        m_run = m_new;
+    }
+    l_run += rs;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        pf[ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
+        pf[ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
+        pf[ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+        pf[ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+    }
+}
+
 // QG = 16-query MFMA groups per wave (1 -> 64 queries per workgroup, 2 -> 128): more MFMAs per staged K/V tile.
 // 4 consecutive ROWS (keys) of one column (d) of a row-major [keys][KROW] LDS tile through the transpose read ds_read_b64_tr_b16
 // (semantics probed in tools/probe/tr_read.hip, as in attention_bwd.hip): lane t of a 16-lane group supplies
@@ -218,52 +303,16 @@ __global__ void __launch_bounds__(256, WPE) attention_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) st[nb] = mfma<BF16>(kf[nb][ks], qf[u][ks], st[nb]);
             }
-            // The softmax is the VALU bottleneck of this kernel (16 scores per lane per group against 16 MFMAs), so it is
-            // kept to max / fma / v_exp_f32 / add per score: the scale is folded into the exponent fma, the prefix mask is
-            // applied only on the tile that straddles a query's key limit, exp2 is the raw hardware instruction (inputs
-            // are <= 0 or -inf: no denormal fix-up needed), and the O rescale is skipped while no lane's max moves.
+            // the prefix mask is applied only on the tile that straddles a query's key limit (one VGPR limit against constants)
             if (kt + KB > wave_minlen[u]) {
+                const int lim = my_len[u] - kt - g * 4;
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kt + nb * 16 + g * 4 + r >= my_len[u]) st[nb][r] = -INFINITY;
+                        if (nb * 16 + r >= lim) st[nb][r] = -INFINITY;
             }
-            float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-            for (int nb = 1; nb < 4; ++nb) mx = fmaxf(fmaxf(mx, fmaxf(st[nb][0], st[nb][1])), fmaxf(st[nb][2], st[nb][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[u], mx * a.scale_log2e);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            float rs = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[nb][r], a.scale_log2e, -m_use));
-                    st[nb][r] = p;
-                    rs += p;
-                }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run[u]) != 0) {  // wave-uniform: some query's running max moved
-                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_use);
-                l_run[u] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int db = 0; db < 4; ++db) o[u][db][r] *= alpha;   // (O is held transposed: this lane's registers are all its own query's)
-                m_run[u] = m_new;
-            }
-            l_run[u] += rs;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                pf[u][ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
-                pf[u][ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
-                pf[u][ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-                pf[u][ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
-            }
+            softmax_tile<BF16>(st, a.scale_log2e, m_run[u], l_run[u], o[u], pf[u]);
         }
         // O += P V ; V fragments shared by the query groups
 #pragma unroll
@@ -356,64 +405,47 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = f4{0.f, 0.f, 0.f, 0.f};
         float m_run = -INFINITY, l_run = 0.f;
-        for (int kt = 0; kt < Lk; kt += KB) {
-            const int nbmax = min(4, (Lk - kt + 15) >> 4);  // 16-key sub-blocks of this tile that hold keys (wave-uniform)
+        int kt = 0;
+        for (; kt + KB <= Lk; kt += KB) {   // full tiles: straight-line code, no sub-block conditions
+            f4 st[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const unsigned short *kr = &sK[(kt + nb * 16 + c16) * KROW + g * 8];
+                st[nb] = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr), qf0, f4{0.f, 0.f, 0.f, 0.f});
+                st[nb] = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr + 32), qf1, st[nb]);
+            }
+            uint4 pf[2];
+            softmax_tile<BF16>(st, a.scale_log2e, m_run, l_run, o, pf);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint2 lo = v_rows4(sV, kt + (2 * ks) * 16 + g * 4, db * 16, c16);
+                    const uint2 hi = v_rows4(sV, kt + (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                    o[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[ks], o[db]);   // O^T += V^T P^T
+                }
+        }
+        if (kt < Lk) {   // the partial last tile: only the 16-key sub-blocks that hold keys (wave-uniform conditions)
+            const int nbmax = (Lk - kt + 15) >> 4;
             f4 st[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 st[nb] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 if (nb < nbmax) {
                     const unsigned short *kr = &sK[(kt + nb * 16 + c16) * KROW + g * 8];
-                    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-                    acc = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr), qf0, acc);
-                    acc = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr + 32), qf1, acc);
-                    st[nb] = acc;
+                    f4 acc = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr), qf0, f4{0.f, 0.f, 0.f, 0.f});
+                    st[nb] = mfma<BF16>(*reinterpret_cast<const uint4 *>(kr + 32), qf1, acc);
                 }
             }
-            if (kt + KB > Lk) {  // straddling tile: keys past Lk are padding
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kt + nb * 16 + g * 4 + r >= Lk) st[nb][r] = -INFINITY;
-            }
-            float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-            for (int nb = 1; nb < 4; ++nb) mx = fmaxf(fmaxf(mx, fmaxf(st[nb][0], st[nb][1])), fmaxf(st[nb][2], st[nb][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx * a.scale_log2e);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            float rs = 0.f;
+            const int lim = Lk - kt - g * 4;   // keys past Lk are padding
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[nb][r], a.scale_log2e, -m_use));
-                    st[nb][r] = p;
-                    rs += p;
-                }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-                l_run *= alpha;
-#pragma unroll
                 for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int db = 0; db < 4; ++db) o[db][r] *= alpha;
-                m_run = m_new;
-            }
-            l_run += rs;
+                    if (nb * 16 + r >= lim) st[nb][r] = -INFINITY;
             uint4 pf[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                pf[ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
-                pf[ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
-                pf[ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-                pf[ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
-            }
-            const int ksmax = (nbmax + 1) >> 1;  // 32-key MFMA steps that hold keys (V^T padding beyond is zero)
+            softmax_tile<BF16>(st, a.scale_log2e, m_run, l_run, o, pf);
+            const int ksmax = (nbmax + 1) >> 1;  // 32-key MFMA steps that hold keys (V rows beyond Lk are zero)
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -422,7 +454,7 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
                         const uint2 lo = v_rows4(sV, kt + (2 * ks) * 16 + g * 4, db * 16, c16);
                         uint2 hi = make_uint2(0, 0);
                         if (2 * ks + 1 < nbmax) hi = v_rows4(sV, kt + (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                        o[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[ks], o[db]);   // O^T += V^T P^T
+                        o[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[ks], o[db]);
                     }
                 }
             }
