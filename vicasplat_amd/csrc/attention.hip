@@ -65,10 +65,10 @@ __device__ __forceinline__ unsigned short to16(float v) {
 
 // ---- online-softmax step of one 16-query group over one 64-key tile.  The softmax is the VALU bottleneck of both kernels (16 scores
 // per lane and group against 16 MFMAs = 256 matrix cycles; v_exp_f32 is quarter rate, 16 of them are 256 issue cycles on their own), so
-// everything around the exponentials is kept to the fewest issue slots: bare v_max3_f32 (fmaxf() on raw MFMA outputs canonicalises
-// both operands under IEEE mode: 16 extra v_max per tile in the compiled code), the two cross-row reductions through v_permlane16_swap /
-// v_permlane32_swap (VALU, no ds_bpermute round trip through the LDS queue and its lgkmcnt(0) drain), scale, subtract and the row
-// sum on the packed-f32 forms (v_pk_mul_f32 / v_pk_add_f32: two scores per slot).  Scores are finite or -inf, never NaN. ----
+// everything around the exponentials is kept to the fewest issue slots: bare v_max3_f32, the two cross-row reductions through
+// v_permlane16_swap / v_permlane32_swap (VALU, no ds_bpermute round trip through the LDS queue and its lgkmcnt(0) drain), scale-and-
+// subtract and the row sum on the packed-f32 forms (v_pk_fma_f32 / v_pk_add_f32; measured equal to the scalar forms here).  Scores are
+// finite or -inf, never NaN. ----
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // the value of the lane 16 (32) positions away, i.e. in the neighbouring 16-lane row (32-lane half): a swap of two copies of x hands
@@ -99,33 +99,30 @@ __device__ __forceinline__ void softmax_tile(f4 (&st)[4], float scale_log2e, flo
     // scores to the log2 domain first (packed multiplies).  It also makes the MFMA results' first reader an instruction the compiler's
     // hazard recogniser sees (an inline-asm v_max3 reading them directly gets no MFMA -> VALU wait states: NaNs from in-flight
     // registers), and lets fmaxf() compile to bare v_max3_f32: arithmetic results are known canonical, MFMA outputs are not.
-    const f2v sc = f2v{scale_log2e, scale_log2e};
-    f2v t[4][2];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        t[nb][0] = f2v{st[nb][0], st[nb][1]} * sc;
-        t[nb][1] = f2v{st[nb][2], st[nb][3]} * sc;
-    }
-    float mx = fmaxf(fmaxf(t[0][0].x, t[0][0].y), t[0][1].x);
-    mx = fmaxf(fmaxf(mx, t[0][1].y), t[1][0].x);
-    mx = fmaxf(fmaxf(mx, t[1][0].y), t[1][1].x);
-    mx = fmaxf(fmaxf(mx, t[1][1].y), t[2][0].x);
-    mx = fmaxf(fmaxf(mx, t[2][0].y), t[2][1].x);
-    mx = fmaxf(fmaxf(mx, t[2][1].y), t[3][0].x);
-    mx = fmaxf(fmaxf(mx, t[3][0].y), t[3][1].x);
-    mx = fmaxf(mx, t[3][1].y);
-    mx = rows_max(mx);
+    // the maximum is taken on the raw MFMA outputs and scaled once: this file is compiled with -fno-honor-nans (Makefile), without which
+    // fmaxf() on values the compiler cannot prove canonical costs an extra v_max per operand under IEEE mode (16 per tile; measured
+    // -4 % on the whole kernel family).  The MFMA results' first readers stay compiler-visible instructions: an inline-asm v_max3
+    // reading them gets no MFMA -> VALU wait states from the hazard recogniser (tried: NaNs from in-flight registers).
+    float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+    mx = fmaxf(fmaxf(mx, st[0][3]), st[1][0]);
+    mx = fmaxf(fmaxf(mx, st[1][1]), st[1][2]);
+    mx = fmaxf(fmaxf(mx, st[1][3]), st[2][0]);
+    mx = fmaxf(fmaxf(mx, st[2][1]), st[2][2]);
+    mx = fmaxf(fmaxf(mx, st[2][3]), st[3][0]);
+    mx = fmaxf(fmaxf(mx, st[3][1]), st[3][2]);
+    mx = fmaxf(mx, st[3][3]);
+    mx = rows_max(mx) * scale_log2e;
     const float m_new = vmax2(m_run, mx);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const f2v neg_m = f2v{-m_use, -m_use};
+    const f2v sc = f2v{scale_log2e, scale_log2e}, neg_m = f2v{-m_use, -m_use};
     f2v acc = f2v{0.f, 0.f};
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const f2v x = t[nb][h] + neg_m;
+            const f2v x = f2v{st[nb][2 * h], st[nb][2 * h + 1]} * sc + neg_m;
             f2v p;
-            p.x = __builtin_amdgcn_exp2f(x.x);   // raw hardware exp2: inputs are <= 0 or -inf, no denormal fix-up needed
+            p.x = __builtin_amdgcn_exp2f(x.x);
             p.y = __builtin_amdgcn_exp2f(x.y);
             st[nb][2 * h] = p.x; st[nb][2 * h + 1] = p.y;
             acc += p;
