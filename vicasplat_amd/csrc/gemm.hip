@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
         if constexpr (EPI == 0 && BF16 != kDtF32) {
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
         } else if constexpr (EPI == 1 && BF16 != kDtF32) {
-            v = gelu_erf(v);
+            v = gelu_poly(v);
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
         } else if constexpr (EPI == 1) {     // f32 operands: GELU, f32 store
             reinterpret_cast<float *>(g.out)[orow * g.ldo + n] = gelu_erf(v);

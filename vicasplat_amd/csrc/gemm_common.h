@@ -173,6 +173,29 @@ __device__ __forceinline__ f2v gelu_erf2(f2v v) {
     return v * 0.5f * (e + 1.0f);
 }
 
+// GELU for the 16-bit epilogues without transcendentals: erf(x / sqrt 2) ~ t * P(t^2), t = clamp(x, -4.2, 4.2) / 4.2, P of degree 7
+// (minimax fit of the GELU error with P(1) = 1 so that the clamp is seamless; tools/fit_gelu_poly.py).  |gelu_poly - gelu_erf| <= 8.1e-5
+// absolute in f32 evaluation -- a sixth of an f16 ulp at 1 -- for 13 packed issue slots per two elements instead of ~30 (the rcp and
+// exp2 of the erf form are quarter rate, and the GELU epilogue of a one-workgroup-per-CU kernel is exposed VALU time).  The f32 outputs
+// (EPI_STORE32-class paths, linear_f32) keep gelu_erf.
+__device__ __forceinline__ f2v gelu_poly2(f2v v) {
+    constexpr float X = 4.2f;
+    f2v t;
+    t.x = __builtin_amdgcn_fmed3f(v.x, -X, X); t.y = __builtin_amdgcn_fmed3f(v.y, -X, X);
+    t = t * (1.0f / X);
+    const f2v u = t * t;
+    f2v p = u * (-4.02584553f) + 20.0985432f;
+    p = p * u + (-43.586319f);
+    p = p * u + 54.4050636f;
+    p = p * u + (-43.8327904f);
+    p = p * u + 24.3039417f;
+    p = p * u + (-9.70970726f);
+    p = p * u + 3.34711337f;
+    const f2v e = p * t, h = v * 0.5f;
+    return h * e + h;
+}
+__device__ __forceinline__ float gelu_poly(float v) { return gelu_poly2(f2v{v, v}).x; }
+
 // cos/sin of an angle given in radians on the hardware v_cos/v_sin (argument in revolutions; |angle| stays < 2^8 rev)
 __device__ __forceinline__ void sincos_hw(float ang, float &sn, float &cs) {
     const float rev = ang * 0.15915494309189535f;
@@ -328,7 +351,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
                         for (int r = 0; r < 4; r += 2) {
                             if constexpr (EPI == 1) {
-                                const f2v gl = gelu_erf2(f2v{acc[i][j][r] + bv[j][r], acc[i][j][r + 1] + bv[j][r + 1]});
+                                const f2v gl = gelu_poly2(f2v{acc[i][j][r] + bv[j][r], acc[i][j][r + 1] + bv[j][r + 1]});
                                 v[j][r] = gl.x; v[j][r + 1] = gl.y;
                             } else {
                                 v[j][r] = acc[i][j][r] + bv[j][r];
@@ -430,7 +453,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[j][r] = acc[i][j][r] + bv[j][r];
-                if constexpr (EPI == 1) v[j][r] = gelu_erf(v[j][r]);
+                if constexpr (EPI == 1) v[j][r] = gelu_poly(v[j][r]);   // same function as the wide path: results do not depend on the tile path
             }
         if constexpr (EPI == 4) {
             if (rope_on) {
