@@ -101,6 +101,96 @@ layernorm_mod_kernel(const float *__restrict__ x, long long ldx, const float *__
     }
 }
 
+// C = 256 * NV (1024 and 768: every LayerNorm of the model): a wave takes R consecutive rows and keeps w, b (and the AdaLN scale /
+// shift of the rows' frame) in registers across them.  One row per wave re-reads 8-16 KB of parameters from L2 per 4 KB row of x: at
+// the bench's row count the kernel was bound by the vector-memory pipe, not by HBM (4.7 TB/s plain, 3.3 TB/s with AdaLN at C = 1024
+// against 6.3 achievable; tools/bench_ln.py).  All R rows' loads are issued before the first reduction.
+template <int DT, int NV, int R>
+__global__ void __launch_bounds__(256)
+layernorm_rows_kernel(const float *__restrict__ x, long long ldx, const float *__restrict__ w, const float *__restrict__ b,
+                      const float *__restrict__ scale, const float *__restrict__ shift, int mod_rows, int mod_ld,
+                      typename Out<DT>::T *__restrict__ out, long long ldo, int M, float eps, int grp_in, int grp_out, int grp_off) {
+    constexpr int C = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (m0 >= M) return;
+    float4 v[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float *xr = x + (long long)min(m0 + r, M - 1) * ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[r][i] = *reinterpret_cast<const float4 *>(xr + 4 * (lane + 64 * i));
+    }
+    float4 ww[NV], bv[NV], s4[NV], h4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ww[i] = *reinterpret_cast<const float4 *>(w + 4 * (lane + 64 * i));
+        bv[i] = *reinterpret_cast<const float4 *>(b + 4 * (lane + 64 * i));
+    }
+    int grp_loaded = -1;
+    if (scale || shift) {   // the first row's frame, fetched with the other parameters (before the reductions, not behind them)
+        grp_loaded = m0 / mod_rows;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s4[i] = scale ? *reinterpret_cast<const float4 *>(scale + (long long)grp_loaded * mod_ld + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            h4[i] = shift ? *reinterpret_cast<const float4 *>(shift + (long long)grp_loaded * mod_ld + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int m = m0 + r;
+        if (m >= M) break;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = wave_sum(s) * (1.0f / (float)C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float a = v[r][i].x - mean, bb = v[r][i].y - mean, c = v[r][i].z - mean, d = v[r][i].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / (float)C) + eps);
+        if (scale || shift) {
+            const int gq = m / mod_rows;
+            if (gq != grp_loaded) {   // wave-uniform; the frame changes every mod_rows rows
+                grp_loaded = gq;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    s4[i] = scale ? *reinterpret_cast<const float4 *>(scale + (long long)gq * mod_ld + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    h4[i] = shift ? *reinterpret_cast<const float4 *>(shift + (long long)gq * mod_ld + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        const long long orow = (long long)(m / grp_in) * grp_out + grp_off + (m % grp_in);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float y0 = (v[r][i].x - mean) * rstd * ww[i].x + bv[i].x, y1 = (v[r][i].y - mean) * rstd * ww[i].y + bv[i].y;
+            float y2 = (v[r][i].z - mean) * rstd * ww[i].z + bv[i].z, y3 = (v[r][i].w - mean) * rstd * ww[i].w + bv[i].w;
+            if (scale) { y0 *= 1.0f + s4[i].x; y1 *= 1.0f + s4[i].y; y2 *= 1.0f + s4[i].z; y3 *= 1.0f + s4[i].w; }
+            if (shift) { y0 += h4[i].x; y1 += h4[i].y; y2 += h4[i].z; y3 += h4[i].w; }
+            Out<DT>::st4(out + orow * ldo + 4 * (lane + 64 * i), y0, y1, y2, y3);
+        }
+    }
+}
+
+template <int DT>
+void launch_layernorm(const float *x, long long ldx, const float *w, const float *b, const float *scale, const float *shift, int mod_rows,
+                      int mod_ld, typename Out<DT>::T *out, long long ldo, int M, int C, float eps, int grp_in, int grp_out, int grp_off,
+                      hipStream_t stream) {
+#ifndef LN_R
+#define LN_R 4
+#endif
+    constexpr int R = LN_R;
+    const dim3 block(256), grid_rows(vs::cdiv(M, 4 * R));
+    if (C == 1024)
+        hipLaunchKernelGGL((layernorm_rows_kernel<DT, 4, R>), grid_rows, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, eps, grp_in, grp_out, grp_off);
+    else if (C == 768)
+        hipLaunchKernelGGL((layernorm_rows_kernel<DT, 3, R>), grid_rows, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, eps, grp_in, grp_out, grp_off);
+    else
+        hipLaunchKernelGGL(layernorm_mod_kernel<DT>, dim3(vs::cdiv(M, 4)), block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, C, eps, grp_in, grp_out, grp_off);
+}
+
 template <bool BF16>
 __device__ __forceinline__ float ld16(const unsigned short *p) {
     if constexpr (BF16) return __uint_as_float(((unsigned)*p) << 16);
@@ -217,11 +307,10 @@ extern "C" int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, con
     if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
     if (mod_rows <= 0) mod_rows = M;
     if (mod_ld <= 0) mod_ld = C;
-    dim3 grid(vs::cdiv(M, 4)), block(256);
     switch (out_dtype) {
-        case 0: hipLaunchKernelGGL(layernorm_mod_kernel<0>, grid, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, (float *)out, ldo, M, C, eps, grp_in, grp_out, grp_off); break;
-        case 1: hipLaunchKernelGGL(layernorm_mod_kernel<1>, grid, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off); break;
-        default: hipLaunchKernelGGL(layernorm_mod_kernel<2>, grid, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off); break;
+        case 0: launch_layernorm<0>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (float *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
+        case 1: launch_layernorm<1>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
+        default: launch_layernorm<2>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
     }
     VS_HIP(hipGetLastError());
     return 0;
