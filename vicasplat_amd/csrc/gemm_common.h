@@ -351,7 +351,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
                         for (int r = 0; r < 4; r += 2) {
                             if constexpr (EPI == 1) {
-                                const f2v gl = gelu_poly2(f2v{acc[i][j][r] + bv[j][r], acc[i][j][r + 1] + bv[j][r + 1]});
+                                const f2v zin = f2v{acc[i][j][r] + bv[j][r], acc[i][j][r + 1] + bv[j][r + 1]};
+                                const f2v gl = BF16 == kDtF32 ? gelu_erf2(zin) : gelu_poly2(zin);   // f32 operands = reference-precision path: exact erf
                                 v[j][r] = gl.x; v[j][r + 1] = gl.y;
                             } else {
                                 v[j][r] = acc[i][j][r] + bv[j][r];
@@ -453,7 +454,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[j][r] = acc[i][j][r] + bv[j][r];
-                if constexpr (EPI == 1) v[j][r] = gelu_poly(v[j][r]);   // same function as the wide path: results do not depend on the tile path
+                if constexpr (EPI == 1) v[j][r] = BF16 == kDtF32 ? gelu_erf(v[j][r]) : gelu_poly(v[j][r]);   // same function as the wide path: results do not depend on the tile path
             }
         if constexpr (EPI == 4) {
             if (rope_on) {
