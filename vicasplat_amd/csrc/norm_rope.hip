@@ -105,22 +105,15 @@ layernorm_mod_kernel(const float *__restrict__ x, long long ldx, const float *__
 // shift of the rows' frame) in registers across them.  One row per wave re-reads 8-16 KB of parameters from L2 per 4 KB row of x: at
 // the bench's row count the kernel was bound by the vector-memory pipe, not by HBM (4.7 TB/s plain, 3.3 TB/s with AdaLN at C = 1024
 // against 6.3 achievable; tools/bench_ln.py).  All R rows' loads are issued before the first reduction.
-template <int DT, int NV, int R>
+template <int DT, int NV, int R, int ITER>
 __global__ void __launch_bounds__(256)
 layernorm_rows_kernel(const float *__restrict__ x, long long ldx, const float *__restrict__ w, const float *__restrict__ b,
                       const float *__restrict__ scale, const float *__restrict__ shift, int mod_rows, int mod_ld,
                       typename Out<DT>::T *__restrict__ out, long long ldo, int M, float eps, int grp_in, int grp_out, int grp_off) {
     constexpr int C = 256 * NV;
     const int lane = threadIdx.x & 63;
-    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    if (m0 >= M) return;
-    float4 v[R][NV];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float *xr = x + (long long)min(m0 + r, M - 1) * ldx;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[r][i] = *reinterpret_cast<const float4 *>(xr + 4 * (lane + 64 * i));
-    }
+    const int mw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (R * ITER);   // the wave's R * ITER consecutive rows
+    if (mw >= M) return;
     float4 ww[NV], bv[NV], s4[NV], h4[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -129,12 +122,22 @@ layernorm_rows_kernel(const float *__restrict__ x, long long ldx, const float *_
     }
     int grp_loaded = -1;
     if (scale || shift) {   // the first row's frame, fetched with the other parameters (before the reductions, not behind them)
-        grp_loaded = m0 / mod_rows;
+        grp_loaded = mw / mod_rows;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             s4[i] = scale ? *reinterpret_cast<const float4 *>(scale + (long long)grp_loaded * mod_ld + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
             h4[i] = shift ? *reinterpret_cast<const float4 *>(shift + (long long)grp_loaded * mod_ld + 4 * (lane + 64 * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    }
+    for (int it = 0; it < ITER; ++it) {
+    const int m0 = mw + it * R;
+    if (m0 >= M) break;
+    float4 v[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float *xr = x + (long long)min(m0 + r, M - 1) * ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[r][i] = *reinterpret_cast<const float4 *>(xr + 4 * (lane + 64 * i));
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -172,23 +175,26 @@ layernorm_rows_kernel(const float *__restrict__ x, long long ldx, const float *_
             Out<DT>::st4(out + orow * ldo + 4 * (lane + 64 * i), y0, y1, y2, y3);
         }
     }
+    }
 }
 
 template <int DT>
 void launch_layernorm(const float *x, long long ldx, const float *w, const float *b, const float *scale, const float *shift, int mod_rows,
                       int mod_ld, typename Out<DT>::T *out, long long ldo, int M, int C, float eps, int grp_in, int grp_out, int grp_off,
                       hipStream_t stream) {
-#ifndef LN_R
-#define LN_R 4
-#endif
-    constexpr int R = LN_R;
-    const dim3 block(256), grid_rows(vs::cdiv(M, 4 * R));
-    if (C == 1024)
-        hipLaunchKernelGGL((layernorm_rows_kernel<DT, 4, R>), grid_rows, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, eps, grp_in, grp_out, grp_off);
-    else if (C == 768)
-        hipLaunchKernelGGL((layernorm_rows_kernel<DT, 3, R>), grid_rows, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, eps, grp_in, grp_out, grp_off);
+    // plain LayerNorm: one group of R rows per wave (more waves in flight); with AdaLN two groups per wave -- the frame's scale / shift
+    // rows are hot L2 lines shared by ~64 waves, and halving those requests is worth more than the lost overlap (tools/bench_ln.py:
+    // 70 -> 58 us at 49344 x 1024; plain 51 us either way with one group, 56 with two)
+    constexpr int R = 4;
+    const dim3 block(256);
+    const bool mod = scale || shift;
+    const dim3 grid_rows(vs::cdiv(M, 4 * R * (mod ? 2 : 1)));
+#define VS_LN_LAUNCH(NV_, IT_) hipLaunchKernelGGL((layernorm_rows_kernel<DT, NV_, R, IT_>), grid_rows, block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, eps, grp_in, grp_out, grp_off)
+    if (C == 1024) { if (mod) VS_LN_LAUNCH(4, 2); else VS_LN_LAUNCH(4, 1); }
+    else if (C == 768) { if (mod) VS_LN_LAUNCH(3, 2); else VS_LN_LAUNCH(3, 1); }
     else
         hipLaunchKernelGGL(layernorm_mod_kernel<DT>, dim3(vs::cdiv(M, 4)), block, 0, stream, x, ldx, w, b, scale, shift, mod_rows, mod_ld, out, ldo, M, C, eps, grp_in, grp_out, grp_off);
+#undef VS_LN_LAUNCH
 }
 
 template <bool BF16>
