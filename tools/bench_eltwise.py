@@ -16,6 +16,9 @@ fns = {"relu_mask (3 x 2 B)": (lambda: ops.relu_mask(dy, x), 6 * n)}
 z = torch.randn(49344, 4096, device=d).half()
 if hasattr(ops, "gelu"): fns["gelu (2 x 2 B)"] = (lambda: ops.gelu(z), 4 * z.numel())
 if hasattr(ops, "gelu_backward"): fns["gelu_backward (3 x 2 B)"] = (lambda: ops.gelu_backward(z, z), 6 * z.numel())
+for N_ in (1024, 3072, 4096):
+    zz = torch.randn(49344, N_, device=d).half()
+    fns[f"colsum N={N_}"] = ((lambda t: (lambda: ops.colsum(t)))(zz), 2 * zz.numel())
 for k, (f, byt) in fns.items():
     once(f, 2); t = min(once(f) for _ in range(4))
     print(f"{k:28s} {t:8.1f} us  {byt / t / 1e6:5.2f} TB/s")
