@@ -31,6 +31,21 @@ print(f"cameras {Cn}, P {P}, R {st['num_rendered']}, tiles {n.size}")
 print("tile list length: mean %.0f  p50 %d  p90 %d  p99 %d  max %d" % (n.mean(), *np.percentile(n, [50, 90, 99]).astype(int), n.max()))
 for lo, hi in ((0, 1), (1, 1025), (1025, 4097), (4097, 16385), (16385, 1 << 30)):
     m = (n >= lo) & (n < hi); print(f"  tiles with {lo} <= n < {hi}: {m.sum()} ({100.0 * m.mean():.1f} %), keys {n[m].sum()} ({100.0 * n[m].sum() / max(n.sum(), 1):.1f} %)")
+# ---- what dispatch order costs: greedy list scheduling of the (camera, tile) workgroups over S resident slots, cost = a + n (entries),
+# in the launch order (camera-major, tile-minor) vs longest-first
+import heapq
+def makespan(costs, S):
+    h = [0.0] * S
+    for c in costs:
+        t = heapq.heappop(h); heapq.heappush(h, t + c)
+    return max(h)
+for a in (64.0, 256.0):
+    c = n.astype(np.float64) + a
+    for S in (512, 1024, 2048):
+        ideal = c.sum() / S
+        print(f"  overhead {a:.0f} entries/tile, {S} slots: launch order {makespan(c, S) / ideal:.3f} x ideal, longest-first {makespan(np.sort(c)[::-1], S) / ideal:.3f} x, max tile / ideal {c.max() / ideal:.3f}")
+
+if L.VS_BUF_RECT not in t: sys.exit(0)   # (the autograd path frees the transient buffers)
 rect = t[L.VS_BUF_RECT].view(torch.int16)[:Cn * P * 4].view(Cn * P, 4).cpu().numpy().astype(np.int64)
 cells = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
 vis = cells > 0

@@ -135,14 +135,47 @@ __device__ __forceinline__ void stage_tile(const unsigned short *src, int ld, in
     }
 }
 
+// ---- asynchronous staging (round 2): the 64 x 64 tiles are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, so
+// no occupancy cost -- a register-prefetch variant lost more to occupancy than it won) into a two-slot ring, the NEXT tile in flight
+// while the current one is multiplied, one barrier per tile.  The synchronous version (load -> LDS store -> barrier -> compute ->
+// barrier) spent ~3.3 us per tile and workgroup against ~0.7 us of MFMA + VALU work: latency-bound with 3-4 workgroups per CU.
+// A DMA instruction writes 1 KiB contiguous (lane l -> base + 16 l), so rows are unpadded (128 B) and the 16-byte chunk index is XOR-
+// swizzled with (row >> 1) & 7 on the GLOBAL side: the sixteen rows of a ds_read_b128 fragment read then fall into sixteen different
+// 16-byte slots of the 256-byte bank row, and the four rows of a transpose read into different windows.  Rows past the end of the
+// list are duplicates of the last row (a DMA cannot zero-fill): their scores are finite and their probabilities are forced to 0 by
+// the existing masks (L = +inf for missing queries; key >= my_len for missing keys: a tile with a missing key is never "full").
+typedef void __attribute__((address_space(3))) *lds_ptr_t;
+__device__ __forceinline__ void glds16(const void *gp, unsigned lds_off) {   // (inline asm: the compiler adds no waits of its own)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
+}
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * HD + ((chunk ^ ((row >> 1) & 7)) << 3); }   // halfs
+__device__ __forceinline__ uint2 tr_rows4_sw(const unsigned short *tile, int row0, int col0, int t) {
+    typedef tr4_t __attribute__((address_space(3))) *trp_t;
+    const int row = row0 + (t >> 2), col = col0 + (t & 3) * 4;
+    const unsigned short *p = tile + sw_off(row, col >> 3) + (col & 7);
+    const tr4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned short *>(p)));
+    return __builtin_bit_cast(uint2, v);
+}
+// 64 rows x 128 B: wave w issues pieces 2w, 2w + 1 (8 rows each); lane -> (row = piece * 8 + lane / 8, slot = lane % 8)
+template <class RowFn>
+__device__ __forceinline__ void dma_tile(const unsigned short *src, int ld, int col0, RowFn row_of, unsigned lds_base, int tid) {
+    const int w = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = w * 2 + j, row = piece * 8 + (lane >> 3), gchunk = (lane & 7) ^ ((row >> 1) & 7);
+        glds16(src + row_of(row) * ld + col0 + gchunk * 8, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)piece * 1024u));
+    }
+}
+
 // ---- dQ: workgroup = 64 queries (4 waves x 16), lane = (query c16, key group g); loops over 64-key tiles ----
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(const AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sK[TB * ROW], sV[TB * ROW];
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2][2][TB * HD];   // [ring slot][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     const KeyList kl = key_list(a, b);
     const int qi = q0 + wid * 16 + c16;
     const bool qvalid = qi < a.Lq;
@@ -160,13 +193,17 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
     f4 dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = f4{0.f, 0.f, 0.f, 0.f};
-    auto krow = [&](int j) { return kl.row(j); };
-    for (int kt = 0; kt < kl.Lk; kt += TB) {
-        __syncthreads();
-        auto rk = [&](int r) { return krow(kt + r); };
-        stage_tile<true, false>(a.k, a.ldk, h * HD, rk, kl.Lk - kt, sK, nullptr, tid);
-        stage_tile<true, false>(a.v, a.ldv, h * HD, rk, kl.Lk - kt, sV, nullptr, tid);
-        __syncthreads();
+    auto issue = [&](int kt, int slot) {
+        auto rk = [&](int r) { return kl.row(kt + r); };   // (clamped to the last key)
+        dma_tile(a.k, a.ldk, h * HD, rk, lds0 + (unsigned)(slot * 2) * (TB * HD * 2), tid);
+        dma_tile(a.v, a.ldv, h * HD, rk, lds0 + (unsigned)(slot * 2 + 1) * (TB * HD * 2), tid);
+    };
+    if (kl.Lk > 0) issue(0, 0);
+    for (int kt = 0, it = 0; kt < kl.Lk; kt += TB, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed ...
+        __syncthreads();                                     // ... and everybody's; all waves are done with the other slot
+        if (kt + TB < kl.Lk) issue(kt + TB, (it + 1) & 1);
+        const unsigned short *sK = smem[it & 1][0], *sV = smem[it & 1][1];
         const bool tile_full = __builtin_amdgcn_ballot_w64(my_len < kt + TB) == 0ull;
         uint4 dsf[2];
         f4 ds[4];
@@ -175,8 +212,8 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
             f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[(nb * 16 + c16) * ROW + ks * 32 + g * 8]);
-                const uint4 vf = *reinterpret_cast<const uint4 *>(&sV[(nb * 16 + c16) * ROW + ks * 32 + g * 8]);
+                const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[sw_off(nb * 16 + c16, ks * 4 + g)]);
+                const uint4 vf = *reinterpret_cast<const uint4 *>(&sV[sw_off(nb * 16 + c16, ks * 4 + g)]);
                 s = mfma<BF16>(kf, qf[ks], s);      // S^T[key][query]
                 dp = mfma<BF16>(vf, dof[ks], dp);   // dP^T[key][query]
             }
@@ -204,8 +241,8 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const uint2 lo = tr_rows4(sK, (2 * ks) * 16 + g * 4, db * 16, c16);        // K[keys g*4..+3 of block 2ks][d = db*16 + c16]
-                const uint2 hi = tr_rows4(sK, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 lo = tr_rows4_sw(sK, (2 * ks) * 16 + g * 4, db * 16, c16);        // K[keys g*4..+3 of block 2ks][d = db*16 + c16]
+                const uint2 hi = tr_rows4_sw(sK, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 dq[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), dsf[ks], dq[db]);   // dQ^T += K^T dS^T: lane = query, registers = 4 consecutive d
             }
     }
@@ -232,10 +269,10 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(const AttnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * ROW], sDO[TB * ROW];
-    __shared__ __attribute__((aligned(16))) float sL[TB], sD[TB];
-    __shared__ __attribute__((aligned(16))) int sLen[TB];
-    __shared__ int s_minlen;
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2][2][TB * HD];   // [ring slot][Q | dO]
+    __shared__ __attribute__((aligned(16))) float sL2[2][TB], sD2[2][TB];
+    __shared__ __attribute__((aligned(16))) int sLen2[2][TB];
+    __shared__ int s_minlen2[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
@@ -252,25 +289,46 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     f4 dk[4], dv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f4{0.f, 0.f, 0.f, 0.f};
-    for (int qt = 0; qt < a.Lq; qt += TB) {
-        __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
+    auto issue = [&](int qt, int slot) {
         auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
-        stage_tile<true, false>(a.q, a.ldq, h * HD, rq, a.Lq - qt, sQ, nullptr, tid);
-        stage_tile<true, false>(a.dout, a.lddo, h * HD, rq, a.Lq - qt, sDO, nullptr, tid);
-        if (tid < TB) {
-            const int qi = qt + tid;
-            const bool ok = qi < a.Lq;
-            const long long row = b * a.q_batch_rows + (ok ? qi : a.Lq - 1);
-            sL[tid] = ok ? a.lse[row * a.H + h] : INFINITY;
-            sD[tid] = ok ? a.delta[row * a.H + h] : 0.f;
-            const int len = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
-            sLen[tid] = len;
-            int mn = len;                             // (tid < 64 is exactly wave 0)
+        dma_tile(a.q, a.ldq, h * HD, rq, lds0 + (unsigned)(slot * 2) * (TB * HD * 2), tid);
+        dma_tile(a.dout, a.lddo, h * HD, rq, lds0 + (unsigned)(slot * 2 + 1) * (TB * HD * 2), tid);
+    };
+    // per-query scalars of a tile (wave 0): logsumexp (+inf for missing queries: p = 0), delta, key limit, and the tile's smallest limit
+    float aL = 0.f, aD = 0.f; int aN = 0;
+    auto aux_load = [&](int qt) {
+        const int qi = qt + tid;
+        const bool ok = qi < a.Lq;
+        const long long row = b * a.q_batch_rows + (ok ? qi : a.Lq - 1);
+        aL = ok ? a.lse[row * a.H + h] : INFINITY;
+        aD = ok ? a.delta[row * a.H + h] : 0.f;
+        aN = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
+    };
+    auto aux_store = [&](int slot) {   // (tid < 64 is exactly wave 0)
+        sL2[slot][tid] = aL; sD2[slot][tid] = aD; sLen2[slot][tid] = aN;
+        int mn = aN;
 #pragma unroll
-            for (int o_ = 32; o_ > 0; o_ >>= 1) mn = min(mn, __shfl_xor(mn, o_, 64));
-            if (tid == 0) s_minlen = mn;
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mn = min(mn, __shfl_xor(mn, o_, 64));
+        if (tid == 0) s_minlen2[slot] = mn;
+    };
+    if (a.Lq > 0) {
+        issue(0, 0);
+        if (tid < TB) { aux_load(0); aux_store(0); }
+    }
+    for (int qt = 0, it = 0; qt < a.Lq; qt += TB, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile qt have landed ...
+        __syncthreads();                                     // ... and everybody's (and wave 0's scalars); the other slot is free
+        const bool more = qt + TB < a.Lq;
+        if (more) {
+            issue(qt + TB, (it + 1) & 1);
+            if (tid < TB) aux_load(qt + TB);
         }
-        __syncthreads();
+        const int slot = it & 1;
+        const unsigned short *sQ = smem[slot][0], *sDO = smem[slot][1];
+        const float *sL = sL2[slot], *sD = sD2[slot];
+        const int *sLen = sLen2[slot];
+        const int s_minlen = s_minlen2[slot];
         // all 16 keys of the wave are real and visible to all 64 queries of the tile: no mask arithmetic, no per-element length reads
         const bool tile_full = kt0 + wid * 16 + 16 <= min(kl.Lk, s_minlen);
         f4 p[4], ds[4];
@@ -279,8 +337,8 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
             f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const uint4 qa = *reinterpret_cast<const uint4 *>(&sQ[(qb * 16 + c16) * ROW + ks * 32 + g * 8]);
-                const uint4 da = *reinterpret_cast<const uint4 *>(&sDO[(qb * 16 + c16) * ROW + ks * 32 + g * 8]);
+                const uint4 qa = *reinterpret_cast<const uint4 *>(&sQ[sw_off(qb * 16 + c16, ks * 4 + g)]);
+                const uint4 da = *reinterpret_cast<const uint4 *>(&sDO[sw_off(qb * 16 + c16, ks * 4 + g)]);
                 s = mfma<BF16>(qa, kf[ks], s);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
                 dp = mfma<BF16>(da, vf[ks], dp);   // dP[query][key]
             }
@@ -317,11 +375,12 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const uint2 dlo = tr_rows4(sDO, (2 * ks) * 16 + g * 4, db * 16, c16), dhi = tr_rows4(sDO, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                const uint2 qlo = tr_rows4(sQ, (2 * ks) * 16 + g * 4, db * 16, c16), qhi = tr_rows4(sQ, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 dlo = tr_rows4_sw(sDO, (2 * ks) * 16 + g * 4, db * 16, c16), dhi = tr_rows4_sw(sDO, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 qlo = tr_rows4_sw(sQ, (2 * ks) * 16 + g * 4, db * 16, c16), qhi = tr_rows4_sw(sQ, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 dv[db] = mfma<BF16>(pf[ks], make_uint4(dlo.x, dlo.y, dhi.x, dhi.y), dv[db]);
                 dk[db] = mfma<BF16>(dsf[ks], make_uint4(qlo.x, qlo.y, qhi.x, qhi.y), dk[db]);
             }
+        if (more && tid < TB) aux_store((it + 1) & 1);   // (read after the next barrier; last read two barriers ago)
     }
     // dK / dV rows key = g*4 + r (of this wave's 16), cols d = db*16 + c16
 #pragma unroll
