@@ -259,6 +259,14 @@ int vs_attention_backward(const void *q, const void *k, const void *v, const voi
                           int32_t lddk, int32_t lddv, const int32_t *kv_seg, const int32_t *q_kvlen, int32_t max_keys, float scale,
                           int32_t dtype, vs_stream_t stream);
 
+/* The same without key segments (every K/V row belongs to one batch item): dk, dv are 16-bit [key rows, lddk / lddv] and are WRITTEN
+ * (plain stores: no atomics, no zero fill, no f32 -> 16-bit cast pass afterwards), e.g. the k | v blocks of a packed [rows, 3*H*64]
+ * gradient buffer.  Reference: torch autograd of F.scaled_dot_product_attention in croco/blocks.py:106-110. */
+int vs_attention_backward16(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse, float *delta,
+                            void *dq, void *dk, void *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk, int64_t q_batch_rows,
+                            int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int32_t lddo, int32_t lddq,
+                            int32_t lddk, int32_t lddv, const int32_t *q_kvlen, float scale, int32_t dtype, vs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Encoder backward building blocks (training_step, model_wrapper.py:184-321: the reference differentiates the encoder
  * with torch autograd).  They are assembled into torch.autograd.Functions in vicasplat_amd/autograd.py and drive

@@ -813,6 +813,12 @@ def test_attention_backward_matches_autograd(dt, case):
     assert torch.isfinite(lse).all()
     for got, ref, nm in ((dq.float(), gq, "dq"), (dk, gk, "dk"), (dv, gv, "dv")):
         assert (got - ref).abs().max() <= rt * ref.abs().max(), (nm, float((got - ref).abs().max()), float(ref.abs().max()))
+    if seg is None:   # direct mode (vs_attention_backward16): dk / dv stored as 16-bit values into the k | v blocks of a packed gradient buffer
+        dqkv = torch.full((rows, 3 * C), float("nan"), dtype=dt, device=d)
+        ops.attention_backward(q2, k2, v2, out, dout, lse, dq_out=dqkv[:, :C], dk_out=dqkv[:, C:2 * C], dv_out=dqkv[:, 2 * C:], **kw)
+        assert torch.equal(dqkv[:, :C], dq)
+        for got, f32, nm in ((dqkv[:, C:2 * C], dk, "dk16"), (dqkv[:, 2 * C:], dv, "dv16")):
+            assert torch.equal(got, f32.to(dt)), nm        # one owner per row: the same sums in the same order, rounded once
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

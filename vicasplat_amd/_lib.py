@@ -102,6 +102,9 @@ def lib() -> C.CDLL:
             L.vs_attention_backward.restype = C.c_int
             L.vs_attention_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32,
                                                 i32, i32, i32, vp, vp, i32, f32, i32, vp]
+            L.vs_attention_backward16.restype = C.c_int
+            L.vs_attention_backward16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32,
+                                                  i32, i32, i32, vp, f32, i32, vp]
             L.vs_upsample2x_backward_nhwc.restype = C.c_int
             L.vs_upsample2x_backward_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
             L.vs_relu_mask16.restype = C.c_int

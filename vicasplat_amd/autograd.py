@@ -156,11 +156,16 @@ class AttentionFn(torch.autograd.Function):
         nbatch, H, Lq, Lk, qbr, kbr, kv_seg, q_kvlen, max_keys = ctx.meta
         C = H * 64
         dqkv = torch.empty((qkv.shape[0], 3 * C), dtype=qkv.dtype, device=qkv.device)   # dq lands in its block directly; dk / dv are f32
-        _, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H,
-                                           Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, kv_seg=kv_seg, q_kvlen=q_kvlen,
-                                           max_keys=max_keys, dq_out=dqkv[:, :C])
-        dqkv[:, C:2 * C] = dk                                                            # (one cast-copy each)
-        dqkv[:, 2 * C:] = dv
+        if kv_seg is None:   # every K/V row has one owner: dk / dv land in their blocks directly (no zero fill, atomics or cast pass)
+            ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H, Lq=Lq, Lk=Lk,
+                                   q_batch_rows=qbr, k_batch_rows=kbr, q_kvlen=q_kvlen, dq_out=dqkv[:, :C], dk_out=dqkv[:, C:2 * C],
+                                   dv_out=dqkv[:, 2 * C:])
+        else:
+            _, dk, dv = ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H,
+                                               Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, kv_seg=kv_seg, q_kvlen=q_kvlen,
+                                               max_keys=max_keys, dq_out=dqkv[:, :C])
+            dqkv[:, C:2 * C] = dk                                                        # (one cast-copy each)
+            dqkv[:, 2 * C:] = dv
         dqkv._vs_owned_grad = True     # fresh buffer with a single consumer: LinearFn.backward may un-rotate it in place
         return dqkv, None, None, None, None, None, None, None, None, None
 

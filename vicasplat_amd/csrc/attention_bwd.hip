@@ -40,6 +40,7 @@ struct AttnBwdArgs {
     float *delta;
     unsigned short *dq;
     float *dk, *dv;
+    unsigned short *dk16, *dv16;   // direct mode (no key segments: a K/V row has one owner): 16-bit stores, no atomics, no zero fill
     const int32_t *kv_seg, *q_kvlen;
     int nbatch, H, Lq, Lk;
     long long q_batch_rows, k_batch_rows;
@@ -388,6 +389,15 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
         const int kpos = kt0 + wid * 16 + g * 4 + r;
         if (kpos >= kl.Lk) continue;
         const long long row = kl.row(kpos);
+        if (a.dk16) {
+            unsigned short *pk = a.dk16 + row * a.lddk + h * HD + c16, *pv = a.dv16 + row * a.lddv + h * HD + c16;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                pk[db * 16] = (unsigned short)(pack2<BF16>(dk[db][r], 0.f) & 0xffffu);
+                pv[db * 16] = (unsigned short)(pack2<BF16>(dv[db][r], 0.f) & 0xffffu);
+            }
+            continue;
+        }
         float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -399,13 +409,15 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
 
 }  // namespace
 
-extern "C" int vs_attention_backward(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse,
-                                     float *delta, void *dq, float *dk, float *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
-                                     int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
-                                     int32_t lddo, int32_t lddq, int32_t lddk, int32_t lddv, const int32_t *kv_seg,
-                                     const int32_t *q_kvlen, int32_t max_keys, float scale, int32_t dtype, vs_stream_t stream_) {
+namespace {
+int attention_backward_impl(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse,
+                            float *delta, void *dq, float *dk, float *dv, void *dk16, void *dv16, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
+                            int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                            int32_t lddo, int32_t lddq, int32_t lddk, int32_t lddv, const int32_t *kv_seg,
+                            const int32_t *q_kvlen, int32_t max_keys, float scale, int32_t dtype, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK(q && k && v && o && dout && lse && delta && dq && dk && dv, "vs_attention_backward: null pointer");
+    VS_CHECK(q && k && v && o && dout && lse && delta && dq && ((dk && dv) || (dk16 && dv16)), "vs_attention_backward: null pointer");
+    VS_CHECK(!(dk16 && kv_seg), "vs_attention_backward16: key segments share K/V rows between batch items: use the f32 (atomic) entry");
     VS_CHECK(nbatch >= 0 && H > 0 && Lq >= 0, "vs_attention_backward: bad sizes");
     VS_CHECK(dtype == 1 || dtype == 2, "vs_attention_backward: dtype must be 1 (f16) or 2 (bf16)");
     VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0, "vs_attention_backward: row strides must be multiples of 8 elements");
@@ -415,7 +427,7 @@ extern "C" int vs_attention_backward(const void *q, const void *k, const void *v
     AttnBwdArgs a;
     a.q = (const unsigned short *)q; a.k = (const unsigned short *)k; a.v = (const unsigned short *)v;
     a.o = (const unsigned short *)o; a.dout = (const unsigned short *)dout; a.lse = lse; a.delta = delta;
-    a.dq = (unsigned short *)dq; a.dk = dk; a.dv = dv; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;
+    a.dq = (unsigned short *)dq; a.dk = dk; a.dv = dv; a.dk16 = (unsigned short *)dk16; a.dv16 = (unsigned short *)dv16; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;
     a.nbatch = nbatch; a.H = H; a.Lq = Lq; a.Lk = Lk; a.q_batch_rows = q_batch_rows; a.k_batch_rows = k_batch_rows;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
@@ -433,4 +445,23 @@ extern "C" int vs_attention_backward(const void *q, const void *k, const void *v
     }
     VS_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int vs_attention_backward(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse,
+                                     float *delta, void *dq, float *dk, float *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
+                                     int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                     int32_t lddo, int32_t lddq, int32_t lddk, int32_t lddv, const int32_t *kv_seg,
+                                     const int32_t *q_kvlen, int32_t max_keys, float scale, int32_t dtype, vs_stream_t stream_) {
+    return attention_backward_impl(q, k, v, o, dout, lse, delta, dq, dk, dv, nullptr, nullptr, nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, ldq, ldk, ldv,
+                                   ldo, lddo, lddq, lddk, lddv, kv_seg, q_kvlen, max_keys, scale, dtype, stream_);
+}
+
+extern "C" int vs_attention_backward16(const void *q, const void *k, const void *v, const void *o, const void *dout, const float *lse,
+                                       float *delta, void *dq, void *dk, void *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk,
+                                       int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                       int32_t lddo, int32_t lddq, int32_t lddk, int32_t lddv, const int32_t *q_kvlen, float scale,
+                                       int32_t dtype, vs_stream_t stream_) {
+    return attention_backward_impl(q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, dk, dv, nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, ldq, ldk,
+                                   ldv, ldo, lddo, lddq, lddk, lddv, nullptr, q_kvlen, 0, scale, dtype, stream_);
 }

@@ -163,9 +163,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, *,
                        nbatch: int, H: int, Lq: int, Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0,
                        kv_seg: Optional[torch.Tensor] = None, q_kvlen: Optional[torch.Tensor] = None, max_keys: int = 0,
-                       scale: float = 0.125, dq_out: Optional[torch.Tensor] = None):
+                       scale: float = 0.125, dq_out: Optional[torch.Tensor] = None, dk_out: Optional[torch.Tensor] = None,
+                       dv_out: Optional[torch.Tensor] = None):
     """Backward of `attention` (used by autograd.AttentionFn).  Returns dq (16-bit [rows, H*64]; written into dq_out, e.g. the q
-    block of a packed [rows, 3*H*64] gradient buffer, when given) and dk, dv (f32 [key rows, H*64], accumulated from zero)."""
+    block of a packed [rows, 3*H*64] gradient buffer, when given) and dk, dv (f32 [key rows, H*64], accumulated from zero).
+    Without key segments dk_out / dv_out (16-bit [key rows, H*64] views, e.g. the k | v blocks of the same packed buffer) may be
+    given: they are written directly (vs_attention_backward16: no atomics, no zero fill, no cast pass) and returned."""
     dev = L.require_device(q, k, v, out, dout, lse, kv_seg, q_kvlen)
     for t in (q, k, v, out, dout):
         assert t.dim() == 2 and t.stride(1) == 1
@@ -175,9 +178,20 @@ def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: t
     else:
         dq = dq_out
         assert dq.shape == (q.shape[0], Cc) and dq.dtype == q.dtype and dq.stride(1) == 1
+    delta = torch.empty((q.shape[0], H), dtype=torch.float32, device=dev)
+    if dk_out is not None:
+        assert kv_seg is None and dv_out is not None, "direct dk / dv need key rows with a single owner (no key segments)"
+        for t, ref in ((dk_out, k), (dv_out, v)):
+            assert t.shape == (ref.shape[0], Cc) and t.dtype == q.dtype and t.stride(1) == 1
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_attention_backward16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dq),
+                                                 L.ptr(dk_out), L.ptr(dv_out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, q.stride(0),
+                                                 k.stride(0), v.stride(0), out.stride(0), dout.stride(0), dq.stride(0), dk_out.stride(0),
+                                                 dv_out.stride(0), L.ptr(q_kvlen), scale, _DT[q.dtype], L.stream_ptr(dev))
+        L.check(rc, "vs_attention_backward16")
+        return dq, dk_out, dv_out
     dk = torch.zeros((k.shape[0], Cc), dtype=torch.float32, device=dev)
     dv = torch.zeros((v.shape[0], Cc), dtype=torch.float32, device=dev)
-    delta = torch.empty((q.shape[0], H), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = L.lib().vs_attention_backward(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dq),
                                            L.ptr(dk), L.ptr(dv), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, q.stride(0),
