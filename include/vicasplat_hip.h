@@ -81,7 +81,7 @@ enum {
     VS_BUF_GEOM = 0,      /* [C,P,12] f32: x y ext_x ext_y | conic.x conic.y conic.z opacity | r g b depth (ext = {alpha>=1/255} half extents) */
     VS_BUF_RECT = 1,      /* [C,P,4] u16 tile rectangle (min.x min.y max.x max.y) */
     VS_BUF_CLAMPED = 2,   /* [C,P] u8 bit c set => colour channel c clamped at 0 */
-    VS_BUF_TILE_RANGES = 3, /* [C,tiles,2] i32 */
+    VS_BUF_TILE_RANGES = 3, /* [C,tiles,2] i32, followed by [C*tiles] i32: the (camera, tile) ids in the launch order of the per-tile kernels (largest lists first) */
     VS_BUF_TILE_CURSOR = 4, /* [C,tiles] i32 scratch */
     VS_BUF_KEYS = 5,      /* [R] u64 (depth_bits<<32 | gaussian) */
     VS_BUF_POINT_LIST = 6, /* [R] u32 sorted Gaussian ids, per (camera,tile) segment */

@@ -55,10 +55,12 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
     __shared__ uint32_t sid[NT];
     __shared__ float sgr[NT][kG + 1];   // [entry][component], 11-float rows: block adds and the flush below both spread over the banks
     __shared__ int s_max;
-    const int c = blockIdx.y;
     const int gx = (W + kTile - 1) / kTile;
     const int tiles = gridDim.x;
-    const int tile = blockIdx.x;
+    // (camera, tile) from the forward's longest-first launch order, stored behind the ranges (raster_fwd.hip, tile_scan_kernel)
+    const int t_lin = reinterpret_cast<const int32_t *>(ranges + (size_t)gridDim.x * gridDim.y)[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
+    const int c = t_lin / tiles;
+    const int tile = t_lin - c * tiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
