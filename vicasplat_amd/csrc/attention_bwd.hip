@@ -8,7 +8,8 @@
 //                                                                                        lane = query, as in the forward)
 //   dV_j = sum_i P_ij dO_i,   dK_j = sum_i dS_ij Q_i            attn_bwd_dkv_kernel    (workgroup = 64 keys, loops query tiles;
 //                                                                                        lane = key); f32 atomics into dK / dV
-//                                                               because with key segments a K/V row serves several batch items
+//                                                               because with key segments a K/V row serves several batch items;
+//                                                               without segments 16-bit stores in place (vs_attention_backward16)
 // S and dP are recomputed in both kernels (7 instead of 5 MFMA products per (i, j) tile, no atomics on dQ).
 #include "common.h"
 
@@ -19,20 +20,11 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 64, TB = 64;
-constexpr int ROW = HD + 8;   // halfs per row-major tile row (144 B)
-constexpr int TROW = TB + 8;  // halfs per transposed tile row (stage_tile's optional transposed image; unused by the kernels now)
-
-// 4 consecutive tile ROWS of one column through the LDS transpose read (ds_read_b64_tr_b16, tools/probe/tr_read.hip): lane t of a
-// 16-lane group supplies &tile[row0 + (t >> 2)][col0 + (t & 3) * 4] and receives tile[row0 .. row0 + 3][col0 + t].  With it the
-// "k along rows" MFMA operands (dO^T, Q^T, K^T) are gathered from the ROW-MAJOR tiles: no transposed LDS images, no packing pass.
-// (ROW = 72 halfs = 144 B: the four rows of a read fall into four different 8-bank windows.)
+// LDS transpose read (ds_read_b64_tr_b16, tools/probe/tr_read.hip): lane t of a 16-lane group supplies the address of 4 consecutive
+// halfs of row (row0 + (t >> 2)) at column col0 + (t & 3) * 4 and receives tile[row0 .. row0 + 3][col0 + t].  With it the "k along
+// rows" MFMA operands (dO^T, Q^T, K^T) are gathered from the ROW-MAJOR tiles: no transposed LDS images, no packing pass (tr_rows4_sw
+// below, on the swizzled 128-byte rows the LDS-DMA staging writes).
 typedef short tr4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 tr_rows4(const unsigned short *tile, int row0, int col0, int t) {
-    typedef tr4_t __attribute__((address_space(3))) *trp_t;
-    const unsigned short *p = tile + (row0 + (t >> 2)) * ROW + col0 + (t & 3) * 4;
-    const tr4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned short *>(p)));
-    return __builtin_bit_cast(uint2, v);
-}
 
 struct AttnBwdArgs {
     const unsigned short *q, *k, *v, *o, *dout;
@@ -110,30 +102,6 @@ __device__ __forceinline__ KeyList key_list(const AttnBwdArgs &a, int b) {
     }
     kl.Lk = kl.len0 + kl.len1;
     return kl;
-}
-
-// stage 64 rows x 64 halfs: row-major image (ROW stride) and, optionally, the transposed image (TROW stride); rows >= nvalid are
-// zero.  256 threads: thread -> (row pair rp = tid & 31, 8-half chunk c = tid >> 5).
-template <bool WANT_ROWMAJOR, bool WANT_T, class RowFn>
-__device__ __forceinline__ void stage_tile(const unsigned short *src, int ld, int col0, RowFn row_of, int nvalid, unsigned short *sR,
-                                           unsigned short *sT, int tid) {
-    const int rp = tid & 31, c = tid >> 5;
-    uint4 va = make_uint4(0, 0, 0, 0), vb = va;
-    if (2 * rp < nvalid) va = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp) * ld + col0 + c * 8);
-    if (2 * rp + 1 < nvalid) vb = *reinterpret_cast<const uint4 *>(src + row_of(2 * rp + 1) * ld + col0 + c * 8);
-    if constexpr (WANT_ROWMAJOR) {
-        *reinterpret_cast<uint4 *>(&sR[(2 * rp) * ROW + c * 8]) = va;
-        *reinterpret_cast<uint4 *>(&sR[(2 * rp + 1) * ROW + c * 8]) = vb;
-    }
-    if constexpr (WANT_T) {
-        const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
-        unsigned *vt = reinterpret_cast<unsigned *>(sT);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vt[((c * 8 + 2 * i) * TROW) / 2 + rp] = (wa[i] & 0xFFFFu) | (wb[i] << 16);
-            vt[((c * 8 + 2 * i + 1) * TROW) / 2 + rp] = (wa[i] >> 16) | (wb[i] & 0xFFFF0000u);
-        }
-    }
 }
 
 // ---- asynchronous staging (round 2): the 64 x 64 tiles are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, so
