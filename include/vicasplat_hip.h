@@ -144,7 +144,33 @@ int vs_rope2d(void *tokens, const int64_t *pos, int32_t B, int32_t N, int32_t H,
  * vs_attention(_lse), vs_conv3x3_nhwc (Cin % 16 == 0) and vs_upsample2x_nhwc.  A, W, activations and EVERY output that is
  * "16-bit" for dtype 1/2 (epilogues 0, 1, the RoPE epilogue, attention / convolution / upsample outputs, residuals) are
  * float arrays then; strides stay in elements.
+ * dtype 4 = SPLIT operands (round 3) -- f32-class results at a third of the 16-bit matrix rate, the tolerance-meeting precision of
+ * the headline benchmark: activations and outputs are float arrays exactly as for dtype 3; a weight is packed once by
+ * vs_split_pack_weight into f16 (hi, lo) pairs, hi = rne16(w 2^e), lo = rne16(w 2^e - hi); the kernels convert the activation
+ * fragments the same way in registers and form every product as three v_mfma_f32_16x16x32_f16 (lo_w hi_a + hi_w lo_a + hi_w hi_a,
+ * f32 accumulate; the dropped lo lo term is 2^-22 relative).  Entry points: vs_gemm_split, vs_conv3x3_split_nhwc, and dtype 4 of
+ * vs_attention(_lse) (q | k | v | out f32; Q, K, V and P are split in the kernel).  Replaces the reference's TF32 nn.Linear /
+ * nn.Conv2d / attention matmuls (backbone_vica.py:9) with arithmetic that is at least as precise as theirs in every product.
  * ------------------------------------------------------------------------------------------------ */
+
+/* W [N, K] f32 (row stride ldw floats; K % 32 == 0) -> out [N, K] 4-byte units (row stride ldo units): per block of 32 k, 32 hi halves
+ * then 32 lo halves of w * 2^scale_exp (inside a block, 8-half chunk g holds k = {4g..4g+3, 16+4g..16+4g+3}: the order in which a lane
+ * group reads an f32 activation row).  The caller picks scale_exp so that max|w| 2^scale_exp stays below 2^15 (f16 range) and passes
+ * acc_scale = 2^-scale_exp to the product entry points. */
+int vs_split_pack_weight(const float *w, int64_t ldw, void *out, int64_t ldo, int32_t N, int32_t K, int32_t scale_exp, vs_stream_t stream);
+
+/* out = epilogue(acc_scale * (A Wp^T) + bias), A [M, K] f32, Wp from vs_split_pack_weight, out f32.  epilogue 0 / 3 store, 1 exact-erf
+ * GELU, 2 out = (resid ? resid : out) + (1 + gate) * (...), 4 packed q|k|v with RoPE (pos, kind, C, base2d, theta1d as vs_gemm_qkv_rope).
+ * Row maps / gate / strides (in floats) as vs_gemm_bias_act. */
+int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,
+                  int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t grp_in, int32_t grp_out,
+                  int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
+                  const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d, vs_stream_t stream);
+
+/* vs_conv3x3_nhwc on split operands: in / residual / out f32 NHWC, wp = packed [Cout, 9 * Cin] (tap-major, channel-minor; Cin % 32 == 0) */
+int vs_conv3x3_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *residual, float *out, int32_t Nimg,
+                          int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,
+                          vs_stream_t stream);
 
 /* y = LN(x; w, b, eps) [* (1 + scale[row / mod_rows]) + shift[row / mod_rows]].  x f32 [M,C] (row stride ldx);
  * out_dtype 0 = f32, 1 = f16, 2 = bf16 (row stride ldo); output row = (row / grp_in) * grp_out + grp_off + row % grp_in

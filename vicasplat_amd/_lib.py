@@ -75,8 +75,8 @@ def lib() -> C.CDLL:
             L = C.CDLL(_SO)
             L.vs_last_error.restype = C.c_char_p
             L.vs_abi_version.restype = C.c_int
-            if L.vs_abi_version() != 2:     # the ctypes mirrors of the structs below are for exactly this layout
-                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 2: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+            if L.vs_abi_version() != 3:     # the ctypes mirrors of the structs below are for exactly this layout
+                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 3: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
             L.vs_raster_forward.restype = C.c_int64
             L.vs_raster_forward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), AllocFn, C.c_void_p, C.c_void_p]
             L.vs_rope2d.restype = C.c_int
@@ -156,6 +156,12 @@ def lib() -> C.CDLL:
             L.vs_silu_cast.argtypes = [vp, vp, i64, i32, vp]
             L.vs_conv3x3_head1x1_nhwc.restype = C.c_int
             L.vs_conv3x3_head1x1_nhwc.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 11 + [vp]
+            L.vs_split_pack_weight.restype = C.c_int
+            L.vs_split_pack_weight.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
+            L.vs_gemm_split.restype = C.c_int
+            L.vs_gemm_split.argtypes = [vp, vp, f32, vp, vp, vp, vp] + [i32] * 15 + [vp, vp, i32, f32, f32, vp]
+            L.vs_conv3x3_split_nhwc.restype = C.c_int
+            L.vs_conv3x3_split_nhwc.argtypes = [vp, vp, f32, vp, vp, vp] + [i32] * 8 + [vp]
             L.vs_upsample2x_nhwc.restype = C.c_int
             L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             if hasattr(L, "vs_raster_backward"):

@@ -12,4 +12,4 @@ void set_error(const char *fmt, ...) {
 }  // namespace vs
 
 extern "C" const char *vs_last_error(void) { return vs::g_err; }
-extern "C" int vs_abi_version(void) { return 2; }   // 2: VsRasterIn.capacity, VS_BUF_DEPTH (round 2)
+extern "C" int vs_abi_version(void) { return 3; }   // 2: VsRasterIn.capacity, VS_BUF_DEPTH (round 2); 3: split operands (dtype 4, vs_gemm_split, ...)

@@ -461,6 +461,205 @@ __global__ void __launch_bounds__(512, 2) attention_res_kernel(const AttnArgs a)
     }
 }
 
+// ---- split-operand attention (dtype code 4; gemm_common.h, kDtSplit): q | k | v and the output are f32 arrays, every matrix product
+// is three f16 MFMAs on (hi, lo) pairs -- hi = rne16(x), lo = rne16(x - hi) -- with f32 accumulation: f32-class results at a third of
+// the 16-bit matrix rate instead of the 1/16 of the exact-f32 MFMA.  Same structure, masks and segments as attention_kernel: the K / V
+// tiles are converted once when they are staged (two LDS images each), Q when it is loaded, P in registers after the exponentials. ----
+struct AttnArgsSplit {
+    const float *q, *k, *v;
+    float *out;
+    const int32_t *kv_seg, *q_kvlen;
+    int nbatch, H, Lq, Lk;
+    long long q_batch_rows, k_batch_rows;
+    int ldq, ldk, ldv, ldo;
+    float scale_log2e;
+    float *lse;
+};
+
+__device__ __forceinline__ unsigned cvt_pk_f16s(float a, float b) { return pack2<false>(a, b); }
+// 8 floats -> 8 hi halves + 8 lo halves (in order); x - float(hi) on v_fma_mix_f32 (f16 source operand, exact f32 result)
+__device__ __forceinline__ void split8s(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        h[p] = cvt_pk_f16s(x[2 * p], x[2 * p + 1]);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h[p]), "v"(x[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h[p]), "v"(x[2 * p + 1]));
+        l[p] = cvt_pk_f16s(r0, r1);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// c += b a over (hi, lo) pairs: lo_b hi_a + hi_b lo_a + hi_b hi_a
+__device__ __forceinline__ f4 mma3(const uint4 &bh, const uint4 &bl, const uint4 &ah, const uint4 &al, f4 c) {
+    c = mfma<false>(bl, ah, c);
+    c = mfma<false>(bh, al, c);
+    return mfma<false>(bh, ah, c);
+}
+
+template <int QG>
+__global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsSplit a) {
+    constexpr int QBLK = 64 * QG;
+    __shared__ __attribute__((aligned(16))) unsigned short sKh2[2][KB * KROW], sKl2[2][KB * KROW];   // two-tile ring, hi / lo images
+    __shared__ __attribute__((aligned(16))) unsigned short sVh2[2][KB * KROW], sVl2[2][KB * KROW];
+    __shared__ int s_maxlen;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QBLK;
+
+    int base0, len0, base1, len1;
+    if (a.kv_seg) {
+        base0 = a.kv_seg[4 * b + 0]; len0 = a.kv_seg[4 * b + 1]; base1 = a.kv_seg[4 * b + 2]; len1 = a.kv_seg[4 * b + 3];
+    } else {
+        base0 = (int)(b * a.k_batch_rows); len0 = a.Lk; base1 = 0; len1 = 0;
+    }
+    const int Lk = len0 + len1;
+
+    int my_len[QG];
+    uint4 qh[QG][2], ql[QG][2];
+    int wave_len = 0;
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int qi = q0 + (wid * QG + u) * 16 + c16;
+        const bool qvalid = qi < a.Lq;
+        const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+        int ml = Lk;
+        if (a.q_kvlen && qvalid) ml = min(Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+        if (!qvalid) ml = 0;
+        my_len[u] = ml;
+        wave_len = max(wave_len, ml);
+        const float *qp = a.q + qrow * a.ldq + h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            split8s(*reinterpret_cast<const float4 *>(qp + ks * 32), *reinterpret_cast<const float4 *>(qp + ks * 32 + 4), qh[u][ks], ql[u][ks]);
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) wave_len = max(wave_len, __shfl_xor(wave_len, o_, 64));
+    int wave_minlen[QG];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        int mn = my_len[u];
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mn = min(mn, __shfl_xor(mn, o_, 64));
+        wave_minlen[u] = mn;
+    }
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_maxlen, wave_len);
+    __syncthreads();
+    const int maxlen = s_maxlen;
+
+    f4 o[QG][4];
+    float m_run[QG], l_run[QG];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        m_run[u] = -INFINITY; l_run[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int k_key = tid >> 2, k_chunk = (tid & 3) * 16;  // staging: one key row, 16 floats of K and of V per thread
+    auto key_row = [&](int j) -> long long {
+        j = min(j, Lk - 1);
+        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
+    };
+    float4 pk[4], pv[4];  // register prefetch of the NEXT tile
+    auto gload = [&](int kt) {
+        const long long r = key_row(kt + k_key);
+        const float *kp = a.k + r * a.ldk + h * HD + k_chunk, *vp = a.v + r * a.ldv + h * HD + k_chunk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pk[i] = *reinterpret_cast<const float4 *>(kp + 4 * i); pv[i] = *reinterpret_cast<const float4 *>(vp + 4 * i); }
+    };
+    auto lds_store = [&](int buf) {
+        uint4 h0, l0, h1, l1;
+        split8s(pk[0], pk[1], h0, l0); split8s(pk[2], pk[3], h1, l1);
+        *reinterpret_cast<uint4 *>(&sKh2[buf][k_key * KROW + k_chunk]) = h0; *reinterpret_cast<uint4 *>(&sKh2[buf][k_key * KROW + k_chunk + 8]) = h1;
+        *reinterpret_cast<uint4 *>(&sKl2[buf][k_key * KROW + k_chunk]) = l0; *reinterpret_cast<uint4 *>(&sKl2[buf][k_key * KROW + k_chunk + 8]) = l1;
+        split8s(pv[0], pv[1], h0, l0); split8s(pv[2], pv[3], h1, l1);
+        *reinterpret_cast<uint4 *>(&sVh2[buf][k_key * KROW + k_chunk]) = h0; *reinterpret_cast<uint4 *>(&sVh2[buf][k_key * KROW + k_chunk + 8]) = h1;
+        *reinterpret_cast<uint4 *>(&sVl2[buf][k_key * KROW + k_chunk]) = l0; *reinterpret_cast<uint4 *>(&sVl2[buf][k_key * KROW + k_chunk + 8]) = l1;
+    };
+    if (maxlen > 0) {
+        gload(0);
+        lds_store(0);
+        if (KB < maxlen) gload(KB);
+    }
+    __syncthreads();
+
+    for (int kt = 0, it = 0; kt < maxlen; kt += KB, ++it) {
+        const unsigned short *sKh = sKh2[it & 1], *sKl = sKl2[it & 1], *sVh = sVh2[it & 1], *sVl = sVl2[it & 1];
+        if (kt + KB < maxlen) {
+            lds_store((it + 1) & 1);
+            if (kt + 2 * KB < maxlen) gload(kt + 2 * KB);
+        }
+        if (kt >= wave_len) { __syncthreads(); continue; }
+        uint4 pfh[QG][2], pfl[QG][2];
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            f4 st[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                st[nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = (nb * 16 + c16) * KROW + ks * 32 + g * 8;
+                    st[nb] = mma3(*reinterpret_cast<const uint4 *>(&sKh[off]), *reinterpret_cast<const uint4 *>(&sKl[off]), qh[u][ks], ql[u][ks], st[nb]);
+                }
+            }
+            if (kt + KB > wave_minlen[u]) {
+                const int lim = my_len[u] - kt - g * 4;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb * 16 + r >= lim) st[nb][r] = -INFINITY;
+            }
+            softmax_tile<false>(st, a.scale_log2e, m_run[u], l_run[u], o[u], pfh[u]);   // st now holds P (f32), pfh its rne16
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned hh[4] = {pfh[u][ks].x, pfh[u][ks].y, pfh[u][ks].z, pfh[u][ks].w};
+                unsigned ll[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float p0 = st[2 * ks + (w >> 1)][(w & 1) * 2], p1 = st[2 * ks + (w >> 1)][(w & 1) * 2 + 1];
+                    float r0, r1;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh[w]), "v"(p0));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh[w]), "v"(p1));
+                    ll[w] = cvt_pk_f16s(r0, r1);
+                }
+                pfl[u][ks] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint2 h0 = v_rows4(sVh, (2 * ks) * 16 + g * 4, db * 16, c16), h1 = v_rows4(sVh, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 l0 = v_rows4(sVl, (2 * ks) * 16 + g * 4, db * 16, c16), l1 = v_rows4(sVl, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+#pragma unroll
+                for (int u = 0; u < QG; ++u) o[u][db] = mma3(vh, vl, pfh[u][ks], pfl[u][ks], o[u][db]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O^T: query = this lane's c16, d = db*16 + g*4 + r -> one 16-byte f32 store per (query, db) ----
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int qo = q0 + (wid * QG + u) * 16 + c16;
+        if (qo >= a.Lq) continue;
+        const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
+        float *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + g * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+            *reinterpret_cast<float4 *>(op + db * 16) = make_float4(o[u][db][0] * inv, o[u][db][1] * inv, o[u][db][2] * inv, o[u][db][3] * inv);
+        if (a.lse && g == 0) a.lse[(b * a.q_batch_rows + qo) * a.H + h] = l_run[u] > 0.f ? m_run[u] + log2f(l_run[u]) : -INFINITY;
+    }
+}
+
 }  // namespace
 
 // ---- reference-precision attention (f32 q | k | v and output, exact f32 MFMA v_mfma_f32_16x16x4_f32; DESIGN 2 "f32 path") ----
@@ -627,9 +826,24 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
     VS_CHECK(kv_seg || Lk > 0, "vs_attention: Lk must be positive when kv_seg is null");
     VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "vs_attention: row strides must be multiples of 8 elements");
     VS_CHECK(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "vs_attention: 16-byte alignment required");
-    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_attention: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "vs_attention: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split: f32 data, 3 x f16 MFMA)");
     VS_CHECK(H <= 65535 && nbatch <= 65535, "vs_attention: grid too large");
     if (nbatch == 0 || Lq == 0) return 0;
+    if (dtype == 4) {
+        VS_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, "vs_attention: split operands need 16-byte aligned f32 rows");
+        AttnArgsSplit f;
+        f.q = (const float *)q; f.k = (const float *)k; f.v = (const float *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;
+        f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
+        f.ldq = ldq; f.ldk = ldk; f.ldv = ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse;
+        const int Lk_eff = kv_seg ? 2 * Lk : Lk;
+        static const int force_qg4 = [] { const char *e = getenv("VS_ATTN_SPLIT_QG"); return e ? atoi(e) : 0; }();
+        bool big = (long long)vs::cdiv(Lq, 128) * H * nbatch >= 512 && Lk_eff > 256;
+        if (force_qg4) big = force_qg4 == 2;
+        if (big) hipLaunchKernelGGL((attention_split_kernel<2>), dim3(vs::cdiv(Lq, 128), H, nbatch), dim3(256), 0, stream, f);
+        else hipLaunchKernelGGL((attention_split_kernel<1>), dim3(vs::cdiv(Lq, 64), H, nbatch), dim3(256), 0, stream, f);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
     if (dtype == 3) {
         AttnArgsF32 f;
         f.q = (const float *)q; f.k = (const float *)k; f.v = (const float *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;

@@ -32,6 +32,7 @@ struct ConvArgs {
     const float *bias2;
     unsigned short *out2;
     int C2, C2pad, ld2;
+    float acc_scale;            // split operands: 2^-e of the packed weights (gemm_common.h, kDtSplit)
 };
 
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
@@ -40,6 +41,12 @@ struct ConvArgs {
 template <int BF16, int MI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int mw0, int nbase, int M, void *, int, int lane) {
     const int mrow = lane & 15, c4 = (lane >> 4) * 4;
+    if constexpr (BF16 == kDtSplit) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= g.acc_scale;
+    }
     float bv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -53,7 +60,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
     // interior wave tile, 16-bit output: 16-byte stores -- row fragments in pairs, v_permlane16_swap gives an even-row lane 8 consecutive
     // columns of fragment i and an odd-row lane 8 consecutive columns of fragment i + 1 (as in gemm_epilogue: the tile's store tail is
     // issue-bound, 8-byte stores cost twice the instructions)
-    if constexpr (BF16 != kDtF32 && MI % 2 == 0) {
+    if constexpr (!is_f32io(BF16) && MI % 2 == 0) {
         if (vec_ok && g.Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0 && mw0 + 16 * MI <= M) {
             constexpr int D16 = BF16;
             typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
@@ -111,7 +118,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-            if constexpr (BF16 == kDtF32) {   // f32 activations: residual / output are float arrays with the same element indices
+            if constexpr (is_f32io(BF16)) {   // f32 activations: residual / output are float arrays with the same element indices
                 const float *res32 = reinterpret_cast<const float *>(g.res);
                 float *out32 = reinterpret_cast<float *>(g.out);
 #pragma unroll
@@ -134,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                 }
                 continue;
             }
-            constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;
+            constexpr int D16 = is_f32io(BF16) ? 0 : BF16;
             if (vec_ok) {
                 if (g.res) {
                     const uint2 rv = *reinterpret_cast<const uint2 *>(g.res + o + j * 16);
@@ -415,9 +422,10 @@ __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&a
 }
 
 template <int BF16, int MI, bool FUSE_DOT = false>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
+__global__ void __launch_bounds__(256, (MI == 8 || BF16 == kDtSplit) ? 2 : 3) conv3x3_kernel(const ConvArgs g) {
     constexpr int BM = 32 * MI;
-    constexpr int NS = 3;
+    constexpr bool SPLIT = BF16 == kDtSplit;
+    constexpr int NS = SPLIT ? 4 : 3;
     constexpr int GL = MI / 2 + 2;
     // same 3-stage LDS ring / counted-vmcnt pipeline as gemm.hip (32-channel stages: one tap x 32 input channels)
     __shared__ __attribute__((aligned(1024))) unsigned short smem[NS * (BM + BN) * 32];
@@ -515,12 +523,51 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) conv3x3_kernel(const Con
             _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fb[j], fa, acc[i][j]);     \
         }                                                                                                   \
     }
-    VS_STAGE(0)
-    if (nk > 1) VS_STAGE(1)
-    for (int kt = 0; kt < nk; kt += 3) {
-        VS_STEP(kt, 0, 2)
-        if (kt + 1 < nk) VS_STEP(kt + 1, 1, 0)
-        if (kt + 2 < nk) VS_STEP(kt + 2, 2, 1)
+    if constexpr (SPLIT) {
+        // split operands: stages in pairs = one 128-byte block of 32 input channels (f32 activations: floats 0..15 / 16..31; packed
+        // weights: hi / lo halves), two pairs of ring slots, one barrier per pair (as gemm_kernel)
+        const int np = nk >> 1;
+        VS_STAGE(0)
+        VS_STAGE(1)
+        for (int p = 0; p < np; ++p) {
+            const int s0 = (p & 1) * 2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + 1 < np) {
+                VS_STAGE(s0 ^ 2)
+                VS_STAGE((s0 ^ 2) + 1)
+            }
+            const unsigned short *cA0 = sA + s0 * (BM * 32), *cA1 = cA0 + BM * 32, *cW0 = sW + s0 * (BN * 32), *cW1 = cW0 + BN * 32;
+            uint4 fbh[4], fbl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb_ = wc * 64 + j * 16 + frow;
+                fbh[j] = *reinterpret_cast<const uint4 *>(&cW0[rb_ * 32 + ((fg ^ swz4(rb_)) << 3)]);
+                fbl[j] = *reinterpret_cast<const uint4 *>(&cW1[rb_ * 32 + ((fg ^ swz4(rb_)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ra_ = wr * (16 * MI) + i * 16 + frow;
+                uint4 fa0 = *reinterpret_cast<const uint4 *>(&cA0[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);
+                uint4 fa1 = *reinterpret_cast<const uint4 *>(&cA1[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);
+                if (g.relu_in) {
+                    fa0.x = relu_reg<BF16>(fa0.x); fa0.y = relu_reg<BF16>(fa0.y); fa0.z = relu_reg<BF16>(fa0.z); fa0.w = relu_reg<BF16>(fa0.w);
+                    fa1.x = relu_reg<BF16>(fa1.x); fa1.y = relu_reg<BF16>(fa1.y); fa1.z = relu_reg<BF16>(fa1.z); fa1.w = relu_reg<BF16>(fa1.w);
+                }
+                split8(fa0, fa1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma2<BF16>(fbh[j], fbl[j], fa0, fa1, acc[i][j]);
+            }
+        }
+    } else {
+        VS_STAGE(0)
+        if (nk > 1) VS_STAGE(1)
+        for (int kt = 0; kt < nk; kt += 3) {
+            VS_STEP(kt, 0, 2)
+            if (kt + 1 < nk) VS_STEP(kt + 1, 1, 0)
+            if (kt + 2 < nk) VS_STEP(kt + 2, 2, 1)
+        }
     }
 #undef VS_STEP
 #undef VS_STAGE
@@ -692,15 +739,15 @@ upsample2x_backward_kernel(const unsigned short *__restrict__ dout, unsigned sho
 
 }  // namespace
 
-extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg,
-                               int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,
-                               int32_t dtype, vs_stream_t stream_) {
+static int conv3x3_entry(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg,
+                         int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,
+                         int32_t dtype, float acc_scale, vs_stream_t stream_) {
     const int H = (Hin - 1) / (stride > 0 ? stride : 1) + 1, W = (Win - 1) / (stride > 0 ? stride : 1) + 1;  // k=3, pad=1
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && w && out, "vs_conv3x3_nhwc: null pointer");
     VS_CHECK(Nimg >= 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2), "vs_conv3x3_nhwc: bad sizes");
-    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_conv3x3_nhwc: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
-    if (dtype == 3) {   // f32 activations / weights: the kernels address them in 2-byte units (gemm_common.h, kDtF32)
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "vs_conv3x3_nhwc: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split)");
+    if (dtype == 3 || dtype == 4) {   // f32 activations (and f32 / packed-split weights): the kernels address them in 2-byte units (gemm_common.h)
         VS_CHECK(Cin % 16 == 0, "vs_conv3x3_nhwc: Cin=%d must be a multiple of 16 for f32 (pad the channels)", Cin);
         Cin *= 2;
     }
@@ -710,7 +757,7 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
     if (Nimg == 0) return 0;
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
-               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0};
+               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale};
     const long long M = (long long)Nimg * H * W;
     static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
     int cshift = -1;
@@ -719,7 +766,10 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     const long long t256 = vs::cdiv64(M, 256) * vs::cdiv(Cout, 256);
     if (force != 8 && force != 4 && cshift >= 0 && Cout % 256 == 0 && (9 * Cin / 64) % 2 == 0 && t256 >= 224) {
         dim3 grid((unsigned)t256), block(512);
-        if (dtype == 3) {
+        if (dtype == 4) {
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, true>), grid, block, 0, stream, g, cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false>), grid, block, 0, stream, g, cshift);
+        } else if (dtype == 3) {
             if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, true>), grid, block, 0, stream, g, cshift);
             else hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, false>), grid, block, 0, stream, g, cshift);
         } else if (dtype == 2) {
@@ -733,7 +783,11 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
         return 0;
     }
     const long long big = vs::cdiv64(M, 256) * vs::cdiv(Cout, BN);
-    if (dtype == 3) {
+    if (dtype == 4) {
+        VS_CHECK(Cin % 64 == 0, "vs_conv3x3_split_nhwc: Cin must be a multiple of 32");
+        if (big >= 512) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8>), dim3((unsigned)big), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
+    } else if (dtype == 3) {
         hipLaunchKernelGGL((conv3x3_kernel<kDtF32, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
     } else if ((big >= 256 || force == 8) && force != 4) {
         dim3 grid((unsigned)big);
@@ -746,6 +800,22 @@ extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias,
     }
     VS_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int vs_conv3x3_nhwc(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg,
+                               int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,
+                               int32_t dtype, vs_stream_t stream_) {
+    VS_CHECK(dtype != 4, "vs_conv3x3_nhwc: split operands go through vs_conv3x3_split_nhwc (they need the weights' scale)");
+    return conv3x3_entry(in, w, bias, residual, out, Nimg, Hin, Win, Cin, Cout, stride, relu_in, relu_out, dtype, 1.f, stream_);
+}
+
+// 3x3 convolution on split operands (gemm_common.h, kDtSplit): in / residual / out f32 NHWC, wp = vs_split_pack_weight image of the
+// [Cout, 9 * Cin] f32 weight (tap-major, channel-minor; Cin a multiple of 32), acc_scale = 2^-scale_exp.  Otherwise as vs_conv3x3_nhwc.
+extern "C" int vs_conv3x3_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *residual, float *out,
+                                     int32_t Nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in,
+                                     int32_t relu_out, vs_stream_t stream_) {
+    VS_CHECK(acc_scale > 0.f && Cin % 32 == 0, "vs_conv3x3_split_nhwc: acc_scale must be positive and Cin a multiple of 32");
+    return conv3x3_entry(in, wp, bias, residual, out, Nimg, Hin, Win, Cin, Cout, stride, relu_in, relu_out, 4, acc_scale, stream_);
 }
 
 /* out2[pixel, 0..C2) = W2 relu_out(conv3x3(in) + bias) + bias2 in ONE kernel (the 3x3 result stays on chip): the last two layers of
@@ -765,7 +835,7 @@ extern "C" int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const floa
              ((uintptr_t)bias2 & 15) == 0, "vs_conv3x3_head1x1_nhwc: alignment");
     VS_CHECK(relu_out == 0 || relu_out == 1, "vs_conv3x3_head1x1_nhwc: relu_out must be 0 or 1");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, nullptr, nullptr, Nimg, H, W, Cin, Cout, relu_in, relu_out, H, W, 1,
-               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2pad, ld2};
+               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2pad, ld2, 1.f};
     if (Cout == 256) {
         int cshift = -1;
         for (int sft = 0; sft < 4; ++sft)

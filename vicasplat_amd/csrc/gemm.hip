@@ -27,7 +27,7 @@
 namespace {
 
 template <int BF16, int EPI, int MI>
-__global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmArgs g_in) {
+__global__ void __launch_bounds__(256, (MI == 8 || BF16 == kDtSplit) ? 2 : 3) gemm_kernel(const GemmArgs g_in) {
     GemmArgs g = g_in;
     int ksp = (EPI == 2 && g.ksplit > 1) ? (int)blockIdx.y : 0;  // split-K slice (tail launches of the f32 residual epilogue)
     int tap = -1, lin_tile = -1;
@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
         g.ksplit = -1;
     }
     constexpr int BM = 32 * MI;
-    constexpr int NS = 3;                       // LDS ring depth
+    constexpr bool SPLIT = BF16 == kDtSplit;
+    constexpr int NS = SPLIT ? 4 : 3;           // LDS ring depth (split operands: two PAIRS of stages, see below)
     constexpr int GL = MI / 2 + 2;              // global_load_lds per wave per stage (A: BM/16/4, W: 128/16/4)
     // K is consumed in 32-wide stages through a 3-deep LDS ring filled by global_load_lds_dwordx4 (LDS address = wave-uniform
     // base + lane*16, so every stage is lane-linear: rows of 64 B, chunk index XOR-swizzled on the GLOBAL source address and
@@ -149,12 +150,48 @@ __global__ void __launch_bounds__(256, MI == 8 ? 2 : 3) gemm_kernel(const GemmAr
             _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma<BF16>(fb[j], fa, acc[i][j]);     \
         }                                                                                                   \
     }
-    VS_STAGE(0, 0)
-    if (nk > 1) VS_STAGE(1, 1)
-    for (int kt = 0; kt < nk; kt += 3) {
-        VS_STEP(kt, 0, 2)
-        if (kt + 1 < nk) VS_STEP(kt + 1, 1, 0)
-        if (kt + 2 < nk) VS_STEP(kt + 2, 2, 1)
+    if constexpr (SPLIT) {
+        // split operands: stages are consumed in PAIRS (2p, 2p + 1) = the two 64-byte halves of a 128-byte block of 32 k -- floats 0..15 /
+        // 16..31 of an f32 A row, hi / lo halves of a packed W row -- double-buffered as two pairs of ring slots.  One barrier per pair:
+        // pair p has landed (its loads are the only ones outstanding) and every wave is done with pair p - 1, whose slots take pair p + 1.
+        const int np = nk >> 1;
+        VS_STAGE(0, 0)
+        VS_STAGE(1, 1)
+        for (int p = 0; p < np; ++p) {
+            const int s0 = (p & 1) * 2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + 1 < np) {
+                VS_STAGE(2 * p + 2, s0 ^ 2)
+                VS_STAGE(2 * p + 3, (s0 ^ 2) + 1)
+            }
+            const unsigned short *cA0 = sA + s0 * (BM * 32), *cA1 = cA0 + BM * 32, *cW0 = sW + s0 * (BN * 32), *cW1 = cW0 + BN * 32;
+            uint4 fbh[4], fbl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb_ = wc * 64 + j * 16 + frow;
+                fbh[j] = *reinterpret_cast<const uint4 *>(&cW0[rb_ * 32 + ((fg ^ swz4(rb_)) << 3)]);
+                fbl[j] = *reinterpret_cast<const uint4 *>(&cW1[rb_ * 32 + ((fg ^ swz4(rb_)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ra_ = wr * (16 * MI) + i * 16 + frow;
+                uint4 fa0 = *reinterpret_cast<const uint4 *>(&cA0[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);
+                uint4 fa1 = *reinterpret_cast<const uint4 *>(&cA1[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);
+                split8(fa0, fa1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma2<BF16>(fbh[j], fbl[j], fa0, fa1, acc[i][j]);
+            }
+        }
+    } else {
+        VS_STAGE(0, 0)
+        if (nk > 1) VS_STAGE(1, 1)
+        for (int kt = 0; kt < nk; kt += 3) {
+            VS_STEP(kt, 0, 2)
+            if (kt + 1 < nk) VS_STEP(kt + 1, 1, 0)
+            if (kt + 2 < nk) VS_STEP(kt + 2, 2, 1)
+        }
     }
 #undef VS_STEP
 #undef VS_STAGE
@@ -187,7 +224,44 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
     f4 acc[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
-    const int ksteps = g.K / 32;
+    if constexpr (BF16 == kDtSplit) {
+        // split operands: k-steps in pairs = one 128-byte block of 32 k (f32 A: floats 4 fg.. and 16 + 4 fg..; packed W: hi / lo chunk fg)
+        const int kpairs = g.K / 64;
+        const int per = (kpairs + NW - 1) / NW;
+        const int kp0 = wid * per, kp1 = min(kp0 + per, kpairs);
+        constexpr int U = MF == 4 ? 2 : 4;
+        int kp = kp0;
+        for (; kp + U <= kp1; kp += U) {
+            uint4 fb[U][2], fa[U][MF][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                fb[u][0] = *reinterpret_cast<const uint4 *>(pw + (kp + u) * 64);
+                fb[u][1] = *reinterpret_cast<const uint4 *>(pw + (kp + u) * 64 + 32);
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    fa[u][i][0] = *reinterpret_cast<const uint4 *>(pa[i] + (kp + u) * 64);
+                    fa[u][i][1] = *reinterpret_cast<const uint4 *>(pa[i] + (kp + u) * 64 + 32);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    split8(fa[u][i][0], fa[u][i][1]);
+                    acc[i] = mma2<BF16>(fa[u][i][0], fa[u][i][1], fb[u][0], fb[u][1], acc[i]);
+                }
+        }
+        for (; kp < kp1; ++kp) {
+            const uint4 fb0 = *reinterpret_cast<const uint4 *>(pw + kp * 64), fb1 = *reinterpret_cast<const uint4 *>(pw + kp * 64 + 32);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                uint4 fa0 = *reinterpret_cast<const uint4 *>(pa[i] + kp * 64), fa1 = *reinterpret_cast<const uint4 *>(pa[i] + kp * 64 + 32);
+                split8(fa0, fa1);
+                acc[i] = mma2<BF16>(fa0, fa1, fb0, fb1, acc[i]);
+            }
+        }
+    }
+    const int ksteps = BF16 == kDtSplit ? 0 : g.K / 32;
     const int per = (ksteps + NW - 1) / NW;
     const int ks0 = wid * per, ks1 = min(ks0 + per, ksteps);
     constexpr int U = MF == 4 ? 4 : 8;  // k-steps per batch: (MF + 1) * U 16-byte loads in flight per lane
@@ -222,13 +296,15 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
     for (int e = tid; e < MF * 256; e += 64 * NW) {
         const int i = e >> 8, rc = e & 255, m = g.m_lo + i * 16 + (rc >> 4), n = n0 + (rc & 15);
         if (m >= g.M || n >= g.N) continue;
-        float v = g.bias ? g.bias[n] : 0.0f;
+        float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][i][rc];
+        if constexpr (BF16 == kDtSplit) v *= g.acc_scale;
+        if (g.bias) v += g.bias[n];
         const size_t orow = (size_t)(m / g.grp_in) * g.grp_out + g.grp_off + (m % g.grp_in);
-        if constexpr (EPI == 0 && BF16 != kDtF32) {
+        if constexpr (EPI == 0 && !is_f32io(BF16)) {
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
-        } else if constexpr (EPI == 1 && BF16 != kDtF32) {
+        } else if constexpr (EPI == 1 && !is_f32io(BF16)) {
             v = gelu_poly(v);
             reinterpret_cast<unsigned short *>(g.out)[orow * g.ldo + n] = to16<BF16>(v);
         } else if constexpr (EPI == 1) {     // f32 operands: GELU, f32 store
@@ -378,6 +454,17 @@ int launch_f32(const GemmArgs &g, int epi, hipStream_t stream) {
     return launch_mi<kDtF32, 4>(g, epi, stream);
 }
 
+// split operands (kDtSplit): same routing as the f32 class -- K counts 2-byte units of the f32 A rows, a multiple of 64 (32 k)
+int launch_split(const GemmArgs &g, int epi, hipStream_t stream) {
+    if (g.M <= 64 && epi != 4) return launch_smallm<kDtSplit>(g, epi, stream);
+    if (g.K % 128 == 0) {
+        // 256 x 256 tiles unless they would leave most of the chip idle (few tiles) -- then 128 x 128
+        const long long t256 = (long long)vs::cdiv(g.M, 256) * vs::cdiv(g.N, 256);
+        if (t256 >= 128) return launch_256<kDtSplit>(g, epi, stream);
+    }
+    return launch_mi<kDtSplit, 4>(g, epi, stream);
+}
+
 template <int BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
@@ -503,11 +590,12 @@ namespace {
 int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, void *out, const float *gate, const float *resid, int32_t M, int32_t N,
                int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype, int32_t grp_in, int32_t grp_out,
                int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
-               const int32_t *rope_pos, const uint8_t *rope_kind, int32_t rope_C, float base2d, float theta1d, hipStream_t stream) {
+               const int32_t *rope_pos, const uint8_t *rope_kind, int32_t rope_C, float base2d, float theta1d, hipStream_t stream,
+               float acc_scale = 1.f) {
     VS_CHECK(A && W && out, "%s: null pointer", fn);
     VS_CHECK(M >= 0 && N > 0 && K > 0, "%s: bad sizes M=%d N=%d K=%d", fn, M, N, K);
-    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "%s: dtype must be 1 (f16), 2 (bf16) or 3 (f32)", fn);
-    if (dtype == 3) {   // f32 operands are addressed in 2-byte units by the kernels (gemm_common.h, kDtF32): K, lda, ldw double
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "%s: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split)", fn);
+    if (dtype == 3 || dtype == 4) {   // f32 operands are addressed in 2-byte units by the kernels (gemm_common.h, kDtF32 / kDtSplit): K, lda, ldw double
         VS_CHECK(K % 32 == 0, "%s: K=%d must be a multiple of 32 for f32 operands", fn, K);
         VS_CHECK(lda % 4 == 0 && ldw % 4 == 0, "%s: lda/ldw must be multiples of 4 floats (16-byte rows)", fn);
         K *= 2; lda *= 2; ldw *= 2;
@@ -534,7 +622,9 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     { static const int stg = [] { const char *e = getenv("VS_GEMM_STAGGER"); return e ? atoi(e) : 0; }(); g.stagger = stg; }
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
-    const int rc = dtype == 3 ? launch_f32(g, epilogue, stream) : dtype == 2 ? launch<1>(g, epilogue, stream) : launch<0>(g, epilogue, stream);
+    g.acc_scale = acc_scale;
+    const int rc = dtype == 4 ? launch_split(g, epilogue, stream)
+                 : dtype == 3 ? launch_f32(g, epilogue, stream) : dtype == 2 ? launch<1>(g, epilogue, stream) : launch<0>(g, epilogue, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;
@@ -574,6 +664,64 @@ extern "C" int vs_gemm_qkv_rope(const void *A, const void *W, const float *bias,
                       a_grp_in, a_grp_out, a_grp_off, pos, kind, C, base2d, theta1d, (hipStream_t)stream_);
 }
 
+// ---- split operands (dtype code 4; gemm_common.h, kDtSplit): f32-class GEMM at a third of the 16-bit matrix rate ----
+// W [N, K] f32 (row stride ldw floats, K a multiple of 32) -> packed [N, K] 4-byte units: per block of 32 k, 32 halves hi then 32 halves
+// lo of w * 2^scale_exp, hi = rne16, lo = rne16(w 2^e - hi); inside a block chunk g (8 halves) holds k = {4g..4g+3, 16+4g..16+4g+3}.
+namespace {
+__global__ void __launch_bounds__(256) split_pack_kernel(const float *__restrict__ w, long long ldw, unsigned short *__restrict__ out, long long ldo,
+                                                         int N, int K, float scale) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;       // one thread per (row, 4 consecutive k)
+    const int kq = K / 4;
+    if (idx >= (long long)N * kq) return;
+    const int n = (int)(idx / kq), k4 = (int)(idx - (long long)n * kq) * 4;
+    const float4 v = *reinterpret_cast<const float4 *>(w + n * ldw + k4);
+    const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const _Float16 hh = (_Float16)x[r];
+        const _Float16 ll = (_Float16)(x[r] - (float)hh);
+        h[r] = __builtin_bit_cast(unsigned short, hh);
+        l[r] = __builtin_bit_cast(unsigned short, ll);
+    }
+    const int blk = k4 >> 5, kk = k4 & 31;                                  // kk in {0, 4, .., 28}
+    const int g = (kk & 15) >> 2, pos = g * 8 + (kk >= 16 ? 4 : 0);         // chunk g, first / second half of the chunk
+    unsigned short *o = out + n * ldo + blk * 64 + pos;
+    *reinterpret_cast<uint2 *>(o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2 *>(o + 32) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+}
+}  // namespace
+
+extern "C" int vs_split_pack_weight(const float *w, int64_t ldw, void *out, int64_t ldo, int32_t N, int32_t K, int32_t scale_exp,
+                                    vs_stream_t stream_) {
+    VS_CHECK(w && out, "vs_split_pack_weight: null pointer");
+    VS_CHECK(N > 0 && K > 0 && K % 32 == 0 && ldw % 4 == 0 && ldo % 4 == 0, "vs_split_pack_weight: K must be a multiple of 32, row strides of 4 (N=%d K=%d)", N, K);
+    VS_CHECK((((uintptr_t)w | (uintptr_t)out) & 15) == 0, "vs_split_pack_weight: 16-byte alignment required");
+    VS_CHECK(scale_exp >= -30 && scale_exp <= 30, "vs_split_pack_weight: scale_exp out of range");
+    const long long items = (long long)N * (K / 4);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w, (long long)ldw,
+                       (unsigned short *)out, 2LL * ldo, N, K, ldexpf(1.0f, scale_exp));
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// out = epilogue(acc_scale * (A Wp^T) + bias): A [M, K] f32 activations, Wp = vs_split_pack_weight image of the f32 weight (acc_scale =
+// 2^-scale_exp), every output f32.  Epilogues 0 / 3 store, 1 exact-erf GELU, 2 gated residual update (resid null: in place), 4 packed
+// q|k|v with RoPE (pos / kind / C / bases as vs_gemm_qkv_rope).  Row maps, gate and strides (in floats) as vs_gemm_bias_act.
+extern "C" int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,
+                             int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t grp_in,
+                             int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out,
+                             int32_t a_grp_off, const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d,
+                             vs_stream_t stream_) {
+    VS_CHECK(epilogue >= 0 && epilogue <= 4, "vs_gemm_split: unknown epilogue %d", epilogue);
+    VS_CHECK(epilogue != 4 || (pos && C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0 && base2d > 0.f && theta1d > 0.f),
+             "vs_gemm_split: the RoPE epilogue needs pos, C %% 64 == 0, N >= 2C, positive bases");
+    VS_CHECK(acc_scale > 0.f, "vs_gemm_split: acc_scale must be positive");
+    return gemm_entry("vs_gemm_split", A, Wp, bias, out, gate, resid, M, N, K, lda, ldw, ldo, epilogue, 4, grp_in, grp_out, grp_off, gate_rows,
+                      gate_ld, a_grp_in, a_grp_out, a_grp_off, epilogue == 4 ? pos : nullptr, epilogue == 4 ? kind : nullptr, C, base2d, theta1d,
+                      (hipStream_t)stream_, acc_scale);
+}
+
 // Weight-gradient GEMM: out32[t][M,N] += A[M,K] (W + shift[t])[N,K]^T for t < max(ntaps, 1), the K range cut into `ksplit` slices
 // that run as separate workgroups: long thin reductions (M, N = channels, K = millions of pixels or tokens).  ntaps = 0: one
 // plain GEMM (shifts ignored); 1..9: the taps of a 3x3 convolution -- A = dY^T [Cout, pixels], W = X^T [Cin, pixels]
@@ -599,7 +747,7 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
     g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
@@ -636,7 +784,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
@@ -686,7 +834,7 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
     g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
     const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
@@ -758,7 +906,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
     static const int no256 = [] { const char *e = getenv("VS_STEM_NO256"); return e ? atoi(e) : 0; }();
     if (Cout % 256 == 0 && g.M >= 256 && !no256) {
         const int nwg = vs::cdiv(g.M, 256) * (Cout / 256);

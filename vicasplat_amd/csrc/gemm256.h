@@ -45,6 +45,7 @@ __device__ __forceinline__ int unit_b_tile_row256(int q, int h) { return (q >> 5
 template <int BF16, bool RELU_A, class Stager, bool TN = false>
 __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[8][4], const unsigned char *smem, const int lane,
                                             const int wid) {
+    static_assert(!(TN && BF16 == kDtSplit), "split operands: forward (NT) GEMMs only");
     constexpr unsigned UNITB = kUnitBytes256;
     const int wr = wid >> 2, wc = wid & 3;
     typedef void __attribute__((address_space(3))) *lptr_t;
@@ -109,12 +110,12 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
                 fa[i][s_].z = relu_reg<BF16>(fa[i][s_].z); fa[i][s_].w = relu_reg<BF16>(fa[i][s_].w);            \
             }                                                                                                    \
     }
-#define VS_MM(ha_, hb_)                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fb[hb_][j][0], fa[i][0], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
-            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mfma<BF16>(fb[hb_][j][1], fa[i][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
-        }
+#define VS_MM(ha_, hb_, cvt_)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+        if constexpr (BF16 == kDtSplit) { if (cvt_) split8(fa[i][0], fa[i][1]); }   /* f32 fragment -> (hi, lo), once per K-tile */ \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mma2<BF16>(fb[hb_][j][0], fb[hb_][j][1], fa[i][0], fa[i][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
+    }
 #define VS_BAR()                                  \
     {                                             \
         __builtin_amdgcn_sched_barrier(0);        \
@@ -126,7 +127,7 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
         VS_BAR()                                  \
         __builtin_amdgcn_s_setprio(1);            \
         if (relu_) VS_RELU_A()                    \
-        VS_MM(ha_, hb_)                           \
+        VS_MM(ha_, hb_, relu_)                    \
         __builtin_amdgcn_s_setprio(0);            \
         VS_BAR()                                  \
     }

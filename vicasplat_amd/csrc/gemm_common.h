@@ -56,6 +56,7 @@ struct GemmArgs {
     int rope_C;  // columns [0, C) = q, [C, 2C) = k, rest untouched
     float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
     int stagger;  // experiment: first-round workgroups of gemm256_kernel sleep (bid % 8) * stagger * ~4 us before starting
+    float acc_scale;  // split operands (kDtSplit): the packed weights carry a power-of-two scale 2^e; the epilogue multiplies the accumulators by 2^-e
 };
 
 // Operand dtype of the MFMA kernels (template parameter `BF16` of every kernel below: the name predates the third value).
@@ -66,7 +67,40 @@ struct GemmArgs {
 //     consecutive k, and one 16x16x32 MFMA becomes four v_mfma_f32_16x16x4_f32 (exact f32 products and sums == an fmaf chain;
 //     64 FLOP/clk/SIMD = 1/16 of the 16-bit rate).  Lane (row = l & 15, group = l >> 4) feeds float s of its quad to step s,
 //     i.e. k = 4 * group + s for BOTH operands -- any bijection of k onto (step, group) is a valid summation order.
+//   3 split (kDtSplit): f32-class results at 1/3 of the 16-bit matrix rate (SURVEY 7-5 "fp32 MFMA or 3x split").  Activations
+//     stay f32 in HBM and LDS (same 2-byte-unit addressing as kDtF32); a lane converts its A fragment -- 8 floats -- in registers to
+//     hi = rne16(x) and lo = rne16(x - hi) (the difference is exact in f32, so hi + lo carries x to 2^-23), the weights are packed
+//     ONCE on the host side of the ABI (vs_split_pack_weight) as [hi 32 halves | lo 32 halves] per block of 32 k, scaled by a power
+//     of two so that lo stays a normal f16, and the product is three v_mfma_f32_16x16x32_f16: lo_w hi_a + hi_w lo_a + hi_w hi_a
+//     (the dropped lo lo term is 2^-22 relative).  Within a block the packed weights are ordered so that chunk g (8 halves) holds
+//     k = {4g..4g+3, 16+4g..16+4g+3}: exactly the floats lane group g reads from an f32 A row (chunks g and 4+g).
 constexpr int kDtF32 = 2;
+constexpr int kDtSplit = 3;
+// operand classes whose activations / outputs are f32 arrays (addressed in 2-byte units by the kernels)
+__host__ __device__ constexpr bool is_f32io(int dt) { return dt == kDtF32 || dt == kDtSplit; }
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// 8 floats (the two 16-byte chunks a lane reads from an f32 A row) -> hi / lo f16x8 MFMA operands.  x - float(hi) runs on
+// v_fma_mix_f32 (f16 source operand, f32 result: one instruction instead of convert + subtract): 16 VALU per fragment.
+__device__ __forceinline__ void split8(uint4 &f0, uint4 &f1) {
+    const float x[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                        __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        h[p] = cvt_pk_f16(x[2 * p], x[2 * p + 1]);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h[p]), "v"(x[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h[p]), "v"(x[2 * p + 1]));
+        l[p] = cvt_pk_f16(r0, r1);
+    }
+    f0 = make_uint4(h[0], h[1], h[2], h[3]);
+    f1 = make_uint4(l[0], l[1], l[2], l[3]);
+}
 
 template <int BF16>
 __device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
@@ -82,11 +116,25 @@ __device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
     }
 }
 
+// One K step of a (W fragment pair, A fragment pair): two consecutive 32-wide MFMA steps for the 16-bit / f32 operand classes; for
+// split operands (b0, b1) = (hi, lo) of the packed weights and (a0, a1) = (hi, lo) of the converted activations: three products.
+template <int BF16>
+__device__ __forceinline__ f4 mma2(const uint4 &b0, const uint4 &b1, const uint4 &a0, const uint4 &a1, f4 c) {
+    if constexpr (BF16 == kDtSplit) {
+        c = mfma<0>(b1, a0, c);
+        c = mfma<0>(b0, a1, c);
+        return mfma<0>(b0, a0, c);
+    } else {
+        c = mfma<BF16>(b0, a0, c);
+        return mfma<BF16>(b1, a1, c);
+    }
+}
+
 // two floats -> one packed pair of 16-bit values (low half = a), round to nearest even: ONE instruction on gfx950 (v_cvt_pk_f16_f32 /
 // v_cvt_pk_bf16_f32) where two scalar converts plus the shift / or (and, for bf16, the integer rounding sequence) were 4-10
 template <int BF16>
 __device__ __forceinline__ unsigned pack16x2(float a, float b) {
-    static_assert(BF16 != kDtF32, "f32 operands are stored as floats");
+    static_assert(!is_f32io(BF16), "f32 operands are stored as floats");
     unsigned r;
     if constexpr (BF16 == 1) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -95,7 +143,7 @@ __device__ __forceinline__ unsigned pack16x2(float a, float b) {
 
 template <int BF16>
 __device__ __forceinline__ unsigned short to16(float v) {
-    static_assert(BF16 != kDtF32, "f32 operands are stored as floats, not through to16");
+    static_assert(!is_f32io(BF16), "f32 operands are stored as floats, not through to16");
     if constexpr (BF16 == 1) {
         unsigned u = __float_as_uint(v);
         u += 0x7FFFu + ((u >> 16) & 1u);
@@ -108,7 +156,7 @@ __device__ __forceinline__ unsigned short to16(float v) {
 
 template <int BF16>
 __device__ __forceinline__ float from16(unsigned short h) {
-    static_assert(BF16 != kDtF32, "f32 operands are read as floats, not through from16");
+    static_assert(!is_f32io(BF16), "f32 operands are read as floats, not through from16");
     if constexpr (BF16 == 1) return __uint_as_float(((unsigned)h) << 16);
     else return (float)*reinterpret_cast<_Float16 *>(&h);
 }
@@ -121,7 +169,7 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {
 // the same on one fragment register of operand dtype DT (f32: one float per register)
 template <int DT>
 __device__ __forceinline__ unsigned relu_reg(unsigned x) {
-    if constexpr (DT == kDtF32) {
+    if constexpr (is_f32io(DT)) {
         return x & ~(unsigned)((int)x >> 31);
     } else if constexpr (DT == 0) {
         // f16: ONE packed max per register (relu2 is shift / and / quarter-rate 32-bit multiply / and-not: ~7 issue slots, and the
@@ -224,6 +272,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
     // (opaque copy of the lane id: keeps the compiler from hoisting the epilogue's per-lane constants -- bias, RoPE frequencies --
     //  above the main loop, where they cost a spill that is reloaded inside it)
     asm volatile("" : "+v"(lane));
+    if constexpr (BF16 == kDtSplit) {   // undo the power-of-two scale of the packed weights (exact)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= g.acc_scale;
+    }
     const int mrow = lane & 15, c4 = (lane >> 4) * 4;
     const bool full_n = nbase + 64 <= g.N;
     float bv[4][4];
@@ -260,7 +314,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
         }
         __syncthreads();
     }
-    constexpr bool OUT16 = (EPI == 0 || EPI == 1 || EPI == 4) && BF16 != kDtF32;   // f32 operands: every epilogue stores floats
+    constexpr bool OUT16 = (EPI == 0 || EPI == 1 || EPI == 4) && !is_f32io(BF16);   // f32 operands: every epilogue stores floats
     const bool vec_ok = full_n && (OUT16 ? (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 7) == 0)
                                          : (g.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0));
     // ---- fast path: interior wave tile (every row and column valid, vector-aligned output).  All conditions are wave-uniform,
@@ -352,7 +406,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                         for (int r = 0; r < 4; r += 2) {
                             if constexpr (EPI == 1) {
                                 const f2v zin = f2v{acc[i][j][r] + bv[j][r], acc[i][j][r + 1] + bv[j][r + 1]};
-                                const f2v gl = BF16 == kDtF32 ? gelu_erf2(zin) : gelu_poly2(zin);   // f32 operands = reference-precision path: exact erf
+                                const f2v gl = is_f32io(BF16) ? gelu_erf2(zin) : gelu_poly2(zin);   // f32 operands = reference-precision path: exact erf
                                 v[j][r] = gl.x; v[j][r + 1] = gl.y;
                             } else {
                                 v[j][r] = acc[i][j][r] + bv[j][r];
@@ -402,7 +456,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                         }
                     }
                     if constexpr (OUT16) {
-                        constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;
+                        constexpr int D16 = is_f32io(BF16) ? 0 : BF16;
                         uint2 pk[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -454,7 +508,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[j][r] = acc[i][j][r] + bv[j][r];
-                if constexpr (EPI == 1) v[j][r] = BF16 == kDtF32 ? gelu_erf(v[j][r]) : gelu_poly(v[j][r]);   // same function as the wide path: results do not depend on the tile path
+                if constexpr (EPI == 1) v[j][r] = is_f32io(BF16) ? gelu_erf(v[j][r]) : gelu_poly(v[j][r]);   // same function as the wide path: results do not depend on the tile path
             }
         if constexpr (EPI == 4) {
             if (rope_on) {
@@ -490,7 +544,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
         }
         if (!valid) continue;
         if constexpr (OUT16) {
-            constexpr int D16 = BF16 == kDtF32 ? 0 : BF16;   // (never instantiated for f32: keeps to16<> well-formed)
+            constexpr int D16 = is_f32io(BF16) ? 0 : BF16;   // (never instantiated for f32: keeps to16<> well-formed)
             unsigned short *dst = reinterpret_cast<unsigned short *>(g.out) + orow * g.ldo + nbase + c4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

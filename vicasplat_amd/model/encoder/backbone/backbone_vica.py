@@ -110,6 +110,7 @@ class VicaNet(nn.Module):
         # attribute fallbacks the heads rely on (dpt_head.py:105-110 reads net.dec_depth / enc_embed_dim / dec_embed_dim)
         self.enc_depth, self.dec_depth, self.enc_embed_dim, self.dec_embed_dim = enc_depth, dec_depth, enc_embed_dim, dec_embed_dim
         self.compute_dtype = compute_dtype
+        self.split = False    # split operand class (ops.SplitWeight): f32 activations, weights packed as f16 (hi, lo) pairs -- set by VicaSplat.set_compute_dtype("split")
         self.patch_embed = _PatchEmbed(patch_size, enc_embed_dim)
         self.enc_blocks = nn.ModuleList([_EncBlock(enc_embed_dim, enc_num_heads, mlp_ratio) for _ in range(enc_depth)])
         self.enc_norm = nn.LayerNorm(enc_embed_dim, eps=1e-6)
@@ -147,12 +148,12 @@ class VicaNet(nn.Module):
     # 16-bit operand copies of the GEMM weights (re-made when a parameter changes or moves)
     # ------------------------------------------------------------------------------------------------------
     def _weights16(self):
-        key = (self.compute_dtype, self.patch_embed.proj.weight.device,
+        key = (self.compute_dtype, self.split, self.patch_embed.proj.weight.device,
                sum(p._version for p in self.parameters()), id(self.patch_embed.proj.weight))
         if key == self._w16_key:
             return self._w16
         dt = self.compute_dtype
-        c = lambda t: t.detach().to(dt).contiguous()
+        c = (lambda t: ops.split_pack_weight(t)) if self.split else (lambda t: t.detach().to(dt).contiguous())
         W = {"patch": c(self.patch_embed.proj.weight.flatten(1)), "dec_embed": c(self.decoder_embed.weight)}
         for i, b in enumerate(self.enc_blocks):
             W[f"e{i}.qkv"], W[f"e{i}.proj"] = c(b.attn.qkv.weight), c(b.attn.proj.weight)
@@ -245,7 +246,7 @@ class VicaNet(nn.Module):
         for i, blk in enumerate(self.enc_blocks):
             ops.layernorm_mod(xe, blk.norm1.weight, blk.norm1.bias, h)
             ops.gemm_qkv_rope(h, W[f"e{i}.qkv"], blk.attn.qkv.bias, qkv, Ce, tabs["pos_img"], None, 100.0, 1.0)
-            ops.attention(qkv[:, :Ce], qkv[:, Ce:2 * Ce], qkv[:, 2 * Ce:], att, nbatch=BT, H=He, Lq=N, Lk=N, q_batch_rows=N, k_batch_rows=N)
+            ops.attention(qkv[:, :Ce], qkv[:, Ce:2 * Ce], qkv[:, 2 * Ce:], att, nbatch=BT, H=He, Lq=N, Lk=N, q_batch_rows=N, k_batch_rows=N, split=self.split)
             ops.gemm(att, W[f"e{i}.proj"], blk.attn.proj.bias, xe, ops.EPI_RESID32)
             ops.layernorm_mod(xe, blk.norm2.weight, blk.norm2.bias, h)
             ops.gemm(h, W[f"e{i}.fc1"], blk.mlp.fc1.bias, hid, ops.EPI_GELU16)
@@ -286,7 +287,7 @@ class VicaNet(nn.Module):
             hmix.view(BT, M2, Cd)[:, 0] = cn.to(dt)
             ops.gemm_qkv_rope(hmix, W[f"d{i}.qkv"], blk.attn.qkv.bias, qkvm, Cd, tabs["pos_mix"], tabs["kind_mix"], 100.0, theta)
             ops.attention(qkvm[:, :Cd], qkvm[:, Cd:2 * Cd], qkvm[:, 2 * Cd:], attm, nbatch=B, H=Hd, Lq=T * M2, Lk=T * M2,
-                          q_batch_rows=T * M2, k_batch_rows=T * M2, q_kvlen=tabs["kvlen"])
+                          q_batch_rows=T * M2, k_batch_rows=T * M2, q_kvlen=tabs["kvlen"], split=self.split)
             ops.gemm(attm, W[f"d{i}.proj"], blk.attn.proj.bias, xd, ops.EPI_RESID32, gate=mod1[:, 2 * Cd:], gate_rows=N,
                      M=BT * N, a_grp_in=N, a_grp_out=M2, a_grp_off=1)
             ops.gemm(attm, W[f"d{i}.proj"], blk.attn.proj.bias, cam, ops.EPI_RESID32, M=BT, a_grp_in=1, a_grp_out=M2, a_grp_off=0)
@@ -297,7 +298,7 @@ class VicaNet(nn.Module):
             # -- cross-neighbour attention (:152-191): keys/values of frames t-1, t+1 gathered by row segments
             ops.layernorm_mod(xd, blk.norm2.weight, blk.norm2.bias, h, scale=mod2[:, :Cd], shift=mod2[:, Cd:2 * Cd], mod_rows=N)
             ops.gemm_qkv_rope(h, W[f"d{i}.cqkv"], W[f"d{i}.cqkv_b"], qkv, Cd, tabs["pos_img"], None, 100.0, 1.0)
-            ops.attention(qkv[:, :Cd], qkv[:, Cd:2 * Cd], qkv[:, 2 * Cd:], att, nbatch=BT, H=Hd, Lq=N, q_batch_rows=N, kv_seg=tabs["seg"])
+            ops.attention(qkv[:, :Cd], qkv[:, Cd:2 * Cd], qkv[:, 2 * Cd:], att, nbatch=BT, H=Hd, Lq=N, q_batch_rows=N, kv_seg=tabs["seg"], split=self.split)
             ops.gemm(att, W[f"d{i}.cproj"], blk.cross_attn.proj.bias, xd, ops.EPI_RESID32, gate=mod2[:, 2 * Cd:3 * Cd], gate_rows=N)
             # -- MLPs (:323-333); the camera MLP reads cam_norm2(cam), not a fresh norm
             ops.layernorm_mod(xd, blk.norm3.weight, blk.norm3.bias, h, scale=mod2[:, 3 * Cd:4 * Cd], shift=mod2[:, 4 * Cd:5 * Cd], mod_rows=N)

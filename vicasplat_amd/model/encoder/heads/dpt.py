@@ -4,7 +4,7 @@ heads/dpt_gs_head.py:98-206, heads/postprocess.py:10-63.  Parameter names == the
 
 SURVEY.md 8(f)-1: the heads are 42 % of the forward FLOPs.  All 3x3 / 1x1 / transposed convolutions and the
 bilinear upsampling run on the hand-written HIP kernels (implicit-GEMM MFMA conv, GEMM, upsample) on NHWC 16-bit
-activations; only the 7x7 RGB stem conv (3 input channels) stays on MIOpen.  HIP device tensors only.
+activations; the 7x7 RGB stem conv is a window GEMM on the same main loop (`vs_conv7x7_rgb_nhwc`; im2col + GEMM on the f32 / split paths).  HIP device tensors only.
 """
 from __future__ import annotations
 
@@ -102,7 +102,7 @@ class PixelwiseTaskWithDPT(nn.Module):
       * every 1x1 convolution and both ConvTranspose2d(k == stride) layers are plain GEMMs (`vs_gemm_bias_act`) -- tokens
         [BT, 256, C] ARE an NHWC 16x16 map, so no reshape copy is needed on the way in;
       * bilinear x2 (align_corners=True) is `vs_upsample2x_nhwc` (with the image-feature add of the GS head fused).
-    Only the 7x7 stem conv on the RGB image (3 input channels, 2.7 % of the head FLOPs) stays on MIOpen.
+    The 7x7 stem conv on the RGB image is `vs_conv7x7_rgb_nhwc` (window GEMM; im2col + GEMM on the f32 / split paths).
     Channel counts that are not multiples of 64 (96, 192) are zero-padded inside the packed weights."""
 
     def __init__(self, net, num_channels: int, head_type: str):
@@ -113,6 +113,7 @@ class PixelwiseTaskWithDPT(nn.Module):
         self.head_type = head_type
         self.num_channels = num_channels
         self.compute_dtype = torch.float16
+        self.split = False    # split operand class: f32 activations + ops.SplitWeight weights (VicaSplat.set_compute_dtype("split"))
         self._pk: dict = {}
         self._pk_key = None
 
@@ -120,10 +121,11 @@ class PixelwiseTaskWithDPT(nn.Module):
     def _packed(self):
         d = self.dpt
         w0 = d.scratch.layer1_rn.weight
-        key = (self.compute_dtype, w0.device, sum(p._version for p in self.parameters()), id(w0))
+        key = (self.compute_dtype, self.split, w0.device, sum(p._version for p in self.parameters()), id(w0))
         if key == self._pk_key:
             return self._pk
         dt = self.compute_dtype
+        fin = (lambda t: ops.split_pack_weight(t)) if self.split else (lambda t: t)   # (split: pack the padded f32 GEMM weight)
         P = {}
 
         def lin(name, conv, n_pad=0, k_pad=0):  # 1x1 conv -> GEMM weight [N(+pad), K(+pad)], f32 bias [N(+pad)]
@@ -135,7 +137,7 @@ class PixelwiseTaskWithDPT(nn.Module):
             b = torch.zeros(Np, dtype=torch.float32, device=w.device)
             if conv.bias is not None:
                 b[:N] = conv.bias.detach().float()
-            P[name + ".w"], P[name + ".b"] = wp, b
+            P[name + ".w"], P[name + ".b"] = fin(wp), b
 
         def convT(name, ct, k_pad, co_pad):  # ConvTranspose2d(k == stride) -> GEMM weight [(i, j, co_pad), ci_pad]
             w = ct.weight.detach()  # [Cin, Cout, k, k]
@@ -144,10 +146,10 @@ class PixelwiseTaskWithDPT(nn.Module):
             wp[:, :, :Cout, :Cin] = w.permute(2, 3, 1, 0).to(dt)
             b = torch.zeros(k, k, co_pad, dtype=torch.float32, device=w.device)
             b[:, :, :Cout] = ct.bias.detach().float()
-            P[name + ".w"], P[name + ".b"] = wp.reshape(k * k * co_pad, k_pad).contiguous(), b.reshape(-1).contiguous()
+            P[name + ".w"], P[name + ".b"] = fin(wp.reshape(k * k * co_pad, k_pad).contiguous()), b.reshape(-1).contiguous()
 
         def c3(name, conv, cin_pad=0):
-            P[name + ".w"] = ops.pack_conv3x3_weight(conv.weight, dt, cin_pad)
+            P[name + ".w"] = ops.pack_conv3x3_weight(conv.weight, "split" if self.split else dt, cin_pad)
             P[name + ".b"] = None if conv.bias is None else conv.bias.detach().float().contiguous()
 
         ap = d.act_postprocess
@@ -186,6 +188,11 @@ class PixelwiseTaskWithDPT(nn.Module):
         c = self.dpt.input_merger[0]
         N, _, H, W = frames.shape
         wk = F.pad(c.weight.detach().float().flatten(1), (0, 160 - 147)).contiguous()
+        if self.split:
+            P = self._packed()
+            if "stem.ws" not in P:
+                P["stem.ws"] = ops.split_pack_weight(wk)
+            wk = P["stem.ws"]
         bias = c.bias.detach().float().contiguous()
         out = torch.empty(N, H, W, wk.shape[0], dtype=torch.float32, device=frames.device)
         step = 8

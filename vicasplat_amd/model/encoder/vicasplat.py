@@ -98,12 +98,15 @@ class VicaSplat(Encoder[VicaSplatCfg]):
     def set_compute_dtype(self, dt):
         """Operand dtype of the MFMA kernels: torch.float16 (default; 10-bit mantissa = the TF32 products the reference runs at,
         backbone_vica.py:9), torch.bfloat16, or torch.float32 / "f32" -- the reference-precision path: fp32 weights AND activations
-        through exact-f32 MFMA (1/16 of the 16-bit matrix rate), matching an fp32 evaluation of the reference to f32 rounding."""
-        dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32, "f32x": torch.float32}.get(dt, dt)
+        through exact-f32 MFMA (1/16 of the 16-bit matrix rate), matching an fp32 evaluation of the reference to f32 rounding; or "split" --
+        f32 activations with every weight / activation operand split into f16 (hi, lo) pairs and three f16 MFMAs per product
+        (ops.SplitWeight; csrc/gemm_common.h kDtSplit): f32-class results at a third of the 16-bit matrix rate."""
+        split = dt == "split"
+        dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32, "f32x": torch.float32, "split": torch.float32}.get(dt, dt)
         assert dt in (torch.float16, torch.bfloat16, torch.float32), dt
-        self.backbone.compute_dtype = dt
-        self.downstream_head1.compute_dtype = dt
-        self.gaussian_param_head.compute_dtype = dt
+        for m in (self.backbone, self.downstream_head1, self.gaussian_param_head):
+            m.compute_dtype = dt
+            m.split = split
 
     def enable_gradient_checkpointing(self):
         self.backbone.enable_gradient_checkpointing()

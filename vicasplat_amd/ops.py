@@ -19,6 +19,40 @@ _OPERAND_DTYPES = (torch.float16, torch.bfloat16, torch.float32)
 EPI_STORE16, EPI_GELU16, EPI_RESID32, EPI_STORE32 = 0, 1, 2, 3
 
 
+class SplitWeight:
+    """A weight packed for the SPLIT operand class (dtype code 4; csrc/gemm_common.h, kDtSplit): f16 (hi, lo) pairs of w * 2^scale_exp,
+    blocked by 32 k (vs_split_pack_weight).  `data` is an int32 tensor of the logical shape (4 bytes per element); the product entry
+    points multiply the accumulators by `acc_scale` = 2^-scale_exp.  Activations of this class are plain f32 tensors."""
+    __slots__ = ("data", "acc_scale", "shape")
+
+    def __init__(self, data: torch.Tensor, acc_scale: float, shape):
+        self.data, self.acc_scale, self.shape = data, acc_scale, tuple(shape)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def is_contiguous(self):
+        return self.data.is_contiguous()
+
+
+def split_pack_weight(w: torch.Tensor) -> SplitWeight:
+    """f32 weight [N, ...] (flattened to [N, K], K % 32 == 0) -> SplitWeight.  The power-of-two scale puts max|w| just below 2^14: lo stays a
+    normal f16 for every element within 2^-16 of the largest, and the products of the f16 range cannot overflow the f32 accumulator."""
+    dev = L.require_device(w)
+    w2 = w.detach().float().reshape(w.shape[0], -1).contiguous()
+    N, K = w2.shape
+    assert K % 32 == 0, f"split operands need K % 32 == 0 (K={K}): pad the reduction dimension"
+    amax = float(w2.abs().max())
+    import math
+    e = 0 if amax == 0.0 or not math.isfinite(amax) else max(-24, min(24, 13 - math.frexp(amax)[1] + 1))   # amax * 2^e in [2^13, 2^14)
+    out = torch.empty((N, K), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_split_pack_weight(L.ptr(w2), w2.stride(0), L.ptr(out), out.stride(0), N, K, e, L.stream_ptr(dev))
+    L.check(rc, "vs_split_pack_weight")
+    return SplitWeight(out.view(w.shape[0], *w.shape[1:]) if w.dim() > 2 else out, 2.0 ** (-e), w.shape)
+
+
 def layernorm_mod(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, *, eps: float = 1e-6,
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, mod_rows: int = 0,
                   grp_in: int = 0, grp_out: int = 0, grp_off: int = 0) -> torch.Tensor:
@@ -74,6 +108,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
          M: Optional[int] = None, a_grp_in: int = 0, a_grp_out: int = 0, a_grp_off: int = 0) -> torch.Tensor:
     """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w 16-bit; out 16-bit (epilogue 0/1) or f32 (2: in-place residual
     update with optional per-group gate [G,N]; 3: store)."""
+    if isinstance(w, SplitWeight):
+        return _gemm_split(a, w, bias, out, epilogue, gate=gate, gate_rows=gate_rows, grp_in=grp_in, grp_out=grp_out, grp_off=grp_off, M=M,
+                           a_grp_in=a_grp_in, a_grp_out=a_grp_out, a_grp_off=a_grp_off)
     dev = L.require_device(a, w, bias, out, gate)
     assert a.dtype == w.dtype and a.dtype in _OPERAND_DTYPES
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
@@ -93,10 +130,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def _gemm_split(a, w: SplitWeight, bias, out, epilogue, *, gate=None, gate_rows=0, grp_in=0, grp_out=0, grp_off=0, M=None, a_grp_in=0,
+                a_grp_out=0, a_grp_off=0, resid=None, pos=None, kind=None, C=0, base2d=0.0, theta1d=0.0):
+    """vs_gemm_split: a f32 [M,K], w SplitWeight [N,K], every output f32 (epilogue codes of `gemm`, 4 = q|k|v + RoPE)."""
+    wd = w.data
+    dev = L.require_device(a, wd, bias, out, gate, resid, pos, kind)
+    assert a.dtype == torch.float32 and out.dtype == torch.float32 and a.dim() == 2 and wd.dim() == 2 and a.stride(1) == 1
+    assert wd.stride(1) == 1 and a.shape[1] == wd.shape[1] and (resid is None or (resid.dtype == torch.float32 and resid.stride() == out.stride()))
+    M = a.shape[0] if M is None else M
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_split(L.ptr(a), L.ptr(wd), w.acc_scale, L.ptr(bias), L.ptr(out), L.ptr(gate), L.ptr(resid), M, wd.shape[0], a.shape[1],
+                                   a.stride(0), wd.stride(0), out.stride(-2), epilogue, grp_in, grp_out, grp_off, gate_rows,
+                                   gate.stride(0) if gate is not None else 0, a_grp_in, a_grp_out, a_grp_off, L.ptr(pos), L.ptr(kind), C,
+                                   base2d, theta1d, L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_split")
+    return out
+
+
 def gemm_resid(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor, *, gate: Optional[torch.Tensor] = None,
                gate_rows: int = 0) -> torch.Tensor:
     """resid [M,N] f32 + (1 + gate) * (a @ w^T + bias) into a NEW tensor (vs_gemm_resid): the residual update of gemm(..., EPI_RESID32)
     without touching (or cloning) the old stream."""
+    if isinstance(w, SplitWeight):
+        assert resid.is_contiguous() and resid.shape == (a.shape[0], w.shape[0])
+        return _gemm_split(a, w, bias, torch.empty_like(resid), EPI_RESID32, gate=gate, gate_rows=gate_rows, resid=resid)
     dev = L.require_device(a, w, bias, resid, gate)
     assert a.dtype == w.dtype and a.dtype in _OPERAND_DTYPES and a.stride(1) == 1 and w.stride(1) == 1
     assert resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == (a.shape[0], w.shape[0])
@@ -114,6 +171,10 @@ def gemm_qkv_rope(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
                   grp_out: int = 0, grp_off: int = 0, M: Optional[int] = None, a_grp_in: int = 0, a_grp_out: int = 0,
                   a_grp_off: int = 0) -> torch.Tensor:
     """Packed q|k|v projection (w [N >= 2C, K]) with rope_qk(out, C // 64, C, pos, kind, ...) fused into the epilogue."""
+    assert pos.dtype == torch.int32 and pos.is_contiguous() and (kind is None or (kind.dtype == torch.uint8 and kind.is_contiguous()))
+    if isinstance(w, SplitWeight):
+        return _gemm_split(a, w, bias, out, 4, grp_in=grp_in, grp_out=grp_out, grp_off=grp_off, M=M, a_grp_in=a_grp_in, a_grp_out=a_grp_out,
+                           a_grp_off=a_grp_off, pos=pos, kind=kind, C=C, base2d=base2d, theta1d=theta1d)
     dev = L.require_device(a, w, bias, out, pos, kind)
     assert a.dtype == w.dtype == out.dtype and a.dtype in _OPERAND_DTYPES
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
@@ -143,19 +204,22 @@ def rope_qk(buf: torch.Tensor, H: int, k_col: int, pos: torch.Tensor, kind: Opti
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, nbatch: int, H: int, Lq: int,
               Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0, kv_seg: Optional[torch.Tensor] = None,
-              q_kvlen: Optional[torch.Tensor] = None, scale: float = 0.125, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+              q_kvlen: Optional[torch.Tensor] = None, scale: float = 0.125, lse: Optional[torch.Tensor] = None,
+              split: bool = False) -> torch.Tensor:
     """q/k/v: 2-D views [rows, ld] whose column 0 is head 0 (e.g. slices of a packed q|k|v buffer); out [rows, H*64].
-    lse (optional, f32 [rows, H] contiguous) receives the log2-domain logsumexp for attention_backward."""
+    lse (optional, f32 [rows, H] contiguous) receives the log2-domain logsumexp for attention_backward.
+    split=True (f32 tensors only): the split operand class -- three f16 MFMAs per product instead of the exact-f32 MFMA (dtype code 4)."""
     dev = L.require_device(q, k, v, out, kv_seg, q_kvlen, lse)
     for t in (q, k, v, out):
         assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == q.dtype
     assert kv_seg is None or (kv_seg.dtype == torch.int32 and kv_seg.is_contiguous())
     assert q_kvlen is None or (q_kvlen.dtype == torch.int32 and q_kvlen.is_contiguous())
     assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (q.shape[0], H))
+    assert not split or q.dtype == torch.float32
     with torch.cuda.device(dev):
         rc = L.lib().vs_attention_lse(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
                                       q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
-                                      _DTX[q.dtype], L.ptr(lse), L.stream_ptr(dev))
+                                      4 if split else _DTX[q.dtype], L.ptr(lse), L.stream_ptr(dev))
     L.check(rc, "vs_attention")
     return out
 
@@ -268,15 +332,23 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     if mask_by is not None:
         assert residual is None and not relu_out
         residual, relu_out = mask_by, 2
-    dev = L.require_device(x, w, bias, residual, out)
-    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype and x.dtype in _OPERAND_DTYPES
+    split = isinstance(w, SplitWeight)
+    dev = L.require_device(x, w.data if split else w, bias, residual, out)
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype in _OPERAND_DTYPES
+    assert (split and x.dtype == torch.float32) or (not split and x.dtype == w.dtype)
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
-    assert w.shape == (Cout, 3, 3, Cin)
+    assert tuple(w.shape) == (Cout, 3, 3, Cin)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=dev)
     assert residual is None or (residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype)
+    if split:
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv3x3_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(residual), L.ptr(out), N, H, W, Cin, Cout,
+                                               stride, int(relu_in), int(relu_out), L.stream_ptr(dev))
+        L.check(rc, "vs_conv3x3_split_nhwc")
+        return out
     with torch.cuda.device(dev):
         rc = L.lib().vs_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(residual), L.ptr(out), N, H, W, Cin, Cout, stride,
                                      int(relu_in), int(relu_out), _DTX[x.dtype], L.stream_ptr(dev))
@@ -314,6 +386,8 @@ def pack_conv3x3_weight(w: torch.Tensor, dtype: torch.dtype, cin_pad: int = 0) -
     wp = w.detach().permute(0, 2, 3, 1)
     if cin_pad > w.shape[1]:
         wp = torch.nn.functional.pad(wp, (0, cin_pad - w.shape[1]))
+    if dtype == "split":
+        return split_pack_weight(wp.float().contiguous())
     return wp.to(dtype).contiguous()
 
 
