@@ -12,6 +12,8 @@
 // (means [P,3], covariances [P,3,3], harmonics [P,3,d_sh], opacities [P], scales [P,3], rotations [P,4], raw [P,11+3*d_sh]).
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct AdapterArgs {
@@ -117,6 +119,11 @@ __device__ __forceinline__ float cvt16(unsigned short h) {
     else { _Float16 f = *reinterpret_cast<_Float16 *>(&h); return (float)f; }
 }
 
+template <int DT>
+__device__ __forceinline__ float cvtin(float v) { return v; }
+template <int DT>
+__device__ __forceinline__ float cvtin(unsigned short h) { return cvt16<DT == 2>(h); }
+
 // x / d == umulhi(x, div_magic(d)) for every index used here (x < 64 * 96, 2 <= d <= 96): the error x * (m d - 2^32) stays below 2^32
 __device__ __forceinline__ unsigned div_magic(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }   // d >= 2
 
@@ -145,46 +152,49 @@ __device__ __forceinline__ void write_rows(float *__restrict__ dst, int np, int 
     }
 }
 
-template <bool BF16>
+// DT: 0 = f32 inputs (the f32 / split operand classes), 1 = f16, 2 = bf16
+template <int DT>
 __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a) {
+    typedef typename std::conditional<DT == 0, float, unsigned short>::type elem_t;
+    constexpr int EV = 16 / (int)sizeof(elem_t);   // elements per 16-byte vector
     // pixel strides may exceed the channel counts (gs rows padded to a multiple of 16 channels, pts rows to 4: what the fused
     // conv3 -> conv1 head kernel writes); the staged blocks keep the stride
     constexpr int kPx = 28;   // per-pixel results: means 3 | raw opacity 1 | raw scale 3 | raw quat 4 | cov 9 | scale 3 | quat 4 | opacity 1
-    __shared__ __attribute__((aligned(16))) unsigned short sin[64 * kMaxPixStride + 64 * 8 + 16];
+    __shared__ __attribute__((aligned(16))) elem_t sin[64 * kMaxPixStride + 64 * 8 + 16];
     __shared__ float spx[64][kPx + 1];
     __shared__ float smask[kMaxCh];
     const int lane = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * 64;
     const int np = (int)min((long long)64, a.npix - p0);
     const int nsh = a.d_sh, cg = (int)a.gs_pix, cp = (int)a.pts_pix, craw = 11 + 3 * nsh;
-    unsigned short *sgs = sin, *spt = sin + ((64 * cg + 7) & ~7);
+    elem_t *sgs = sin, *spt = sin + ((64 * cg + 7) & ~7);
     {   // coalesced 16-byte loads of the two input blocks
-        const unsigned short *ggs = reinterpret_cast<const unsigned short *>(a.gs) + p0 * cg;
-        const unsigned short *gpt = reinterpret_cast<const unsigned short *>(a.pts) + p0 * cp;
+        const elem_t *ggs = reinterpret_cast<const elem_t *>(a.gs) + p0 * cg;
+        const elem_t *gpt = reinterpret_cast<const elem_t *>(a.pts) + p0 * cp;
         const int n1 = np * cg, n2 = np * cp;
-        for (int k = lane; k < (n1 >> 3); k += 64) reinterpret_cast<uint4 *>(sgs)[k] = reinterpret_cast<const uint4 *>(ggs)[k];
-        for (int k = ((n1 >> 3) << 3) + lane; k < n1; k += 64) sgs[k] = ggs[k];
-        for (int k = lane; k < (n2 >> 3); k += 64) reinterpret_cast<uint4 *>(spt)[k] = reinterpret_cast<const uint4 *>(gpt)[k];
-        for (int k = ((n2 >> 3) << 3) + lane; k < n2; k += 64) spt[k] = gpt[k];
+        for (int k = lane; k < n1 / EV; k += 64) reinterpret_cast<uint4 *>(sgs)[k] = reinterpret_cast<const uint4 *>(ggs)[k];
+        for (int k = (n1 / EV) * EV + lane; k < n1; k += 64) sgs[k] = ggs[k];
+        for (int k = lane; k < n2 / EV; k += 64) reinterpret_cast<uint4 *>(spt)[k] = reinterpret_cast<const uint4 *>(gpt)[k];
+        for (int k = (n2 / EV) * EV + lane; k < n2; k += 64) spt[k] = gpt[k];
         for (int c = lane; c < 3 * nsh; c += 64) smask[c] = a.sh_mask[c % nsh];   // mask per (channel, coefficient) column
     }
     __syncthreads();
     const bool live = lane < np;
-    const unsigned short *mg = sgs + lane * cg;
+    const elem_t *mg = sgs + lane * cg;
     float mx = 0.f, my = 0.f, mz = 0.f, p = 0.f, s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 1.f}, cov[9];
     float o_raw = 0.f, sr[3] = {0.f, 0.f, 0.f}, qr[4] = {0.f, 0.f, 0.f, 1.f};
 #pragma unroll
     for (int c = 0; c < 9; ++c) cov[c] = 0.f;
     if (live) {
-        const float x = cvt16<BF16>(spt[lane * cp]), y = cvt16<BF16>(spt[lane * cp + 1]), z = cvt16<BF16>(spt[lane * cp + 2]);
+        const float x = cvtin<DT>(spt[lane * cp]), y = cvtin<DT>(spt[lane * cp + 1]), z = cvtin<DT>(spt[lane * cp + 2]);
         const float d = sqrtf(x * x + y * y + z * z);
         const float k = expm1f(d) / fmaxf(d, 1e-8f);
         mx = x * k; my = y * k; mz = z * k;
-        o_raw = cvt16<BF16>(mg[0]);
+        o_raw = cvtin<DT>(mg[0]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sr[c] = cvt16<BF16>(mg[1 + c]);
+        for (int c = 0; c < 3; ++c) sr[c] = cvtin<DT>(mg[1 + c]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qr[c] = cvt16<BF16>(mg[4 + c]);
+        for (int c = 0; c < 4; ++c) qr[c] = cvtin<DT>(mg[4 + c]);
         p = 1.0f / (1.0f + expf(-o_raw));
         if (a.opacity_exponent > 0.0f && a.opacity_exponent != 1.0f) {
             const float e = a.opacity_exponent;
@@ -236,9 +246,9 @@ __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a)
     __syncthreads();
     // raw [px][11 + 3 d_sh] = means | pre-activation opacity, scale, quaternion | SH as the head wrote them
     if (a.raw)
-        write_rows(a.raw + p0 * craw, np, craw, lane, [&](int px, int c) { return c < 11 ? spx[px][c] : cvt16<BF16>(sgs[px * cg + c - 3]); });
+        write_rows(a.raw + p0 * craw, np, craw, lane, [&](int px, int c) { return c < 11 ? spx[px][c] : cvtin<DT>(sgs[px * cg + c - 3]); });
     // harmonics [px][3][d_sh] = SH * sh_mask
-    write_rows(a.harmonics + p0 * 3 * nsh, np, 3 * nsh, lane, [&](int px, int c) { return cvt16<BF16>(sgs[px * cg + 8 + c]) * smask[c]; });
+    write_rows(a.harmonics + p0 * 3 * nsh, np, 3 * nsh, lane, [&](int px, int c) { return cvtin<DT>(sgs[px * cg + 8 + c]) * smask[c]; });
     write_rows(a.cov + p0 * 9, np, 9, lane, [&](int px, int c) { return spx[px][11 + c]; });
     write_rows(a.means + p0 * 3, np, 3, lane, [&](int px, int c) { return spx[px][c]; });
     write_rows(a.scales + p0 * 3, np, 3, lane, [&](int px, int c) { return spx[px][20 + c]; });
@@ -435,13 +445,15 @@ extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts
     if (npix <= 0) return 0;
     AdapterArgs a{pts, gs, pts_pix, pts_ch, gs_pix, gs_ch, in_dtype, npix, d_sh, sh_mask, scale_act, scale_min, scale_max,
                   opacity_exponent, means, cov, harmonics, opacities, scales, rotations, raw};
-    const bool dense16 = in_dtype != 0 && pts_ch == 1 && pts_pix >= 3 && pts_pix <= 8 && gs_ch == 1 && gs_pix >= 8 + 3 * d_sh &&
+    const int ev = in_dtype == 0 ? 4 : 8;   // elements per 16-byte vector: every 64-pixel block must start on one
+    const bool dense16 = pts_ch == 1 && pts_pix >= 3 && pts_pix <= 8 && gs_ch == 1 && gs_pix >= 8 + 3 * d_sh &&
                          gs_pix <= kMaxPixStride && 11 + 3 * d_sh <= kMaxCh && ((uintptr_t)pts & 15) == 0 && ((uintptr_t)gs & 15) == 0 &&
-                         ((64 * pts_pix) % 8 == 0) && ((64 * gs_pix) % 8 == 0);
+                         ((64 * pts_pix) % ev == 0) && ((64 * gs_pix) % ev == 0);
     if (dense16) {
         dim3 g64((unsigned)vs::cdiv64(npix, 64));
-        if (in_dtype == 1) hipLaunchKernelGGL(adapter_nhwc16_kernel<false>, g64, dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL(adapter_nhwc16_kernel<true>, g64, dim3(64), 0, stream, a);
+        if (in_dtype == 0) hipLaunchKernelGGL(adapter_nhwc16_kernel<0>, g64, dim3(64), 0, stream, a);
+        else if (in_dtype == 1) hipLaunchKernelGGL(adapter_nhwc16_kernel<1>, g64, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(adapter_nhwc16_kernel<2>, g64, dim3(64), 0, stream, a);
         VS_HIP(hipGetLastError());
         return 0;
     }

@@ -108,6 +108,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
             return;
         }
     }
+    // f32 activations (f32 / split operand classes), interior wave tile: 16-byte residual loads and output stores, straight-line
+    if constexpr (is_f32io(BF16)) {
+        if (g.Cout % 4 == 0 && nbase + 64 <= g.Cout && mw0 + 16 * MI <= M && ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(g.res)) & 15) == 0) {
+            const float *res32 = reinterpret_cast<const float *>(g.res);
+            float *out32 = reinterpret_cast<float *>(g.out);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const size_t o = (size_t)(mw0 + i * 16 + mrow) * g.Cout + nbase + c4;
+                float4 rv[4];
+                if (res32) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const float4 *>(res32 + o + j * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (res32) {
+                        const float rr[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = g.relu_out == 2 ? (rr[r] > 0.f ? v[r] : 0.f) : v[r] + rr[r];
+                    }
+                    if (g.relu_out == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                    }
+                    *reinterpret_cast<float4 *>(out32 + o + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mw0 + i * 16 + mrow;
@@ -361,7 +394,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
         }
     }
     f4 acc[8][4];
-    mainloop256<BF16, RELU_IN>(st, K / 64, acc, smem, lane, wid);
+    if constexpr (BF16 == kDtSplit) mainloop256_split<RELU_IN>(st, K / 64, acc, smem, lane, wid);
+    else mainloop256<BF16, RELU_IN>(st, K / 64, acc, smem, lane, wid);
     if constexpr (FUSE_NF > 0) conv_head1x1_epilogue256<BF16, FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
     else conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
 }
@@ -785,7 +819,8 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     const long long big = vs::cdiv64(M, 256) * vs::cdiv(Cout, BN);
     if (dtype == 4) {
         VS_CHECK(Cin % 64 == 0, "vs_conv3x3_split_nhwc: Cin must be a multiple of 32");
-        if (big >= 512) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8>), dim3((unsigned)big), dim3(256), 0, stream, g);
+        static const int smi = [] { const char *e = getenv("VS_CONV_SPLIT_MI"); return e ? atoi(e) : 0; }();
+        if ((big >= 512 && smi != 4) || smi == 8) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8>), dim3((unsigned)big), dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
     } else if (dtype == 3) {
         hipLaunchKernelGGL((conv3x3_kernel<kDtF32, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);

@@ -454,17 +454,6 @@ int launch_f32(const GemmArgs &g, int epi, hipStream_t stream) {
     return launch_mi<kDtF32, 4>(g, epi, stream);
 }
 
-// split operands (kDtSplit): same routing as the f32 class -- K counts 2-byte units of the f32 A rows, a multiple of 64 (32 k)
-int launch_split(const GemmArgs &g, int epi, hipStream_t stream) {
-    if (g.M <= 64 && epi != 4) return launch_smallm<kDtSplit>(g, epi, stream);
-    if (g.K % 128 == 0) {
-        // 256 x 256 tiles unless they would leave most of the chip idle (few tiles) -- then 128 x 128
-        const long long t256 = (long long)vs::cdiv(g.M, 256) * vs::cdiv(g.N, 256);
-        if (t256 >= 128) return launch_256<kDtSplit>(g, epi, stream);
-    }
-    return launch_mi<kDtSplit, 4>(g, epi, stream);
-}
-
 template <int BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
@@ -623,7 +612,9 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
     g.acc_scale = acc_scale;
-    const int rc = dtype == 4 ? launch_split(g, epilogue, stream)
+    // split operands (kDtSplit) take the 16-bit classes' routing: whole rounds of 256 x 256 tiles + a tail launch (K counts 2-byte units
+    // of the f32 rows; every stage pair / K-tile of the kernels is one 128-byte block of 32 k)
+    const int rc = dtype == 4 ? launch<kDtSplit>(g, epilogue, stream)
                  : dtype == 3 ? launch_f32(g, epilogue, stream) : dtype == 2 ? launch<1>(g, epilogue, stream) : launch<0>(g, epilogue, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());

@@ -45,7 +45,7 @@ __device__ __forceinline__ int unit_b_tile_row256(int q, int h) { return (q >> 5
 template <int BF16, bool RELU_A, class Stager, bool TN = false>
 __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[8][4], const unsigned char *smem, const int lane,
                                             const int wid) {
-    static_assert(!(TN && BF16 == kDtSplit), "split operands: forward (NT) GEMMs only");
+    static_assert(BF16 != kDtSplit, "split operands run mainloop256_split");
     constexpr unsigned UNITB = kUnitBytes256;
     const int wr = wid >> 2, wc = wid & 3;
     typedef void __attribute__((address_space(3))) *lptr_t;
@@ -110,12 +110,10 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
                 fa[i][s_].z = relu_reg<BF16>(fa[i][s_].z); fa[i][s_].w = relu_reg<BF16>(fa[i][s_].w);            \
             }                                                                                                    \
     }
-#define VS_MM(ha_, hb_, cvt_)                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
-        if constexpr (BF16 == kDtSplit) { if (cvt_) split8(fa[i][0], fa[i][1]); }   /* f32 fragment -> (hi, lo), once per K-tile */ \
+#define VS_MM(ha_, hb_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mma2<BF16>(fb[hb_][j][0], fb[hb_][j][1], fa[i][0], fa[i][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]); \
-    }
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mma2<BF16>(fb[hb_][j][0], fb[hb_][j][1], fa[i][0], fa[i][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]);
 #define VS_BAR()                                  \
     {                                             \
         __builtin_amdgcn_sched_barrier(0);        \
@@ -127,7 +125,7 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
         VS_BAR()                                  \
         __builtin_amdgcn_s_setprio(1);            \
         if (relu_) VS_RELU_A()                    \
-        VS_MM(ha_, hb_, relu_)                    \
+        VS_MM(ha_, hb_)                           \
         __builtin_amdgcn_s_setprio(0);            \
         VS_BAR()                                  \
     }
@@ -166,6 +164,147 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
 #undef VS_BAR
 #undef VS_MM
 #undef VS_RELU_A
+#undef VS_RD_B
+#undef VS_RD_A
+#undef VS_STAGE
+    __syncthreads();  // every wave is done with the ring before an epilogue reuses it
+}
+
+// ---- split operands (gemm_common.h, kDtSplit) on the same tile, ring, units and phases.  The A units arrive as f32 rows (LDS-DMA
+// cannot convert) and are converted IN PLACE in LDS, once per workgroup, to the (hi, lo) f16 form the MFMAs take: a thread reads the two
+// 16-byte chunks (c, c + 4) of a row -- 8 floats, exactly the pair a lane group reads as a fragment -- and writes hi back over chunk c
+// and lo over chunk c + 4 (16 VALU; the per-wave conversion of every fragment read it replaces cost 4x that, in the waves that feed the
+// matrix pipe: measured 0.37 -> of the 16-bit peak on the ViT-L GEMMs).  Rows 64 g .. 64 g + 63 of an A unit are staged, converted
+// and read by wave group g alone, one item per thread and unit, in the two light read segments of a K-tile:
+//     R0: read B_0, A_0 | M0 (A0,B0) | R1: read B_1; stage A_0, B_0 of kt+2; CONVERT A_1 of kt | M1 (A0,B1)
+//     R2: read A_1; stage B_1 of kt+2 | M2 (A1,B1) | R3: stage A_1 of kt+2; CONVERT A_0 of kt+1 | M3 (A1,B0)
+// Issue order per wave and tile: A_0, B_0, B_1, A_1.  A unit must have LANDED one barrier before its conversion: W2 (B_1, A_1 of kt:
+// four younger units in flight, vmcnt 8) closes the barrier interval of group 0's M0 / group 1's R0, W1 (A_0, B_0 of kt+1: five
+// younger units, vmcnt 10) that of group 0's M2 / group 1's R2 -- the groups run one barrier apart, so the same interval is a compute
+// segment for one and a read segment for the other.  The ReLU of an implicit-GEMM convolution is applied during the conversion.
+template <bool RELU_A, class Stager>
+__device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (&acc)[8][4], unsigned char *smem, const int lane, const int wid) {
+    constexpr unsigned UNITB = kUnitBytes256;
+    constexpr int BF16 = kDtSplit;
+    const int wr = wid >> 2, wc = wid & 3;
+    typedef void __attribute__((address_space(3))) *lptr_t;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wid * 2048u);
+#define VS_STAGE(u_, kt_, d_) st.stage(u_, kt_, lds_w + (unsigned)(((d_) * 4 + (u_)) * UNITB));
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned rd0 = (unsigned)(frow * 128 + (((0 + fg) ^ (frow >> 1)) << 4));
+    const unsigned rd1 = (unsigned)(frow * 128 + (((4 + fg) ^ (frow >> 1)) << 4));
+    const unsigned char *rdA = smem + wr * (64 * 128);
+    const unsigned char *rdB = smem + wc * (32 * 128);
+    // this thread's conversion item inside an A unit: unit row wr*64 + (wid&3)*16 + frow, chunk pair (fg, fg + 4) -- the fragment read pattern
+    unsigned char *cvp = smem + (wr * 64 + (wid & 3) * 16) * 128;
+    uint4 fa[4][2], fb[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+#define VS_RD_A(h_, d_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+        fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd0);           \
+        fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd1);           \
+    }
+#define VS_RD_B(h_, d_)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+        fb[h_][j][0] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd0);   \
+        fb[h_][j][1] = *reinterpret_cast<const uint4 *>(rdB + ((d_) * 4 + 2 + (h_)) * UNITB + j * 2048 + rd1);   \
+    }
+    // the conversion of one item is cut in two: its LDS loads are issued at the start of a read segment, the VALU work and the stores at
+    // its end, and the wave only waits for the stores (lgkmcnt) at the END of the following compute segment -- the converted rows are
+    // read two barriers later, and a wait inside the read segment made it longer than the 24 MFMAs it runs beside
+    uint4 cx0, cx1;
+#define VS_CVT_LD(h_, d_)                                                                                        \
+    {                                                                                                            \
+        cx0 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + rd0);                           \
+        cx1 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + rd1);                           \
+    }
+#define VS_CVT_ST(h_, d_)                                                                                        \
+    {                                                                                                            \
+        if constexpr (RELU_A) {                                                                                  \
+            cx0.x = relu_reg<BF16>(cx0.x); cx0.y = relu_reg<BF16>(cx0.y); cx0.z = relu_reg<BF16>(cx0.z); cx0.w = relu_reg<BF16>(cx0.w); \
+            cx1.x = relu_reg<BF16>(cx1.x); cx1.y = relu_reg<BF16>(cx1.y); cx1.z = relu_reg<BF16>(cx1.z); cx1.w = relu_reg<BF16>(cx1.w); \
+        }                                                                                                        \
+        split8(cx0, cx1);                                                                                        \
+        *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + rd0) = cx0;                                 \
+        *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + rd1) = cx1;                                 \
+    }
+#define VS_LGK0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* conversion stores are in LDS before the barrier that publishes them */
+#define VS_MM(ha_, hb_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+            acc[(ha_) * 4 + i][(hb_) * 2 + j] = mma2<BF16>(fb[hb_][j][0], fb[hb_][j][1], fa[i][0], fa[i][1], acc[(ha_) * 4 + i][(hb_) * 2 + j]);
+#define VS_BAR()                                  \
+    {                                             \
+        asm volatile("" ::: "memory");   /* (compiler fence: LDS accesses of the in-place conversion stay on their side) */ \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("" ::: "memory");            \
+    }
+#define VS_WAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
+    // one compute segment; wr_wait_ (a VS_WAIT or nothing) is executed at its END by wave group 0 -- for group 1 the same barrier
+    // interval is the preceding read segment, where the caller places the same wait
+#define VS_COMPUTE(ha_, hb_, g0_wait_, all_wait_) \
+    {                                             \
+        VS_BAR()                                  \
+        __builtin_amdgcn_s_setprio(1);            \
+        VS_MM(ha_, hb_)                           \
+        __builtin_amdgcn_s_setprio(0);            \
+        if (wr == 0) { g0_wait_ }                 \
+        all_wait_                                 \
+        VS_BAR()                                  \
+    }
+    // MODE 0: steady state (tiles kt+1 and kt+2 exist), 1: kt == KT-2, 2: kt == KT-1
+#define VS_KTILE(kt_, d_, MODE_)                                                  \
+    {                                                                             \
+        VS_RD_B(0, d_) VS_RD_A(0, d_)                                             \
+        if (wr == 1) { if (MODE_ <= 1) { VS_WAIT(8) } else { VS_WAIT(0) } }       \
+        if (MODE_ <= 1) { VS_COMPUTE(0, 0, VS_WAIT(8), ) } else { VS_COMPUTE(0, 0, VS_WAIT(0), ) } \
+        VS_CVT_LD(1, d_)                                                          \
+        VS_RD_B(1, d_)                                                            \
+        if (MODE_ == 0) { VS_STAGE(0, (kt_) + 2, d_) VS_STAGE(2, (kt_) + 2, d_) } \
+        VS_CVT_ST(1, d_)                                                          \
+        VS_COMPUTE(0, 1, , VS_LGK0)                                               \
+        VS_RD_A(1, d_)                                                            \
+        if (MODE_ == 0) VS_STAGE(3, (kt_) + 2, d_)                                \
+        if (wr == 1) { if (MODE_ == 0) { VS_WAIT(10) } else if (MODE_ == 1) { VS_WAIT(4) } } \
+        if (MODE_ == 0) { VS_COMPUTE(1, 1, VS_WAIT(10), ) } else if (MODE_ == 1) { VS_COMPUTE(1, 1, VS_WAIT(4), ) } else { VS_COMPUTE(1, 1, , ) } \
+        if (MODE_ <= 1) VS_CVT_LD(0, (d_) ^ 1)                                    \
+        if (MODE_ == 0) VS_STAGE(1, (kt_) + 2, d_)                                \
+        if (MODE_ <= 1) VS_CVT_ST(0, (d_) ^ 1)                                    \
+        VS_COMPUTE(1, 0, , VS_LGK0)                                               \
+    }
+
+    // KT is even and >= 2 (checked by the launchers).  Prologue: both tiles' units in the steady-state order, A_0 of tile 0 converted by
+    // its owners before the first fragment read.
+    VS_STAGE(0, 0, 0) VS_STAGE(2, 0, 0) VS_STAGE(3, 0, 0) VS_STAGE(1, 0, 0) VS_STAGE(0, 1, 1) VS_STAGE(2, 1, 1) VS_STAGE(3, 1, 1) VS_STAGE(1, 1, 1)
+    VS_WAIT(12)
+    VS_BAR()
+    VS_CVT_LD(0, 0)
+    VS_CVT_ST(0, 0)
+    VS_LGK0
+    VS_BAR()
+    if (wr == 1) VS_BAR()  // the second wave group trails the first by one barrier from here on
+    for (int kt = 0; kt + 2 < KT; kt += 2) {
+        VS_KTILE(kt, 0, 0)
+        VS_KTILE(kt + 1, 1, 0)
+    }
+    VS_KTILE(KT - 2, 0, 1)
+    VS_KTILE(KT - 1, 1, 2)
+    if (wr == 0) VS_BAR()
+#undef VS_KTILE
+#undef VS_WAIT
+#undef VS_COMPUTE
+#undef VS_BAR
+#undef VS_MM
+#undef VS_CVT_LD
+#undef VS_CVT_ST
+#undef VS_LGK0
 #undef VS_RD_B
 #undef VS_RD_A
 #undef VS_STAGE
@@ -220,7 +359,8 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
         }
     }
     f4 acc[8][4];
-    mainloop256<BF16, false>(st, g.K / 64, acc, smem, lane, wid);
+    if constexpr (BF16 == kDtSplit) mainloop256_split<false>(st, g.K / 64, acc, smem, lane, wid);
+    else mainloop256<BF16, false>(st, g.K / 64, acc, smem, lane, wid);
     gemm_epilogue<BF16, EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 

@@ -170,7 +170,9 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {
 template <int DT>
 __device__ __forceinline__ unsigned relu_reg(unsigned x) {
     if constexpr (is_f32io(DT)) {
-        return x & ~(unsigned)((int)x >> 31);
+        unsigned r;   // one v_max_f32 (the sign-mask form is two VALU; fmaxf() under IEEE mode adds a canonicalisation)
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+        return r;
     } else if constexpr (DT == 0) {
         // f16: ONE packed max per register (relu2 is shift / and / quarter-rate 32-bit multiply / and-not: ~7 issue slots, and the
         // implicit-GEMM main loop applies this to 32 A-fragment registers per K-tile beside 64 MFMAs of a one-wave-per-SIMD kernel).
