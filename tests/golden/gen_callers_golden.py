@@ -5,6 +5,8 @@ CPU through ref_import.py's stub finder) on seeded inputs:
                           the stub's PlyElement.describe records the structured array instead of writing it)
   * callers_interp.npz -- src/visualization/camera_trajectory/interpolation.py `interpolate_extrinsics` / `interpolate_intrinsics`
                           as demo.py:204-221 calls them (10 steps per interval of a 4-camera path)
+  * callers_fov.npz    -- src/geometry/projection.py:247-261 `get_fov` on the view-mean of seeded context intrinsics and the l2 fov term
+                          LossCamera adds for the *_no_intrin configurations (loss_camera.py:76-79, loss.py:23-28)
   * callers_dq.npz     -- src/loss/loss_camera.py:30-45 `camera_dq_loss` and src/misc/dq.py `homogeneous_matrix` on seeded dual
                           quaternions (the pypose SO3 algebra comes from ref_import's shim)
 
@@ -128,7 +130,23 @@ def gen_dq():
     print("[golden] callers_dq.npz loss", float(l))
 
 
+def gen_fov():
+    from src.geometry.projection import get_fov
+    from src.loss.loss import l2_loss
+    g = torch.Generator().manual_seed(3)
+    B, V = 5, 4
+    K = torch.eye(3).repeat(B, V, 1, 1)
+    K[..., 0, 0] = 0.6 + 0.8 * torch.rand(B, V, generator=g); K[..., 1, 1] = 0.6 + 0.8 * torch.rand(B, V, generator=g)
+    K[..., 0, 2] = 0.5 + 0.02 * torch.randn(B, V, generator=g); K[..., 1, 2] = 0.5 + 0.02 * torch.randn(B, V, generator=g)
+    pred = math.pi * 50 / 180 + 0.2 * torch.randn(B, 2, generator=g)
+    fov = get_fov(K.mean(dim=1))
+    np.savez_compressed(os.path.join(HERE, "callers_fov.npz"), K=K.numpy(), pred_intrins=pred.numpy(), fov=fov.numpy(),
+                        l2=np.float64(l2_loss(pred, fov)))
+    print("[golden] callers_fov.npz l2", float(l2_loss(pred, fov)))
+
+
 if __name__ == "__main__":
+    gen_fov()
     gen_ply()
     gen_interp()
     gen_dq()

@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 import torch
 
 from vicasplat_amd import callers
@@ -193,6 +194,45 @@ def test_dual_quaternion_camera_loss_matches_the_reference():
     perfect = callers.camera_dq_array_from_Rt(E[:, 1:, :3, :3], E[:, 1:, :3, 3])
     assert float(callers.camera_loss(perfect, E)) <= 1e-6
     assert float(callers.camera_loss(perfect + 0.05, E)) > 0.05
+
+
+def test_camera_loss_fov_term_matches_the_reference():
+    """with a fov head (use_intrinsic_embedding=False) LossCamera adds l2(pred_intrins, get_fov(mean_v K)) (loss_camera.py:76-79).
+    Fixture from the reference's get_fov / l2_loss (tests/golden/gen_callers_golden.py)."""
+    from vicasplat_amd.geometry.projection import get_fov
+    z = np.load(os.path.join(_G, "callers_fov.npz"))
+    K, pred = torch.tensor(z["K"]), torch.tensor(z["pred_intrins"])
+    assert np.abs(get_fov(K.mean(1)).numpy() - z["fov"]).max() <= 2e-6
+    B, V = K.shape[:2]
+    E = torch.eye(4).repeat(B, V, 1, 1)
+    perfect = callers.camera_dq_array_from_Rt(E[:, 1:, :3, :3], E[:, 1:, :3, 3])
+    base = float(callers.camera_loss(perfect, E))
+    with_fov = float(callers.camera_loss(perfect, E, pred_intrins=pred, context_intrinsics=K))
+    assert abs(with_fov - base - float(z["l2"])) <= 1e-6
+    assert abs(float(callers.camera_loss(perfect, E, weight=0.5, pred_intrins=pred, context_intrinsics=K)) - 0.5 * (base + float(z["l2"]))) <= 1e-6
+    with pytest.raises(ValueError):
+        callers.camera_loss(perfect, E, pred_intrins=pred)
+    # the fov head receives a gradient through it
+    p = pred.clone().requires_grad_(True)
+    callers.camera_loss(perfect, E, pred_intrins=p, context_intrinsics=K).backward()
+    assert float(p.grad.abs().min()) > 0
+
+
+def test_matrix_to_quaternion_is_standardised_for_large_angles():
+    """rotations beyond ~120 degrees pick a candidate whose real part can come out negative; pytorch3d's
+    matrix_to_quaternion ends with standardize_quaternion (real part >= 0), which the sign-sensitive camera losses rely on."""
+    g = torch.Generator().manual_seed(4)
+    axis = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    ang = torch.linspace(2.2, 3.1, 64) * torch.where(torch.arange(64) % 2 == 0, 1.0, -1.0)
+    q = torch.cat([torch.cos(ang / 2)[:, None], axis * torch.sin(ang / 2)[:, None]], -1)          # wxyz, w > 0 for |angle| < pi
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    back = callers.matrix_to_quaternion_wxyz(R)
+    assert float(back[:, 0].min()) >= 0
+    assert float((back - q).abs().max()) <= 1e-5
+    dq = callers.camera_dq_array_from_Rt(R, torch.zeros(64, 3))
+    assert float(dq[:, 3].min()) >= 0                                                           # xyzw layout: real part last
 
 
 def test_optimizer_groups_and_schedule_follow_the_reference():

@@ -225,6 +225,40 @@ def test_conv3x3_split(N, H, W, Cin, Cout, stride):
         assert _rel(y, F.relu(F.conv2d(xn, w.double(), None, padding=1)).permute(0, 2, 3, 1)) <= TOL
 
 
+@pytest.mark.parametrize("cls", ["split", "f32", "f16"])
+def test_conv3x3_256_tile_kernel_with_relu_at_scale(cls):
+    """The 256 x 256 implicit-GEMM kernel only takes over from ~224 tiles on (N*H*W >= 57 344 pixels): every ReLU / residual variant of
+    every operand class at that size.  (Round 3: an inline-asm ReLU in front of the f32 MFMAs -- invisible to the compiler's hazard
+    recogniser -- left one fragment stale in 1/64 of the outputs, and no test was large enough to route there.)"""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(7)
+    N, H, W, Cin, Cout = 64, 32, 32, 256, 256
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(d)
+    b = torch.randn(Cout, generator=g).to(d)
+    res = torch.randn(N, H, W, Cout, generator=g).to(d)
+    dt = {"split": "split", "f32": torch.float32, "f16": torch.float16}[cls]
+    wp = ops.pack_conv3x3_weight(w, dt)
+    xx, rr = (x.half(), res.half()) if cls == "f16" else (x, res)
+    tol = 2e-3 if cls == "f16" else TOL
+    xn = xx.permute(0, 3, 1, 2).double()
+    wd = (wp if cls != "split" else w.permute(0, 2, 3, 1)).double().permute(0, 3, 1, 2) if cls != "split" else w.double()
+    for relu_in in (False, True):
+        for relu_out in (False, True):
+            for with_res in (False, True):
+                if with_res and relu_out:
+                    continue
+                y = ops.conv3x3_nhwc(xx, wp, b, residual=rr if with_res else None, relu_in=relu_in, relu_out=relu_out)
+                ref = F.conv2d(F.relu(xn) if relu_in else xn, wd, b.double(), padding=1).permute(0, 2, 3, 1)
+                if with_res:
+                    ref = ref + rr.double()
+                if relu_out:
+                    ref = F.relu(ref)
+                e = _rel(y, ref)
+                assert e <= tol, (cls, relu_in, relu_out, with_res, e)
+
+
 def _model(kind):
     from vicasplat_amd.model.encoder import default_cfg, get_encoder
     shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))

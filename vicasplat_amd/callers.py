@@ -402,7 +402,10 @@ def matrix_to_quaternion_wxyz(R: Tensor) -> Tensor:
         torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
     cand = cand / (2.0 * q_abs[..., None].clamp_min(0.1))
     best = q_abs.argmax(-1)
-    return torch.gather(cand, -2, best[..., None, None].expand(*best.shape, 1, 4))[..., 0, :]
+    q = torch.gather(cand, -2, best[..., None, None].expand(*best.shape, 1, 4))[..., 0, :]
+    # standardize_quaternion (pytorch3d main applies it at the end of matrix_to_quaternion): the representative with a non-negative real
+    # part -- the L1 / dual-quaternion losses are sign-sensitive and the pose head predicts w ~ +1
+    return torch.where(q[..., :1] < 0, -q, q)
 
 
 def camera_dq_array_from_Rt(R: Tensor, t: Tensor) -> Tensor:
@@ -431,13 +434,21 @@ def camera_dq_loss(prediction: Tensor, target: Tensor) -> Tensor:
     return (dq_mul(prediction, dq_conj(target)) - ident).abs().mean() + (dq_mul(target, dq_conj(prediction)) - ident).abs().mean()
 
 
-def camera_loss(pred_extrins: Tensor, context_extrinsics: Tensor, weight: float = 1.0, use_dq_loss: bool = True) -> Tensor:
-    """LossCamera.forward for camera_type 'dq' without an intrinsics head (loss_camera.py:47-80): pred_extrins [B,V-1,8] against the
-    dual quaternions of the context cameras 1.. (c2w [B,V,4,4], already expressed in frame 0)."""
+def camera_loss(pred_extrins: Tensor, context_extrinsics: Tensor, weight: float = 1.0, use_dq_loss: bool = True,
+                pred_intrins: Tensor | None = None, context_intrinsics: Tensor | None = None) -> Tensor:
+    """LossCamera.forward for camera_type 'dq' (loss_camera.py:47-80): pred_extrins [B,V-1,8] against the dual quaternions of the
+    context cameras 1.. (c2w [B,V,4,4], already expressed in frame 0); with a fov head (the *_no_intrin configurations: pred_intrins
+    [B,2]) the reference adds l2(pred_intrins, get_fov(mean over views of the context intrinsics)) (:76-79)."""
     E = context_extrinsics[:, 1:]
     tgt = camera_dq_array_from_Rt(E[..., :3, :3], E[..., :3, 3])
     l1 = (pred_extrins - tgt).abs().mean()
-    return weight * ((camera_dq_loss(pred_extrins, tgt) + l1) if use_dq_loss else l1)
+    loss = (camera_dq_loss(pred_extrins, tgt) + l1) if use_dq_loss else l1
+    if pred_intrins is not None:
+        if context_intrinsics is None:
+            raise ValueError("camera_loss: a fov head (pred_intrins) needs the context intrinsics for its target")
+        from .geometry.projection import get_fov
+        loss = loss + ((pred_intrins - get_fov(context_intrinsics.float().mean(dim=1))) ** 2).mean()
+    return weight * loss
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -553,7 +564,8 @@ def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, c
     render = decoder.forward(gs, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
     parts = dict(mse=mse_loss(render.color, tgt["image"], mse_weight))
     if camera_weight > 0 and "extrinsics" in ctx:
-        parts["camera"] = camera_loss(out["pred_extrins"], ctx["extrinsics"].float(), camera_weight)
+        parts["camera"] = camera_loss(out["pred_extrins"], ctx["extrinsics"].float(), camera_weight, pred_intrins=out.get("pred_intrins"),
+                                      context_intrinsics=ctx["intrinsics"])
     for i, fn in enumerate(extra_losses):
         parts[getattr(fn, "__name__", f"extra{i}")] = fn(render, batch, out)
     loss = sum(parts.values())

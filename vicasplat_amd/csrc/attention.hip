@@ -624,10 +624,12 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const float p0 = st[2 * ks + (w >> 1)][(w & 1) * 2], p1 = st[2 * ks + (w >> 1)][(w & 1) * 2 + 1];
-                    float r0, r1;
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh[w]), "v"(p0));
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh[w]), "v"(p1));
-                    ll[w] = cvt_pk_f16s(r0, r1);
+                    // compiler-visible instructions only: the result feeds the P V MFMAs, and the VALU-write -> MFMA-read wait state
+                    // is inserted by the compiler's hazard recogniser, which does not look inside inline asm
+                    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+                    typedef float f2_ __attribute__((ext_vector_type(2)));
+                    const h2_ hv = __builtin_bit_cast(h2_, hh[w]);
+                    ll[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_{p0 - (float)hv.x, p1 - (float)hv.y}, h2_));
                 }
                 pfl[u][ks] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
             }

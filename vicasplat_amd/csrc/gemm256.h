@@ -226,10 +226,10 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
 #define VS_CVT_ST(h_, d_)                                                                                        \
     {                                                                                                            \
         if constexpr (RELU_A) {                                                                                  \
-            cx0.x = relu_reg<BF16>(cx0.x); cx0.y = relu_reg<BF16>(cx0.y); cx0.z = relu_reg<BF16>(cx0.z); cx0.w = relu_reg<BF16>(cx0.w); \
-            cx1.x = relu_reg<BF16>(cx1.x); cx1.y = relu_reg<BF16>(cx1.y); cx1.z = relu_reg<BF16>(cx1.z); cx1.w = relu_reg<BF16>(cx1.w); \
+            cx0.x = relu_f32_lds(cx0.x); cx0.y = relu_f32_lds(cx0.y); cx0.z = relu_f32_lds(cx0.z); cx0.w = relu_f32_lds(cx0.w); \
+            cx1.x = relu_f32_lds(cx1.x); cx1.y = relu_f32_lds(cx1.y); cx1.z = relu_f32_lds(cx1.z); cx1.w = relu_f32_lds(cx1.w); \
         }                                                                                                        \
-        split8(cx0, cx1);                                                                                        \
+        split8_lds(cx0, cx1);                                                                                    \
         *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + rd0) = cx0;                                 \
         *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + rd1) = cx1;                                 \
     }

@@ -84,9 +84,30 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// 8 floats (the two 16-byte chunks a lane reads from an f32 A row) -> hi / lo f16x8 MFMA operands.  x - float(hi) runs on
-// v_fma_mix_f32 (f16 source operand, f32 result: one instruction instead of convert + subtract): 16 VALU per fragment.
+// 8 floats (the two 16-byte chunks a lane reads from an f32 A row) -> hi / lo f16x8 MFMA operands, in place (f0 <- hi, f1 <- lo).
+// Two forms with identical results (round to nearest even; x - float(hi) is exact in f32):
+//   split8      compiler-visible instructions only.  Its results may feed an MFMA in the next issue slot, and the VALU-write -> MFMA-read
+//               wait state is something only the compiler's hazard recogniser inserts -- it does not look inside inline asm (found the
+//               hard way: an inline-asm v_max_f32 in front of the f32 MFMAs left one fragment stale in 1/64 of the outputs).
+//   split8_lds  x - float(hi) on v_fma_mix_f32 (f16 source operand, f32 result: one instruction instead of convert + subtract), 16 VALU
+//               per 8 floats; for results that go to LDS or memory, never straight into an MFMA.
+typedef _Float16 half2v_ __attribute__((ext_vector_type(2)));
+typedef float float2v_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(uint4 &f0, uint4 &f1) {
+    const float x[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                        __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const half2v_ hh = __builtin_convertvector(float2v_{x[2 * p], x[2 * p + 1]}, half2v_);      // v_cvt_pk_f16_f32
+        const half2v_ ll = __builtin_convertvector(float2v_{x[2 * p] - (float)hh.x, x[2 * p + 1] - (float)hh.y}, half2v_);
+        h[p] = __builtin_bit_cast(unsigned, hh);
+        l[p] = __builtin_bit_cast(unsigned, ll);
+    }
+    f0 = make_uint4(h[0], h[1], h[2], h[3]);
+    f1 = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void split8_lds(uint4 &f0, uint4 &f1) {
     const float x[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
                         __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
     unsigned h[4], l[4];
@@ -100,6 +121,12 @@ __device__ __forceinline__ void split8(uint4 &f0, uint4 &f1) {
     }
     f0 = make_uint4(h[0], h[1], h[2], h[3]);
     f1 = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// max(x, 0) of an f32 value whose result goes to LDS / memory (one VALU; inline asm: see split8 for why not in front of an MFMA)
+__device__ __forceinline__ unsigned relu_f32_lds(unsigned x) {
+    unsigned r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 template <int BF16>
@@ -170,9 +197,7 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {
 template <int DT>
 __device__ __forceinline__ unsigned relu_reg(unsigned x) {
     if constexpr (is_f32io(DT)) {
-        unsigned r;   // one v_max_f32 (the sign-mask form is two VALU; fmaxf() under IEEE mode adds a canonicalisation)
-        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-        return r;
+        return x & ~(unsigned)((int)x >> 31);   // (compiler-visible on purpose: the result feeds an MFMA, see split8)
     } else if constexpr (DT == 0) {
         // f16: ONE packed max per register (relu2 is shift / and / quarter-rate 32-bit multiply / and-not: ~7 issue slots, and the
         // implicit-GEMM main loop applies this to 32 A-fragment registers per K-tile beside 64 MFMAs of a one-wave-per-SIMD kernel).

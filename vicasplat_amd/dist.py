@@ -92,7 +92,9 @@ class GradReducer:
     or copied back.  A post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its all-reduce is
     issued asynchronously (RCCL over xGMI runs it on its own stream while the backward kernels continue).  `finish()` launches
     the buckets that never completed (parameters without a gradient this step -- scratch.refinenet4.resConfUnit1 of both DPT
-    heads, SURVEY 2.2 -- contribute the zeros `zero_grad()` left there, so every rank reduces identical buckets) and waits.
+    heads, SURVEY 2.2 -- contribute the zeros `zero_grad()` left there, so every rank reduces identical buckets), waits, and leaves
+    `.grad = None` on those parameters (DDP's behaviour: AdamW then neither updates nor weight-decays them).  Buckets are launched
+    strictly in index order, whatever order the hooks fire in.
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring collectives are per-link bound, so buckets are large (64 MiB
     default -> ~36 collectives for the 2.31 GB gradient) rather than DDP's 25 MB.  `comm_dtype=torch.bfloat16` halves the bytes
@@ -104,6 +106,9 @@ class GradReducer:
         self.group, self.average, self.comm_dtype = group, average, comm_dtype
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         ps = [p for p in params if p.requires_grad]
+        for p in ps:
+            if p.dtype != torch.float32:
+                raise TypeError(f"GradReducer keeps f32 master gradients: parameter of dtype {p.dtype} (cast the module with .float())")
         self.params = ps[::-1]
         self.buckets: List[dict] = []
         cur, size = [], 0
@@ -128,7 +133,7 @@ class GradReducer:
         for p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, views=views, ready=0, launched=False,
+        self.buckets.append(dict(params=plist, flat=flat, views=views, ready=0, launched=False, got=[False] * len(plist),
                                  stage=torch.empty(n, dtype=self.comm_dtype, device=dev) if self.comm_dtype else None))
         for i, p in enumerate(plist):
             p._vs_bucket, p._vs_slot = len(self.buckets) - 1, i
@@ -137,10 +142,11 @@ class GradReducer:
         """Zero the flat buckets and (re)attach every p.grad as a view of its bucket."""
         for b in self.buckets:
             b["flat"].zero_()
-            b["ready"], b["launched"] = 0, False
+            b["ready"], b["launched"], b["got"] = 0, False, [False] * len(b["params"])
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
         self._pending = []
+        self._next = 0            # buckets are launched strictly in index order: every rank issues the same collective sequence
 
     def _launch(self, b):
         if b["launched"]:
@@ -160,14 +166,20 @@ class GradReducer:
         if p.grad is not v:      # someone replaced .grad (zero_grad(set_to_none=True)): fold it back
             v.copy_(p.grad)
             p.grad = v
-        b["ready"] += 1
-        if b["ready"] == len(b["params"]):
-            self._launch(b)
+        if not b["got"][p._vs_slot]:
+            b["got"][p._vs_slot] = True
+            b["ready"] += 1
+        # launch in INDEX order only (a bucket that completes before an earlier one waits for it): the order in which hooks fire may
+        # differ between ranks or steps, the order of the collectives must not
+        while self._next < len(self.buckets) and self.buckets[self._next]["ready"] == len(self.buckets[self._next]["params"]):
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def finish(self) -> int:
         """Issue what is left, wait for every collective, finish the averaging.  Returns the number of collectives of the step."""
-        for b in self.buckets:
+        for b in self.buckets[self._next:]:
             self._launch(b)
+        self._next = len(self.buckets)
         n = len(self._pending)
         for b, work in self._pending:
             work.wait()
@@ -176,6 +188,13 @@ class GradReducer:
             if self.average:
                 b["flat"] /= self.world
         self._pending = []
+        # parameters that received no gradient this step keep .grad = None, as under DDP: the optimizer skips them (a zero gradient
+        # would still be weight-decayed by AdamW every step).  The model's graph does not depend on the rank or the data, so the set is
+        # the same on every rank; the zeros they contributed to the buckets kept the collectives identical.  zero_grad() re-attaches.
+        for b in self.buckets:
+            for p, got in zip(b["params"], b["got"]):
+                if not got:
+                    p.grad = None
         return n
 
     def remove(self):
