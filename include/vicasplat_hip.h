@@ -167,6 +167,17 @@ int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *
                   int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
                   const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d, vs_stream_t stream);
 
+/* vs_conv7x7_rgb_nhwc on split operands: in_padded f32 [Nimg, Hp, Wp, 3] (+ one spare padded row + 64 spare floats), wp = packed
+ * [Cout, 8 * 32] (kernel row dy at columns dy * 32 + dx * 3 + c), out f32 [Nimg, H, W, Cout], Cout % 256 == 0 */
+int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp, float acc_scale, const float *bias, float *out, int32_t Nimg, int32_t H,
+                              int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, vs_stream_t stream);
+
+/* conv3x3(Cin -> 128) -> relu_out -> conv1x1(128 -> C2 <= 4) in one kernel on split operands (dot-product form of
+ * vs_conv3x3_head1x1_nhwc): in f32 NHWC, wp packed [128, 9 * Cin], w2 f32 [C2, 128], bias2 f32 [4], out2 f32 [N*H*W, ld2] */
+int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *w2, const float *bias2,
+                                   float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t ld2, int32_t relu_in,
+                                   int32_t relu_out, vs_stream_t stream);
+
 /* vs_conv3x3_nhwc on split operands: in / residual / out f32 NHWC, wp = packed [Cout, 9 * Cin] (tap-major, channel-minor; Cin % 32 == 0) */
 int vs_conv3x3_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *residual, float *out, int32_t Nimg,
                           int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,

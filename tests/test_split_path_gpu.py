@@ -259,6 +259,31 @@ def test_conv3x3_256_tile_kernel_with_relu_at_scale(cls):
                 assert e <= tol, (cls, relu_in, relu_out, with_res, e)
 
 
+def test_conv7x7_stem_and_fused_pts_head_split():
+    """The two remaining head kernels of the split class: the 7x7 RGB stem as a window GEMM on the f32 zero-bordered image
+    (dpt_gs_head.py:112-118) and conv3(128->128) -> ReLU -> conv1(128->3) of the pts3d head in one kernel (dpt_block.py:316-333)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(9)
+    frames = torch.randn(3, 3, 64, 96, generator=g).to(d)
+    w7 = (torch.randn(256, 3, 7, 7, generator=g) / math.sqrt(147)).to(d)
+    b7 = torch.randn(256, generator=g).to(d)
+    y = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), ops.pack_conv7x7_rgb_weight(w7, "split"), b7, 64, 96)
+    ref = F.conv2d(frames.double(), w7.double(), b7.double(), padding=3).permute(0, 2, 3, 1)
+    assert y.dtype == torch.float32 and _rel(y, ref) <= TOL
+    x = torch.randn(2, 32, 64, 128, generator=g).to(d)
+    w3 = (torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(9 * 128)).to(d)
+    b3 = torch.randn(128, generator=g).to(d)
+    w1 = torch.zeros(4, 128, device=d)
+    w1[:3] = (torch.randn(3, 128, generator=g) / math.sqrt(128)).to(d)
+    b1 = torch.zeros(4, device=d)
+    b1[:3] = torch.randn(3, generator=g).to(d)
+    out = ops.conv3x3_head1x1_nhwc(x, ops.pack_conv3x3_weight(w3, "split"), b3, w1, b1, 3)
+    h = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w3.double(), b3.double(), padding=1))
+    ref = F.conv2d(h, w1[:3].double()[:, :, None, None], b1[:3].double()).permute(0, 2, 3, 1)
+    assert out.shape == (2, 32, 64, 4) and out.dtype == torch.float32 and _rel(out[..., :3], ref) <= TOL
+
+
 def _model(kind):
     from vicasplat_amd.model.encoder import default_cfg, get_encoder
     shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))

@@ -406,7 +406,16 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
 // (wc = 0 / 1) through LDS; the activation is rounded to 16 bit first, as the unfused path stores it.  Output [pixels, ld2 >= 4] 16-bit.
 template <int BF16, int MI>
 __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int m0, int wr, int wc, float *red, int lane) {
+    // f32 activations (split operand class): w2 is an f32 [C2, Cout] array, nothing is rounded to 16 bit, the output row is 4 floats
+    constexpr bool F32 = is_f32io(BF16);
+    constexpr int D16 = F32 ? 0 : BF16;
     const int mrow = lane & 15, grp = lane >> 4;
+    if constexpr (BF16 == kDtSplit) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= g.acc_scale;
+    }
     float w2v[4][4][4], bv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -415,7 +424,10 @@ __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&a
             const int col = wc * 64 + j * 16 + grp * 4 + r;
             bv[j][r] = g.bias ? g.bias[col] : 0.0f;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) w2v[o][j][r] = o < g.C2 ? from16<BF16>(g.w2[(size_t)o * g.Cout + col]) : 0.0f;
+            for (int o = 0; o < 4; ++o) {
+                if constexpr (F32) w2v[o][j][r] = o < g.C2 ? reinterpret_cast<const float *>(g.w2)[(size_t)o * g.Cout + col] : 0.0f;
+                else w2v[o][j][r] = o < g.C2 ? from16<D16>(g.w2[(size_t)o * g.Cout + col]) : 0.0f;
+            }
         }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -426,7 +438,7 @@ __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&a
             for (int r = 0; r < 4; ++r) {
                 float v = acc[i][j][r] + bv[j][r];
                 if (g.relu_out == 1) v = fmaxf(v, 0.0f);
-                v = from16<BF16>(to16<BF16>(v));
+                if constexpr (!F32) v = from16<D16>(to16<D16>(v));
 #pragma unroll
                 for (int o = 0; o < 4; ++o) p[o] = fmaf(v, w2v[o][j][r], p[o]);
             }
@@ -447,10 +459,14 @@ __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&a
             const float4 q = *reinterpret_cast<const float4 *>(red + row * 4);
             const float o0 = acc[i][0][0] + q.x + g.bias2[0], o1 = acc[i][0][1] + q.y + g.bias2[1];
             const float o2 = acc[i][0][2] + q.z + g.bias2[2], o3 = acc[i][0][3] + q.w + g.bias2[3];
-            uint2 pk;
-            pk.x = pack16x2<BF16>(o0, o1);
-            pk.y = pack16x2<BF16>(o2, o3);
-            *reinterpret_cast<uint2 *>(g.out2 + ((size_t)m0 + row) * g.ld2) = pk;
+            if constexpr (F32) {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out2) + ((size_t)m0 + row) * g.ld2) = make_float4(o0, o1, o2, o3);
+            } else {
+                uint2 pk;
+                pk.x = pack16x2<D16>(o0, o1);
+                pk.y = pack16x2<D16>(o2, o3);
+                *reinterpret_cast<uint2 *>(g.out2 + ((size_t)m0 + row) * g.ld2) = pk;
+            }
         }
     }
 }
@@ -898,6 +914,25 @@ extern "C" int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const floa
         if (dtype == 2) hipLaunchKernelGGL((conv3x3_kernel<1, 8, true>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<0, 8, true>), grid, dim3(256), 0, stream, g);
     }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv3(Cin -> 128) -> ReLU -> conv1(128 -> C2 <= 3) of the pts3d head on split operands, one kernel (the dot-product form of
+// vs_conv3x3_head1x1_nhwc): in f32 NHWC, wp packed [128, 9 * Cin], w2 f32 [C2, 128], bias2 f32 [4], out2 f32 [N*H*W, ld2 >= 4, ld2 % 4 == 0];
+// N*H*W a multiple of 256, Cin a multiple of 32.
+extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *w2, const float *bias2,
+                                              float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t ld2, int32_t relu_in,
+                                              int32_t relu_out, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && wp && w2 && bias2 && out2 && acc_scale > 0.f, "vs_conv3x3_head_dot_split_nhwc: null pointer / bad scale");
+    const long long M = (long long)Nimg * H * W;
+    VS_CHECK(Nimg > 0 && H > 0 && W > 0 && H < 32767 && W < 65536 && M % 256 == 0 && M < 2147483647LL, "vs_conv3x3_head_dot_split_nhwc: N*H*W must be a positive multiple of 256");
+    VS_CHECK(Cin % 32 == 0 && C2 >= 1 && C2 <= 4 && ld2 >= 4 && ld2 % 4 == 0 && (relu_out == 0 || relu_out == 1), "vs_conv3x3_head_dot_split_nhwc: Cin %% 32, C2 <= 4, ld2 >= 4");
+    VS_CHECK((((uintptr_t)in | (uintptr_t)wp | (uintptr_t)out2 | (uintptr_t)bias2) & 15) == 0, "vs_conv3x3_head_dot_split_nhwc: 16-byte alignment required");
+    ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 128, relu_in, relu_out, H, W, 1,
+               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2, ld2, acc_scale};
+    hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8, true>), dim3((unsigned)(M / 256)), dim3(256), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;
 }

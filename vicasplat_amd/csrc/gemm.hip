@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
     WindowStager256 st;
-    st.kstep = 2ll * g.a_kstride;
+    // split operands: the image is f32, a 128-byte staged row is ONE kernel row (32 floats, 21 used) and K = 8 rows = 8 K-tiles
+    constexpr bool SPLIT = BF16 == kDtSplit;
+    st.kstep = SPLIT ? (long long)g.a_kstride : 2ll * g.a_kstride;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = unit_row256(wid, j, lane);
@@ -402,13 +404,14 @@ __global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
             const int ra_ = min(m0 + unit_a_tile_row256(q, h), g.M - 1);
             const int rg_ = ra_ / g.a_grp_in;
             const size_t arow = (size_t)rg_ * g.a_grp_out + (ra_ % g.a_grp_in) + (size_t)(rg_ / g.a_sup_in) * g.a_sup_extra;
-            st.pa[h][j] = A + arow * g.lda + (size_t)(c >> 2) * g.a_kstride + (c & 3) * 8;
+            st.pa[h][j] = SPLIT ? A + arow * g.lda + c * 8 : A + arow * g.lda + (size_t)(c >> 2) * g.a_kstride + (c & 3) * 8;
             const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.N - 1);
             st.pw[h][j] = W + (size_t)rw_ * g.ldw + c * 8;
         }
     }
     f4 acc[8][4];
-    mainloop256<BF16, false>(st, 4, acc, smem, lane, wid);
+    if constexpr (SPLIT) mainloop256_split<false>(st, 8, acc, smem, lane, wid);
+    else mainloop256<BF16, false>(st, 4, acc, smem, lane, wid);
     gemm_epilogue<BF16, 0, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 
@@ -908,6 +911,35 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     }
     const int rc = dtype == 2 ? launch_mi<true, 8>(g, 0, stream) : launch_mi<false, 8>(g, 0, stream);
     if (rc) return rc;
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// The 7x7 RGB stem on split operands (gemm_common.h, kDtSplit): in_padded is the f32 zero-bordered NHWC image [Nimg, Hp, Wp, 3] (plus one
+// spare padded row and 64 spare floats behind it), wp the vs_split_pack_weight image of the [Cout, 8 * 32] f32 weight (kernel row dy at
+// columns dy * 32 + dx * 3 + c, the rest zero), out f32 [Nimg, H, W, Cout]; Cout a multiple of 256.
+extern "C" int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp, float acc_scale, const float *bias, float *out, int32_t Nimg,
+                                         int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in_padded && wp && out && acc_scale > 0.f, "vs_conv7x7_rgb_split_nhwc: null pointer / bad scale");
+    VS_CHECK(Nimg >= 0 && H > 0 && W > 0 && Cout > 0 && Cout % 256 == 0, "vs_conv7x7_rgb_split_nhwc: bad sizes (Cout must be a multiple of 256)");
+    VS_CHECK(Hp >= H + 6 && Wp >= W + 6, "vs_conv7x7_rgb_split_nhwc: padded image must be at least (H+6) x (W+6), got %d x %d", Hp, Wp);
+    VS_CHECK((long long)Nimg * H * W < 2147483647LL && (long long)Nimg * Hp * Wp * 6 < 2147483647LL, "vs_conv7x7_rgb_split_nhwc: too large");
+    VS_CHECK((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(in_padded) & 3) == 0, "vs_conv7x7_rgb_split_nhwc: alignment");
+    if (Nimg == 0) return 0;
+    GemmArgs g;
+    g.A = in_padded; g.W = wp; g.bias = bias; g.out = out; g.gate = nullptr; g.resid = nullptr;
+    g.M = Nimg * H * W; g.N = Cout; g.K = 8 * 64;         // (2-byte units of the f32 rows)
+    g.lda = 6; g.ldw = 8 * 64; g.ldo = Cout;
+    g.grp_in = g.M; g.grp_out = g.M; g.grp_off = 0;
+    g.gate_rows = g.M; g.gate_ld = Cout;
+    g.m_lo = 0;
+    g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;
+    g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
+    g.a_kstride = Wp * 6;
+    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale;
+    hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -252,7 +252,16 @@ class PixelwiseTaskWithDPT(nn.Module):
         x, P = self._trunk(tokens, gh, gw)
         x = ops.conv3x3_nhwc(x, P["h0.w"], P["h0.b"])
         x = ops.upsample2x_nhwc(x)
-        if self.compute_dtype != torch.float32 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0:
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        if self.split and npix % 256 == 0 and x.shape[-1] == 128 and self.dpt.head[2].out_channels == 128:
+            # split operands: the same fusion in f32 (conv3 -> ReLU -> three 128-long dot products per pixel), w2 stays f32
+            if "h4f32.w" not in P:
+                c4 = self.dpt.head[4]
+                P["h4f32.w"] = torch.nn.functional.pad(c4.weight.detach().float().flatten(1), (0, 0, 0, 4 - c4.out_channels)).contiguous()
+                P["h4f32.b"] = torch.nn.functional.pad(c4.bias.detach().float(), (0, 4 - c4.out_channels)).contiguous()
+            y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f32.w"], P["h4f32.b"], 3)          # [BT,H,W,4] f32
+            return y[..., :3].permute(0, 3, 1, 2)
+        if self.compute_dtype != torch.float32 and npix % 256 == 0 and x.shape[-1] == 128:
             # conv3(128->128) -> ReLU -> conv1(128->3) in one kernel: the 128-channel activation at full resolution never reaches HBM
             y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f.w"], P["h4f.b"], 3)          # [BT,H,W,4]
             return y[..., :3].permute(0, 3, 1, 2)
@@ -274,13 +283,20 @@ class PixelwiseTaskWithDPT(nn.Module):
         dt = self.compute_dtype
         # 7x7 stem on the RGB image (dpt_gs_head.py:112-118): window GEMM on the zero-bordered NHWC frames, bias fused; its
         # ReLU is fused into the upsample-add kernel below
-        if dt == torch.float32:
+        if self.split and self.dpt.input_merger[0].out_channels % 256 == 0:
+            P = self._packed()
+            if "stem.ws7" not in P:
+                c7 = self.dpt.input_merger[0]
+                P["stem.ws7"], P["stem.b"] = ops.pack_conv7x7_rgb_weight(c7.weight, "split"), c7.bias.detach().float().contiguous()
+            img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], frames.shape[-2], frames.shape[-1])
+        elif dt == torch.float32:
             img = self._stem_f32(frames)
         else:
             P7 = self._stem_weights()
             img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
         x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
-        if dt != torch.float32 and self.num_channels <= 96 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0:
+        if (dt != torch.float32 and self.num_channels <= 96 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0
+                and self.dpt.head[0].out_channels == 256 and x.shape[-1] in (64, 128, 256, 512)):
             # conv3(256->256) -> ReLU -> conv1(256->83) in one kernel (dpt_block.py:335-343; Dropout(0.1) is the identity at inference)
             y = ops.conv3x3_head1x1_nhwc(x, P["h0.w"], None, P["h4f.w"], P["h4f.b"], self.num_channels)   # [BT,H,W,96]
             return y[..., :self.num_channels].permute(0, 3, 1, 2)

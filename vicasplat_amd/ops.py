@@ -361,6 +361,17 @@ def conv3x3_head1x1_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.
     """[N,H,W,Cin] 16-bit -> [N,H,W,ld2] 16-bit = conv1x1(act(conv3x3(x) + bias)) + bias2 in one kernel (vs_conv3x3_head1x1_nhwc): the
     last two layers of a DPT head.  w [Cout,3,3,Cin]; w2 [C2pad, Cout] (rows >= n_out zero) with bias2 [C2pad] for Cout = 256, or
     w2 [<= 4, 128] with bias2 [4] for Cout = 128.  The result keeps its padded channel stride (ld2 = w2 rows, or 4): slice it."""
+    if isinstance(w, SplitWeight):   # split operands: the dot-product form (Cout = 128, n_out <= 4), f32 in / out, w2 f32 [>= n_out, 128]
+        dev = L.require_device(x, w.data, bias, w2, bias2)
+        N, H, W, Cin = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32 and tuple(w.shape) == (128, 3, 3, Cin) and n_out <= 4
+        assert w2.dtype == torch.float32 and w2.is_contiguous() and w2.shape[1] == 128 and w2.shape[0] >= n_out and bias2.numel() >= 4
+        out = torch.empty((N, H, W, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv3x3_head_dot_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(w2), L.ptr(bias2), L.ptr(out), N, H, W,
+                                                        Cin, n_out, 4, 0, int(relu_out), L.stream_ptr(dev))
+        L.check(rc, "vs_conv3x3_head_dot_split_nhwc")
+        return out
     dev = L.require_device(x, w, bias, w2, bias2)
     assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and w2.is_contiguous() and x.dtype == w.dtype == w2.dtype
     assert x.dtype in (torch.float16, torch.bfloat16) and bias2.dtype == torch.float32 and bias2.is_contiguous()
@@ -396,9 +407,10 @@ def pack_conv7x7_rgb_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor
     (K = 256 for the 256x256 tile kernel; the 7-row route reads the same buffer with a row stride of 256)."""
     Cout = w.shape[0]
     assert w.shape == (Cout, 3, 7, 7)
-    wp = torch.zeros(Cout, 8, 32, dtype=dtype, device=w.device)
-    wp[:, :7, :21] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 7, 21).to(dtype)
-    return wp.contiguous()
+    split = dtype == "split"
+    wp = torch.zeros(Cout, 8, 32, dtype=torch.float32 if split else dtype, device=w.device)
+    wp[:, :7, :21] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 7, 21).to(wp.dtype)
+    return split_pack_weight(wp.reshape(Cout, 256)) if split else wp.contiguous()
 
 
 def pad_rgb_nhwc(frames: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -416,6 +428,18 @@ def pad_rgb_nhwc(frames: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], H: int, W: int) -> torch.Tensor:
     """img_padded from pad_rgb_nhwc, w from pack_conv7x7_rgb_weight -> [N,H,W,Cout] = conv2d(k=7, s=1, p=3) + bias."""
+    if isinstance(w, SplitWeight):     # split operands: f32 image, packed [Cout, 256] weight (pack_conv7x7_rgb_weight(w, "split"))
+        dev = L.require_device(img_padded, w.data, bias)
+        N, Hp, Wp, C = img_padded.shape
+        Cout = w.shape[0]
+        assert C == 3 and img_padded.is_contiguous() and img_padded.dtype == torch.float32 and tuple(w.shape) == (Cout, 256)
+        assert img_padded.untyped_storage().nbytes() >= (img_padded.storage_offset() + img_padded.numel() + Wp * 3 + 64) * 4
+        out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv7x7_rgb_split_nhwc(L.ptr(img_padded), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(out), N, H, W, Hp, Wp, Cout,
+                                                   L.stream_ptr(dev))
+        L.check(rc, "vs_conv7x7_rgb_split_nhwc")
+        return out
     dev = L.require_device(img_padded, w, bias)
     N, Hp, Wp, C = img_padded.shape
     Cout = w.shape[0]
