@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 MFMA leg")
     ap.add_argument("--no-fast", action="store_true", help="skip the 16-bit (f16) fast-path leg")
+    ap.add_argument("--no-targets70", action="store_true", help="skip the 70-view demo workload leg")
+    ap.add_argument("--dry-run-dist", action="store_true",
+                    help="no GPU work: run the N > 1 control flow of this file (process-group init from the launcher's environment, barriers, MAX-reduce of "
+                         "the elapsed time, the training leg's watchdog and one GradReducer exchange) on CPU with the gloo backend and print the JSON line")
     ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of the secondary precision legs")
     return ap.parse_args()
 
@@ -149,8 +153,78 @@ def train_leg(args, enc, dec, dev, rank, world, dist):
                               what="whole step: 3 x 3407 GFLOP per 8-view scene (fwd + 2x bwd, SURVEY 8d) / step time"))
 
 
+def dry_run_dist(args):
+    """The multi-rank control flow of main() / train_leg() with the GPU work replaced by a toy computation: what the driver's
+    `torch.distributed.run ... bench.py --gpus N` exercises before any kernel matters.  CPU, gloo, rendezvous on 127.0.0.1."""
+    import threading
+
+    import torch.distributed as dist
+    from vicasplat_amd import dist as vdist
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    B = args.scenes_per_gpu
+    g = torch.Generator().manual_seed(rank)
+    x = torch.randn(B, 32, 32, generator=g)                         # this rank's scene shard: scenes are sharded, no data-path collective
+
+    def step():
+        return (x @ x.transpose(1, 2)).sum()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # training leg: watchdog + overlapped gradient exchange on a toy replica
+    fired = []
+    dog = threading.Timer(args.train_timeout, lambda: fired.append(1))
+    dog.daemon = True
+    dog.start()
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+    reducer = vdist.GradReducer(model.parameters(), bucket_bytes=4096) if world > 1 else None
+    ncoll = 0
+    for _ in range(2):
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            model.zero_grad()
+        model(x.mean(1)).square().mean().backward()
+        if reducer is not None:
+            ncoll = reducer.finish()
+    chk = torch.stack([p.grad.double().sum() for p in model.parameters()])
+    same = True
+    if world > 1:
+        all_chk = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(all_chk, chk)
+        same = all(torch.equal(all_chk[0], c) for c in all_chk)
+    dog.cancel()
+    if rank == 0:
+        print(json.dumps(dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(world * B * args.steps / max(elapsed, 1e-9), 3), unit="scenes/s",
+                              n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
+                              scaling="weak", vs_baseline=None, dtype="dry run (CPU toy computation)", data="synthetic", dry_run=True,
+                              config=dict(workload="control-flow dry run: no kernel of the hot path is executed", scenes_per_gpu=B,
+                                          parallelism=f"scene-sharded x{world} (no collective)"),
+                              train=dict(gradient_exchange=("none (1 rank)" if world == 1 else f"GradReducer: {ncoll} bucket all-reduces launched during backward, gloo x{world}"),
+                                         replicas_identical=bool(same), watchdog_fired=bool(fired)))), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.dry_run_dist:
+        return dry_run_dist(args)
     if args.mode == "train":      # only the training leg is of interest: keep the forward part to one untimed-quality pass
         args.steps, args.warmup, args.no_roofline, args.no_cpu_baseline = 1, 0, True, True
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
@@ -186,15 +260,28 @@ def main():
     ctx = dict(image=img.to(dev), intrinsics=K.to(dev))
     tE, tK, tnear, tfar = target_cameras(B, Vt, dev)
 
+    # The rasterizer's exact mode copies its instance count back to size the sort buffers (one host synchronisation per batched call;
+    # upstream does it per view).  The bench step runs the CAPACITY mode instead: one untimed exact pass measures the
+    # instance count, the timed steps use buffers 1.25x that size and never touch the host; the device-side overflow flags of every timed
+    # call are checked after the timed region (an overflowed call would have rendered background only: the run is then invalid).
+    cap = {"n": None, "flags": []}
+
     def step():
         out = enc(ctx, compute_viewspace_depth=False)
         g = out["gaussians"]
         gs = Gaussians(g.means, g.covariances, g.harmonics, g.opacities)
-        r = dec(gs, tE, tK, tnear, tfar, (256, 256))
+        with raster.instance_capacity(cap["n"]) as scope:
+            r = dec(gs, tE, tK, tnear, tfar, (256, 256))
+        if cap["n"] is None:
+            cap["n"] = int(max(n for n, _ in scope.calls) * 1.25) + 65536
+        else:
+            cap["flags"].append(scope.overflow_flag())
         return out, r
 
-    for _ in range(args.warmup):
+    step()                                   # untimed: exact mode, sizes the capacity
+    for _ in range(max(0, args.warmup - 1)):
         step()
+    cap["flags"].clear()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -211,6 +298,8 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    if cap["flags"] and bool(torch.stack(cap["flags"]).max().item() != 0):
+        raise RuntimeError("a timed rasterizer call outgrew its instance capacity (it rendered background only): the measurement is invalid")
 
     roofline, extra = None, {}
     if rank == 0 and not args.no_roofline:
@@ -251,6 +340,7 @@ def main():
                    (raster, "_forward_impl", raster_meta)]
         saved = [(m, n, kt.wrap(m, n, f)) for m, n, f in wrapped]
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cap["n"] = None      # the instrumented step runs the rasterizer's exact mode: its state carries the true instance count R
         s.record(); out, r = step(); e.record()
         summ = kt.summary()
         for m, n, o in saved:
@@ -379,13 +469,18 @@ def main():
         try:
             enc.set_compute_dtype(DT[name])
             torch.cuda.empty_cache()
+            cap["n"] = None
+            step()                           # exact mode: sizes this precision's capacity
             step()
+            cap["flags"].clear()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.leg_steps):
                 o_, r_ = step()
             torch.cuda.synchronize()
             ms_ = (time.perf_counter() - t1) / args.leg_steps * 1e3
+            if cap["flags"] and bool(torch.stack(cap["flags"]).max().item() != 0):
+                raise RuntimeError("rasterizer capacity overflow in a timed step")
             tf_ = 3407e9 * (V / 8.0) * B / (ms_ * 1e-3) / 1e12
             leg = dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(B / (ms_ * 1e-3), 2), unit="scenes/s", dtype=name,
                        ms_per_step=round(ms_, 2), scenes_per_gpu=B, steps=args.leg_steps,
@@ -405,6 +500,61 @@ def main():
             enc.set_compute_dtype(dt)
             torch.cuda.empty_cache()
 
+    # ---- the demo workload (demo.py:204-243, SURVEY 8d "report both"): 70 novel views per scene -- 10 cameras interpolated on each of the
+    # 7 intervals between the 8 PREDICTED context cameras -- all sharing the scene's one Gaussian set (one batched rasterizer call, no
+    # replication).  Same encoder pass, same precision as the headline; N = 1 only. ----
+    def targets70_leg():
+        try:
+            from vicasplat_amd import callers
+            t_ = torch.linspace(0, 1, 10, dtype=torch.float32, device=dev)
+            n70 = (V - 1) * 10
+            near70, far70 = torch.full((B, n70), 0.01, device=dev), torch.full((B, n70), 100.0, device=dev)
+            cap70 = {"n": None, "flags": []}
+            K_host = ctx["intrinsics"].float().cpu()
+
+            def step70():
+                out = enc(ctx, compute_viewspace_depth=False)
+                # the camera path is host code in the demo too (a few hundred 4x4 matrices; on the device its float64 least-squares solves
+                # cost more than the whole render): predicted poses -> host -> 70 cameras per scene -> device
+                P_ = out["gaussian_camera_extrins"].cpu()
+                tc = t_.cpu()
+                E70 = callers.interpolate_extrinsics(P_[:, :-1].reshape(-1, 4, 4), P_[:, 1:].reshape(-1, 4, 4), tc).reshape(B, n70, 4, 4).float().to(dev)
+                Kc = K_host
+                K70 = callers.interpolate_intrinsics(Kc[:, :-1].reshape(-1, 3, 3), Kc[:, 1:].reshape(-1, 3, 3), tc).reshape(B, n70, 3, 3).float().to(dev)
+                g = out["gaussians"]
+                with raster.instance_capacity(cap70["n"]) as scope:
+                    r = dec(Gaussians(g.means, g.covariances, g.harmonics, g.opacities), E70, K70, near70, far70, (256, 256))
+                if cap70["n"] is None:
+                    cap70["n"] = int(max(n for n, _ in scope.calls) * 1.25) + 65536
+                    cap70["R"] = max(n for n, _ in scope.calls)
+                else:
+                    cap70["flags"].append(scope.overflow_flag())
+                return r
+
+            step70(); step70()
+            cap70["flags"].clear()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_ = max(2, args.leg_steps // 2)
+            for _ in range(n_):
+                step70()
+            torch.cuda.synchronize()
+            ms_ = (time.perf_counter() - t1) / n_ * 1e3
+            if cap70["flags"] and bool(torch.stack(cap70["flags"]).max().item() != 0):
+                raise RuntimeError("rasterizer capacity overflow in a timed step")
+            return dict(metric="scenes/sec (8-view 256x256) encode + 70 interpolated novel views", value=round(B / (ms_ * 1e-3), 2), unit="scenes/s",
+                        dtype=DTYPE_NOTE[args.dtype], ms_per_step=round(ms_, 2), steps=n_, scenes_per_gpu=B, views_per_scene=n70,
+                        rendered_views=B * n70, num_rendered=int(cap70["R"]),
+                        workload="demo.py:204-243: per scene 70 cameras interpolated between the predicted context poses, one Gaussian set")
+        except Exception as e:
+            return dict(error=repr(e)[:300])
+        finally:
+            torch.cuda.empty_cache()
+
+    targets70 = None
+    if rank == 0 and world == 1 and args.mode != "train" and not args.no_targets70:
+        targets70 = targets70_leg()
+
     f32_path = fast_path = None
     if rank == 0 and world == 1 and args.mode != "train":
         if not args.no_fast and args.dtype not in ("f16", "bf16"):
@@ -419,7 +569,7 @@ def main():
                     config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
                                          f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
                                 parallelism=f"scene-sharded x{world} (no collective)"),
-                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, fast_path=fast_path, f32_path=f32_path, train=train, **extra)
+                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, targets70=targets70, fast_path=fast_path, f32_path=f32_path, train=train, **extra)
 
     train = None
     if args.mode in ("train", "both"):

@@ -39,14 +39,39 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-def _check(name, dt, tol_pose, tol_raw):
+PROBE = [0, 1, 7, 100, 1000, 5000, 20000, 50000]      # flat indices of the goldens' per-block checksums (gen_encoder_golden.py)
+
+
+def block_drift(z, probes):
+    """Per-block distance to the reference's float64 block outputs (goldens' f64_blocks: mean, mean |x|, 8 probed elements of every
+    encoder / decoder block's output stream), relative to the block's mean |x|: localises a drift to the block where it starts."""
+    names = [str(n) for n in z["f64_block_names"]]
+    worst = {}
+    for n, row in zip(names, z["f64_blocks"]):
+        t = probes[n].double().flatten()
+        got = torch.cat([t.mean()[None], t.abs().mean()[None], t[torch.tensor([p % t.numel() for p in PROBE], device=t.device)]]).cpu().numpy()
+        worst[n] = float(np.abs(got - row).max() / row[1])
+    return worst
+
+
+def _check(name, dt, tol_pose, tol_raw, tol_block=None):
     z = np.load(os.path.join(G, f"encoder_{name}.npz"))
     kind = "tiny_noint" if name.startswith("tiny_noint") else "tiny" if name.startswith("tiny") else "full"
     m = _model(kind, dt)
     B, V = int(z["cfg_B"]), int(z["cfg_V"])
     img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    probes = {}
+    m.backbone._probe = lambda n, t: probes.__setitem__(n, t.detach().clone())
     out = m(dict(image=img.cuda(), intrinsics=K.cuda()), compute_viewspace_depth=False)
+    m.backbone._probe = None
     torch.cuda.synchronize()
+    if "f64_blocks" in z.files:
+        drift = block_drift(z, probes)
+        first_bad = next((n for n in sorted(drift) if tol_block is not None and drift[n] > tol_block), None)
+        print(name, dt, "block drift: max %.2e at %s; enc23 %.2e, last dec img %.2e cam %.2e" % (
+            max(drift.values()), max(drift, key=drift.get), drift.get("enc23", drift.get("enc01", 0.0)), drift[sorted(k for k in drift if k.endswith("_img"))[-1]],
+            drift[sorted(k for k in drift if k.endswith("_cam"))[-1]]))
+        assert first_bad is None, (first_bad, drift[first_bad], tol_block)
     errs = dict(pose=_rel(out["pred_extrins"].cpu(), z["f64_pred_extrins"]), c2w=_rel(out["gaussian_camera_extrins"].cpu(), z["f64_c2w"]))
     raw = out["raw_gaussians"][:, :, LAT, LAT].cpu().numpy()
     for nm, sl in (("xyz", slice(0, 3)), ("opacity", slice(3, 4)), ("scale", slice(4, 7)), ("quat", slice(7, 11)), ("sh", slice(11, 86))):

@@ -85,25 +85,27 @@ def align_poses(decoder, gaussians, target_image: Tensor, extrinsics: Tensor, in
     from . import raster
     ext0 = extrinsics.clone()
 
-    def run(sync_free: bool):
-        extr = ext0.clone()
-        history, overflow, cap = [], None, None
-        with torch.no_grad():
-            rot.zero_(); trans.zero_()
-        opt_ = torch.optim.Adam([{"params": [rot], "lr": rot_lr}, {"params": [trans], "lr": trans_lr}])
+    def run(sync_free: bool, cap=None, start=0, extr=None, history=None):
+        """Steps start.. of the alignment.  sync_free: after the first (exact) render the steps run in the capacity mode; the overflow
+        flags of ALL rasterizer calls of a step are accumulated on the device (raster.CapacityScope) and read once at the end."""
+        extr = ext0.clone() if extr is None else extr
+        history = [] if history is None else history
+        flags = []
+        if start == 0:
+            with torch.no_grad():
+                rot.zero_(); trans.zero_()
         with torch.enable_grad():
-            for it in range(steps):
+            for it in range(start, steps):
                 opt_.zero_grad()
-                # the first render runs in the exact mode and tells how many (Gaussian, tile) instances these cameras produce; the other
-                # 99 run without the per-call host synchronisation, in buffers 1.5x that size (the poses move by millimetres per step)
-                with raster.instance_capacity(cap if (sync_free and it > 0) else None):
+                # the first render runs in the exact mode and tells how many (Gaussian, tile) instances these cameras produce; the others
+                # run without the per-call host synchronisation, in buffers 1.5x that size (the poses move by millimetres per step)
+                with raster.instance_capacity(cap if (sync_free and it > 0) else None) as scope:
                     out = decoder.forward(gaussians, extr, intrinsics, near, far, (h, w), cam_rot_delta=rot, cam_trans_delta=trans)
-                info = raster.last_call()
-                if sync_free and info is not None:
+                if sync_free and scope.calls:
                     if it == 0:
-                        cap = int(info["num_rendered"] * 1.5) + 65536
+                        cap = int(max(r for r, _ in scope.calls) * 1.5) + 65536
                     else:
-                        overflow = info["misc"][2] if overflow is None else torch.maximum(overflow, info["misc"][2])
+                        flags.append(scope.overflow_flag())
                 loss = mse_loss(out.color, target_image, mse_weight)
                 loss.backward()
                 history.append(loss.detach())
@@ -112,10 +114,12 @@ def align_poses(decoder, gaussians, target_image: Tensor, extrinsics: Tensor, in
                     extr = update_pose(trans.flatten(0, 1), rot.flatten(0, 1), extr.flatten(0, 1)).unflatten(0, (b, v))
                     rot.zero_()
                     trans.zero_()
-        return extr, history, (overflow is not None and bool(overflow.item() != 0))
+        return extr, history, (bool(torch.stack(flags).max().item() != 0) if flags else False)
 
+    opt_ = torch.optim.Adam([{"params": [rot], "lr": rot_lr}, {"params": [trans], "lr": trans_lr}])
     extrinsics, history, overflowed = run(True)
-    if overflowed:      # some step outgrew the buffers (its render was empty): repeat with exact sizing
+    if overflowed:      # some step outgrew the buffers (its render was empty): repeat with exact sizing (fresh optimizer state)
+        opt_ = torch.optim.Adam([{"params": [rot], "lr": rot_lr}, {"params": [trans], "lr": trans_lr}])
         extrinsics, history, _ = run(False)
     return (extrinsics, torch.stack(history)) if return_history else extrinsics
 
@@ -532,7 +536,7 @@ class LossScaler:
 
 def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, compute_dtype: torch.dtype = torch.float16,
                   loss_scale: float | LossScaler | None = None, clip: float = 0.5, mse_weight: float = 1.0, camera_weight: float = 0.0,
-                  extra_losses=(), allreduce: bool = False, reducer=None, global_step: int = 0) -> dict:
+                  extra_losses=(), allreduce: bool = False, reducer=None, global_step: int = 0, forward_fn=None) -> dict:
     """One optimisation step of the reference's objective (training_step, model_wrapper.py:184-321): MSE (loss_mse.py) + camera
     dual-quaternion loss (loss_camera.py, `camera_weight` > 0 and batch["context"]["extrinsics"] present) + `extra_losses`
     (callables (render, batch, out) -> scalar; the reference's LPIPS term needs VGG weights that are not available offline and plugs
@@ -545,8 +549,12 @@ def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, c
     `loss_scale`: a LossScaler (dynamic; default: one kept on the optimizer), or a fixed float.  f16 needs it for the 16-bit
     activation gradients; gradients are unscaled before clipping; an overflowed step is skipped, its gradients dropped.
     Gradient exchange: `reducer` (vicasplat_amd.dist.GradReducer: buckets all-reduced DURING backward, RCCL over xGMI) or
-    allreduce=True (bucketed all-reduce after backward)."""
-    from .model.encoder.train_forward import forward_train
+    allreduce=True (bucketed all-reduce after backward).  The skip decision of an overflowed step is taken from the norm of the
+    REDUCED gradients, so every rank takes the same decision (an inf / nan on one rank reaches all of them through the sum).
+    `forward_fn(encoder, image, intrinsics, compute_dtype, global_step=) -> dict` replaces the HIP training forward (tests drive the
+    step's control flow -- loss scaling, gradient exchange, clipping, skipping -- with a toy encoder / decoder on CPU)."""
+    if forward_fn is None:
+        from .model.encoder.train_forward import forward_train as forward_fn
     ctx, tgt = batch["context"], batch["target"]
     if loss_scale is None:
         loss_scale = getattr(optimizer, "_vs_loss_scaler", None)
@@ -557,7 +565,7 @@ def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, c
         reducer.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=True)
-    out = forward_train(encoder, ctx["image"], ctx["intrinsics"], compute_dtype, global_step=global_step)
+    out = forward_fn(encoder, ctx["image"], ctx["intrinsics"], compute_dtype, global_step=global_step)
     g = out["gaussians"]
     gs = Gaussians(g["means"].flatten(1, 3), g["covariances"].flatten(1, 3), g["harmonics"].flatten(1, 3), g["opacities"].flatten(1))
     h, w = tgt["image"].shape[-2:]

@@ -122,6 +122,7 @@ class VicaNet(nn.Module):
         self.camera_extrinsic_token = nn.Parameter(torch.empty(dec_embed_dim).normal_(std=0.02))
         self.camera_intrinsic_token = nn.Parameter(torch.empty(dec_embed_dim).normal_(std=0.02))
         self.gradient_checkpointing = False
+        self._probe = None    # test hook: callable(name, tensor) on every block's output stream (enc%02d, dec%02d_img, dec%02d_cam)
         self._init_weights()
         self._w16: dict = {}
         self._w16_key = None
@@ -251,6 +252,8 @@ class VicaNet(nn.Module):
             ops.layernorm_mod(xe, blk.norm2.weight, blk.norm2.bias, h)
             ops.gemm(h, W[f"e{i}.fc1"], blk.mlp.fc1.bias, hid, ops.EPI_GELU16)
             ops.gemm(hid, W[f"e{i}.fc2"], blk.mlp.fc2.bias, xe, ops.EPI_RESID32)
+            if self._probe is not None:
+                self._probe(f"enc{i:02d}", xe)
         enc16 = torch.empty(BT * N, Ce, **f16)
         ops.layernorm_mod(xe, self.enc_norm.weight, self.enc_norm.bias, enc16)
         del h, qkv, att, hid
@@ -306,6 +309,9 @@ class VicaNet(nn.Module):
             ops.gemm(hid, W[f"d{i}.fc2"], blk.mlp.fc2.bias, xd, ops.EPI_RESID32, gate=mod2[:, 5 * Cd:], gate_rows=N)
             ops.gemm(cn16, W[f"d{i}.cfc1"], blk.mlp_cam.fc1.bias, chid, ops.EPI_GELU16)
             ops.gemm(chid, W[f"d{i}.cfc2"], blk.mlp_cam.fc2.bias, cam, ops.EPI_RESID32)
+            if self._probe is not None:
+                self._probe(f"dec{i:02d}_img", xd)
+                self._probe(f"dec{i:02d}_cam", cam)
             if (i + 1) in hooks and (i + 1) != cfg.dec_depth:
                 inter[i + 1] = xd.view(B, T, N, Cd)[:, :, :n].to(dt, copy=True)   # (copy: xd keeps changing, and dt may be f32)
         last = torch.empty(BT * N, Cd, **f16)

@@ -27,18 +27,41 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _hint = threading.local()
 
 
+class CapacityScope:
+    """What `instance_capacity` yields: the record of EVERY rasterizer call made inside the context (a decoder may issue several per
+    forward, or none), not only the most recent one."""
+
+    def __init__(self, n):
+        self.n = n
+        self.calls: list = []      # per call: (host num_rendered, device int64[4] misc = [R, largest tile, overflow flag, 0])
+
+    def overflow_flag(self):
+        """Device int64 scalar: non-zero when some call of the scope needed more than its capacity (it rendered background only).  No
+        host synchronisation: read it whenever the caller next synchronises.  None if no call was made."""
+        flags = [m[2] for _, m in self.calls]
+        return None if not flags else torch.stack(flags).max()
+
+    def instances(self):
+        """Device int64 scalar: the largest instance count any call of the scope needed (exact mode: produced)."""
+        cnt = [m[0] for _, m in self.calls]
+        return None if not cnt else torch.stack(cnt).max()
+
+
 @contextlib.contextmanager
 def instance_capacity(n: Optional[int]):
     """Inside this context every rasterizer call runs in the CAPACITY mode of vs_raster_forward (include/vicasplat_hip.h): buffers sized
     for `n` (Gaussian, tile) instances, NO host synchronisation per call (the exact mode copies the instance count back, as upstream's
-    extension does per view).  A call that needs more than `n` renders nothing and raises the device-side flag that `overflow_flag()`
-    returns; the caller checks it whenever it next synchronises and repeats with a larger capacity (callers.align_poses does)."""
-    prev = getattr(_hint, "n", None)
-    _hint.n = None if n is None else int(n)
+    extension does per view).  A call that needs more than `n` renders nothing and raises a device-side flag; the yielded CapacityScope
+    accumulates the flags and counts of ALL calls of the context (`overflow_flag()`, `instances()`), which the caller reads whenever
+    it next synchronises, repeating with a larger capacity on overflow (callers.align_poses, bench.py).  n = None: exact mode (the scope
+    still records the calls)."""
+    prev, prev_scope = getattr(_hint, "n", None), getattr(_hint, "scope", None)
+    scope = CapacityScope(None if n is None else int(n))
+    _hint.n, _hint.scope = scope.n, scope
     try:
-        yield
+        yield scope
     finally:
-        _hint.n = prev
+        _hint.n, _hint.scope = prev, prev_scope
 
 
 def last_call() -> Optional[dict]:
@@ -84,6 +107,8 @@ def _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, pr
     if n_touched is None:
         n_touched = torch.zeros((Cn, P), dtype=torch.int32, device=dev)
     _hint.last = dict(num_rendered=int(R), misc=alloc.tensors[L.VS_BUF_MISC].view(torch.int64)[:4])
+    if getattr(_hint, "scope", None) is not None:
+        _hint.scope.calls.append((int(R), _hint.last["misc"]))
     state = dict(inp=inp, out=out, alloc=alloc, dims=(S, P, Cn, M, H, W, cov33), num_rendered=int(R),
                  keep=(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
                        cam_scene, color, depth, opacity, radii))
