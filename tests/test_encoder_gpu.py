@@ -39,6 +39,9 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+# f16 bounds = 1.5 x the largest value measured over the five golden configurations (round 3, vs the reference's float64 run: pose 1.1e-3 /
+# c2w 1.9e-3, raw and adapter quantities <= 5.2e-3, covariances <= 1.35e-2, per-block drift <= 4.0e-3): (pose, raw, block, covariances)
+F16_TOL = (3e-3, 8e-3, 6e-3, 2e-2)
 PROBE = [0, 1, 7, 100, 1000, 5000, 20000, 50000]      # flat indices of the goldens' per-block checksums (gen_encoder_golden.py)
 
 
@@ -54,7 +57,7 @@ def block_drift(z, probes):
     return worst
 
 
-def _check(name, dt, tol_pose, tol_raw, tol_block=None):
+def _check(name, dt, tol_pose, tol_raw, tol_block=None, tol_cov=None):
     z = np.load(os.path.join(G, f"encoder_{name}.npz"))
     kind = "tiny_noint" if name.startswith("tiny_noint") else "tiny" if name.startswith("tiny") else "full"
     m = _model(kind, dt)
@@ -81,8 +84,9 @@ def _check(name, dt, tol_pose, tol_raw, tol_block=None):
         errs["g_" + k] = _rel(getattr(g, k)[:, :, LAT, LAT].cpu().numpy(), z[f"f64_{k}"])
     print(name, dt, {k: f"{v:.2e}" for k, v in errs.items()})
     assert errs["pose"] <= tol_pose and errs["c2w"] <= tol_pose, errs
-    for k in ("xyz", "opacity", "scale", "quat", "sh", "g_means", "g_covariances", "g_harmonics", "g_opacities"):
+    for k in ("xyz", "opacity", "scale", "quat", "sh", "g_means", "g_harmonics", "g_opacities"):
         assert errs[k] <= tol_raw, (k, errs)
+    assert errs["g_covariances"] <= (tol_cov if tol_cov is not None else tol_raw), errs      # (R S)(R S)^T squares the scale error
     assert out["raw_gaussians"].shape == (B, V, 256, 256, 86) and g.covariances.shape == (B, V, 256, 256, 3, 3)
     if kind == "tiny_noint":
         e_fov = _rel(out["pred_intrins"].cpu(), z["f64_pred_intrins"])
@@ -105,22 +109,22 @@ def test_state_dict_is_the_reference_abi():
 
 @pytest.mark.parametrize("name", ["tiny_v2", "tiny_v3"])
 def test_encoder_tiny_matches_reference(name):
-    _check(name, torch.float16, 5e-3, 3e-2)
+    _check(name, torch.float16, *F16_TOL)
 
 
 def test_encoder_without_intrinsic_embedding_matches_reference():
     """use_intrinsic_embedding=false (the released *_no_intrin checkpoints, README.md:51-53): 256 tokens per frame, global scope for
     camera token 0, fov head; goldens from the real reference built with that flag."""
-    _check("tiny_noint_v3", torch.float16, 5e-3, 3e-2)
+    _check("tiny_noint_v3", torch.float16, *F16_TOL)
 
 
 def test_encoder_full_vitl_2view_matches_reference():
-    _check("full_v2", torch.float16, 5e-3, 3e-2)
+    _check("full_v2", torch.float16, *F16_TOL)
 
 
 def test_encoder_full_vitl_8view_matches_reference():
     """BASELINE.json bench configuration: 8 context views, ViT-L, 524 288 Gaussians."""
-    _check("full_v8", torch.float16, 5e-3, 3e-2)
+    _check("full_v8", torch.float16, *F16_TOL)
 
 
 def test_encoder_full_vitl_2view_batch16_matches_reference():
@@ -144,8 +148,8 @@ def test_encoder_full_vitl_2view_batch16_matches_reference():
     for k in ("means", "covariances", "harmonics", "opacities"):
         errs["g_" + k] = _rel(getattr(g, k)[5:6, :, LAT, LAT].cpu().numpy(), z[f"f64_{k}"])
     print({k: f"{v:.2e}" for k, v in errs.items()})
-    assert errs["pose"] <= 5e-3, errs
-    assert all(errs[k] <= 3e-2 for k in errs if k != "pose"), errs
+    assert errs["pose"] <= F16_TOL[0], errs
+    assert all(errs[k] <= F16_TOL[1] for k in errs if k not in ("pose", "g_covariances")) and errs["g_covariances"] <= F16_TOL[3], errs
     assert bool(torch.isfinite(out["raw_gaussians"]).all()) and bool(torch.isfinite(out["pred_extrins"]).all())
 
 

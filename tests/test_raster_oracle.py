@@ -179,6 +179,59 @@ def test_c_oracle_backward_matches_autograd():
     close(bwd["tau"], tau.grad.numpy(), "tau", rtol=5e-3)
 
 
+def test_single_isotropic_gaussian_backward_known_answer():
+    """Closed-form gradients of ONE isotropic Gaussian on the optical axis -- the backward counterpart of
+    test_single_isotropic_gaussian_known_answer; the rasterizer parity stays UNPINNED against upstream (no source in the reference tree),
+    these vectors pin the oracle's backward against SURVEY Appendix B.5 written out by hand:
+      C_r(p) = c_r alpha,  alpha = o G,  G = exp(-(dx^2 + dy^2) / (2 v)),  v = (f sigma / Z)^2 + 0.3   [B.1 dilation, B.3 alpha]
+      dL/do = c_r G                       [B.5: dL/dopacity += G dL/dalpha, dL/dalpha = c T dL/dC]
+      dL/dSH[0, r] = C0 alpha             [B.5: dL/drgb += alpha T dL/dC; band 0 = C0 * coefficient + 0.5]
+      dL/dx_c = c_r o G (-dx / v), dx = x_c - x_p   -> means2D = dL/dx_c * W/2   [B.5: dG/dDelta (W/2, H/2)]
+      dL/dX = dL/dx_c f / Z  (x_c = f X / Z + (W-1)/2);  dL/dZ = dalpha/dv dv/dZ,  dv/dZ = -2 (f sigma)^2 / Z^3
+      dL/dSigma_xx = c_r o G dx^2 / (2 v^2) (f/Z)^2,  dL/dSigma_xy = c_r o G dx dy / v^2 (f/Z)^2   (J's third column vanishes on the axis)
+      dL/dtau = (g, p x ... ): left perturbation T' = Exp(tau) T: dp = rho + theta x p, p = (0, 0, Z) -> (gX, gY, gZ, -Z gY, Z gX, 0)."""
+    W = H = 64
+    cam = _cam()
+    sig, Z, o_, c = 0.05, 2.0, 0.8, np.array([0.9, 0.4, 0.1])
+    C0 = 0.28209479177387814
+    sh = np.zeros((1, 25, 3), np.float32)
+    sh[0, 0] = (c.astype(np.float32) - 0.5) / C0
+    means = np.array([[0, 0, Z]], np.float32)
+    cov = _iso(1, sig * sig)
+    op = np.array([o_], np.float32)
+    bg = np.zeros(3, np.float32)
+    fwd = rr.rasterize_forward(cam, W, H, bg, means, cov, sh, op)
+    px, py = 33, 31                                  # pixel offsets from the projected centre (31.5, 31.5): dx = x_c - x_p = -1.5, dy = +0.5
+    gC = np.zeros((3, H, W), np.float32)
+    gC[0, py, px] = 1.0                              # L = C_r(px, py)
+    bwd = rr.rasterize_backward(cam, W, H, bg, means, cov, sh, op, fwd, gC, np.zeros((H, W), np.float32))
+    f = W / (2 * cam.tanfovx)
+    v = (f * sig / Z) ** 2 + 0.3
+    dx, dy = 31.5 - px, 31.5 - py
+    G = math.exp(-0.5 * (dx * dx + dy * dy) / v)
+    cr = float(c[0])
+    assert np.isclose(fwd["color"][0, py, px], cr * o_ * G, rtol=1e-5)
+    rel = lambda a, b: abs(a - b) <= 2e-5 * max(abs(b), 1e-12) + 1e-9
+    assert rel(bwd["opacities"][0], cr * G)
+    # colour = 0.5 + sum_k SH_k Y_k(dir), dir = (0, 0, 1): dL/dSH_k = Y_k(dir) alpha for the red channel, nothing for green / blue;
+    # Y_0 = C0, band 1 = (-C1 y, C1 z, -C1 x) -> only its z term, band 4 is never read (B.1)
+    assert rel(bwd["shs"][0, 0, 0], C0 * o_ * G) and np.abs(bwd["shs"][0, :, 1:]).max() == 0
+    assert rel(bwd["shs"][0, 2, 0], 0.4886025119029199 * o_ * G) and bwd["shs"][0, 1, 0] == 0 and bwd["shs"][0, 3, 0] == 0
+    assert np.abs(bwd["shs"][0, 16:]).max() == 0
+    gxc, gyc = cr * o_ * G * (-dx / v), cr * o_ * G * (-dy / v)
+    assert rel(bwd["means2D"][0, 0], gxc * W / 2) and rel(bwd["means2D"][0, 1], gyc * H / 2)
+    gX, gY = gxc * f / Z, gyc * f / Z
+    gZ = cr * o_ * G * (0.5 * (dx * dx + dy * dy) / v ** 2) * (-2 * (f * sig) ** 2 / Z ** 3)
+    assert rel(bwd["means3D"][0, 0], gX) and rel(bwd["means3D"][0, 1], gY) and rel(bwd["means3D"][0, 2], gZ)
+    a = (f / Z) ** 2
+    want6 = [cr * o_ * G * dx * dx / (2 * v * v) * a, cr * o_ * G * dx * dy / (v * v) * a, 0.0, cr * o_ * G * dy * dy / (2 * v * v) * a, 0.0, 0.0]
+    for k in range(6):
+        assert rel(bwd["cov3D"][0, k], want6[k]) or abs(bwd["cov3D"][0, k] - want6[k]) <= 1e-7 * abs(want6[0]), (k, bwd["cov3D"][0], want6)
+    want_tau = [gX, gY, gZ, -Z * gY, Z * gX, 0.0]
+    for k in range(6):
+        assert abs(bwd["tau"][k] - want_tau[k]) <= 3e-5 * max(abs(t) for t in want_tau), (k, bwd["tau"], want_tau)
+
+
 def test_autograd_tau_matches_finite_differences():
     # pins the twist convention itself: T_cw' = Exp(tau) T_cw, all of view/proj/campos derived from it
     W, H = 32, 32

@@ -462,6 +462,8 @@ def camera_loss(pred_extrins: Tensor, context_extrinsics: Tensor, weight: float 
 # has them.  Without weights the constructor raises; nothing is silently substituted.  The loss network runs on PyTorch convolutions (it
 # is not part of the encoder / rasterizer hot path and has no counterpart kernel in this library).
 # ---------------------------------------------------------------------------------------------------------------------------
+# STATUS: UNVERIFIED -- no reference weights, package or fixture exists offline, so nothing pins this class against `lpips.LPIPS`; it is
+# NOT part of any parity claim and does NOT count toward SURVEY 8(f)-4.  It is kept as a plug-in point (`extra_losses`).
 class LossLpips(torch.nn.Module):
     """LPIPS with the VGG-16 backbone ("vgg" variant, v0.1): inputs in [0, 1] (`normalize=True` of loss_lpips.py:48-52), scaling layer,
     the five ReLU taps relu1_2 / 2_2 / 3_3 / 4_3 / 5_3, channel-unit-normalised squared differences, non-negative 1x1 linear heads, spatial
