@@ -662,6 +662,11 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
     }
 }
 
+
+// (Measured and not kept, round 3: a resident variant -- one 8-wave workgroup per (frame, head), all K / V converted once into 153 KiB of
+// LDS -- runs the frame encoder's 257 x 257 attention at the same 28 ms per step as this tiled kernel: the time is the per-group softmax /
+// split VALU work and the 3 x MFMAs, not the re-staging.)
+
 }  // namespace
 
 // ---- reference-precision attention (f32 q | k | v and output, exact f32 MFMA v_mfma_f32_16x16x4_f32; DESIGN 2 "f32 path") ----
