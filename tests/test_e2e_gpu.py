@@ -104,3 +104,56 @@ def test_config1_2view_4targets_f16_vs_oracle_f64():
 def test_config4_8view_12targets_f16_vs_oracle_f32():
     """Config 4 forward: one 8-view scene, 524 288 Gaussians, 12 target cameras."""
     _bounds(*_run(8, 12, torch.float16), max_flip_frac=0.16)
+
+
+# ---- the CONDITIONED synthetic checkpoint (VERDICT r2 item 1c; vicasplat_amd/synthetic.py conditioned_weights): residual branches damped,
+# SH DC tied to the input pixel, Gaussians a few pixels wide and translucent.  On it the render is a smooth function of the network's outputs
+# and the render PSNR separates the precision classes by tens of dB, so the 16-bit path gets ABSOLUTE bounds (on the plain random-init
+# scene above every TF32-class evaluation, the reference's own included, decorrelates to 19-21 dB and only relative bounds are possible).
+# Measured (round 3, HIP vs exact-f32 HIP / oracle): split 90-97 dB, f16 49-50 dB, the TF32-emulated oracle the same class, bf16 33 dB. ----
+def _conditioned(V, Vt):
+    from vicasplat_amd import synthetic
+    shapes = json.load(open(os.path.join(G, "shapes_full.json")))
+    W = synthetic.conditioned_weights(shapes, seed=0)
+    img, K = synthetic.smooth_input(1, V, 256, 0)
+    E, Kt, near, far = chain.config1_targets(Vt, 0.05)
+    o_out, views, _ = chain.oracle_chain(W, er.default_cfg(), img, K, E, Kt, near, far)
+    return W, img, K, (E, Kt, near, far), o_out, views
+
+
+def _hip_on(W, dt, img, K, cams):
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    m, _ = get_encoder(default_cfg())
+    m.load_state_dict(W, strict=True)
+    m = m.cuda().eval()
+    m.set_compute_dtype(dt)
+    return _hip_chain(m, img, K, *cams)
+
+
+def test_conditioned_checkpoint_separates_the_precision_classes():
+    W, img, K, cams, o_out, views = _conditioned(2, 3)
+    ref_img = np.stack([v["color"] for v in views])
+    assert 0.3 <= float(ref_img.mean()) <= 0.7 and float(ref_img.std()) >= 0.05, "the conditioned scene must be an actual image"
+    # the yardstick on THIS checkpoint: the reference's CUDA precision (TF32 operands) emulated on the oracle
+    t_out, t_views, _ = chain.oracle_chain(W, er.default_cfg(), img, K, *cams, operand_mantissa_bits=10)
+    tf32 = chain.compare_renders(np.stack([v["color"] for v in t_views]), views)
+    res = {}
+    for dt in ("split", torch.float16, torch.bfloat16):
+        out, r = _hip_on(W, dt, img, K, cams)
+        c = chain.compare_renders(r["color"].cpu().numpy(), views)
+        tiles = chain.tile_assignment_diff(r["radii"].cpu().numpy(), r["rect"].cpu().numpy(), views)
+        pose = float((out["gaussian_camera_extrins"].cpu().double() - o_out["gaussian_camera_extrins"].double()).abs().max())
+        res[str(dt)] = (c, tiles, pose)
+        print(f"conditioned {dt}: PSNR vs oracle f32 chain {['%.1f' % p for p in c['psnr_between']]} dB, |dPSNR| {['%.1e' % p for p in c['dpsnr_common_target']]}, "
+              f"tile changes {tiles['visibility_flips'] + tiles['rect_changes']} of {tiles['gaussian_views']}, pose {pose:.1e}")
+    print(f"conditioned TF32-emulated oracle: PSNR {['%.1f' % p for p in tf32['psnr_between']]} dB, |dPSNR| {['%.1e' % p for p in tf32['dpsnr_common_target']]}")
+    c, tiles, pose = res["split"]
+    assert min(c["psnr_between"]) >= 80.0 and max(c["dpsnr_common_target"]) <= 1e-4 and pose <= 2e-5
+    assert tiles["visibility_flips"] + tiles["rect_changes"] <= 2e-3 * tiles["gaussian_views"]
+    c, tiles, pose = res[str(torch.float16)]
+    assert min(c["psnr_between"]) >= 44.0, c                                    # absolute: measured 49-50 dB
+    assert min(c["psnr_between"]) >= min(tf32["psnr_between"]) - 3.0, (c, tf32)   # and no worse than the reference's own precision class
+    assert max(c["dpsnr_common_target"]) <= 5e-3 and pose <= 5e-3
+    assert tiles["visibility_flips"] + tiles["rect_changes"] <= 0.05 * tiles["gaussian_views"], tiles
+    c, tiles, pose = res[str(torch.bfloat16)]
+    assert min(c["psnr_between"]) >= 28.0, c                                    # measured 33 dB: three mantissa bits fewer, ~ -17 dB

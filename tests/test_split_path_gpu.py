@@ -284,6 +284,26 @@ def test_conv7x7_stem_and_fused_pts_head_split():
     assert out.shape == (2, 32, 64, 4) and out.dtype == torch.float32 and _rel(out[..., :3], ref) <= TOL
 
 
+@pytest.mark.parametrize("M,K,N", [(192, 768, 2304), (16, 9, 1024), (14, 768, 8), (192, 3072, 768)])
+def test_linear_split_autograd_function(M, K, N):
+    """autograd.LinearSplitFn (the f32 camera-token layers of the training forward: no vendor BLAS in either direction): y, dx, dw, db
+    against float64 autograd, including reduction dimensions that are not multiples of 32 (9 -> 1024 intrinsic embedding, 768 -> 8 pose head)."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(d).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(d).requires_grad_(True)
+    gy = torch.randn(M, N, generator=g).to(d)
+    y = A.linear_split(x, w, b)
+    y.backward(gy)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = xd @ wd.t() + bd
+    yr.backward(gy.double())
+    for name, got, ref in (("y", y, yr), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
+        assert _rel(got.detach(), ref.detach()) <= 2e-5, (name, _rel(got.detach(), ref.detach()))
+
+
 def _model(kind):
     from vicasplat_amd.model.encoder import default_cfg, get_encoder
     shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))

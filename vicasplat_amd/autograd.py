@@ -69,6 +69,74 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torc
     return LinearFn.apply(x, w, b, dt, rope)
 
 
+class LinearSplitFn(torch.autograd.Function):
+    """y = x @ w^T + b in the SPLIT operand class (f32 in / out, every product three f16 MFMAs on hi+lo pairs: f32-class results; csrc/
+    gemm_common.h kDtSplit): the tiny f32 layers of the camera-token path of the training forward (intrinsic embedding, AdaLN projections,
+    camera MLPs, pose / fov heads) without a vendor-BLAS launch in either direction (143 `Cijk_*` launches per step came
+    from F.linear here).  dx = dy @ w and dw = dy^T @ x are the same kernel on packed transposes; db = column sums (vs_colsum)."""
+
+    @staticmethod
+    def _pad32(t, dim):
+        n = t.shape[dim]
+        pad = (-n) % 32
+        if pad == 0:
+            return t.contiguous()
+        cfg = [0, 0] * (t.dim() - 1 - dim) + [0, pad]
+        return torch.nn.functional.pad(t, cfg).contiguous()
+
+    # power-of-two scale of each parameter's packed image, refreshed every 64 uses: reading max|w| is a host synchronisation, and these
+    # layers are packed every step (the weights move).  2^e max|w| starts in [2^13, 2^14): a weight may grow 4x between refreshes.
+    _exp_cache: dict = {}
+
+    @staticmethod
+    def _scale_exp(w):
+        key = (id(w), w.data_ptr())
+        ent = LinearSplitFn._exp_cache.get(key)
+        if ent is None or ent[1] <= 0:
+            ent = [ops.split_scale_exp(w), 64]
+            LinearSplitFn._exp_cache[key] = ent
+        ent[1] -= 1
+        return ent[0]
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K, N = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, K).float()
+        xp = LinearSplitFn._pad32(x2, 1)
+        e = LinearSplitFn._scale_exp(w)
+        ctx.scale_exp = e
+        wp = ops.split_pack_weight(LinearSplitFn._pad32(w.detach().float(), 1), e)
+        y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+        ops.gemm(xp, wp, None if b is None else b.detach().float().contiguous(), y, ops.EPI_STORE32)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, b is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xshape, has_b = ctx.meta
+        N, K = w.shape
+        dy2 = dy.reshape(-1, N).float().contiguous()
+        M = dy2.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:       # dx [M, K] = dy [M, N] @ w [N, K]: reduction over N, "weight" rows = w^T [K, N]
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            ops.gemm(LinearSplitFn._pad32(dy2, 1), ops.split_pack_weight(LinearSplitFn._pad32(w.detach().float().t(), 1), ctx.scale_exp), None, dx, ops.EPI_STORE32)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:       # dw [N, K] = dy^T [N, M] @ x [M, K]: reduction over M, "weight" rows = x^T [K, M]
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            # (x is an activation: packed unscaled, like every activation operand of this class -- and without a host read of its maximum)
+            ops.gemm(LinearSplitFn._pad32(dy2.t(), 1), ops.split_pack_weight(LinearSplitFn._pad32(x2.t(), 1), 0), None, dw, ops.EPI_STORE32)
+        if has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2)
+        return dx, dw, db
+
+
+def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    return LinearSplitFn.apply(x, w, b)
+
+
 class LayerNormModFn(torch.autograd.Function):
     """out = LN(x; w, b) [* (1 + scale[row // mod_rows]) + shift[...]], x f32 [M,C] -> out in `out_dtype`.
     lead (optional, [M // lead_rows, C]): the output gets one extra row in FRONT of every lead_rows rows holding lead (the

@@ -25,7 +25,8 @@ def _ln_f32(P, name, x):
 
 
 def _lin_f32(P, name, x):
-    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+    # f32-class (split operands: three f16 MFMAs per product) on the hand-written GEMM, forward and backward -- no vendor-BLAS launch
+    return A.linear_split(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
 def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torch.dtype = torch.float16, global_step: int = 0) -> dict:

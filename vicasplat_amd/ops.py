@@ -36,16 +36,22 @@ class SplitWeight:
         return self.data.is_contiguous()
 
 
-def split_pack_weight(w: torch.Tensor) -> SplitWeight:
+def split_scale_exp(w: torch.Tensor) -> int:
+    """Power-of-two exponent e with max|w| 2^e in [2^13, 2^14) (one host read of the maximum)."""
+    import math
+    amax = float(w.detach().abs().max())
+    return 0 if amax == 0.0 or not math.isfinite(amax) else max(-24, min(24, 13 - math.frexp(amax)[1] + 1))
+
+
+def split_pack_weight(w: torch.Tensor, scale_exp: Optional[int] = None) -> SplitWeight:
     """f32 weight [N, ...] (flattened to [N, K], K % 32 == 0) -> SplitWeight.  The power-of-two scale puts max|w| just below 2^14: lo stays a
     normal f16 for every element within 2^-16 of the largest, and the products of the f16 range cannot overflow the f32 accumulator."""
     dev = L.require_device(w)
     w2 = w.detach().float().reshape(w.shape[0], -1).contiguous()
     N, K = w2.shape
     assert K % 32 == 0, f"split operands need K % 32 == 0 (K={K}): pad the reduction dimension"
-    amax = float(w2.abs().max())
-    import math
-    e = 0 if amax == 0.0 or not math.isfinite(amax) else max(-24, min(24, 13 - math.frexp(amax)[1] + 1))   # amax * 2^e in [2^13, 2^14)
+    # scale_exp given: no host synchronisation (callers that pack every step cache the exponent; 0 = unscaled, the activations' convention)
+    e = split_scale_exp(w2) if scale_exp is None else int(scale_exp)
     out = torch.empty((N, K), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         rc = L.lib().vs_split_pack_weight(L.ptr(w2), w2.stride(0), L.ptr(out), out.stride(0), N, K, e, L.stream_ptr(dev))

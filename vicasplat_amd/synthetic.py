@@ -84,3 +84,77 @@ def synthetic_input(B: int, V: int, res: int = 256, seed: int = 0):
     img = (img - 0.5) / 0.5
     K = torch.tensor([[0.9, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1.0]]).expand(B, V, 3, 3).contiguous()
     return img, K
+
+
+def conditioned_weights(shapes: dict, seed: int = 0, resid_gain: float = 0.1, scale_bias: float = 30.0, opacity_bias: float = -1.5,
+                        dc_gain: float = 1.2, dtype=torch.float32) -> dict:
+    """A CONDITIONED synthetic checkpoint: `golden_weights` with a handful of tensors rewritten so that the rendered
+    image is a smooth function of the network's outputs -- on the plain random-init weights the scene is per-pixel noise in colour and
+    depth, sub-pixel shifts of the Gaussians decorrelate the render and ANY TF32-class evaluation (the reference on its CUDA GPU
+    included) scores 19-21 dB against an fp32 one, which makes the render PSNR uninformative for the 16-bit path.  Here:
+      * every residual branch of the 36 transformer blocks (attn.proj, cross_attn.proj, mlp.fc2, mlp_cam.fc2) is scaled by `resid_gain`
+        (a trained network's branches are small corrections of the stream, not equal partners);
+      * the SH DC of a Gaussian is TIED TO ITS INPUT PIXEL: stem channels 0-2 / 3-5 carry relu(+rgb) / relu(-rgb) of the centre tap, the
+        trunk and the 3x3 head conv pass those six channels through untouched, the final 1x1 conv forms DC_c = dc_gain * rgb_c; the
+        higher SH bands keep a tenth of their random gain;
+      * the Gaussians are a few pixels wide and translucent (scale bias -> sigma ~ 0.03 world units, opacity ~ 0.2), so that a pixel
+        blends tens of them.
+    Everything else -- architecture, tensor names, the kernels that run -- is untouched: it is a state_dict like any other."""
+    W = golden_weights(shapes, seed, dtype)
+    for k in W:
+        if k.startswith("backbone.") and (k.endswith("attn.proj.weight") or k.endswith("attn.proj.bias") or k.endswith("mlp.fc2.weight")
+                                         or k.endswith("mlp.fc2.bias") or k.endswith("mlp_cam.fc2.weight") or k.endswith("mlp_cam.fc2.bias")):
+            W[k] = W[k] * resid_gain
+    g = "gaussian_param_head.dpt."
+    if g + "input_merger.0.weight" in W and W[g + "head.0.weight"].shape[0] >= 6:
+        stem_w, stem_b = W[g + "input_merger.0.weight"], W[g + "input_merger.0.bias"]
+        stem_w[:6] = 0.0
+        stem_b[:6] = 0.0
+        for c in range(3):
+            stem_w[c, c, 3, 3] = 1.0
+            stem_w[c + 3, c, 3, 3] = -1.0
+        W[g + "scratch.refinenet1.out_conv.weight"][:6] = 0.0
+        W[g + "scratch.refinenet1.out_conv.bias"][:6] = 0.0
+        h0 = W[g + "head.0.weight"]                      # conv3 256 -> 256, no bias
+        h0[:6] = 0.0
+        h0[:, :6] *= 0.0                                 # the colour channels feed nothing but themselves
+        for c in range(6):
+            h0[c, c, 1, 1] = 1.0
+        h4, b4 = W[g + "head.4.weight"], W[g + "head.4.bias"]   # [8 + 3 * d_sh, 256]: opacity | scale 3 | quat 4 | sh (rgb-major)
+        d_sh = (h4.shape[0] - 8) // 3
+        h4[:, :6] = 0.0
+        for c in range(3):
+            lo = 8 + c * d_sh
+            h4[lo] = 0.0
+            h4[lo, c], h4[lo, c + 3] = dc_gain, -dc_gain
+            b4[lo] = 0.0
+            h4[lo + 1:lo + d_sh] *= 0.1
+        b4[0] = opacity_bias
+        b4[1:4] = scale_bias
+    # the damped residual branches change the statistics of the pts3d head's output: re-centre the cloud in front of camera 0 with the
+    # constants measured for THIS checkpoint (tools/_cond_calib.py: exact-f32 HIP path, 8-view smooth input), as _calibrate_scene does
+    # for the plain weights
+    if _COND_CALIB is not None and "backbone.enc_blocks.23.norm1.weight" in shapes and resid_gain == 0.1:
+        w, wb = W["downstream_head1.dpt.head.4.weight"], W["downstream_head1.dpt.head.4.bias"]
+        mean, std = _COND_CALIB
+        for c in range(3):
+            k = _PTS3D_TARGET_STD[c] / std[c]
+            w[c] *= k
+            wb[c] = _PTS3D_TARGET_MEAN[c] + k * (float(wb[c]) - mean[c])
+    return W
+
+
+_COND_CALIB = ((-1.2245568527050026, 0.3811309264168061, 1.6605721493175314), (0.21660378770669295, 0.36242989951717225, 0.05466144700395106))
+
+
+def smooth_input(B: int, V: int, res: int = 256, seed: int = 0):
+    """`synthetic_input` without the per-pixel noise term: the image the conditioned checkpoint is meant for."""
+    ys, xs = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing="ij")
+    img = torch.empty(B, V, 3, res, res)
+    for b in range(B):
+        for v in range(V):
+            for c in range(3):
+                img[b, v, c] = 0.5 + 0.4 * torch.sin(2 * math.pi * ((2 + (seed + b) % 3) * xs + (3 + c) * ys) / res + c + v)
+    img = (img - 0.5) / 0.5
+    K = torch.tensor([[0.9, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1.0]]).expand(B, V, 3, 3).contiguous()
+    return img, K
