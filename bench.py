@@ -360,9 +360,10 @@ def main():
         gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         # dominant hand-written kernel family of the step: the MFMA GEMM (ViT encoder/decoder linears, 1x1 convolutions)
         traffic = {}
-        try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null unless they cover this workload
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")))
-            if pm.get("workload", {}).get("scenes_per_gpu") == B and V == 8 and Vt == 12 and args.dtype == "f16":
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null unless they cover this workload and operand class
+            fn = {"split": "round3_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
+            pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            if pm.get("workload", {}).get("scenes_per_gpu") == B and V == 8 and Vt == 12 and pm["workload"].get("dtype", "f16") == args.dtype:
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm["kernels"].items()}
                 traffic["rasterizer"] = pm["kernels"]["rasterizer"]["hbm_bytes_per_step"]  # one forward = 6 kernels
         except Exception:
@@ -374,7 +375,7 @@ def main():
             args.dtype, f"gemm256_kernel/gemm_kernel<{args.dtype}> (vs_gemm_bias_act, vs_gemm_qkv_rope)")
         roofline = dict(kernel=kname, bound="mfma",
                         achieved=round(gemm_tf, 1), peak=round(peak_tf / mfma_mult, 1), unit="TFLOP/s",
-                        frac=round(gemm_tf * mfma_mult / peak_tf, 4), traffic=traffic.get("gemm") if args.dtype == "f16" else None,
+                        frac=round(gemm_tf * mfma_mult / peak_tf, 4), traffic=traffic.get("gemm"),
                         executed_mfma_tflops=round(gemm_tf * mfma_mult, 1), mfma_peak=peak_tf, mfma_per_product=mfma_mult,
                         launches=gm["calls"], avg_launch_us=round(gm["ms"] * 1e3 / gm["calls"], 2))
         known = gm["ms"] + at["ms"] + ln["ms"] + rs["ms"] + cv["ms"] + up["ms"] + ad["ms"] + stem["ms"]
