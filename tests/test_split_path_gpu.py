@@ -225,6 +225,37 @@ def test_conv3x3_split(N, H, W, Cin, Cout, stride):
         assert _rel(y, F.relu(F.conv2d(xn, w.double(), None, padding=1)).permute(0, 2, 3, 1)) <= TOL
 
 
+@pytest.mark.parametrize("Cin,Cout,H", [(256, 128, 64), (128, 128, 96)])
+def test_conv3x3_256x128_split_kernel_at_scale(Cin, Cout, H):
+    """The 256 x 128 tile kernel of the split class (the Cout = 128 layers of the pts3d head: from 224 tiles on), every ReLU / residual
+    variant, and the fused conv3 -> ReLU -> conv1(128 -> 3) head on it."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    N, W = 16, 64
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(d)
+    b = torch.randn(Cout, generator=g).to(d)
+    res = torch.randn(N, H, W, Cout, generator=g).to(d)
+    wp = ops.pack_conv3x3_weight(w, "split")
+    xn = x.permute(0, 3, 1, 2).double()
+    for relu_in, relu_out, with_res in ((False, False, False), (True, True, False), (True, False, True), (False, True, False)):
+        y = ops.conv3x3_nhwc(x, wp, b, residual=res if with_res else None, relu_in=relu_in, relu_out=relu_out)
+        ref = F.conv2d(F.relu(xn) if relu_in else xn, w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if with_res:
+            ref = ref + res.double()
+        if relu_out:
+            ref = F.relu(ref)
+        assert _rel(y, ref) <= TOL, (relu_in, relu_out, with_res, _rel(y, ref))
+    if Cin == 128:
+        w1 = torch.zeros(4, 128, device=d); w1[:3] = (torch.randn(3, 128, generator=g) / math.sqrt(128)).to(d)
+        b1 = torch.zeros(4, device=d); b1[:3] = torch.randn(3, generator=g).to(d)
+        out = ops.conv3x3_head1x1_nhwc(x, wp, b, w1, b1, 3)
+        h = F.relu(F.conv2d(xn, w.double(), b.double(), padding=1))
+        ref = F.conv2d(h, w1[:3].double()[:, :, None, None], b1[:3].double()).permute(0, 2, 3, 1)
+        assert _rel(out[..., :3], ref) <= TOL
+
+
 @pytest.mark.parametrize("cls", ["split", "f32", "f16"])
 def test_conv3x3_256_tile_kernel_with_relu_at_scale(cls):
     """The 256 x 256 implicit-GEMM kernel only takes over from ~224 tiles on (N*H*W >= 57 344 pixels): every ReLU / residual variant of

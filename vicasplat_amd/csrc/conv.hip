@@ -400,6 +400,85 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     else conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
 }
 
+// ---- 256 x 128 tile on the split main loop (gemm256.h, mainloop256x128_split): the Cout = 128 layers of the pts3d head (conv 256 -> 128
+// at 128^2, conv 128 -> 128 at 256^2 with the fused 128 -> 3 head).  The 4-wave pair-step kernel ran them at 0.30 of the split ceiling with
+// ONE workgroup of 4 waves per CU (96 KiB of LDS): one wave per SIMD cannot overlap its own conversion VALU with its MFMAs. ----
+struct ConvStager256x128 {
+    const unsigned short *pa[2][2];  // [A_h][round]
+    const unsigned short *pz[2];
+    unsigned vmask[2][2];
+    const unsigned short *pw[2];     // [round] the B unit: 128 weight rows
+    int Cin, Win, cshift;
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
+        if (u < 2) {
+            const int tap = kt >> cshift, kc = kt & ((1 << cshift) - 1);
+            const int ty = (tap * 11) >> 5;
+            const int dy = ty - 1, dx = tap - ty * 3 - 1;
+            const long long off = (long long)(dy * Win + dx) * Cin + kc * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = (vmask[u][j] >> tap) & 1u;
+                glds16(ok ? pa[u][j] + off : pz[j], lds + j * 1024u);
+            }
+        } else {
+            glds16(pw[0] + kt * 64, lds);
+            glds16(pw[1] + kt * 64, lds + 1024u);
+        }
+    }
+};
+
+template <int BF16, int MI>
+__device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int m0, int wr, int wc, float *red, int lane);
+
+template <bool RELU_IN, bool FUSE_DOT>
+__global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const ConvArgs g, const int cshift) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 3 * kUnitBytes256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wid >> 2) * 2 + ((wid & 3) >> 1), wc = wid & 1;
+    const int HW = g.H * g.W;
+    const int M = g.Nimg * HW;
+    const int K = 9 * g.Cin;
+    const int tiles_n = (g.Cout + 127) / 128;
+    const int nwg = ((M + 255) / 256) * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * 256, n0 = tn * 128;
+    ConvStager256x128 st;
+    st.Cin = g.Cin; st.Win = g.Win; st.cshift = cshift;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = unit_row256(wid, j, lane);                 // unit row 0..127 this lane stages
+        const int chunk = unit_src_chunk256(q, lane);
+        st.pz[j] = vs_zero_page + chunk * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + (q >> 5) * 64 + h * 32 + (q & 31);   // A_h: tile rows {wm*64 + h*32 + 0..31}
+            const int p = m < M ? m : 0;
+            const int nimg = p / HW, rem = p - nimg * HW;
+            const int y = (rem / g.W) * g.stride, x = (rem % g.W) * g.stride;
+            st.pa[h][j] = g.in + ((size_t)((nimg * g.Hin + y) * g.Win + x) * g.Cin + chunk * 8);
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (m < M && (unsigned)yy < (unsigned)g.Hin && (unsigned)xx < (unsigned)g.Win) vm |= 1u << t;
+            }
+            st.vmask[h][j] = vm;
+        }
+        const int rw_ = min(n0 + q, g.Cout - 1);
+        st.pw[j] = g.w + (size_t)rw_ * K + chunk * 8;
+    }
+    f4 acc[4][4];
+    mainloop256x128_split<RELU_IN>(st, K / 64, acc, smem, lane, wid);
+    if constexpr (FUSE_DOT) conv_head_dot_epilogue<kDtSplit, 4>(g, acc, m0, wm, wc, reinterpret_cast<float *>(smem), lane);
+    else conv_epilogue<kDtSplit, 4>(g, acc, m0 + wm * 64, n0 + wc * 64, M, smem, wid, lane);
+}
+
 // ---- fused 1x1 head with <= 4 outputs behind a 3x3 convolution whose Cout fits one 128-column tile (the pts3d head: conv3(128->128)
 // -> ReLU -> conv1(128->3), dpt_block.py:316-333): per pixel three 128-long dot products on the VALU.  A lane owns 16 channels of a pixel
 // row per fragment; partial sums are reduced over the 4 lane groups of the wave (xor 16 / 32) and over the two waves that share a row
@@ -894,6 +973,14 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     const long long big = vs::cdiv64(M, 256) * vs::cdiv(Cout, BN);
     if (dtype == 4) {
         VS_CHECK(Cin % 64 == 0, "vs_conv3x3_split_nhwc: Cin must be a multiple of 32");
+        static const int no128 = [] { const char *e = getenv("VS_CONV_SPLIT_NO256X128"); return e ? atoi(e) : 0; }();
+        if (!no128 && cshift >= 0 && Cout % 128 == 0 && Cout % 256 != 0 && (9 * Cin / 64) % 2 == 0 && big >= 224) {   // (Cout = 256 maps too small for the 256 x 256 kernel: the 4-wave kernel is 8 % faster there, measured)
+            dim3 grid((unsigned)(vs::cdiv64(M, 256) * (Cout / 128))), block(512);
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<true, false>), grid, block, 0, stream, g, cshift);
+            else hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false>), grid, block, 0, stream, g, cshift);
+            VS_HIP(hipGetLastError());
+            return 0;
+        }
         static const int smi = [] { const char *e = getenv("VS_CONV_SPLIT_MI"); return e ? atoi(e) : 0; }();
         if ((big >= 512 && smi != 4) || smi == 8) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8>), dim3((unsigned)big), dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
@@ -991,7 +1078,14 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
     VS_CHECK((((uintptr_t)in | (uintptr_t)wp | (uintptr_t)out2 | (uintptr_t)bias2) & 15) == 0, "vs_conv3x3_head_dot_split_nhwc: 16-byte alignment required");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 128, relu_in, relu_out, H, W, 1,
                (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2, ld2, acc_scale};
-    hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8, true>), dim3((unsigned)(M / 256)), dim3(256), 0, stream, g);
+    int cshift = -1;
+    for (int sft = 0; sft < 4; ++sft)
+        if (2 * Cin == (64 << sft)) cshift = sft;
+    static const int no128 = [] { const char *e = getenv("VS_CONV_SPLIT_NO256X128"); return e ? atoi(e) : 0; }();
+    if (!no128 && cshift >= 0 && (9 * 2 * Cin / 64) % 2 == 0 && !relu_in)
+        hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, cshift);
+    else
+        hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8, true>), dim3((unsigned)(M / 256)), dim3(256), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;
 }

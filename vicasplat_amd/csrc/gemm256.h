@@ -317,6 +317,130 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
     __syncthreads();  // every wave is done with the ring before an epilogue reuses it
 }
 
+// ---- 256 x 128 tile on the split main loop (the Cout = 128 convolutions of the pts3d head; round 3).  8 waves as 4 (M) x 2 (N), wave
+// tile 64 x 64 (acc[4][4]); a K-tile of 32 k is THREE 16 KiB units: A_h = tile rows {wm*64 + h*32 + 0..31 : wm = 0..3} (h = 0, 1) and B =
+// the 128 weight rows; ring of 2 slots x 3 units = 96 KiB.  Wave group g = wid >> 2 owns tile rows 128 g .. 128 g + 127, i.e. unit rows
+// 64 g .. 64 g + 63 of both A units: it stages, converts (in place, as mainloop256_split) and reads them alone; the B unit is shared.
+// Two phases of 24 MFMAs per K-tile and wave, the groups one barrier apart:
+//     R0: convert A_1 of kt (own rows); read B, A_0; stage A_1 of kt+1 | M0: (A0, B) | R1: convert A_0 of kt+1; read A_1; stage A_0, B of
+//     kt+2 | M1: (A1, B)
+// Issue order per wave: .. R0(kt): A_1(kt+1) | R1(kt): A_0(kt+2), B(kt+2) ..  Waits (own pieces only for the A units -- a wave converts
+// the rows it staged itself; the shared B unit is waited for one barrier before its first read): start of R0: A_1(kt) (four younger
+// pieces in flight), start of R1: A_0(kt+1) and B(kt+1) (two younger pieces).
+template <bool RELU_A, class Stager>
+__device__ __forceinline__ void mainloop256x128_split(Stager &st, const int KT, f4 (&acc)[4][4], unsigned char *smem, const int lane, const int wid) {
+    constexpr unsigned UNITB = kUnitBytes256;
+    constexpr int BF16 = kDtSplit;
+    const int grp = wid >> 2, wl = wid & 3;
+    const int wm = grp * 2 + (wl >> 1), wc = wl & 1;
+    typedef void __attribute__((address_space(3))) *lptr_t;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wid * 2048u);
+#define VS_STAGE(u_, kt_, d_) st.stage(u_, kt_, lds_w + (unsigned)(((d_) * 3 + (u_)) * UNITB));
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned rd0 = (unsigned)(frow * 128 + (((0 + fg) ^ (frow >> 1)) << 4));
+    const unsigned rd1 = (unsigned)(frow * 128 + (((4 + fg) ^ (frow >> 1)) << 4));
+    const unsigned char *rdA = smem + wm * (32 * 128);
+    const unsigned char *rdB = smem + 2 * UNITB + wc * (64 * 128);
+    unsigned char *cvp = smem + (wid * 16) * 128;
+    const int crow = 2 * (frow & 7) + (frow >> 3);
+    const unsigned cv0 = (unsigned)(crow * 128 + (((0 + fg) ^ (crow >> 1)) << 4));
+    const unsigned cv1 = (unsigned)(crow * 128 + (((4 + fg) ^ (crow >> 1)) << 4));
+    uint4 fa[2][2], fb[4][2], cx0, cx1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#define VS_RD_A(h_, d_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                              \
+        fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 3 + (h_)) * UNITB + i * 2048 + rd0);           \
+        fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 3 + (h_)) * UNITB + i * 2048 + rd1);           \
+    }
+#define VS_RD_B(d_)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+        fb[j][0] = *reinterpret_cast<const uint4 *>(rdB + (d_) * 3 * UNITB + j * 2048 + rd0);                    \
+        fb[j][1] = *reinterpret_cast<const uint4 *>(rdB + (d_) * 3 * UNITB + j * 2048 + rd1);                    \
+    }
+#define VS_CVT_LD(h_, d_)                                                                                        \
+    {                                                                                                            \
+        cx0 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 3 + (h_)) * UNITB + cv0);                           \
+        cx1 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 3 + (h_)) * UNITB + cv1);                           \
+    }
+#define VS_CVT_ST(h_, d_)                                                                                        \
+    {                                                                                                            \
+        if constexpr (RELU_A) {                                                                                  \
+            cx0.x = relu_f32_lds(cx0.x); cx0.y = relu_f32_lds(cx0.y); cx0.z = relu_f32_lds(cx0.z); cx0.w = relu_f32_lds(cx0.w); \
+            cx1.x = relu_f32_lds(cx1.x); cx1.y = relu_f32_lds(cx1.y); cx1.z = relu_f32_lds(cx1.z); cx1.w = relu_f32_lds(cx1.w); \
+        }                                                                                                        \
+        split8_lds(cx0, cx1);                                                                                    \
+        *reinterpret_cast<uint4 *>(cvp + ((d_) * 3 + (h_)) * UNITB + cv0) = cx0;                                 \
+        *reinterpret_cast<uint4 *>(cvp + ((d_) * 3 + (h_)) * UNITB + cv1) = cx1;                                 \
+    }
+#define VS_MM(ha_)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+            acc[(ha_) * 2 + i][j] = mma2<BF16>(fb[j][0], fb[j][1], fa[i][0], fa[i][1], acc[(ha_) * 2 + i][j]);
+#define VS_BAR()                                  \
+    {                                             \
+        asm volatile("" ::: "memory");            \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("" ::: "memory");            \
+    }
+#define VS_WAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
+#define VS_COMPUTE(ha_)                           \
+    {                                             \
+        VS_BAR()                                  \
+        __builtin_amdgcn_s_setprio(1);            \
+        VS_MM(ha_)                                \
+        __builtin_amdgcn_s_setprio(0);            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* conversion stores are in LDS before the barrier that publishes them */ \
+        VS_BAR()                                  \
+    }
+    // MODE 0: steady state (tiles kt+1 and kt+2 exist), 1: kt == KT-2, 2: kt == KT-1
+#define VS_KTILE(kt_, d_, MODE_)                                                  \
+    {                                                                             \
+        if (MODE_ <= 1) { VS_WAIT(4) } else { VS_WAIT(0) }                        \
+        VS_CVT_LD(1, d_)                                                          \
+        VS_RD_B(d_) VS_RD_A(0, d_)                                                \
+        if (MODE_ <= 1) VS_STAGE(1, (kt_) + 1, (d_) ^ 1)                          \
+        VS_CVT_ST(1, d_)                                                          \
+        VS_COMPUTE(0)                                                             \
+        if (MODE_ <= 1) { VS_WAIT(2) VS_CVT_LD(0, (d_) ^ 1) }                     \
+        VS_RD_A(1, d_)                                                            \
+        if (MODE_ == 0) { VS_STAGE(0, (kt_) + 2, d_) VS_STAGE(2, (kt_) + 2, d_) } \
+        if (MODE_ <= 1) VS_CVT_ST(0, (d_) ^ 1)                                    \
+        VS_COMPUTE(1)                                                             \
+    }
+    // KT even and >= 2.  Prologue: A_0(0), B(0) | A_1(0) | A_0(1), B(1) -- the issue order of the steady state
+    VS_STAGE(0, 0, 0) VS_STAGE(2, 0, 0) VS_STAGE(1, 0, 0) VS_STAGE(0, 1, 1) VS_STAGE(2, 1, 1)
+    VS_WAIT(6)
+    VS_CVT_LD(0, 0)
+    VS_CVT_ST(0, 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    VS_BAR()
+    if (grp == 1) VS_BAR()
+    for (int kt = 0; kt + 2 < KT; kt += 2) {
+        VS_KTILE(kt, 0, 0)
+        VS_KTILE(kt + 1, 1, 0)
+    }
+    VS_KTILE(KT - 2, 0, 1)
+    VS_KTILE(KT - 1, 1, 2)
+    if (grp == 0) VS_BAR()
+#undef VS_KTILE
+#undef VS_WAIT
+#undef VS_COMPUTE
+#undef VS_BAR
+#undef VS_MM
+#undef VS_CVT_LD
+#undef VS_CVT_ST
+#undef VS_RD_B
+#undef VS_RD_A
+#undef VS_STAGE
+    __syncthreads();
+}
+
 struct GemmStager256 {
     const unsigned short *pu[4][2];  // [A0 A1 B0 B1][round]
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
