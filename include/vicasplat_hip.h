@@ -178,6 +178,12 @@ int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, float acc_sc
                                    float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t ld2, int32_t relu_in,
                                    int32_t relu_out, vs_stream_t stream);
 
+/* conv3x3(Cin -> 256) -> relu_out -> conv1x1(256 -> C2pad <= 96) in one kernel on split operands (MFMA form of vs_conv3x3_head1x1_nhwc):
+ * w2p = packed [C2pad, 256], bias2 f32 [C2pad], out2 f32 [N*H*W, ld2 >= C2pad] */
+int vs_conv3x3_head1x1_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const void *w2p, float acc_scale2,
+                                  const float *bias2, float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t C2pad,
+                                  int32_t ld2, int32_t relu_out, vs_stream_t stream);
+
 /* vs_conv3x3_nhwc on split operands: in / residual / out f32 NHWC, wp = packed [Cout, 9 * Cin] (tap-major, channel-minor; Cin % 32 == 0) */
 int vs_conv3x3_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *residual, float *out, int32_t Nimg,
                           int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,

@@ -225,6 +225,26 @@ def test_conv3x3_split(N, H, W, Cin, Cout, stride):
         assert _rel(y, F.relu(F.conv2d(xn, w.double(), None, padding=1)).permute(0, 2, 3, 1)) <= TOL
 
 
+def test_fused_gs_head_split():
+    """conv3(256 -> 256) -> ReLU -> conv1(256 -> 83) of the Gaussian-parameter head in one kernel on split operands (dpt_block.py:335-343):
+    the second GEMM runs on (hi, lo) images of the tile in LDS, four K-quarters."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 4, 64, 64
+    x = torch.randn(N, H, W, 256, generator=g).to(d)
+    w3 = (torch.randn(256, 256, 3, 3, generator=g) / math.sqrt(9 * 256)).to(d)
+    w1 = torch.zeros(96, 256, device=d); w1[:83] = (torch.randn(83, 256, generator=g) / 16).to(d)
+    b1 = torch.zeros(96, device=d); b1[:83] = torch.randn(83, generator=g).to(d)
+    out = ops.conv3x3_head1x1_nhwc(x, ops.pack_conv3x3_weight(w3, "split"), None, ops.split_pack_weight(w1), b1, 83)
+    h = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w3.double(), None, padding=1))
+    ref = F.conv2d(h, w1[:83].double()[:, :, None, None], b1[:83].double()).permute(0, 2, 3, 1)
+    assert out.shape == (N, H, W, 96) and out.dtype == torch.float32
+    e = _rel(out[..., :83], ref)
+    assert e <= TOL, e
+    assert float(out[..., 83:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Cin,Cout,H", [(256, 128, 64), (128, 128, 96)])
 def test_conv3x3_256x128_split_kernel_at_scale(Cin, Cout, H):
     """The 256 x 128 tile kernel of the split class (the Cout = 128 layers of the pts3d head: from 224 tiles on), every ReLU / residual

@@ -33,6 +33,7 @@ struct ConvArgs {
     unsigned short *out2;
     int C2, C2pad, ld2;
     float acc_scale;            // split operands: 2^-e of the packed weights (gemm_common.h, kDtSplit)
+    float acc_scale2;           // split operands, fused head: 2^-e of the packed w2
 };
 
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
@@ -317,6 +318,103 @@ __device__ __forceinline__ void conv_head1x1_epilogue256(const ConvArgs &g, f4 (
     }
 }
 
+// ---- the same fusion for SPLIT operands (round 3): conv3(256 -> 256) -> ReLU -> conv1(256 -> C2pad <= 96) of the Gaussian-parameter head
+// at f32-class precision.  The [256 px x 256 ch] tile of the 3x3 result is f32 in the accumulators; the second GEMM needs it as (hi, lo)
+// f16 operands -- 2 x 128 KiB for the whole tile -- so it runs in FOUR K-quarters of 64 channels: the two waves that own the quarter's
+// channels (wave column wc = quarter) write relu(acc 2^-e + bias) as hi / lo images of [256 rows][64 halves] (2 x 32 KiB, the packed
+// weights' k order inside each block of 32, chunk index XOR (row >> 1) & 7), every thread brings the quarter's slice of the packed W2
+// ([C2pad rows][256 B], chunk XOR row & 15) from L2, one barrier, then all eight waves run the quarter's 2 k-steps x 3 MFMAs for their 32
+// pixel rows x C2pad outputs.  72 MFMAs per wave and quarter: +2 % on the tile; the 256-channel f32 activation at 256^2 (12.9 GB per
+// 24-scene step, written and read) and the HBM-bound 1x1 GEMM behind it (5.2 ms) are gone.
+template <int NF>
+__device__ __forceinline__ void conv_head1x1_split_epilogue256(const ConvArgs &g, f4 (&acc)[8][4], int m0, int wr, int wc, unsigned char *smem, int wid,
+                                                               int lane) {
+    const int mrow = lane & 15, grp = lane >> 4, tid = wid * 64 + lane;
+    unsigned char *sXh = smem, *sXl = smem + 32 * 1024, *sW = smem + 64 * 1024;      // [256][128 B] | [256][128 B] | [NF*16][256 B]
+    f4 acc2[2][NF];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc2[a_][n] = f4{0.f, 0.f, 0.f, 0.f};
+    const bool relu = g.relu_out == 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q > 0) __syncthreads();                       // every wave is done with the previous quarter's X and W2 slice
+        {   // W2 slice: rows 0..NF*16-1, bytes [q*256, q*256 + 256) of each packed row (row stride = Cout 4-byte units)
+            constexpr int kPieces = NF * 16 * 16;         // 16-byte pieces
+#pragma unroll
+            for (int r = 0; r < (kPieces + 511) / 512; ++r) {
+                const int p = r * 512 + tid;
+                if (p < kPieces) {
+                    const int row = p >> 4, ch = p & 15;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(g.w2) + (size_t)row * (g.Cout * 4) + q * 256 + ch * 16);
+                    *reinterpret_cast<uint4 *>(sW + row * 256 + ((ch ^ (row & 15)) << 4)) = v;
+                }
+            }
+        }
+        if (wc == q) {                                    // this wave's 64 channels are the quarter: relu(acc * s + bias) -> (hi, lo) -> LDS
+            float4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bv[j] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + wc * 64 + j * 16 + grp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wr * 128 + i * 16 + mrow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v0 = acc[i][j][0] * g.acc_scale + bv[j].x, v1 = acc[i][j][1] * g.acc_scale + bv[j].y;
+                    float v2 = acc[i][j][2] * g.acc_scale + bv[j].z, v3 = acc[i][j][3] * g.acc_scale + bv[j].w;
+                    if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    const unsigned h0 = cvt_pk_f16(v0, v1), h1 = cvt_pk_f16(v2, v3);
+                    float r0, r1, r2, r3;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h0), "v"(v0));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h0), "v"(v1));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h1), "v"(v2));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h1), "v"(v3));
+                    const unsigned l0 = cvt_pk_f16(r0, r1), l1 = cvt_pk_f16(r2, r3);
+                    // channels j*16 + grp*4 + 0..3 of the quarter: block j >> 1, chunk grp, first / second half of the chunk (packed k order)
+                    const int chunk = ((j >> 1) * 4 + grp) ^ ((row >> 1) & 7);
+                    const int off = row * 128 + chunk * 16 + (j & 1) * 8;
+                    *reinterpret_cast<uint2 *>(sXh + off) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(sXl + off) = make_uint2(l0, l1);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 xh[2], xl[2];
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_) {
+                const int row = wid * 32 + a_ * 16 + mrow;
+                const int o = row * 128 + (((ks * 4 + grp) ^ ((row >> 1) & 7)) << 4);
+                xh[a_] = *reinterpret_cast<const uint4 *>(sXh + o); xl[a_] = *reinterpret_cast<const uint4 *>(sXl + o);
+            }
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {      // (W2 fragments one output block at a time: all NF of them beside the 128 accumulators spill)
+                const int row = n * 16 + mrow;
+                const uint4 wh = *reinterpret_cast<const uint4 *>(sW + row * 256 + (((ks * 8 + grp) ^ (row & 15)) << 4));
+                const uint4 wl = *reinterpret_cast<const uint4 *>(sW + row * 256 + (((ks * 8 + 4 + grp) ^ (row & 15)) << 4));
+#pragma unroll
+                for (int a_ = 0; a_ < 2; ++a_) acc2[a_][n] = mma2<kDtSplit>(wh, wl, xh[a_], xl[a_], acc2[a_][n]);
+            }
+        }
+    }
+    // C^T layout: lane holds output channels n*16 + grp*4 + 0..3 of pixel row wid*32 + a*16 + mrow -> 16-byte f32 stores
+    float *out2 = reinterpret_cast<float *>(g.out2);
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+        const float4 b2 = *reinterpret_cast<const float4 *>(g.bias2 + n * 16 + grp * 4);
+#pragma unroll
+        for (int a_ = 0; a_ < 2; ++a_) {
+            const size_t m = (size_t)m0 + wid * 32 + a_ * 16 + mrow;
+            *reinterpret_cast<float4 *>(out2 + m * g.ld2 + n * 16 + grp * 4) =
+                make_float4(acc2[a_][n][0] * g.acc_scale2 + b2.x, acc2[a_][n][1] * g.acc_scale2 + b2.y, acc2[a_][n][2] * g.acc_scale2 + b2.z,
+                            acc2[a_][n][3] * g.acc_scale2 + b2.w);
+        }
+    }
+}
+
 // ---- 256 x 256 x 64 implicit-GEMM variant on the phase-interleaved main loop of gemm256.h (Cout tile 256, one tap x 64
 // input channels per K-tile; needs Cin = 64 << cshift).  Only the staging differs from the GEMM: per staged row the source
 // is the tap-shifted pixel's 128-byte channel slice, or the zero page outside the image. ----
@@ -396,7 +494,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     f4 acc[8][4];
     if constexpr (BF16 == kDtSplit) mainloop256_split<RELU_IN>(st, K / 64, acc, smem, lane, wid);
     else mainloop256<BF16, RELU_IN>(st, K / 64, acc, smem, lane, wid);
-    if constexpr (FUSE_NF > 0) conv_head1x1_epilogue256<BF16, FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
+    if constexpr (FUSE_NF > 0 && BF16 == kDtSplit) conv_head1x1_split_epilogue256<FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
+    else if constexpr (FUSE_NF > 0) conv_head1x1_epilogue256<BF16, FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
     else conv_epilogue<BF16, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, M, smem, wid, lane);
 }
 
@@ -945,7 +1044,7 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
     if (Nimg == 0) return 0;
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
-               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale};
+               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale, 1.f};
     const long long M = (long long)Nimg * H * W;
     static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
     int cshift = -1;
@@ -1032,7 +1131,7 @@ extern "C" int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const floa
              ((uintptr_t)bias2 & 15) == 0, "vs_conv3x3_head1x1_nhwc: alignment");
     VS_CHECK(relu_out == 0 || relu_out == 1, "vs_conv3x3_head1x1_nhwc: relu_out must be 0 or 1");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, nullptr, nullptr, Nimg, H, W, Cin, Cout, relu_in, relu_out, H, W, 1,
-               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2pad, ld2, 1.f};
+               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2pad, ld2, 1.f, 1.f};
     if (Cout == 256) {
         int cshift = -1;
         for (int sft = 0; sft < 4; ++sft)
@@ -1077,7 +1176,7 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
     VS_CHECK(Cin % 32 == 0 && C2 >= 1 && C2 <= 4 && ld2 >= 4 && ld2 % 4 == 0 && (relu_out == 0 || relu_out == 1), "vs_conv3x3_head_dot_split_nhwc: Cin %% 32, C2 <= 4, ld2 >= 4");
     VS_CHECK((((uintptr_t)in | (uintptr_t)wp | (uintptr_t)out2 | (uintptr_t)bias2) & 15) == 0, "vs_conv3x3_head_dot_split_nhwc: 16-byte alignment required");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 128, relu_in, relu_out, H, W, 1,
-               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2, ld2, acc_scale};
+               (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2, ld2, acc_scale, 1.f};
     int cshift = -1;
     for (int sft = 0; sft < 4; ++sft)
         if (2 * Cin == (64 << sft)) cshift = sft;
@@ -1086,6 +1185,39 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
         hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, cshift);
     else
         hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8, true>), dim3((unsigned)(M / 256)), dim3(256), 0, stream, g);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv3x3(Cin -> 256) -> relu_out -> conv1x1(256 -> C2 <= C2pad <= 96) in one kernel on split operands (the MFMA form of
+// vs_conv3x3_head1x1_nhwc): in f32 NHWC, wp packed [256, 9 * Cin], w2p = vs_split_pack_weight image of the [C2pad, 256] f32 weight (rows >= C2
+// zero), bias2 f32 [C2pad], out2 f32 [N*H*W, ld2 >= C2pad, ld2 % 4 == 0]; N*H*W a multiple of 256, Cin in {32, 64, 128, 256}.
+extern "C" int vs_conv3x3_head1x1_split_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const void *w2p, float acc_scale2,
+                                             const float *bias2, float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t C2pad,
+                                             int32_t ld2, int32_t relu_out, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in && wp && w2p && bias2 && out2 && acc_scale > 0.f && acc_scale2 > 0.f, "vs_conv3x3_head1x1_split_nhwc: null pointer / bad scale");
+    const long long M = (long long)Nimg * H * W;
+    VS_CHECK(Nimg > 0 && H > 0 && W > 0 && H < 32767 && W < 65536 && M % 256 == 0 && M < 2147483647LL, "vs_conv3x3_head1x1_split_nhwc: N*H*W must be a positive multiple of 256");
+    int cshift = -1;
+    for (int sft = 0; sft < 4; ++sft)
+        if (2 * Cin == (64 << sft)) cshift = sft;
+    VS_CHECK(cshift >= 0 && (9 * 2 * Cin / 64) % 2 == 0, "vs_conv3x3_head1x1_split_nhwc: Cin=%d not supported", Cin);
+    VS_CHECK(C2pad % 16 == 0 && C2pad >= 16 && C2pad <= 96 && C2 <= C2pad && ld2 >= C2pad && ld2 % 4 == 0 && (relu_out == 0 || relu_out == 1),
+             "vs_conv3x3_head1x1_split_nhwc: need C2pad in 16..96 (multiple of 16), ld2 >= C2pad (C2pad=%d ld2=%d)", C2pad, ld2);
+    VS_CHECK((((uintptr_t)in | (uintptr_t)wp | (uintptr_t)w2p | (uintptr_t)out2 | (uintptr_t)bias2) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0),
+             "vs_conv3x3_head1x1_split_nhwc: 16-byte alignment required");
+    ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 256, 0, relu_out, H, W, 1,
+               (const unsigned short *)w2p, bias2, (unsigned short *)out2, C2, C2pad, ld2, acc_scale, acc_scale2};
+    dim3 grid((unsigned)(M / 256)), block(512);
+    switch (C2pad / 16) {
+        case 1: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 1>), grid, block, 0, stream, g, cshift); break;
+        case 2: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 2>), grid, block, 0, stream, g, cshift); break;
+        case 3: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 3>), grid, block, 0, stream, g, cshift); break;
+        case 4: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 4>), grid, block, 0, stream, g, cshift); break;
+        case 5: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 5>), grid, block, 0, stream, g, cshift); break;
+        default: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 6>), grid, block, 0, stream, g, cshift); break;
+    }
     VS_HIP(hipGetLastError());
     return 0;
 }

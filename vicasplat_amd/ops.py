@@ -367,6 +367,18 @@ def conv3x3_head1x1_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.
     """[N,H,W,Cin] 16-bit -> [N,H,W,ld2] 16-bit = conv1x1(act(conv3x3(x) + bias)) + bias2 in one kernel (vs_conv3x3_head1x1_nhwc): the
     last two layers of a DPT head.  w [Cout,3,3,Cin]; w2 [C2pad, Cout] (rows >= n_out zero) with bias2 [C2pad] for Cout = 256, or
     w2 [<= 4, 128] with bias2 [4] for Cout = 128.  The result keeps its padded channel stride (ld2 = w2 rows, or 4): slice it."""
+    if isinstance(w, SplitWeight) and isinstance(w2, SplitWeight):   # split operands, MFMA form: Cout = 256, w2 packed [C2pad <= 96, 256]
+        dev = L.require_device(x, w.data, bias, w2.data, bias2)
+        N, H, W, Cin = x.shape
+        c2pad = w2.shape[0]
+        assert x.is_contiguous() and x.dtype == torch.float32 and tuple(w.shape) == (256, 3, 3, Cin) and tuple(w2.shape) == (c2pad, 256)
+        assert bias2.dtype == torch.float32 and bias2.numel() == c2pad and n_out <= c2pad
+        out = torch.empty((N, H, W, c2pad), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv3x3_head1x1_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(w2.data), w2.acc_scale, L.ptr(bias2),
+                                                       L.ptr(out), N, H, W, Cin, n_out, c2pad, c2pad, int(relu_out), L.stream_ptr(dev))
+        L.check(rc, "vs_conv3x3_head1x1_split_nhwc")
+        return out
     if isinstance(w, SplitWeight):   # split operands: the dot-product form (Cout = 128, n_out <= 4), f32 in / out, w2 f32 [>= n_out, 128]
         dev = L.require_device(x, w.data, bias, w2, bias2)
         N, H, W, Cin = x.shape

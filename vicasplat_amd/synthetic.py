@@ -132,7 +132,7 @@ def conditioned_weights(shapes: dict, seed: int = 0, resid_gain: float = 0.1, sc
         b4[0] = opacity_bias
         b4[1:4] = scale_bias
     # the damped residual branches change the statistics of the pts3d head's output: re-centre the cloud in front of camera 0 with the
-    # constants measured for THIS checkpoint (tools/_cond_calib.py: exact-f32 HIP path, 8-view smooth input), as _calibrate_scene does
+    # constants measured for THIS checkpoint (tools/cond_calib.py: exact-f32 HIP path, 8-view smooth input), as _calibrate_scene does
     # for the plain weights
     if _COND_CALIB is not None and "backbone.enc_blocks.23.norm1.weight" in shapes and resid_gain == 0.1:
         w, wb = W["downstream_head1.dpt.head.4.weight"], W["downstream_head1.dpt.head.4.bias"]
