@@ -414,6 +414,49 @@ int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *g
                                  const float *d_means, const float *d_cov, const float *d_harmonics, const float *d_opacities,
                                  const float *d_raw, void *d_pts, int32_t d_pts_ld, void *d_gs, int32_t d_gs_ld, vs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Split-class BACKWARD (round 3; the reference trains in fp32 / TF32: model_wrapper.py:184-321, config/experiment/re10k_8view.yaml:75-80).
+ * Every activation and gradient is an f32 tensor; every MFMA product is three f16 MFMAs on (hi, lo) pairs (dtype 4 above).
+ *   dX = dY W        vs_gemm_split on the packed transposed weight
+ *   dW = dY^T X      vs_gemm_wgrad(dtype 4): A = vs_transpose_f32(dY) [N, rows], W = vs_transpose_pack_split(X) [K, rows] (packed)
+ *   conv 3x3         dgrad = vs_conv3x3_split_nhwc on the flipped weights; wgrad = nine tap GEMMs, W = vs_transpose_pack_split with the
+ *                    tap (and the ResidualConvUnit's ReLU) applied on the way
+ *   attention        vs_attention_backward_split on the (hi, lo) images vs_split16 writes
+ * Gradients are kept in the f16 range by the caller's power-of-two loss scale (exact in f32); lo degrades gracefully into f16
+ * subnormals (absolute floor 2^-25 per element).
+ * ------------------------------------------------------------------------------------------------ */
+/* out[c][r] = act(in[src(r)][c]) for r < R, 0 for R <= r < Rpad (Rpad % 64 == 0, ld_out >= Rpad, ld_out % 4 == 0); relu != 0: act = max(., 0).
+ * conv_H, conv_W > 0: r indexes the pixels of whole H x W images and src(r) = r + tap_dy * W + tap_dx when that pixel is inside the
+ * image (zero otherwise) -- the shifted operand of one tap of a 3x3 convolution's weight gradient; 0, 0: src(r) = r. */
+int vs_transpose_f32(const float *in, int64_t ld_in, float *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu, int32_t conv_H,
+                     int32_t conv_W, int32_t tap_dy, int32_t tap_dx, vs_stream_t stream);
+/* The same, written as the packed split operand of vs_gemm_split / vs_gemm_wgrad(dtype 4): out [C, ld_out] 4-byte units, rows scaled by
+ * 2^scale_exp (0 for activations), layout of vs_split_pack_weight. */
+int vs_transpose_pack_split(const float *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu,
+                            int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, int32_t scale_exp, vs_stream_t stream);
+/* hi = rne16(x), lo = rne16(x - hi) as two 16-bit images [rows, ld_out] of the f32 tensor in [rows, ld_in] (C columns, C % 4 == 0). */
+int vs_split16(const float *in, int64_t ld_in, void *hi, void *lo, int64_t ld_out, int64_t rows, int32_t C, vs_stream_t stream);
+/* Backward of vs_attention(_lse) with dtype 4 (same addressing, mask and key segments as vs_attention_backward).  *_hi / *_lo: the
+ * vs_split16 images of q, k, v, dout (row strides ldq / ldk / ldv / lddo in 16-bit elements, shared by hi and lo); o, dout: the f32
+ * tensors (row strides ldo32 / lddo32, floats) for delta; lse from vs_attention_lse; delta [rows, H] scratch.  dq f32 [rows, lddq]
+ * written; dk, dv f32 by key row: written when kv_seg is null, ADDED to with f32 atomics otherwise (zero them first). */
+int vs_attention_backward_split(const void *q_hi, const void *q_lo, const void *k_hi, const void *k_lo, const void *v_hi, const void *v_lo,
+                                const void *do_hi, const void *do_lo, const float *o, const float *dout, const float *lse, float *delta, float *dq,
+                                float *dk, float *dv, int32_t nbatch, int32_t H, int32_t Lq, int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows,
+                                int32_t ldq, int32_t ldk, int32_t ldv, int32_t lddo, int32_t ldo32, int32_t lddo32, int32_t lddq, int32_t lddk,
+                                int32_t lddv, const int32_t *kv_seg, const int32_t *q_kvlen, int32_t max_keys, float scale, vs_stream_t stream);
+/* f32 forms of the element-wise operators of the training step (n % 4 == 0, 16-byte aligned): exact-erf GELU and its backward, the ReLU
+ * mask out = x > 0 ? dy : 0, the gated residual update / its backward with an f32 branch (vs_gated_resid / _backward), and the transpose of
+ * the bilinear x2 interpolation (vs_upsample2x_backward_nhwc). */
+int vs_gelu_f32(const float *z, float *out, int64_t n, vs_stream_t stream);
+int vs_gelu_backward_f32(const float *dy, const float *z, float *dz, int64_t n, vs_stream_t stream);
+int vs_relu_mask_f32(const float *dy, const float *x, float *out, int64_t n, vs_stream_t stream);
+int vs_gated_resid_f32(const float *x, const float *y, int64_t ldy, const float *gate, int32_t gate_rows, float *out, int32_t M, int32_t C,
+                       int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream);
+int vs_gated_resid_backward_f32(const float *dout, const float *y, int64_t ldy, const float *gate, int32_t gate_rows, float *dy, int64_t lddy,
+                                float *dgate, int32_t M, int32_t C, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream);
+int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg, int32_t H, int32_t W, int32_t C, vs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

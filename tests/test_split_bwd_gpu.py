@@ -1,0 +1,221 @@
+"""The SPLIT-class BACKWARD (reference-precision training step): f32 activations and gradients, every matrix product
+three f16 MFMAs on (hi, lo) pairs with f32 accumulation (C-ABI dtype 4; csrc/split_bwd.hip, gemm.hip vs_gemm_wgrad, attention_bwd.hip
+vs_attention_backward_split).  Reference: the fp32 / TF32 training step of model_wrapper.py:184-321 (config/experiment/re10k_8view.yaml:75-80).
+
+Operator level, against float64 torch autograd on the SAME f32 inputs: <= 1e-5 of the output scale (the 16-bit backward: ~2e-3) for
+gradients of O(1) magnitude, and a stated graceful degradation for small ones (f16 subnormal lo halves: absolute floor 2^-25 per element).  -m gpu.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max().cpu() + 1e-300))
+
+
+@pytest.mark.parametrize("R,C,relu", [(257, 64, False), (1000, 96, True), (64, 8, False), (4100, 256, False)])
+def test_transpose_f32_and_pack(R, C, relu):
+    """vs_transpose_f32 is an exact transpose (+ ReLU, zero padding); vs_transpose_pack_split is vs_split_pack_weight of that transpose."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).to(d)
+    t = ops.transpose_f32(x, 128, relu=relu)
+    Rp = (R + 127) // 128 * 128
+    ref = torch.zeros(C, Rp, device=d)
+    ref[:, :R] = (x.clamp_min(0) if relu else x).t()
+    assert t.shape == (C, Rp) and torch.equal(t, ref)
+    p = ops.transpose_pack_split(x, 128, relu=relu)
+    q = ops.split_pack_weight(ref, 0)
+    assert torch.equal(p.data, q.data) and p.acc_scale == 1.0
+
+
+def test_transpose_conv_tap():
+    from vicasplat_amd import ops
+    d = _dev()
+    N, H, W, C = 2, 7, 9, 32
+    x = torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(0)).to(d)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            t = ops.transpose_f32(x.view(-1, C), 64, conv_hw=(H, W), tap=(dy, dx))
+            ref = torch.zeros(N, H, W, C, device=d)
+            ys, ye = max(0, -dy), min(H, H - dy)
+            xs, xe = max(0, -dx), min(W, W - dx)
+            ref[:, ys:ye, xs:xe] = x[:, ys + dy:ye + dy, xs + dx:xe + dx]
+            assert torch.equal(t[:, :N * H * W], ref.view(-1, C).t()), (dy, dx)
+            assert float(t[:, N * H * W:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(514, 768, 768), (16448, 1024, 1024), (100, 192, 64), (257, 3072, 768), (300, 8, 128), (5000, 83, 256), (2056, 1024, 4096)])
+def test_linear_backward_split_matches_float64(M, N, K):
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(d)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+    dy = torch.randn(M, N, generator=g).to(d)
+    dx, dw, db = ops.linear_backward_split(dy, x, w)
+    assert _rel(dx, dy.double() @ w.double()) <= TOL
+    assert _rel(dw, dy.double().t() @ x.double()) <= TOL
+    assert _rel(db, dy.double().sum(0)) <= TOL
+
+
+def test_linear_backward_split_small_gradients_degrade_gracefully():
+    """Gradients far below the f16 normal range (no loss scale): lo underflows into subnormals, the error relative to the gradient's own
+    scale grows like 2^-25 / |g| -- 3e-4 at |g| ~ 1e-4 -- and a power-of-two loss scale restores the full precision exactly."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 2056, 768, 768
+    x = torch.randn(M, K, generator=g).to(d)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+    dy = (torch.randn(M, N, generator=g) * 1e-4).to(d)
+    dx, dw, _ = ops.linear_backward_split(dy, x, w)
+    e_small = max(_rel(dx, dy.double() @ w.double()), _rel(dw, dy.double().t() @ x.double()))
+    S = 2.0 ** 14
+    dx2, dw2, _ = ops.linear_backward_split(dy * S, x, w)
+    e_scaled = max(_rel(dx2 / S, dy.double() @ w.double()), _rel(dw2 / S, dy.double().t() @ x.double()))
+    print("small gradients: rel err %.2e unscaled, %.2e with loss scale 2^14" % (e_small, e_scaled))
+    assert e_small <= 2e-3 and e_scaled <= TOL
+
+
+def _attn_ref(q, k, v, keymask, scale):
+    s = torch.einsum("qhd,khd->hqk", q, k) * scale
+    s = s.masked_fill(~keymask[None], float("-inf"))
+    return torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("case", ["encoder", "video_prefix", "neighbour_segments"])
+def test_attention_backward_split_matches_float64(case):
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(len(case))
+    H, C = 3, 192
+    if case == "encoder":
+        nb, Lq = 3, 257
+    elif case == "video_prefix":
+        nb, Lq = 2, 3 * 86
+    else:
+        nb, Lq = 4, 100
+    rows = nb * Lq
+    qkv = (torch.randn(rows, 3 * C, generator=g) * 0.7).to(d)
+    dout = torch.randn(rows, C, generator=g).to(d)
+    q2, k2, v2 = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    kw, kvlen, seg = dict(nbatch=nb, H=H, Lq=Lq, q_batch_rows=Lq), None, None
+    if case == "neighbour_segments":
+        nbr = [[1, 1], [0, 2], [1, 3], [2, 2]]
+        seg = torch.tensor([[a * Lq, Lq, b * Lq, Lq] for a, b in nbr], dtype=torch.int32, device=d)
+        kw.update(kv_seg=seg)
+    else:
+        kw.update(Lk=Lq, k_batch_rows=Lq)
+        if case == "video_prefix":
+            kvlen = torch.full((nb, Lq), Lq, dtype=torch.int32)
+            for t in range(3):
+                kvlen[:, t * 86] = (t + 1) * 86
+            kvlen = kvlen.reshape(-1).contiguous().to(d)
+            kw.update(q_kvlen=kvlen)
+    out = torch.empty(rows, C, dtype=torch.float32, device=d)
+    lse = torch.empty(rows, H, dtype=torch.float32, device=d)
+    ops.attention(q2, k2, v2, out, lse=lse, split=True, **kw)
+    dqkv = torch.empty_like(qkv)
+    if seg is None:
+        ops.attention_backward_split(q2, k2, v2, out, dout, lse, dq_out=dqkv[:, :C], dk_out=dqkv[:, C:2 * C], dv_out=dqkv[:, 2 * C:], **kw)
+        dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
+    else:
+        dq, dk, dv = ops.attention_backward_split(q2, k2, v2, out, dout, lse, max_keys=2 * Lq, **kw)
+    qf = qkv.double().clone().requires_grad_()
+    outs = []
+    for b in range(nb):
+        qb = qf[b * Lq:(b + 1) * Lq, :C].reshape(Lq, H, 64)
+        if seg is None:
+            kb = qf[b * Lq:(b + 1) * Lq, C:2 * C].reshape(Lq, H, 64); vb = qf[b * Lq:(b + 1) * Lq, 2 * C:].reshape(Lq, H, 64)
+            mask = torch.ones(Lq, Lq, dtype=torch.bool, device=d)
+            if kvlen is not None:
+                mask = torch.arange(Lq, device=d)[None, :] < kvlen[b * Lq:(b + 1) * Lq, None]
+        else:
+            a0, b0 = nbr[b]
+            idx = torch.cat([torch.arange(a0 * Lq, (a0 + 1) * Lq), torch.arange(b0 * Lq, (b0 + 1) * Lq)]).to(d)
+            kb = qf[idx, C:2 * C].reshape(2 * Lq, H, 64); vb = qf[idx, 2 * C:].reshape(2 * Lq, H, 64)
+            mask = torch.ones(Lq, 2 * Lq, dtype=torch.bool, device=d)
+        outs.append(_attn_ref(qb, kb, vb, mask, 0.125).reshape(Lq, C))
+    ref_out = torch.cat(outs)
+    (ref_out * dout.double()).sum().backward()
+    gq, gk, gv = qf.grad[:, :C], qf.grad[:, C:2 * C], qf.grad[:, 2 * C:]
+    errs = dict(out=_rel(out, ref_out), dq=_rel(dq, gq), dk=_rel(dk, gk), dv=_rel(dv, gv))
+    print(case, {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= TOL, errs
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,relu_in", [(2, 16, 16, 64, 128, False), (1, 37, 21, 128, 256, True), (3, 64, 64, 256, 256, True),
+                                                    (1, 8, 8, 768, 256, False), (2, 32, 32, 128, 128, True)])
+def test_conv3x3_backward_split_matches_float64(N, H, W, Cin, Cout, relu_in):
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(N * H + Cin)
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(d)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(d)
+    dx, dw, db = ops.conv3x3_backward_split(dy, x, w, relu_in=relu_in)
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_()
+    wr = w.double().clone().requires_grad_()
+    br = torch.zeros(Cout, dtype=torch.float64, device=d, requires_grad=True)
+    y = F.conv2d(F.relu(xr) if relu_in else xr, wr, br, padding=1)
+    (y * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    errs = dict(dx=_rel(dx, xr.grad.permute(0, 2, 3, 1)), dw=_rel(dw, wr.grad), db=_rel(db, br.grad))
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= TOL, errs
+
+
+def test_f32_elementwise_backward_operators():
+    """GELU / its derivative, ReLU mask, gated residual (+ backward), bilinear x2 transpose and the inverse RoPE on f32 tensors vs torch."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(1000, 256, generator=g) * 2).to(d)
+    dy = torch.randn(1000, 256, generator=g).to(d)
+    zr = z.double().clone().requires_grad_()
+    a = F.gelu(zr)
+    (a * dy.double()).sum().backward()
+    assert _rel(ops.gelu16(z), a.detach()) <= 2e-6 and _rel(ops.gelu_backward(dy, z), zr.grad) <= 2e-6
+    assert torch.equal(ops.relu_mask(dy, z), torch.where(z > 0, dy, torch.zeros_like(dy)))
+    # gated residual with an interleaved f32 branch: rows 1..5 of every 6-row group of y
+    M, C, G = 40, 192, 8
+    x = torch.randn(M, C, generator=g).to(d)
+    y = torch.randn(M // 5 * 6, C, generator=g).to(d)
+    gate = torch.randn(G, C, generator=g).to(d)
+    out = ops.gated_resid(x, y, gate, 5, grp_in=5, grp_out=6, grp_off=1)
+    ysel = y.view(-1, 6, C)[:, 1:].reshape(M, C)
+    ref = x + (1 + gate.repeat_interleave(5, 0)) * ysel
+    assert _rel(out, ref) <= 1e-6
+    dout = torch.randn(M, C, generator=g).to(d)
+    dyb = torch.zeros_like(y)
+    dgate = ops.gated_resid_backward(dout, y, gate, 5, dyb, grp_in=5, grp_out=6, grp_off=1)
+    assert _rel(dyb.view(-1, 6, C)[:, 1:].reshape(M, C), dout * (1 + gate.repeat_interleave(5, 0))) <= 1e-6
+    assert float(dyb.view(-1, 6, C)[:, 0].abs().max()) == 0.0
+    assert _rel(dgate, (dout * ysel).view(G, 5, C).sum(1)) <= 1e-5
+    # bilinear x2 transpose
+    u = torch.randn(2, 16, 12, 64, generator=g).to(d)
+    ur = torch.randn(2, 8, 6, 64, generator=g).to(d).double().requires_grad_()
+    up = F.interpolate(ur.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    (up * u.double()).sum().backward()
+    assert _rel(ops.upsample2x_backward_nhwc(u), ur.grad) <= 2e-6
+    # inverse RoPE undoes the forward rotation on an f32 packed q|k|v
+    rows, Hh = 50, 3
+    Cc = Hh * 64
+    buf = torch.randn(rows, 3 * Cc, generator=g).to(d)
+    pos = torch.randint(0, 16, (rows, 2), generator=g, dtype=torch.int32).to(d)
+    b2 = buf.clone()
+    ops.rope_qk(b2, Hh, Cc, pos, None, 100.0, 1.0)
+    assert not torch.allclose(b2[:, :Cc], buf[:, :Cc]) and torch.equal(b2[:, 2 * Cc:], buf[:, 2 * Cc:])
+    ops.rope_qk(b2, Hh, Cc, pos, None, 100.0, 1.0, inverse=True)
+    assert _rel(b2, buf) <= 2e-6

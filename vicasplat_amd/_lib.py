@@ -170,6 +170,20 @@ def lib() -> C.CDLL:
             L.vs_conv7x7_rgb_split_nhwc.argtypes = [vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             L.vs_upsample2x_nhwc.restype = C.c_int
             L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_transpose_f32.restype = C.c_int
+            L.vs_transpose_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_transpose_pack_split.restype = C.c_int
+            L.vs_transpose_pack_split.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_split16.restype = C.c_int
+            L.vs_split16.argtypes = [vp, i64, vp, vp, i64, i64, i32, vp]
+            L.vs_attention_backward_split.restype = C.c_int
+            L.vs_attention_backward_split.argtypes = [vp] * 15 + [i32, i32, i32, i32, i64, i64] + [i32] * 9 + [vp, vp, i32, f32, vp]
+            for nm, at in (("vs_gelu_f32", [vp, vp, i64, vp]), ("vs_gelu_backward_f32", [vp, vp, vp, i64, vp]), ("vs_relu_mask_f32", [vp, vp, vp, i64, vp]),
+                           ("vs_gated_resid_f32", [vp, vp, i64, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+                           ("vs_gated_resid_backward_f32", [vp, vp, i64, vp, i32, vp, i64, vp, i32, i32, i32, i32, i32, vp]),
+                           ("vs_upsample2x_backward_f32_nhwc", [vp, vp, i32, i32, i32, i32, vp])):
+                getattr(L, nm).restype = C.c_int
+                getattr(L, nm).argtypes = at
             if hasattr(L, "vs_raster_backward"):
                 L.vs_raster_backward.restype = C.c_int
                 L.vs_raster_backward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), C.POINTER(VsRasterGrads),

@@ -38,6 +38,12 @@ struct AttnBwdArgs {
     long long q_batch_rows, k_batch_rows;
     int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     float scale, scale_log2e;
+    // split operand class (dtype 4): q / k / v / dout above are the HI 16-bit images of the f32 tensors, these the LO images (same strides);
+    // o32 / dout32 the f32 tensors themselves (delta), dq32 / dk / dv the f32 outputs (dk / dv: atomics with key segments, plain stores without)
+    const unsigned short *q_lo, *k_lo, *v_lo, *dout_lo;
+    const float *o32, *dout32;
+    float *dq32;
+    int ldo32, lddo32, lddq32, kv_direct;
 };
 
 template <bool BF16>
@@ -375,6 +381,248 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     }
 }
 
+
+// ================= split operand class (dtype 4): the reference-precision backward =================
+// Every tensor is f32 in HBM; the MFMA operands are (hi, lo) f16 pairs, hi = rne16(x), lo = rne16(x - hi), and every product is three
+// v_mfma_f32_16x16x32_f16 (lo hi + hi lo + hi hi, f32 accumulate; gemm_common.h kDtSplit).  Q, K, V and dO arrive as separate hi / lo
+// 16-bit images (vs_split16: one elementwise pass), so the tiles keep the 16-bit layout of the kernels above -- LDS-DMA staging,
+// swizzled rows, transpose reads -- twice; P and dS are split in registers.  Gradients may be small: the caller keeps them in the f16
+// range with a power-of-two loss scale (exact in f32), lo then degrades gracefully into f16 subnormals (absolute floor 2^-25).
+typedef _Float16 half2b_ __attribute__((ext_vector_type(2)));
+typedef float float2b_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float x, float y, unsigned &h, unsigned &l) {   // compiler-visible: the results feed MFMAs
+    const half2b_ hh = __builtin_convertvector(float2b_{x, y}, half2b_);
+    const half2b_ ll = __builtin_convertvector(float2b_{x - (float)hh.x, y - (float)hh.y}, half2b_);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ f4 mma3(const uint4 &ah, const uint4 &al, const uint4 &bh, const uint4 &bl, f4 c) {
+    c = mfma<false>(al, bh, c);
+    c = mfma<false>(ah, bl, c);
+    return mfma<false>(ah, bh, c);
+}
+// f32 [rows 4-float groups] -> four split pairs of one fragment register quad
+__device__ __forceinline__ void split_frag(const f4 &a, const f4 &b, uint4 &h, uint4 &l, int) {
+    split2(a[0], a[1], h.x, l.x); split2(a[2], a[3], h.y, l.y); split2(b[0], b[1], h.z, l.z); split2(b[2], b[3], h.w, l.w);
+}
+
+__global__ void __launch_bounds__(256)
+attn_delta_f32_kernel(const AttnBwdArgs a, long long rows) {
+    const long long item = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;  // (row, head)
+    const int sub = threadIdx.x & 7;
+    float v = 0.f;
+    const bool live = item < rows * a.H;
+    if (live) {
+        const long long row = item / a.H;
+        const int h = (int)(item % a.H);
+        const float *op = a.o32 + row * a.ldo32 + h * HD + sub * 8, *dp = a.dout32 + row * a.lddo32 + h * HD + sub * 8;
+        const float4 o0 = *reinterpret_cast<const float4 *>(op), o1 = *reinterpret_cast<const float4 *>(op + 4);
+        const float4 d0 = *reinterpret_cast<const float4 *>(dp), d1 = *reinterpret_cast<const float4 *>(dp + 4);
+        v = o0.x * d0.x + o0.y * d0.y + o0.z * d0.z + o0.w * d0.w + o1.x * d1.x + o1.y * d1.y + o1.z * d1.z + o1.w * d1.w;
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (live && sub == 0) a.delta[item] = v;
+}
+
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_split_kernel(const AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2][4][TB * HD];   // [ring slot][K hi | K lo | V hi | V lo]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
+    const KeyList kl = key_list(a, b);
+    const int qi = q0 + wid * 16 + c16;
+    const bool qvalid = qi < a.Lq;
+    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+    int my_len = qvalid ? kl.Lk : 0;
+    if (a.q_kvlen && qvalid) my_len = min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+    uint4 qh[2], ql[2], doh[2], dol[2];
+    {
+        const long long qo = qrow * a.ldq + h * HD + g * 8, dO = qrow * a.lddo + h * HD + g * 8;
+        qh[0] = *reinterpret_cast<const uint4 *>(a.q + qo); qh[1] = *reinterpret_cast<const uint4 *>(a.q + qo + 32);
+        ql[0] = *reinterpret_cast<const uint4 *>(a.q_lo + qo); ql[1] = *reinterpret_cast<const uint4 *>(a.q_lo + qo + 32);
+        doh[0] = *reinterpret_cast<const uint4 *>(a.dout + dO); doh[1] = *reinterpret_cast<const uint4 *>(a.dout + dO + 32);
+        dol[0] = *reinterpret_cast<const uint4 *>(a.dout_lo + dO); dol[1] = *reinterpret_cast<const uint4 *>(a.dout_lo + dO + 32);
+    }
+    if (!qvalid) doh[0] = doh[1] = dol[0] = dol[1] = make_uint4(0, 0, 0, 0);
+    const float L = qvalid ? a.lse[qrow * a.H + h] : INFINITY;
+    const float D = qvalid ? a.delta[qrow * a.H + h] : 0.f;
+    f4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int kt, int slot) {
+        auto rk = [&](int r) { return kl.row(kt + r); };
+        const unsigned base = lds0 + (unsigned)(slot * 4) * (TB * HD * 2);
+        dma_tile(a.k, a.ldk, h * HD, rk, base, tid);
+        dma_tile(a.k_lo, a.ldk, h * HD, rk, base + (TB * HD * 2), tid);
+        dma_tile(a.v, a.ldv, h * HD, rk, base + 2 * (TB * HD * 2), tid);
+        dma_tile(a.v_lo, a.ldv, h * HD, rk, base + 3 * (TB * HD * 2), tid);
+    };
+    if (kl.Lk > 0) issue(0, 0);
+    for (int kt = 0, it = 0; kt < kl.Lk; kt += TB, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + TB < kl.Lk) issue(kt + TB, (it + 1) & 1);
+        const unsigned short *sKh = smem[it & 1][0], *sKl = smem[it & 1][1], *sVh = smem[it & 1][2], *sVl = smem[it & 1][3];
+        f4 ds[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = sw_off(nb * 16 + c16, ks * 4 + g);
+                const uint4 kfh = *reinterpret_cast<const uint4 *>(&sKh[off]), kfl = *reinterpret_cast<const uint4 *>(&sKl[off]);
+                const uint4 vfh = *reinterpret_cast<const uint4 *>(&sVh[off]), vfl = *reinterpret_cast<const uint4 *>(&sVl[off]);
+                s = mma3(kfh, kfl, qh[ks], ql[ks], s);       // S^T[key][query]
+                dp = mma3(vfh, vfl, doh[ks], dol[ks], dp);   // dP^T[key][query]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + nb * 16 + g * 4 + r;
+                const float p = key < my_len ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) : 0.f;
+                ds[nb][r] = p * (dp[r] - D) * a.scale;
+            }
+        }
+        uint4 dsh[2], dsl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) split_frag(ds[2 * ks], ds[2 * ks + 1], dsh[ks], dsl[ks], 0);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint2 hlo = tr_rows4_sw(sKh, (2 * ks) * 16 + g * 4, db * 16, c16), hhi = tr_rows4_sw(sKh, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 llo = tr_rows4_sw(sKl, (2 * ks) * 16 + g * 4, db * 16, c16), lhi = tr_rows4_sw(sKl, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                dq[db] = mma3(make_uint4(hlo.x, hlo.y, hhi.x, hhi.y), make_uint4(llo.x, llo.y, lhi.x, lhi.y), dsh[ks], dsl[ks], dq[db]);
+            }
+    }
+    // dQ^T: query = this lane's c16, d = db*16 + g*4 + r: one 16-byte f32 store per block
+    if (qvalid) {
+        float *op = a.dq32 + qrow * a.lddq32 + h * HD + g * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<float4 *>(op + db * 16) = make_float4(dq[db][0], dq[db][1], dq[db][2], dq[db][3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_split_kernel(const AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2][4][TB * HD];   // [ring slot][Q hi | Q lo | dO hi | dO lo]
+    __shared__ __attribute__((aligned(16))) float sL2[2][TB], sD2[2][TB];
+    __shared__ __attribute__((aligned(16))) int sLen2[2][TB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
+    const KeyList kl = key_list(a, b);
+    if (kt0 >= kl.Lk) return;
+    const int kj = kt0 + wid * 16 + c16;
+    const bool kvalid = kj < kl.Lk;
+    const long long krow = kl.row(kj);
+    uint4 kh[2], klo[2], vh[2], vl[2];
+    {
+        const long long ko = krow * a.ldk + h * HD + g * 8, vo = krow * a.ldv + h * HD + g * 8;
+        kh[0] = *reinterpret_cast<const uint4 *>(a.k + ko); kh[1] = *reinterpret_cast<const uint4 *>(a.k + ko + 32);
+        klo[0] = *reinterpret_cast<const uint4 *>(a.k_lo + ko); klo[1] = *reinterpret_cast<const uint4 *>(a.k_lo + ko + 32);
+        vh[0] = *reinterpret_cast<const uint4 *>(a.v + vo); vh[1] = *reinterpret_cast<const uint4 *>(a.v + vo + 32);
+        vl[0] = *reinterpret_cast<const uint4 *>(a.v_lo + vo); vl[1] = *reinterpret_cast<const uint4 *>(a.v_lo + vo + 32);
+    }
+    f4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
+    auto issue = [&](int qt, int slot) {
+        auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
+        const unsigned base = lds0 + (unsigned)(slot * 4) * (TB * HD * 2);
+        dma_tile(a.q, a.ldq, h * HD, rq, base, tid);
+        dma_tile(a.q_lo, a.ldq, h * HD, rq, base + (TB * HD * 2), tid);
+        dma_tile(a.dout, a.lddo, h * HD, rq, base + 2 * (TB * HD * 2), tid);
+        dma_tile(a.dout_lo, a.lddo, h * HD, rq, base + 3 * (TB * HD * 2), tid);
+    };
+    float aL = 0.f, aD = 0.f; int aN = 0;
+    auto aux_load = [&](int qt) {
+        const int qi = qt + tid;
+        const bool ok = qi < a.Lq;
+        const long long row = b * a.q_batch_rows + (ok ? qi : a.Lq - 1);
+        aL = ok ? a.lse[row * a.H + h] : INFINITY;
+        aD = ok ? a.delta[row * a.H + h] : 0.f;
+        aN = !ok ? 0 : (a.q_kvlen ? min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]) : kl.Lk);
+    };
+    auto aux_store = [&](int slot) { sL2[slot][tid] = aL; sD2[slot][tid] = aD; sLen2[slot][tid] = aN; };
+    if (a.Lq > 0) {
+        issue(0, 0);
+        if (tid < TB) { aux_load(0); aux_store(0); }
+    }
+    for (int qt = 0, it = 0; qt < a.Lq; qt += TB, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool more = qt + TB < a.Lq;
+        if (more) {
+            issue(qt + TB, (it + 1) & 1);
+            if (tid < TB) aux_load(qt + TB);
+        }
+        const int slot = it & 1;
+        const unsigned short *sQh = smem[slot][0], *sQl = smem[slot][1], *sDh = smem[slot][2], *sDl = smem[slot][3];
+        const float *sL = sL2[slot], *sD = sD2[slot];
+        const int *sLen = sLen2[slot];
+        f4 p[4], ds[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = sw_off(qb * 16 + c16, ks * 4 + g);
+                const uint4 qah = *reinterpret_cast<const uint4 *>(&sQh[off]), qal = *reinterpret_cast<const uint4 *>(&sQl[off]);
+                const uint4 dah = *reinterpret_cast<const uint4 *>(&sDh[off]), dal = *reinterpret_cast<const uint4 *>(&sDl[off]);
+                s = mma3(qah, qal, kh[ks], klo[ks], s);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
+                dp = mma3(dah, dal, vh[ks], vl[ks], dp);    // dP[query][key]
+            }
+            const float4 L4 = *reinterpret_cast<const float4 *>(&sL[qb * 16 + g * 4]), D4 = *reinterpret_cast<const float4 *>(&sD[qb * 16 + g * 4]);
+            const int4 N4 = *reinterpret_cast<const int4 *>(&sLen[qb * 16 + g * 4]);
+            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+            const int Nr[4] = {N4.x, N4.y, N4.z, N4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (kvalid && kj < Nr[r]) ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -Lr[r])) : 0.f;
+                p[qb][r] = pv;
+                ds[qb][r] = pv * (dp[r] - Dr[r]) * a.scale;
+            }
+        }
+        uint4 pfh[2], pfl[2], dsh[2], dsl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            split_frag(p[2 * ks], p[2 * ks + 1], pfh[ks], pfl[ks], 0);
+            split_frag(ds[2 * ks], ds[2 * ks + 1], dsh[ks], dsl[ks], 0);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int r0 = (2 * ks) * 16 + g * 4, r1 = (2 * ks + 1) * 16 + g * 4;
+                const uint2 dh0 = tr_rows4_sw(sDh, r0, db * 16, c16), dh1 = tr_rows4_sw(sDh, r1, db * 16, c16);
+                const uint2 dl0 = tr_rows4_sw(sDl, r0, db * 16, c16), dl1 = tr_rows4_sw(sDl, r1, db * 16, c16);
+                const uint2 qh0 = tr_rows4_sw(sQh, r0, db * 16, c16), qh1 = tr_rows4_sw(sQh, r1, db * 16, c16);
+                const uint2 ql0 = tr_rows4_sw(sQl, r0, db * 16, c16), ql1 = tr_rows4_sw(sQl, r1, db * 16, c16);
+                dv[db] = mma3(pfh[ks], pfl[ks], make_uint4(dh0.x, dh0.y, dh1.x, dh1.y), make_uint4(dl0.x, dl0.y, dl1.x, dl1.y), dv[db]);
+                dk[db] = mma3(dsh[ks], dsl[ks], make_uint4(qh0.x, qh0.y, qh1.x, qh1.y), make_uint4(ql0.x, ql0.y, ql1.x, ql1.y), dk[db]);
+            }
+        if (more && tid < TB) aux_store((it + 1) & 1);
+    }
+    // dK / dV rows key = g*4 + r (of this wave's 16), cols d = db*16 + c16
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kpos = kt0 + wid * 16 + g * 4 + r;
+        if (kpos >= kl.Lk) continue;
+        const long long row = kl.row(kpos);
+        float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            if (a.kv_direct) { pk[db * 16] = dk[db][r]; pv[db * 16] = dv[db][r]; }
+            else { unsafeAtomicAdd(pk + db * 16, dk[db][r]); unsafeAtomicAdd(pv + db * 16, dv[db][r]); }
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -432,4 +680,44 @@ extern "C" int vs_attention_backward16(const void *q, const void *k, const void 
                                        int32_t dtype, vs_stream_t stream_) {
     return attention_backward_impl(q, k, v, o, dout, lse, delta, dq, nullptr, nullptr, dk, dv, nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, ldq, ldk,
                                    ldv, ldo, lddo, lddq, lddk, lddv, nullptr, q_kvlen, 0, scale, dtype, stream_);
+}
+
+// Backward of vs_attention(_lse) in the split operand class (dtype 4): every tensor f32.  q_hi / q_lo ... are the 16-bit (hi, lo) images of
+// q, k, v, dout written by vs_split16 (row strides ldq / ldk / ldv / lddo in 16-bit elements, shared by hi and lo); o, dout the f32
+// tensors (delta); dq f32 [rows, lddq] written; dk, dv f32 indexed by key row: written (kv_seg null: every K/V row has one owner) or
+// ADDED to with f32 atomics (kv_seg: zero them first).  Three f16 MFMAs per product, f32 accumulate: the reference-precision backward
+// of F.scaled_dot_product_attention (croco/blocks.py:106-110).
+extern "C" int vs_attention_backward_split(const void *q_hi, const void *q_lo, const void *k_hi, const void *k_lo, const void *v_hi,
+                                           const void *v_lo, const void *do_hi, const void *do_lo, const float *o, const float *dout,
+                                           const float *lse, float *delta, float *dq, float *dk, float *dv, int32_t nbatch, int32_t H,
+                                           int32_t Lq, int32_t Lk, int64_t q_batch_rows, int64_t k_batch_rows, int32_t ldq, int32_t ldk,
+                                           int32_t ldv, int32_t lddo, int32_t ldo32, int32_t lddo32, int32_t lddq, int32_t lddk, int32_t lddv,
+                                           const int32_t *kv_seg, const int32_t *q_kvlen, int32_t max_keys, float scale, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(q_hi && q_lo && k_hi && k_lo && v_hi && v_lo && do_hi && do_lo && o && dout && lse && delta && dq && dk && dv,
+             "vs_attention_backward_split: null pointer");
+    VS_CHECK(nbatch >= 0 && H > 0 && Lq >= 0, "vs_attention_backward_split: bad sizes");
+    VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0, "vs_attention_backward_split: 16-bit row strides must be multiples of 8");
+    VS_CHECK(ldo32 % 4 == 0 && lddo32 % 4 == 0 && lddq % 4 == 0, "vs_attention_backward_split: f32 row strides must be multiples of 4");
+    VS_CHECK((((uintptr_t)q_hi | (uintptr_t)q_lo | (uintptr_t)k_hi | (uintptr_t)k_lo | (uintptr_t)v_hi | (uintptr_t)v_lo | (uintptr_t)do_hi |
+               (uintptr_t)do_lo | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq) & 15) == 0, "vs_attention_backward_split: 16-byte alignment required");
+    VS_CHECK(kv_seg ? max_keys > 0 : Lk > 0, "vs_attention_backward_split: Lk (or max_keys with kv_seg) must be positive");
+    if (nbatch == 0 || Lq == 0) return 0;
+    AttnBwdArgs a;
+    a.q = (const unsigned short *)q_hi; a.k = (const unsigned short *)k_hi; a.v = (const unsigned short *)v_hi; a.dout = (const unsigned short *)do_hi;
+    a.q_lo = (const unsigned short *)q_lo; a.k_lo = (const unsigned short *)k_lo; a.v_lo = (const unsigned short *)v_lo; a.dout_lo = (const unsigned short *)do_lo;
+    a.o = nullptr; a.o32 = o; a.dout32 = dout; a.lse = lse; a.delta = delta;
+    a.dq = nullptr; a.dq32 = dq; a.dk = dk; a.dv = dv; a.dk16 = nullptr; a.dv16 = nullptr; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;
+    a.nbatch = nbatch; a.H = H; a.Lq = Lq; a.Lk = Lk; a.q_batch_rows = q_batch_rows; a.k_batch_rows = k_batch_rows;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = 0; a.lddo = lddo; a.lddq = 0; a.lddk = lddk; a.lddv = lddv;
+    a.ldo32 = ldo32; a.lddo32 = lddo32; a.lddq32 = lddq; a.kv_direct = kv_seg ? 0 : 1;
+    a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    const long long rows = (long long)(nbatch - 1) * q_batch_rows + Lq;
+    const int keys = kv_seg ? max_keys : Lk;
+    dim3 block(256);
+    hipLaunchKernelGGL(attn_delta_f32_kernel, dim3((unsigned)vs::cdiv64(rows * H, 32)), block, 0, stream, a, rows);
+    hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+    VS_HIP(hipGetLastError());
+    return 0;
 }

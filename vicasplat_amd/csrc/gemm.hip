@@ -565,6 +565,7 @@ int launch_wgrad(GemmArgs &g, int ksplit, float *ws, long long ws_bytes, int acc
         g.ksplit = slices;
         if (slices != ksplit && (g.a_slice_stride || g.w_slice_stride)) { vs::set_error("weight-gradient GEMM: slice-blocked operands need ksplit >= 2 on the 128x128 tiling"); return -1; }
         if (g.K % (32 * slices) != 0) { vs::set_error("weight-gradient GEMM: K=%d must be a multiple of %d", g.K, 32 * slices); return -1; }
+        if (BF16 == kDtSplit && g.K % (64 * slices) != 0) { vs::set_error("weight-gradient GEMM (split operands): K=%d floats must be a multiple of %d (whole 32-float blocks per slice)", g.K / 2, 32 * slices); return -1; }
         rc = launch_mi<BF16, 4>(g, 2, stream);
     }
     if (rc || !ws) return rc;
@@ -734,7 +735,12 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     VS_CHECK(M > 0 && N > 0 && K > 0 && ksplit >= 1 && ksplit <= 65535, "vs_gemm_wgrad: bad sizes M=%d N=%d K=%d ksplit=%d", M, N, K, ksplit);
     VS_CHECK(ntaps >= 0 && ntaps <= 9 && (ntaps == 0 || shifts), "vs_gemm_wgrad: 0 <= ntaps <= 9, and shifts when ntaps > 0");
     VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_wgrad: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_gemm_wgrad: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 4, "vs_gemm_wgrad: dtype must be 1 (f16), 2 (bf16) or 4 (split: A f32, W packed by vs_split_pack_weight / vs_transpose_pack_split)");
+    if (dtype == 4) {   // split operands: f32 rows addressed in 2-byte units (gemm_common.h, kDtSplit); no tap shifts (a packed W cannot be shifted)
+        VS_CHECK(ntaps == 0, "vs_gemm_wgrad: split operands take no tap shifts (pack one shifted image per tap: vs_transpose_pack_split)");
+        VS_CHECK(lda % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0, "vs_gemm_wgrad: split operands need 16-byte aligned rows");
+        K *= 2; lda *= 2; ldw *= 2; a_slice_stride *= 2; w_slice_stride *= 2;
+    }
     GemmArgs g;
     g.A = A; g.W = W; g.bias = nullptr; g.out = out; g.gate = nullptr; g.resid = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo;
@@ -747,8 +753,9 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
     for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
     VS_CHECK(accumulate || workspace, "vs_gemm_wgrad: accumulate = 0 (overwrite out) needs a workspace; the atomics path can only add");
-    const int rc = dtype == 2 ? launch_wgrad<true>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
-                              : launch_wgrad<false>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream);
+    const int rc = dtype == 4 ? launch_wgrad<kDtSplit>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
+                 : dtype == 2 ? launch_wgrad<1>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
+                              : launch_wgrad<0>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream);
     if (rc) return rc;
     VS_HIP(hipGetLastError());
     return 0;

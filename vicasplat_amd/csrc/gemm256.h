@@ -542,7 +542,8 @@ __global__ void __launch_bounds__(512, 1) gemm256_splitk_kernel(const GemmArgs g
         }
     }
     f4 acc[8][4];
-    mainloop256<BF16, false>(st, KT, acc, smem, lane, wid);
+    if constexpr (BF16 == kDtSplit) mainloop256_split<false>(st, KT, acc, smem, lane, wid);   // (split class: A f32, W packed; K counts 2-byte units)
+    else mainloop256<BF16, false>(st, KT, acc, smem, lane, wid);
     g.bias = nullptr;
     g.gate = nullptr;
     gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);

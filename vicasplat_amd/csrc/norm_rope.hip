@@ -208,10 +208,11 @@ __device__ __forceinline__ void st16(unsigned short *p, float v) {
     else *p = Out<1>::cv(v);
 }
 
-// one wave per row; lane = (q|k selector) * 32 + pair index; loops over heads. head_dim fixed at 64.
-template <bool BF16>
+// one wave per row; lane = (q|k selector) * 32 + pair index; loops over heads. head_dim fixed at 64.  DT 0 f32 (the split / f32 classes'
+// packed q|k|v and its gradient), 1 f16, 2 bf16.
+template <int DT>
 __global__ void __launch_bounds__(256)
-rope_qk_kernel(unsigned short *__restrict__ buf, long long ld, int rows, int H, int k_col, const int32_t *__restrict__ pos,
+rope_qk_kernel(typename Out<DT>::T *__restrict__ buf, long long ld, int rows, int H, int k_col, const int32_t *__restrict__ pos,
                const uint8_t *__restrict__ kind, float base2d, float theta1d, float dir) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -231,12 +232,15 @@ rope_qk_kernel(unsigned short *__restrict__ buf, long long ld, int rows, int H, 
     }
     float sn, cs;
     sincosf(ang * dir, &sn, &cs);  // dir = -1: the inverse rotation = the backward pass of the (orthogonal) embedding
-    unsigned short *r = buf + (long long)row * ld + (sel ? k_col : 0);
+    typename Out<DT>::T *r = buf + (long long)row * ld + (sel ? k_col : 0);
     for (int h = 0; h < H; ++h) {
-        unsigned short *pu = r + h * 64 + iu, *pv = r + h * 64 + iv;
-        const float u = ld16<BF16>(pu), v = ld16<BF16>(pv);
-        st16<BF16>(pu, u * cs - v * sn);
-        st16<BF16>(pv, v * cs + u * sn);
+        typename Out<DT>::T *pu = r + h * 64 + iu, *pv = r + h * 64 + iv;
+        float u, v;
+        if constexpr (DT == 0) { u = *pu; v = *pv; }
+        else { u = ld16<DT == 2>(pu); v = ld16<DT == 2>(pv); }
+        const float a = u * cs - v * sn, b = v * cs + u * sn;
+        if constexpr (DT == 0) { *pu = a; *pv = b; }
+        else { st16<DT == 2>(pu, a); st16<DT == 2>(pv, b); }
     }
 }
 
@@ -326,12 +330,13 @@ extern "C" int vs_rope_qk_dir(void *buf, int64_t ld, int32_t rows, int32_t H, in
                               const uint8_t *kind, float base2d, float theta1d, float dir, int32_t dtype, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(buf && pos, "vs_rope_qk: null pointer");
-    VS_CHECK(dtype == 1 || dtype == 2, "vs_rope_qk: dtype must be 1 (f16) or 2 (bf16)");
+    VS_CHECK(dtype >= 0 && dtype <= 2, "vs_rope_qk: dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
     VS_CHECK(dir == 1.0f || dir == -1.0f, "vs_rope_qk_dir: dir must be +1 (forward) or -1 (inverse / backward)");
     if (rows <= 0 || H <= 0) return 0;
     dim3 grid(vs::cdiv(rows, 4)), block(256);
-    if (dtype == 2) hipLaunchKernelGGL(rope_qk_kernel<true>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
-    else hipLaunchKernelGGL(rope_qk_kernel<false>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
+    if (dtype == 2) hipLaunchKernelGGL(rope_qk_kernel<2>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
+    else if (dtype == 1) hipLaunchKernelGGL(rope_qk_kernel<1>, grid, block, 0, stream, (unsigned short *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
+    else hipLaunchKernelGGL(rope_qk_kernel<0>, grid, block, 0, stream, (float *)buf, ld, rows, H, k_col, pos, kind, base2d, theta1d, dir);
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -561,6 +561,12 @@ def gated_resid(x: torch.Tensor, y: torch.Tensor, gate: Optional[torch.Tensor] =
     assert gate is None or (gate.is_contiguous() and gate.dtype == torch.float32 and gate.shape[1] == x.shape[1])
     if out is None:
         out = torch.empty_like(x)
+    if y.dtype == torch.float32:      # f32 branch (split / f32 operand classes)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_gated_resid_f32(L.ptr(x), L.ptr(y), y.stride(0), L.ptr(gate), gate_rows, L.ptr(out), x.shape[0], x.shape[1], grp_in,
+                                            grp_out, grp_off, L.stream_ptr(dev))
+        L.check(rc, "vs_gated_resid_f32")
+        return out
     with torch.cuda.device(dev):
         rc = L.lib().vs_gated_resid(L.ptr(x), L.ptr(y), y.stride(0), L.ptr(gate), gate_rows, L.ptr(out), x.shape[0], x.shape[1], grp_in,
                                     grp_out, grp_off, _DT[y.dtype], L.stream_ptr(dev))
@@ -575,6 +581,12 @@ def gated_resid_backward(dout: torch.Tensor, y: torch.Tensor, gate: Optional[tor
     dev = L.require_device(dout, y, gate, dy)
     assert dout.dim() == 2 and dout.is_contiguous() and dout.dtype == torch.float32 and dy.stride(1) == 1 and dy.dtype == y.dtype
     dgate = None if gate is None else torch.zeros_like(gate)
+    if y.dtype == torch.float32:
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_gated_resid_backward_f32(L.ptr(dout), L.ptr(y), y.stride(0), L.ptr(gate), gate_rows, L.ptr(dy), dy.stride(0),
+                                                     L.ptr(dgate), dout.shape[0], dout.shape[1], grp_in, grp_out, grp_off, L.stream_ptr(dev))
+        L.check(rc, "vs_gated_resid_backward_f32")
+        return dgate
     with torch.cuda.device(dev):
         rc = L.lib().vs_gated_resid_backward(L.ptr(dout), L.ptr(y), y.stride(0), L.ptr(gate), gate_rows, L.ptr(dy), dy.stride(0),
                                              L.ptr(dgate), dout.shape[0], dout.shape[1], grp_in, grp_out, grp_off, _DT[y.dtype],
@@ -586,8 +598,13 @@ def gated_resid_backward(dout: torch.Tensor, y: torch.Tensor, gate: Optional[tor
 def gelu16(z: torch.Tensor) -> torch.Tensor:
     """gelu_erf(z) on a contiguous 16-bit tensor (numel % 8 == 0)."""
     dev = L.require_device(z)
-    assert z.is_contiguous() and z.dtype in (torch.float16, torch.bfloat16)
+    assert z.is_contiguous() and z.dtype in (torch.float16, torch.bfloat16, torch.float32)
     out = torch.empty_like(z)
+    if z.dtype == torch.float32:
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_gelu_f32(L.ptr(z), L.ptr(out), z.numel(), L.stream_ptr(dev))
+        L.check(rc, "vs_gelu_f32")
+        return out
     with torch.cuda.device(dev):
         rc = L.lib().vs_gelu16(L.ptr(z), L.ptr(out), z.numel(), _DT[z.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_gelu16")
@@ -599,6 +616,11 @@ def gelu_backward(dy: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     dev = L.require_device(dy, z)
     assert dy.shape == z.shape and dy.dtype == z.dtype and dy.is_contiguous() and z.is_contiguous()
     dz = torch.empty_like(dy)
+    if z.dtype == torch.float32:
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_gelu_backward_f32(L.ptr(dy), L.ptr(z), L.ptr(dz), dy.numel(), L.stream_ptr(dev))
+        L.check(rc, "vs_gelu_backward_f32")
+        return dz
     with torch.cuda.device(dev):
         rc = L.lib().vs_gelu_backward(L.ptr(dy), L.ptr(z), L.ptr(dz), dy.numel(), _DT[dy.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_gelu_backward")
@@ -706,6 +728,11 @@ def relu_mask(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     dev = L.require_device(dy, x)
     assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous() and x.is_contiguous()
     out = torch.empty_like(dy)
+    if x.dtype == torch.float32:
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_relu_mask_f32(L.ptr(dy), L.ptr(x), L.ptr(out), dy.numel(), L.stream_ptr(dev))
+        L.check(rc, "vs_relu_mask_f32")
+        return out
     with torch.cuda.device(dev):
         rc = L.lib().vs_relu_mask16_to(L.ptr(dy), L.ptr(x), L.ptr(out), dy.numel(), L.stream_ptr(dev))
     L.check(rc, "vs_relu_mask16_to")
@@ -835,10 +862,202 @@ def conv3x3_backward(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu
 def upsample2x_backward_nhwc(dout: torch.Tensor) -> torch.Tensor:
     """Backward of upsample2x_nhwc (no add): dout [N,2H,2W,C] contiguous 16-bit -> din [N,H,W,C]."""
     dev = L.require_device(dout)
-    assert dout.dim() == 4 and dout.is_contiguous() and dout.dtype in (torch.float16, torch.bfloat16)
+    assert dout.dim() == 4 and dout.is_contiguous() and dout.dtype in (torch.float16, torch.bfloat16, torch.float32)
     N, Ho, Wo, Cc = dout.shape
     din = torch.empty((N, Ho // 2, Wo // 2, Cc), dtype=dout.dtype, device=dev)
+    if dout.dtype == torch.float32:
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_upsample2x_backward_f32_nhwc(L.ptr(dout), L.ptr(din), N, Ho // 2, Wo // 2, Cc, L.stream_ptr(dev))
+        L.check(rc, "vs_upsample2x_backward_f32_nhwc")
+        return din
     with torch.cuda.device(dev):
         rc = L.lib().vs_upsample2x_backward_nhwc(L.ptr(dout), L.ptr(din), N, Ho // 2, Wo // 2, Cc, _DT[dout.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_upsample2x_backward_nhwc")
     return din
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Split-class backward (reference precision: f32 tensors, three f16 MFMAs per product; csrc/split_bwd.hip, gemm.hip, attention_bwd.hip).
+# Gradients must sit in the f16 range (|g| < 65504, typical magnitude >~ 1e-2 for full precision): callers.training_step keeps its
+# power-of-two loss scale for this class too.
+# ------------------------------------------------------------------------------------------------------------------------------
+def transpose_f32(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0)) -> torch.Tensor:
+    """x [R,C] f32 (row stride any multiple of 4 or contiguous) -> [C, Rpad] f32, Rpad = R rounded up to pad_to (a multiple of 64), zero padded.
+    conv_hw = (H, W) with tap = (dy, dx): row r reads pixel r shifted by the tap, zero outside its image."""
+    dev = L.require_device(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0
+    R, Cc = x.shape
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, Rpad), dtype=torch.float32, device=dev)
+    h, w = conv_hw if conv_hw is not None else (0, 0)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_transpose_f32(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, int(relu), h, w, tap[0], tap[1], L.stream_ptr(dev))
+    L.check(rc, "vs_transpose_f32")
+    return out
+
+
+def transpose_pack_split(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0),
+                         scale_exp: int = 0) -> SplitWeight:
+    """transpose_f32 written as the packed split "weight" operand [C, Rpad] (SplitWeight, acc_scale = 2^-scale_exp)."""
+    dev = L.require_device(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0
+    R, Cc = x.shape
+    Rpad = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, Rpad), dtype=torch.int32, device=dev)
+    h, w = conv_hw if conv_hw is not None else (0, 0)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_transpose_pack_split(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, int(relu), h, w, tap[0], tap[1], scale_exp,
+                                             L.stream_ptr(dev))
+    L.check(rc, "vs_transpose_pack_split")
+    return SplitWeight(out, 2.0 ** (-scale_exp), (Cc, Rpad))
+
+
+def split16(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """f32 [rows, C] (row stride any multiple of 4) -> (hi, lo) f16 [rows, C] contiguous: hi = rne16(x), lo = rne16(x - hi)."""
+    dev = L.require_device(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and x.shape[1] % 8 == 0
+    hi = torch.empty(x.shape, dtype=torch.float16, device=dev)
+    lo = torch.empty_like(hi)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_split16(L.ptr(x), x.stride(0), L.ptr(hi), L.ptr(lo), hi.stride(0), x.shape[0], x.shape[1], L.stream_ptr(dev))
+    L.check(rc, "vs_split16")
+    return hi, lo
+
+
+def gemm_wgrad_split(a: torch.Tensor, w: SplitWeight, out: torch.Tensor, ksplit: int) -> torch.Tensor:
+    """out32 [M,N] = a [M,K] @ w [N,K]^T in the split class, the reduction cut into ksplit slices (vs_gemm_wgrad, dtype 4; partial
+    tiles in a workspace + a reduce kernel).  K % (64 * ksplit) == 0."""
+    wd = w.data
+    dev = L.require_device(a, wd, out)
+    assert a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and wd.dim() == 2 and wd.stride(1) == 1 and a.shape[1] == wd.shape[1]
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == (a.shape[0], wd.shape[0])
+    M, N, K = a.shape[0], wd.shape[0], a.shape[1]
+    assert K % (64 * ksplit) == 0, (K, ksplit)
+    ws = torch.empty(max(2, ksplit) * M * N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(wd), L.ptr(out), M, N, K, a.stride(0), wd.stride(0), N, 0, 0, 0, None, 0, ksplit, 4, L.ptr(ws),
+                                   ws.numel() * 4, 0, L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_wgrad(split)")
+    if w.acc_scale != 1.0:
+        out.mul_(w.acc_scale)
+    return out
+
+
+def _wgrad_split(dyT: torch.Tensor, xT: SplitWeight, out: torch.Tensor) -> torch.Tensor:
+    M, N, K = dyT.shape[0], xT.shape[0], dyT.shape[1]
+    if M % 256 == 0 and N % 256 == 0:
+        tiles = (M // 256) * (N // 256)
+        ks = max(1, min((256 + tiles // 2) // tiles, K // 512))
+        while ks > 1 and K % (64 * ks) != 0:
+            ks -= 1
+    else:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        ks = max(2, min(768 // tiles, K // 512, 1024))
+        while ks > 2 and K % (64 * ks) != 0:
+            ks -= 1
+    return gemm_wgrad_split(dyT, xT, out, ks)
+
+
+def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_dx: bool = True, need_dw: bool = True, need_db: bool = True,
+                          scale_exp: Optional[int] = None):
+    """Backward of y = x @ w^T + b in the split class: dy [M,N], x [M,K], w [N,K] all f32 -> dx [M,K], dw [N,K], db [N] f32.
+    dx = vs_gemm_split(dy, pack(w^T)); dw = vs_gemm_wgrad(transpose(dy), transpose_pack(x)) over the M rows; db = column sums."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dev = dy.device
+    assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
+    dx = dw = db = None
+    if need_dx:
+        wt = w.detach().float().t()
+        if N % 32 != 0:
+            wt = torch.nn.functional.pad(wt, (0, (-N) % 32))
+            dyp = torch.nn.functional.pad(dy, (0, (-N) % 32))
+        else:
+            dyp = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
+        wtp = split_pack_weight(wt.contiguous(), scale_exp)
+        dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+        _gemm_split(dyp, wtp, None, dx, EPI_STORE32)
+    if need_dw:
+        Mp = (M + 1023) // 1024 * 1024 if M >= 4096 else (M + 127) // 128 * 128      # (room for the K split; zero rows cost nothing exact)
+        dys = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
+        xs = x if (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+        dyT = transpose_f32(dys, Mp)                 # [N, Mp]
+        xT = transpose_pack_split(xs, Mp)            # [K, Mp] packed
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        _wgrad_split(dyT, xT, dw)
+    if need_db:
+        db = colsum(dy)
+    return dx, dw, db
+
+
+def attention_backward_split(qkv_q: torch.Tensor, qkv_k: torch.Tensor, qkv_v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, *,
+                             nbatch: int, H: int, Lq: int, Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0,
+                             kv_seg: Optional[torch.Tensor] = None, q_kvlen: Optional[torch.Tensor] = None, max_keys: int = 0, scale: float = 0.125,
+                             dq_out: Optional[torch.Tensor] = None, dk_out: Optional[torch.Tensor] = None, dv_out: Optional[torch.Tensor] = None):
+    """Backward of attention(..., split=True): q / k / v f32 views [rows, H*64] (row stride any), out / dout f32.  Returns (dq, dk, dv) f32;
+    dq_out / dk_out / dv_out: views to write into (e.g. the blocks of a packed [rows, 3*H*64] gradient).  With key segments dk / dv are
+    accumulated with atomics (zeroed here)."""
+    dev = L.require_device(qkv_q, qkv_k, qkv_v, out, dout, lse, kv_seg, q_kvlen)
+    Cc = H * 64
+    for t in (qkv_q, qkv_k, qkv_v, out, dout):
+        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.shape[1] == Cc
+    dout = dout if (dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0) else dout.contiguous()
+    qh, ql = split16(qkv_q)
+    kh, kl = split16(qkv_k)
+    vh, vl = split16(qkv_v)
+    dh, dl = split16(dout)
+    dq = dq_out if dq_out is not None else torch.empty((qkv_q.shape[0], Cc), dtype=torch.float32, device=dev)
+    if kv_seg is None:
+        dk = dk_out if dk_out is not None else torch.empty((qkv_k.shape[0], Cc), dtype=torch.float32, device=dev)
+        dv = dv_out if dv_out is not None else torch.empty((qkv_v.shape[0], Cc), dtype=torch.float32, device=dev)
+    else:
+        assert dk_out is None and dv_out is None
+        dk = torch.zeros((qkv_k.shape[0], Cc), dtype=torch.float32, device=dev)
+        dv = torch.zeros((qkv_v.shape[0], Cc), dtype=torch.float32, device=dev)
+    for t in (dq, dk, dv):
+        assert t.dtype == torch.float32 and t.stride(1) == 1
+    delta = torch.empty((qkv_q.shape[0], H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_attention_backward_split(L.ptr(qh), L.ptr(ql), L.ptr(kh), L.ptr(kl), L.ptr(vh), L.ptr(vl), L.ptr(dh), L.ptr(dl), L.ptr(out),
+                                                 L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dq), L.ptr(dk), L.ptr(dv), nbatch, H, Lq, Lk, q_batch_rows,
+                                                 k_batch_rows, qh.stride(0), kh.stride(0), vh.stride(0), dh.stride(0), out.stride(0), dout.stride(0),
+                                                 dq.stride(0), dk.stride(0), dv.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), max_keys, scale,
+                                                 L.stream_ptr(dev))
+    L.check(rc, "vs_attention_backward_split")
+    return dq, dk, dv
+
+
+def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu_in: bool = False, need_dx: bool = True, need_db: bool = True,
+                           scale_exp: Optional[int] = None):
+    """Backward of conv3x3_nhwc(x, pack(w), relu_in=relu_in) (stride 1, pad 1) in the split class.  dy [N,H,W,Cout], x [N,H,W,Cin] f32 NHWC,
+    w the module's [Cout,Cin,3,3] f32 parameter -> dx [N,H,W,Cin], dw [Cout,Cin,3,3], db [Cout], all f32.
+      dx: the forward kernel on the spatially flipped, channel-transposed weights (ReLU backward in its epilogue);
+      dw: per tap one weight-gradient GEMM dY^T [Cout, pixels] x act(X shifted by the tap)^T [Cin, pixels] -- the shifted operand is
+          written by the transposing pack kernel (zero outside the image), so no im2col buffer and no zero-bordered copy exists."""
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    dev = x.device
+    assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.is_contiguous() and x.is_contiguous()
+    dx = None
+    if need_dx:
+        wd = w.detach().float().flip(2, 3).permute(1, 2, 3, 0).contiguous()          # [Cin, 3, 3, Cout]: flipped taps, channels swapped
+        pad_o = (-Cout) % 32
+        dyp = dy
+        if pad_o:
+            wd = torch.nn.functional.pad(wd, (0, pad_o))
+            dyp = torch.nn.functional.pad(dy, (0, pad_o))
+        wdp = split_pack_weight(wd, scale_exp)
+        dx = conv3x3_nhwc(dyp, wdp, None, mask_by=x if relu_in else None)
+    P = N * H * W
+    Pp = (P + 1023) // 1024 * 1024 if P >= 4096 else (P + 127) // 128 * 128
+    dyT = transpose_f32(dy.view(P, Cout), Pp)                                       # [Cout, Pp]
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    tmp = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    x2 = x.view(P, Cin)
+    for ky in range(3):
+        for kx in range(3):
+            xT = transpose_pack_split(x2, Pp, relu=relu_in, conv_hw=(H, W), tap=(ky - 1, kx - 1))     # [Cin, Pp] packed
+            _wgrad_split(dyT, xT, tmp)
+            dw[:, :, ky, kx] = tmp
+    db = colsum(dy.view(P, Cout)) if need_db else None
+    return dx, dw, db
