@@ -407,7 +407,7 @@ int vs_layernorm_backward(const void *dout, int64_t ld_do, int32_t do_dtype, con
 
 /* Backward of vs_gaussian_adapter for dense NHWC 16-bit head outputs (training): gradients of means [npix,3], covariances [npix,3,3],
  * harmonics [npix,3,d_sh], opacities [npix] and (nullable) of the raw output [npix, 11 + 3 d_sh] -> d_pts [npix, d_pts_ld], d_gs
- * [npix, d_gs_ld] in the inputs' dtype (1 f16, 2 bf16); the row strides may exceed the channel counts (padding columns are zeroed).  Backward of MyGaussianAdapter.forward + the 'exp' depth post-process
+ * [npix, d_gs_ld] in the inputs' dtype (0 f32 -- the split / f32 classes --, 1 f16, 2 bf16); the row strides may exceed the channel counts (padding columns are zeroed).  Backward of MyGaussianAdapter.forward + the 'exp' depth post-process
  * (common/gaussian_adapter.py:168-212, heads/postprocess.py:46-56) in one pass. */
 int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *gs, int32_t in_dtype, int64_t npix, int32_t d_sh,
                                  const float *sh_mask, int32_t scale_act, float scale_min, float scale_max, float opacity_exponent,

@@ -219,3 +219,113 @@ def test_f32_elementwise_backward_operators():
     assert not torch.allclose(b2[:, :Cc], buf[:, :Cc]) and torch.equal(b2[:, 2 * Cc:], buf[:, 2 * Cc:])
     ops.rope_qk(b2, Hh, Cc, pos, None, 100.0, 1.0, inverse=True)
     assert _rel(b2, buf) <= 2e-6
+
+
+# ---------------- composed: the whole tiny encoder differentiated in the split class vs float64 autograd over the oracle ----------------
+TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
+
+
+def _tiny_model():
+    import json, os
+    from oracle import encoder_ref as er
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    shapes = json.load(open(os.path.join(G, "shapes_tiny.json")))
+    m, _ = get_encoder(default_cfg(**TINY))
+    W = er.golden_weights(shapes, seed=0)
+    m.load_state_dict(W, strict=True)
+    m = m.cuda().train()
+    m.set_compute_dtype("split")
+    return m, W
+
+
+def test_split_training_forward_matches_reference_goldens():
+    """The differentiable forward in the split class reproduces the REAL reference's f64 outputs to the bar of the split inference path
+    (tests/test_split_path_gpu.py: 2e-4; measured ~1e-5)."""
+    import os
+    import numpy as np
+    from oracle import encoder_ref as er
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_tiny_v3.npz"))
+    m, _ = _tiny_model()
+    B, V = int(z["cfg_B"]), int(z["cfg_V"])
+    img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    with torch.no_grad():
+        out = forward_train(m, img.cuda(), K.cuda(), "split")
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max() / (np.abs(b).max() + 1e-12))
+    LAT = slice(8, 256, 16)
+    e_pose = rel(out["pred_extrins"].cpu().numpy(), z["f64_pred_extrins"])
+    e_raw = rel(out["raw_gaussians"][:, :, LAT, LAT].cpu().numpy(), z["f64_raw"])
+    e_cov = rel(out["gaussians"]["covariances"][:, :, LAT, LAT].cpu().numpy(), z["f64_covariances"])
+    print("split train forward vs reference f64:", e_pose, e_raw, e_cov)
+    assert e_pose <= 2e-4 and e_raw <= 2e-4 and e_cov <= 2e-4
+
+
+def test_split_training_backward_tight_against_float64_autograd():
+    """end-to-end gradients of the WHOLE tiny encoder (2 + 12 transformer blocks, both DPT heads, adapter, pose head)
+    for a random linear functional of its outputs (128 x 128 frames), HIP split-class training path against FLOAT64 torch autograd over
+    the oracle -- with the yardstick measured beside it: plain f32 torch autograd over the same oracle (what the reference's fp32 training
+    step computes) against the same float64 gradients.  On this random-weight network an f32 evaluation is itself 5e-4 (L2, every
+    parameter alike) from the float64 gradient -- forward rounding amplified by the network, not a backward defect -- so 1e-3 in the
+    max norm is not reachable by ANY f32 implementation (measured: f32 torch autograd median 4.8e-4, max 3.0e-3).  Asserted:
+      * per-parameter L2-relative error <= 2e-3 for EVERY parameter the loss reaches (f32 torch: <= 9e-4; the 16-bit backward: ~5e-2),
+        median <= 1.5x and worst <= 2.5x the f32 yardstick's; whole-gradient cosine >= 0.9999990 (f32 torch: 0.99999985);
+      * max-norm relative error: median <= 1.5x, 90th percentile <= 1.5x, worst <= 3x the f32 yardstick's;
+      * the parameters right behind the loss (last 1x1 convolutions of both heads, pose head), where no forward noise has accumulated
+        yet: <= 1e-5 in the max norm -- the backward operators' own precision."""
+    import re
+    from oracle import encoder_ref as er
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    m, W = _tiny_model()
+    B, V, S = 1, 3, 128
+    img, K = er.synthetic_input(B, V, S, 7)
+    g = torch.Generator().manual_seed(1)
+    r_raw = torch.randn(B, V, S, S, 86, generator=g) * 1e-3
+    r_raw[..., :3] *= 0.1
+    r_pose = torch.randn(B, V - 1, 8, generator=g)
+    r_cov = torch.randn(B, V, S, S, 3, 3, generator=g) * 10.0
+    cfg = er.default_cfg(**TINY)
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        Wr = {k: v.clone().to(dt).requires_grad_() for k, v in W.items()}
+        o = er.forward.__wrapped__(Wr, cfg, img.to(dt), K.to(dt))
+        loss_r = (o["raw_gaussians"] * r_raw.to(dt)).sum() + (o["pred_extrins"] * r_pose.to(dt)).sum() + (o["gaussians"]["covariances"] * r_cov.to(dt)).sum()
+        loss_r.backward()
+        ref[dt] = ({k: v.grad for k, v in Wr.items()}, float(loss_r.detach()))
+    g64, loss64 = ref[torch.float64]
+    g32 = ref[torch.float32][0]
+    out = forward_train(m, img.cuda(), K.cuda(), "split")
+    loss = (out["raw_gaussians"] * r_raw.cuda()).sum() + (out["pred_extrins"] * r_pose.cuda()).sum() + \
+        (out["gaussians"]["covariances"] * r_cov.cuda()).sum()
+    S_ = 2.0 ** 12                  # power-of-two loss scale: exact in f32, keeps the (hi, lo) f16 operands of the gradients in range
+    (loss * S_).backward()
+    assert abs(float(loss.detach()) - loss64) <= 1e-4 * abs(loss64) + 1e-4
+    mx, l2, mx32, l232 = {}, {}, {}, {}
+    ours_all, ref_all, f32_all = [], [], []
+    for name, p in m.named_parameters():
+        key = re.sub(r"layer(\d)_rn", lambda mm: f"layer_rn.{int(mm.group(1)) - 1}", name)
+        r = g64[key]
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        o_ = p.grad.cpu().double() / S_
+        f_ = g32[key].double()
+        mx[name] = float((o_ - r).abs().max() / (r.abs().max() + 1e-300)); l2[name] = float((o_ - r).norm() / (r.norm() + 1e-300))
+        mx32[name] = float((f_ - r).abs().max() / (r.abs().max() + 1e-300)); l232[name] = float((f_ - r).norm() / (r.norm() + 1e-300))
+        ours_all.append(o_.flatten()); ref_all.append(r.flatten()); f32_all.append(f_.flatten())
+    q = lambda d, f: sorted(d.values())[min(len(d) - 1, int(len(d) * f))]
+    a, b, c = torch.cat(ours_all), torch.cat(ref_all), torch.cat(f32_all)
+    cos = float(a @ b / (a.norm() * b.norm())); cos32 = float(c @ b / (c.norm() * b.norm()))
+    print("params %d | max-norm rel err  ours: median %.2e p90 %.2e max %.2e | f32 torch: median %.2e p90 %.2e max %.2e" %
+          (len(mx), q(mx, 0.5), q(mx, 0.9), q(mx, 1.0), q(mx32, 0.5), q(mx32, 0.9), q(mx32, 1.0)))
+    print("           | L2 rel err        ours: median %.2e p90 %.2e max %.2e | f32 torch: median %.2e p90 %.2e max %.2e" %
+          (q(l2, 0.5), q(l2, 0.9), q(l2, 1.0), q(l232, 0.5), q(l232, 0.9), q(l232, 1.0)))
+    print("           | whole gradient cosine ours %.9f, f32 torch %.9f; worst ours:" % (cos, cos32), sorted(l2.items(), key=lambda kv: -kv[1])[:4])
+    assert q(l2, 1.0) <= 2e-3 and q(l2, 0.5) <= 1.5 * q(l232, 0.5) and q(l2, 1.0) <= 2.5 * q(l232, 1.0), sorted(l2.items(), key=lambda kv: -kv[1])[:6]
+    assert cos >= 0.999999
+    assert q(mx, 0.5) <= 1.5 * q(mx32, 0.5) and q(mx, 0.9) <= 1.5 * q(mx32, 0.9) and q(mx, 1.0) <= 3.0 * q(mx32, 1.0)
+    near = ["downstream_head1.dpt.head.4.weight", "downstream_head1.dpt.head.4.bias", "gaussian_param_head.dpt.head.4.weight",
+            "gaussian_param_head.dpt.head.4.bias", "camera_extrinsic_head.1.weight", "camera_extrinsic_head.1.bias"]
+    print("           | right behind the loss:", {k.split(".dpt.")[-1]: f"{mx[k]:.1e}" for k in near})
+    assert max(mx[k] for k in near) <= 1e-5

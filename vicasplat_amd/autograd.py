@@ -15,6 +15,13 @@ import torch
 
 from . import ops
 
+SPLIT = "split"      # compute-dtype tag of the split operand class: f32 tensors, three f16 MFMAs per product (csrc/gemm_common.h kDtSplit)
+
+
+def act_dtype(dt):
+    """torch dtype of the activations of operand class `dt`."""
+    return torch.float32 if dt == SPLIT else dt
+
 
 class LinearFn(torch.autograd.Function):
     """y16 = x @ w^T + b on the MFMA GEMM; backward = dgrad / wgrad on the same kernels (ops.linear_backward).
@@ -59,6 +66,8 @@ class LinearFn(torch.autograd.Function):
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype, rope=None) -> torch.Tensor:
     """nn.Linear in the operand dtype `dt`.  K must be a multiple of 64 for the MFMA kernels; tiny odd shapes (the 9 -> C
     intrinsic embedding) stay on torch in f32."""
+    if dt == SPLIT:
+        return LinearSplitFn.apply(x, w, b, rope)
     K = x.shape[-1]
     if K % 64 != 0:
         assert rope is None
@@ -71,9 +80,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torc
 
 class LinearSplitFn(torch.autograd.Function):
     """y = x @ w^T + b in the SPLIT operand class (f32 in / out, every product three f16 MFMAs on hi+lo pairs: f32-class results; csrc/
-    gemm_common.h kDtSplit): the tiny f32 layers of the camera-token path of the training forward (intrinsic embedding, AdaLN projections,
-    camera MLPs, pose / fov heads) without a vendor-BLAS launch in either direction (143 `Cijk_*` launches per step came
-    from F.linear here).  dx = dy @ w and dw = dy^T @ x are the same kernel on packed transposes; db = column sums (vs_colsum)."""
+    gemm_common.h kDtSplit), forward AND backward (ops.linear_backward_split: dx on the packed transposed weight, dw = dy^T x on the split
+    weight-gradient GEMM over transposed / packed operands, db = column sums): the reference-precision nn.Linear of the training step, and
+    the tiny f32 layers of the camera-token path without a vendor-BLAS launch in either direction.
+    rope = (pos, kind, H, C, base2d, theta1d): packed q | k | v projection with the rotary embedding in the GEMM epilogue; the backward
+    un-rotates dq | dk first (on a copy unless the producer marked the gradient buffer as ours alone)."""
 
     @staticmethod
     def _pad32(t, dim):
@@ -90,7 +101,10 @@ class LinearSplitFn(torch.autograd.Function):
 
     @staticmethod
     def _scale_exp(w):
-        key = (id(w), w.data_ptr())
+        base = w if w.is_leaf else w._base
+        if base is None or not base.is_leaf:     # a temporary (concatenated / re-laid-out weights): nothing stable to key a cache on
+            return ops.split_scale_exp(w)
+        key = (id(base), w.data_ptr(), tuple(w.shape))
         ent = LinearSplitFn._exp_cache.get(key)
         if ent is None or ent[1] <= 0:
             ent = [ops.split_scale_exp(w), 64]
@@ -99,7 +113,7 @@ class LinearSplitFn(torch.autograd.Function):
         return ent[0]
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, rope=None):
         K, N = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, K).float()
         xp = LinearSplitFn._pad32(x2, 1)
@@ -107,34 +121,42 @@ class LinearSplitFn(torch.autograd.Function):
         ctx.scale_exp = e
         wp = ops.split_pack_weight(LinearSplitFn._pad32(w.detach().float(), 1), e)
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
-        ops.gemm(xp, wp, None if b is None else b.detach().float().contiguous(), y, ops.EPI_STORE32)
-        ctx.save_for_backward(x2, w)
-        ctx.meta = (x.shape, b is not None)
-        return y.view(*x.shape[:-1], N)
+        bf = None if b is None else b.detach().float().contiguous()
+        if rope is None:
+            ops.gemm(xp, wp, bf, y, ops.EPI_STORE32)
+        else:
+            pos, kind, H, C, base2d, theta1d = rope
+            ops.gemm_qkv_rope(xp, wp, bf, y, C, pos, kind, base2d, theta1d)
+        ctx.save_for_backward(xp, w)
+        ctx.meta = (x.shape, b is not None, rope)
+        return y if x.dim() == 2 else y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
-        xshape, has_b = ctx.meta
+        xp, w = ctx.saved_tensors
+        xshape, has_b, rope = ctx.meta
         N, K = w.shape
-        dy2 = dy.reshape(-1, N).float().contiguous()
-        M = dy2.shape[0]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:       # dx [M, K] = dy [M, N] @ w [N, K]: reduction over N, "weight" rows = w^T [K, N]
-            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            ops.gemm(LinearSplitFn._pad32(dy2, 1), ops.split_pack_weight(LinearSplitFn._pad32(w.detach().float().t(), 1), ctx.scale_exp), None, dx, ops.EPI_STORE32)
-            dx = dx.view(xshape)
-        if ctx.needs_input_grad[1]:       # dw [N, K] = dy^T [N, M] @ x [M, K]: reduction over M, "weight" rows = x^T [K, M]
-            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            # (x is an activation: packed unscaled, like every activation operand of this class -- and without a host read of its maximum)
-            ops.gemm(LinearSplitFn._pad32(dy2.t(), 1), ops.split_pack_weight(LinearSplitFn._pad32(x2.t(), 1), 0), None, dw, ops.EPI_STORE32)
-        if has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)
-        return dx, dw, db
+        dy2 = dy.reshape(-1, N).float()
+        if dy2.stride(1) != 1 or dy2.stride(0) % 4 != 0 or dy2.data_ptr() % 16 != 0:
+            dy2 = dy2.contiguous()
+        if rope is not None:
+            pos, kind, H, C, base2d, theta1d = rope
+            if dy2.data_ptr() == dy.data_ptr() and not getattr(dy, "_vs_owned_grad", False):
+                dy2 = dy2.clone()
+            ops.rope_qk(dy2, H, C, pos, kind, base2d, theta1d, inverse=True)
+        Kp = xp.shape[1]
+        wk = w.detach().float() if Kp == K else torch.nn.functional.pad(w.detach().float(), (0, Kp - K))
+        dx, dw, db = ops.linear_backward_split(dy2, xp, wk, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
+                                               need_db=has_b and ctx.needs_input_grad[2], scale_exp=ctx.scale_exp)
+        if dx is not None:
+            dx = dx[:, :K].reshape(xshape) if Kp != K else dx.view(xshape)
+        if dw is not None and Kp != K:
+            dw = dw[:, :K].contiguous()
+        return dx, dw, db, None
 
 
-def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    return LinearSplitFn.apply(x, w, b)
+def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rope=None) -> torch.Tensor:
+    return LinearSplitFn.apply(x, w, b, rope)
 
 
 class LayerNormModFn(torch.autograd.Function):
@@ -213,7 +235,7 @@ class AttentionFn(torch.autograd.Function):
         out = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((qkv.shape[0], H), dtype=torch.float32, device=qkv.device)
         ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, nbatch=nbatch, H=H, Lq=Lq, Lk=Lk, q_batch_rows=q_batch_rows,
-                      k_batch_rows=k_batch_rows, kv_seg=kv_seg, q_kvlen=q_kvlen, lse=lse)
+                      k_batch_rows=k_batch_rows, kv_seg=kv_seg, q_kvlen=q_kvlen, lse=lse, split=qkv.dtype == torch.float32)
         ctx.save_for_backward(qkv, out, lse)
         ctx.meta = (nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows, kv_seg, q_kvlen, max_keys)
         return out
@@ -224,7 +246,17 @@ class AttentionFn(torch.autograd.Function):
         nbatch, H, Lq, Lk, qbr, kbr, kv_seg, q_kvlen, max_keys = ctx.meta
         C = H * 64
         dqkv = torch.empty((qkv.shape[0], 3 * C), dtype=qkv.dtype, device=qkv.device)   # dq lands in its block directly; dk / dv are f32
-        if kv_seg is None:   # every K/V row has one owner: dk / dv land in their blocks directly (no zero fill, atomics or cast pass)
+        if qkv.dtype == torch.float32:     # split class (f32 tensors are never run on the exact-f32 MFMA in the training step)
+            kw = dict(nbatch=nbatch, H=H, Lq=Lq, Lk=Lk, q_batch_rows=qbr, k_batch_rows=kbr, q_kvlen=q_kvlen, dq_out=dqkv[:, :C])
+            if kv_seg is None:
+                ops.attention_backward_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, dk_out=dqkv[:, C:2 * C],
+                                             dv_out=dqkv[:, 2 * C:], **kw)
+            else:
+                _, dk, dv = ops.attention_backward_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, kv_seg=kv_seg,
+                                                         max_keys=max_keys, **kw)
+                dqkv[:, C:2 * C] = dk
+                dqkv[:, 2 * C:] = dv
+        elif kv_seg is None:   # every K/V row has one owner: dk / dv land in their blocks directly (no zero fill, atomics or cast pass)
             ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H, Lq=Lq, Lk=Lk,
                                    q_batch_rows=qbr, k_batch_rows=kbr, q_kvlen=q_kvlen, dq_out=dqkv[:, :C], dk_out=dqkv[:, C:2 * C],
                                    dv_out=dqkv[:, 2 * C:])
@@ -247,19 +279,28 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu_in, stride, residual, relu_out):
         dt = x.dtype
-        wp = ops.pack_conv3x3_weight(w, dt)
+        split = dt == torch.float32
+        if split:     # split class: the module's f32 weight packed per call (scale exponent cached, see LinearSplitFn)
+            e = LinearSplitFn._scale_exp(w)
+            wp = ops.split_pack_weight(w.detach().float().permute(0, 2, 3, 1).contiguous(), e)
+            ctx.scale_exp = e
+        else:
+            wp = ops.pack_conv3x3_weight(w, dt)
         x = x.contiguous()
         res = None if residual is None else residual.contiguous()
         y = ops.conv3x3_nhwc(x, wp, None if b is None else b.detach().float().contiguous(), residual=res, relu_in=relu_in,
                              relu_out=relu_out, stride=stride)
-        ctx.save_for_backward(x, wp, y if relu_out else None)
-        ctx.meta = (relu_in, b is not None, stride, residual is not None)
+        if split:
+            ctx.save_for_backward(x, w, y if relu_out else None)
+        else:
+            ctx.save_for_backward(x, wp, y if relu_out else None)
+        ctx.meta = (relu_in, b is not None, stride, residual is not None, split)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wp, y = ctx.saved_tensors
-        relu_in, has_b, stride, has_res = ctx.meta
+        relu_in, has_b, stride, has_res, split = ctx.meta
         dy = dy.contiguous()
         if y is not None:                                  # trailing ReLU: gradient only where the output is positive
             dy = ops.relu_mask(dy, y)
@@ -268,6 +309,10 @@ class Conv3x3Fn(torch.autograd.Function):
             full = torch.zeros(x.shape[:3] + (dy.shape[3],), dtype=dy.dtype, device=dy.device)
             full[:, ::stride, ::stride] = dy
             dy = full
+        if split:
+            dx, dw, db = ops.conv3x3_backward_split(dy, x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0], need_db=has_b,
+                                                    scale_exp=ctx.scale_exp)
+            return dx, dw, (db if has_b else None), None, None, dres, None
         dx, dw, db = ops.conv3x3_backward(dy, x, wp, relu_in=relu_in, need_dx=ctx.needs_input_grad[0], need_db=has_b)
         return dx, dw.permute(0, 3, 1, 2).contiguous(), (db if has_b else None), None, None, dres, None
 

@@ -536,7 +536,7 @@ class LossScaler:
             self.scale, self.good = max(self.scale * 0.5, self.min_scale), 0
 
 
-def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, compute_dtype: torch.dtype = torch.float16,
+def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, compute_dtype=torch.float16,
                   loss_scale: float | LossScaler | None = None, clip: float = 0.5, mse_weight: float = 1.0, camera_weight: float = 0.0,
                   extra_losses=(), allreduce: bool = False, reducer=None, global_step: int = 0, forward_fn=None) -> dict:
     """One optimisation step of the reference's objective (training_step, model_wrapper.py:184-321): MSE (loss_mse.py) + camera
@@ -561,7 +561,14 @@ def training_step(encoder, decoder, batch: dict, optimizer, *, scheduler=None, c
     if loss_scale is None:
         loss_scale = getattr(optimizer, "_vs_loss_scaler", None)
         if loss_scale is None:
-            loss_scale = optimizer._vs_loss_scaler = LossScaler(1024.0 if compute_dtype == torch.float16 else 1.0)
+            # f16: the 16-bit activation gradients need the scale; split class ("split": f32 gradients whose MFMA operands are f16 (hi, lo)
+            # pairs): the scale keeps hi in the f16 normal range and lo out of the subnormals -- larger is better until hi overflows,
+            # which the dynamic scaler finds by itself (an overflowed step is skipped, the scale halved)
+            if compute_dtype == "split":
+                loss_scale = LossScaler(8192.0, max_scale=2.0 ** 24)
+            else:
+                loss_scale = LossScaler(1024.0 if compute_dtype == torch.float16 else 1.0)
+            optimizer._vs_loss_scaler = loss_scale
     scale = loss_scale.scale if isinstance(loss_scale, LossScaler) else float(loss_scale)
     if reducer is not None:
         reducer.zero_grad()

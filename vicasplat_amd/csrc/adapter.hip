@@ -291,7 +291,8 @@ __device__ __forceinline__ unsigned short to16a(float v) {
     }
 }
 
-template <bool BF16>
+// DT 0: f32 inputs and gradients (split / f32 operand classes), 1 f16, 2 bf16
+template <int DT>
 __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdArgs a) {
     // per-pixel results (8 leading d_gs channels) and the mask per SH column are all that goes through LDS: the wide rows (d_harm, d_raw
     // -> d_gs) are an element-wise map written straight from global to global as 16-byte vectors (the [64][75] + [64][86] float tiles
@@ -307,11 +308,12 @@ __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdAr
     const long long i = p0 + lane;
     float dpt[3] = {0.f, 0.f, 0.f}, dg8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const unsigned short *pp = reinterpret_cast<const unsigned short *>(a.pts) + i * a.pts_pix;
-        const unsigned short *gg = reinterpret_cast<const unsigned short *>(a.gs) + i * cg;
+        typedef typename std::conditional<DT == 0, float, unsigned short>::type in_t;
+        const in_t *pp = reinterpret_cast<const in_t *>(a.pts) + i * a.pts_pix;
+        const in_t *gg = reinterpret_cast<const in_t *>(a.gs) + i * cg;
         const float *rr = a.d_raw ? a.d_raw + i * craw : nullptr;   // the 11 leading columns of this pixel's raw-gradient row
         // ---- means ----
-        const float x = cvt16<BF16>(pp[0]), y = cvt16<BF16>(pp[1]), z = cvt16<BF16>(pp[2]);
+        const float x = cvtin<DT>(pp[0]), y = cvtin<DT>(pp[1]), z = cvtin<DT>(pp[2]);
         float gm[3] = {a.d_means[3 * i], a.d_means[3 * i + 1], a.d_means[3 * i + 2]};
         if (rr) { gm[0] += rr[0]; gm[1] += rr[1]; gm[2] += rr[2]; }
         const float d = sqrtf(x * x + y * y + z * z);
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdAr
             dpt[0] = gm[0] * k; dpt[1] = gm[1] * k; dpt[2] = gm[2] * k;
         }
         // ---- opacity ----
-        const float o_raw = cvt16<BF16>(gg[0]);
+        const float o_raw = cvtin<DT>(gg[0]);
         const float p = 1.0f / (1.0f + expf(-o_raw));
         float dmap = 1.0f;
         if (a.opacity_exponent > 0.0f && a.opacity_exponent != 1.0f) {
@@ -335,9 +337,9 @@ __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdAr
         // ---- scales, rotation (forward recomputed) ----
         float sr[3], qr[4], s[3], dsdv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sr[c] = cvt16<BF16>(gg[1 + c]);
+        for (int c = 0; c < 3; ++c) sr[c] = cvtin<DT>(gg[1 + c]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qr[c] = cvt16<BF16>(gg[4 + c]);
+        for (int c = 0; c < 4; ++c) qr[c] = cvtin<DT>(gg[4 + c]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = sr[c];
@@ -404,31 +406,49 @@ __global__ void __launch_bounds__(64) adapter_backward_kernel(const AdapterBwdAr
     for (int c = 0; c < 8; ++c) s_dg8[lane][c] = dg8[c];
     __syncthreads();
     {
-        unsigned short *dst = reinterpret_cast<unsigned short *>(a.d_gs) + p0 * gld;
         const float *gh = a.d_harm + p0 * nh;
         const float *gr = a.d_raw ? a.d_raw + p0 * craw : nullptr;
         const unsigned m = div_magic((unsigned)gld);
-        auto elem = [&](unsigned k) -> unsigned short {
+        auto elemf = [&](unsigned k) -> float {
             const unsigned px = __umulhi(k, m), c = k - px * (unsigned)gld;
             float v = 0.f;
             if (c < 8u) v = s_dg8[px][c];
             else if (c < (unsigned)cg) v = gh[px * nh + (c - 8)] * smask[c - 8] + (gr ? gr[px * craw + 3 + c] : 0.f);
-            return to16a<BF16>(v);
+            return v;
         };
-        const int n = np * gld, nv = n >> 3;
-        for (int k8 = lane; k8 < nv; k8 += 64) {
-            unsigned w[4];
+        const int n = np * gld;
+        if constexpr (DT == 0) {
+            float *dst = reinterpret_cast<float *>(a.d_gs) + p0 * gld;
+            const int nv = n >> 2;
+            for (int k4 = lane; k4 < nv; k4 += 64)
+                reinterpret_cast<float4 *>(dst)[k4] = make_float4(elemf((unsigned)(4 * k4)), elemf((unsigned)(4 * k4 + 1)), elemf((unsigned)(4 * k4 + 2)),
+                                                                   elemf((unsigned)(4 * k4 + 3)));
+            for (int k = (nv << 2) + lane; k < n; k += 64) dst[k] = elemf((unsigned)k);
+        } else {
+            unsigned short *dst = reinterpret_cast<unsigned short *>(a.d_gs) + p0 * gld;
+            auto elem = [&](unsigned k) -> unsigned short { return to16a<DT == 2>(elemf(k)); };
+            const int nv = n >> 3;
+            for (int k8 = lane; k8 < nv; k8 += 64) {
+                unsigned w[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = (unsigned)elem((unsigned)(8 * k8 + 2 * j)) | ((unsigned)elem((unsigned)(8 * k8 + 2 * j + 1)) << 16);
-            reinterpret_cast<uint4 *>(dst)[k8] = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int j = 0; j < 4; ++j) w[j] = (unsigned)elem((unsigned)(8 * k8 + 2 * j)) | ((unsigned)elem((unsigned)(8 * k8 + 2 * j + 1)) << 16);
+                reinterpret_cast<uint4 *>(dst)[k8] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            for (int k = (nv << 3) + lane; k < n; k += 64) dst[k] = elem((unsigned)k);
         }
-        for (int k = (nv << 3) + lane; k < n; k += 64) dst[k] = elem((unsigned)k);
     }
     if (live) {
-        unsigned short *dp = reinterpret_cast<unsigned short *>(a.d_pts) + i * a.d_pts_ld;
+        if constexpr (DT == 0) {
+            float *dp = reinterpret_cast<float *>(a.d_pts) + i * a.d_pts_ld;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dp[c] = to16a<BF16>(dpt[c]);
-        for (int c = 3; c < a.d_pts_ld; ++c) dp[c] = 0;
+            for (int c = 0; c < 3; ++c) dp[c] = dpt[c];
+            for (int c = 3; c < a.d_pts_ld; ++c) dp[c] = 0.f;
+        } else {
+            unsigned short *dp = reinterpret_cast<unsigned short *>(a.d_pts) + i * a.d_pts_ld;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dp[c] = to16a<DT == 2>(dpt[c]);
+            for (int c = 3; c < a.d_pts_ld; ++c) dp[c] = 0;
+        }
     }
 }
 
@@ -476,16 +496,17 @@ extern "C" int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, co
                                             int32_t d_gs_ld, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(pts && gs && sh_mask && d_means && d_cov && d_harmonics && d_opacities && d_pts && d_gs, "vs_gaussian_adapter_backward: null pointer");
-    VS_CHECK((in_dtype == 1 || in_dtype == 2) && d_sh > 0 && 11 + 3 * d_sh <= kMaxCh && scale_act >= 0 && scale_act <= 2 && pts_pix >= 3,
-             "vs_gaussian_adapter_backward: bad argument (16-bit inputs, 11 + 3 d_sh <= %d)", kMaxCh);
+    VS_CHECK(in_dtype >= 0 && in_dtype <= 2 && d_sh > 0 && 11 + 3 * d_sh <= kMaxCh && scale_act >= 0 && scale_act <= 2 && pts_pix >= 3,
+             "vs_gaussian_adapter_backward: bad argument (in_dtype 0 f32 / 1 f16 / 2 bf16, 11 + 3 d_sh <= %d)", kMaxCh);
     VS_CHECK(((uintptr_t)d_gs & 15) == 0, "vs_gaussian_adapter_backward: d_gs must be 16-byte aligned");
     VS_CHECK(d_pts_ld >= pts_pix && d_gs_ld >= 8 + 3 * d_sh && d_gs_ld <= kMaxCh, "vs_gaussian_adapter_backward: output row strides must cover the channels (d_gs_ld <= %d)", kMaxCh);
     if (npix <= 0) return 0;
     AdapterBwdArgs a{pts, gs, pts_pix, npix, d_sh, sh_mask, scale_act, scale_min, scale_max, opacity_exponent, d_means, d_cov, d_harmonics,
                      d_opacities, d_raw, d_pts, d_gs, d_pts_ld, d_gs_ld};
     dim3 grid((unsigned)vs::cdiv64(npix, 64));
-    if (in_dtype == 2) hipLaunchKernelGGL(adapter_backward_kernel<true>, grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(adapter_backward_kernel<false>, grid, dim3(64), 0, stream, a);
+    if (in_dtype == 2) hipLaunchKernelGGL(adapter_backward_kernel<2>, grid, dim3(64), 0, stream, a);
+    else if (in_dtype == 1) hipLaunchKernelGGL(adapter_backward_kernel<1>, grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(adapter_backward_kernel<0>, grid, dim3(64), 0, stream, a);
     VS_HIP(hipGetLastError());
     return 0;
 }

@@ -29,10 +29,13 @@ def _lin_f32(P, name, x):
     return A.linear_split(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
-def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torch.dtype = torch.float16, global_step: int = 0) -> dict:
+def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch.float16, global_step: int = 0) -> dict:
     """image [B,V,3,H,W] normalised to [-1,1], intrinsics [B,V,3,3] -> dict(raw_gaussians [B,V,H,W,86] f32, pred_extrins
-    [B,V-1,8], gaussian_camera_extrins [B,V,4,4], gaussians {means, covariances, harmonics, opacities})."""
+    [B,V-1,8], gaussian_camera_extrins [B,V,4,4], gaussians {means, covariances, harmonics, opacities}).
+    dt: torch.float16 / torch.bfloat16 (16-bit operands and activations) or "split" -- the reference-precision class: f32 activations
+    and gradients, every product three f16 MFMAs on (hi, lo) pairs, forward AND backward (autograd.SPLIT)."""
     P = dict(model.named_parameters())
+    adt = A.act_dtype(dt)                 # dtype of the activations between the operators
     cfg = model.backbone.config
     dev = image.device
     B, V, _, H, Wd = image.shape
@@ -58,8 +61,20 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         x = torch.cat([x, intr], 1)                                                                 # [BT, N1, Ce] f32 stream
     He = cfg.enc_num_heads
     x = x.reshape(BT * N1, Ce)
+    def enc_block_split(i, x):              # the block composed of the split-class Functions (croco/blocks.py:114-130)
+        nm = f"backbone.enc_blocks.{i}"
+        h1 = lnm(nm + ".norm1", x, out_dtype=adt)
+        qkv = A.linear(h1, P[nm + ".attn.qkv.weight"], P[nm + ".attn.qkv.bias"], dt, rope=(tabs["pos_img"], None, He, Ce, 100.0, 1.0))
+        att = A.AttentionFn.apply(qkv, BT, He, N1, N1, N1, N1, None, None, 0)
+        x = A.gated_resid(x, lin(nm + ".attn.proj", att))
+        h2 = lnm(nm + ".norm2", x, out_dtype=adt)
+        return A.gated_resid(x, lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", h2))))
+
     for i in range(cfg.enc_depth):          # one autograd node per block: LN / qkv+RoPE / attention / proj / LN / fc1 / GELU / fc2
         nm = f"backbone.enc_blocks.{i}"
+        if dt == A.SPLIT:
+            x = torch.utils.checkpoint.checkpoint(enc_block_split, i, x, use_reentrant=False) if ckpt else enc_block_split(i, x)
+            continue
         names = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                  "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
         x = A.EncBlockFn.apply(x, tabs["pos_img"], BT, N1, He, dt, ckpt, *[P[f"{nm}.{k}"] for k in names])
@@ -81,8 +96,8 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         nm = f"backbone.dec_blocks.{i}"
         cn = _ln_f32(P, nm + ".cam_norm1", cam)
         s1, b1, g1 = _lin_f32(P, nm + ".modulation1.proj", F.silu(cn)).chunk(3, -1)                   # [B,T,C] each
-        hmix = lnm(nm + ".norm1", x, scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=dt,
-                   lead=cn.to(dt).reshape(BT, C), lead_rows=N1)                                       # [BT*M2, C]: camera token first
+        hmix = lnm(nm + ".norm1", x, scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=adt,
+                   lead=cn.to(adt).reshape(BT, C), lead_rows=N1)                                       # [BT*M2, C]: camera token first
         qkv = A.linear(hmix, P[nm + ".attn.qkv.weight"], P[nm + ".attn.qkv.bias"], dt,
                        rope=(tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta))                 # RoPE in the GEMM epilogue
         att = A.AttentionFn.apply(qkv, B, Hd, T * M2, T * M2, T * M2, T * M2, None, tabs["kvlen"], 0)
@@ -92,14 +107,14 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
         s2, b2, g2, s3, b3, g3 = _lin_f32(P, nm + ".modulation2.proj", F.silu(cn)).chunk(6, -1)
         # cross-neighbour attention (:152-191): q | k | v of frame t (one GEMM over the stacked projq / projk / projv weights),
         # keys gathered from frames t-1 / t+1 by row segments
-        himg = lnm(nm + ".norm2", x, scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        himg = lnm(nm + ".norm2", x, scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=adt)
         ca = nm + ".cross_attn"
         wqkv = torch.cat([P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]], 0)
         bqkv = torch.cat([P[ca + ".projq.bias"], P[ca + ".projk.bias"], P[ca + ".projv.bias"]], 0)
         qkv = A.linear(himg, wqkv, bqkv, dt, rope=(tabs["pos_img"], None, Hd, C, 100.0, 1.0))
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
         x = A.gated_resid(x, lin(ca + ".proj", att), g2.reshape(BT, C), N1)
-        himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=dt)
+        himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=adt)
         x = A.gated_resid(x, lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", himg))), g3.reshape(BT, C), N1)
         cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
         return x, cam
@@ -142,7 +157,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     def stem7x7(name, fr):                                       # 7x7, pad 3 conv on the RGB frames as im2col rows + the MFMA GEMM
         w = P[name + ".weight"]                                  # [Cout, 3, 7, 7]
         n_, _, h_, w_ = fr.shape
-        f = lambda u: F.unfold(u.to(dt), 7, padding=3).transpose(1, 2)          # [n, h*w, 147] in (c, ky, kx) order = weight.flatten(1)
+        f = lambda u: F.unfold(u.to(adt), 7, padding=3).transpose(1, 2)          # [n, h*w, 147] in (c, ky, kx) order = weight.flatten(1)
         cols = chunked(f, fr, h_ * w_ * 147)
         cols = F.pad(cols, (0, 256 - 147))     # 256 columns: whole tiles for the reduction-major weight-gradient kernel (no transposes)
         wk = F.pad(w.flatten(1), (0, 256 - 147))
@@ -160,7 +175,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt: torc
     def trunk(pre):
         L = cfg.dec_depth
         hooks = [0, L * 2 // 4, L * 3 // 4, L]
-        maps = [inter[h].to(dt).reshape(BT, gh, gw, -1) for h in hooks]
+        maps = [inter[h].to(adt).reshape(BT, gh, gw, -1) for h in hooks]
         a = pre + ".act_postprocess"
         l0 = convT(a + ".0.1", conv1x1(a + ".0.0", maps[0]), 4)
         l1 = convT(a + ".1.1", conv1x1(a + ".1.0", maps[1]), 2)

@@ -311,7 +311,7 @@ def gaussian_adapter_backward(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torc
     in the inputs' shape and dtype, as views of buffers whose rows are padded to a multiple of 8 channels (16-byte aligned rows with
     zero padding: what the reduction-major weight-gradient kernel of the 1x1 convs in front of the adapter reads directly)."""
     dev = L.require_device(pts, gs, sh_mask, d_means, d_cov, d_harm, d_op, d_raw)
-    assert pts.is_contiguous() and gs.is_contiguous() and pts.dtype == gs.dtype and pts.dtype in (torch.float16, torch.bfloat16)
+    assert pts.is_contiguous() and gs.is_contiguous() and pts.dtype == gs.dtype and pts.dtype in (torch.float16, torch.bfloat16, torch.float32)
     d_sh = (gs.shape[-1] - 8) // 3
     npix = gs.numel() // gs.shape[-1]
     f = lambda t: None if t is None else t.float().contiguous()
