@@ -46,6 +46,9 @@ def parse():
                          "and report it in the `train` object of the same JSON line; train: `value` IS the training throughput")
     ap.add_argument("--train-scenes-per-gpu", type=int, default=24)    # README.md:104 / distill.yaml: 24 scenes per GPU
     ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-split-scenes", type=int, default=8, help="scenes per GPU of the reference-precision (split class) training leg: f32 "
+                    "activations double the footprint of the 16-bit step (24 scenes: 158 GB), so the secondary leg runs a third of the batch")
+    ap.add_argument("--no-train-split", action="store_true", help="skip the split-class training leg")
     ap.add_argument("--train-timeout", type=float, default=240.0, help="seconds after which a stalled training leg is abandoned and the headline line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -99,7 +102,7 @@ class KernelTimer:
         return out
 
 
-def train_leg(args, enc, dec, dev, rank, world, dist):
+def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, steps=None):
     """BASELINE configs 4 / 5: the full training step -- encoder + decoder + rasterizer forward, MSE, backward on the HIP kernels,
     gradient exchange (GradReducer: bucketed all-reduce over RCCL overlapped with backward; N > 1 only), clip 0.5, AdamW -- on
     `--train-scenes-per-gpu` 8-view scenes with `--targets` target views each (re10k_8view.yaml:19-20).  Timed like the headline:
@@ -107,8 +110,12 @@ def train_leg(args, enc, dec, dev, rank, world, dist):
     screen within a few steps, which would change the rasterizer's work between timed steps; every kernel of the step still runs."""
     from vicasplat_amd import callers, synthetic
     from vicasplat_amd import dist as vdist
-    B, V, Vt = args.train_scenes_per_gpu, args.views, args.targets
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16      # the backward exists for 16-bit operands only (DESIGN 7)
+    B, V, Vt = (scenes or args.train_scenes_per_gpu), args.views, args.targets
+    # operand class of the step: 16-bit (the fast class) or "split" -- the reference's precision in BOTH directions (f32 activations and
+    # gradients, three f16 MFMAs per product; round 3, DESIGN 7)
+    dt = cdt if cdt is not None else (torch.bfloat16 if args.dtype == "bf16" else torch.float16)
+    nsteps = steps or args.train_steps
+    peak_tf = PEAK_MFMA_16BIT_TFLOPS / 3.0 if dt == "split" else PEAK_MFMA_16BIT_TFLOPS
     img, K = synthetic.synthetic_input(B, V, 256, seed=100 + rank)
     tE, tK, tn, tf = target_cameras(B, Vt, dev)
     gen = torch.Generator().manual_seed(7 + rank)
@@ -124,7 +131,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.train_steps):
+    for _ in range(nsteps):
         r = callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer)
     torch.cuda.synchronize()
     if dist is not None:
@@ -134,7 +141,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist):
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    ms = el / args.train_steps * 1e3
+    ms = el / nsteps * 1e3
     # algorithmic FLOPs of the step: 3 407 GFLOP forward per 8-view scene, backward = 2x forward
     flops = 3.0 * 3407e9 * (V / 8.0) * B
     tf_s = flops / (ms * 1e-3) / 1e12
@@ -144,12 +151,14 @@ def train_leg(args, enc, dec, dev, rank, world, dist):
     for p in enc.parameters():
         p.grad = None
     return dict(metric="scenes/sec training step (fwd+bwd+clip+AdamW)", value=round(world * B / (ms * 1e-3), 3), unit="scenes/s",
-                ms_per_step=round(ms, 2), steps=args.train_steps, scenes_per_gpu=B, context_views=V, target_views=Vt, dtype="bf16" if args.dtype == "bf16" else "f16",
+                ms_per_step=round(ms, 2), steps=nsteps, scenes_per_gpu=B, context_views=V, target_views=Vt,
+                dtype=("split (f32 activations and gradients, 3 x f16 MFMA per product, forward and backward)" if dt == "split" else "bf16" if dt == torch.bfloat16 else "f16"),
+                loss_scale=float(r["loss_scale"]),
                 loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
                 peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                 gradient_exchange=("none (1 GPU)" if world == 1 else f"GradReducer: 64 MiB buckets all-reduced during backward, RCCL x{world}"),
-                roofline=dict(bound="mfma", achieved=round(tf_s, 1), peak=PEAK_MFMA_16BIT_TFLOPS, unit="TFLOP/s",
-                              frac=round(tf_s / PEAK_MFMA_16BIT_TFLOPS, 4),
+                roofline=dict(bound="mfma", achieved=round(tf_s, 1), peak=round(peak_tf, 1), unit="TFLOP/s",
+                              frac=round(tf_s / peak_tf, 4),
                               what="whole step: 3 x 3407 GFLOP per 8-view scene (fwd + 2x bwd, SURVEY 8d) / step time"))
 
 
@@ -588,7 +597,15 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            train = train_leg(args, enc, dec, dev, rank, world, dist)
+            if args.mode == "train" and args.dtype == "split":
+                train = train_leg(args, enc, dec, dev, rank, world, dist, cdt="split", scenes=args.train_split_scenes if args.train_scenes_per_gpu == 24 else None)
+            else:
+                train = train_leg(args, enc, dec, dev, rank, world, dist)
+                if world == 1 and not args.no_train_split:      # the same step at the reference's precision (secondary leg, reduced batch)
+                    try:
+                        train["split_class"] = train_leg(args, enc, dec, dev, rank, world, None, cdt="split", scenes=args.train_split_scenes, steps=2)
+                    except Exception as e:
+                        train["split_class"] = dict(error=repr(e)[:300])
         except Exception as e:      # the headline line must survive a failure of the optional training leg
             if args.mode == "train":
                 raise
