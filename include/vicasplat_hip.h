@@ -167,6 +167,12 @@ int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *
                   int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
                   const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d, vs_stream_t stream);
 
+/* vs_gemm_split with the A operand ALREADY in the packed (hi, lo) form (Ap = vs_split_pack_weight(A, scale_exp 0) or a producer that
+ * writes that form; lda in 4-byte units): the main loops skip the in-kernel conversion.  M > 64 routes only (tile kernels). */
+int vs_gemm_split_packed(const void *Ap, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,
+                         int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t grp_in, int32_t grp_out,
+                         int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
+                         const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d, vs_stream_t stream);
 /* vs_conv7x7_rgb_nhwc on split operands: in_padded f32 [Nimg, Hp, Wp, 3] (+ one spare padded row + 64 spare floats), wp = packed
  * [Cout, 8 * 32] (kernel row dy at columns dy * 32 + dx * 3 + c), out f32 [Nimg, H, W, Cout], Cout % 256 == 0 */
 int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp, float acc_scale, const float *bias, float *out, int32_t Nimg, int32_t H,

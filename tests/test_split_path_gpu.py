@@ -417,3 +417,57 @@ def test_end_to_end_split_render_matches_the_oracle_chain(V, Vt):
         assert max(c["dpsnr_common_target"]) <= 1e-4, c                                     # the north-star's 1e-4 dB bar
         assert tiles["visibility_flips"] + tiles["rect_changes"] <= 2e-3 * tiles["gaussian_views"], tiles
         assert pose <= 2e-5
+
+
+@pytest.mark.parametrize("M,C,N", [(2056, 1024, 3072), (49344 // 8 + 192, 1024, 1024), (516, 768, 2304), (300, 192, 576), (70, 256, 256)])
+def test_packed_activation_producers_are_bit_identical(M, C, N):
+    """Round 3: activations that only feed a GEMM are written by their producer in the packed (hi, lo) form (ops.split_act): LayerNorm
+    (plain, AdaLN-modulated, with the decoder's interleaving row map) and the GEMM store / GELU epilogues; the consuming GEMM
+    (vs_gemm_split_packed) skips its in-loop conversion.  Same roundings in a different place: results are BIT-identical to the f32 route."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(d)
+    lw, lb = (1 + 0.1 * torch.randn(C, generator=g)).to(d), (0.1 * torch.randn(C, generator=g)).to(d)
+    w = ops.split_pack_weight((torch.randn(N, C, generator=g) / math.sqrt(C)).to(d))
+    b = torch.randn(N, generator=g).to(d)
+    # LayerNorm -> GEMM
+    h32 = torch.empty(M, C, device=d)
+    ops.layernorm_mod(x, lw, lb, h32)
+    hp = ops.split_act(M, C, d)
+    ops.layernorm_mod(x, lw, lb, hp)
+    assert torch.equal(hp.data, ops.split_pack_weight(h32, 0).data)
+    o1, o2 = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+    ops.gemm(h32, w, b, o1, ops.EPI_STORE32)
+    ops.gemm(hp, w, b, o2, ops.EPI_STORE32)
+    assert torch.equal(o1, o2)
+    # GELU epilogue -> packed -> second GEMM (the MLP)
+    w2 = ops.split_pack_weight((torch.randn(C, N, generator=g) / math.sqrt(N)).to(d))
+    hid32 = torch.empty(M, N, device=d)
+    ops.gemm(h32, w, b, hid32, ops.EPI_GELU16)
+    hidp = ops.split_act(M, N, d)
+    ops.gemm(hp, w, b, hidp, ops.EPI_GELU16)
+    assert torch.equal(hidp.data, ops.split_pack_weight(hid32, 0).data)
+    r1, r2 = x.clone(), x.clone()
+    ops.gemm(hid32, w2, None, r1, ops.EPI_RESID32)
+    ops.gemm(hidp, w2, None, r2, ops.EPI_RESID32)
+    assert torch.equal(r1, r2)
+    # AdaLN modulation + the decoder's interleaved rows (one extra row in front of every `grp` rows), read back through the input row map
+    grp = M // 2 if M % 2 == 0 else M
+    G = M // grp
+    sc, sh = (0.1 * torch.randn(G, C, generator=g)).to(d), (0.1 * torch.randn(G, C, generator=g)).to(d)
+    m32 = torch.zeros(M + G, C, device=d)
+    ops.layernorm_mod(x, lw, lb, m32, scale=sc, shift=sh, mod_rows=grp, grp_in=grp, grp_out=grp + 1, grp_off=1)
+    mp = ops.split_act(M + G, C, d)
+    mp.data.zero_()
+    ops.layernorm_mod(x, lw, lb, mp, scale=sc, shift=sh, mod_rows=grp, grp_in=grp, grp_out=grp + 1, grp_off=1)
+    assert torch.equal(mp.data, ops.split_pack_weight(m32, 0).data)
+    q1, q2 = torch.empty(M + G, N, device=d), torch.empty(M + G, N, device=d)
+    ops.gemm(m32, w, b, q1, ops.EPI_STORE32)
+    ops.gemm(mp, w, b, q2, ops.EPI_STORE32)
+    assert torch.equal(q1, q2)
+    s1, s2 = x.clone(), x.clone()
+    wc = ops.split_pack_weight((torch.randn(C, C, generator=g) / math.sqrt(C)).to(d))
+    ops.gemm(m32, wc, None, s1, ops.EPI_RESID32, M=M, a_grp_in=grp, a_grp_out=grp + 1, a_grp_off=1)
+    ops.gemm(mp, wc, None, s2, ops.EPI_RESID32, M=M, a_grp_in=grp, a_grp_out=grp + 1, a_grp_off=1)
+    assert torch.equal(s1, s2)

@@ -160,6 +160,8 @@ def lib() -> C.CDLL:
             L.vs_split_pack_weight.argtypes = [vp, i64, vp, i64, i32, i32, i32, vp]
             L.vs_gemm_split.restype = C.c_int
             L.vs_gemm_split.argtypes = [vp, vp, f32, vp, vp, vp, vp] + [i32] * 15 + [vp, vp, i32, f32, f32, vp]
+            L.vs_gemm_split_packed.restype = C.c_int
+            L.vs_gemm_split_packed.argtypes = [vp, vp, f32, vp, vp, vp, vp] + [i32] * 15 + [vp, vp, i32, f32, f32, vp]
             L.vs_conv3x3_split_nhwc.restype = C.c_int
             L.vs_conv3x3_split_nhwc.argtypes = [vp, vp, f32, vp, vp, vp] + [i32] * 8 + [vp]
             L.vs_conv3x3_head1x1_split_nhwc.restype = C.c_int

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, (MI == 8 || BF16 == kDtSplit) ? 2 : 3) ge
                 const int ra_ = wr * (16 * MI) + i * 16 + frow;
                 uint4 fa0 = *reinterpret_cast<const uint4 *>(&cA0[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);
                 uint4 fa1 = *reinterpret_cast<const uint4 *>(&cA1[ra_ * 32 + ((fg ^ swz4(ra_)) << 3)]);
-                split8(fa0, fa1);
+                if (!g.a_packed) split8(fa0, fa1);     // (wave-uniform; a packed A block is already [hi | lo])
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mma2<BF16>(fbh[j], fbl[j], fa0, fa1, acc[i][j]);
             }
@@ -419,6 +419,19 @@ template <int BF16>
 int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
     const int nwg = vs::cdiv(g.M - g.m_lo, 256) * vs::cdiv(g.N, 256);
     dim3 grid(nwg), block(512);
+    if constexpr (BF16 == kDtSplit) {
+        if (g.a_packed) {
+            switch (epi) {
+                case 0: hipLaunchKernelGGL((gemm256_kernel<BF16, 0, true>), grid, block, 0, stream, g); break;
+                case 1: hipLaunchKernelGGL((gemm256_kernel<BF16, 1, true>), grid, block, 0, stream, g); break;
+                case 2: hipLaunchKernelGGL((gemm256_kernel<BF16, 2, true>), grid, block, 0, stream, g); break;
+                case 3: hipLaunchKernelGGL((gemm256_kernel<BF16, 3, true>), grid, block, 0, stream, g); break;
+                case 4: hipLaunchKernelGGL((gemm256_kernel<BF16, 4, true>), grid, block, 0, stream, g); break;
+                default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
+            }
+            return 0;
+        }
+    }
     switch (epi) {
         case 0: hipLaunchKernelGGL((gemm256_kernel<BF16, 0>), grid, block, 0, stream, g); break;
         case 1: hipLaunchKernelGGL((gemm256_kernel<BF16, 1>), grid, block, 0, stream, g); break;
@@ -445,7 +458,7 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
         t.ksplit = ks;
     }
     // (the RoPE epilogue pairs columns 16 apart: only the tile kernels hold both in one workgroup)
-    return rem <= 64 && epi != 4 ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
+    return rem <= 64 && epi != 4 && !g.a_packed ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
 }
 
 // reference-precision path (exact f32 MFMA at 1/16 of the 16-bit rate): the matrix pipe, not the tile schedule, sets the time, so
@@ -461,7 +474,7 @@ template <int BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
-    if (g.M <= 64 && force == 0 && epi != 4) return launch_smallm<BF16>(g, epi, stream);
+    if (g.M <= 64 && force == 0 && epi != 4 && !g.a_packed) return launch_smallm<BF16>(g, epi, stream);
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
     // 256x256 tiles run one 8-wave workgroup per CU, i.e. in rounds of 256 tiles, and a partly filled round costs as much
@@ -584,7 +597,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
                int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t dtype, int32_t grp_in, int32_t grp_out,
                int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
                const int32_t *rope_pos, const uint8_t *rope_kind, int32_t rope_C, float base2d, float theta1d, hipStream_t stream,
-               float acc_scale = 1.f) {
+               float acc_scale = 1.f, int a_packed = 0, int out_packed = 0) {
     VS_CHECK(A && W && out, "%s: null pointer", fn);
     VS_CHECK(M >= 0 && N > 0 && K > 0, "%s: bad sizes M=%d N=%d K=%d", fn, M, N, K);
     VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "%s: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split)", fn);
@@ -616,6 +629,8 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.rope_l2base = base2d > 0.f ? log2f(base2d) : 0.f;
     g.rope_l2theta = theta1d > 0.f ? log2f(theta1d) : 0.f;
     g.acc_scale = acc_scale;
+    g.a_packed = a_packed;
+    g.out_packed = out_packed;
     // split operands (kDtSplit) take the 16-bit classes' routing: whole rounds of 256 x 256 tiles + a tail launch (K counts 2-byte units
     // of the f32 rows; every stage pair / K-tile of the kernels is one 128-byte block of 32 k)
     const int rc = dtype == 4 ? launch<kDtSplit>(g, epilogue, stream)
@@ -708,13 +723,37 @@ extern "C" int vs_gemm_split(const float *A, const void *Wp, float acc_scale, co
                              int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out,
                              int32_t a_grp_off, const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d,
                              vs_stream_t stream_) {
+    const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3), the A operand of vs_gemm_split_packed
+    epilogue &= ~16;
     VS_CHECK(epilogue >= 0 && epilogue <= 4, "vs_gemm_split: unknown epilogue %d", epilogue);
+    VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
+             "vs_gemm_split: a packed output needs epilogue 0 / 1 / 3, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
     VS_CHECK(epilogue != 4 || (pos && C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0 && base2d > 0.f && theta1d > 0.f),
              "vs_gemm_split: the RoPE epilogue needs pos, C %% 64 == 0, N >= 2C, positive bases");
     VS_CHECK(acc_scale > 0.f, "vs_gemm_split: acc_scale must be positive");
     return gemm_entry("vs_gemm_split", A, Wp, bias, out, gate, resid, M, N, K, lda, ldw, ldo, epilogue, 4, grp_in, grp_out, grp_off, gate_rows,
                       gate_ld, a_grp_in, a_grp_out, a_grp_off, epilogue == 4 ? pos : nullptr, epilogue == 4 ? kind : nullptr, C, base2d, theta1d,
-                      (hipStream_t)stream_, acc_scale);
+                      (hipStream_t)stream_, acc_scale, 0, out_packed);
+}
+
+// vs_gemm_split with the A operand ALREADY packed (Ap = the vs_split_pack_weight image, scale_exp 0, of the f32 activation matrix; lda in
+// 4-byte units as for the f32 matrix): the kernels skip the in-loop conversion -- what a producer that writes the packed form buys.
+extern "C" int vs_gemm_split_packed(const void *Ap, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,
+                                    int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t grp_in,
+                                    int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out,
+                                    int32_t a_grp_off, const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d,
+                                    vs_stream_t stream_) {
+    const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3), the A operand of vs_gemm_split_packed
+    epilogue &= ~16;
+    VS_CHECK(epilogue >= 0 && epilogue <= 4, "vs_gemm_split_packed: unknown epilogue %d", epilogue);
+    VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
+             "vs_gemm_split_packed: a packed output needs epilogue 0 / 1 / 3, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
+    VS_CHECK(epilogue != 4 || (pos && C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0 && base2d > 0.f && theta1d > 0.f),
+             "vs_gemm_split_packed: the RoPE epilogue needs pos, C %% 64 == 0, N >= 2C, positive bases");
+    VS_CHECK(acc_scale > 0.f, "vs_gemm_split_packed: acc_scale must be positive");
+    return gemm_entry("vs_gemm_split_packed", Ap, Wp, bias, out, gate, resid, M, N, K, lda, ldw, ldo, epilogue, 4, grp_in, grp_out, grp_off, gate_rows,
+                      gate_ld, a_grp_in, a_grp_out, a_grp_off, epilogue == 4 ? pos : nullptr, epilogue == 4 ? kind : nullptr, C, base2d, theta1d,
+                      (hipStream_t)stream_, acc_scale, 1, out_packed);
 }
 
 // Weight-gradient GEMM: out32[t][M,N] += A[M,K] (W + shift[t])[N,K]^T for t < max(ntaps, 1), the K range cut into `ksplit` slices
@@ -747,7 +786,7 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
     g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
@@ -785,7 +824,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
@@ -835,7 +874,7 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
     g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
     const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
@@ -907,7 +946,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
     static const int no256 = [] { const char *e = getenv("VS_STEM_NO256"); return e ? atoi(e) : 0; }();
     if (Cout % 256 == 0 && g.M >= 256 && !no256) {
         const int nwg = vs::cdiv(g.M, 256) * (Cout / 256);
@@ -945,7 +984,7 @@ extern "C" int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp,
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
     g.a_kstride = Wp * 6;
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0;
     hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;

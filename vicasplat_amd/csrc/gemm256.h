@@ -182,8 +182,11 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
 // four younger units in flight, vmcnt 8) closes the barrier interval of group 0's M0 / group 1's R0, W1 (A_0, B_0 of kt+1: five
 // younger units, vmcnt 10) that of group 0's M2 / group 1's R2 -- the groups run one barrier apart, so the same interval is a compute
 // segment for one and a read segment for the other.  The ReLU of an implicit-GEMM convolution is applied during the conversion.
-template <bool RELU_A, class Stager>
+// A_PACKED: the A units arrive ALREADY converted (the packed (hi, lo) image of vs_split_pack_weight, whose 128-byte block of 32 k is exactly
+// the post-conversion LDS row: hi chunks 0..3 | lo chunks 0..3): no conversion segment, the loop is VALU-free like the 16-bit one.
+template <bool RELU_A, class Stager, bool A_PACKED = false>
 __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (&acc)[8][4], unsigned char *smem, const int lane, const int wid) {
+    static_assert(!(RELU_A && A_PACKED), "a packed A operand carries its ReLU already");
     constexpr unsigned UNITB = kUnitBytes256;
     constexpr int BF16 = kDtSplit;
     const int wr = wid >> 2, wc = wid & 3;
@@ -223,14 +226,14 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
     // the conversion of one item is cut in two: its LDS loads are issued at the start of a read segment, the VALU work and the stores at
     // its end, and the wave only waits for the stores (lgkmcnt) at the END of the following compute segment -- the converted rows are
     // read two barriers later, and a wait inside the read segment made it longer than the 24 MFMAs it runs beside
-    uint4 cx0, cx1;
+    [[maybe_unused]] uint4 cx0, cx1;
 #define VS_CVT_LD(h_, d_)                                                                                        \
-    {                                                                                                            \
+    if constexpr (!A_PACKED) {                                                                                   \
         cx0 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cv0);                           \
         cx1 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cv1);                           \
     }
 #define VS_CVT_ST(h_, d_)                                                                                        \
-    {                                                                                                            \
+    if constexpr (!A_PACKED) {                                                                                   \
         if constexpr (RELU_A) {                                                                                  \
             cx0.x = relu_f32_lds(cx0.x); cx0.y = relu_f32_lds(cx0.y); cx0.z = relu_f32_lds(cx0.z); cx0.w = relu_f32_lds(cx0.w); \
             cx1.x = relu_f32_lds(cx1.x); cx1.y = relu_f32_lds(cx1.y); cx1.z = relu_f32_lds(cx1.z); cx1.w = relu_f32_lds(cx1.w); \
@@ -239,7 +242,7 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
         *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cv0) = cx0;                                 \
         *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cv1) = cx1;                                 \
     }
-#define VS_LGK0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* conversion stores are in LDS before the barrier that publishes them */
+#define VS_LGK0 if constexpr (!A_PACKED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* conversion stores are in LDS before the barrier that publishes them */
 #define VS_MM(ha_, hb_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
@@ -329,6 +332,7 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
 // pieces in flight), start of R1: A_0(kt+1) and B(kt+1) (two younger pieces).
 template <bool RELU_A, class Stager>
 __device__ __forceinline__ void mainloop256x128_split(Stager &st, const int KT, f4 (&acc)[4][4], unsigned char *smem, const int lane, const int wid) {
+    constexpr bool A_PACKED = false;   // (the packed-A form exists on the 256 x 256 loop only)
     constexpr unsigned UNITB = kUnitBytes256;
     constexpr int BF16 = kDtSplit;
     const int grp = wid >> 2, wl = wid & 3;
@@ -362,12 +366,12 @@ __device__ __forceinline__ void mainloop256x128_split(Stager &st, const int KT, 
         fb[j][1] = *reinterpret_cast<const uint4 *>(rdB + (d_) * 3 * UNITB + j * 2048 + rd1);                    \
     }
 #define VS_CVT_LD(h_, d_)                                                                                        \
-    {                                                                                                            \
+    if constexpr (!A_PACKED) {                                                                                   \
         cx0 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 3 + (h_)) * UNITB + cv0);                           \
         cx1 = *reinterpret_cast<const uint4 *>(cvp + ((d_) * 3 + (h_)) * UNITB + cv1);                           \
     }
 #define VS_CVT_ST(h_, d_)                                                                                        \
-    {                                                                                                            \
+    if constexpr (!A_PACKED) {                                                                                   \
         if constexpr (RELU_A) {                                                                                  \
             cx0.x = relu_f32_lds(cx0.x); cx0.y = relu_f32_lds(cx0.y); cx0.z = relu_f32_lds(cx0.z); cx0.w = relu_f32_lds(cx0.w); \
             cx1.x = relu_f32_lds(cx1.x); cx1.y = relu_f32_lds(cx1.y); cx1.z = relu_f32_lds(cx1.z); cx1.w = relu_f32_lds(cx1.w); \
@@ -449,7 +453,7 @@ struct GemmStager256 {
     }
 };
 
-template <int BF16, int EPI>
+template <int BF16, int EPI, bool APACK = false>
 __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
     constexpr int BM2 = 256, BN2 = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
@@ -489,7 +493,7 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
         }
     }
     f4 acc[8][4];
-    if constexpr (BF16 == kDtSplit) mainloop256_split<false>(st, g.K / 64, acc, smem, lane, wid);
+    if constexpr (BF16 == kDtSplit) mainloop256_split<false, GemmStager256, APACK>(st, g.K / 64, acc, smem, lane, wid);
     else mainloop256<BF16, false>(st, g.K / 64, acc, smem, lane, wid);
     gemm_epilogue<BF16, EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }

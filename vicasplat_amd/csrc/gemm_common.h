@@ -56,6 +56,8 @@ struct GemmArgs {
     int rope_C;  // columns [0, C) = q, [C, 2C) = k, rest untouched
     float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
     int stagger;  // experiment: first-round workgroups of gemm256_kernel sleep (bid % 8) * stagger * ~4 us before starting
+    int out_packed;   // split operands, epilogues 0 / 1 / 3: the output is written in the packed (hi, lo) form (the A operand of the next GEMM)
+    int a_packed;     // split operands: A is ALREADY in the packed (hi, lo) form of vs_split_pack_weight (scale 2^0): the kernels skip the conversion
     float acc_scale;  // split operands (kDtSplit): the packed weights carry a power-of-two scale 2^e; the epilogue multiplies the accumulators by 2^-e
 };
 
@@ -121,6 +123,26 @@ __device__ __forceinline__ void split8_lds(uint4 &f0, uint4 &f1) {
     }
     f0 = make_uint4(h[0], h[1], h[2], h[3]);
     f1 = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// Four consecutive columns n .. n + 3 (n % 4 == 0) of an f32 activation row, written in the packed (hi, lo) form of vs_split_pack_weight
+// (scale 2^0): per block of 32 columns 32 hi halves then 32 lo halves, chunk g = columns {4g..4g+3, 16+4g..16+4g+3}.  `row` = start of the
+// row in 4-byte units (rows are whole 128-byte blocks).  What lets a producer hand the next GEMM an operand it need not convert.
+__device__ __forceinline__ void store_split4(float *row, int n, float a, float b, float c, float d) {
+    uint4 f0 = make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)), f1 = f0;
+    // (split8_lds on a duplicated quad: lanes of f1 are ignored)
+    unsigned h[2], l[2];
+    h[0] = cvt_pk_f16(a, b); h[1] = cvt_pk_f16(c, d);
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h[0]), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h[0]), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h[1]), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h[1]), "v"(d));
+    l[0] = cvt_pk_f16(r0, r1); l[1] = cvt_pk_f16(r2, r3);
+    (void)f0; (void)f1;
+    const int kk = n & 31;
+    unsigned short *o = reinterpret_cast<unsigned short *>(row + (n & ~31)) + ((kk & 15) >> 2) * 8 + (kk >> 4) * 4;
+    *reinterpret_cast<uint2 *>(o) = make_uint2(h[0], h[1]);
+    *reinterpret_cast<uint2 *>(o + 32) = make_uint2(l[0], l[1]);
 }
 // max(x, 0) of an f32 value whose result goes to LDS / memory (one VALU; inline asm: see split8 for why not in front of an MFMA)
 __device__ __forceinline__ unsigned relu_f32_lds(unsigned x) {
@@ -514,9 +536,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                             for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2 *>(dst + j * 16) = pk[j];
                         }
                     } else {
-                        float *dst = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo + nbase + c4;
+                        if (BF16 == kDtSplit && g.out_packed) {
+                            float *rowp = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(dst + j * 16) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                            for (int j = 0; j < 4; ++j) store_split4(rowp, nbase + c4 + j * 16, v[j][0], v[j][1], v[j][2], v[j][3]);
+                        } else {
+                            float *dst = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo + nbase + c4;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(dst + j * 16) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                        }
                     }
                 }
                 return;
@@ -614,7 +642,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                             *reinterpret_cast<float4 *>(dst + j * 16) = o;
                         }
                     } else {
-                        *reinterpret_cast<float4 *>(dst + j * 16) = val;
+                        if (BF16 == kDtSplit && g.out_packed) store_split4(reinterpret_cast<float *>(g.out) + orow * g.ldo, nbase + c4 + j * 16, val.x, val.y, val.z, val.w);
+                        else *reinterpret_cast<float4 *>(dst + j * 16) = val;
                     }
                 } else {
 #pragma unroll

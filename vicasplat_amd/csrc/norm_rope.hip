@@ -37,6 +37,22 @@ template <> struct Out<2> {
     }
 };
 
+// 3: the packed (hi, lo) form of the split operand class (vs_split_pack_weight layout, scale 2^0; rows are whole 128-byte blocks): the
+// LayerNorm output goes straight to a GEMM that then has no conversion to do.  p = address of columns c .. c + 3 in 4-byte units.
+template <> struct Out<3> {
+    using T = float;
+    static __device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const h2 h0 = __builtin_convertvector(f2{a, b}, h2), h1 = __builtin_convertvector(f2{c, d}, h2);
+        const h2 l0 = __builtin_convertvector(f2{a - (float)h0.x, b - (float)h0.y}, h2), l1 = __builtin_convertvector(f2{c - (float)h1.x, d - (float)h1.y}, h2);
+        const unsigned kk = (unsigned)((reinterpret_cast<uintptr_t>(p) >> 2) & 31u);
+        unsigned short *o = reinterpret_cast<unsigned short *>(p - kk) + ((kk & 15u) >> 2) * 8 + (kk >> 4) * 4;
+        *reinterpret_cast<uint2 *>(o) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+        *reinterpret_cast<uint2 *>(o + 32) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+    }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -312,7 +328,8 @@ extern "C" int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, con
     VS_CHECK(x && w && b && out, "vs_layernorm_mod: null pointer");
     VS_CHECK(C > 0 && C % 4 == 0 && C <= 64 * 4 * kMaxVec, "vs_layernorm_mod: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * kMaxVec);
     VS_CHECK(ldx % 4 == 0 && ldo % 4 == 0, "vs_layernorm_mod: row strides must be multiples of 4 elements");
-    VS_CHECK(out_dtype >= 0 && out_dtype <= 2, "vs_layernorm_mod: bad out_dtype %d", out_dtype);
+    VS_CHECK(out_dtype >= 0 && out_dtype <= 3, "vs_layernorm_mod: bad out_dtype %d (0 f32, 1 f16, 2 bf16, 3 packed split)", out_dtype);
+    VS_CHECK(out_dtype != 3 || (C % 32 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0), "vs_layernorm_mod: a packed output needs C %% 32 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
     if (M <= 0) return 0;
     if (grp_in <= 0) { grp_in = M; grp_out = M; grp_off = 0; }
     if (mod_rows <= 0) mod_rows = M;
@@ -320,6 +337,7 @@ extern "C" int vs_layernorm_mod(const float *x, int64_t ldx, const float *w, con
     switch (out_dtype) {
         case 0: launch_layernorm<0>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (float *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
         case 1: launch_layernorm<1>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
+        case 3: launch_layernorm<3>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (float *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
         default: launch_layernorm<2>(x, ldx, w, b, scale, shift, mod_rows, mod_ld, (unsigned short *)out, ldo, M, C, eps, grp_in, grp_out, grp_off, stream); break;
     }
     VS_HIP(hipGetLastError());

@@ -240,10 +240,13 @@ class VicaNet(nn.Module):
             xe.view(BT, N, Ce)[:, n] = ops.linear_f32(intrinsics.reshape(BT, 9), self.intrinsic_encoder.weight, self.intrinsic_encoder.bias)
 
         # ---- 24 encoder blocks (blocks.py:94-130) ----
-        h = torch.empty(BT * N, Ce, **f16)
+        # split class: activations that only feed a GEMM (LayerNorm outputs, the MLP's hidden layer) are written by their producer in the
+        # packed (hi, lo) form, so the consuming GEMM's main loop has no conversion to do (ops.split_act; +15-20 % on these GEMMs)
+        act = (lambda r, c: ops.split_act(r, c, dev)) if self.split else (lambda r, c: torch.empty(r, c, **f16))
+        h = act(BT * N, Ce)
         qkv = torch.empty(BT * N, 3 * Ce, **f16)
         att = torch.empty(BT * N, Ce, **f16)
-        hid = torch.empty(BT * N, int(Ce * cfg.mlp_ratio), **f16)
+        hid = act(BT * N, int(Ce * cfg.mlp_ratio))
         for i, blk in enumerate(self.enc_blocks):
             ops.layernorm_mod(xe, blk.norm1.weight, blk.norm1.bias, h)
             ops.gemm_qkv_rope(h, W[f"e{i}.qkv"], blk.attn.qkv.bias, qkv, Ce, tabs["pos_img"], None, 100.0, 1.0)
@@ -267,13 +270,13 @@ class VicaNet(nn.Module):
         ti, te = self.camera_intrinsic_token.float(), self.camera_extrinsic_token.float()
         cam = torch.cat([ti.expand(B, 1, Cd), (ti + te).expand(B, T - 1, Cd)], 1).reshape(BT, Cd).contiguous()
         M2 = N + 1  # rows per frame in the interleaved buffer
-        hmix = torch.empty(BT * M2, Cd, **f16)
+        hmix = act(BT * M2, Cd)
         qkvm = torch.empty(BT * M2, 3 * Cd, **f16)
         attm = torch.empty(BT * M2, Cd, **f16)
-        h = torch.empty(BT * N, Cd, **f16)
+        h = act(BT * N, Cd)
         qkv = torch.empty(BT * N, 3 * Cd, **f16)
         att = torch.empty(BT * N, Cd, **f16)
-        hid = torch.empty(BT * N, int(Cd * cfg.mlp_ratio), **f16)
+        hid = act(BT * N, int(Cd * cfg.mlp_ratio))
         cn = torch.empty(BT, Cd, **f32)
         cn16 = torch.empty(BT, Cd, **f16)
         chid = torch.empty(BT, int(Cd * cfg.mlp_ratio), **f16)
@@ -287,7 +290,10 @@ class VicaNet(nn.Module):
             # -- video/camera self-attention over the interleaved [cam_t, img_t] sequence (:76-126)
             ops.layernorm_mod(xd, blk.norm1.weight, blk.norm1.bias, hmix, scale=mod1[:, :Cd], shift=mod1[:, Cd:2 * Cd],
                               mod_rows=N, grp_in=N, grp_out=M2, grp_off=1)
-            hmix.view(BT, M2, Cd)[:, 0] = cn.to(dt)
+            if self.split:
+                hmix.data.view(BT, M2, Cd)[:, 0] = ops.split_pack_weight(cn, 0).data
+            else:
+                hmix.view(BT, M2, Cd)[:, 0] = cn.to(dt)
             ops.gemm_qkv_rope(hmix, W[f"d{i}.qkv"], blk.attn.qkv.bias, qkvm, Cd, tabs["pos_mix"], tabs["kind_mix"], 100.0, theta)
             ops.attention(qkvm[:, :Cd], qkvm[:, Cd:2 * Cd], qkvm[:, 2 * Cd:], attm, nbatch=B, H=Hd, Lq=T * M2, Lk=T * M2,
                           q_batch_rows=T * M2, k_batch_rows=T * M2, q_kvlen=tabs["kvlen"], split=self.split)

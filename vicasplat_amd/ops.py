@@ -19,6 +19,14 @@ _OPERAND_DTYPES = (torch.float16, torch.bfloat16, torch.float32)
 EPI_STORE16, EPI_GELU16, EPI_RESID32, EPI_STORE32 = 0, 1, 2, 3
 
 
+def split_act(rows: int, cols: int, device) -> "SplitWeight":
+    """Uninitialised [rows, cols] activation buffer in the PACKED (hi, lo) form (scale 2^0) for producers that write it directly --
+    layernorm_mod(out=...), gemm(..., out=...) with the store / GELU epilogues -- and GEMMs that read it as their A operand without a
+    conversion (vs_gemm_split_packed).  cols % 32 == 0; 4 bytes per element like the f32 tensor it stands for."""
+    assert cols % 32 == 0
+    return SplitWeight(torch.empty((rows, cols), dtype=torch.int32, device=device), 1.0, (rows, cols))
+
+
 class SplitWeight:
     """A weight packed for the SPLIT operand class (dtype code 4; csrc/gemm_common.h, kDtSplit): f16 (hi, lo) pairs of w * 2^scale_exp,
     blocked by 32 k (vs_split_pack_weight).  `data` is an int32 tensor of the logical shape (4 bytes per element); the product entry
@@ -63,6 +71,11 @@ def layernorm_mod(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, mod_rows: int = 0,
                   grp_in: int = 0, grp_out: int = 0, grp_off: int = 0) -> torch.Tensor:
     """x f32 [M,C] -> out [*,C] (f32/f16/bf16).  scale/shift: [G,C] f32 views (row stride taken from .stride(0))."""
+    odt = None
+    out_obj = out
+    if isinstance(out, SplitWeight):      # packed (hi, lo) output of the split class: the consumer GEMM skips its conversion
+        assert out.acc_scale == 1.0
+        out, odt = out.data, 3
     dev = L.require_device(x, weight, bias, out, scale, shift)
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     M, C = x.shape
@@ -74,10 +87,10 @@ def layernorm_mod(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out
         mod_ld = shift.stride(0)
     with torch.cuda.device(dev):
         rc = L.lib().vs_layernorm_mod(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(bias), L.ptr(scale), L.ptr(shift),
-                                      mod_rows, mod_ld, L.ptr(out), out.stride(-2), _DT[out.dtype], M, C, eps, grp_in,
+                                      mod_rows, mod_ld, L.ptr(out), out.stride(-2), _DT[out.dtype] if odt is None else odt, M, C, eps, grp_in,
                                       grp_out, grp_off, L.stream_ptr(dev))
     L.check(rc, "vs_layernorm_mod")
-    return out
+    return out_obj
 
 
 def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
@@ -140,17 +153,26 @@ def _gemm_split(a, w: SplitWeight, bias, out, epilogue, *, gate=None, gate_rows=
                 a_grp_out=0, a_grp_off=0, resid=None, pos=None, kind=None, C=0, base2d=0.0, theta1d=0.0):
     """vs_gemm_split: a f32 [M,K], w SplitWeight [N,K], every output f32 (epilogue codes of `gemm`, 4 = q|k|v + RoPE)."""
     wd = w.data
+    packed = isinstance(a, SplitWeight)       # A already in the packed (hi, lo) form (scale 2^0): the kernels skip their conversion
+    if packed:
+        assert a.acc_scale == 1.0
+        a = a.data
+    out_obj = out
+    if isinstance(out, SplitWeight):          # packed output (epilogues 0 / 1 / 3): the A operand of the next GEMM, written by this one's epilogue
+        assert out.acc_scale == 1.0 and epilogue in (EPI_STORE16, EPI_GELU16, EPI_STORE32) and out.data.dtype == torch.int32
+        out, epilogue = out.data.view(torch.float32), epilogue | 16
     dev = L.require_device(a, wd, bias, out, gate, resid, pos, kind)
-    assert a.dtype == torch.float32 and out.dtype == torch.float32 and a.dim() == 2 and wd.dim() == 2 and a.stride(1) == 1
+    assert a.dtype == (torch.int32 if packed else torch.float32) and out.dtype == torch.float32 and a.dim() == 2 and wd.dim() == 2 and a.stride(1) == 1
     assert wd.stride(1) == 1 and a.shape[1] == wd.shape[1] and (resid is None or (resid.dtype == torch.float32 and resid.stride() == out.stride()))
     M = a.shape[0] if M is None else M
+    fn = L.lib().vs_gemm_split_packed if packed else L.lib().vs_gemm_split
     with torch.cuda.device(dev):
-        rc = L.lib().vs_gemm_split(L.ptr(a), L.ptr(wd), w.acc_scale, L.ptr(bias), L.ptr(out), L.ptr(gate), L.ptr(resid), M, wd.shape[0], a.shape[1],
+        rc = fn(L.ptr(a), L.ptr(wd), w.acc_scale, L.ptr(bias), L.ptr(out), L.ptr(gate), L.ptr(resid), M, wd.shape[0], a.shape[1],
                                    a.stride(0), wd.stride(0), out.stride(-2), epilogue, grp_in, grp_out, grp_off, gate_rows,
                                    gate.stride(0) if gate is not None else 0, a_grp_in, a_grp_out, a_grp_off, L.ptr(pos), L.ptr(kind), C,
                                    base2d, theta1d, L.stream_ptr(dev))
     L.check(rc, "vs_gemm_split")
-    return out
+    return out_obj
 
 
 def gemm_resid(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor, *, gate: Optional[torch.Tensor] = None,
