@@ -34,6 +34,7 @@ struct ConvArgs {
     int C2, C2pad, ld2;
     float acc_scale;            // split operands: 2^-e of the packed weights (gemm_common.h, kDtSplit)
     float acc_scale2;           // split operands, fused head: 2^-e of the packed w2
+    int a_packed;               // split operands: `in` is already the packed (hi, lo) image (ops.split_act; any ReLU applied by its producer)
 };
 
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
@@ -446,7 +447,7 @@ struct ConvStager256 {
     }
 };
 
-template <int BF16, bool RELU_IN, int FUSE_NF = 0>
+template <int BF16, bool RELU_IN, int FUSE_NF = 0, bool APACK = false>
 __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, const int cshift) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -492,7 +493,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
         }
     }
     f4 acc[8][4];
-    if constexpr (BF16 == kDtSplit) mainloop256_split<RELU_IN>(st, K / 64, acc, smem, lane, wid);
+    if constexpr (BF16 == kDtSplit) mainloop256_split<RELU_IN, ConvStager256, APACK>(st, K / 64, acc, smem, lane, wid);
     else mainloop256<BF16, RELU_IN>(st, K / 64, acc, smem, lane, wid);
     if constexpr (FUSE_NF > 0 && BF16 == kDtSplit) conv_head1x1_split_epilogue256<FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
     else if constexpr (FUSE_NF > 0) conv_head1x1_epilogue256<BF16, FUSE_NF>(g, acc, m0, wr, wc, smem, wid, lane);
@@ -926,7 +927,7 @@ upsample2x_f32_kernel(const float *__restrict__ in, const float *__restrict__ ad
 // every output is lerp_y(lerp_x(.)) of its own four neighbours with its own weights: the results of the one-output-per-thread form)
 __global__ void __launch_bounds__(256)
 upsample2x_f32_block_kernel(const float *__restrict__ in, const float *__restrict__ add, float *__restrict__ out, int Nimg, int H, int W, int C,
-                            int relu_add) {
+                            int relu_add, int pack_out) {
     const int Ho = 2 * H, Wo = 2 * W, c4 = C >> 2;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= W * c4) return;
@@ -967,8 +968,10 @@ upsample2x_f32_block_kernel(const float *__restrict__ in, const float *__restric
             av = *reinterpret_cast<const float4 *>(add + o);
             if (relu_add) { av.x = fmaxf(av.x, 0.f); av.y = fmaxf(av.y, 0.f); av.z = fmaxf(av.z, 0.f); av.w = fmaxf(av.w, 0.f); }
         }
-        *reinterpret_cast<float4 *>(out + o) = make_float4(top[0] * (1.f - ly) + bot[0] * ly + av.x, top[1] * (1.f - ly) + bot[1] * ly + av.y,
-                                                           top[2] * (1.f - ly) + bot[2] * ly + av.z, top[3] * (1.f - ly) + bot[3] * ly + av.w);
+        const float4 r = make_float4(top[0] * (1.f - ly) + bot[0] * ly + av.x, top[1] * (1.f - ly) + bot[1] * ly + av.y,
+                                     top[2] * (1.f - ly) + bot[2] * ly + av.z, top[3] * (1.f - ly) + bot[3] * ly + av.w);
+        if (pack_out) store_split4(out + (o - cc * 4), cc * 4, r.x, r.y, r.z, r.w);   // packed (hi, lo) pixel row: the next conv's operand as it is
+        else *reinterpret_cast<float4 *>(out + o) = r;
     };
     emit(ha[0], ha[1], lya, oa);
     emit(hb[0], hb[1], lya, oa + C);
@@ -1043,8 +1046,11 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     VS_CHECK(relu_out >= 0 && relu_out <= 2 && (relu_out != 2 || residual), "vs_conv3x3_nhwc: relu_out must be 0, 1 or 2 (2 = mask by `residual`, which must be given)");
     VS_CHECK(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "vs_conv3x3_nhwc: 16-byte alignment required");
     if (Nimg == 0) return 0;
+    const int in_packed = (relu_in & 16) ? 1 : 0;      // + 16 (split class): `in` is the packed (hi, lo) image, its ReLU already applied by the producer
+    relu_in &= ~16;
+    VS_CHECK(!in_packed || (dtype == 4 && relu_in == 0), "vs_conv3x3_split_nhwc: a packed input is a split-class operand that carries its ReLU already");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
-               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale, 1.f};
+               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale, 1.f, in_packed};
     const long long M = (long long)Nimg * H * W;
     static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
     int cshift = -1;
@@ -1054,7 +1060,8 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     if (force != 8 && force != 4 && cshift >= 0 && Cout % 256 == 0 && (9 * Cin / 64) % 2 == 0 && t256 >= 224) {
         dim3 grid((unsigned)t256), block(512);
         if (dtype == 4) {
-            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, true>), grid, block, 0, stream, g, cshift);
+            if (g.a_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 0, true>), grid, block, 0, stream, g, cshift);
+            else if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, true>), grid, block, 0, stream, g, cshift);
             else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false>), grid, block, 0, stream, g, cshift);
         } else if (dtype == 3) {
             if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, true>), grid, block, 0, stream, g, cshift);
@@ -1196,6 +1203,8 @@ extern "C" int vs_conv3x3_head1x1_split_nhwc(const float *in, const void *wp, fl
                                              const float *bias2, float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t C2pad,
                                              int32_t ld2, int32_t relu_out, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int in_packed = (relu_out & 16) ? 1 : 0;     // + 16: `in` is the packed (hi, lo) image of the f32 tensor (vs_upsample2x_nhwc relu_add + 16, ...)
+    relu_out &= ~16;
     VS_CHECK(in && wp && w2p && bias2 && out2 && acc_scale > 0.f && acc_scale2 > 0.f, "vs_conv3x3_head1x1_split_nhwc: null pointer / bad scale");
     const long long M = (long long)Nimg * H * W;
     VS_CHECK(Nimg > 0 && H > 0 && W > 0 && H < 32767 && W < 65536 && M % 256 == 0 && M < 2147483647LL, "vs_conv3x3_head1x1_split_nhwc: N*H*W must be a positive multiple of 256");
@@ -1210,14 +1219,18 @@ extern "C" int vs_conv3x3_head1x1_split_nhwc(const float *in, const void *wp, fl
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 256, 0, relu_out, H, W, 1,
                (const unsigned short *)w2p, bias2, (unsigned short *)out2, C2, C2pad, ld2, acc_scale, acc_scale2};
     dim3 grid((unsigned)(M / 256)), block(512);
+    g.a_packed = in_packed;
+#define VS_HEAD(NF_) { if (in_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_, true>), grid, block, 0, stream, g, cshift); \
+                       else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_>), grid, block, 0, stream, g, cshift); }
     switch (C2pad / 16) {
-        case 1: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 1>), grid, block, 0, stream, g, cshift); break;
-        case 2: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 2>), grid, block, 0, stream, g, cshift); break;
-        case 3: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 3>), grid, block, 0, stream, g, cshift); break;
-        case 4: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 4>), grid, block, 0, stream, g, cshift); break;
-        case 5: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 5>), grid, block, 0, stream, g, cshift); break;
-        default: hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 6>), grid, block, 0, stream, g, cshift); break;
+        case 1: VS_HEAD(1) break;
+        case 2: VS_HEAD(2) break;
+        case 3: VS_HEAD(3) break;
+        case 4: VS_HEAD(4) break;
+        case 5: VS_HEAD(5) break;
+        default: VS_HEAD(6) break;
     }
+#undef VS_HEAD
     VS_HIP(hipGetLastError());
     return 0;
 }
@@ -1227,6 +1240,9 @@ extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, in
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && out, "vs_upsample2x_nhwc: null pointer");
     VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3, "vs_upsample2x_nhwc: dtype must be 1 (f16), 2 (bf16) or 3 (f32)");
+    const int pack_out = (relu_add & 16) ? 1 : 0;      // + 16 (f32 only): write the packed (hi, lo) form of the split class (C % 32 == 0, 128-byte aligned out)
+    relu_add &= ~16;
+    VS_CHECK(!pack_out || (dtype == 3 && C % 32 == 0 && ((uintptr_t)out & 127) == 0), "vs_upsample2x_nhwc: a packed output needs dtype 3, C %% 32 == 0, 128-byte alignment");
     if (dtype == 3) {
         VS_CHECK(C % 4 == 0, "vs_upsample2x_nhwc: C=%d must be a multiple of 4", C);
         if ((long long)Nimg * H * W * C <= 0) return 0;
@@ -1234,10 +1250,11 @@ extern "C" int vs_upsample2x_nhwc(const void *in, const void *add, void *out, in
         if (H >= 2 && W >= 2 && !oldk) {
             const int rows = Nimg * H, gy = rows < 32768 ? rows : 32768;
             hipLaunchKernelGGL(upsample2x_f32_block_kernel, dim3((unsigned)vs::cdiv(W * (C / 4), 256), gy, vs::cdiv(rows, gy)), dim3(256), 0, stream,
-                               (const float *)in, (const float *)add, (float *)out, Nimg, H, W, C, relu_add);
+                               (const float *)in, (const float *)add, (float *)out, Nimg, H, W, C, relu_add, pack_out);
             VS_HIP(hipGetLastError());
             return 0;
         }
+        VS_CHECK(!pack_out, "vs_upsample2x_nhwc: the packed output needs H, W >= 2");
         const int rows = Nimg * 2 * H, gy = rows < 32768 ? rows : 32768;
         hipLaunchKernelGGL(upsample2x_f32_kernel, dim3((unsigned)vs::cdiv(2 * W * (C / 4), 256), gy, vs::cdiv(rows, gy)), dim3(256), 0, stream,
                            (const float *)in, (const float *)add, (float *)out, Nimg, H, W, C, relu_add);

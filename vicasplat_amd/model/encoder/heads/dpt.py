@@ -294,13 +294,15 @@ class PixelwiseTaskWithDPT(nn.Module):
         else:
             P7 = self._stem_weights()
             img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
-        x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
-        if (self.split and self.num_channels <= 96 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0
+        if (self.split and self.num_channels <= 96 and (x.shape[0] * 4 * x.shape[1] * x.shape[2]) % 256 == 0
                 and self.dpt.head[0].out_channels == 256 and x.shape[-1] in (32, 64, 128, 256)):
             # split operands: conv3(256->256) -> ReLU -> conv1(256->83) in one kernel, the second GEMM in four K-quarters on (hi, lo) images
-            # of the tile in LDS (P["h4f.w"] is the packed [96, 256] weight in this class)
+            # of the tile in LDS (P["h4f.w"] is the packed [96, 256] weight in this class).  The upsample-add kernel writes the 256 x 256 x 256
+            # operand in the packed (hi, lo) form (same bytes as f32): the convolution's main loop has no conversion left
+            x = ops.upsample2x_nhwc(x, add=img, relu_add=True, packed=True)
             y = ops.conv3x3_head1x1_nhwc(x, P["h0.w"], None, P["h4f.w"], P["h4f.b"], self.num_channels)   # [BT,H,W,96] f32
             return y[..., :self.num_channels].permute(0, 3, 1, 2)
+        x = ops.upsample2x_nhwc(x, add=img, relu_add=True)
         if (dt != torch.float32 and self.num_channels <= 96 and (x.shape[0] * x.shape[1] * x.shape[2]) % 256 == 0
                 and self.dpt.head[0].out_channels == 256 and x.shape[-1] in (64, 128, 256, 512)):
             # conv3(256->256) -> ReLU -> conv1(256->83) in one kernel (dpt_block.py:335-343; Dropout(0.1) is the identity at inference)

@@ -390,15 +390,18 @@ def conv3x3_head1x1_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.
     last two layers of a DPT head.  w [Cout,3,3,Cin]; w2 [C2pad, Cout] (rows >= n_out zero) with bias2 [C2pad] for Cout = 256, or
     w2 [<= 4, 128] with bias2 [4] for Cout = 128.  The result keeps its padded channel stride (ld2 = w2 rows, or 4): slice it."""
     if isinstance(w, SplitWeight) and isinstance(w2, SplitWeight):   # split operands, MFMA form: Cout = 256, w2 packed [C2pad <= 96, 256]
+        xin_packed = isinstance(x, SplitWeight)      # the input already in the packed (hi, lo) form (upsample2x_nhwc(..., packed=True))
+        if xin_packed:
+            x = x.data
         dev = L.require_device(x, w.data, bias, w2.data, bias2)
         N, H, W, Cin = x.shape
         c2pad = w2.shape[0]
-        assert x.is_contiguous() and x.dtype == torch.float32 and tuple(w.shape) == (256, 3, 3, Cin) and tuple(w2.shape) == (c2pad, 256)
+        assert x.is_contiguous() and x.dtype == (torch.int32 if xin_packed else torch.float32) and tuple(w.shape) == (256, 3, 3, Cin) and tuple(w2.shape) == (c2pad, 256)
         assert bias2.dtype == torch.float32 and bias2.numel() == c2pad and n_out <= c2pad
         out = torch.empty((N, H, W, c2pad), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = L.lib().vs_conv3x3_head1x1_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(w2.data), w2.acc_scale, L.ptr(bias2),
-                                                       L.ptr(out), N, H, W, Cin, n_out, c2pad, c2pad, int(relu_out), L.stream_ptr(dev))
+                                                       L.ptr(out), N, H, W, Cin, n_out, c2pad, c2pad, int(relu_out) | (16 if xin_packed else 0), L.stream_ptr(dev))
         L.check(rc, "vs_conv3x3_head1x1_split_nhwc")
         return out
     if isinstance(w, SplitWeight):   # split operands: the dot-product form (Cout = 128, n_out <= 4), f32 in / out, w2 f32 [>= n_out, 128]
@@ -493,17 +496,20 @@ def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[t
     return out
 
 
-def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_add: bool = False) -> torch.Tensor:
-    """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit; optional fused `+ add` / `+ relu(add)`."""
+def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_add: bool = False, packed: bool = False):
+    """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit / f32; optional fused `+ add` / `+ relu(add)`.
+    packed=True (f32 input, C % 32 == 0): the result is written in the packed (hi, lo) form of the split class and returned as a SplitWeight
+    of shape [N,2H,2W,C] -- the operand of a split convolution that then skips its in-loop conversion."""
     dev = L.require_device(x, add)
     assert x.dim() == 4 and x.is_contiguous() and x.dtype in _OPERAND_DTYPES
     N, H, W, Cc = x.shape
-    out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=x.dtype, device=dev)
+    assert not packed or (x.dtype == torch.float32 and Cc % 32 == 0 and H >= 2 and W >= 2)
+    out = torch.empty((N, 2 * H, 2 * W, Cc), dtype=torch.int32 if packed else x.dtype, device=dev)
     assert add is None or (add.shape == out.shape and add.is_contiguous() and add.dtype == x.dtype)
     with torch.cuda.device(dev):
-        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, int(relu_add), _DTX[x.dtype], L.stream_ptr(dev))
+        rc = L.lib().vs_upsample2x_nhwc(L.ptr(x), L.ptr(add), L.ptr(out), N, H, W, Cc, int(relu_add) | (16 if packed else 0), _DTX[x.dtype], L.stream_ptr(dev))
     L.check(rc, "vs_upsample2x_nhwc")
-    return out
+    return SplitWeight(out, 1.0, out.shape) if packed else out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
