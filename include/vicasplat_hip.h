@@ -433,7 +433,9 @@ int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *g
  * ------------------------------------------------------------------------------------------------ */
 /* out[c][r] = act(in[src(r)][c]) for r < R, 0 for R <= r < Rpad (Rpad % 64 == 0, ld_out >= Rpad, ld_out % 4 == 0); relu != 0: act = max(., 0).
  * conv_H, conv_W > 0: r indexes the pixels of whole H x W images and src(r) = r + tap_dy * W + tap_dx when that pixel is inside the
- * image (zero otherwise) -- the shifted operand of one tap of a 3x3 convolution's weight gradient; 0, 0: src(r) = r. */
+ * image (zero otherwise) -- the shifted operand of one tap of a 3x3 convolution's weight gradient; 0, 0: src(r) = r.  tap_dy = 2: r
+ * indexes the pixels of zero-BORDERED (H + 2) x (W + 2) maps (R = their total), the interior read from the unpadded tensor `in` -- the
+ * operands of the tap-fused weight gradient vs_gemm_wgrad(dtype 4, ntaps = 9), whose tap shifts move the f32 A operand. */
 int vs_transpose_f32(const float *in, int64_t ld_in, float *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu, int32_t conv_H,
                      int32_t conv_W, int32_t tap_dy, int32_t tap_dx, vs_stream_t stream);
 /* The same, written as the packed split operand of vs_gemm_split / vs_gemm_wgrad(dtype 4): out [C, ld_out] 4-byte units, rows scaled by

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/ts_$1
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o t -- python $R/tools/bench_train.py --scenes 24 --steps 2 --warmup 1 > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o t -- python $R/tools/bench_train.py --scenes ${SCENES:-24} --steps 2 --warmup 1 $TRAIN_ARGS > $O/log.txt 2>&1
 python - "$O" "${2:-28}" <<'PY'
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]

@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(256, (MI == 8 || BF16 == kDtSplit) ? 2 : 3) ge
         const int rem = blockIdx.x - ksp * tiles * g.ntaps;
         tap = rem / tiles;
         lin_tile = rem - tap * tiles;
-        g.W = reinterpret_cast<const unsigned short *>(g.W) + g_in.tap_shift[tap];  // (indexing the kernarg, not the copy: a
-                                                                                     //  dynamically indexed local struct lives in scratch)
+        if (g.tap_on_a) g.A = reinterpret_cast<const unsigned short *>(g.A) + g_in.tap_shift[tap];
+        else g.W = reinterpret_cast<const unsigned short *>(g.W) + g_in.tap_shift[tap];  // (indexing the kernarg, not the copy: a
+                                                                                          //  dynamically indexed local struct lives in scratch)
         g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
     }
     if (ksp > 0) g.bias = nullptr;                                      // the bias belongs to slice 0
@@ -631,6 +632,7 @@ int gemm_entry(const char *fn, const void *A, const void *W, const float *bias, 
     g.acc_scale = acc_scale;
     g.a_packed = a_packed;
     g.out_packed = out_packed;
+    g.tap_on_a = 0;
     // split operands (kDtSplit) take the 16-bit classes' routing: whole rounds of 256 x 256 tiles + a tail launch (K counts 2-byte units
     // of the f32 rows; every stage pair / K-tile of the kernels is one 128-byte block of 32 k)
     const int rc = dtype == 4 ? launch<kDtSplit>(g, epilogue, stream)
@@ -775,8 +777,8 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     VS_CHECK(ntaps >= 0 && ntaps <= 9 && (ntaps == 0 || shifts), "vs_gemm_wgrad: 0 <= ntaps <= 9, and shifts when ntaps > 0");
     VS_CHECK(K % (32 * ksplit) == 0, "vs_gemm_wgrad: K=%d must be a multiple of 32 * ksplit (%d)", K, 32 * ksplit);
     VS_CHECK(dtype == 1 || dtype == 2 || dtype == 4, "vs_gemm_wgrad: dtype must be 1 (f16), 2 (bf16) or 4 (split: A f32, W packed by vs_split_pack_weight / vs_transpose_pack_split)");
-    if (dtype == 4) {   // split operands: f32 rows addressed in 2-byte units (gemm_common.h, kDtSplit); no tap shifts (a packed W cannot be shifted)
-        VS_CHECK(ntaps == 0, "vs_gemm_wgrad: split operands take no tap shifts (pack one shifted image per tap: vs_transpose_pack_split)");
+    if (dtype == 4) {   // split operands: f32 rows addressed in 2-byte units (gemm_common.h, kDtSplit); tap shifts (in floats) move the f32 A
+                        // operand -- a packed W cannot be shifted: A = zero-bordered X^T with a readable halo of |shift| floats on both sides
         VS_CHECK(lda % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0, "vs_gemm_wgrad: split operands need 16-byte aligned rows");
         K *= 2; lda *= 2; ldw *= 2; a_slice_stride *= 2; w_slice_stride *= 2;
     }
@@ -786,11 +788,12 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
     g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
-    for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] : 0;
+    for (int t = 0; t < 9; ++t) g.tap_shift[t] = t < ntaps ? shifts[t] * (dtype == 4 ? 2 : 1) : 0;
+    g.tap_on_a = dtype == 4 ? 1 : 0;
     VS_CHECK(accumulate || workspace, "vs_gemm_wgrad: accumulate = 0 (overwrite out) needs a workspace; the atomics path can only add");
     const int rc = dtype == 4 ? launch_wgrad<kDtSplit>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
                  : dtype == 2 ? launch_wgrad<1>(g, ksplit, (float *)workspace, workspace_bytes, accumulate, stream)
@@ -824,7 +827,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
@@ -874,7 +877,7 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
     const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
@@ -946,7 +949,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     static const int no256 = [] { const char *e = getenv("VS_STEM_NO256"); return e ? atoi(e) : 0; }();
     if (Cout % 256 == 0 && g.M >= 256 && !no256) {
         const int nwg = vs::cdiv(g.M, 256) * (Cout / 256);
@@ -984,7 +987,7 @@ extern "C" int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp,
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
     g.a_kstride = Wp * 6;
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;

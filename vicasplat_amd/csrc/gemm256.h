@@ -523,7 +523,8 @@ __global__ void __launch_bounds__(512, 1) gemm256_splitk_kernel(const GemmArgs g
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A) + ksp * (g.a_slice_stride ? g.a_slice_stride : (long long)KT * 64);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + ksp * (g.w_slice_stride ? g.w_slice_stride : (long long)KT * 64);
     if (g.ntaps > 0) {
-        W += g_in.tap_shift[tap];  // index the kernarg: a dynamically indexed local copy would live in scratch
+        if (g.tap_on_a) A += g_in.tap_shift[tap];
+        else W += g_in.tap_shift[tap];  // index the kernarg: a dynamically indexed local copy would live in scratch
         g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
     }
     g.ksplit = 2;  // epilogue: "partial sums meet through atomics" ...

@@ -56,6 +56,7 @@ struct GemmArgs {
     int rope_C;  // columns [0, C) = q, [C, 2C) = k, rest untouched
     float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
     int stagger;  // experiment: first-round workgroups of gemm256_kernel sleep (bid % 8) * stagger * ~4 us before starting
+    int tap_on_a;     // tap-fused weight gradient: the tap shift moves the A operand instead of W (split class: a packed W cannot be shifted)
     int out_packed;   // split operands, epilogues 0 / 1 / 3: the output is written in the packed (hi, lo) form (the A operand of the next GEMM)
     int a_packed;     // split operands: A is ALREADY in the packed (hi, lo) form of vs_split_pack_weight (scale 2^0): the kernels skip the conversion
     float acc_scale;  // split operands (kDtSplit): the packed weights carry a power-of-two scale 2^e; the epilogue multiplies the accumulators by 2^-e

@@ -45,10 +45,18 @@ transpose_f32_kernel(const float *__restrict__ in, long long ld_in, void *__rest
         bool ok = r < R;
         long long src = r;
         if (cH > 0 && ok) {
-            const int x = r % cW, y = (r / cW) % cH;
-            const int sy = y + dy, sx = x + dx;
-            ok = sy >= 0 && sy < cH && sx >= 0 && sx < cW;
-            src = (long long)r + dy * cW + dx;
+            if (dy == 2) {   // border mode: r indexes the pixels of zero-bordered (cH + 2) x (cW + 2) maps
+                const int Wp = cW + 2, HWp = (cH + 2) * Wp;
+                const int n = r / HWp, rem = r - n * HWp;
+                const int y = rem / Wp - 1, x = rem - (rem / Wp) * Wp - 1;
+                ok = y >= 0 && y < cH && x >= 0 && x < cW;
+                src = ((long long)n * cH + y) * cW + x;
+            } else {
+                const int x = r % cW, y = (r / cW) % cH;
+                const int sy = y + dy, sx = x + dx;
+                ok = sy >= 0 && sy < cH && sx >= 0 && sx < cW;
+                src = (long long)r + dy * cW + dx;
+            }
         }
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
@@ -235,8 +243,9 @@ int transpose_f32_entry(const char *fn, bool pack, const float *in, int64_t ld_i
                         int32_t relu, int32_t cH, int32_t cW, int32_t dy, int32_t dx, int32_t scale_exp, hipStream_t stream) {
     VS_CHECK(in && out, "%s: null pointer", fn);
     VS_CHECK(R >= 0 && C > 0 && Rpad >= R && Rpad % 64 == 0 && ld_in >= C && ld_out >= Rpad, "%s: bad sizes R=%d C=%d Rpad=%d (Rpad %% 64 == 0, ld_out >= Rpad)", fn, R, C, Rpad);
-    VS_CHECK((cH == 0 && cW == 0) || (cH > 0 && cW > 0 && R % (cH * cW) == 0 && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1),
-             "%s: a convolution tap needs R = whole H x W images and |dy|, |dx| <= 1", fn);
+    VS_CHECK((cH == 0 && cW == 0) || (cH > 0 && cW > 0 && dy == 2 && R % ((cH + 2) * (cW + 2)) == 0) ||
+                 (cH > 0 && cW > 0 && R % (cH * cW) == 0 && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1),
+             "%s: a convolution tap needs R = whole H x W images and |dy|, |dx| <= 1 (tap_dy = 2: R = whole zero-bordered (H+2) x (W+2) images)", fn);
     VS_CHECK(ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "%s: out must be 16-byte aligned with ld_out %% 4 == 0", fn);
     VS_CHECK(scale_exp >= -30 && scale_exp <= 30, "%s: scale_exp out of range", fn);
     if (Rpad == 0) return 0;

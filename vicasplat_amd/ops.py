@@ -909,30 +909,50 @@ def upsample2x_backward_nhwc(dout: torch.Tensor) -> torch.Tensor:
 # Gradients must sit in the f16 range (|g| < 65504, typical magnitude >~ 1e-2 for full precision): callers.training_step keeps its
 # power-of-two loss scale for this class too.
 # ------------------------------------------------------------------------------------------------------------------------------
-def transpose_f32(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0)) -> torch.Tensor:
+def _border_rows(R, conv_hw, border):
+    if not border:
+        return R
+    h, w = conv_hw
+    assert R % (h * w) == 0
+    return R // (h * w) * (h + 2) * (w + 2)
+
+
+def transpose_f32(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0),
+                  border: bool = False, halo: int = 0) -> torch.Tensor:
     """x [R,C] f32 (row stride any multiple of 4 or contiguous) -> [C, Rpad] f32, Rpad = R rounded up to pad_to (a multiple of 64), zero padded.
-    conv_hw = (H, W) with tap = (dy, dx): row r reads pixel r shifted by the tap, zero outside its image."""
+    conv_hw = (H, W) with tap = (dy, dx): row r reads pixel r shifted by the tap, zero outside its image.  border=True: the transposed
+    rows are the pixels of the zero-bordered (H+2) x (W+2) maps; halo > 0 (a multiple of 4): the result is the middle of a zero buffer with
+    `halo` readable zero columns on both sides (the operand whose shifted views the tap-fused weight gradient reads)."""
     dev = L.require_device(x)
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0 and halo % 4 == 0
     R, Cc = x.shape
-    Rpad = (R + pad_to - 1) // pad_to * pad_to
-    out = torch.empty((Cc, Rpad), dtype=torch.float32, device=dev)
+    Rb = _border_rows(R, conv_hw, border)
+    Rpad = (Rb + pad_to - 1) // pad_to * pad_to
+    if halo:
+        buf = torch.zeros((Cc, halo + Rpad + halo), dtype=torch.float32, device=dev)
+        out = buf[:, halo:halo + Rpad]
+    else:
+        out = torch.empty((Cc, Rpad), dtype=torch.float32, device=dev)
     h, w = conv_hw if conv_hw is not None else (0, 0)
+    dy, dx = (2, 0) if border else tap
     with torch.cuda.device(dev):
-        rc = L.lib().vs_transpose_f32(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, int(relu), h, w, tap[0], tap[1], L.stream_ptr(dev))
+        rc = L.lib().vs_transpose_f32(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), Rb, Cc, Rpad, int(relu), h, w, dy, dx, L.stream_ptr(dev))
     L.check(rc, "vs_transpose_f32")
     return out
 
 
 def transpose_pack_split(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0),
-                         scale_exp: int = 0) -> SplitWeight:
+                         scale_exp: int = 0, border: bool = False) -> SplitWeight:
     """transpose_f32 written as the packed split "weight" operand [C, Rpad] (SplitWeight, acc_scale = 2^-scale_exp)."""
     dev = L.require_device(x)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0
     R, Cc = x.shape
+    R = _border_rows(R, conv_hw, border)
     Rpad = (R + pad_to - 1) // pad_to * pad_to
     out = torch.empty((Cc, Rpad), dtype=torch.int32, device=dev)
     h, w = conv_hw if conv_hw is not None else (0, 0)
+    if border:
+        tap = (2, 0)
     with torch.cuda.device(dev):
         rc = L.lib().vs_transpose_pack_split(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, int(relu), h, w, tap[0], tap[1], scale_exp,
                                              L.stream_ptr(dev))
@@ -952,18 +972,22 @@ def split16(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     return hi, lo
 
 
-def gemm_wgrad_split(a: torch.Tensor, w: SplitWeight, out: torch.Tensor, ksplit: int) -> torch.Tensor:
+def gemm_wgrad_split(a: torch.Tensor, w: SplitWeight, out: torch.Tensor, ksplit: int, shifts=None) -> torch.Tensor:
     """out32 [M,N] = a [M,K] @ w [N,K]^T in the split class, the reduction cut into ksplit slices (vs_gemm_wgrad, dtype 4; partial
-    tiles in a workspace + a reduce kernel).  K % (64 * ksplit) == 0."""
+    tiles in a workspace + a reduce kernel).  K % (64 * ksplit) == 0.  shifts (<= 9 column offsets, in floats): out [len(shifts), M, N],
+    tap t reads `a` shifted by shifts[t] columns -- `a` must be a view with that many readable (zero) columns on both sides."""
     wd = w.data
     dev = L.require_device(a, wd, out)
     assert a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and wd.dim() == 2 and wd.stride(1) == 1 and a.shape[1] == wd.shape[1]
-    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == (a.shape[0], wd.shape[0])
     M, N, K = a.shape[0], wd.shape[0], a.shape[1]
+    ntaps = 0 if shifts is None else len(shifts)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == ((M, N) if shifts is None else (ntaps, M, N))
     assert K % (64 * ksplit) == 0, (K, ksplit)
-    ws = torch.empty(max(2, ksplit) * M * N, dtype=torch.float32, device=dev)
+    import ctypes
+    sh = None if shifts is None else (ctypes.c_int32 * ntaps)(*shifts)
+    ws = torch.empty(max(2, ksplit) * max(1, ntaps) * M * N, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(wd), L.ptr(out), M, N, K, a.stride(0), wd.stride(0), N, 0, 0, 0, None, 0, ksplit, 4, L.ptr(ws),
+        rc = L.lib().vs_gemm_wgrad(L.ptr(a), L.ptr(wd), L.ptr(out), M, N, K, a.stride(0), wd.stride(0), N, 0, 0, M * N, sh, ntaps, ksplit, 4, L.ptr(ws),
                                    ws.numel() * 4, 0, L.stream_ptr(dev))
     L.check(rc, "vs_gemm_wgrad(split)")
     if w.acc_scale != 1.0:
@@ -1076,16 +1100,24 @@ def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *
             dyp = torch.nn.functional.pad(dy, (0, pad_o))
         wdp = split_pack_weight(wd, scale_exp)
         dx = conv3x3_nhwc(dyp, wdp, None, mask_by=x if relu_in else None)
+    # weight gradient: ONE tap-fused launch over the zero-bordered pixel grid.  A = act(X)^T [Cin, pixels] f32 with a zero halo (the nine tap
+    # shifts are column offsets of this operand: LDS-DMA reads any 4-byte aligned f32 address), W = dY^T [Cout, pixels] packed (hi, lo);
+    # out[tap] = [Cin, Cout].  Two transposing passes instead of nine packed shifted images.
     P = N * H * W
-    Pp = (P + 1023) // 1024 * 1024 if P >= 4096 else (P + 127) // 128 * 128
-    dyT = transpose_f32(dy.view(P, Cout), Pp)                                       # [Cout, Pp]
-    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
-    tmp = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
-    x2 = x.view(P, Cin)
-    for ky in range(3):
-        for kx in range(3):
-            xT = transpose_pack_split(x2, Pp, relu=relu_in, conv_hw=(H, W), tap=(ky - 1, kx - 1))     # [Cin, Pp] packed
-            _wgrad_split(dyT, xT, tmp)
-            dw[:, :, ky, kx] = tmp
+    Wp = W + 2
+    Pb = N * (H + 2) * Wp
+    tiles = ((Cin + 255) // 256) * ((Cout + 255) // 256) * 9 if (Cin % 256 == 0 and Cout % 256 == 0) else ((Cin + 127) // 128) * ((Cout + 127) // 128) * 9
+    if Cin % 256 == 0 and Cout % 256 == 0:
+        ks = max(1, min((256 + tiles // 2) // tiles, Pb // 512))
+    else:
+        ks = max(2, min(768 // tiles, Pb // 512, 1024))
+    unit = 64 * ks * (2 if (Cin % 256 == 0 and Cout % 256 == 0) else 1)
+    halo = (Wp + 2 + 3) // 4 * 4
+    xT = transpose_f32(x.view(P, Cin), unit, relu=relu_in, conv_hw=(H, W), border=True, halo=halo)          # [Cin, Pp] view of the haloed buffer
+    dyT = transpose_pack_split(dy.view(P, Cout), unit, conv_hw=(H, W), border=True)                          # [Cout, Pp] packed
+    dw9 = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
+    shifts = [(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)]
+    gemm_wgrad_split(xT, dyT, dw9, ks, shifts=shifts)
+    dw = dw9.view(3, 3, Cin, Cout).permute(3, 2, 0, 1).contiguous()                                          # [Cout, Cin, ky, kx]
     db = colsum(dy.view(P, Cout)) if need_db else None
     return dx, dw, db
