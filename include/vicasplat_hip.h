@@ -465,6 +465,12 @@ int vs_gated_resid_backward_f32(const float *dout, const float *y, int64_t ldy, 
                                 float *dgate, int32_t M, int32_t C, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream);
 int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg, int32_t H, int32_t W, int32_t C, vs_stream_t stream);
 
+/* Measurement aid of bench.py (`roofline.sustained_mfma_tflops`): back-to-back v_mfma_f32_16x16x32_f16 on register operands filled from
+ * `operands` (>= 1 MiB of f16 data), no memory traffic in the loop, 512 workgroups x 4 waves x iters x 16 MFMAs; scratch >= 131072 floats.
+ * Asynchronous on `stream`; *flop_out_host receives the FLOP count of the launch.  Its rate is what the chip sustains on the matrix pipe
+ * alone (power-limited: ~0.67 of the 2.5 PFLOP/s dense-f16 headline on MI355X). */
+int vs_probe_mfma_rate(const void *operands, float *scratch, int32_t iters, double *flop_out_host, vs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

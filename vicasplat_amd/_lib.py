@@ -172,6 +172,8 @@ def lib() -> C.CDLL:
             L.vs_conv7x7_rgb_split_nhwc.argtypes = [vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             L.vs_upsample2x_nhwc.restype = C.c_int
             L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_probe_mfma_rate.restype = C.c_int
+            L.vs_probe_mfma_rate.argtypes = [vp, vp, i32, C.POINTER(C.c_double), vp]
             L.vs_transpose_f32.restype = C.c_int
             L.vs_transpose_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]
             L.vs_transpose_pack_split.restype = C.c_int

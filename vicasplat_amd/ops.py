@@ -43,6 +43,9 @@ class SplitWeight:
     def is_contiguous(self):
         return self.data.is_contiguous()
 
+    def numel(self):
+        return self.data.numel()
+
 
 def split_scale_exp(w: torch.Tensor) -> int:
     """Power-of-two exponent e with max|w| 2^e in [2^13, 2^14) (one host read of the maximum)."""
@@ -1121,3 +1124,26 @@ def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *
     dw = dw9.view(3, 3, Cin, Cout).permute(3, 2, 0, 1).contiguous()                                          # [Cout, Cin, ky, kx]
     db = colsum(dy.view(P, Cout)) if need_db else None
     return dx, dw, db
+
+
+def sustained_mfma_tflops(device, ms_target: float = 40.0) -> float:
+    """TFLOP/s the chip sustains on back-to-back v_mfma_f32_16x16x32_f16 with register operands holding random data and no memory traffic
+    (vs_probe_mfma_rate): the power-limited ceiling of every 16-bit MFMA kernel on this device, measured, beside the 2.5 PFLOP/s headline."""
+    import ctypes
+    dev = torch.device(device)
+    src = (torch.rand(1 << 19, device=dev) * 4 - 2).half()
+    scratch = torch.empty(512 * 256, dtype=torch.float32, device=dev)
+    fl = ctypes.c_double(0.0)
+    def run(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.device(dev):
+            s.record()
+            rc = L.lib().vs_probe_mfma_rate(L.ptr(src), L.ptr(scratch), iters, ctypes.byref(fl), L.stream_ptr(dev))
+            e.record()
+        L.check(rc, "vs_probe_mfma_rate")
+        e.synchronize()
+        return s.elapsed_time(e), fl.value
+    ms, f = run(20000)                                   # warm-up and calibration (clocks settle within a few ms)
+    iters = max(20000, int(20000 * ms_target / max(ms, 1e-3)))
+    ms, f = run(iters)
+    return f / (ms * 1e-3) / 1e12
