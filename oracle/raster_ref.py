@@ -251,10 +251,14 @@ def cov6(cov33: np.ndarray) -> np.ndarray:
                                           cov33[:, 1, 2], cov33[:, 2, 2]], -1).astype(np.float32))
 
 
-def render_views(scene: dict, res: int = 256, bg=(0, 0, 0)) -> list[dict]:
-    """Oracle equivalent of render_cuda(...) on a scene dict (shared Gaussians)."""
+def render_views(scene: dict, res: int = 256, bg=(0, 0, 0), threads: int = 1) -> list[dict]:
+    """Oracle equivalent of render_cuda(...) on a scene dict (shared Gaussians).  threads > 1: the views on that many host threads."""
     cams = make_cameras(scene["extrinsics"], scene["intrinsics"], scene["near"], scene["far"])
     shs = np.ascontiguousarray(np.transpose(scene["harmonics"], (0, 2, 1)))  # [P,25,3]
     c6 = cov6(scene["covariances"])
-    return [rasterize_forward(cam, res, res, np.asarray(bg, np.float32), scene["means"], c6, shs, scene["opacities"])
-            for cam in cams]
+    one = lambda cam: rasterize_forward(cam, res, res, np.asarray(bg, np.float32), scene["means"], c6, shs, scene["opacities"])
+    if threads > 1 and len(cams) > 1:      # views are independent: one host thread each (the C call releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(threads, len(cams))) as ex:
+            return list(ex.map(one, cams))
+    return [one(cam) for cam in cams]

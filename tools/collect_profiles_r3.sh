@@ -21,6 +21,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/gemm_t -o g -- python
 # 4. the training step (24 scenes, 12 targets: BASELINE configs 4 / 5), 4 executed steps
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python $R/tools/bench_train.py --scenes 24 --steps 3 --warmup 1 > $O/train.log 2>&1
 python $R/tools/bench_train.py --scenes 24 --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/train_line.json
+# 5. the same step in the split class (reference precision forward AND backward), 8 scenes, 3 executed steps
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_split -o t -- python $R/tools/bench_train.py --scenes 8 --steps 2 --warmup 1 --dtype split > $O/train_split.log 2>&1
+python $R/tools/bench_train.py --scenes 8 --steps 3 --warmup 1 --dtype split 2>/dev/null | tail -1 > $O/train_split_line.json
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*.db" -delete
 du -sh $O; find $O -type f | head -60

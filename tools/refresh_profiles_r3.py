@@ -10,6 +10,8 @@ shutil.copy(one("stats16/**/*kernel_stats.csv"), os.path.join(OUT, "round3_f16_k
 shutil.copy(one("stats32/**/*kernel_stats.csv"), os.path.join(OUT, "round3_f32_kernel_stats.csv"))
 tr = "train2" if os.path.isdir(os.path.join(P3, "train2")) else "train"
 shutil.copy(one(tr + "/**/*kernel_stats.csv"), os.path.join(OUT, "round3_train_kernel_stats.csv"))
+if os.path.isdir(os.path.join(P3, "train_split")):
+    shutil.copy(one("train_split/**/*kernel_stats.csv"), os.path.join(OUT, "round3_train_split_kernel_stats.csv"))
 subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_traffic.py"), one("fetch/**/*counter_collection.csv"), one("write/**/*counter_collection.csv"),
                        "2", os.path.join(OUT, "round3_pmc_traffic.json")])
 pm = json.load(open(os.path.join(OUT, "round3_pmc_traffic.json")))
