@@ -302,3 +302,35 @@ def test_lpips_structure_and_properties():
     x = a.clone().requires_grad_()
     loss(x, b, 3).backward()
     assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+
+
+def test_split_class_training_step_defaults_and_operand_geometry():
+    """Host logic of the split-class (reference-precision) training step, no GPU: callers.training_step(compute_dtype="split") creates the
+    scaler the f16 (hi, lo) gradient operands need (8192, growing to 2^24, halved on overflow -- exact powers of two), keeps the 16-bit
+    defaults unchanged, and the border geometry of the tap-fused convolution weight gradient (ops._border_rows, the halo of
+    conv3x3_backward_split) matches the kernel contract of vs_transpose_f32 / vs_gemm_wgrad(dtype 4)."""
+    from tests.test_distributed_cpu import _ToyDecoder, _ToyEncoder, _toy_forward, _toy_train_batch
+    from vicasplat_amd import autograd as A
+    from vicasplat_amd import ops
+    assert A.act_dtype("split") == torch.float32 and A.act_dtype(torch.float16) == torch.float16 and A.SPLIT == "split"
+    torch.manual_seed(0)
+    for cdt, init in (("split", 8192.0), (torch.float16, 1024.0), (torch.bfloat16, 1.0)):
+        enc = _ToyEncoder()
+        opt = torch.optim.AdamW(enc.parameters(), lr=1e-3)
+        r = callers.training_step(enc, _ToyDecoder(), _toy_train_batch(), opt, compute_dtype=cdt, forward_fn=_toy_forward)
+        sc = opt._vs_loss_scaler
+        assert r["loss_scale"] == init and sc.scale == init and not r["skipped"]
+        assert sc.max_scale == (2.0 ** 24 if cdt == "split" else 65536.0)
+    sc = callers.LossScaler(8192.0, max_scale=2.0 ** 24, growth_interval=1)
+    for _ in range(20):
+        sc.update(True)
+    assert sc.scale == 2.0 ** 24
+    sc.update(False)
+    assert sc.scale == 2.0 ** 23
+    # zero-bordered pixel grid of the tap-fused weight gradient: N images of (H + 2) x (W + 2) pixels; halo >= largest |tap shift| + 1, 16-byte rows
+    assert ops._border_rows(2 * 5 * 7, (5, 7), True) == 2 * 7 * 9 and ops._border_rows(70, (5, 7), False) == 70
+    for W in (4, 16, 37, 256):
+        Wp = W + 2
+        halo = (Wp + 2 + 3) // 4 * 4
+        shifts = [(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)]
+        assert halo % 4 == 0 and halo > max(abs(s) for s in shifts)

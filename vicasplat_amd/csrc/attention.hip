@@ -474,7 +474,20 @@ struct AttnArgsSplit {
     int ldq, ldk, ldv, ldo;
     float scale_log2e;
     float *lse;
+    int out_packed;   // write O in the packed (hi, lo) form of the split class (the A operand of the projection GEMM: vs_gemm_split_packed)
 };
+
+// four consecutive columns n .. n + 3 of an f32 row written in the packed (hi, lo) layout of vs_split_pack_weight (gemm_common.h, store_split4)
+__device__ __forceinline__ void store_split4_attn(float *row, int n, float a, float b, float c, float d) {
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    const h2_ h0 = __builtin_convertvector(f2_{a, b}, h2_), h1 = __builtin_convertvector(f2_{c, d}, h2_);
+    const h2_ l0 = __builtin_convertvector(f2_{a - (float)h0.x, b - (float)h0.y}, h2_), l1 = __builtin_convertvector(f2_{c - (float)h1.x, d - (float)h1.y}, h2_);
+    const int kk = n & 31;
+    unsigned short *o = reinterpret_cast<unsigned short *>(row + (n & ~31)) + ((kk & 15) >> 2) * 8 + (kk >> 4) * 4;
+    *reinterpret_cast<uint2 *>(o) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    *reinterpret_cast<uint2 *>(o + 32) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
 
 __device__ __forceinline__ unsigned cvt_pk_f16s(float a, float b) { return pack2<false>(a, b); }
 // 8 floats -> 8 hi halves + 8 lo halves (in order); x - float(hi) on v_fma_mix_f32 (f16 source operand, exact f32 result)
@@ -655,9 +668,16 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
         if (qo >= a.Lq) continue;
         const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
         float *op = a.out + (b * a.q_batch_rows + qo) * a.ldo + h * HD + g * 4;
+        if (a.out_packed) {
+            float *rowp = a.out + (b * a.q_batch_rows + qo) * a.ldo;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
-            *reinterpret_cast<float4 *>(op + db * 16) = make_float4(o[u][db][0] * inv, o[u][db][1] * inv, o[u][db][2] * inv, o[u][db][3] * inv);
+            for (int db = 0; db < 4; ++db)
+                store_split4_attn(rowp, h * HD + db * 16 + g * 4, o[u][db][0] * inv, o[u][db][1] * inv, o[u][db][2] * inv, o[u][db][3] * inv);
+        } else {
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                *reinterpret_cast<float4 *>(op + db * 16) = make_float4(o[u][db][0] * inv, o[u][db][1] * inv, o[u][db][2] * inv, o[u][db][3] * inv);
+        }
         if (a.lse && g == 0) a.lse[(b * a.q_batch_rows + qo) * a.H + h] = l_run[u] > 0.f ? m_run[u] + log2f(l_run[u]) : -INFINITY;
     }
 }
@@ -833,7 +853,10 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
     VS_CHECK(kv_seg || Lk > 0, "vs_attention: Lk must be positive when kv_seg is null");
     VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "vs_attention: row strides must be multiples of 8 elements");
     VS_CHECK(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "vs_attention: 16-byte alignment required");
-    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "vs_attention: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split: f32 data, 3 x f16 MFMA)");
+    const int out_packed = dtype == 20 ? 1 : 0;       // 4 + 16: split class with the output in the packed (hi, lo) form (ldo % 32 == 0, 128-byte aligned)
+    if (out_packed) dtype = 4;
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "vs_attention: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split: f32 data, 3 x f16 MFMA; 20 = 4 with a packed output)");
+    VS_CHECK(!out_packed || (ldo % 32 == 0 && ((uintptr_t)out & 127) == 0), "vs_attention: a packed output needs ldo %% 32 == 0 and a 128-byte aligned buffer");
     VS_CHECK(H <= 65535 && nbatch <= 65535, "vs_attention: grid too large");
     if (nbatch == 0 || Lq == 0) return 0;
     if (dtype == 4) {
@@ -841,7 +864,7 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
         AttnArgsSplit f;
         f.q = (const float *)q; f.k = (const float *)k; f.v = (const float *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;
         f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
-        f.ldq = ldq; f.ldk = ldk; f.ldv = ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse;
+        f.ldq = ldq; f.ldk = ldk; f.ldv = ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse; f.out_packed = out_packed;
         const int Lk_eff = kv_seg ? 2 * Lk : Lk;
         static const int force_qg4 = [] { const char *e = getenv("VS_ATTN_SPLIT_QG"); return e ? atoi(e) : 0; }();
         bool big = (long long)vs::cdiv(Lq, 128) * H * nbatch >= 512 && Lk_eff > 256;

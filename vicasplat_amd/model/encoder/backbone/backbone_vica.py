@@ -245,7 +245,7 @@ class VicaNet(nn.Module):
         act = (lambda r, c: ops.split_act(r, c, dev)) if self.split else (lambda r, c: torch.empty(r, c, **f16))
         h = act(BT * N, Ce)
         qkv = torch.empty(BT * N, 3 * Ce, **f16)
-        att = torch.empty(BT * N, Ce, **f16)
+        att = act(BT * N, Ce)
         hid = act(BT * N, int(Ce * cfg.mlp_ratio))
         for i, blk in enumerate(self.enc_blocks):
             ops.layernorm_mod(xe, blk.norm1.weight, blk.norm1.bias, h)
@@ -272,10 +272,10 @@ class VicaNet(nn.Module):
         M2 = N + 1  # rows per frame in the interleaved buffer
         hmix = act(BT * M2, Cd)
         qkvm = torch.empty(BT * M2, 3 * Cd, **f16)
-        attm = torch.empty(BT * M2, Cd, **f16)
+        attm = act(BT * M2, Cd)
         h = act(BT * N, Cd)
         qkv = torch.empty(BT * N, 3 * Cd, **f16)
-        att = torch.empty(BT * N, Cd, **f16)
+        att = act(BT * N, Cd)
         hid = act(BT * N, int(Cd * cfg.mlp_ratio))
         cn = torch.empty(BT, Cd, **f32)
         cn16 = torch.empty(BT, Cd, **f16)

@@ -240,6 +240,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     """q/k/v: 2-D views [rows, ld] whose column 0 is head 0 (e.g. slices of a packed q|k|v buffer); out [rows, H*64].
     lse (optional, f32 [rows, H] contiguous) receives the log2-domain logsumexp for attention_backward.
     split=True (f32 tensors only): the split operand class -- three f16 MFMAs per product instead of the exact-f32 MFMA (dtype code 4)."""
+    out_obj, out_packed = out, isinstance(out, SplitWeight)
+    if out_packed:          # split class: O written in the packed (hi, lo) form, the A operand of the projection GEMM as it is
+        assert split and out.acc_scale == 1.0
+        out = out.data.view(torch.float32)
     dev = L.require_device(q, k, v, out, kv_seg, q_kvlen, lse)
     for t in (q, k, v, out):
         assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == q.dtype
@@ -250,9 +254,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     with torch.cuda.device(dev):
         rc = L.lib().vs_attention_lse(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
                                       q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
-                                      4 if split else _DTX[q.dtype], L.ptr(lse), L.stream_ptr(dev))
+                                      (20 if out_packed else 4) if split else _DTX[q.dtype], L.ptr(lse), L.stream_ptr(dev))
     L.check(rc, "vs_attention")
-    return out
+    return out_obj
 
 
 def attention_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, *,
