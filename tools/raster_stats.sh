@@ -5,7 +5,7 @@ O=$R/gpurun_out/rs_$1
 mkdir -p $O
 [ -n "$2" ] && export VICASPLAT_HIP_LIB=$R/$2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o b -- python $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-f32 > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o b -- python $R/bench.py --mode infer --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-f32 --no-fast --no-targets70 > $O/log.txt 2>&1
 python - "$O" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]

@@ -289,7 +289,7 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
       __syncthreads();
       const int ncam = ncam_s;
       for (int kc = 0; kc < ncam; ++kc) {
-        const int c = cams[kc];
+        const int c = __builtin_amdgcn_readfirstlane(cams[kc]);   // wave-uniform: scalar loads of the camera matrices
         const size_t ci = (size_t)c * P + (live ? i : 0);
         float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live && radii[ci] > 0) {

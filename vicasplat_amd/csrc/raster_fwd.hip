@@ -135,7 +135,7 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
       __syncthreads();
       const int ncam = ncam_s;
       for (int k = 0; k < ncam; ++k) {
-        const int c = cams[k];
+        const int c = __builtin_amdgcn_readfirstlane(cams[k]);   // wave-uniform: the camera matrices become scalar loads (SGPRs), not 37 per-lane loads
         const size_t ci = (size_t)c * P + i;
         bool visible = false;
         int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
