@@ -75,8 +75,8 @@ def lib() -> C.CDLL:
             L = C.CDLL(_SO)
             L.vs_last_error.restype = C.c_char_p
             L.vs_abi_version.restype = C.c_int
-            if L.vs_abi_version() != 3:     # the ctypes mirrors of the structs below are for exactly this layout
-                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 3: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+            if L.vs_abi_version() != 4:     # the ctypes mirrors of the structs below are for exactly this layout
+                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 4: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
             L.vs_raster_forward.restype = C.c_int64
             L.vs_raster_forward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), AllocFn, C.c_void_p, C.c_void_p]
             L.vs_rope2d.restype = C.c_int

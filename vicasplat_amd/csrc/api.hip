@@ -12,7 +12,8 @@ void set_error(const char *fmt, ...) {
 }  // namespace vs
 
 extern "C" const char *vs_last_error(void) { return vs::g_err; }
-extern "C" int vs_abi_version(void) { return 3; }   // 2: VsRasterIn.capacity, VS_BUF_DEPTH (round 2); 3: split operands (dtype 4, vs_gemm_split, ...)
+extern "C" int vs_abi_version(void) { return 4; }   // 2: VsRasterIn.capacity, VS_BUF_DEPTH (round 2); 3: split operands (dtype 4, vs_gemm_split, ...);
+                                                      // 4: split-class backward entries, packed activations (+16 flags, vs_gemm_split_packed), vs_probe_mfma_rate
 
 // ---- measurement aid (bench.py `roofline.sustained_mfma_tflops`): the rate the chip SUSTAINS on the matrix pipe alone.  The MFMA kernels
 // of this library run power-limited (DVFS: DESIGN 5); the 2.5 PFLOP/s dense-f16 figure assumes 2.4 GHz on every CU, which gfx950 does
