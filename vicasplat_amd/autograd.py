@@ -104,10 +104,13 @@ class LinearSplitFn(torch.autograd.Function):
         base = w if w.is_leaf else w._base
         if base is None or not base.is_leaf:     # a temporary (concatenated / re-laid-out weights): nothing stable to key a cache on
             return ops.split_scale_exp(w)
+        import weakref
         key = (id(base), w.data_ptr(), tuple(w.shape))
         ent = LinearSplitFn._exp_cache.get(key)
-        if ent is None or ent[1] <= 0:
-            ent = [ops.split_scale_exp(w), 64]
+        if ent is None or ent[1] <= 0 or ent[2]() is not base:     # (the weak reference guards against a recycled id / address of a freed parameter)
+            if len(LinearSplitFn._exp_cache) > 4096:
+                LinearSplitFn._exp_cache.clear()
+            ent = [ops.split_scale_exp(w), 64, weakref.ref(base)]
             LinearSplitFn._exp_cache[key] = ent
         ent[1] -= 1
         return ent[0]
