@@ -167,6 +167,11 @@ int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *
                   int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,
                   const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d, vs_stream_t stream);
 
+/* vs_conv3x3_split_nhwc with a second f32 residual: out = act(conv(in) + bias + residual + residual2) -- the FeatureFusionBlock's
+ * x + ResidualConvUnit(skip) (heads/dpt_block.py:196-208) folded into the unit's last convolution (no element-wise add pass). */
+int vs_conv3x3_split_res2_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *residual, const float *residual2,
+                               float *out, int32_t Nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in,
+                               int32_t relu_out, vs_stream_t stream);
 /* vs_gemm_split with the A operand ALREADY in the packed (hi, lo) form (Ap = vs_split_pack_weight(A, scale_exp 0) or a producer that
  * writes that form; lda in 4-byte units): the main loops skip the in-kernel conversion.  M > 64 routes only (tile kernels). */
 int vs_gemm_split_packed(const void *Ap, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,

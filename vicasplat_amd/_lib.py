@@ -164,6 +164,8 @@ def lib() -> C.CDLL:
             L.vs_gemm_split_packed.argtypes = [vp, vp, f32, vp, vp, vp, vp] + [i32] * 15 + [vp, vp, i32, f32, f32, vp]
             L.vs_conv3x3_split_nhwc.restype = C.c_int
             L.vs_conv3x3_split_nhwc.argtypes = [vp, vp, f32, vp, vp, vp] + [i32] * 8 + [vp]
+            L.vs_conv3x3_split_res2_nhwc.restype = C.c_int
+            L.vs_conv3x3_split_res2_nhwc.argtypes = [vp, vp, f32, vp, vp, vp, vp] + [i32] * 8 + [vp]
             L.vs_conv3x3_head1x1_split_nhwc.restype = C.c_int
             L.vs_conv3x3_head1x1_split_nhwc.argtypes = [vp, vp, f32, vp, vp, f32, vp, vp] + [i32] * 8 + [vp]
             L.vs_conv3x3_head_dot_split_nhwc.restype = C.c_int

@@ -35,6 +35,7 @@ struct ConvArgs {
     float acc_scale;            // split operands: 2^-e of the packed weights (gemm_common.h, kDtSplit)
     float acc_scale2;           // split operands, fused head: 2^-e of the packed w2
     int a_packed;               // split operands: `in` is already the packed (hi, lo) image (ops.split_act; any ReLU applied by its producer)
+    const float *res2;          // f32 activations: a SECOND residual [N,H,W,Cout] added with `res` (the FeatureFusionBlock's x + rcu(skip), dpt_block.py:196-208)
 };
 
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
@@ -112,7 +113,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
     }
     // f32 activations (f32 / split operand classes), interior wave tile: 16-byte residual loads and output stores, straight-line
     if constexpr (is_f32io(BF16)) {
-        if (g.Cout % 4 == 0 && nbase + 64 <= g.Cout && mw0 + 16 * MI <= M && ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(g.res)) & 15) == 0) {
+        if (g.Cout % 4 == 0 && nbase + 64 <= g.Cout && mw0 + 16 * MI <= M &&
+            ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(g.res) | reinterpret_cast<uintptr_t>(g.res2)) & 15) == 0) {
             const float *res32 = reinterpret_cast<const float *>(g.res);
             float *out32 = reinterpret_cast<float *>(g.out);
 #pragma unroll
@@ -132,6 +134,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                         const float rr[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = g.relu_out == 2 ? (rr[r] > 0.f ? v[r] : 0.f) : v[r] + rr[r];
+                    }
+                    if (g.res2) {
+                        const float4 r2 = *reinterpret_cast<const float4 *>(g.res2 + o + j * 16);
+                        v[0] += r2.x; v[1] += r2.y; v[2] += r2.z; v[3] += r2.w;
                     }
                     if (g.relu_out == 1) {
 #pragma unroll
@@ -164,6 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &g, f4 (&acc)[MI][4
                             const float rr = res32[o + j * 16 + r];
                             x = g.relu_out == 2 ? (rr > 0.f ? x : 0.f) : x + rr;
                         }
+                        if (g.res2) x += g.res2[o + j * 16 + r];
                         if (g.relu_out == 1) x = fmaxf(x, 0.0f);
                         v[r] = x;
                     }
@@ -1031,7 +1038,7 @@ upsample2x_backward_kernel(const unsigned short *__restrict__ dout, unsigned sho
 
 static int conv3x3_entry(const void *in, const void *w, const float *bias, const void *residual, void *out, int32_t Nimg,
                          int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu_in, int32_t relu_out,
-                         int32_t dtype, float acc_scale, vs_stream_t stream_) {
+                         int32_t dtype, float acc_scale, vs_stream_t stream_, const float *residual2 = nullptr) {
     const int H = (Hin - 1) / (stride > 0 ? stride : 1) + 1, W = (Win - 1) / (stride > 0 ? stride : 1) + 1;  // k=3, pad=1
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in && w && out, "vs_conv3x3_nhwc: null pointer");
@@ -1050,7 +1057,8 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     relu_in &= ~16;
     VS_CHECK(!in_packed || (dtype == 4 && relu_in == 0), "vs_conv3x3_split_nhwc: a packed input is a split-class operand that carries its ReLU already");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
-               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale, 1.f, in_packed};
+               Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale, 1.f, in_packed, residual2};
+    VS_CHECK(!residual2 || ((dtype == 3 || dtype == 4) && relu_out != 2), "vs_conv3x3_nhwc: a second residual needs f32 activations (dtype 3 / 4) and no mask epilogue");
     const long long M = (long long)Nimg * H * W;
     static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
     int cshift = -1;
@@ -1119,6 +1127,15 @@ extern "C" int vs_conv3x3_split_nhwc(const float *in, const void *wp, float acc_
                                      int32_t relu_out, vs_stream_t stream_) {
     VS_CHECK(acc_scale > 0.f && Cin % 32 == 0, "vs_conv3x3_split_nhwc: acc_scale must be positive and Cin a multiple of 32");
     return conv3x3_entry(in, wp, bias, residual, out, Nimg, Hin, Win, Cin, Cout, stride, relu_in, relu_out, 4, acc_scale, stream_);
+}
+
+// vs_conv3x3_split_nhwc with a SECOND residual: out = conv(in) + bias + residual + residual2 (relu_out applies after both) -- the
+// FeatureFusionBlock's `x + ResidualConvUnit(skip)` (dpt_block.py:196-208) folded into the unit's last convolution.
+extern "C" int vs_conv3x3_split_res2_nhwc(const float *in, const void *wp, float acc_scale, const float *bias, const float *residual,
+                                          const float *residual2, float *out, int32_t Nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout,
+                                          int32_t stride, int32_t relu_in, int32_t relu_out, vs_stream_t stream_) {
+    VS_CHECK(acc_scale > 0.f && Cin % 32 == 0, "vs_conv3x3_split_res2_nhwc: acc_scale must be positive and Cin a multiple of 32");
+    return conv3x3_entry(in, wp, bias, residual, out, Nimg, Hin, Win, Cin, Cout, stride, relu_in, relu_out, 4, acc_scale, stream_, residual2);
 }
 
 /* out2[pixel, 0..C2) = W2 relu_out(conv3x3(in) + bias) + bias2 in ONE kernel (the 3x3 result stays on chip): the last two layers of

@@ -212,14 +212,17 @@ class PixelwiseTaskWithDPT(nn.Module):
         return out.view(*lead, w.shape[0])
 
     @staticmethod
-    def _rcu(x, P, name):
-        """ResidualConvUnit (dpt_block.py:79-142): x + conv2(relu(conv1(relu(x))))."""
+    def _rcu(x, P, name, extra=None):
+        """ResidualConvUnit (dpt_block.py:79-142): x + conv2(relu(conv1(relu(x)))) (+ extra: a second residual added in the same epilogue)."""
         t = ops.conv3x3_nhwc(x, P[name + ".c1.w"], P[name + ".c1.b"], relu_in=True, relu_out=True)
-        return ops.conv3x3_nhwc(t, P[name + ".c2.w"], P[name + ".c2.b"], residual=x)
+        return ops.conv3x3_nhwc(t, P[name + ".c2.w"], P[name + ".c2.b"], residual=x, residual2=extra)
 
     def _fusion(self, P, r, x, skip=None):
         if skip is not None:
-            x = x + self._rcu(skip, P, f"rf{r}.resConfUnit1")
+            if self.split:      # x + rcu(skip): the add rides on the epilogue of the unit's last convolution
+                x = self._rcu(skip, P, f"rf{r}.resConfUnit1", extra=x.contiguous())
+            else:
+                x = x + self._rcu(skip, P, f"rf{r}.resConfUnit1")
         # out_conv (1x1) commutes with the bilinear x2 (both linear, interpolation weights sum to 1): run it on the 4x
         # smaller map, then upsample (dpt_block.py:210-218 upsamples first)
         return ops.upsample2x_nhwc(self._gemm1x1(self._rcu(x, P, f"rf{r}.resConfUnit2"), P, f"rf{r}.out"))

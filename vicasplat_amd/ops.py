@@ -361,7 +361,7 @@ def gaussian_adapter_backward(pts: torch.Tensor, gs: torch.Tensor, sh_mask: torc
 
 def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                  relu_in: bool = False, relu_out: bool = False, out: Optional[torch.Tensor] = None, stride: int = 1,
-                 mask_by: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 mask_by: Optional[torch.Tensor] = None, residual2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [N,H,W,Cin] contiguous 16-bit, w [Cout,3,3,Cin] (see pack_conv3x3_weight) -> [N,Ho,Wo,Cout] (k=3, pad=1).
     mask_by [N,Ho,Wo,Cout]: the result is zeroed where mask_by <= 0 (ReLU backward fused into a data-gradient conv)."""
     if mask_by is not None:
@@ -378,6 +378,14 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     if out is None:
         out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=dev)
     assert residual is None or (residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype)
+    assert residual2 is None or (split and mask_by is None and residual2.shape == out.shape and residual2.is_contiguous() and residual2.dtype == torch.float32)
+    if split and residual2 is not None:      # split class: out = conv + bias + residual + residual2 in the epilogue (no add pass)
+        L.require_device(residual2)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv3x3_split_res2_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(residual), L.ptr(residual2), L.ptr(out), N, H, W,
+                                                    Cin, Cout, stride, int(relu_in), int(relu_out), L.stream_ptr(dev))
+        L.check(rc, "vs_conv3x3_split_res2_nhwc")
+        return out
     if split:
         with torch.cuda.device(dev):
             rc = L.lib().vs_conv3x3_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(residual), L.ptr(out), N, H, W, Cin, Cout,
