@@ -159,6 +159,14 @@ __device__ __forceinline__ uint2 v_rows4(const unsigned short *tile, int row0, i
     return __builtin_bit_cast(uint2, v);
 }
 
+template <int PITCH>
+__device__ __forceinline__ uint2 v_rows4p(const unsigned short *tile, int row0, int col0, int t) {   // v_rows4 on rows of PITCH halves
+    typedef tr4v_t __attribute__((address_space(3))) *trp_t;
+    const unsigned short *p = tile + (row0 + (t >> 2)) * PITCH + col0 + (t & 3) * 4;
+    const tr4v_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned short *>(p)));
+    return __builtin_bit_cast(uint2, v);
+}
+
 // O is accumulated TRANSPOSED (O^T = V^T P^T: the MFMA's operands swapped), so a lane holds its own query's output: registers
 // o[db][r] = O[query][db*16 + g*4 + r].  The running-max rescale and the final 1/l then need no cross-lane traffic, and the row leaves
 // as 16-byte stores: v_permlane16_swap gives an even-g lane 8 consecutive d of block db and an odd-g lane 8 of block db + 1 (the
@@ -516,7 +524,10 @@ template <int QG>
 __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsSplit a) {
     constexpr int QBLK = 64 * QG;
     __shared__ __attribute__((aligned(16))) unsigned short sKh2[2][KB * KROW], sKl2[2][KB * KROW];   // two-tile ring, hi / lo images
-    __shared__ __attribute__((aligned(16))) unsigned short sVh2[2][KB * KROW], sVl2[2][KB * KROW];
+    // V tiles keep the K pitch (144 B).  A 160-byte pitch (the four rows of a transpose read in four disjoint 8-bank windows) was measured:
+    // the bank-conflict counter drops 42 -> 38 %, the stores become 2-way conflicted, the kernel time is unchanged (+-2 %).
+    constexpr int VROW = KROW;
+    __shared__ __attribute__((aligned(16))) unsigned short sVh2[2][KB * VROW], sVl2[2][KB * VROW];
     __shared__ int s_maxlen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
@@ -591,8 +602,8 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
         *reinterpret_cast<uint4 *>(&sKh2[buf][k_key * KROW + k_chunk]) = h0; *reinterpret_cast<uint4 *>(&sKh2[buf][k_key * KROW + k_chunk + 8]) = h1;
         *reinterpret_cast<uint4 *>(&sKl2[buf][k_key * KROW + k_chunk]) = l0; *reinterpret_cast<uint4 *>(&sKl2[buf][k_key * KROW + k_chunk + 8]) = l1;
         split8s(pv[0], pv[1], h0, l0); split8s(pv[2], pv[3], h1, l1);
-        *reinterpret_cast<uint4 *>(&sVh2[buf][k_key * KROW + k_chunk]) = h0; *reinterpret_cast<uint4 *>(&sVh2[buf][k_key * KROW + k_chunk + 8]) = h1;
-        *reinterpret_cast<uint4 *>(&sVl2[buf][k_key * KROW + k_chunk]) = l0; *reinterpret_cast<uint4 *>(&sVl2[buf][k_key * KROW + k_chunk + 8]) = l1;
+        *reinterpret_cast<uint4 *>(&sVh2[buf][k_key * VROW + k_chunk]) = h0; *reinterpret_cast<uint4 *>(&sVh2[buf][k_key * VROW + k_chunk + 8]) = h1;
+        *reinterpret_cast<uint4 *>(&sVl2[buf][k_key * VROW + k_chunk]) = l0; *reinterpret_cast<uint4 *>(&sVl2[buf][k_key * VROW + k_chunk + 8]) = l1;
     };
     if (maxlen > 0) {
         gload(0);
@@ -609,18 +620,24 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
         }
         if (kt >= wave_len) { __syncthreads(); continue; }
         uint4 pfh[QG][2], pfl[QG][2];
+        // S^T for all QG query groups of the wave from ONE read of each K fragment (the LDS pipe is this kernel's busiest unit: PMC, 47 % of
+        // the cycles + 20 % bank conflicts on the 2064-key video attention; re-reading the fragments per group was a third of its reads)
+        f4 stq[QG][4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int u = 0; u < QG; ++u) stq[u][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = (nb * 16 + c16) * KROW + ks * 32 + g * 8;
+                const uint4 kh_ = *reinterpret_cast<const uint4 *>(&sKh[off]), kl_ = *reinterpret_cast<const uint4 *>(&sKl[off]);
+#pragma unroll
+                for (int u = 0; u < QG; ++u) stq[u][nb] = mma3(kh_, kl_, qh[u][ks], ql[u][ks], stq[u][nb]);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
-            f4 st[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                st[nb] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int off = (nb * 16 + c16) * KROW + ks * 32 + g * 8;
-                    st[nb] = mma3(*reinterpret_cast<const uint4 *>(&sKh[off]), *reinterpret_cast<const uint4 *>(&sKl[off]), qh[u][ks], ql[u][ks], st[nb]);
-                }
-            }
+            f4 (&st)[4] = stq[u];
             if (kt + KB > wave_minlen[u]) {
                 const int lim = my_len[u] - kt - g * 4;
 #pragma unroll
@@ -651,8 +668,8 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const uint2 h0 = v_rows4(sVh, (2 * ks) * 16 + g * 4, db * 16, c16), h1 = v_rows4(sVh, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                const uint2 l0 = v_rows4(sVl, (2 * ks) * 16 + g * 4, db * 16, c16), l1 = v_rows4(sVl, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 h0 = v_rows4p<VROW>(sVh, (2 * ks) * 16 + g * 4, db * 16, c16), h1 = v_rows4p<VROW>(sVh, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                const uint2 l0 = v_rows4p<VROW>(sVl, (2 * ks) * 16 + g * 4, db * 16, c16), l1 = v_rows4p<VROW>(sVl, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
 #pragma unroll
                 for (int u = 0; u < QG; ++u) o[u][db] = mma3(vh, vl, pfh[u][ks], pfl[u][ks], o[u][db]);
