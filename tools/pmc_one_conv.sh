@@ -1,0 +1,25 @@
+#!/bin/bash
+# SQ counters of the fused Gaussian-parameter head convolution: bash tools/pmc_one_conv.sh <tag> [frames]
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/pc_$1
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $O/sq1 -o g -- python $R/tools/one_conv.py $2 > $O/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/sq2 -o g -- python $R/tools/one_conv.py $2 > $O/sq2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o g -- python $R/tools/one_conv.py $2 > $O/t.log 2>&1
+python - "$O" <<'PY'
+import collections, csv, glob, sys
+O = sys.argv[1]
+cnt = collections.defaultdict(list)
+for tag in ("sq1", "sq2"):
+    for r in csv.DictReader(open(glob.glob(f"{O}/{tag}/**/*counter_collection.csv", recursive=True)[0])):
+        if "conv3x3_256_kernel" in r["Kernel_Name"]:
+            cnt[r["Counter_Name"]].append(float(r["Counter_Value"]))
+c = {k: sum(v) / len(v) for k, v in cnt.items()}
+dur = next(float(r["TotalDurationNs"]) / int(r["Calls"]) / 1e3 for r in csv.DictReader(open(glob.glob(f"{O}/t/**/*kernel_stats.csv", recursive=True)[0])) if "conv3x3_256_kernel" in r["Name"])
+cyc = c["SQ_BUSY_CYCLES"] / 32
+print(f"{dur:.1f} us/dispatch; clock {cyc / dur / 1e3:.2f} GHz; MFMA busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.1f} %; LDS active {100 * c['SQ_LDS_IDX_ACTIVE'] / (cyc * 256):.1f} % + conflicts {100 * c['SQ_LDS_BANK_CONFLICT'] / (cyc * 256):.1f} % of the kernel's cycles")
+for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+    print(f"  {k:22s} {100 * c[k] / c['SQ_WAVE_CYCLES']:.1f} % of wave cycles")
+PY
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
