@@ -121,7 +121,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     gen = torch.Generator().manual_seed(7 + rank)
     target = torch.rand(B, Vt, 3, 256, 256, generator=gen).to(dev)
     batch = dict(context=dict(image=img.to(dev), intrinsics=K.to(dev)), target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
-    enc.train()
+    enc.train().requires_grad_(True)
     opt, _ = callers.configure_optimizer(enc, lr=1e-12)
     reducer = vdist.GradReducer(enc.parameters()) if world > 1 else None
     torch.cuda.empty_cache()
@@ -145,7 +145,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     # algorithmic FLOPs of the step: 3 407 GFLOP forward per 8-view scene, backward = 2x forward
     flops = 3.0 * 3407e9 * (V / 8.0) * B
     tf_s = flops / (ms * 1e-3) / 1e12
-    enc.eval()
+    enc.eval().requires_grad_(False)
     if reducer is not None:
         reducer.remove()
     for p in enc.parameters():
@@ -262,7 +262,7 @@ def main():
     W = synthetic.golden_weights(shapes, seed=0)
     enc, _ = get_encoder(default_cfg())
     enc.load_state_dict(W, strict=True)
-    enc = enc.to(dev).eval()
+    enc = enc.to(dev).eval().requires_grad_(False)     # inference legs: frozen weights -> the fused no-grad path (train_leg re-enables)
     enc.set_compute_dtype(dt)
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(dev)
     img, K = synthetic.synthetic_input(B, V, 256, seed=rank)

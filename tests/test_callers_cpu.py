@@ -334,3 +334,44 @@ def test_split_class_training_step_defaults_and_operand_geometry():
         halo = (Wp + 2 + 3) // 4 * 4
         shifts = [(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)]
         assert halo % 4 == 0 and halo > max(abs(s) for s in shifts)
+
+
+def test_boundary_grad_scale_leaves_plain_gradients_and_handles_accumulation():
+    """autograd.BoundaryGradScale (the Module API's internal power-of-two gradient scale, VicaSplat.forward under autograd): cotangents
+    enter the network multiplied by S, parameter gradients leave divided by S when the backward pass ends -- bit-identical to an unscaled
+    backward (power of two), also when `.grad` already holds a gradient (micro-batch accumulation) and with unused outputs."""
+    from vicasplat_amd import autograd as A
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4))
+    ref.load_state_dict(net.state_dict())
+    seen = []
+
+    class Spy(torch.autograd.Function):      # sits where the encoder's operators sit: records the size of the cotangent it receives
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(float(g.abs().max()))
+            return g
+
+    sc = A.BoundaryGradScale(list(net.parameters()), 4096.0)
+    for it in range(2):                      # second iteration accumulates onto the first one's gradients
+        x = torch.randn(3, 6)
+        y = Spy.apply(net(x))
+        a, b, unused = sc.outputs(y[:, :2], y[:, 2:], None)
+        assert unused is None and torch.equal(a, y[:, :2])
+        (a.square().sum() + b.sum()).backward()
+        yr = ref(x)
+        (yr[:, :2].square().sum() + yr[:, 2:].sum()).backward()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad), it
+    assert seen[0] >= 4096.0 * 0.99         # the network saw scaled cotangents
+    with pytest.raises(AssertionError):
+        A.BoundaryGradScale(list(net.parameters()), 1000.0)
+    # S = 1: pass-through, no node
+    one = A.BoundaryGradScale(list(net.parameters()), 1.0)
+    t = torch.ones(2, requires_grad=True)
+    assert one.outputs(t)[0] is t

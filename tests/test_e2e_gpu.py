@@ -30,7 +30,7 @@ def _model(dt):
     m, _ = get_encoder(default_cfg())
     W = er.golden_weights(shapes, seed=0)
     m.load_state_dict(W, strict=True)
-    m = m.cuda().eval()
+    m = m.cuda().eval().requires_grad_(False)     # inference: frozen weights -> the fused no-grad path of VicaSplat.forward
     m.set_compute_dtype(dt)
     return m, W
 
@@ -125,7 +125,7 @@ def _hip_on(W, dt, img, K, cams):
     from vicasplat_amd.model.encoder import default_cfg, get_encoder
     m, _ = get_encoder(default_cfg())
     m.load_state_dict(W, strict=True)
-    m = m.cuda().eval()
+    m = m.cuda().eval().requires_grad_(False)     # inference: frozen weights -> the fused no-grad path of VicaSplat.forward
     m.set_compute_dtype(dt)
     return _hip_chain(m, img, K, *cams)
 

@@ -29,7 +29,7 @@ def _model(kind, dt=torch.float16):
     m, _ = get_encoder(default_cfg(**over))
     W = er.golden_weights(shapes, seed=0)
     missing = m.load_state_dict(W, strict=True)
-    m = m.cuda().eval()
+    m = m.cuda().eval().requires_grad_(False)     # inference: frozen weights -> the fused no-grad path of VicaSplat.forward
     m.set_compute_dtype(dt)
     return m
 

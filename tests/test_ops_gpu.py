@@ -655,7 +655,7 @@ def test_gaussian_adapter_function_matches_autograd(dt, act, exponent):
         gs[..., 1:4] *= 3                       # some scales past the clamp / softplus knee
     mask = torch.linspace(1.0, 0.1, nsh, device=d)
     smin, smax = 0.5, 15.0
-    means, cov, sh, op, raw = A.gaussian_adapter(pts, gs, mask, scale_act=act, scale_min=smin, scale_max=smax, opacity_exponent=exponent)
+    means, cov, sh, op, raw, scales_o, rot_o = A.gaussian_adapter(pts, gs, mask, scale_act=act, scale_min=smin, scale_max=smax, opacity_exponent=exponent)
 
     pr, gr = pts.detach().float().requires_grad_(), gs.detach().float().requires_grad_()
     xyz = pr[..., :3]
@@ -695,6 +695,14 @@ def test_gaussian_adapter_function_matches_autograd(dt, act, exponent):
     g2 = torch.autograd.grad((cov * ws[1]).sum(), gs, retain_graph=True)[0]
     r2 = torch.autograd.grad((cov_r * ws[1]).sum(), gr, retain_graph=True)[0]
     assert (g2.float() - r2).abs().max() <= tol * r2.abs().max() + 1e-6
+    # scales / rotations (the reference's Gaussians carry them, gaussian_adapter.py:150-155): values, and gradients when a loss reads them
+    assert (scales_o - sc.detach()).abs().max() <= 2e-5 * sc.detach().abs().max() + 1e-7
+    assert (rot_o - rot.detach()).abs().max() <= 2e-5
+    w_s, w_r = torch.randn_like(sc), torch.randn_like(rot)
+    g3 = torch.autograd.grad((scales_o * w_s).sum() + (rot_o * w_r).sum() + (op * ws[3]).sum(), gs, retain_graph=True)[0]
+    r3 = torch.autograd.grad((sc * w_s).sum() + (rot * w_r).sum() + (o * ws[3]).sum(), gr, retain_graph=True)[0]
+    for name, sl in (("opacity", slice(0, 1)), ("scales", slice(1, 4)), ("rotation", slice(4, 8))):
+        assert (g3.float()[..., sl] - r3[..., sl]).abs().max() <= tol * r3[..., sl].abs().max() + 1e-6, name
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

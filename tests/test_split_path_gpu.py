@@ -361,7 +361,7 @@ def _model(kind):
     m, _ = get_encoder(default_cfg(**(TINY if kind == "tiny" else {})))
     W = er.golden_weights(shapes, seed=0)
     m.load_state_dict(W, strict=True)
-    m = m.cuda().eval()
+    m = m.cuda().eval().requires_grad_(False)     # inference: frozen weights -> the fused no-grad path of VicaSplat.forward
     m.set_compute_dtype("split")
     return m, W
 

@@ -444,3 +444,104 @@ def test_encoder_block_backward_tight_against_rounding_matched_autograd():
     print("rounding-matched block: forward", f"{e_fwd:.2e}", {k_: f"{v_:.2e}" for k_, v_ in errs.items()})
     assert e_fwd <= 5e-4
     assert max(errs.values()) <= 1.5e-3, errs          # measured 2e-4 .. 5.4e-4
+
+
+@pytest.mark.parametrize("cdt", ["split", "f16"])
+def test_module_api_trains_like_the_reference_wrapper(cdt):
+    """SURVEY 8(b) / VERDICT r3 item 1: the reference's ModelWrapper.training_step calls the encoder MODULE under autograd
+    (model_wrapper.py:207-230): `out = self.encoder(batch["context"], self.global_step)`, `self.decoder.forward(out["gaussians"], ...)`,
+    the losses, `.backward()` -- no loss scale, plain `.grad`s.  The same sequence here must (1) return the dict of the fused inference
+    path (same keys, same values to the class's rounding), (2) leave in `.grad` what the explicit training forward produces for fixed
+    cotangents on the encoder's outputs, and (3) end to end (through the rasterizer backward) agree with callers.training_step's
+    gradients -- both to the run-to-run spread measured in the same test (the LayerNorm-backward column sums, the cross-neighbour dK / dV
+    and the rasterizer backward accumulate with f32 atomics, so two runs of the SAME code differ in the last bits; the internal gradient
+    scale itself is exact, a power of two: tests/test_callers_cpu.py checks that part bit for bit)."""
+    import bench
+    from vicasplat_amd import callers
+    from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    dt = torch.float16 if cdt == "f16" else "split"
+    m, _ = _tiny_model(dt)
+    d = torch.device("cuda:0")
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
+    B, V, Vt, S = 1, 2, 2, 64
+    img, K = er.synthetic_input(B, V, S, 3)
+    tE, tK, tn, tf = bench.target_cameras(B, Vt, d)
+    target = torch.rand(B, Vt, 3, S, S, generator=torch.Generator().manual_seed(5)).to(d)
+    E = torch.eye(4).repeat(B, V, 1, 1)
+    E[:, :, 0, 3] = 0.1 * torch.arange(V)[None]
+    ctx = dict(image=img.to(d), intrinsics=K.to(d), extrinsics=E.to(d))
+    batch = dict(context=ctx, target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
+    names = [n for n, _ in m.named_parameters()]
+    grads = lambda: {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}
+
+    # ---- (1) same dict as the fused inference path ----
+    with torch.no_grad():
+        ref_out = m(ctx, 0)
+    out = m(ctx, 0)
+    assert set(out) == set(ref_out) and out["pred_extrins"].requires_grad and out["gaussians"].means.requires_grad
+    tol = 2e-5 if cdt == "split" else 2e-2
+    for k in ("pred_extrins", "raw_gaussians", "gaussian_camera_extrins", "gaussian_centers", "context_view_depths"):
+        a, b = out[k].detach().float(), ref_out[k].float()
+        assert a.shape == b.shape and float((a - b).abs().max() / (b.abs().max() + 1e-12)) <= tol, k
+    for k in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
+        a, b = getattr(out["gaussians"], k).detach(), getattr(ref_out["gaussians"], k)
+        assert a.shape == b.shape and float((a - b).abs().max() / (b.abs().max() + 1e-12)) <= tol, k
+
+    # ---- (2) encoder half: fixed cotangents on the encoder outputs, Module API vs the explicit training forward ----
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-20))
+    gen = torch.Generator().manual_seed(11)
+    g = out["gaussians"]
+    cots = [(torch.randn(t.shape, generator=gen) * 1e-3).to(d) for t in (g.means, g.covariances, g.harmonics, g.opacities, out["pred_extrins"])]
+
+    def module_backward():
+        m.zero_grad(set_to_none=True)
+        mo = m(ctx, 0)
+        gm = mo["gaussians"]
+        torch.autograd.backward([gm.means, gm.covariances, gm.harmonics, gm.opacities, mo["pred_extrins"]], cots)
+        return grads()
+    ga, ga2 = module_backward(), module_backward()
+    S_ = m._boundary_scaler.scale
+    assert S_ == (8192.0 if cdt == "split" else 1024.0)
+    m.zero_grad(set_to_none=True)
+    o = forward_train(m, ctx["image"], ctx["intrinsics"], dt, global_step=0)
+    gg = o["gaussians"]
+    outs2 = [gg["means"], gg["covariances"], gg["harmonics"], gg["opacities"].unsqueeze(-1), o["pred_extrins"]]
+    torch.autograd.backward(outs2, [c * S_ for c in cots])
+    gb = grads()
+    n_grad = sum(int(ga[n] is not None) for n in names)
+    assert all((ga[n] is None) == (gb[n] is None) for n in names)
+    assert n_grad >= len(names) - 16          # only scratch.refinenet4.resConfUnit1 of both heads is unreachable
+    spread_e = max(rel(ga[n], ga2[n]) for n in names if ga[n] is not None)
+    worst_e = max(rel(gb[n] / S_, ga[n]) for n in names if ga[n] is not None)
+    print(cdt, "encoder half: run-to-run spread %.2e  module API vs forward_train %.2e" % (spread_e, worst_e))
+    # f16 class: a last-bit difference of an f32 atomic sum occasionally flips the f16 rounding of one activation gradient (5e-4 of that
+    # element), which the layers behind it spread -- measured with tools/dbg/module_api_diff.py: identical call sequences land 1.5e-3 ..
+    # 2.5e-3 apart in the max norm, in a few discrete states; the split class keeps f32 gradients and stays at 1e-6
+    floor = 1e-2 if cdt == "f16" else 1e-5
+    assert worst_e <= max(4 * spread_e, floor), (worst_e, spread_e)
+
+    # ---- (3) end to end, exactly the wrapper's sequence vs callers.training_step ----
+    def wrapper_step():
+        m.zero_grad(set_to_none=True)
+        mo = m(batch["context"], 0)
+        rp = dec.forward(mo["gaussians"], tE, tK, tn, tf, (S, S), depth_mode=None)
+        loss = ((rp.color - target) ** 2).mean() + callers.camera_loss(mo["pred_extrins"], ctx["extrinsics"].float(), 1.0)
+        loss.backward()
+        return float(loss.detach()), grads()
+    l1, g1 = wrapper_step()
+    l2, g2 = wrapper_step()
+    opt, _ = callers.configure_optimizer(m, lr=0.0)           # lr 0: the step leaves the weights alone; clip off: grads = unscaled gradients
+    r = callers.training_step(m, dec, batch, opt, compute_dtype=dt, clip=1e30, camera_weight=1.0)
+    g3 = grads()
+    assert not r["skipped"] and abs(float(r["loss"]) - l1) <= 1e-6 * max(1.0, abs(l1)) and abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1))
+    spread = max(rel(g1[n], g2[n]) for n in names if g1[n] is not None)
+    worst = max(rel(g3[n], g1[n]) for n in names if g1[n] is not None)
+    print(cdt, "loss %.6f run-to-run spread %.2e  wrapper vs training_step %.2e" % (l1, spread, worst))
+    assert all((g1[n] is None) == (g3[n] is None) for n in names)
+    assert worst <= max(4 * spread, floor), (worst, spread)
+    # an output no loss reads stays out of the backward pass: without a camera loss the pose head gets no gradient (None, as in the reference)
+    m.zero_grad(set_to_none=True)
+    mo = m(batch["context"], 0)
+    ((dec.forward(mo["gaussians"], tE, tK, tn, tf, (S, S)).color - target) ** 2).mean().backward()
+    assert m.camera_extrinsic_head[1].weight.grad is None and m.backbone.camera_extrinsic_token.grad is not None

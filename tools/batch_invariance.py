@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 dts = sys.argv[2:] or ["split", "f32", "f16"]
 d = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "shapes_full.json")))
-enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval()
+enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval().requires_grad_(False)
 img, K = synthetic.synthetic_input(B, 8, 256, 0)
 img, K = img.to(d), K.to(d)
 for dt in dts:

@@ -7,7 +7,7 @@ d = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "shapes_full.json")))
 synthetic._COND_CALIB = None      # measure WITHOUT the conditioned calibration
 W = synthetic.conditioned_weights(shapes, 0)
-enc, _ = get_encoder(default_cfg()); enc.load_state_dict(W, strict=True); enc = enc.to(d).eval(); enc.set_compute_dtype("f32")
+enc, _ = get_encoder(default_cfg()); enc.load_state_dict(W, strict=True); enc = enc.to(d).eval().requires_grad_(False); enc.set_compute_dtype("f32")
 for V in (8, 2):
     img, K = synthetic.smooth_input(1, V, 256, 0)
     o = enc(dict(image=img.to(d), intrinsics=K.to(d)), compute_viewspace_depth=False)

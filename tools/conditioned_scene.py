@@ -14,7 +14,7 @@ shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "
 V, Vt = 2, 3
 for name, W, (img, K) in (("plain", synthetic.golden_weights(shapes, 0), synthetic.synthetic_input(1, V, 256, 0)),
                           ("conditioned", synthetic.conditioned_weights(shapes, 0, *a), synthetic.smooth_input(1, V, 256, 0))):
-    enc, _ = get_encoder(default_cfg()); enc.load_state_dict(W, strict=True); enc = enc.to(d).eval()
+    enc, _ = get_encoder(default_cfg()); enc.load_state_dict(W, strict=True); enc = enc.to(d).eval().requires_grad_(False)
     E = torch.eye(4, device=d).repeat(Vt, 1, 1); E[:, 0, 3] = torch.arange(Vt, device=d) * 0.05
     Kt = torch.tensor([[0.9, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1.0]], device=d).repeat(Vt, 1, 1)
     near, far = torch.full((Vt,), 0.01, device=d), torch.full((Vt,), 100.0, device=d)

@@ -24,7 +24,7 @@ dev = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "shapes_full.json")))
 enc, _ = get_encoder(default_cfg())
 enc.load_state_dict(synthetic.golden_weights(shapes, seed=0), strict=True)
-enc = enc.to(dev).eval(); enc.set_compute_dtype(os.environ.get('VS_DTYPE', 'split'))
+enc = enc.to(dev).eval().requires_grad_(False); enc.set_compute_dtype(os.environ.get('VS_DTYPE', 'split'))
 img, K = synthetic.synthetic_input(scenes, 8, 256, seed=0)
 ctx = dict(image=img.to(dev), intrinsics=K.to(dev))
 def step():

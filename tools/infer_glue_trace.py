@@ -12,7 +12,7 @@ import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 d = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "shapes_full.json")))
-enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval(); enc.set_compute_dtype(os.environ.get("VS_DTYPE", "split"))
+enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval().requires_grad_(False); enc.set_compute_dtype(os.environ.get("VS_DTYPE", "split"))
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
 img, K = synthetic.synthetic_input(B, 8, 256, 0)
 ctx = dict(image=img.to(d), intrinsics=K.to(d))

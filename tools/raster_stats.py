@@ -9,7 +9,7 @@ import bench
 
 dev = torch.device("cuda:0")
 shapes = json.load(open("tests/golden/shapes_full.json"))
-enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(dev).eval()
+enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(dev).eval().requires_grad_(False)
 B, V, Vt = 2, 8, 12
 img, K = synthetic.synthetic_input(B, V, 256, 0)
 out = enc(dict(image=img.to(dev), intrinsics=K.to(dev)), compute_viewspace_depth=False)

@@ -11,7 +11,7 @@ from vicasplat_amd.model.types import Gaussians
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 d = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "shapes_full.json")))
-enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval(); enc.set_compute_dtype(torch.float16)
+enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval().requires_grad_(False); enc.set_compute_dtype(torch.float16)
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
 img, K = synthetic.synthetic_input(B, 8, 256, 0)
 tE, tK, tn, tf = bench.target_cameras(B, 12, d)

@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 dA, dB = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("split", "f32")
 d = torch.device("cuda:0")
 shapes = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "shapes_full.json")))
-enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval()
+enc, _ = get_encoder(default_cfg()); enc.load_state_dict(synthetic.golden_weights(shapes, 0), strict=True); enc = enc.to(d).eval().requires_grad_(False)
 img, K = synthetic.synthetic_input(B, 8, 256, 0)
 ctx = dict(image=img.to(d), intrinsics=K.to(d))
 NAMES = ["gemm", "gemm_qkv_rope", "attention", "layernorm_mod", "conv3x3_nhwc", "upsample2x_nhwc", "silu_cast", "linear_f32", "gaussian_adapter"]

@@ -18,6 +18,64 @@ from . import ops
 SPLIT = "split"      # compute-dtype tag of the split operand class: f32 tensors, three f16 MFMAs per product (csrc/gemm_common.h kDtSplit)
 
 
+class BoundaryGradScale:
+    """Internal power-of-two gradient scale of the Module API under autograd (VicaSplat.forward with grad enabled).
+
+    The reference trains in fp32 (model_wrapper.py:184-321, trainer precision 32): `loss.backward()` with no loss scale.  Here the MFMA
+    operands of the backward are 16-bit (f16 class) or f16 (hi, lo) pairs (split class), so gradients must sit in f16's range while they
+    pass through the encoder.  `outputs(...)` multiplies the COTANGENTS of the encoder's outputs by S = 2^k on their way in (exact);
+    parameter gradients therefore accumulate in units of S; when the backward pass ends (autograd engine callback) every parameter
+    gradient is multiplied by 1/S (exact), so the caller observes plain unscaled `.grad`s as from the reference.  Gradients that were
+    already in `.grad` before this backward (accumulation over micro-batches) are lifted by S first, so the sum stays consistent.  The
+    callback re-queues itself once so that it runs after DDP's own end-of-backward callback (the bucket all-reduce runs on scaled values:
+    exact for a power of two).  S = 1 disables all of it."""
+
+    def __init__(self, params, scale: float):
+        self.params, self.scale = [p for p in params if p.requires_grad], float(scale)
+        m, e = __import__("math").frexp(self.scale)
+        assert self.scale >= 1.0 and m == 0.5, "the boundary gradient scale must be a power of two"
+        self._armed = False
+
+    def _begin(self):
+        if self._armed:
+            return
+        self._armed = True
+        old = [p.grad for p in self.params if p.grad is not None]
+        if old:
+            torch._foreach_mul_(old, self.scale)
+        torch.autograd.Variable._execution_engine.queue_callback(self._requeue)
+
+    def _requeue(self):
+        torch.autograd.Variable._execution_engine.queue_callback(self._end)
+
+    def _end(self):
+        self._armed = False
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if grads:
+            with torch.no_grad():
+                torch._foreach_mul_(grads, 1.0 / self.scale)
+
+    def outputs(self, *tensors):
+        """Identity on the values; cotangents x S (None stays None).  One autograd node PER tensor: an output no loss reads (the poses
+        without a camera loss, raw_gaussians, scales / rotations) then never enters the backward pass -- a shared node would hand its
+        producers materialised zero cotangents, i.e. zero `.grad`s where the reference leaves None."""
+        if self.scale == 1.0:
+            return tensors
+        return tuple(None if t is None else _BoundaryScaleFn.apply(self, t) for t in tensors)
+
+
+class _BoundaryScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaler, t):
+        ctx.scaler = scaler
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.scaler._begin()
+        return None, g * ctx.scaler.scale
+
+
 def act_dtype(dt):
     """torch dtype of the activations of operand class `dt`."""
     return torch.float32 if dt == SPLIT else dt
@@ -457,8 +515,11 @@ def gated_resid(x, y, gate=None, gate_rows=0, grp_in=0, grp_out=0, grp_off=0):
 class GaussianAdapterFn(torch.autograd.Function):
     """'exp' depth post-process + raw_gaussians concat + MyGaussianAdapter (heads/postprocess.py:46-56, vicasplat.py:256,
     common/gaussian_adapter.py:168-212) on the fused HIP kernel in both directions.  pts [N,H,W,>=3], gs [N,H,W,8+3*d_sh]: the
-    heads' 16-bit NHWC outputs -> (means [N,H,W,3], covariances [N,H,W,3,3], harmonics [N,H,W,3,d_sh], opacities [N,H,W], raw
-    [N,H,W,11+3*d_sh]), all f32."""
+    heads' NHWC outputs -> (means [N,H,W,3], covariances [N,H,W,3,3], harmonics [N,H,W,3,d_sh], opacities [N,H,W], raw
+    [N,H,W,11+3*d_sh], scales [N,H,W,3], rotations [N,H,W,4]), all f32.  `scales` / `rotations` (the reference's Gaussians carry them,
+    gaussian_adapter.py:150-155; only exports and regularisers read them) are differentiable too: their cotangents, when some loss
+    uses them, are folded into d_raw with the activation's derivative (a few element-wise torch ops on 7 channels; nothing runs when
+    they are unused)."""
 
     @staticmethod
     def forward(ctx, pts, gs, sh_mask, scale_act, scale_min, scale_max, opacity_exponent):
@@ -468,15 +529,31 @@ class GaussianAdapterFn(torch.autograd.Function):
                                  scale_max=scale_max, opacity_exponent=opacity_exponent)
         ctx.save_for_backward(pts, gs, mask)
         ctx.meta = (scale_act, scale_min, scale_max, opacity_exponent)
-        return o["means"], o["covariances"], o["harmonics"], o["opacities"][..., 0], o["raw"]
+        ctx.set_materialize_grads(False)      # unused outputs arrive as None (raw alone is 4.3 GB of zeros at 24 scenes otherwise)
+        return o["means"], o["covariances"], o["harmonics"], o["opacities"][..., 0], o["raw"], o["scales"], o["rotations"]
 
     @staticmethod
-    def backward(ctx, d_means, d_cov, d_harm, d_op, d_raw):
+    def backward(ctx, d_means, d_cov, d_harm, d_op, d_raw, d_scales=None, d_rot=None):
         pts, gs, mask = ctx.saved_tensors
         scale_act, scale_min, scale_max, opacity_exponent = ctx.meta
         z = lambda g, ref_shape: torch.zeros(ref_shape, dtype=torch.float32, device=pts.device) if g is None else g
         N, H, W = gs.shape[:3]
         d_sh = (gs.shape[-1] - 8) // 3
+        if d_scales is not None or d_rot is not None:     # raw[..., 4:7] / raw[..., 7:11] are the pre-activation scales / quaternion
+            import torch.nn.functional as F
+            with torch.enable_grad():
+                pre = gs[..., 1:8].detach().float().requires_grad_(True)
+                s = pre[..., :3]
+                if scale_act == "bounded":
+                    s = scale_min + (scale_max - scale_min) * s.sigmoid()
+                elif scale_act == "exp":
+                    s = s.exp().clamp_max(0.3)
+                else:
+                    s = (0.001 * F.softplus(s)).clamp_max(0.3)
+                r = F.normalize(pre[..., 3:], dim=-1)
+                (g7,) = torch.autograd.grad([s, r], [pre], [z(d_scales, s.shape), z(d_rot, r.shape)])
+            d_raw = z(d_raw, (N, H, W, 11 + 3 * d_sh)).clone()
+            d_raw[..., 4:11] += g7
         d_pts, d_gs = ops.gaussian_adapter_backward(pts, gs, mask, z(d_means, (N, H, W, 3)), z(d_cov, (N, H, W, 3, 3)),
                                                     z(d_harm, (N, H, W, 3, d_sh)), z(d_op, (N, H, W)), d_raw, scale_act=scale_act,
                                                     scale_min=scale_min, scale_max=scale_max, opacity_exponent=opacity_exponent)

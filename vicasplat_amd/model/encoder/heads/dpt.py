@@ -9,37 +9,34 @@ activations; the 7x7 RGB stem conv is a window GEMM on the same main loop (`vs_c
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F      # F.pad / F.unfold of the exact-f32 class's im2col stem only -- no torch convolution / interpolation anywhere
 from torch import nn
 
 from .... import ops
 
 
-def _up2(x):
-    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+def _no_torch_forward(self, *a, **k):
+    raise RuntimeError(f"{type(self).__name__} is a PARAMETER CONTAINER (the reference's state_dict names): the computation runs on the HIP "
+                       "kernels driven by PixelwiseTaskWithDPT -- there is no PyTorch / MIOpen forward in vicasplat_amd")
 
 
-class _RCU(nn.Module):
+class _RCU(nn.Module):      # ResidualConvUnit_custom (dpt_block.py:79-150): parameters only
+    forward = _no_torch_forward
+
     def __init__(self, c: int):
         super().__init__()
         self.conv1 = nn.Conv2d(c, c, 3, 1, 1, bias=True)
         self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=True)
 
-    def forward(self, x):
-        return self.conv2(F.relu(self.conv1(F.relu(x)))) + x
 
+class _Fusion(nn.Module):   # FeatureFusionBlock_custom (dpt_block.py:153-218): parameters only
+    forward = _no_torch_forward
 
-class _Fusion(nn.Module):
     def __init__(self, c: int):
         super().__init__()
         self.out_conv = nn.Conv2d(c, c, 1, bias=True)
         self.resConfUnit1 = _RCU(c)
         self.resConfUnit2 = _RCU(c)
-
-    def forward(self, x, skip=None):
-        if skip is not None:
-            x = x + self.resConfUnit1(skip)
-        return self.out_conv(_up2(self.resConfUnit2(x)))
 
 
 class _Scratch(nn.Module):
@@ -57,7 +54,9 @@ class _Scratch(nn.Module):
         self.refinenet4 = _Fusion(feat)
 
 
-class _DPT(nn.Module):
+class _DPT(nn.Module):      # DPTOutputAdapter / its GS variant (dpt_block.py:264-419, dpt_gs_head.py:98-157): parameters only
+    forward = _no_torch_forward
+
     def __init__(self, dim_tokens, hooks, num_channels: int, head_type: str, feat: int = 256, layer_dims=(96, 192, 384, 768)):
         super().__init__()
         self.hooks, self.head_type = list(hooks), head_type
@@ -76,18 +75,6 @@ class _DPT(nn.Module):
             self.head = nn.Sequential(nn.Conv2d(feat, feat, 3, padding=1, bias=False), nn.Identity(), nn.ReLU(True),
                                       nn.Dropout(0.1, False), nn.Conv2d(feat, num_channels, 1))
             self.input_merger = nn.Sequential(nn.Conv2d(3, feat, 7, 1, 3), nn.ReLU())
-
-    def trunk(self, tokens, gh: int, gw: int):
-        maps = []
-        for idx, hk in enumerate(self.hooks):
-            t = tokens[hk]  # [BT, n, C] 16-bit
-            m = t.transpose(1, 2).reshape(t.shape[0], t.shape[2], gh, gw).contiguous(memory_format=torch.channels_last)
-            maps.append(self.scratch.layer_rn[idx](self.act_postprocess[idx](m)))
-        s = self.scratch
-        p4 = s.refinenet4(maps[3])[:, :, :maps[2].shape[2], :maps[2].shape[3]]
-        p3 = s.refinenet3(p4, maps[2])
-        p2 = s.refinenet2(p3, maps[1])
-        return s.refinenet1(p2, maps[0])
 
 
 def _pad_to(n: int, m: int = 64) -> int:

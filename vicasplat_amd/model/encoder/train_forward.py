@@ -29,11 +29,19 @@ def _lin_f32(P, name, x):
     return A.linear_split(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
-def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch.float16, global_step: int = 0) -> dict:
+def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch.float16, global_step: int = 0,
+                  distill: bool = False) -> dict:
     """image [B,V,3,H,W] normalised to [-1,1], intrinsics [B,V,3,3] -> dict(raw_gaussians [B,V,H,W,86] f32, pred_extrins
-    [B,V-1,8], gaussian_camera_extrins [B,V,4,4], gaussians {means, covariances, harmonics, opacities}).
+    [B,V-1,8], gaussians {means, covariances, harmonics, opacities, scales, rotations}, gaussian_centers, camera_tokens, pred_intrins).
     dt: torch.float16 / torch.bfloat16 (16-bit operands and activations) or "split" -- the reference-precision class: f32 activations
-    and gradients, every product three f16 MFMAs on (hi, lo) pairs, forward AND backward (autograd.SPLIT)."""
+    and gradients, every product three f16 MFMAs on (hi, lo) pairs, forward AND backward (autograd.SPLIT).
+    distill: the distillation-only phase of the reference (vicasplat.py:234-243) needs the centres and the poses only -- the
+    Gaussian-parameter head and the adapter are skipped (`gaussian_centers` = post-processed pts3d, no `gaussians`).
+    The exact-f32 MFMA class (torch.float32) has no backward kernels: it is rejected here instead of silently mixing operand classes
+    (the convolution / attention Functions dispatch f32 tensors to the split kernels)."""
+    if dt in (torch.float32, "f32", "f32x"):
+        raise NotImplementedError('the exact-f32 operand class is inference-only; train in "split" (f32 activations and gradients, '
+                                  'f32-class products), torch.float16 or torch.bfloat16')
     P = dict(model.named_parameters())
     adt = A.act_dtype(dt)                 # dtype of the activations between the operators
     cfg = model.backbone.config
@@ -194,6 +202,15 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"], relu_out=True)
     pts16 = conv1x1(pre + ".head.4", t)                                                              # [BT,H,W,4] 16-bit: xyz | confidence
 
+    pred_intrins = None
+    if not use_intr:
+        pred_intrins = _lin_f32(P, "camera_intrinsic_head.1", F.relu(cam[:, 0]))                      # fov head (vicasplat.py:201-205)
+    if distill:      # 'exp' post-process of the centres in torch (postprocess.py:46-56): xyz * expm1(|xyz|) / |xyz|
+        xyz = pts16[..., :3].float()
+        nrm = xyz.norm(dim=-1, keepdim=True)
+        centers = (xyz / nrm.clamp(min=1e-8) * torch.expm1(nrm)).unflatten(0, (B, V))
+        return dict(pred_extrins=d, gaussian_centers=centers, camera_tokens=cam, pred_intrins=pred_intrins)
+
     pre = "gaussian_param_head.dpt"
     t = A.upsample2x_add_relu(trunk(pre), stem7x7(pre + ".input_merger.0", frames))             # up2(trunk) + relu(stem), one launch
     t = A.conv3x3(t, P[pre + ".head.0.weight"], None, relu_out=True)
@@ -204,12 +221,10 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     ga = model.gaussian_adapter
     c = model.cfg.opacity_mapping
     exponent = -1.0 if model.cfg.predict_opacity else 2 ** (c.initial + min(global_step / c.warm_up, 1) * (c.final - c.initial))
-    means, cov, sh, op, raw = A.gaussian_adapter(pts16, gs16, ga.sh_mask, scale_act=ga.cfg.scale_act, scale_min=ga.cfg.gaussian_scale_min,
+    means, cov, sh, op, raw, scales, rot = A.gaussian_adapter(pts16, gs16, ga.sh_mask, scale_act=ga.cfg.scale_act, scale_min=ga.cfg.gaussian_scale_min,
                                                  scale_max=ga.cfg.gaussian_scale_max, opacity_exponent=float(exponent))
     un = lambda u: u.unflatten(0, (B, V))
     raw = un(raw)
-    gaussians = dict(means=un(means), covariances=un(cov), harmonics=un(sh), opacities=un(op))
-    pred_intrins = None
-    if not use_intr:
-        pred_intrins = _lin_f32(P, "camera_intrinsic_head.1", F.relu(cam[:, 0]))                      # fov head (vicasplat.py:201-205)
-    return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, camera_tokens=cam, pred_intrins=pred_intrins)
+    gaussians = dict(means=un(means), covariances=un(cov), harmonics=un(sh), opacities=un(op), scales=un(scales), rotations=un(rot))
+    return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, gaussian_centers=gaussians["means"], camera_tokens=cam,
+                pred_intrins=pred_intrins)

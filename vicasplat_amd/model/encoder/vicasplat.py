@@ -116,12 +116,74 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         exponent = 2 ** (c.initial + min(global_step / c.warm_up, 1) * (c.final - c.initial))
         return 0.5 * (1 - (1 - pdf) ** exponent + pdf ** (1 / exponent))
 
-    @torch.no_grad()
+    # Internal power-of-two gradient scale of the differentiable forward per operand class (autograd.BoundaryGradScale): the caller sees
+    # unscaled gradients, as from the reference's fp32 training.  `encoder.grad_scale = 1.0` turns it off (e.g. when the caller runs its
+    # own loss scaling, as callers.training_step does through forward_train).
+    grad_scale: Optional[float] = None
+    _DEFAULT_GRAD_SCALE = {"split": 8192.0, torch.float16: 1024.0, torch.bfloat16: 1.0}
+
+    def train_compute_class(self):
+        """Operand class of the differentiable forward: "split" | torch.float16 | torch.bfloat16 (from set_compute_dtype)."""
+        if self.backbone.split:
+            return "split"
+        return self.backbone.compute_dtype
+
     def forward(self, context: dict, global_step: int = 0, visualization_dump: Optional[dict] = None, distill: bool = False,
                 compute_viewspace_depth: bool = True, **kwargs) -> dict:
+        """The reference's module call (vicasplat.py:158-278).  Under autograd -- grad mode on and a parameter (or the input image) requires
+        grad, i.e. exactly how ModelWrapper.training_step calls it (model_wrapper.py:207) -- the differentiable HIP forward runs
+        (train_forward.forward_train: every operator on the hand-written kernels in both directions) and `loss.backward()` leaves plain
+        gradients in `.grad`; otherwise (torch.no_grad() / eval with frozen weights) the fused, buffer-reusing inference path runs.  Both
+        return the same dict."""
         image = context["image"]
         if not image.is_cuda:
             raise RuntimeError("VicaSplat.forward needs HIP device tensors: vicasplat_amd has no CPU fallback path")
+        if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(context, global_step, visualization_dump, distill, compute_viewspace_depth)
+        with torch.no_grad():
+            return self._forward_fused(context, global_step, visualization_dump, distill, compute_viewspace_depth)
+
+    def _forward_autograd(self, context, global_step, visualization_dump, distill, compute_viewspace_depth) -> dict:
+        from ... import autograd as A
+        from .train_forward import forward_train
+        image = context["image"]
+        B, T = image.shape[:2]
+        cls = self.train_compute_class()
+        o = forward_train(self, image, context.get("intrinsics", None), cls, global_step=global_step, distill=distill)
+        S = self.grad_scale if self.grad_scale is not None else self._DEFAULT_GRAD_SCALE[cls]
+        sc = getattr(self, "_boundary_scaler", None)
+        if sc is None or sc.scale != S:
+            sc = self._boundary_scaler = A.BoundaryGradScale(list(self.parameters()), S)
+        g = o.get("gaussians")
+        names = ("means", "covariances", "harmonics", "opacities", "scales", "rotations")
+        outs = sc.outputs(o["pred_extrins"], o["pred_intrins"], o.get("raw_gaussians"), o["gaussian_centers"] if distill else None,
+                          *([g[k] for k in names] if g is not None else []))
+        pred_extrins, pred_intrins, raw_gaussians, centers = outs[:4]
+        dev = image.device
+        eye = torch.eye(4, device=dev, dtype=pred_extrins.dtype).expand(B, 1, 4, 4)
+        pred_extrinsics_4x4 = torch.cat([eye, camera_matrix_from_dq_array(pred_extrins)], dim=1)
+        pred_K = None
+        if pred_intrins is not None:     # fov head -> pinhole K (vicasplat.py:201-205, cam_utils.py:220-234), differentiable
+            fx, fy = 0.5 / torch.tan(pred_intrins[:, 0] * 0.5), 0.5 / torch.tan(pred_intrins[:, 1] * 0.5)
+            zero, one, half = torch.zeros_like(fx), torch.ones_like(fx), torch.full_like(fx, 0.5)
+            pred_K = torch.stack([fx, zero, half, zero, fy, half, zero, zero, one], -1).view(B, 1, 3, 3).repeat(1, T, 1, 1)
+        if distill:
+            return dict(pred_extrins=pred_extrins, pred_intrins=pred_intrins, gaussian_camera_extrins=pred_extrinsics_4x4,
+                        gaussian_camera_intrins=pred_K, gaussian_centers=centers, confidence=None,
+                        context_view_depths=self._viewspace_depth(context, centers) if compute_viewspace_depth else None)
+        gv = dict(zip(names, outs[4:]))
+        gaussians = Gaussians(means=gv["means"], covariances=gv["covariances"], harmonics=gv["harmonics"],
+                              opacities=gv["opacities"].unsqueeze(-1), scales=gv["scales"], rotations=gv["rotations"])
+        if visualization_dump is not None:
+            visualization_dump["depth"] = gaussians.means[..., -1:]
+        return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=pred_intrins, raw_gaussians=raw_gaussians,
+                    gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=pred_K, gaussian_centers=gaussians.means,
+                    confidence=None,
+                    context_view_depths=self._viewspace_depth(context, gaussians.means) if compute_viewspace_depth else None)
+
+    def _forward_fused(self, context: dict, global_step: int = 0, visualization_dump: Optional[dict] = None, distill: bool = False,
+                       compute_viewspace_depth: bool = True) -> dict:
+        image = context["image"]
         B, T, _, H, Wd = image.shape
         dev = image.device
         gh, gw = H // self.patch_size, Wd // self.patch_size
