@@ -375,3 +375,35 @@ def test_boundary_grad_scale_leaves_plain_gradients_and_handles_accumulation():
     one = A.BoundaryGradScale(list(net.parameters()), 1.0)
     t = torch.ones(2, requires_grad=True)
     assert one.outputs(t)[0] is t
+
+
+def test_split_weight_exponent_cache_policy():
+    """autograd.LinearSplitFn._scale_exp (the cached power-of-two scale of a split-class weight pack): an all-zero weight is
+    never cached (the zero-initialised pose head would otherwise be packed unscaled for 64 steps), a stacked temporary takes the smallest
+    exponent of its source parameters without a host read of its own, and clear_split_caches() / VicaSplat's load_state_dict hook drop
+    exponents that new values under the same storage have made stale."""
+    from vicasplat_amd import autograd as A
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    A.clear_split_caches()
+    z = torch.nn.Parameter(torch.zeros(8, 32))
+    assert A.LinearSplitFn._scale_exp(z) == 0 and not A.LinearSplitFn._exp_cache
+    with torch.no_grad():
+        z.normal_(0, 0.02)
+    e = A.LinearSplitFn._scale_exp(z)
+    amax = float(z.detach().abs().max())
+    assert 2 ** 13 <= amax * 2.0 ** e < 2 ** 14 and len(A.LinearSplitFn._exp_cache) == 1
+    big = torch.nn.Parameter(z.detach() * 16)
+    assert A.LinearSplitFn._scale_exp(torch.cat([z, big], 0), z, big) == e - 4          # smallest exponent of the sources
+    with torch.no_grad():
+        z.mul_(1000.0)                                                                     # new values under the same storage ...
+    assert A.LinearSplitFn._scale_exp(z) == e                                              # ... the cache cannot see them
+    A.clear_split_caches()
+    assert A.LinearSplitFn._scale_exp(z) < e - 8
+    # load_state_dict on the encoder clears the cache by itself
+    m, _ = get_encoder(default_cfg(enc_depth=1, dec_depth=10, dec_embed_dim=64, dec_num_heads=1, enc_embed_dim=64, enc_num_heads=1))
+    w = m.backbone.decoder_embed.weight
+    e0 = A.LinearSplitFn._scale_exp(w)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["backbone.decoder_embed.weight"] *= 256.0
+    m.load_state_dict(sd)
+    assert A.LinearSplitFn._scale_exp(w) == e0 - 8

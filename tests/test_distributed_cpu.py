@@ -108,8 +108,13 @@ def _reducer_worker(rank, world, port, q, comm_bf16):
             red.zero_grad()
             loss = ((m(x[r.start:r.stop]) - y[r.start:r.stop]) ** 2).mean()
             loss.backward()
+            # `unused` is registered last = laid out FIRST (bucket 0): on the first step it holds every bucket back until finish(); from
+            # the second step on it is known (static graph) and every collective is already in flight when backward returns
+            assert red._next == (0 if step == 0 else len(red.buckets)), (step, red._next)
+            assert len(red._pending) == (0 if step == 0 else len(red.buckets))
             ncoll = red.finish()
             assert ncoll == len(red.buckets)
+            assert m.unused.weight.grad is None and m.net[0].weight.grad is not None
         # numpy arrays travel by value; tensors would travel as shared-memory handles that die with this process (the parent may read late)
         q.put((rank, {n: (None if p.grad is None else p.grad.detach().numpy().copy()) for n, p in m.named_parameters()}))
     except Exception as e:  # pragma: no cover

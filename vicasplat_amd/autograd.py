@@ -121,11 +121,11 @@ class LinearFn(torch.autograd.Function):
         return (None if dx is None else dx.view(xshape).to(xdtype)), dw, db, None, None
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype, rope=None) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype, rope=None, scale_sources=()) -> torch.Tensor:
     """nn.Linear in the operand dtype `dt`.  K must be a multiple of 64 for the MFMA kernels; tiny odd shapes (the 9 -> C
     intrinsic embedding) stay on torch in f32."""
     if dt == SPLIT:
-        return LinearSplitFn.apply(x, w, b, rope)
+        return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources))
     K = x.shape[-1]
     if K % 64 != 0:
         assert rope is None
@@ -154,13 +154,21 @@ class LinearSplitFn(torch.autograd.Function):
         return torch.nn.functional.pad(t, cfg).contiguous()
 
     # power-of-two scale of each parameter's packed image, refreshed every 64 uses: reading max|w| is a host synchronisation, and these
-    # layers are packed every step (the weights move).  2^e max|w| starts in [2^13, 2^14): a weight may grow 4x between refreshes.
+    # layers are packed every step (the weights move).  2^e max|w| starts in [2^13, 2^14): a weight may grow 4x between refreshes (AdamW at
+    # the reference's learning rates moves a weight by <= lr per step).  What the countdown cannot see is a REPLACEMENT of the values
+    # under the same storage: load_state_dict / copy_ -- VicaSplat clears the cache from a load_state_dict post-hook, and
+    # `clear_split_caches()` is there for callers that overwrite parameters by hand.  All-zero weights (the zero-initialised pose / fov
+    # heads) are never cached: their exponent is re-read on every use until they have moved.
     _exp_cache: dict = {}
 
     @staticmethod
-    def _scale_exp(w):
+    def _scale_exp(w, *sources):
+        """Exponent for packing `w`.  `sources`: the parameters a temporary `w` was assembled from (concatenation / re-layout): the
+        exponent is then the smallest of theirs -- max|w| <= max over the sources -- and no host read happens for the temporary."""
+        if sources:
+            return min(LinearSplitFn._scale_exp(s_) for s_ in sources)
         base = w if w.is_leaf else w._base
-        if base is None or not base.is_leaf:     # a temporary (concatenated / re-laid-out weights): nothing stable to key a cache on
+        if base is None or not base.is_leaf:     # a temporary with unknown sources: nothing stable to key a cache on
             return ops.split_scale_exp(w)
         import weakref
         key = (id(base), w.data_ptr(), tuple(w.shape))
@@ -168,17 +176,21 @@ class LinearSplitFn(torch.autograd.Function):
         if ent is None or ent[1] <= 0 or ent[2]() is not base:     # (the weak reference guards against a recycled id / address of a freed parameter)
             if len(LinearSplitFn._exp_cache) > 4096:
                 LinearSplitFn._exp_cache.clear()
-            ent = [ops.split_scale_exp(w), 64, weakref.ref(base)]
+            e, nonzero = ops.split_scale_exp(w, with_nonzero=True)
+            if not nonzero:
+                LinearSplitFn._exp_cache.pop(key, None)
+                return e
+            ent = [e, 64, weakref.ref(base)]
             LinearSplitFn._exp_cache[key] = ent
         ent[1] -= 1
         return ent[0]
 
     @staticmethod
-    def forward(ctx, x, w, b, rope=None):
+    def forward(ctx, x, w, b, rope=None, scale_sources=()):
         K, N = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, K).float()
         xp = LinearSplitFn._pad32(x2, 1)
-        e = LinearSplitFn._scale_exp(w)
+        e = LinearSplitFn._scale_exp(w, *scale_sources)
         ctx.scale_exp = e
         wp = ops.split_pack_weight(LinearSplitFn._pad32(w.detach().float(), 1), e)
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
@@ -213,11 +225,17 @@ class LinearSplitFn(torch.autograd.Function):
             dx = dx[:, :K].reshape(xshape) if Kp != K else dx.view(xshape)
         if dw is not None and Kp != K:
             dw = dw[:, :K].contiguous()
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rope=None) -> torch.Tensor:
-    return LinearSplitFn.apply(x, w, b, rope)
+def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rope=None, scale_sources=()) -> torch.Tensor:
+    return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources))
+
+
+def clear_split_caches() -> None:
+    """Forget the cached power-of-two weight exponents of the split class (call after overwriting parameter VALUES in place by hand;
+    load_state_dict on a VicaSplat does it by itself)."""
+    LinearSplitFn._exp_cache.clear()
 
 
 class LayerNormModFn(torch.autograd.Function):

@@ -85,17 +85,15 @@ def align_poses(decoder, gaussians, target_image: Tensor, extrinsics: Tensor, in
     from . import raster
     ext0 = extrinsics.clone()
 
-    def run(sync_free: bool, cap=None, start=0, extr=None, history=None):
-        """Steps start.. of the alignment.  sync_free: after the first (exact) render the steps run in the capacity mode; the overflow
-        flags of ALL rasterizer calls of a step are accumulated on the device (raster.CapacityScope) and read once at the end."""
-        extr = ext0.clone() if extr is None else extr
-        history = [] if history is None else history
-        flags = []
-        if start == 0:
-            with torch.no_grad():
-                rot.zero_(); trans.zero_()
+    def run(sync_free: bool):
+        """All steps of the alignment from the initial poses.  sync_free: after the first (exact) render the steps run in the capacity
+        mode; the overflow flags of ALL rasterizer calls of a step are accumulated on the device (raster.CapacityScope) and read once
+        at the end."""
+        extr, history, flags, cap = ext0.clone(), [], [], None
+        with torch.no_grad():
+            rot.zero_(); trans.zero_()
         with torch.enable_grad():
-            for it in range(start, steps):
+            for it in range(steps):
                 opt_.zero_grad()
                 # the first render runs in the exact mode and tells how many (Gaussian, tile) instances these cameras produce; the others
                 # run without the per-call host synchronisation, in buffers 1.5x that size (the poses move by millimetres per step)

@@ -94,7 +94,11 @@ class GradReducer:
     the buckets that never completed (parameters without a gradient this step -- scratch.refinenet4.resConfUnit1 of both DPT
     heads, SURVEY 2.2 -- contribute the zeros `zero_grad()` left there, so every rank reduces identical buckets), waits, and leaves
     `.grad = None` on those parameters (DDP's behaviour: AdamW then neither updates nor weight-decays them).  Buckets are launched
-    strictly in index order, whatever order the hooks fire in.
+    strictly in index order, whatever order the hooks fire in.  Because of that a parameter that NEVER gets a gradient would hold back
+    its bucket -- and every later one -- until finish(): the model's graph is static (DDP's `static_graph`), so the set of such
+    parameters is learned from the first step (or passed as `unused_params=`) and counted as arrived from zero_grad() on; the overlap
+    is then lost on the first step only.  If a parameter of that set does receive a gradient later, it is accepted as long as its
+    bucket has not been launched, and is an error (a gradient that would miss the exchange) otherwise.
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring collectives are per-link bound, so buckets are large (64 MiB
     default -> ~36 collectives for the 2.31 GB gradient) rather than DDP's 25 MB.  `comm_dtype=torch.bfloat16` halves the bytes
@@ -102,8 +106,9 @@ class GradReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True, group=None,
-                 comm_dtype: torch.dtype | None = None):
+                 comm_dtype: torch.dtype | None = None, unused_params: Iterable[torch.nn.Parameter] | None = None):
         self.group, self.average, self.comm_dtype = group, average, comm_dtype
+        self._unused_ids = {id(p) for p in (unused_params or ())}     # parameters known to receive no gradient (static graph)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         ps = [p for p in params if p.requires_grad]
         for p in ps:
@@ -142,7 +147,8 @@ class GradReducer:
         """Zero the flat buckets and (re)attach every p.grad as a view of its bucket."""
         for b in self.buckets:
             b["flat"].zero_()
-            b["ready"], b["launched"], b["got"] = 0, False, [False] * len(b["params"])
+            b["launched"], b["got"] = False, [False] * len(b["params"])
+            b["ready"] = sum(1 for p in b["params"] if id(p) in self._unused_ids)     # known-unused parameters count as arrived
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
         self._pending = []
@@ -168,7 +174,11 @@ class GradReducer:
             p.grad = v
         if not b["got"][p._vs_slot]:
             b["got"][p._vs_slot] = True
-            b["ready"] += 1
+            if id(p) not in self._unused_ids:
+                b["ready"] += 1
+            elif b["launched"]:
+                raise RuntimeError("GradReducer: a parameter recorded as unused (no gradient in the previous step) received a gradient after "
+                                   "its bucket was exchanged -- the graph is not static; rebuild the reducer")
         # launch in INDEX order only (a bucket that completes before an earlier one waits for it): the order in which hooks fire may
         # differ between ranks or steps, the order of the collectives must not
         while self._next < len(self.buckets) and self.buckets[self._next]["ready"] == len(self.buckets[self._next]["params"]):
@@ -191,10 +201,13 @@ class GradReducer:
         # parameters that received no gradient this step keep .grad = None, as under DDP: the optimizer skips them (a zero gradient
         # would still be weight-decayed by AdamW every step).  The model's graph does not depend on the rank or the data, so the set is
         # the same on every rank; the zeros they contributed to the buckets kept the collectives identical.  zero_grad() re-attaches.
+        unused = set()
         for b in self.buckets:
             for p, got in zip(b["params"], b["got"]):
                 if not got:
                     p.grad = None
+                    unused.add(id(p))
+        self._unused_ids = unused        # learned for the next step (a parameter that did get a gradient this time leaves the set)
         return n
 
     def remove(self):

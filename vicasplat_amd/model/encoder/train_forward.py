@@ -119,7 +119,9 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         ca = nm + ".cross_attn"
         wqkv = torch.cat([P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]], 0)
         bqkv = torch.cat([P[ca + ".projq.bias"], P[ca + ".projk.bias"], P[ca + ".projv.bias"]], 0)
-        qkv = A.linear(himg, wqkv, bqkv, dt, rope=(tabs["pos_img"], None, Hd, C, 100.0, 1.0))
+        # (split class: the exponent of the stacked temporary is the smallest of the three parameters' cached ones -- no host read)
+        qkv = A.linear(himg, wqkv, bqkv, dt, rope=(tabs["pos_img"], None, Hd, C, 100.0, 1.0),
+                       scale_sources=(P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]))
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
         x = A.gated_resid(x, lin(ca + ".proj", att), g2.reshape(BT, C), N1)
         himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=adt)
@@ -149,7 +151,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     def convT(name, t, k):                                       # ConvTranspose2d(kernel = stride = k): a GEMM + depth-to-space
         w = P[name + ".weight"]                                  # [Cin, Cout, k, k]
         Cout = w.shape[1]
-        y = A.linear(t, w.permute(2, 3, 1, 0).reshape(k * k * Cout, w.shape[0]), P[name + ".bias"].repeat(k * k), dt)
+        y = A.linear(t, w.permute(2, 3, 1, 0).reshape(k * k * Cout, w.shape[0]), P[name + ".bias"].repeat(k * k), dt, scale_sources=(w,))
         n_, h_, w_ = t.shape[:3]
         return y.view(n_, h_, w_, k, k, Cout).permute(0, 1, 3, 2, 4, 5).reshape(n_, h_ * k, w_ * k, Cout)
 
@@ -169,7 +171,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         cols = chunked(f, fr, h_ * w_ * 147)
         cols = F.pad(cols, (0, 256 - 147))     # 256 columns: whole tiles for the reduction-major weight-gradient kernel (no transposes)
         wk = F.pad(w.flatten(1), (0, 256 - 147))
-        return A.linear(cols, wk, P.get(name + ".bias"), dt).view(n_, h_, w_, w.shape[0])
+        return A.linear(cols, wk, P.get(name + ".bias"), dt, scale_sources=(w,)).view(n_, h_, w_, w.shape[0])
 
     def rcu(name, t):
         y = A.conv3x3(t, P[name + ".conv1.weight"], P[name + ".conv1.bias"], relu_in=True)

@@ -44,6 +44,11 @@ class VicaSplatCfg:
     camera_type: Literal["dq", "qt"] = "dq"
 
 
+def _clear_split_caches():
+    from ... import autograd as A
+    A.clear_split_caches()
+
+
 def quat_mul_xyzw(a, b):
     x1, y1, z1, w1 = a.unbind(-1)
     x2, y2, z2, w2 = b.unbind(-1)
@@ -92,6 +97,8 @@ class VicaSplat(Encoder[VicaSplatCfg]):
             nn.init.zeros_(self.camera_intrinsic_head[1].weight)
             nn.init.constant_(self.camera_intrinsic_head[1].bias, math.pi * 50 / 180)
         self.set_compute_dtype(compute_dtype)
+        # new VALUES under the same storage: the cached split-class weight exponents of the training Functions are stale
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: _clear_split_caches())
         if device is not None or weight_dtype is not None:
             self.to(device=device, dtype=weight_dtype)
 

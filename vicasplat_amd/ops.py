@@ -47,11 +47,15 @@ class SplitWeight:
         return self.data.numel()
 
 
-def split_scale_exp(w: torch.Tensor) -> int:
-    """Power-of-two exponent e with max|w| 2^e in [2^13, 2^14) (one host read of the maximum)."""
+def split_scale_exp(w: torch.Tensor, with_nonzero: bool = False):
+    """Power-of-two exponent e with max|w| 2^e in [2^13, 2^14) (one host read of the maximum); 0 for an all-zero / non-finite weight.
+    with_nonzero: also return whether the exponent came from an actual finite non-zero maximum (a cache must not keep the 0 of a
+    zero-initialised layer: it would pack the layer unscaled long after its weights have moved)."""
     import math
     amax = float(w.detach().abs().max())
-    return 0 if amax == 0.0 or not math.isfinite(amax) else max(-24, min(24, 13 - math.frexp(amax)[1] + 1))
+    ok = amax != 0.0 and math.isfinite(amax)
+    e = max(-24, min(24, 13 - math.frexp(amax)[1] + 1)) if ok else 0
+    return (e, ok) if with_nonzero else e
 
 
 def split_pack_weight(w: torch.Tensor, scale_exp: Optional[int] = None) -> SplitWeight:
