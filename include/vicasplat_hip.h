@@ -476,6 +476,18 @@ int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg,
  * alone (power-limited: ~0.67 of the 2.5 PFLOP/s dense-f16 headline on MI355X). */
 int vs_probe_mfma_rate(const void *operands, float *scratch, int32_t iters, double *flop_out_host, vs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Range guard of the split operand class (ABI 5, round 4).  The reference stores fp32 and multiplies in TF32 (backbone_vica.py:9):
+ * fp32 RANGE.  The split class multiplies f16 (hi, lo) pairs of the f32 activations, unscaled: |x| >= 65520 turns hi into +-inf.
+ * vs_range_check scans one activation operand and ORs into flags[slot]: 1 = a finite value with |x| >= limit (pass 65520), 2 = a
+ * non-finite f32 value, 4 (kind 1) = a hi half that is already +-inf / NaN.  kind 0: f32 [rows, cols], row stride ld floats, cols % 4 == 0;
+ * kind 1: the packed (hi, lo) layout of vs_split_pack_weight / the "+16" producers, [rows, cols] 4-byte units, cols % 32 == 0.  One
+ * atomic per wavefront that found something; flags: int32 device array owned by the caller (zeroed by the caller).  A debug aid: the
+ * product kernels never call it (vicasplat_amd.ops.range_guard drives it around every split-class GEMM / convolution / attention call).
+ * ------------------------------------------------------------------------------------------------ */
+int vs_range_check(const void *x, int64_t rows, int32_t cols, int64_t ld, int32_t kind, float limit, int32_t *flags, int32_t slot,
+                   vs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

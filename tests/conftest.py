@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:          # test modules share a few helpers (e.g. test_split_path_gpu.example_frames_errors)
+    sys.path.insert(0, HERE)
 
 
 def pytest_configure(config):

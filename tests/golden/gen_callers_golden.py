@@ -7,6 +7,8 @@ CPU through ref_import.py's stub finder) on seeded inputs:
                           as demo.py:204-221 calls them (10 steps per interval of a 4-camera path)
   * callers_fov.npz    -- src/geometry/projection.py:247-261 `get_fov` on the view-mean of seeded context intrinsics and the l2 fov term
                           LossCamera adds for the *_no_intrin configurations (loss_camera.py:76-79, loss.py:23-28)
+  * callers_load_images.npz -- demo.py:75-132 `load_images` (its function bodies executed from the reference's source) on non-square
+                          pictures: both branches of the resize rule (Lanczos when shrinking, bicubic when enlarging) + the centre crop
   * callers_dq.npz     -- src/loss/loss_camera.py:30-45 `camera_dq_loss` and src/misc/dq.py `homogeneous_matrix` on seeded dual
                           quaternions (the pypose SO3 algebra comes from ref_import's shim)
 
@@ -145,7 +147,31 @@ def gen_fov():
     print("[golden] callers_fov.npz l2", float(l2_loss(pred, fov)))
 
 
+def gen_load_images():
+    """demo.py:75-132 `load_images` of the real reference (ref_import.reference_load_images) on two NON-square pictures, so that both
+    branches of its resize rule are pinned: a 400 x 300 picture (shrunk: Lanczos) and a 200 x 150 one (enlarged: bicubic), each centre-
+    cropped to 256 x 256.  Sources are smooth synthetic RGB patterns with an edge and saturated patches (data, generated here)."""
+    import tempfile
+    from PIL import Image
+    load_images = ref_import.reference_load_images()
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, (w, h) in (("shrink", (400, 300)), ("enlarge", (200, 150)), ("tall", (180, 320))):
+            yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+            img = np.stack([127.5 + 127.5 * np.sin(xx / 17.0 + yy / 31.0), 255.0 * (xx > w * 0.4), 300.0 * yy / h - 20.0], -1)
+            u8 = np.clip(np.round(img), 0, 255).astype(np.uint8)
+            Image.fromarray(u8).save(os.path.join(td, name + ".png"))
+            x = load_images([os.path.join(td, name + ".png")], size=256, verbose=False)
+            out["src_" + name] = u8
+            r = torch.round((x[0] * 0.5 + 0.5) * 255.0).to(torch.uint8)
+            assert torch.equal((r.float() / 255.0 - 0.5) / 0.5, x[0])
+            out["out_" + name] = r.permute(1, 2, 0).numpy()
+    np.savez_compressed(os.path.join(HERE, "callers_load_images.npz"), **out)
+    print("[golden] callers_load_images.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    gen_load_images()
     gen_fov()
     gen_ply()
     gen_interp()

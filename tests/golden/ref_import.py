@@ -193,3 +193,26 @@ def build_reference_encoder(backbone_overrides: dict | None = None):
                        gaussian_adapter=GaussianAdapterCfg(0.005, 0.04, 4, "softplus"), apply_bounds_shim=True,
                        opacity_mapping=OpacityMappingCfg(0.0, 0.0, 1), predict_opacity=False)
     return VicaSplat(cfg).eval()
+
+
+def reference_load_images():
+    """demo.py:75-132 `load_images` of the REAL reference, for fixture generation.  demo.py as a module cannot be imported here (gradio,
+    tensorboard, the Lightning wrapper), so the two functions are taken out of its source with `ast` AT GENERATION TIME and executed
+    with their own globals: PIL (installed), `exif_transpose`, and one behavioural shim -- `ImgNorm`, torchvision's
+    Compose([ToTensor(), Normalize(0.5, 0.5)]) (uint8 HWC -> float CHW / 255, then (x - 0.5) / 0.5; torchvision is not installed)."""
+    import ast
+    import numpy as np
+    from PIL import Image
+    from PIL.ImageOps import exif_transpose
+    src = open(os.path.join(REF, "demo.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("_resize_pil_image", "load_images")]
+    assert len(keep) == 2
+
+    def ImgNorm(img):
+        a = np.asarray(img, dtype=np.uint8)
+        return (torch.from_numpy(a.copy()).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+
+    ns = dict(os=os, Image=Image, exif_transpose=exif_transpose, torch=torch, ImgNorm=ImgNorm, heif_support_enabled=False)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), os.path.join(REF, "demo.py"), "exec"), ns)
+    return ns["load_images"]

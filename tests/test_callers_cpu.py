@@ -407,3 +407,29 @@ def test_split_weight_exponent_cache_policy():
     sd["backbone.decoder_embed.weight"] *= 256.0
     m.load_state_dict(sd)
     assert A.LinearSplitFn._scale_exp(w) == e0 - 8
+
+
+def test_load_images_reproduces_the_reference_preprocessing_of_its_example_frames(tmp_path):
+    """demo.py:75-132 on the reference's own examples: the fixture holds what the REAL `load_images` returned for
+    examples/<scene>/*.png (uint8-exact: the tensors are (u8 / 255 - 0.5) / 0.5); written back as PNGs, callers.load_images must return the
+    same tensor, files in name order.  callers_load_images.npz (the reference's `load_images` run on three non-square pictures) pins the
+    resize rule of demo.py:62-69 -- Lanczos when shrinking, bicubic when enlarging -- and the centre crop."""
+    import os
+    from PIL import Image
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_full_v8_examples.npz"))
+    u8 = z["frames_u8"][0]                                   # [8,256,256,3]
+    names = [f"{5 + 39 * i:06d}.png" for i in range(8)]     # the reference's file names: 000005.png ... 000278.png
+    for nm, fr in zip(reversed(names), reversed(list(u8))):  # written in reverse: the loader must sort by name
+        Image.fromarray(fr).save(tmp_path / nm)
+    (tmp_path / "notes.txt").write_text("ignored")
+    x = callers.load_images(str(tmp_path))
+    ref = (torch.from_numpy(u8).permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
+    assert x.shape == (8, 3, 256, 256) and torch.equal(x, ref)
+    assert torch.equal(callers.load_images([str(tmp_path / n) for n in names[::-1]]), ref)
+    # non-square sources: the reference's own output for a shrunk (Lanczos), an enlarged (bicubic) and a portrait picture
+    zl = np.load(os.path.join(os.path.dirname(__file__), "golden", "callers_load_images.npz"))
+    for name in ("shrink", "enlarge", "tall"):
+        Image.fromarray(zl["src_" + name]).save(tmp_path / (name + ".png"))
+        y = callers.load_images([str(tmp_path / (name + ".png"))])
+        want = (torch.from_numpy(zl["out_" + name]).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+        assert y.shape == (1, 3, 256, 256) and torch.equal(y[0], want), name

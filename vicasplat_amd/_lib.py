@@ -75,14 +75,16 @@ def lib() -> C.CDLL:
             L = C.CDLL(_SO)
             L.vs_last_error.restype = C.c_char_p
             L.vs_abi_version.restype = C.c_int
-            if L.vs_abi_version() != 4:     # the ctypes mirrors of the structs below are for exactly this layout
-                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 4: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+            if L.vs_abi_version() != 5:     # the ctypes mirrors of the structs below are for exactly this layout
+                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 5: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
             L.vs_raster_forward.restype = C.c_int64
             L.vs_raster_forward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), AllocFn, C.c_void_p, C.c_void_p]
             L.vs_rope2d.restype = C.c_int
             L.vs_rope2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_void_p]
             i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+            L.vs_range_check.restype = C.c_int
+            L.vs_range_check.argtypes = [vp, i64, i32, i64, i32, f32, vp, i32, vp]
             L.vs_layernorm_mod.restype = C.c_int
             L.vs_layernorm_mod.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, i32, i32, i32, f32, i32, i32, i32, vp]
             L.vs_gemm_bias_act.restype = C.c_int

@@ -127,6 +127,11 @@ class VicaSplat(Encoder[VicaSplatCfg]):
     # unscaled gradients, as from the reference's fp32 training.  `encoder.grad_scale = 1.0` turns it off (e.g. when the caller runs its
     # own loss scaling, as callers.training_step does through forward_train).
     grad_scale: Optional[float] = None
+    # Debug mode of the split operand class (`encoder.range_guard = True`): the class multiplies UNSCALED f16 (hi, lo) pairs of the f32
+    # activations, so an activation with |x| >= 65520 turns into +-inf where the reference's fp32 / TF32 arithmetic has range.  With the
+    # guard on, every forward audits its operands on the device (ops.range_guard) and raises ops.SplitRangeError instead of returning
+    # silently wrong Gaussians.
+    range_guard: bool = False
     _DEFAULT_GRAD_SCALE = {"split": 8192.0, torch.float16: 1024.0, torch.bfloat16: 1.0}
 
     def train_compute_class(self):
@@ -145,6 +150,15 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         image = context["image"]
         if not image.is_cuda:
             raise RuntimeError("VicaSplat.forward needs HIP device tensors: vicasplat_amd has no CPU fallback path")
+        if self.range_guard and self.backbone.split:
+            # debug mode of the split class: audit every MFMA operand of this forward against the f16 range of its hi halves and raise
+            # ops.SplitRangeError naming the calls that left it (one extra read pass per operand + one host synchronisation)
+            with ops.range_guard(image.device, raise_on_overflow=True):
+                return self._dispatch(context, global_step, visualization_dump, distill, compute_viewspace_depth)
+        return self._dispatch(context, global_step, visualization_dump, distill, compute_viewspace_depth)
+
+    def _dispatch(self, context, global_step, visualization_dump, distill, compute_viewspace_depth) -> dict:
+        image = context["image"]
         if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self._forward_autograd(context, global_step, visualization_dump, distill, compute_viewspace_depth)
         with torch.no_grad():
