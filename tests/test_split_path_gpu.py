@@ -582,3 +582,67 @@ def test_encoder_split_on_the_reference_example_frames(wname):
         errs, ref32 = example_frames_errors(m, z, f"{wname}_s{si}", si)
         print(wname, "scene", si, "split class vs reference f64:", {k: f"{v:.1e}" for k, v in errs.items()}, f"[reference f32 vs f64 raw: {ref32:.1e}]")
         assert max(errs.values()) <= 2e-4, errs
+
+
+@pytest.mark.parametrize("nb,H,L", [(3, 4, 257), (2, 3, 1032), (1, 2, 2064), (5, 1, 63)])
+def test_attention_split_on_packed_qkv(nb, H, L):
+    """Round 4: q | k | v in the PACKED (hi, lo) form (what the qkv projection's RoPE epilogue writes, vs_gemm_split epilogue 4 + 16) through
+    attention_sp_kernel (C-ABI dtype 4 + 32): LDS-DMA staging, waves split 2 query halves x 2 key halves with one merge at the end,
+    XCD-aware linear grid.  Same semantics as the f32-input kernel -- plain, per-query key-prefix lengths (the blocked-causal mask),
+    two key segments per batch item (cross-neighbour attention), logsumexp, f32 and packed outputs -- against float64 on the same f32
+    values (<= 6e-6), and BIT-identical to the f32-input kernel's result is NOT expected (different summation split): both within TOL."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(5 + L)
+    C = H * 64
+    qkv = torch.randn(nb * L, 3 * C, generator=g).to(d)
+    qp = ops.split_pack_weight(qkv, 0).data                     # the packed image the GEMM epilogue would have written
+    sl = lambda t: (t[:, :C], t[:, C:2 * C], t[:, 2 * C:])
+    out = torch.empty(nb * L, C, device=d)
+    lse = torch.empty(nb * L, H, device=d)
+    kw = dict(nbatch=nb, H=H, Lq=L, q_batch_rows=L, split=True)
+    ops.attention(*sl(qp), out, Lk=L, k_batch_rows=L, lse=lse, **kw)
+    t = qkv.cpu().reshape(nb, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = _attn_ref(t[0], t[1], t[2]).permute(0, 2, 1, 3).reshape(nb * L, C)
+    e = _rel(out.cpu(), ref)
+    print(f"packed split attention nb={nb} H={H} L={L}: rel err {e:.2e}")
+    assert e <= TOL
+    s = (t[0].double() @ t[1].double().transpose(-1, -2)) * 0.125
+    lse_ref = (torch.logsumexp(s, -1) / math.log(2)).permute(0, 2, 1).reshape(nb * L, H)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) <= 1e-4
+    # packed output == the packed image of the f32 output
+    outp = ops.split_act(nb * L, C, d)
+    ops.attention(*sl(qp), outp, Lk=L, k_batch_rows=L, **kw)
+    assert torch.equal(outp.data, ops.split_pack_weight(out, 0).data)
+    # per-query key-prefix lengths
+    lens = torch.randint(1, L + 1, (nb, L), generator=g)
+    lens[:, ::5] = L
+    lens[0, 1] = 1
+    ops.attention(*sl(qp), out, Lk=L, k_batch_rows=L, q_kvlen=lens.int().reshape(-1).contiguous().to(d), **kw)
+    ref = _attn_ref(t[0], t[1], t[2], lens).permute(0, 2, 1, 3).reshape(nb * L, C)
+    assert _rel(out.cpu(), ref) <= TOL
+    if nb == 3:
+        seg = torch.tensor([[L, L, L, L], [0, L, 2 * L, L], [L, L, L, L]], dtype=torch.int32).to(d)
+        ops.attention(*sl(qp), out, kv_seg=seg, **kw)
+        nbr = [[1, 1], [0, 2], [1, 1]]
+        kk = torch.stack([torch.cat([t[1][j] for j in nbr[b]], 1) for b in range(nb)])
+        vv = torch.stack([torch.cat([t[2][j] for j in nbr[b]], 1) for b in range(nb)])
+        ref = _attn_ref(t[0], kk, vv).permute(0, 2, 1, 3).reshape(nb * L, C)
+        assert _rel(out.cpu(), ref) <= TOL
+
+
+def test_gemm_qkv_rope_split_packed_output():
+    """The qkv projection's RoPE epilogue with a packed output (vs_gemm_split epilogue 4 + 16): the packed image of the f32 route, bit for bit."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(9)
+    M, K, C = 2 * 257, 256, 128
+    a = torch.randn(M, K, generator=g).to(d)
+    w = ops.split_pack_weight((torch.randn(3 * C, K, generator=g) / 16).to(d))
+    b = torch.randn(3 * C, generator=g).to(d)
+    pos = torch.stack([torch.arange(M) % 17, torch.arange(M) % 16], -1).int().contiguous().to(d)
+    o32 = torch.empty(M, 3 * C, device=d)
+    ops.gemm_qkv_rope(a, w, b, o32, C, pos, None, 100.0, 1.0)
+    op = ops.split_act(M, 3 * C, d)
+    ops.gemm_qkv_rope(a, w, b, op, C, pos, None, 100.0, 1.0)
+    assert torch.equal(op.data, ops.split_pack_weight(o32, 0).data)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of attention_split_kernel on one shape: bash tools/pmc_one_attn.sh <tag> encoder|video
+# SQ counters of the split attention kernel (attention_sp_kernel, or attention_split_kernel with VS_ATTN_PACKED=0) on one shape: bash tools/pmc_one_attn.sh <tag> encoder|video
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/pa_$1
 mkdir -p $O
@@ -13,10 +13,10 @@ O = sys.argv[1]
 cnt = collections.defaultdict(list)
 for tag in ("sq1", "sq2"):
     for r in csv.DictReader(open(glob.glob(f"{O}/{tag}/**/*counter_collection.csv", recursive=True)[0])):
-        if "attention_split" in r["Kernel_Name"]:
+        if "attention_sp" in r["Kernel_Name"]:
             cnt[r["Counter_Name"]].append(float(r["Counter_Value"]))
 c = {k: sum(v) / len(v) for k, v in cnt.items()}
-dur = next(float(r["TotalDurationNs"]) / int(r["Calls"]) / 1e3 for r in csv.DictReader(open(glob.glob(f"{O}/t/**/*kernel_stats.csv", recursive=True)[0])) if "attention_split" in r["Name"])
+dur = next(float(r["TotalDurationNs"]) / int(r["Calls"]) / 1e3 for r in csv.DictReader(open(glob.glob(f"{O}/t/**/*kernel_stats.csv", recursive=True)[0])) if "attention_sp" in r["Name"])
 cyc = c["SQ_BUSY_CYCLES"] / 32
 print(f"{dur:.1f} us/dispatch; clock {cyc / dur / 1e3:.2f} GHz; MFMA busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.1f} %")
 for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):

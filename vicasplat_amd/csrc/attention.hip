@@ -700,6 +700,353 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
 }
 
 
+// ---- split-operand attention on PACKED q | k | v (round 4; dtype code 4 + 32) ------------------------------------------------------------
+// The qkv projection's RoPE epilogue writes q | k | v in the packed (hi, lo) form of the split class (vs_gemm_split(_packed), epilogue
+// 4 + 16: per block of 32 columns 32 hi halves then 32 lo halves, gemm_common.h store_split4), so a head's row of q, k or v is 256 bytes =
+// [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63] (positions; the column order inside a block is the packed permutation, the same for q and
+// k, so dot products need no un-permutation, and V's column position IS the output's packed position).  What that buys here:
+//   * staging is plain LDS-DMA (global_load_lds_dwordx4): no conversion VALU, no staging registers, the next tile in flight under the
+//     current tile's MFMAs, one barrier per tile.  attention_split_kernel converted every K / V tile again in EVERY workgroup that
+//     staged it (17 x for the 2064-key video attention);
+//   * LDS read traffic per FLOP is HALVED: PMC on attention_split_kernel showed the LDS pipe as its busiest unit (47 % + 20 % conflict
+//     cycles) because each of the four waves read the whole K and V tile (hi and lo) for only 32 queries.  Here the four waves of a
+//     workgroup are 2 query halves x 2 KEY halves: wave (qh, kh) owns 64 queries (four 16-query MFMA groups) and keys kh*32 .. kh*32+31
+//     of every 64-key tile, so it reads half a tile for twice the queries, at the same 2 workgroups x 4 waves per CU and the same MFMA
+//     count per wave and tile (96).  Each wave runs its own online softmax over its keys; the two key halves of a query meet ONCE, after
+//     the last tile, through LDS (m, l, O of the kh = 1 wave; flash-decoding style merge);
+//   * the grid is linear and XCD-aware: all query tiles of one (batch, head) are consecutive logical blocks mapped to ONE XCD
+//     (gemm256.h's remap), so its K / V (1 MB for the video attention) is fetched into one L2 instead of eight.
+// LDS tiles are unpadded 256-byte rows; 16-byte chunk index XOR (key & 15) for K (conflict-free ds_read_b128 over 16 keys), 32-byte
+// chunk index XOR (key & 7) for V (the four rows of a ds_read_b64_tr_b16 in four different 32-byte windows); the swizzle is applied on
+// the GLOBAL side of the DMA.  Rows past the end of the key list are duplicates of the last key, masked by the length logic.
+struct AttnArgsSP {
+    const unsigned char *q, *k, *v;   // packed rows; strides in bytes
+    float *out;
+    const int32_t *kv_seg, *q_kvlen;
+    int nbatch, H, Lq, Lk, nqt;
+    long long q_batch_rows, k_batch_rows;
+    long long ldq_b, ldk_b, ldv_b;
+    int ldo;
+    float scale_log2e;
+    float *lse;
+    int out_packed;
+    int dbg;   // TEMP experiment switch
+};
+
+typedef void __attribute__((address_space(3))) *lds_ptr_sp_t;
+__device__ __forceinline__ void glds16_sp(const void *gp, unsigned lds_off) {   // (inline asm: the compiler adds no waits of its own)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
+}
+
+// online-softmax step of one 16-query group over this wave's 32 keys of a tile (softmax_tile for two 16-key blocks)
+__device__ __forceinline__ void softmax_half(f4 (&st)[2], float scale_log2e, float &m_run, float &l_run, f4 (&o)[4], uint4 &pf) {
+    float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+    mx = fmaxf(fmaxf(mx, st[0][3]), st[1][0]);
+    mx = fmaxf(fmaxf(mx, st[1][1]), st[1][2]);
+    mx = fmaxf(mx, st[1][3]);
+    mx = rows_max(mx) * scale_log2e;
+    const float m_new = vmax2(m_run, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const f2v sc = f2v{scale_log2e, scale_log2e}, neg_m = f2v{-m_use, -m_use};
+    f2v acc = f2v{0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f2v x = f2v{st[nb][2 * h], st[nb][2 * h + 1]} * sc + neg_m;
+            f2v p;
+            p.x = __builtin_amdgcn_exp2f(x.x);
+            p.y = __builtin_amdgcn_exp2f(x.y);
+            st[nb][2 * h] = p.x; st[nb][2 * h + 1] = p.y;
+            acc += p;
+        }
+    const float rs = rows_sum(acc.x + acc.y);
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] *= alpha;
+        m_run = m_new;
+    }
+    l_run += rs;
+    pf.x = pack2<false>(st[0][0], st[0][1]);
+    pf.y = pack2<false>(st[0][2], st[0][3]);
+    pf.z = pack2<false>(st[1][0], st[1][1]);
+    pf.w = pack2<false>(st[1][2], st[1][3]);
+}
+
+// One tile of one wave: its 32 keys (rows kw .. kw + 31 of the staged tile) against its 64 queries.  Straight-line code: ALLQ (all four
+// query groups hold real queries) and MASKED (some query of the wave does not see all 32 keys) are compile-time, so the 96 MFMAs, the four
+// softmax steps and the 24 LDS reads of a tile form ONE basic block the scheduler can interleave.  kofs / vofs: per-lane byte offsets inside a
+// K / V tile (swizzle applied), loop invariant; the ring slot is a compile-time constant, so every LDS address is register + immediate.
+template <int NG, bool ALLQ, bool MASKED>
+__device__ __forceinline__ void sp_tile(const unsigned char *sK, const unsigned char *sV, const int (&kofs)[2][2], const int (&vofs)[8], int nact,
+                                        const int (&my_len)[NG], int kbase, int g, float scale_log2e, const uint4 (&qfh)[NG][2], const uint4 (&qfl)[NG][2],
+                                        float (&m_run)[NG], float (&l_run)[NG], f4 (&o)[NG][4]) {
+    f4 st[NG][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) st[u][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 kh_ = *reinterpret_cast<const uint4 *>(sK + kofs[0][ks] + nb * 4096);
+            const uint4 kl_ = *reinterpret_cast<const uint4 *>(sK + kofs[1][ks] + nb * 4096);
+#pragma unroll
+            for (int u = 0; u < NG; ++u)
+                if (ALLQ || u < nact) st[u][nb] = mma3(kh_, kl_, qfh[u][ks], qfl[u][ks], st[u][nb]);
+        }
+    }
+    uint4 pfh[NG], pfl[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        if (!ALLQ && u >= nact) continue;
+        if (MASKED) {
+            const int lim = my_len[u] - kbase - g * 4;          // keys kbase + nb*16 + g*4 + r are visible while nb*16 + r < lim
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb * 16 + r >= lim) st[u][nb][r] = -INFINITY;
+        }
+        softmax_half(st[u], scale_log2e, m_run[u], l_run[u], o[u], pfh[u]);     // st now holds P (f32), pfh its rne16
+        const unsigned hh[4] = {pfh[u].x, pfh[u].y, pfh[u].z, pfh[u].w};
+        unsigned ll[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            // lo = rne16(p - float(hi)): the difference on v_fma_mix_f32 (f16 source operand, exact f32 result: one instruction instead of a
+            // convert and a subtract), the rounding on a COMPILER-VISIBLE convert -- the value that feeds the P V MFMAs must come out of an
+            // instruction the hazard recogniser sees (VALU write -> MFMA read wait states); asm -> VALU needs no software wait
+            typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+            typedef float f2_ __attribute__((ext_vector_type(2)));
+            const float p0 = st[u][w >> 1][(w & 1) * 2], p1 = st[u][w >> 1][(w & 1) * 2 + 1];
+            float r0, r1;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh[w]), "v"(p0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh[w]), "v"(p1));
+            ll[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_{r0, r1}, h2_));
+        }
+        pfl[u] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+    }
+    // ---- O^T += V^T P^T over the wave's 32 keys: V fragments through the transpose read, once for the four query groups.
+    // db = 16-position block of the head's packed row: (db >> 1) = 32-column block, (db & 1) = its first / second 16 positions
+    typedef tr4v_t __attribute__((address_space(3))) *trp_t;
+    auto trd = [&](int ofs) -> uint2 {
+        return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned char *>(sV + ofs))));
+    };
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int c32h = (db >> 1) * 4 + (db & 1), c32l = c32h + 2;           // 32-byte chunk of the hi / lo positions
+        const uint2 h0 = trd(vofs[c32h]), h1 = trd(vofs[c32h] + 4096), l0 = trd(vofs[c32l]), l1 = trd(vofs[c32l] + 4096);
+        const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+            if (ALLQ || u < nact) o[u][db] = mma3(vh, vl, pfh[u], pfl[u], o[u][db]);
+    }
+}
+
+template <int NG>
+__global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a) {
+    constexpr int QW = 16 * NG;                                               // queries per wave (NG MFMA groups of 16), 2 * QW per workgroup
+    constexpr int TILE_B = KB * 256;                                          // one K (or V) tile: 64 keys x 256 bytes
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][TILE_B];  // [ring slot][K | V]
+    __shared__ int s_maxlen;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    const int qh = wid >> 1, kh = wid & 1;
+    // ---- XCD-aware linear block id -> (batch, head, query tile): consecutive logical ids (one (batch, head)'s query tiles) share an XCD
+    const int nwg = a.nqt * a.H * a.nbatch;
+    int bid = blockIdx.x;
+    {
+        const int qn = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + idx;
+    }
+    const int qt = bid % a.nqt, h = (bid / a.nqt) % a.H, b = bid / (a.nqt * a.H);
+    const int q0 = qt * (2 * QW) + qh * QW;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_sp_t)&smem[0][0][0];
+
+    int base0, len0, base1, len1;
+    if (a.kv_seg) {
+        base0 = a.kv_seg[4 * b + 0]; len0 = a.kv_seg[4 * b + 1]; base1 = a.kv_seg[4 * b + 2]; len1 = a.kv_seg[4 * b + 3];
+    } else {
+        base0 = (int)(b * a.k_batch_rows); len0 = a.Lk; base1 = 0; len1 = 0;
+    }
+    const int Lk = len0 + len1;
+
+    // ---- Q fragments: straight from the packed rows (hi chunk g, lo chunk g of the head's two 32-column blocks)
+    int my_len[NG];
+    uint4 qfh[NG][2], qfl[NG][2];
+    int wave_len = 0, wave_min = 0x7fffffff, nact = 0;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int qi = q0 + u * 16 + c16;
+        const bool qvalid = qi < a.Lq;
+        const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
+        int ml = Lk;
+        if (a.q_kvlen && qvalid) ml = min(Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+        if (!qvalid) ml = 0;
+        my_len[u] = ml;
+        wave_len = max(wave_len, ml);
+        wave_min = min(wave_min, ml);
+        if (q0 + u * 16 < a.Lq) nact = u + 1;            // (wave-uniform: groups 0 .. nact-1 hold at least one real query)
+        const unsigned char *qp = a.q + qrow * a.ldq_b + h * 256 + g * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qfh[u][ks] = *reinterpret_cast<const uint4 *>(qp + ks * 128);
+            qfl[u][ks] = *reinterpret_cast<const uint4 *>(qp + ks * 128 + 64);
+        }
+    }
+    // The Q fragments must have LANDED, as far as the compiler's wait-count tracking is concerned, before the tile loop: the loop's DMA is
+    // issued from inline asm the compiler does not see, so any s_waitcnt vmcnt(N) it inserts inside the loop for THESE loads (it places the
+    // wait at the first use, i.e. at the first MFMAs of the loop body) also waits for the next tile's DMA -- which made the prefetch
+    // synchronous (ISA: vmcnt(7) .. vmcnt(0) in front of the S = K Q^T MFMAs).  An asm that reads the registers forces the wait here.
+#pragma unroll
+    for (int u = 0; u < NG; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            asm volatile("" ::"v"(qfh[u][ks].x), "v"(qfh[u][ks].y), "v"(qfh[u][ks].z), "v"(qfh[u][ks].w), "v"(qfl[u][ks].x), "v"(qfl[u][ks].y),
+                         "v"(qfl[u][ks].z), "v"(qfl[u][ks].w));
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) {
+        wave_len = max(wave_len, __shfl_xor(wave_len, o_, 64));
+        wave_min = min(wave_min, __shfl_xor(wave_min, o_, 64));
+    }
+    wave_len = __builtin_amdgcn_readfirstlane(wave_len);
+    wave_min = __builtin_amdgcn_readfirstlane(wave_min);     // the shortest key list among the wave's 64 query slots (0 with a missing query)
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_maxlen, wave_len);
+    __syncthreads();
+    const int maxlen = s_maxlen;
+
+    f4 o[NG][4];
+    float m_run[NG], l_run[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        m_run[u] = -INFINITY; l_run[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- staging: per tile 16 pieces of 1 KiB (4 key rows) for K and for V; wave w issues pieces w, w + 4, w + 8, w + 12 of each.  Lane l of
+    // a piece = (row l >> 4, LDS slot l & 15); (row & 15) == (w * 4 + (l >> 4)) & 15 for every piece of this wave, so the swizzled source
+    // chunk is a per-thread constant
+    const int r0 = wid * 4 + (lane >> 4);
+    const int kchunk = (lane & 15) ^ (r0 & 15);
+    const int vchunk = ((((lane & 15) >> 1) ^ (r0 & 7)) << 1) | (lane & 1);
+    const unsigned char *kbase = a.k + h * 256 + kchunk * 16, *vbase = a.v + h * 256 + vchunk * 16;
+    auto key_row = [&](int j) -> long long {
+        j = min(j, Lk - 1);
+        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
+    };
+    auto issue = [&](int kt, int slot) {
+        if (a.dbg & 2) return;
+        const unsigned ldsk = lds0 + (unsigned)(slot * 2) * TILE_B + (unsigned)wid * 1024u, ldsv = ldsk + TILE_B;
+        long long rowbase = -1;                  // whole tile inside one segment (and inside the list): rows are base + r
+        if (kt + KB <= len0) rowbase = (long long)base0 + kt;
+        else if (kt >= len0 && kt + KB <= Lk) rowbase = (long long)base1 + (kt - len0);
+        if (rowbase >= 0) {
+            const unsigned char *kp = kbase + (rowbase + r0) * a.ldk_b, *vp = vbase + (rowbase + r0) * a.ldv_b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16_sp(kp + (long long)j * 16 * a.ldk_b, __builtin_amdgcn_readfirstlane(ldsk + (unsigned)j * 4096u));
+                glds16_sp(vp + (long long)j * 16 * a.ldv_b, __builtin_amdgcn_readfirstlane(ldsv + (unsigned)j * 4096u));
+            }
+        } else {                                 // a tile that straddles the segment boundary or the end of the list: per-row lookup
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long r = key_row(kt + j * 16 + r0);
+                glds16_sp(kbase + r * a.ldk_b, __builtin_amdgcn_readfirstlane(ldsk + (unsigned)j * 4096u));
+                glds16_sp(vbase + r * a.ldv_b, __builtin_amdgcn_readfirstlane(ldsv + (unsigned)j * 4096u));
+            }
+        }
+    };
+    if (maxlen > 0) issue(0, 0);
+    if (a.dbg & 4) {   // TEMP: stagger the two co-resident workgroups by about half a tile
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (((hwid >> 16) ^ hwid) & 1) for (int i_ = 0; i_ < (a.dbg >> 3); ++i_) __builtin_amdgcn_s_sleep(4);     // 4 x 64 cycles per trip
+    }
+
+    // ---- loop-invariant LDS offsets of this lane's fragments (bytes inside a K / V tile, swizzle applied)
+    const int kw = kh * 32;                       // this wave's keys inside a tile
+    int kofs[2][2], vofs[8];
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kofs[hl][ks] = (kw + c16) * 256 + (((ks * 8 + hl * 4 + g) ^ c16) << 4);     // (+ nb * 4096)
+    {
+        const int row = kw + g * 4 + (c16 >> 2), inb = (c16 & 3) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vofs[c] = row * 256 + ((c ^ (row & 7)) << 5) + inb;                                // (+ 4096 for the keys + 16)
+    }
+    const bool allq = nact == NG;
+    auto tile = [&](int kt, const unsigned char *sK, const unsigned char *sV) {
+        const int kb = kt + kw;
+        if (a.dbg & 1) return;
+        if (kb >= wave_len) return;                          // none of this wave's queries sees any of its keys of this tile
+        const bool masked = kb + 32 > wave_min;              // (wave-uniform)
+        if (allq) {
+            if (masked) sp_tile<NG, true, true>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
+            else sp_tile<NG, true, false>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
+        } else {
+            sp_tile<NG, false, true>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
+        }
+    };
+    for (int kt = 0; kt < maxlen; kt += 2 * KB) {            // two tiles per trip: the ring slot is a compile-time constant
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
+        __syncthreads();                                       // ... and everybody's; all waves are done with the other slot
+        if (kt + KB < maxlen) issue(kt + KB, 1);
+        tile(kt, &smem[0][0][0], &smem[0][1][0]);
+        if (kt + KB >= maxlen) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 * KB < maxlen) issue(kt + 2 * KB, 0);
+        tile(kt + KB, &smem[1][0][0], &smem[1][1][0]);
+    }
+
+    // ---- merge the two key halves of every query (once): the kh = 1 wave hands (m, l, O) to its kh = 0 partner through LDS
+    __syncthreads();
+    float *xch = reinterpret_cast<float *>(&smem[0][0][0]) + qh * (18 * 64 * 4);      // [u][m | l | 16 x O][lane]: 18 KiB per query half
+    if (kh == 1) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            float *x = xch + u * 18 * 64 + lane;
+            x[0] = m_run[u]; x[64] = l_run[u];
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[(2 + db * 4 + r) * 64] = o[u][db][r];
+        }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int qo = q0 + u * 16 + c16;
+        const float *x = xch + u * 18 * 64 + lane;
+        const float m1 = x[0], l1 = x[64];
+        const float m = fmaxf(m_run[u], m1);
+        const float mu = m == -INFINITY ? 0.f : m;
+        const float a0 = __builtin_amdgcn_exp2f(m_run[u] - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
+        const float l = l_run[u] * a0 + l1 * a1;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        if (qo >= a.Lq) continue;
+        float *rowp = a.out + (b * a.q_batch_rows + qo) * a.ldo;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            float v4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = (o[u][db][r] * a0 + x[(2 + db * 4 + r) * 64] * a1) * inv;
+            // positions (db & 1) * 16 + g * 4 + r of block (db >> 1) = columns {0, 16}[g & 1] + 4 * ((db & 1) * 2 + (g >> 1)) + r
+            const int col = h * HD + (db >> 1) * 32 + ((g & 1) ? 16 : 0) + 4 * ((db & 1) * 2 + (g >> 1));
+            if (a.out_packed) store_split4_attn(rowp, col, v4[0], v4[1], v4[2], v4[3]);
+            else *reinterpret_cast<float4 *>(rowp + col) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        }
+        if (a.lse && g == 0) a.lse[(b * a.q_batch_rows + qo) * a.H + h] = l > 0.f ? m + log2f(l) : -INFINITY;
+    }
+}
+
 // (Measured and not kept, round 3: a resident variant -- one 8-wave workgroup per (frame, head), all K / V converted once into 153 KiB of
 // LDS -- runs the frame encoder's 257 x 257 attention at the same 28 ms per step as this tiled kernel: the time is the per-group softmax /
 // split VALU work and the 3 x MFMAs, not the re-staging.)
@@ -870,14 +1217,34 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
     VS_CHECK(kv_seg || Lk > 0, "vs_attention: Lk must be positive when kv_seg is null");
     VS_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "vs_attention: row strides must be multiples of 8 elements");
     VS_CHECK(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "vs_attention: 16-byte alignment required");
-    const int out_packed = dtype == 20 ? 1 : 0;       // 4 + 16: split class with the output in the packed (hi, lo) form (ldo % 32 == 0, 128-byte aligned)
-    if (out_packed) dtype = 4;
-    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "vs_attention: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split: f32 data, 3 x f16 MFMA; 20 = 4 with a packed output)");
+    // split class (4): + 16 = the output in the packed (hi, lo) form (ldo % 32 == 0, 128-byte aligned); + 32 = q | k | v ALREADY packed
+    // (the qkv GEMM's RoPE epilogue wrote them so: vs_gemm_split(_packed) epilogue 4 + 16) -> attention_sp_kernel
+    const int out_packed = (dtype == 20 || dtype == 52) ? 1 : 0, in_packed = (dtype == 36 || dtype == 52) ? 1 : 0;
+    if (out_packed || in_packed) dtype = 4;
+    VS_CHECK(dtype == 1 || dtype == 2 || dtype == 3 || dtype == 4, "vs_attention: dtype must be 1 (f16), 2 (bf16), 3 (f32) or 4 (split: f32 data, 3 x f16 MFMA; + 16 packed output, + 32 packed q | k | v)");
     VS_CHECK(!out_packed || (ldo % 32 == 0 && ((uintptr_t)out & 127) == 0), "vs_attention: a packed output needs ldo %% 32 == 0 and a 128-byte aligned buffer");
     VS_CHECK(H <= 65535 && nbatch <= 65535, "vs_attention: grid too large");
     if (nbatch == 0 || Lq == 0) return 0;
     if (dtype == 4) {
         VS_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, "vs_attention: split operands need 16-byte aligned f32 rows");
+        if (in_packed) {
+            VS_CHECK(ldq % 32 == 0 && ldk % 32 == 0 && ldv % 32 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 127) == 0,
+                     "vs_attention: packed q | k | v need row strides that are multiples of 32 (4-byte units) and 128-byte aligned head-0 columns");
+            AttnArgsSP f;
+            f.q = (const unsigned char *)q; f.k = (const unsigned char *)k; f.v = (const unsigned char *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;
+            static const int ng = [] { const char *e = getenv("VS_ATTN_SP_NG"); return e ? atoi(e) : 3; }();
+            f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.nqt = vs::cdiv(Lq, 32 * ng); f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
+            f.ldq_b = 4LL * ldq; f.ldk_b = 4LL * ldk; f.ldv_b = 4LL * ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse;
+            f.out_packed = out_packed;
+            { static const int dbg = [] { const char *e = getenv("VS_ATTN_DBG"); return e ? atoi(e) : 0; }(); f.dbg = dbg; }
+            const long long nwg = (long long)f.nqt * H * nbatch;
+            VS_CHECK(nwg < (1LL << 31), "vs_attention: grid too large");
+            if (ng == 4) hipLaunchKernelGGL(attention_sp_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
+            else if (ng == 2) hipLaunchKernelGGL(attention_sp_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
+            else hipLaunchKernelGGL(attention_sp_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
+            VS_HIP(hipGetLastError());
+            return 0;
+        }
         AttnArgsSplit f;
         f.q = (const float *)q; f.k = (const float *)k; f.v = (const float *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;
         f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;

@@ -725,11 +725,11 @@ extern "C" int vs_gemm_split(const float *A, const void *Wp, float acc_scale, co
                              int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out,
                              int32_t a_grp_off, const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d,
                              vs_stream_t stream_) {
-    const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3), the A operand of vs_gemm_split_packed
+    const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3: the A operand of vs_gemm_split_packed; 4: q | k | v for vs_attention dtype 4 + 32)
     epilogue &= ~16;
     VS_CHECK(epilogue >= 0 && epilogue <= 4, "vs_gemm_split: unknown epilogue %d", epilogue);
-    VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
-             "vs_gemm_split: a packed output needs epilogue 0 / 1 / 3, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
+    VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3 || epilogue == 4) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
+             "vs_gemm_split: a packed output needs epilogue 0 / 1 / 3 / 4, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
     VS_CHECK(epilogue != 4 || (pos && C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0 && base2d > 0.f && theta1d > 0.f),
              "vs_gemm_split: the RoPE epilogue needs pos, C %% 64 == 0, N >= 2C, positive bases");
     VS_CHECK(acc_scale > 0.f, "vs_gemm_split: acc_scale must be positive");
@@ -745,11 +745,11 @@ extern "C" int vs_gemm_split_packed(const void *Ap, const void *Wp, float acc_sc
                                     int32_t grp_out, int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out,
                                     int32_t a_grp_off, const int32_t *pos, const uint8_t *kind, int32_t C, float base2d, float theta1d,
                                     vs_stream_t stream_) {
-    const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3), the A operand of vs_gemm_split_packed
+    const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3: the A operand of vs_gemm_split_packed; 4: q | k | v for vs_attention dtype 4 + 32)
     epilogue &= ~16;
     VS_CHECK(epilogue >= 0 && epilogue <= 4, "vs_gemm_split_packed: unknown epilogue %d", epilogue);
-    VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
-             "vs_gemm_split_packed: a packed output needs epilogue 0 / 1 / 3, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
+    VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3 || epilogue == 4) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
+             "vs_gemm_split_packed: a packed output needs epilogue 0 / 1 / 3 / 4, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
     VS_CHECK(epilogue != 4 || (pos && C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0 && base2d > 0.f && theta1d > 0.f),
              "vs_gemm_split_packed: the RoPE epilogue needs pos, C %% 64 == 0, N >= 2C, positive bases");
     VS_CHECK(acc_scale > 0.f, "vs_gemm_split_packed: acc_scale must be positive");

@@ -145,6 +145,26 @@ __device__ __forceinline__ void store_split4(float *row, int n, float a, float b
     *reinterpret_cast<uint2 *>(o) = make_uint2(h[0], h[1]);
     *reinterpret_cast<uint2 *>(o + 32) = make_uint2(l[0], l[1]);
 }
+// Columns n .. n + 3 and n + 16 .. n + 19 (n % 32 < 16, n % 4 == 0) of a row: together they are ONE 16-byte chunk of hi halves and one of lo
+// halves (chunk g = (n & 15) >> 2 holds exactly these eight columns), so the pair leaves as two 16-byte stores -- the same number of store
+// instructions as the f32 row (round 4: store_split4 per fragment was two 8-byte stores each, and the GEMM store tail is issue-bound).
+__device__ __forceinline__ void store_split8(float *row, int n, const float (&a)[4], const float (&b)[4]) {
+    unsigned h[4], l[4];
+    float r[8];
+    h[0] = cvt_pk_f16(a[0], a[1]); h[1] = cvt_pk_f16(a[2], a[3]); h[2] = cvt_pk_f16(b[0], b[1]); h[3] = cvt_pk_f16(b[2], b[3]);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(h[0]), "v"(a[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(h[0]), "v"(a[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[2]) : "v"(h[1]), "v"(a[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[3]) : "v"(h[1]), "v"(a[3]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[4]) : "v"(h[2]), "v"(b[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[5]) : "v"(h[2]), "v"(b[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[6]) : "v"(h[3]), "v"(b[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[7]) : "v"(h[3]), "v"(b[3]));
+    l[0] = cvt_pk_f16(r[0], r[1]); l[1] = cvt_pk_f16(r[2], r[3]); l[2] = cvt_pk_f16(r[4], r[5]); l[3] = cvt_pk_f16(r[6], r[7]);
+    unsigned short *o = reinterpret_cast<unsigned short *>(row + (n & ~31)) + ((n & 15) >> 2) * 8;
+    *reinterpret_cast<uint4 *>(o) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4 *>(o + 32) = make_uint4(l[0], l[1], l[2], l[3]);
+}
 // max(x, 0) of an f32 value whose result goes to LDS / memory (one VALU; inline asm: see split8 for why not in front of an MFMA)
 __device__ __forceinline__ unsigned relu_f32_lds(unsigned x) {
     unsigned r;
@@ -538,9 +558,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                         }
                     } else {
                         if (BF16 == kDtSplit && g.out_packed) {
-                            float *rowp = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo;
+                            float *rowp = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo;   // (nbase % 64 == 0: fragments j, j + 1 share a chunk)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) store_split4(rowp, nbase + c4 + j * 16, v[j][0], v[j][1], v[j][2], v[j][3]);
+                            for (int j = 0; j < 4; j += 2) store_split8(rowp, nbase + c4 + j * 16, v[j], v[j + 1]);
                         } else {
                             float *dst = reinterpret_cast<float *>(g.out) + orow[i] * g.ldo + nbase + c4;
 #pragma unroll

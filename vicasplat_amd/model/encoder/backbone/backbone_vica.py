@@ -23,7 +23,12 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+import os
+
 from .... import ops
+
+# A/B switch of the packed q | k | v route of the split class (VS_ATTN_PACKED=0: f32 q | k | v + attention_split_kernel, the round-3 path)
+_ATTN_PACKED = os.environ.get("VS_ATTN_PACKED", "1") != "0"
 
 
 class _Mlp(nn.Module):
@@ -243,14 +248,19 @@ class VicaNet(nn.Module):
         # split class: activations that only feed a GEMM (LayerNorm outputs, the MLP's hidden layer) are written by their producer in the
         # packed (hi, lo) form, so the consuming GEMM's main loop has no conversion to do (ops.split_act; +15-20 % on these GEMMs)
         act = (lambda r, c: ops.split_act(r, c, dev)) if self.split else (lambda r, c: torch.empty(r, c, **f16))
+        # split class, round 4: q | k | v leave the projection's RoPE epilogue in the packed (hi, lo) form as well and the attention kernel
+        # stages them by LDS-DMA without converting anything (ops.attention on int32 slices -> attention_sp_kernel)
+        qkv_packed = self.split and _ATTN_PACKED
+        qact = act if qkv_packed else (lambda r, c: torch.empty(r, c, **f16))
+        cols3 = lambda t, C_: ((t.data if qkv_packed else t)[:, :C_], (t.data if qkv_packed else t)[:, C_:2 * C_], (t.data if qkv_packed else t)[:, 2 * C_:])
         h = act(BT * N, Ce)
-        qkv = torch.empty(BT * N, 3 * Ce, **f16)
+        qkv = qact(BT * N, 3 * Ce)
         att = act(BT * N, Ce)
         hid = act(BT * N, int(Ce * cfg.mlp_ratio))
         for i, blk in enumerate(self.enc_blocks):
             ops.layernorm_mod(xe, blk.norm1.weight, blk.norm1.bias, h)
             ops.gemm_qkv_rope(h, W[f"e{i}.qkv"], blk.attn.qkv.bias, qkv, Ce, tabs["pos_img"], None, 100.0, 1.0)
-            ops.attention(qkv[:, :Ce], qkv[:, Ce:2 * Ce], qkv[:, 2 * Ce:], att, nbatch=BT, H=He, Lq=N, Lk=N, q_batch_rows=N, k_batch_rows=N, split=self.split)
+            ops.attention(*cols3(qkv, Ce), att, nbatch=BT, H=He, Lq=N, Lk=N, q_batch_rows=N, k_batch_rows=N, split=self.split)
             ops.gemm(att, W[f"e{i}.proj"], blk.attn.proj.bias, xe, ops.EPI_RESID32)
             ops.layernorm_mod(xe, blk.norm2.weight, blk.norm2.bias, h)
             ops.gemm(h, W[f"e{i}.fc1"], blk.mlp.fc1.bias, hid, ops.EPI_GELU16)
@@ -271,10 +281,10 @@ class VicaNet(nn.Module):
         cam = torch.cat([ti.expand(B, 1, Cd), (ti + te).expand(B, T - 1, Cd)], 1).reshape(BT, Cd).contiguous()
         M2 = N + 1  # rows per frame in the interleaved buffer
         hmix = act(BT * M2, Cd)
-        qkvm = torch.empty(BT * M2, 3 * Cd, **f16)
+        qkvm = qact(BT * M2, 3 * Cd)
         attm = act(BT * M2, Cd)
         h = act(BT * N, Cd)
-        qkv = torch.empty(BT * N, 3 * Cd, **f16)
+        qkv = qact(BT * N, 3 * Cd)
         att = act(BT * N, Cd)
         hid = act(BT * N, int(Cd * cfg.mlp_ratio))
         cn = torch.empty(BT, Cd, **f32)
@@ -295,7 +305,7 @@ class VicaNet(nn.Module):
             else:
                 hmix.view(BT, M2, Cd)[:, 0] = cn.to(dt)
             ops.gemm_qkv_rope(hmix, W[f"d{i}.qkv"], blk.attn.qkv.bias, qkvm, Cd, tabs["pos_mix"], tabs["kind_mix"], 100.0, theta)
-            ops.attention(qkvm[:, :Cd], qkvm[:, Cd:2 * Cd], qkvm[:, 2 * Cd:], attm, nbatch=B, H=Hd, Lq=T * M2, Lk=T * M2,
+            ops.attention(*cols3(qkvm, Cd), attm, nbatch=B, H=Hd, Lq=T * M2, Lk=T * M2,
                           q_batch_rows=T * M2, k_batch_rows=T * M2, q_kvlen=tabs["kvlen"], split=self.split)
             ops.gemm(attm, W[f"d{i}.proj"], blk.attn.proj.bias, xd, ops.EPI_RESID32, gate=mod1[:, 2 * Cd:], gate_rows=N,
                      M=BT * N, a_grp_in=N, a_grp_out=M2, a_grp_off=1)
@@ -307,7 +317,7 @@ class VicaNet(nn.Module):
             # -- cross-neighbour attention (:152-191): keys/values of frames t-1, t+1 gathered by row segments
             ops.layernorm_mod(xd, blk.norm2.weight, blk.norm2.bias, h, scale=mod2[:, :Cd], shift=mod2[:, Cd:2 * Cd], mod_rows=N)
             ops.gemm_qkv_rope(h, W[f"d{i}.cqkv"], W[f"d{i}.cqkv_b"], qkv, Cd, tabs["pos_img"], None, 100.0, 1.0)
-            ops.attention(qkv[:, :Cd], qkv[:, Cd:2 * Cd], qkv[:, 2 * Cd:], att, nbatch=BT, H=Hd, Lq=N, q_batch_rows=N, kv_seg=tabs["seg"], split=self.split)
+            ops.attention(*cols3(qkv, Cd), att, nbatch=BT, H=Hd, Lq=N, q_batch_rows=N, kv_seg=tabs["seg"], split=self.split)
             ops.gemm(att, W[f"d{i}.cproj"], blk.cross_attn.proj.bias, xd, ops.EPI_RESID32, gate=mod2[:, 2 * Cd:3 * Cd], gate_rows=N)
             # -- MLPs (:323-333); the camera MLP reads cam_norm2(cam), not a fresh norm
             ops.layernorm_mod(xd, blk.norm3.weight, blk.norm3.bias, h, scale=mod2[:, 3 * Cd:4 * Cd], shift=mod2[:, 4 * Cd:5 * Cd], mod_rows=N)

@@ -260,7 +260,7 @@ def _gemm_split(a, w: SplitWeight, bias, out, epilogue, *, gate=None, gate_rows=
         a = a.data
     out_obj = out
     if isinstance(out, SplitWeight):          # packed output (epilogues 0 / 1 / 3): the A operand of the next GEMM, written by this one's epilogue
-        assert out.acc_scale == 1.0 and epilogue in (EPI_STORE16, EPI_GELU16, EPI_STORE32) and out.data.dtype == torch.int32
+        assert out.acc_scale == 1.0 and epilogue in (EPI_STORE16, EPI_GELU16, EPI_STORE32, 4) and out.data.dtype == torch.int32
         out, epilogue = out.data.view(torch.float32), epilogue | 16
     dev = L.require_device(a, wd, bias, out, gate, resid, pos, kind)
     assert a.dtype == (torch.int32 if packed else torch.float32) and out.dtype == torch.float32 and a.dim() == 2 and wd.dim() == 2 and a.stride(1) == 1
@@ -339,25 +339,31 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               split: bool = False) -> torch.Tensor:
     """q/k/v: 2-D views [rows, ld] whose column 0 is head 0 (e.g. slices of a packed q|k|v buffer); out [rows, H*64].
     lse (optional, f32 [rows, H] contiguous) receives the log2-domain logsumexp for attention_backward.
-    split=True (f32 tensors only): the split operand class -- three f16 MFMAs per product instead of the exact-f32 MFMA (dtype code 4)."""
+    split=True (f32 tensors only): the split operand class -- three f16 MFMAs per product instead of the exact-f32 MFMA (dtype code 4).
+    q, k, v int32 (column slices of the `.data` of a packed (hi, lo) q|k|v buffer, written by gemm_qkv_rope(..., out=split_act(...))):
+    the packed-input kernel (dtype 4 + 32: LDS-DMA staging without conversion, key-split waves, XCD-aware grid)."""
     out_obj, out_packed = out, isinstance(out, SplitWeight)
+    in_packed = q.dtype == torch.int32
+    if in_packed:
+        assert split and k.dtype == torch.int32 and v.dtype == torch.int32
     if out_packed:          # split class: O written in the packed (hi, lo) form, the A operand of the projection GEMM as it is
         assert split and out.acc_scale == 1.0
         out = out.data.view(torch.float32)
     dev = L.require_device(q, k, v, out, kv_seg, q_kvlen, lse)
     for t in (q, k, v, out):
-        assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == q.dtype
+        assert t.dim() == 2 and t.stride(1) == 1 and (t.dtype == q.dtype or (in_packed and t is out))
     assert kv_seg is None or (kv_seg.dtype == torch.int32 and kv_seg.is_contiguous())
     assert q_kvlen is None or (q_kvlen.dtype == torch.int32 and q_kvlen.is_contiguous())
     assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (q.shape[0], H))
-    assert not split or q.dtype == torch.float32
+    assert not split or q.dtype == torch.float32 or in_packed
     if split and RANGE_GUARD.enabled:
         for nm_, t_ in (("q", q), ("k", k), ("v", v)):
-            RANGE_GUARD.check(f"attention {nm_} (H {H}, Lq {Lq})", t_, cols=H * 64)
+            RANGE_GUARD.check(f"attention {nm_} (H {H}, Lq {Lq})", SplitWeight(t_, 1.0, t_.shape) if in_packed else t_, cols=H * 64)
     with torch.cuda.device(dev):
         rc = L.lib().vs_attention_lse(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nbatch, H, Lq, Lk, q_batch_rows, k_batch_rows,
                                       q.stride(0), k.stride(0), v.stride(0), out.stride(0), L.ptr(kv_seg), L.ptr(q_kvlen), scale,
-                                      (20 if out_packed else 4) if split else _DTX[q.dtype], L.ptr(lse), L.stream_ptr(dev))
+                                      (4 + (16 if out_packed else 0) + (32 if in_packed else 0)) if split else _DTX[q.dtype], L.ptr(lse),
+                                      L.stream_ptr(dev))
     L.check(rc, "vs_attention")
     return out_obj
 
