@@ -58,6 +58,22 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return r;
 }
 
+// The same convert for a value that goes STRAIGHT INTO AN MFMA: compiler-visible instructions, so that the hazard recogniser inserts the
+// VALU-write -> MFMA-read wait states (it does not look inside inline asm).  Round 4: attention_sp_kernel's third query group came out
+// 5e-5 off with the asm form whenever the scheduler placed a P V MFMA right behind the convert; the older kernels used the asm form for
+// their P fragments too and were only protected by what happened to be scheduled in between.
+template <bool BF16>
+__device__ __forceinline__ unsigned pack2v(float a, float b) {
+    typedef float f2p_ __attribute__((ext_vector_type(2)));
+    if constexpr (BF16) {
+        typedef __bf16 b2p_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2p_{a, b}, b2p_));
+    } else {
+        typedef _Float16 h2p_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2p_{a, b}, h2p_));
+    }
+}
+
 template <bool BF16>
 __device__ __forceinline__ unsigned short to16(float v) {
     return (unsigned short)(pack2<BF16>(v, 0.f) & 0xFFFFu);
@@ -136,12 +152,13 @@ __device__ __forceinline__ void softmax_tile(f4 (&st)[4], float scale_log2e, flo
         m_run = m_new;
     }
     l_run += rs;
+    // (pack2v: compiler-visible converts -- these registers are MFMA operands, see pack2v)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        pf[ks].x = pack2<BF16>(st[2 * ks][0], st[2 * ks][1]);
-        pf[ks].y = pack2<BF16>(st[2 * ks][2], st[2 * ks][3]);
-        pf[ks].z = pack2<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
-        pf[ks].w = pack2<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+        pf[ks].x = pack2v<BF16>(st[2 * ks][0], st[2 * ks][1]);
+        pf[ks].y = pack2v<BF16>(st[2 * ks][2], st[2 * ks][3]);
+        pf[ks].z = pack2v<BF16>(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+        pf[ks].w = pack2v<BF16>(st[2 * ks + 1][2], st[2 * ks + 1][3]);
     }
 }
 
@@ -730,7 +747,6 @@ struct AttnArgsSP {
     float scale_log2e;
     float *lse;
     int out_packed;
-    int dbg;   // TEMP experiment switch
 };
 
 typedef void __attribute__((address_space(3))) *lds_ptr_sp_t;
@@ -738,7 +754,14 @@ __device__ __forceinline__ void glds16_sp(const void *gp, unsigned lds_off) {   
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_off), "v"(gp) : "memory");
 }
 
-// online-softmax step of one 16-query group over this wave's 32 keys of a tile (softmax_tile for two 16-key blocks)
+// online-softmax step of one 16-query group over this wave's 32 keys of a tile (softmax_tile for two 16-key blocks).  VALU work does NOT
+// hide under MFMAs on gfx950 (tools/probe/mfma_valu_overlap.hip: an MFMA-only wave and an FMA-only wave sharing a SIMD take the SUM of
+// their times; only transcendentals overlap), so every instruction here is paid for in full:
+//   * l_run is a PER-LANE partial sum (the lane's own keys): the maximum is made uniform over the four lanes of a query column every
+//     tile, so the rescale factor is uniform too and the cross-lane row sum can wait for the end of the kernel (one rows_sum per query
+//     group instead of one per tile);
+//   * MASKED = false: every score is finite, the running maximum is finite after the first tile: no -inf guard.
+template <bool MASKED>
 __device__ __forceinline__ void softmax_half(f4 (&st)[2], float scale_log2e, float &m_run, float &l_run, f4 (&o)[4], uint4 &pf) {
     float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
     mx = fmaxf(fmaxf(mx, st[0][3]), st[1][0]);
@@ -746,7 +769,7 @@ __device__ __forceinline__ void softmax_half(f4 (&st)[2], float scale_log2e, flo
     mx = fmaxf(mx, st[1][3]);
     mx = rows_max(mx) * scale_log2e;
     const float m_new = vmax2(m_run, mx);
-    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float m_use = (MASKED && m_new == -INFINITY) ? 0.f : m_new;
     const f2v sc = f2v{scale_log2e, scale_log2e}, neg_m = f2v{-m_use, -m_use};
     f2v acc = f2v{0.f, 0.f};
 #pragma unroll
@@ -760,7 +783,6 @@ __device__ __forceinline__ void softmax_half(f4 (&st)[2], float scale_log2e, flo
             st[nb][2 * h] = p.x; st[nb][2 * h + 1] = p.y;
             acc += p;
         }
-    const float rs = rows_sum(acc.x + acc.y);
     if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         l_run *= alpha;
@@ -768,11 +790,16 @@ __device__ __forceinline__ void softmax_half(f4 (&st)[2], float scale_log2e, flo
         for (int db = 0; db < 4; ++db) o[db] *= alpha;
         m_run = m_new;
     }
-    l_run += rs;
-    pf.x = pack2<false>(st[0][0], st[0][1]);
-    pf.y = pack2<false>(st[0][2], st[0][3]);
-    pf.z = pack2<false>(st[1][0], st[1][1]);
-    pf.w = pack2<false>(st[1][2], st[1][3]);
+    l_run += acc.x + acc.y;
+    // COMPILER-VISIBLE converts: pf feeds the P V MFMAs, and the VALU-write -> MFMA-read wait states come from the compiler's hazard
+    // recogniser, which does not look inside inline asm (pack2<> is asm: with it the third query group's rows came out 5e-5 off whenever the
+    // scheduler placed its first P V MFMA right behind the convert -- the bug class of gemm_common.h split8 / relu_f32_lds, met again here)
+    typedef _Float16 h2s_ __attribute__((ext_vector_type(2)));
+    typedef float f2s_ __attribute__((ext_vector_type(2)));
+    pf.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f2s_{st[0][0], st[0][1]}, h2s_));
+    pf.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f2s_{st[0][2], st[0][3]}, h2s_));
+    pf.z = __builtin_bit_cast(unsigned, __builtin_convertvector(f2s_{st[1][0], st[1][1]}, h2s_));
+    pf.w = __builtin_bit_cast(unsigned, __builtin_convertvector(f2s_{st[1][2], st[1][3]}, h2s_));
 }
 
 // One tile of one wave: its 32 keys (rows kw .. kw + 31 of the staged tile) against its 64 queries.  Straight-line code: ALLQ (all four
@@ -809,7 +836,7 @@ __device__ __forceinline__ void sp_tile(const unsigned char *sK, const unsigned 
                 for (int r = 0; r < 4; ++r)
                     if (nb * 16 + r >= lim) st[u][nb][r] = -INFINITY;
         }
-        softmax_half(st[u], scale_log2e, m_run[u], l_run[u], o[u], pfh[u]);     // st now holds P (f32), pfh its rne16
+        softmax_half<MASKED>(st[u], scale_log2e, m_run[u], l_run[u], o[u], pfh[u]);     // st now holds P (f32), pfh its rne16
         const unsigned hh[4] = {pfh[u].x, pfh[u].y, pfh[u].z, pfh[u].w};
         unsigned ll[4];
 #pragma unroll
@@ -913,11 +940,14 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
     }
     wave_len = __builtin_amdgcn_readfirstlane(wave_len);
     wave_min = __builtin_amdgcn_readfirstlane(wave_min);     // the shortest key list among the wave's 64 query slots (0 with a missing query)
-    if (tid == 0) s_maxlen = 0;
-    __syncthreads();
-    if (lane == 0) atomicMax(&s_maxlen, wave_len);
-    __syncthreads();
-    const int maxlen = s_maxlen;
+    int maxlen = Lk;                                         // keys the workgroup has to stage: all of them unless every query has a shorter prefix
+    if (a.q_kvlen) {                                         // (kernel-uniform)
+        if (tid == 0) s_maxlen = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(&s_maxlen, wave_len);
+        __syncthreads();
+        maxlen = s_maxlen;
+    }
 
     f4 o[NG][4];
     float m_run[NG], l_run[NG];
@@ -940,7 +970,6 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
         return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
     };
     auto issue = [&](int kt, int slot) {
-        if (a.dbg & 2) return;
         const unsigned ldsk = lds0 + (unsigned)(slot * 2) * TILE_B + (unsigned)wid * 1024u, ldsv = ldsk + TILE_B;
         long long rowbase = -1;                  // whole tile inside one segment (and inside the list): rows are base + r
         if (kt + KB <= len0) rowbase = (long long)base0 + kt;
@@ -962,11 +991,6 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
         }
     };
     if (maxlen > 0) issue(0, 0);
-    if (a.dbg & 4) {   // TEMP: stagger the two co-resident workgroups by about half a tile
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (((hwid >> 16) ^ hwid) & 1) for (int i_ = 0; i_ < (a.dbg >> 3); ++i_) __builtin_amdgcn_s_sleep(4);     // 4 x 64 cycles per trip
-    }
 
     // ---- loop-invariant LDS offsets of this lane's fragments (bytes inside a K / V tile, swizzle applied)
     const int kw = kh * 32;                       // this wave's keys inside a tile
@@ -983,7 +1007,6 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
     const bool allq = nact == NG;
     auto tile = [&](int kt, const unsigned char *sK, const unsigned char *sV) {
         const int kb = kt + kw;
-        if (a.dbg & 1) return;
         if (kb >= wave_len) return;                          // none of this wave's queries sees any of its keys of this tile
         const bool masked = kb + 32 > wave_min;              // (wave-uniform)
         if (allq) {
@@ -1006,6 +1029,8 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
     }
 
     // ---- merge the two key halves of every query (once): the kh = 1 wave hands (m, l, O) to its kh = 0 partner through LDS
+#pragma unroll
+    for (int u = 0; u < NG; ++u) l_run[u] = rows_sum(l_run[u]);       // the per-lane partial sums of a query column meet here, once
     __syncthreads();
     float *xch = reinterpret_cast<float *>(&smem[0][0][0]) + qh * (18 * 64 * 4);      // [u][m | l | 16 x O][lane]: 18 KiB per query half
     if (kh == 1) {
@@ -1236,7 +1261,6 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
             f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.nqt = vs::cdiv(Lq, 32 * ng); f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
             f.ldq_b = 4LL * ldq; f.ldk_b = 4LL * ldk; f.ldv_b = 4LL * ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse;
             f.out_packed = out_packed;
-            { static const int dbg = [] { const char *e = getenv("VS_ATTN_DBG"); return e ? atoi(e) : 0; }(); f.dbg = dbg; }
             const long long nwg = (long long)f.nqt * H * nbatch;
             VS_CHECK(nwg < (1LL << 31), "vs_attention: grid too large");
             if (ng == 4) hipLaunchKernelGGL(attention_sp_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
