@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--train-split-scenes", type=int, default=8, help="scenes per GPU of the reference-precision (split class) training leg: f32 "
                     "activations double the footprint of the 16-bit step (24 scenes: 158 GB), so the secondary leg runs a third of the batch")
     ap.add_argument("--no-train-split", action="store_true", help="skip the split-class training leg")
+    ap.add_argument("--no-train-split24", action="store_true", help="skip the 24-scene checkpointed split-class training leg")
     ap.add_argument("--train-timeout", type=float, default=240.0, help="seconds after which a stalled training leg is abandoned and the headline line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -102,7 +103,7 @@ class KernelTimer:
         return out
 
 
-def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, steps=None):
+def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, steps=None, checkpoint=False):
     """BASELINE configs 4 / 5: the full training step -- encoder + decoder + rasterizer forward, MSE, backward on the HIP kernels,
     gradient exchange (GradReducer: bucketed all-reduce over RCCL overlapped with backward; N > 1 only), clip 0.5, AdamW -- on
     `--train-scenes-per-gpu` 8-view scenes with `--targets` target views each (re10k_8view.yaml:19-20).  Timed like the headline:
@@ -122,6 +123,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     target = torch.rand(B, Vt, 3, 256, 256, generator=gen).to(dev)
     batch = dict(context=dict(image=img.to(dev), intrinsics=K.to(dev)), target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
     enc.train().requires_grad_(True)
+    enc.backbone.gradient_checkpointing = bool(checkpoint)      # enable_gradient_checkpointing(): per-block recomputation (backbone_vica.py:464-516)
     opt, _ = callers.configure_optimizer(enc, lr=1e-12)
     reducer = vdist.GradReducer(enc.parameters()) if world > 1 else None
     torch.cuda.empty_cache()
@@ -146,6 +148,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     flops = 3.0 * 3407e9 * (V / 8.0) * B
     tf_s = flops / (ms * 1e-3) / 1e12
     enc.eval().requires_grad_(False)
+    enc.backbone.gradient_checkpointing = False
     if reducer is not None:
         reducer.remove()
     for p in enc.parameters():
@@ -153,7 +156,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     return dict(metric="scenes/sec training step (fwd+bwd+clip+AdamW)", value=round(world * B / (ms * 1e-3), 3), unit="scenes/s",
                 ms_per_step=round(ms, 2), steps=nsteps, scenes_per_gpu=B, context_views=V, target_views=Vt,
                 dtype=("split (f32 activations and gradients, 3 x f16 MFMA per product, forward and backward)" if dt == "split" else "bf16" if dt == torch.bfloat16 else "f16"),
-                loss_scale=float(r["loss_scale"]),
+                loss_scale=float(r["loss_scale"]), gradient_checkpointing=bool(checkpoint),
                 loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
                 peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                 gradient_exchange=("none (1 GPU)" if world == 1 else f"GradReducer: 64 MiB buckets all-reduced during backward, RCCL x{world}"),
@@ -620,6 +623,14 @@ def main():
                         train["split_class"] = train_leg(args, enc, dec, dev, rank, world, None, cdt="split", scenes=args.train_split_scenes, steps=2)
                     except Exception as e:
                         train["split_class"] = dict(error=repr(e)[:300])
+                    # BASELINE config 5's per-GPU batch at the reference's precision (VERDICT r3 "missing 5"): 24 scenes only fit with
+                    # enable_gradient_checkpointing() (re10k_8view.yaml:19-20,61; the reference trains with it on)
+                    if args.train_scenes_per_gpu == 24 and not args.no_train_split24:
+                        try:
+                            train["split_class_batch24_checkpointed"] = train_leg(args, enc, dec, dev, rank, world, None, cdt="split", scenes=24, steps=2,
+                                                                                   checkpoint=True)
+                        except Exception as e:
+                            train["split_class_batch24_checkpointed"] = dict(error=repr(e)[:300])
         except Exception as e:      # the headline line must survive a failure of the optional training leg
             if args.mode == "train":
                 raise

@@ -750,15 +750,18 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
 // were measured at 18 ms against 7.0 for the blocks: the broadcast reads turn into bank-conflicted gathers.)  Semantics are those of upstream's per-pixel loop: identical skip / stop thresholds,
 // `contributor` counts every list entry, so final_T / n_contrib match the oracle.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kRenderRecsPerThread = 1;   // (2 = 512-entry batches: measured 11 % slower, the LDS costs occupancy)
-
-template <bool COUNT_TOUCHED>
-__global__ void __launch_bounds__(256)
+// NW = waves per tile.  4 (the product path): a wave per 8x8 quadrant.  1 (round 4, the north star's "one wavefront per tile", built for
+// the A/B VERDICT r3 asked for): ONE wave walks the four quadrants of the tile in turn -- four pixels per lane, one per quadrant -- so a
+// staged record's footprint test is read from LDS once per tile instead of once per quadrant-wave, the batch barriers are wave-local, and
+// a tile occupies one wave slot (12 tiles per CU by LDS instead of 3-4 workgroups of four waves).  Same arithmetic, same order per pixel:
+// bit-identical output (tests/test_raster_gpu.py runs both).  Measured: see DESIGN 5.
+template <bool COUNT_TOUCHED, int NW>
+__global__ void __launch_bounds__(64 * NW)
 render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ background, float *__restrict__ out_color,
               float *__restrict__ out_depth, float *__restrict__ out_opacity, float *__restrict__ final_T,
               int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched) {
-    constexpr int RPT = kRenderRecsPerThread, NT = 256 * RPT;   // staged batch: RPT records per thread
+    constexpr int NTHR = 64 * NW, NT = 256, RPT = NT / NTHR, NQ = 4 / NW;   // staged batch: 256 records, RPT per thread; NQ quadrants per wave
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
     __shared__ uint32_t sid[NT];
     const int gx = (W + kTile - 1) / kTile;
@@ -769,35 +772,46 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     const int tile = t_lin - c * tiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile_x = tile % gx, tile_y = tile / gx;
-    const int qx0 = tile_x * kTile + (wid & 1) * 8, qy0 = tile_y * kTile + (wid >> 1) * 8;
-    const int sb = lane >> 2;                                    // this lane's 2x2 pixel block inside the wave's 8x8 quadrant (4 x 4 blocks)
+    const int sb = lane >> 2;                                    // this lane's 2x2 pixel block inside an 8x8 quadrant (4 x 4 blocks)
     const int bxi = sb & 3, byi = sb >> 2;
-    const int pxi = qx0 + bxi * 2 + (lane & 1), pyi = qy0 + byi * 2 + ((lane >> 1) & 1);
-    const float pixfx = (float)pxi, pixfy = (float)pyi;
-    const float bcx = (float)qx0 + 0.5f, bcy = (float)qy0 + 0.5f;  // centre of block column / row 0; 2 px apart, half size 0.5 px
+    int pxi[NQ], pyi[NQ];
+    float pixfx[NQ], pixfy[NQ], bcx[NQ], bcy[NQ];
+    bool inside[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int quad = NW == 4 ? wid : q;
+        const int qx0 = tile_x * kTile + (quad & 1) * 8, qy0 = tile_y * kTile + (quad >> 1) * 8;
+        pxi[q] = qx0 + bxi * 2 + (lane & 1); pyi[q] = qy0 + byi * 2 + ((lane >> 1) & 1);
+        pixfx[q] = (float)pxi[q]; pixfy[q] = (float)pyi[q];
+        bcx[q] = (float)qx0 + 0.5f; bcy[q] = (float)qy0 + 0.5f;  // centre of block column / row 0; 2 px apart, half size 0.5 px
+        inside[q] = pxi[q] < W && pyi[q] < H;
+    }
     const int2 rg = ranges[(size_t)c * tiles + tile];
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
     const uint32_t *__restrict__ plist = point_list + rg.x;
-    const bool inside = pxi < W && pyi < H;
     const int n = rg.y - rg.x;
 
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f;
-    int last_contrib = 0;
-    bool done = !inside;
+    float T[NQ], Cr[NQ], Cg[NQ], Cb[NQ], Dd[NQ], thr[NQ];
+    int last_contrib[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        T[q] = 1.0f; Cr[q] = Cg[q] = Cb[q] = Dd[q] = 0.f; last_contrib[q] = 0;
+        thr[q] = inside[q] ? 1.0f / 255.0f : __builtin_inff();   // alpha threshold: 1/255 while live, +inf once done / outside the image
+    }
 
     // pipeline registers: records (and id) of the batch that is staged next, id of the batch after it
     uint32_t g_cur[RPT], g_nxt[RPT];
     float4 r0[RPT], r1[RPT], r2[RPT];
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
-        const int e = u * 256 + tid;
+        const int e = u * NTHR + tid;
         g_cur[u] = e < n ? plist[e] : 0u;
         g_nxt[u] = NT + e < n ? plist[NT + e] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
         r0[u] = r1[u] = r2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u * 256 + tid < n) {
+        if (u * NTHR + tid < n) {
             r0[u] = g4[(size_t)g_cur[u] * 3 + 0];
             r1[u] = g4[(size_t)g_cur[u] * 3 + 1];
             r2[u] = g4[(size_t)g_cur[u] * 3 + 2];
@@ -814,33 +828,38 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     //   act   this lane's block has an entry in this trip (alpha forced to 0 otherwise);
     //   the accumulators take w = 0 in lanes where upstream's three conditions do not all hold: x + c*0 == x for the finite
     //   colours / depths preprocess writes, so those lanes are unchanged and the others see upstream's operations in its order.
-    float thr = done ? __builtin_inff() : 1.0f / 255.0f;
-    auto step = [&](int j, bool act) -> bool {
+    auto step = [&](int q, int j, bool act) -> bool {
         const float4 q0 = sq0[j];
         const float4 q1 = sq1[j];
         const float4 q2 = sq2[j];
-        const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+        const float dx = q0.x - pixfx[q], dy = q0.y - pixfy[q];
         const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
         float alpha = fminf(0.99f, q1.w * __expf(fminf(power, 0.0f)));
         alpha = (act && power <= 0.0f) ? alpha : 0.0f;   // upstream skips power > 0 (a NaN power compares false here too)
-        const bool pass = alpha >= thr;
-        const float test_T = T * (1.0f - alpha);
+        const bool pass = alpha >= thr[q];
+        const float test_T = T[q] * (1.0f - alpha);
         const bool go = pass && !(test_T < 0.0001f);
-        thr = (pass && !go) ? __builtin_inff() : thr;
-        const float w = go ? alpha * T : 0.0f;
-        Cr += q2.x * w; Cg += q2.y * w; Cb += q2.z * w;
-        Dd += q2.w * w;
-        T = go ? test_T : T;
-        last_contrib = go ? contributor + j + 1 : last_contrib;
+        thr[q] = (pass && !go) ? __builtin_inff() : thr[q];
+        const float w = go ? alpha * T[q] : 0.0f;
+        Cr[q] += q2.x * w; Cg[q] += q2.y * w; Cb[q] += q2.z * w;
+        Dd[q] += q2.w * w;
+        T[q] = go ? test_T : T[q];
+        last_contrib[q] = go ? contributor + j + 1 : last_contrib[q];
         return go && test_T > 0.5f;
+    };
+    auto lane_done = [&]() -> bool {
+        bool d = true;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) d = d && thr[q] > 1.0f;
+        return d;
     };
 
     for (int base = 0; base < n; base += NT) {
         // (also orders the previous batch's LDS reads before this batch's stores)
-        if (__syncthreads_count(thr > 1.0f) == NT) break;
+        if (__syncthreads_count(lane_done()) == NTHR) break;
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            const int e = u * 256 + tid;
+            const int e = u * NTHR + tid;
             if (base + e < n) {
                 sq0[e] = r0[u]; sq1[e] = r1[u]; sq2[e] = r2[u];
                 if (COUNT_TOUCHED) sid[e] = g_cur[u];
@@ -849,7 +868,7 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
-            const int e = u * 256 + tid;
+            const int e = u * NTHR + tid;
             g_cur[u] = g_nxt[u];
             if (base + NT + e < n) {
                 r0[u] = g4[(size_t)g_cur[u] * 3 + 0];
@@ -859,49 +878,53 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
             if (base + 2 * NT + e < n) g_nxt[u] = plist[base + 2 * NT + e];
         }
         const int cnt = min(NT, n - base);
-        if (!__all(thr > 1.0f)) {
+        if (!__all(lane_done())) {
             for (int j0 = 0; j0 < cnt; j0 += 64) {
                 const int je = j0 + lane;
-                // entry je against the four block columns and the four block rows: a block's mask is column-mask & row-mask
-                float tx = 0.f, ty = 0.f, ex = -1.f, ey = -1.f;
-                if (je < cnt) {
-                    const float4 t = sq0[je];
-                    tx = t.x - bcx; ty = t.y - bcy; ex = t.z + 0.5f; ey = t.w + 0.5f;
-                }
-                const unsigned long long mx0 = __ballot(fabsf(tx) <= ex), mx1 = __ballot(fabsf(tx - 2.0f) <= ex),
-                                         mx2 = __ballot(fabsf(tx - 4.0f) <= ex), mx3 = __ballot(fabsf(tx - 6.0f) <= ex);
-                const unsigned long long my0 = __ballot(fabsf(ty) <= ey), my1 = __ballot(fabsf(ty - 2.0f) <= ey),
-                                         my2 = __ballot(fabsf(ty - 4.0f) <= ey), my3 = __ballot(fabsf(ty - 6.0f) <= ey);
-                unsigned long long mine = ((bxi & 2) ? ((bxi & 1) ? mx3 : mx2) : ((bxi & 1) ? mx1 : mx0)) &
-                                          ((byi & 2) ? ((byi & 1) ? my3 : my2) : ((byi & 1) ? my1 : my0));
-                while (__any(mine != 0ull)) {
-                    const bool act = mine != 0ull;
-                    const int j = j0 + (act ? __builtin_ctzll(mine) : 0);
-                    mine &= mine - 1ull;
-                    const bool touched = step(j, act);
-                    if (COUNT_TOUCHED) {   // the sixteen blocks blend different entries: one count per block
-                        const int tot = __popcll(__ballot(touched) & (0xFull << (sb * 4)));
-                        if ((lane & 3) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+                float4 t = make_float4(0.f, 0.f, -1.5f, -1.5f);   // (extent -1: matches no block)
+                if (je < cnt) t = sq0[je];                          // read ONCE for all the quadrants of this wave
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (NQ > 1 && __all(thr[q] > 1.0f)) continue;  // this quadrant is finished
+                    // entry je against the four block columns and the four block rows: a block's mask is column-mask & row-mask
+                    const float tx = t.x - bcx[q], ty = t.y - bcy[q], ex = t.z + 0.5f, ey = t.w + 0.5f;
+                    const unsigned long long mx0 = __ballot(fabsf(tx) <= ex), mx1 = __ballot(fabsf(tx - 2.0f) <= ex),
+                                             mx2 = __ballot(fabsf(tx - 4.0f) <= ex), mx3 = __ballot(fabsf(tx - 6.0f) <= ex);
+                    const unsigned long long my0 = __ballot(fabsf(ty) <= ey), my1 = __ballot(fabsf(ty - 2.0f) <= ey),
+                                             my2 = __ballot(fabsf(ty - 4.0f) <= ey), my3 = __ballot(fabsf(ty - 6.0f) <= ey);
+                    unsigned long long mine = ((bxi & 2) ? ((bxi & 1) ? mx3 : mx2) : ((bxi & 1) ? mx1 : mx0)) &
+                                              ((byi & 2) ? ((byi & 1) ? my3 : my2) : ((byi & 1) ? my1 : my0));
+                    while (__any(mine != 0ull)) {
+                        const bool act = mine != 0ull;
+                        const int j = j0 + (act ? __builtin_ctzll(mine) : 0);
+                        mine &= mine - 1ull;
+                        const bool touched = step(q, j, act);
+                        if (COUNT_TOUCHED) {   // the sixteen blocks blend different entries: one count per block
+                            const int tot = __popcll(__ballot(touched) & (0xFull << (sb * 4)));
+                            if ((lane & 3) == 0 && tot > 0) atomicAdd(&n_touched[(size_t)c * P + sid[j]], tot);
+                        }
                     }
                 }
-                if (__all(thr > 1.0f)) break;
+                if (__all(lane_done())) break;
             }
         }
         contributor += cnt;
     }
 
-    if (inside) {
-        const float bgr = background[3 * c], bgg = background[3 * c + 1], bgb = background[3 * c + 2];
-        const size_t HW = (size_t)H * W;
-        const size_t pix = (size_t)pyi * W + pxi;
-        final_T[c * HW + pix] = T;
-        n_contrib[c * HW + pix] = last_contrib;
-        out_color[(c * 3 + 0) * HW + pix] = Cr + T * bgr;
-        out_color[(c * 3 + 1) * HW + pix] = Cg + T * bgg;
-        out_color[(c * 3 + 2) * HW + pix] = Cb + T * bgb;
-        out_depth[c * HW + pix] = Dd;
-        out_opacity[c * HW + pix] = 1.0f - T;
-    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (inside[q]) {
+            const float bgr = background[3 * c], bgg = background[3 * c + 1], bgb = background[3 * c + 2];
+            const size_t HW = (size_t)H * W;
+            const size_t pix = (size_t)pyi[q] * W + pxi[q];
+            final_T[c * HW + pix] = T[q];
+            n_contrib[c * HW + pix] = last_contrib[q];
+            out_color[(c * 3 + 0) * HW + pix] = Cr[q] + T[q] * bgr;
+            out_color[(c * 3 + 1) * HW + pix] = Cg[q] + T[q] * bgg;
+            out_color[(c * 3 + 2) * HW + pix] = Cb[q] + T[q] * bgb;
+            out_depth[c * HW + pix] = Dd[q];
+            out_opacity[c * HW + pix] = 1.0f - T[q];
+        }
 }
 
 }  // namespace
@@ -993,12 +1016,17 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     }
     const bool count = (in->flags & VS_RASTER_COUNT_TOUCHED) && out->n_touched;
     dim3 rgrid(tiles, C);
-    if (count)
-        hipLaunchKernelGGL((render_kernel<true>), rgrid, dim3(256), 0, stream, P, W, H, ranges, point_list, geom, in->background,
-                           out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched);
-    else
-        hipLaunchKernelGGL((render_kernel<false>), rgrid, dim3(256), 0, stream, P, W, H, ranges, point_list, geom, in->background,
-                           out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched);
+    // One wave per tile when there are enough tiles to fill the chip with single waves (>= 16 per CU: the batched bench / training calls),
+    // four waves per tile (a quadrant each) for small calls, where a tile's latency matters more than wave slots.  Same results either
+    // way (bit-identical); VS_RENDER_WAVES=1 | 4 forces one (A/B: DESIGN 5 -- 5.14 vs 5.20 ms on the 288-view bench step).
+    static const int force_waves = [] { const char *e = getenv("VS_RENDER_WAVES"); return e ? atoi(e) : 0; }();
+    const int render_waves = force_waves ? force_waves : ((long long)tiles * C >= 4096 ? 1 : 4);
+#define VS_RENDER(CNT_, NW_)                                                                                                         \
+    hipLaunchKernelGGL((render_kernel<CNT_, NW_>), rgrid, dim3(64 * NW_), 0, stream, P, W, H, ranges, point_list, geom, in->background, \
+                       out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched)
+    if (render_waves == 1) { if (count) VS_RENDER(true, 1); else VS_RENDER(false, 1); }
+    else { if (count) VS_RENDER(true, 4); else VS_RENDER(false, 4); }
+#undef VS_RENDER
     VS_HIP(hipGetLastError());
     return R;
 }
