@@ -16,7 +16,7 @@ flt = sys.argv[2]
 for r in rows[:200]:
     n = r["Name"]
     if flt and not any(k in n for k in flt.split(",")): continue
-    short = n.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:70]
+    short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
     print(f"{short:70s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs'])/1e3:10.1f} us  total {float(r['TotalDurationNs'])/1e6:9.2f} ms")
     if not flt and rows.index(r) > 28: break
 PY

@@ -201,8 +201,11 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                 } else {
                     const float *__restrict__ cp = in.campos + 3 * c;
                     const float dx = px - cp[0], dy = py - cp[1], dz = pz - cp[2];
-                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                    const float x = dx / len, y = dy / len, z = dz / len;
+                    // (v_rsq_f32 + three multiplies instead of an IEEE sqrt and three IEEE divisions -- ~45 VALU of this kernel's ~600 per
+                    //  (Gaussian, camera): the view direction only feeds the COLOUR, which is float-tolerant (1 ulp of the direction = 1e-7 of
+                    //  the colour; tests bound it at 2e-5); everything that feeds an integer decision or the conic keeps the exact forms)
+                    const float rlen = __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+                    const float x = dx * rlen, y = dy * rlen, z = dz * rlen;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         float r = SH_C0 * sh[0][ch];
@@ -231,11 +234,12 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                 // tau = ln(255 o), Q = conic = inverse of the dilated 2-D covariance (a, b, cc): the ellipse's axis-aligned
                 // half extents are sqrt(2 tau a), sqrt(2 tau cc).  A pixel outside it is skipped by the render loop's
                 // alpha < 1/255 test anyway, so culling with (1% + 0.05 px) margin never changes a result.
-                const float tau = logf(255.0f * opac);
+                // (hardware log2 / sqrt: their 1-ulp error is five orders of magnitude inside the margin)
+                const float tau = __builtin_amdgcn_logf(255.0f * opac) * 0.6931471805599453f;
                 float ext_x = -1.0f, ext_y = -1.0f;
                 if (tau > 0.0f) {
-                    ext_x = sqrtf(2.0f * tau * a) * 1.01f + 0.05f;
-                    ext_y = sqrtf(2.0f * tau * cc) * 1.01f + 0.05f;
+                    ext_x = __builtin_amdgcn_sqrtf(2.0f * tau * a) * 1.01f + 0.05f;
+                    ext_y = __builtin_amdgcn_sqrtf(2.0f * tau * cc) * 1.01f + 0.05f;
                 }
                 float4 *g4 = reinterpret_cast<float4 *>(geom + ci * kGeomFloats);
                 g4[0] = make_float4(pixx, pixy, ext_x, ext_y);
