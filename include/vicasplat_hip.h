@@ -182,6 +182,11 @@ int vs_gemm_split_packed(const void *Ap, const void *Wp, float acc_scale, const 
  * [Cout, 8 * 32] (kernel row dy at columns dy * 32 + dx * 3 + c), out f32 [Nimg, H, W, Cout], Cout % 256 == 0 */
 int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp, float acc_scale, const float *bias, float *out, int32_t Nimg, int32_t H,
                               int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, vs_stream_t stream);
+/* The split-class stem with the Gaussian-parameter head's "bilinear x2 of the trunk + ReLU(stem)" (dpt_gs_head.py:142-150) fused into its
+ * epilogue (ABI 5): out_packed [Nimg, H, W, Cout] in the packed (hi, lo) form = bilinear_x2(up_src [Nimg, H/2, W/2, Cout] f32, align_corners)
+ * + relu(conv7x7(in_padded) + bias): what vs_upsample2x_nhwc(up_src, add = stem output, relu_add + 16) produced, without the f32 stem map. */
+int vs_conv7x7_rgb_split_up_nhwc(const float *in_padded, const void *wp, float acc_scale, const float *bias, const float *up_src, void *out_packed,
+                                 int32_t Nimg, int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, vs_stream_t stream);
 
 /* conv3x3(Cin -> 128) -> relu_out -> conv1x1(128 -> C2 <= 4) in one kernel on split operands (dot-product form of
  * vs_conv3x3_head1x1_nhwc): in f32 NHWC, wp packed [128, 9 * Cin], w2 f32 [C2, 128], bias2 f32 [4], out2 f32 [N*H*W, ld2] */

@@ -646,3 +646,41 @@ def test_gemm_qkv_rope_split_packed_output():
     op = ops.split_act(M, 3 * C, d)
     ops.gemm_qkv_rope(a, w, b, op, C, pos, None, 100.0, 1.0)
     assert torch.equal(op.data, ops.split_pack_weight(o32, 0).data)
+
+
+@pytest.mark.parametrize("N,Hs,Ws", [(2, 32, 32), (1, 128, 128)])
+def test_stem_with_fused_upsample_add_matches_the_two_kernel_route(N, Hs, Ws):
+    """Round 4 (SURVEY f1 "bilinear x2 fused into its consumer", for the Gaussian-parameter head's stem): vs_conv7x7_rgb_split_up_nhwc writes
+    packed( bilinear_x2(trunk) + relu(conv7x7(image) + bias) ) from the stem kernel's epilogue; the round-3 route was the stem's f32 map
+    followed by vs_upsample2x_nhwc(trunk, add = stem, relu_add, packed).  Same expression per output: identical (hi, lo) images."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(N + Hs)
+    H, W, C = 2 * Hs, 2 * Ws, 256
+    frames = (torch.rand(N, 3, H, W, generator=g) * 2 - 1).to(d)
+    w = (torch.randn(C, 3, 7, 7, generator=g) * 0.1).to(d)
+    b = (torch.randn(C, generator=g) * 0.1).to(d)
+    trunk = torch.randn(N, Hs, Ws, C, generator=g).to(d)
+    wp = ops.pack_conv7x7_rgb_weight(w, "split")
+    img = ops.pad_rgb_nhwc(frames, torch.float32)
+    stem = ops.conv7x7_rgb_nhwc(img, wp, b, H, W)
+    two = ops.upsample2x_nhwc(trunk, add=stem, relu_add=True, packed=True)
+    one = ops.conv7x7_rgb_nhwc(img, wp, b, H, W, up_add=trunk)
+    assert one.data.shape == two.data.shape == (N, H, W, C)
+    ref = F.interpolate(trunk.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True) + \
+        F.relu(F.conv2d(frames.double(), w.double(), b.double(), padding=3))
+    def unpack(sw):
+        halves = sw.data.view(torch.float16).reshape(N, H, W, C // 32, 2, 32).float()
+        pos = torch.arange(32)
+        gi, t = pos // 8, pos % 8
+        k_of_pos = torch.where(t < 4, 4 * gi + t, 16 + 4 * gi + (t - 4))
+        rec = torch.zeros(N, H, W, C // 32, 32, device=d)
+        rec[..., k_of_pos] = halves[..., 0, :] + halves[..., 1, :]
+        return rec.reshape(N, H, W, C)
+    v1, v2 = unpack(one), unpack(two)
+    e = _rel(v1.permute(0, 3, 1, 2).cpu(), ref.cpu())
+    same = torch.equal(one.data, two.data)
+    e12 = _rel(v1.cpu(), v2.cpu())
+    print(f"fused stem + upsample-add N={N} {H}x{W}: rel err vs float64 {e:.2e}; vs the two-kernel route {e12:.2e} (bit-identical: {same})")
+    # (the same expression per output; the two kernels contract their multiply-adds differently, so the f32 values agree to an ulp, not bit for bit)
+    assert e <= TOL and e12 <= 3e-6

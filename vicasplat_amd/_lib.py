@@ -174,6 +174,8 @@ def lib() -> C.CDLL:
             L.vs_conv3x3_head_dot_split_nhwc.argtypes = [vp, vp, f32, vp, vp, vp, vp] + [i32] * 8 + [vp]
             L.vs_conv7x7_rgb_split_nhwc.restype = C.c_int
             L.vs_conv7x7_rgb_split_nhwc.argtypes = [vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_conv7x7_rgb_split_up_nhwc.restype = C.c_int
+            L.vs_conv7x7_rgb_split_up_nhwc.argtypes = [vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             L.vs_upsample2x_nhwc.restype = C.c_int
             L.vs_upsample2x_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
             L.vs_probe_mfma_rate.restype = C.c_int

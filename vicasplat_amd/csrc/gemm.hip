@@ -374,6 +374,62 @@ struct WindowStager256 {
     }
 };
 
+// Epilogue of the split-class 7x7 stem fused with the Gaussian-parameter head's "upsample + add" (dpt_gs_head.py:142-150; round 4):
+//     out[pixel] = packed( bilinear_x2(trunk)[pixel] + relu(conv7x7(image)[pixel] + bias) )
+// i.e. what vs_upsample2x_nhwc(trunk, add = stem, relu_add, packed) computed from the stem's f32 output -- 12.9 GB written by this kernel and
+// read again by that one per 24-scene step, plus the trunk read; here the stem's 256 x 256 f32 map never reaches HBM.  g.gate = the
+// low-resolution trunk [Nimg, conv_H, conv_W, N] f32 (NHWC), the output image is (2 conv_H) x (2 conv_W).  The interpolation is the
+// expression of upsample2x_f32_block_kernel (align_corners = True: source = destination * (Hs - 1) / (H - 1), taps clamped to the last
+// row / column), evaluated per output; a wave's 128 pixels x 64 channels touch a 2 x 65 x 64 slab of the trunk (33 KB: vector-L1 resident),
+// so the four taps of an output cost L1 hits, not L2 traffic.
+__device__ __forceinline__ void stem_upadd_epilogue(const GemmArgs &g, f4 (&acc)[8][4], int mw0, int nbase, int lane) {
+    asm volatile("" : "+v"(lane));
+    const int mrow = lane & 15, c4 = (lane >> 4) * 4;
+    const float *__restrict__ trunk = g.gate;
+    const int Hs = g.conv_H, Ws = g.conv_W, H = 2 * Hs, W = 2 * Ws, C = g.N;
+    const float ry = (float)(Hs - 1) / (float)(H - 1), rx = (float)(Ws - 1) / (float)(W - 1);
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4 *>(g.bias + nbase + j * 16 + c4);
+        bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = mw0 + i * 16 + mrow;
+        if (m >= g.M) continue;
+        const int n = m / (H * W), rem = m - n * (H * W), yo = rem / W, xo = rem - yo * W;
+        const float sy = (float)yo * ry, sx = (float)xo * rx;
+        const int y0 = min((int)sy, Hs - 1), x0 = min((int)sx, Ws - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+        const float *r0 = trunk + ((size_t)(n * Hs + y0) * Ws) * C + nbase + c4, *r1 = trunk + ((size_t)(n * Hs + y1) * Ws) * C + nbase + c4;
+        float4 t00[4], t01[4], t10[4], t11[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t00[j] = *reinterpret_cast<const float4 *>(r0 + (size_t)x0 * C + j * 16);
+            t01[j] = *reinterpret_cast<const float4 *>(r0 + (size_t)x1 * C + j * 16);
+            t10[j] = *reinterpret_cast<const float4 *>(r1 + (size_t)x0 * C + j * 16);
+            t11[j] = *reinterpret_cast<const float4 *>(r1 + (size_t)x1 * C + j * 16);
+        }
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a00[4] = {t00[j].x, t00[j].y, t00[j].z, t00[j].w}, a01[4] = {t01[j].x, t01[j].y, t01[j].z, t01[j].w};
+            const float a10[4] = {t10[j].x, t10[j].y, t10[j].z, t10[j].w}, a11[4] = {t11[j].x, t11[j].y, t11[j].z, t11[j].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float top = a00[r] * (1.f - lx) + a01[r] * lx, bot = a10[r] * (1.f - lx) + a11[r] * lx;
+                const float st = fmaxf(acc[i][j][r] * g.acc_scale + bv[j][r], 0.f);
+                v[j][r] = top * (1.f - ly) + bot * ly + st;
+            }
+        }
+        float *rowp = reinterpret_cast<float *>(g.out) + (size_t)m * g.ldo;
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) store_split8(rowp, nbase + c4 + j * 16, v[j], v[j + 1]);
+    }
+}
+
 template <int BF16>
 __global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
     constexpr int BM2 = 256, BN2 = 256;
@@ -413,6 +469,12 @@ __global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
     f4 acc[8][4];
     if constexpr (SPLIT) mainloop256_split<false>(st, 8, acc, smem, lane, wid);
     else mainloop256<BF16, false>(st, 4, acc, smem, lane, wid);
+    if constexpr (SPLIT) {
+        if (g.gate) {   // (kernel-uniform) fused "+ bilinear x2 of the trunk, ReLU, packed output": vs_conv7x7_rgb_split_up_nhwc
+            stem_upadd_epilogue(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+            return;
+        }
+    }
     gemm_epilogue<BF16, 0, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 
@@ -987,6 +1049,37 @@ extern "C" int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp,
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
     g.a_kstride = Wp * 6;
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// The same stem with the Gaussian-parameter head's upsample-add fused into its epilogue (stem_upadd_epilogue): out_packed [Nimg, H, W, Cout] in the
+// packed (hi, lo) form = bilinear_x2(up_src [Nimg, H/2, W/2, Cout] f32) + relu(conv7x7 + bias).  H, W even; bias required.
+extern "C" int vs_conv7x7_rgb_split_up_nhwc(const float *in_padded, const void *wp, float acc_scale, const float *bias, const float *up_src, void *out_,
+                                            int32_t Nimg, int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, vs_stream_t stream_) {
+    float *out = (float *)out_;
+    VS_CHECK(up_src && bias && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 4, "vs_conv7x7_rgb_split_up_nhwc: up_src, bias, even H, W >= 4 required");
+    VS_CHECK(((uintptr_t)out & 127) == 0 && ((uintptr_t)up_src & 15) == 0 && ((uintptr_t)bias & 15) == 0, "vs_conv7x7_rgb_split_up_nhwc: alignment (out 128 B, up_src / bias 16 B)");
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(in_padded && wp && out && acc_scale > 0.f, "vs_conv7x7_rgb_split_up_nhwc: null pointer / bad scale");
+    VS_CHECK(Nimg >= 0 && H > 0 && W > 0 && Cout > 0 && Cout % 256 == 0, "vs_conv7x7_rgb_split_up_nhwc: bad sizes (Cout must be a multiple of 256)");
+    VS_CHECK(Hp >= H + 6 && Wp >= W + 6, "vs_conv7x7_rgb_split_up_nhwc: padded image must be at least (H+6) x (W+6), got %d x %d", Hp, Wp);
+    VS_CHECK((long long)Nimg * H * W < 2147483647LL && (long long)Nimg * Hp * Wp * 6 < 2147483647LL, "vs_conv7x7_rgb_split_up_nhwc: too large");
+    VS_CHECK((reinterpret_cast<uintptr_t>(wp) & 15) == 0 && (reinterpret_cast<uintptr_t>(in_padded) & 3) == 0, "vs_conv7x7_rgb_split_up_nhwc: alignment");
+    if (Nimg == 0) return 0;
+    GemmArgs g;
+    g.A = in_padded; g.W = wp; g.bias = bias; g.out = out; g.gate = up_src; g.resid = nullptr;
+    g.M = Nimg * H * W; g.N = Cout; g.K = 8 * 64;         // (2-byte units of the f32 rows)
+    g.lda = 6; g.ldw = 8 * 64; g.ldo = Cout;
+    g.grp_in = g.M; g.grp_out = g.M; g.grp_off = 0;
+    g.gate_rows = g.M; g.gate_ld = Cout;
+    g.m_lo = 0;
+    g.a_grp_in = W; g.a_grp_out = Wp; g.a_grp_off = 0;
+    g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
+    g.a_kstride = Wp * 6;
+    g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = H / 2; g.conv_W = W / 2;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());

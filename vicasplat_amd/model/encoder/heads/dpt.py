@@ -12,7 +12,11 @@ import torch
 import torch.nn.functional as F      # F.pad / F.unfold of the exact-f32 class's im2col stem only -- no torch convolution / interpolation anywhere
 from torch import nn
 
+import os
+
 from .... import ops
+
+_STEM_UP_FUSED = os.environ.get("VS_STEM_UP_FUSED", "1") != "0"   # A/B switch: 0 = stem -> f32 map -> upsample-add kernel (round 3)
 
 
 def _no_torch_forward(self, *a, **k):
@@ -273,19 +277,28 @@ class PixelwiseTaskWithDPT(nn.Module):
         dt = self.compute_dtype
         # 7x7 stem on the RGB image (dpt_gs_head.py:112-118): window GEMM on the zero-bordered NHWC frames, bias fused; its
         # ReLU is fused into the upsample-add kernel below
+        fuse_gs = (self.split and self.num_channels <= 96 and (x.shape[0] * 4 * x.shape[1] * x.shape[2]) % 256 == 0
+                   and self.dpt.head[0].out_channels == 256 and x.shape[-1] in (32, 64, 128, 256))
         if self.split and self.dpt.input_merger[0].out_channels % 256 == 0:
             P = self._packed()
             if "stem.ws7" not in P:
                 c7 = self.dpt.input_merger[0]
                 P["stem.ws7"], P["stem.b"] = ops.pack_conv7x7_rgb_weight(c7.weight, "split"), c7.bias.detach().float().contiguous()
-            img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], frames.shape[-2], frames.shape[-1])
+            H_, W_ = frames.shape[-2], frames.shape[-1]
+            if (_STEM_UP_FUSED and fuse_gs and x.shape[-1] == d.input_merger[0].out_channels and x.is_contiguous()
+                    and (2 * x.shape[1], 2 * x.shape[2]) == (H_, W_)):
+                # round 4: up2(trunk) + relu(stem) leaves the STEM kernel's epilogue in the packed form -- the f32 stem map (12.9 GB written and
+                # read back per 24-scene step) and the stand-alone upsample-add launch are gone
+                xp = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], H_, W_, up_add=x)
+                y = ops.conv3x3_head1x1_nhwc(xp, P["h0.w"], None, P["h4f.w"], P["h4f.b"], self.num_channels)   # [BT,H,W,96] f32
+                return y[..., :self.num_channels].permute(0, 3, 1, 2)
+            img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], H_, W_)
         elif dt == torch.float32:
             img = self._stem_f32(frames)
         else:
             P7 = self._stem_weights()
             img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, dt), P7[0], P7[1], frames.shape[-2], frames.shape[-1])
-        if (self.split and self.num_channels <= 96 and (x.shape[0] * 4 * x.shape[1] * x.shape[2]) % 256 == 0
-                and self.dpt.head[0].out_channels == 256 and x.shape[-1] in (32, 64, 128, 256)):
+        if fuse_gs:
             # split operands: conv3(256->256) -> ReLU -> conv1(256->83) in one kernel, the second GEMM in four K-quarters on (hi, lo) images
             # of the tile in LDS (P["h4f.w"] is the packed [96, 256] weight in this class).  The upsample-add kernel writes the 256 x 256 x 256
             # operand in the packed (hi, lo) form (same bytes as f32): the convolution's main loop has no conversion left

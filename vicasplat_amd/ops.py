@@ -599,14 +599,28 @@ def pad_rgb_nhwc(frames: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return img
 
 
-def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], H: int, W: int) -> torch.Tensor:
-    """img_padded from pad_rgb_nhwc, w from pack_conv7x7_rgb_weight -> [N,H,W,Cout] = conv2d(k=7, s=1, p=3) + bias."""
+def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], H: int, W: int,
+                     up_add: Optional[torch.Tensor] = None):
+    """img_padded from pad_rgb_nhwc, w from pack_conv7x7_rgb_weight -> [N,H,W,Cout] = conv2d(k=7, s=1, p=3) + bias.
+    up_add (split class only; [N, H/2, W/2, Cout] f32 contiguous): the Gaussian-parameter head's fusion (dpt_gs_head.py:142-150) -- returns
+    the PACKED (hi, lo) activation bilinear_x2(up_add) + relu(conv + bias) as a SplitWeight [N,H,W,Cout] (what
+    upsample2x_nhwc(up_add, add=conv, relu_add=True, packed=True) returns) without writing the f32 stem map."""
     if isinstance(w, SplitWeight):     # split operands: f32 image, packed [Cout, 256] weight (pack_conv7x7_rgb_weight(w, "split"))
-        dev = L.require_device(img_padded, w.data, bias)
+        dev = L.require_device(img_padded, w.data, bias, up_add)
         N, Hp, Wp, C = img_padded.shape
         Cout = w.shape[0]
         assert C == 3 and img_padded.is_contiguous() and img_padded.dtype == torch.float32 and tuple(w.shape) == (Cout, 256)
         assert img_padded.untyped_storage().nbytes() >= (img_padded.storage_offset() + img_padded.numel() + Wp * 3 + 64) * 4
+        if up_add is not None:
+            assert up_add.dtype == torch.float32 and up_add.is_contiguous() and tuple(up_add.shape) == (N, H // 2, W // 2, Cout) and bias is not None
+            if RANGE_GUARD.enabled:
+                RANGE_GUARD.check(f"stem + upsample-add: trunk {Cout} @{H // 2}x{W // 2}", up_add)
+            outp = torch.empty((N, H, W, Cout), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.lib().vs_conv7x7_rgb_split_up_nhwc(L.ptr(img_padded), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(up_add), L.ptr(outp), N, H, W,
+                                                          Hp, Wp, Cout, L.stream_ptr(dev))
+            L.check(rc, "vs_conv7x7_rgb_split_up_nhwc")
+            return SplitWeight(outp, 1.0, outp.shape)
         out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = L.lib().vs_conv7x7_rgb_split_nhwc(L.ptr(img_padded), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(out), N, H, W, Hp, Wp, Cout,
