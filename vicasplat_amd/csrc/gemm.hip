@@ -382,9 +382,34 @@ struct WindowStager256 {
 // expression of upsample2x_f32_block_kernel (align_corners = True: source = destination * (Hs - 1) / (H - 1), taps clamped to the last
 // row / column), evaluated per output; a wave's 128 pixels x 64 channels touch a 2 x 65 x 64 slab of the trunk (33 KB: vector-L1 resident),
 // so the four taps of an output cost L1 hits, not L2 traffic.
-__device__ __forceinline__ void stem_upadd_epilogue(const GemmArgs &g, f4 (&acc)[8][4], int mw0, int nbase, int lane) {
+// Two column fragments (j, j + 1: one 16-byte hi chunk and one lo chunk of the packed row) of one pixel from their four taps
+__device__ __forceinline__ void stem_upadd_pair(const GemmArgs &g, const f4 &acc0, const f4 &acc1, const float (&bv0)[4], const float (&bv1)[4],
+                                                const float4 (&t00)[2], const float4 (&t01)[2], const float4 (&t10)[2], const float4 (&t11)[2], float lx,
+                                                float ly, float *rowp, int ncol) {
+    float v[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float a00[4] = {t00[j].x, t00[j].y, t00[j].z, t00[j].w}, a01[4] = {t01[j].x, t01[j].y, t01[j].z, t01[j].w};
+        const float a10[4] = {t10[j].x, t10[j].y, t10[j].z, t10[j].w}, a11[4] = {t11[j].x, t11[j].y, t11[j].z, t11[j].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float top = a00[r] * (1.f - lx) + a01[r] * lx, bot = a10[r] * (1.f - lx) + a11[r] * lx;
+            const float st = fmaxf((j ? acc1[r] : acc0[r]) * g.acc_scale + (j ? bv1[r] : bv0[r]), 0.f);
+            v[j][r] = top * (1.f - ly) + bot * ly + st;
+        }
+    }
+    store_split8(rowp, ncol, v[0], v[1]);
+}
+
+// The taps are gathered straight from global memory: a wave's 128 pixels x 64 channels touch a 2 x 65 x 64 slab of the trunk (33 KB), eight
+// waves thrash the 32 KB vector L1, so the epilogue runs at L2 latency: +3.8 ms per 24-scene step on this 6 ms kernel against the 5.9 ms of
+// the stand-alone upsample-add launch it replaces (and 25 GB less HBM traffic).  Measured and dropped: staging the tile's two source rows in
+// the released LDS ring in two channel halves (LDS-DMA, swizzled, conflict-free gathers) -- each trunk element then crosses L2 -> CU once per
+// tile, but the two halves serialise (DMA, barrier, half the waves gather) and the kernel was 0.6 ms SLOWER than the global gather.
+__device__ __forceinline__ void stem_upadd_epilogue(const GemmArgs &g, f4 (&acc)[8][4], int m0, int wr, int wc, unsigned char *smem, int tid, int lane) {
     asm volatile("" : "+v"(lane));
     const int mrow = lane & 15, c4 = (lane >> 4) * 4;
+    const int mw0 = m0 + wr * 128, nbase = wc * 64;       // (N == 256: one column tile)
     const float *__restrict__ trunk = g.gate;
     const int Hs = g.conv_H, Ws = g.conv_W, H = 2 * Hs, W = 2 * Ws, C = g.N;
     const float ry = (float)(Hs - 1) / (float)(H - 1), rx = (float)(Ws - 1) / (float)(W - 1);
@@ -404,33 +429,23 @@ __device__ __forceinline__ void stem_upadd_epilogue(const GemmArgs &g, f4 (&acc)
         const float ly = sy - (float)y0, lx = sx - (float)x0;
         const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
         const float *r0 = trunk + ((size_t)(n * Hs + y0) * Ws) * C + nbase + c4, *r1 = trunk + ((size_t)(n * Hs + y1) * Ws) * C + nbase + c4;
-        float4 t00[4], t01[4], t10[4], t11[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t00[j] = *reinterpret_cast<const float4 *>(r0 + (size_t)x0 * C + j * 16);
-            t01[j] = *reinterpret_cast<const float4 *>(r0 + (size_t)x1 * C + j * 16);
-            t10[j] = *reinterpret_cast<const float4 *>(r1 + (size_t)x0 * C + j * 16);
-            t11[j] = *reinterpret_cast<const float4 *>(r1 + (size_t)x1 * C + j * 16);
-        }
-        float v[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a00[4] = {t00[j].x, t00[j].y, t00[j].z, t00[j].w}, a01[4] = {t01[j].x, t01[j].y, t01[j].z, t01[j].w};
-            const float a10[4] = {t10[j].x, t10[j].y, t10[j].z, t10[j].w}, a11[4] = {t11[j].x, t11[j].y, t11[j].z, t11[j].w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float top = a00[r] * (1.f - lx) + a01[r] * lx, bot = a10[r] * (1.f - lx) + a11[r] * lx;
-                const float st = fmaxf(acc[i][j][r] * g.acc_scale + bv[j][r], 0.f);
-                v[j][r] = top * (1.f - ly) + bot * ly + st;
-            }
-        }
         float *rowp = reinterpret_cast<float *>(g.out) + (size_t)m * g.ldo;
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) store_split8(rowp, nbase + c4 + j * 16, v[j], v[j + 1]);
+        for (int jp = 0; jp < 4; jp += 2) {
+            float4 t00[2], t01[2], t10[2], t11[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                t00[j] = *reinterpret_cast<const float4 *>(r0 + (size_t)x0 * C + (jp + j) * 16);
+                t01[j] = *reinterpret_cast<const float4 *>(r0 + (size_t)x1 * C + (jp + j) * 16);
+                t10[j] = *reinterpret_cast<const float4 *>(r1 + (size_t)x0 * C + (jp + j) * 16);
+                t11[j] = *reinterpret_cast<const float4 *>(r1 + (size_t)x1 * C + (jp + j) * 16);
+            }
+            stem_upadd_pair(g, acc[i][jp], acc[i][jp + 1], bv[jp], bv[jp + 1], t00, t01, t10, t11, lx, ly, rowp, nbase + c4 + jp * 16);
+        }
     }
 }
 
-template <int BF16>
+template <int BF16, bool UPADD = false>
 __global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
     constexpr int BM2 = 256, BN2 = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
@@ -469,9 +484,10 @@ __global__ void __launch_bounds__(512, 1) conv7x7_256_kernel(const GemmArgs g) {
     f4 acc[8][4];
     if constexpr (SPLIT) mainloop256_split<false>(st, 8, acc, smem, lane, wid);
     else mainloop256<BF16, false>(st, 4, acc, smem, lane, wid);
-    if constexpr (SPLIT) {
-        if (g.gate) {   // (kernel-uniform) fused "+ bilinear x2 of the trunk, ReLU, packed output": vs_conv7x7_rgb_split_up_nhwc
-            stem_upadd_epilogue(g, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    if constexpr (SPLIT && UPADD) {
+        {               // fused "+ bilinear x2 of the trunk, ReLU, packed output": vs_conv7x7_rgb_split_up_nhwc (its own instantiation:
+                        // the tap registers of this epilogue beside the 128 accumulators must not cost the plain stem kernel anything)
+            stem_upadd_epilogue(g, acc, m0, wr, wc, smem, tid, lane);      // (Cout == 256 is required by the entry: n0 == 0)
             return;
         }
     }
@@ -1061,6 +1077,7 @@ extern "C" int vs_conv7x7_rgb_split_up_nhwc(const float *in_padded, const void *
                                             int32_t Nimg, int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, vs_stream_t stream_) {
     float *out = (float *)out_;
     VS_CHECK(up_src && bias && H % 2 == 0 && W % 2 == 0 && H >= 4 && W >= 4, "vs_conv7x7_rgb_split_up_nhwc: up_src, bias, even H, W >= 4 required");
+    VS_CHECK(Cout == 256, "vs_conv7x7_rgb_split_up_nhwc: Cout must be 256 (one column tile: the epilogue owns whole pixel rows)");
     VS_CHECK(((uintptr_t)out & 127) == 0 && ((uintptr_t)up_src & 15) == 0 && ((uintptr_t)bias & 15) == 0, "vs_conv7x7_rgb_split_up_nhwc: alignment (out 128 B, up_src / bias 16 B)");
     hipStream_t stream = (hipStream_t)stream_;
     VS_CHECK(in_padded && wp && out && acc_scale > 0.f, "vs_conv7x7_rgb_split_up_nhwc: null pointer / bad scale");
@@ -1081,7 +1098,7 @@ extern "C" int vs_conv7x7_rgb_split_up_nhwc(const float *in_padded, const void *
     g.a_kstride = Wp * 6;
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = H / 2; g.conv_W = W / 2;
     g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
-    hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
+    hipLaunchKernelGGL((conv7x7_256_kernel<kDtSplit, true>), dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;
 }
