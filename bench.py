@@ -373,7 +373,9 @@ def main():
         # dominant hand-written kernel family of the step: the MFMA GEMM (ViT encoder/decoder linears, 1x1 convolutions)
         traffic = {}
         try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null unless they cover this workload and operand class
-            fn = {"split": "round3_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
+            fn = {"split": "round4_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
+            if fn == "round4_pmc_traffic.json" and not os.path.exists(os.path.join(ROOT, "profiles", fn)):
+                fn = "round3_pmc_traffic.json"
             pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
             if pm.get("workload", {}).get("scenes_per_gpu") == B and V == 8 and Vt == 12 and pm["workload"].get("dtype", "f16") == args.dtype:
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm["kernels"].items()}
