@@ -537,7 +537,7 @@ struct ConvStager256x128 {
 template <int BF16, int MI>
 __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int m0, int wr, int wc, float *red, int lane);
 
-template <bool RELU_IN, bool FUSE_DOT>
+template <bool RELU_IN, bool FUSE_DOT, bool A_PACKED = false>
 __global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const ConvArgs g, const int cshift) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 3 * kUnitBytes256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const Con
         st.pw[j] = g.w + (size_t)rw_ * K + chunk * 8;
     }
     f4 acc[4][4];
-    mainloop256x128_split<RELU_IN>(st, K / 64, acc, smem, lane, wid);
+    mainloop256x128_split<RELU_IN, ConvStager256x128, A_PACKED>(st, K / 64, acc, smem, lane, wid);
     if constexpr (FUSE_DOT) conv_head_dot_epilogue<kDtSplit, 4>(g, acc, m0, wm, wc, reinterpret_cast<float *>(smem), lane);
     else conv_epilogue<kDtSplit, 4>(g, acc, m0 + wm * 64, n0 + wc * 64, M, smem, wid, lane);
 }
@@ -1090,11 +1090,13 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
         static const int no128 = [] { const char *e = getenv("VS_CONV_SPLIT_NO256X128"); return e ? atoi(e) : 0; }();
         if (!no128 && cshift >= 0 && Cout % 128 == 0 && Cout % 256 != 0 && (9 * Cin / 64) % 2 == 0 && big >= 224) {   // (Cout = 256 maps too small for the 256 x 256 kernel: the 4-wave kernel is 8 % faster there, measured)
             dim3 grid((unsigned)(vs::cdiv64(M, 256) * (Cout / 128))), block(512);
-            if (relu_in) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<true, false>), grid, block, 0, stream, g, cshift);
+            if (g.a_packed) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false, true>), grid, block, 0, stream, g, cshift);
+            else if (relu_in) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<true, false>), grid, block, 0, stream, g, cshift);
             else hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false>), grid, block, 0, stream, g, cshift);
             VS_HIP(hipGetLastError());
             return 0;
         }
+        VS_CHECK(!g.a_packed, "vs_conv3x3_split_nhwc: a packed input is taken by the 256 x 256 and 256 x 128 tile kernels only (this shape runs on the 4-wave kernel)");
         static const int smi = [] { const char *e = getenv("VS_CONV_SPLIT_MI"); return e ? atoi(e) : 0; }();
         if ((big >= 512 && smi != 4) || smi == 8) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8>), dim3((unsigned)big), dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
@@ -1194,6 +1196,8 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
                                               float *out2, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t C2, int32_t ld2, int32_t relu_in,
                                               int32_t relu_out, vs_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int in_packed = (relu_out & 16) ? 1 : 0;     // + 16: `in` is the packed (hi, lo) image of the f32 tensor (vs_upsample2x_nhwc ... + 16), ABI 5
+    relu_out &= ~16;
     VS_CHECK(in && wp && w2 && bias2 && out2 && acc_scale > 0.f, "vs_conv3x3_head_dot_split_nhwc: null pointer / bad scale");
     const long long M = (long long)Nimg * H * W;
     VS_CHECK(Nimg > 0 && H > 0 && W > 0 && H < 32767 && W < 65536 && M % 256 == 0 && M < 2147483647LL, "vs_conv3x3_head_dot_split_nhwc: N*H*W must be a positive multiple of 256");
@@ -1205,7 +1209,11 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
     for (int sft = 0; sft < 4; ++sft)
         if (2 * Cin == (64 << sft)) cshift = sft;
     static const int no128 = [] { const char *e = getenv("VS_CONV_SPLIT_NO256X128"); return e ? atoi(e) : 0; }();
-    if (!no128 && cshift >= 0 && (9 * 2 * Cin / 64) % 2 == 0 && !relu_in)
+    const bool tile128 = !no128 && cshift >= 0 && (9 * 2 * Cin / 64) % 2 == 0 && !relu_in;
+    VS_CHECK(!in_packed || tile128, "vs_conv3x3_head_dot_split_nhwc: a packed input needs the 256 x 128 tile kernel (Cin in {32, 64, 128, 256}, no relu_in)");
+    if (tile128 && in_packed)
+        hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, cshift);
+    else if (tile128)
         hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, cshift);
     else
         hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8, true>), dim3((unsigned)(M / 256)), dim3(256), 0, stream, g);

@@ -330,9 +330,11 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
 // Issue order per wave: .. R0(kt): A_1(kt+1) | R1(kt): A_0(kt+2), B(kt+2) ..  Waits (own pieces only for the A units -- a wave converts
 // the rows it staged itself; the shared B unit is waited for one barrier before its first read): start of R0: A_1(kt) (four younger
 // pieces in flight), start of R1: A_0(kt+1) and B(kt+1) (two younger pieces).
-template <bool RELU_A, class Stager>
+// A_PACKED (round 4): the A units arrive already in the packed (hi, lo) form (the producer wrote it: vs_upsample2x_nhwc relu_add + 16) -- the
+// conversion loads / VALU / stores drop out, the waits and barriers stay (a unit is read one barrier after the wait that covers its pieces).
+template <bool RELU_A, class Stager, bool A_PACKED = false>
 __device__ __forceinline__ void mainloop256x128_split(Stager &st, const int KT, f4 (&acc)[4][4], unsigned char *smem, const int lane, const int wid) {
-    constexpr bool A_PACKED = false;   // (the packed-A form exists on the 256 x 256 loop only)
+    static_assert(!(RELU_A && A_PACKED), "a packed A operand carries its ReLU already");
     constexpr unsigned UNITB = kUnitBytes256;
     constexpr int BF16 = kDtSplit;
     const int grp = wid >> 2, wl = wid & 3;

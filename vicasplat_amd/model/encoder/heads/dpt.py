@@ -16,6 +16,7 @@ import os
 
 from .... import ops
 
+_PTS_UP_PACKED = os.environ.get("VS_PTS_UP_PACKED", "1") != "0"     # A/B switch: 0 = f32 upsampled map into the pts3d head's fused conv (round 3)
 _STEM_UP_FUSED = os.environ.get("VS_STEM_UP_FUSED", "1") != "0"   # A/B switch: 0 = stem -> f32 map -> upsample-add kernel (round 3)
 
 
@@ -208,7 +209,7 @@ class PixelwiseTaskWithDPT(nn.Module):
         t = ops.conv3x3_nhwc(x, P[name + ".c1.w"], P[name + ".c1.b"], relu_in=True, relu_out=True)
         return ops.conv3x3_nhwc(t, P[name + ".c2.w"], P[name + ".c2.b"], residual=x, residual2=extra)
 
-    def _fusion(self, P, r, x, skip=None):
+    def _fusion(self, P, r, x, skip=None, packed_out=False):
         if skip is not None:
             if self.split:      # x + rcu(skip): the add rides on the epilogue of the unit's last convolution
                 x = self._rcu(skip, P, f"rf{r}.resConfUnit1", extra=x.contiguous())
@@ -216,9 +217,9 @@ class PixelwiseTaskWithDPT(nn.Module):
                 x = x + self._rcu(skip, P, f"rf{r}.resConfUnit1")
         # out_conv (1x1) commutes with the bilinear x2 (both linear, interpolation weights sum to 1): run it on the 4x
         # smaller map, then upsample (dpt_block.py:210-218 upsamples first)
-        return ops.upsample2x_nhwc(self._gemm1x1(self._rcu(x, P, f"rf{r}.resConfUnit2"), P, f"rf{r}.out"))
+        return ops.upsample2x_nhwc(self._gemm1x1(self._rcu(x, P, f"rf{r}.resConfUnit2"), P, f"rf{r}.out"), packed=packed_out)
 
-    def _trunk(self, tokens, gh: int, gw: int):
+    def _trunk(self, tokens, gh: int, gw: int, packed_out: bool = False):
         """tokens[hook] [BT, gh*gw, C] 16-bit -> path_1 [BT, 8gh, 8gw, 256] (dpt_head.py:35-62)."""
         P = self._packed()
         d = self.dpt
@@ -239,12 +240,25 @@ class PixelwiseTaskWithDPT(nn.Module):
         p4 = self._fusion(P, 4, l3)[:, :l2.shape[1], :l2.shape[2]].contiguous()
         p3 = self._fusion(P, 3, p4, l2)
         p2 = self._fusion(P, 2, p3, l1)
-        return self._fusion(P, 1, p2, l0), P
+        # packed_out (split class, pts3d head): path_1 only feeds a 3x3 convolution -- the bilinear kernel writes it packed (hi, lo)
+        return self._fusion(P, 1, p2, l0, packed_out=packed_out), P
 
     def forward_pts3d_raw(self, tokens, gh: int, gw: int) -> torch.Tensor:
         """-> [BT,3,H,W] view (channels-last memory) of the head output in the compute dtype, BEFORE the 'exp' post-process."""
-        x, P = self._trunk(tokens, gh, gw)
+        pk = _PTS_UP_PACKED and self.split and self.dpt.head[0].out_channels == 128 and self.dpt.head[0].in_channels in (64, 128, 256)
+        x, P = self._trunk(tokens, gh, gw, packed_out=pk and (tokens[self.dpt.hooks[0]].shape[0] * 64 * gh * gw) >= 224 * 256)
         x = ops.conv3x3_nhwc(x, P["h0.w"], P["h0.b"])
+        npix = x.shape[0] * 4 * x.shape[1] * x.shape[2]
+        if _PTS_UP_PACKED and self.split and npix % 256 == 0 and x.shape[-1] == 128 and self.dpt.head[2].out_channels == 128:
+            # round 4: the upsampled 256^2 x 128 map is written PACKED (hi, lo) by the bilinear kernel (same bytes) and the fused conv3 -> ReLU ->
+            # dot head reads it without converting (conv3x3_256x128_split_kernel<., ., A_PACKED>)
+            if "h4f32.w" not in P:
+                c4 = self.dpt.head[4]
+                P["h4f32.w"] = torch.nn.functional.pad(c4.weight.detach().float().flatten(1), (0, 0, 0, 4 - c4.out_channels)).contiguous()
+                P["h4f32.b"] = torch.nn.functional.pad(c4.bias.detach().float(), (0, 4 - c4.out_channels)).contiguous()
+            xp = ops.upsample2x_nhwc(x, packed=True)
+            y = ops.conv3x3_head1x1_nhwc(xp, P["h2.w"], P["h2.b"], P["h4f32.w"], P["h4f32.b"], 3)          # [BT,H,W,4] f32
+            return y[..., :3].permute(0, 3, 1, 2)
         x = ops.upsample2x_nhwc(x)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
         if self.split and npix % 256 == 0 and x.shape[-1] == 128 and self.dpt.head[2].out_channels == 128:

@@ -477,19 +477,23 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
         assert residual is None and not relu_out
         residual, relu_out = mask_by, 2
     split = isinstance(w, SplitWeight)
+    xin_packed = isinstance(x, SplitWeight)     # split class: the input already in the packed (hi, lo) form (its producer wrote it; ReLU applied there)
+    if xin_packed:
+        assert split and not relu_in and residual2 is None
+        x = x.data
     dev = L.require_device(x, w.data if split else w, bias, residual, out)
-    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and x.dtype in _OPERAND_DTYPES
-    assert (split and x.dtype == torch.float32) or (not split and x.dtype == w.dtype)
+    assert x.dim() == 4 and x.is_contiguous() and w.is_contiguous() and (x.dtype in _OPERAND_DTYPES or xin_packed)
+    assert (split and x.dtype == (torch.int32 if xin_packed else torch.float32)) or (not split and x.dtype == w.dtype)
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
     assert tuple(w.shape) == (Cout, 3, 3, Cin)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
-        out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=dev)
-    assert residual is None or (residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype)
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if xin_packed else x.dtype, device=dev)
+    assert residual is None or (residual.shape == out.shape and residual.is_contiguous() and residual.dtype == out.dtype)
     assert residual2 is None or (split and mask_by is None and residual2.shape == out.shape and residual2.is_contiguous() and residual2.dtype == torch.float32)
     if split and RANGE_GUARD.enabled:
-        RANGE_GUARD.check(f"conv3x3 {Cin}->{Cout} @{H}x{W}", x)
+        RANGE_GUARD.check(f"conv3x3 {Cin}->{Cout} @{H}x{W}", SplitWeight(x.view(-1, Cin), 1.0, (N * H * W, Cin)) if xin_packed else x)
     if split and residual2 is not None:      # split class: out = conv + bias + residual + residual2 in the epilogue (no add pass)
         L.require_device(residual2)
         with torch.cuda.device(dev):
@@ -500,7 +504,7 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     if split:
         with torch.cuda.device(dev):
             rc = L.lib().vs_conv3x3_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(residual), L.ptr(out), N, H, W, Cin, Cout,
-                                               stride, int(relu_in), int(relu_out), L.stream_ptr(dev))
+                                               stride, int(relu_in) | (16 if xin_packed else 0), int(relu_out), L.stream_ptr(dev))
         L.check(rc, "vs_conv3x3_split_nhwc")
         return out
     with torch.cuda.device(dev):
@@ -533,16 +537,19 @@ def conv3x3_head1x1_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.
         L.check(rc, "vs_conv3x3_head1x1_split_nhwc")
         return out
     if isinstance(w, SplitWeight):   # split operands: the dot-product form (Cout = 128, n_out <= 4), f32 in / out, w2 f32 [>= n_out, 128]
+        xin_packed = isinstance(x, SplitWeight)      # the input already packed (upsample2x_nhwc(..., packed=True)): no conversion in the main loop
+        if xin_packed:
+            x = x.data
         dev = L.require_device(x, w.data, bias, w2, bias2)
         N, H, W, Cin = x.shape
-        assert x.is_contiguous() and x.dtype == torch.float32 and tuple(w.shape) == (128, 3, 3, Cin) and n_out <= 4
+        assert x.is_contiguous() and x.dtype == (torch.int32 if xin_packed else torch.float32) and tuple(w.shape) == (128, 3, 3, Cin) and n_out <= 4
         assert w2.dtype == torch.float32 and w2.is_contiguous() and w2.shape[1] == 128 and w2.shape[0] >= n_out and bias2.numel() >= 4
         out = torch.empty((N, H, W, 4), dtype=torch.float32, device=dev)
         if RANGE_GUARD.enabled:
-            RANGE_GUARD.check(f"fused head conv3x3 {Cin}->128 -> dot @{H}x{W}", x)
+            RANGE_GUARD.check(f"fused head conv3x3 {Cin}->128 -> dot @{H}x{W}", SplitWeight(x.view(-1, Cin), 1.0, (N * H * W, Cin)) if xin_packed else x)
         with torch.cuda.device(dev):
             rc = L.lib().vs_conv3x3_head_dot_split_nhwc(L.ptr(x), L.ptr(w.data), w.acc_scale, L.ptr(bias), L.ptr(w2), L.ptr(bias2), L.ptr(out), N, H, W,
-                                                        Cin, n_out, 4, 0, int(relu_out), L.stream_ptr(dev))
+                                                        Cin, n_out, 4, 0, int(relu_out) | (16 if xin_packed else 0), L.stream_ptr(dev))
         L.check(rc, "vs_conv3x3_head_dot_split_nhwc")
         return out
     dev = L.require_device(x, w, bias, w2, bias2)
