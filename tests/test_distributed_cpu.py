@@ -294,3 +294,62 @@ def test_bench_dry_run_dist_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["train"]["gradient_exchange"].startswith("GradReducer") and d["train"]["replicas_identical"] is True
+
+
+# ---- the Module API's internal gradient scale under torch's DistributedDataParallel (what Lightning wraps the reference's ModelWrapper in,
+# src/main.py:110-115): cotangents x S on the way in, parameter gradients / S from an autograd-engine callback that re-queues itself once so
+# that it runs AFTER DDP's own end-of-backward callback (the bucket all-reduce and the copy back into .grad work on scaled values) ----
+class _ScaledToy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.GELU(), torch.nn.Linear(32, 5))
+        self.scaler = None
+
+    def forward(self, x):
+        from vicasplat_amd import autograd as A
+        y = self.net(x)
+        if self.scaler is None:
+            self.scaler = A.BoundaryGradScale(list(self.parameters()), 8192.0)
+        return self.scaler.outputs(y)[0]
+
+
+def _ddp_scale_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        m = _ScaledToy()
+        ddp = torch.nn.parallel.DistributedDataParallel(m)          # gradient_as_bucket_view=False: DDP copies the reduced buckets back at the end
+        x, y = _toy_batch()
+        r = vd.shard_range(x.shape[0], rank, world)
+        for step in range(2):
+            ddp.zero_grad(set_to_none=(step == 0))
+            loss = ((ddp(x[r.start:r.stop]) - y[r.start:r.stop]) ** 2).mean()
+            loss.backward()
+        q.put((rank, {n: p.grad.detach().numpy().copy() for n, p in m.named_parameters()}))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_boundary_grad_scale_under_ddp_matches_the_unscaled_full_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_scale_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(v, dict) for v in out.values()), out
+    torch.manual_seed(3)
+    ref = _ScaledToy()
+    x, y = _toy_batch()
+    ((ref.net(x) - y) ** 2).mean().backward()                        # 1 rank x full batch, no scale, no DDP
+    for n, p in ref.named_parameters():
+        for rank in (0, 1):
+            g = torch.from_numpy(out[rank][n])
+            assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-8), (rank, n, float((g - p.grad).abs().max()))
+        assert np.array_equal(out[0][n], out[1][n]), n               # replicas bit-identical

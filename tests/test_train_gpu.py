@@ -545,3 +545,27 @@ def test_module_api_trains_like_the_reference_wrapper(cdt):
     mo = m(batch["context"], 0)
     ((dec.forward(mo["gaussians"], tE, tK, tn, tf, (S, S)).color - target) ** 2).mean().backward()
     assert m.camera_extrinsic_head[1].weight.grad is None and m.backbone.camera_extrinsic_token.grad is not None
+
+
+def test_module_api_distillation_only_phase():
+    """`self.encoder(batch["context"], self.global_step, distill=True)` (model_wrapper.py:207 during `distill_only_steps`): the reference returns
+    the centres and poses only (vicasplat.py:234-243) and never runs the Gaussian-parameter head.  Same keys and values as the fused inference
+    path; the distillation loss on `gaussian_centers` reaches the pts3d head and the backbone, not the Gaussian-parameter head."""
+    m, _ = _tiny_model("split")
+    d = torch.device("cuda:0")
+    img, K = er.synthetic_input(1, 2, 64, 3)
+    E = torch.eye(4).repeat(1, 2, 1, 1)
+    ctx = dict(image=img.to(d), intrinsics=K.to(d), extrinsics=E.to(d))
+    with torch.no_grad():
+        ref = m(ctx, 0, distill=True)
+    out = m(ctx, 0, distill=True)
+    assert set(out) == set(ref) and "gaussians" not in out and out["gaussian_centers"].requires_grad
+    for k in ("pred_extrins", "gaussian_camera_extrins", "gaussian_centers", "context_view_depths"):
+        a, b = out[k].detach(), ref[k]
+        assert a.shape == b.shape and float((a - b).abs().max() / (b.abs().max() + 1e-12)) <= 2e-5, k
+    m.zero_grad(set_to_none=True)
+    (out["gaussian_centers"].square().mean() + out["pred_extrins"].square().mean()).backward()
+    g = {n: p.grad for n, p in m.named_parameters()}
+    assert g["downstream_head1.dpt.head.4.weight"] is not None and torch.isfinite(g["downstream_head1.dpt.head.4.weight"]).all()
+    assert g["backbone.enc_blocks.0.attn.qkv.weight"] is not None and g["camera_extrinsic_head.1.weight"] is not None
+    assert all(v is None for n, v in g.items() if n.startswith("gaussian_param_head."))
