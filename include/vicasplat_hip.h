@@ -445,13 +445,15 @@ int vs_gaussian_adapter_backward(const void *pts, int32_t pts_pix, const void *g
  * conv_H, conv_W > 0: r indexes the pixels of whole H x W images and src(r) = r + tap_dy * W + tap_dx when that pixel is inside the
  * image (zero otherwise) -- the shifted operand of one tap of a 3x3 convolution's weight gradient; 0, 0: src(r) = r.  tap_dy = 2: r
  * indexes the pixels of zero-BORDERED (H + 2) x (W + 2) maps (R = their total), the interior read from the unpadded tensor `in` -- the
- * operands of the tap-fused weight gradient vs_gemm_wgrad(dtype 4, ntaps = 9), whose tap shifts move the f32 A operand. */
+ * operands of the tap-fused weight gradient vs_gemm_wgrad(dtype 4, ntaps = 9), whose tap shifts move the f32 A operand.
+ * colsum (nullable, f32 [C], overwritten): the column sums of `in` over its R rows -- the bias gradient rides on the transpose of dY that
+ * the weight gradient needs anyway (as vs_transpose16_ex; plain and bordered forms only, relu == 0; partial sums meet through f32 atomics). */
 int vs_transpose_f32(const float *in, int64_t ld_in, float *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu, int32_t conv_H,
-                     int32_t conv_W, int32_t tap_dy, int32_t tap_dx, vs_stream_t stream);
+                     int32_t conv_W, int32_t tap_dy, int32_t tap_dx, float *colsum, vs_stream_t stream);
 /* The same, written as the packed split operand of vs_gemm_split / vs_gemm_wgrad(dtype 4): out [C, ld_out] 4-byte units, rows scaled by
  * 2^scale_exp (0 for activations), layout of vs_split_pack_weight. */
 int vs_transpose_pack_split(const float *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu,
-                            int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, int32_t scale_exp, vs_stream_t stream);
+                            int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, int32_t scale_exp, float *colsum, vs_stream_t stream);
 /* hi = rne16(x), lo = rne16(x - hi) as two 16-bit images [rows, ld_out] of the f32 tensor in [rows, ld_in] (C columns, C % 4 == 0). */
 int vs_split16(const float *in, int64_t ld_in, void *hi, void *lo, int64_t ld_out, int64_t rows, int32_t C, vs_stream_t stream);
 /* Backward of vs_attention(_lse) with dtype 4 (same addressing, mask and key segments as vs_attention_backward).  *_hi / *_lo: the

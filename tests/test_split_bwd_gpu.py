@@ -38,6 +38,15 @@ def test_transpose_f32_and_pack(R, C, relu):
     p = ops.transpose_pack_split(x, 128, relu=relu)
     q = ops.split_pack_weight(ref, 0)
     assert torch.equal(p.data, q.data) and p.acc_scale == 1.0
+    if not relu:     # the bias gradient rides on the transpose of dY (f32 atomics over 64-row partial sums: order-dependent in the last bits)
+        cs = torch.full((C,), 7.0, device=d)
+        t2 = ops.transpose_f32(x, 128, colsum=cs)
+        want = x.double().sum(0)
+        assert torch.equal(t2, t) and float((cs.double() - want).abs().max()) <= 1e-5 * float(x.abs().sum(0).max())
+        cs2 = torch.full((C,), -3.0, device=d)
+        p2 = ops.transpose_pack_split(x, 128, scale_exp=3, colsum=cs2)
+        assert torch.equal(p2.data, ops.split_pack_weight(ref, 3).data)
+        assert float((cs2.double() - want).abs().max()) <= 1e-5 * float(x.abs().sum(0).max())
 
 
 def test_transpose_conv_tap():

@@ -75,8 +75,8 @@ def lib() -> C.CDLL:
             L = C.CDLL(_SO)
             L.vs_last_error.restype = C.c_char_p
             L.vs_abi_version.restype = C.c_int
-            if L.vs_abi_version() != 5:     # the ctypes mirrors of the structs below are for exactly this layout
-                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 5: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+            if L.vs_abi_version() != 6:     # the ctypes mirrors of the structs below are for exactly this layout
+                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 6: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
             L.vs_raster_forward.restype = C.c_int64
             L.vs_raster_forward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), AllocFn, C.c_void_p, C.c_void_p]
             L.vs_rope2d.restype = C.c_int
@@ -181,9 +181,9 @@ def lib() -> C.CDLL:
             L.vs_probe_mfma_rate.restype = C.c_int
             L.vs_probe_mfma_rate.argtypes = [vp, vp, i32, C.POINTER(C.c_double), vp]
             L.vs_transpose_f32.restype = C.c_int
-            L.vs_transpose_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_transpose_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
             L.vs_transpose_pack_split.restype = C.c_int
-            L.vs_transpose_pack_split.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+            L.vs_transpose_pack_split.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
             L.vs_split16.restype = C.c_int
             L.vs_split16.argtypes = [vp, i64, vp, vp, i64, i64, i32, vp]
             L.vs_attention_backward_split.restype = C.c_int

@@ -32,7 +32,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &h, unsign
 template <bool PACK>
 __global__ void __launch_bounds__(256)
 transpose_f32_kernel(const float *__restrict__ in, long long ld_in, void *__restrict__ out_, long long ld_out, int R, int C, int relu,
-                     int cH, int cW, int dy, int dx, float scale) {
+                     int cH, int cW, int dy, int dx, float scale, float *__restrict__ colsum) {
     __shared__ float t[64][65];
     const int tiles_c = (C + 63) >> 6;
     const int r0 = (int)(blockIdx.x / tiles_c) * 64, c0 = (int)(blockIdx.x % tiles_c) * 64;
@@ -78,6 +78,15 @@ transpose_f32_kernel(const float *__restrict__ in, long long ld_in, void *__rest
         }
     }
     __syncthreads();
+    if (colsum) {   // bias gradient on the way: thread (column tid >> 2, quarter tid & 3) sums 16 rows of the tile, the quarters meet by DPP
+        const int cc = threadIdx.x >> 2, part = threadIdx.x & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += t[part * 16 + i][cc];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0 && c0 + cc < C) unsafeAtomicAdd(colsum + c0 + cc, s / scale);   // (scale is a power of two: exact)
+    }
     if constexpr (!PACK) {
         float *out = reinterpret_cast<float *>(out_);
 #pragma unroll
@@ -240,21 +249,23 @@ upsample2x_backward_f32_kernel(const float *__restrict__ dout, float *__restrict
 }
 
 int transpose_f32_entry(const char *fn, bool pack, const float *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad,
-                        int32_t relu, int32_t cH, int32_t cW, int32_t dy, int32_t dx, int32_t scale_exp, hipStream_t stream) {
+                        int32_t relu, int32_t cH, int32_t cW, int32_t dy, int32_t dx, int32_t scale_exp, float *colsum, hipStream_t stream) {
     VS_CHECK(in && out, "%s: null pointer", fn);
+    VS_CHECK(!colsum || (!relu && (cH == 0 || dy == 2)), "%s: colsum goes with the plain and the bordered forms, without ReLU (every input row counted once)", fn);
     VS_CHECK(R >= 0 && C > 0 && Rpad >= R && Rpad % 64 == 0 && ld_in >= C && ld_out >= Rpad, "%s: bad sizes R=%d C=%d Rpad=%d (Rpad %% 64 == 0, ld_out >= Rpad)", fn, R, C, Rpad);
     VS_CHECK((cH == 0 && cW == 0) || (cH > 0 && cW > 0 && dy == 2 && R % ((cH + 2) * (cW + 2)) == 0) ||
                  (cH > 0 && cW > 0 && R % (cH * cW) == 0 && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1),
              "%s: a convolution tap needs R = whole H x W images and |dy|, |dx| <= 1 (tap_dy = 2: R = whole zero-bordered (H+2) x (W+2) images)", fn);
     VS_CHECK(ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "%s: out must be 16-byte aligned with ld_out %% 4 == 0", fn);
     VS_CHECK(scale_exp >= -30 && scale_exp <= 30, "%s: scale_exp out of range", fn);
+    if (colsum) VS_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)C, stream));
     if (Rpad == 0) return 0;
     const long long nblk = (long long)vs::cdiv(C, 64) * (Rpad / 64);
     VS_CHECK(nblk <= 0x7fffffffLL, "%s: too many tiles", fn);
     dim3 grid((unsigned)nblk), block(256);
     const float scale = ldexpf(1.0f, scale_exp);
-    if (pack) hipLaunchKernelGGL(transpose_f32_kernel<true>, grid, block, 0, stream, in, (long long)ld_in, out, (long long)ld_out, R, C, relu, cH, cW, dy, dx, scale);
-    else hipLaunchKernelGGL(transpose_f32_kernel<false>, grid, block, 0, stream, in, (long long)ld_in, out, (long long)ld_out, R, C, relu, cH, cW, dy, dx, scale);
+    if (pack) hipLaunchKernelGGL(transpose_f32_kernel<true>, grid, block, 0, stream, in, (long long)ld_in, out, (long long)ld_out, R, C, relu, cH, cW, dy, dx, scale, colsum);
+    else hipLaunchKernelGGL(transpose_f32_kernel<false>, grid, block, 0, stream, in, (long long)ld_in, out, (long long)ld_out, R, C, relu, cH, cW, dy, dx, scale, colsum);
     VS_HIP(hipGetLastError());
     return 0;
 }
@@ -262,14 +273,15 @@ int transpose_f32_entry(const char *fn, bool pack, const float *in, int64_t ld_i
 }  // namespace
 
 extern "C" int vs_transpose_f32(const float *in, int64_t ld_in, float *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu,
-                                int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, vs_stream_t stream_) {
-    return transpose_f32_entry("vs_transpose_f32", false, in, ld_in, out, ld_out, R, C, Rpad, relu, conv_H, conv_W, tap_dy, tap_dx, 0, (hipStream_t)stream_);
+                                int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, float *colsum, vs_stream_t stream_) {
+    return transpose_f32_entry("vs_transpose_f32", false, in, ld_in, out, ld_out, R, C, Rpad, relu, conv_H, conv_W, tap_dy, tap_dx, 0, colsum, (hipStream_t)stream_);
 }
 
 extern "C" int vs_transpose_pack_split(const float *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu,
-                                       int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, int32_t scale_exp, vs_stream_t stream_) {
+                                       int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, int32_t scale_exp, float *colsum,
+                                       vs_stream_t stream_) {
     return transpose_f32_entry("vs_transpose_pack_split", true, in, ld_in, out, ld_out, R, C, Rpad, relu, conv_H, conv_W, tap_dy, tap_dx, scale_exp,
-                               (hipStream_t)stream_);
+                               colsum, (hipStream_t)stream_);
 }
 
 extern "C" int vs_split16(const float *in, int64_t ld_in, void *hi, void *lo, int64_t ld_out, int64_t rows, int32_t C, vs_stream_t stream_) {

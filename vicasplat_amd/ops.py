@@ -1069,13 +1069,15 @@ def _border_rows(R, conv_hw, border):
 
 
 def transpose_f32(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0),
-                  border: bool = False, halo: int = 0) -> torch.Tensor:
+                  border: bool = False, halo: int = 0, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [R,C] f32 (row stride any multiple of 4 or contiguous) -> [C, Rpad] f32, Rpad = R rounded up to pad_to (a multiple of 64), zero padded.
     conv_hw = (H, W) with tap = (dy, dx): row r reads pixel r shifted by the tap, zero outside its image.  border=True: the transposed
     rows are the pixels of the zero-bordered (H+2) x (W+2) maps; halo > 0 (a multiple of 4): the result is the middle of a zero buffer with
-    `halo` readable zero columns on both sides (the operand whose shifted views the tap-fused weight gradient reads)."""
+    `halo` readable zero columns on both sides (the operand whose shifted views the tap-fused weight gradient reads).
+    colsum (f32 [C], overwritten): the column sums of x -- the bias gradient, on the pass that reads dY anyway."""
     dev = L.require_device(x)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0 and halo % 4 == 0
+    assert colsum is None or (colsum.dtype == torch.float32 and colsum.is_contiguous() and colsum.numel() == x.shape[1])
     R, Cc = x.shape
     Rb = _border_rows(R, conv_hw, border)
     Rpad = (Rb + pad_to - 1) // pad_to * pad_to
@@ -1087,13 +1089,13 @@ def transpose_f32(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv
     h, w = conv_hw if conv_hw is not None else (0, 0)
     dy, dx = (2, 0) if border else tap
     with torch.cuda.device(dev):
-        rc = L.lib().vs_transpose_f32(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), Rb, Cc, Rpad, int(relu), h, w, dy, dx, L.stream_ptr(dev))
+        rc = L.lib().vs_transpose_f32(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), Rb, Cc, Rpad, int(relu), h, w, dy, dx, L.ptr(colsum), L.stream_ptr(dev))
     L.check(rc, "vs_transpose_f32")
     return out
 
 
 def transpose_pack_split(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv_hw: Optional[tuple] = None, tap: tuple = (0, 0),
-                         scale_exp: int = 0, border: bool = False) -> SplitWeight:
+                         scale_exp: int = 0, border: bool = False, colsum: Optional[torch.Tensor] = None) -> SplitWeight:
     """transpose_f32 written as the packed split "weight" operand [C, Rpad] (SplitWeight, acc_scale = 2^-scale_exp)."""
     dev = L.require_device(x)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and pad_to % 64 == 0
@@ -1106,7 +1108,7 @@ def transpose_pack_split(x: torch.Tensor, pad_to: int = 64, *, relu: bool = Fals
         tap = (2, 0)
     with torch.cuda.device(dev):
         rc = L.lib().vs_transpose_pack_split(L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), R, Cc, Rpad, int(relu), h, w, tap[0], tap[1], scale_exp,
-                                             L.stream_ptr(dev))
+                                             L.ptr(colsum), L.stream_ptr(dev))
     L.check(rc, "vs_transpose_pack_split")
     return SplitWeight(out, 2.0 ** (-scale_exp), (Cc, Rpad))
 
@@ -1184,11 +1186,13 @@ def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *,
         Mp = (M + 1023) // 1024 * 1024 if M >= 4096 else (M + 127) // 128 * 128      # (room for the K split; zero rows cost nothing exact)
         dys = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
         xs = x if (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
-        dyT = transpose_f32(dys, Mp)                 # [N, Mp]
+        if need_db:
+            db = torch.empty(N, dtype=torch.float32, device=dev)          # the bias gradient rides on the transpose of dY
+        dyT = transpose_f32(dys, Mp, colsum=db)      # [N, Mp]
         xT = transpose_pack_split(xs, Mp)            # [K, Mp] packed
         dw = torch.empty((N, K), dtype=torch.float32, device=dev)
         _wgrad_split(dyT, xT, dw)
-    if need_db:
+    if need_db and db is None:
         db = colsum(dy)
     return dx, dw, db
 
@@ -1265,12 +1269,12 @@ def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *
     unit = 64 * ks * (2 if (Cin % 256 == 0 and Cout % 256 == 0) else 1)
     halo = (Wp + 2 + 3) // 4 * 4
     xT = transpose_f32(x.view(P, Cin), unit, relu=relu_in, conv_hw=(H, W), border=True, halo=halo)          # [Cin, Pp] view of the haloed buffer
-    dyT = transpose_pack_split(dy.view(P, Cout), unit, conv_hw=(H, W), border=True)                          # [Cout, Pp] packed
+    db = torch.empty(Cout, dtype=torch.float32, device=dev) if need_db else None                            # (rides on the transpose of dY)
+    dyT = transpose_pack_split(dy.view(P, Cout), unit, conv_hw=(H, W), border=True, colsum=db)              # [Cout, Pp] packed
     dw9 = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
     shifts = [(ty - 1) * Wp + (tx - 1) for ty in range(3) for tx in range(3)]
     gemm_wgrad_split(xT, dyT, dw9, ks, shifts=shifts)
     dw = dw9.view(3, 3, Cin, Cout).permute(3, 2, 0, 1).contiguous()                                          # [Cout, Cin, ky, kx]
-    db = colsum(dy.view(P, Cout)) if need_db else None
     return dx, dw, db
 
 
