@@ -1082,7 +1082,9 @@ def transpose_f32(x: torch.Tensor, pad_to: int = 64, *, relu: bool = False, conv
     Rb = _border_rows(R, conv_hw, border)
     Rpad = (Rb + pad_to - 1) // pad_to * pad_to
     if halo:
-        buf = torch.zeros((Cc, halo + Rpad + halo), dtype=torch.float32, device=dev)
+        buf = torch.empty((Cc, halo + Rpad + halo), dtype=torch.float32, device=dev)     # (the kernel writes all Rpad columns: only the halos need zeros)
+        buf[:, :halo].zero_()
+        buf[:, halo + Rpad:].zero_()
         out = buf[:, halo:halo + Rpad]
     else:
         out = torch.empty((Cc, Rpad), dtype=torch.float32, device=dev)
@@ -1173,13 +1175,18 @@ def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *,
     assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.stride(1) == 1 and x.stride(1) == 1
     dx = dw = db = None
     if need_dx:
-        wt = w.detach().float().t()
-        if N % 32 != 0:
-            wt = torch.nn.functional.pad(wt, (0, (-N) % 32))
-            dyp = torch.nn.functional.pad(dy, (0, (-N) % 32))
-        else:
+        wf = w.detach().float()
+        if N % 64 == 0 and scale_exp is not None and wf.is_contiguous():
             dyp = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
-        wtp = split_pack_weight(wt.contiguous(), scale_exp)
+            wtp = transpose_pack_split(wf, 64, scale_exp=int(scale_exp))          # pack(w^T) in one pass: no transposed f32 copy of the weight
+        else:
+            wt = wf.t()
+            if N % 32 != 0:
+                wt = torch.nn.functional.pad(wt, (0, (-N) % 32))
+                dyp = torch.nn.functional.pad(dy, (0, (-N) % 32))
+            else:
+                dyp = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
+            wtp = split_pack_weight(wt.contiguous(), scale_exp)
         dx = torch.empty((M, K), dtype=torch.float32, device=dev)
         _gemm_split(dyp, wtp, None, dx, EPI_STORE32)
     if need_dw:
