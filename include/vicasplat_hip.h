@@ -454,6 +454,15 @@ int vs_transpose_f32(const float *in, int64_t ld_in, float *out, int64_t ld_out,
  * 2^scale_exp (0 for activations), layout of vs_split_pack_weight. */
 int vs_transpose_pack_split(const float *in, int64_t ld_in, void *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu,
                             int32_t conv_H, int32_t conv_W, int32_t tap_dy, int32_t tap_dx, int32_t scale_exp, float *colsum, vs_stream_t stream);
+/* Split-class weight gradient with ONE operand read as it is in memory (reduction-major, no transposed copy): out32[M, N] (+)= sum_{k < Kred}
+ * A[k, m] Wp[n, k], A [Kred, M] f32 (row stride lda floats), Wp = vs_transpose_pack_split of the other operand, [N, Kpad] (row stride ldw 4-byte
+ * units, zero beyond Kred).  M, N multiples of 256, Kpad a multiple of 64 * ksplit; workspace (>= ksplit * M * N floats) / accumulate as in
+ * vs_gemm_wgrad.  transpose_out != 0: out is [N, M] (row stride ldo), the transpose of the product (workspace required).  nn.Linear: A = X
+ * [tokens, K], Wp = pack(dY^T) (whose pass also yields the bias gradient, colsum), transpose_out = 1 -> dW [N, K]: the vs_transpose_f32 /
+ * vs_transpose_pack_split pass over X is gone (model_wrapper.py:184-321 differentiates these layers with torch autograd). */
+int vs_gemm_wgrad_split_atn(const float *A, const void *Wp, float *out, int32_t M, int32_t N, int32_t Kred, int32_t Kpad, int32_t lda, int32_t ldw,
+                            int32_t ldo, int32_t ksplit, int32_t transpose_out, void *workspace, int64_t workspace_bytes, int32_t accumulate,
+                            vs_stream_t stream);
 /* hi = rne16(x), lo = rne16(x - hi) as two 16-bit images [rows, ld_out] of the f32 tensor in [rows, ld_in] (C columns, C % 4 == 0). */
 int vs_split16(const float *in, int64_t ld_in, void *hi, void *lo, int64_t ld_out, int64_t rows, int32_t C, vs_stream_t stream);
 /* Backward of vs_attention(_lse) with dtype 4 (same addressing, mask and key segments as vs_attention_backward).  *_hi / *_lo: the

@@ -65,6 +65,29 @@ def test_transpose_conv_tap():
             assert float(t[:, N * H * W:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("T,M,N,ks,tr", [(128, 256, 256, 1, False), (1000, 512, 256, 2, True), (16448, 1024, 768, 4, True), (4100, 256, 1024, 8, False)])
+def test_gemm_wgrad_split_atn_matches_float64(T, M, N, ks, tr):
+    """vs_gemm_wgrad_split_atn: out = a^T b with a [T, M] f32 read reduction-major (LDS transpose reads of the in-place converted (hi, lo)
+    halves) and b through the transposing pack; rows of `a` beyond T are never read (the buffer ends there)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(T + M + N)
+    a = torch.randn(T, M, generator=g).to(d)
+    b = torch.randn(T, N, generator=g).to(d)
+    Tp = (T + 64 * ks - 1) // (64 * ks) * (64 * ks)
+    bp = ops.transpose_pack_split(b, 64 * ks)
+    assert bp.data.shape == (N, Tp)
+    out = torch.full((N, M) if tr else (M, N), float("nan"), device=d)
+    ops.gemm_wgrad_split_atn(a, bp, out, ks, transpose_out=tr)
+    want = a.double().t() @ b.double()
+    assert _rel(out.t() if tr else out, want) <= TOL
+    # the round-3 route (both operands transposed by a pass) computes the same products in the same K-tile order
+    aT = ops.transpose_f32(a, 64 * ks)
+    ref = torch.empty(M, N, device=d)
+    ops.gemm_wgrad_split(aT, bp, ref, ks)
+    assert _rel(out.t() if tr else out, ref) <= 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(514, 768, 768), (16448, 1024, 1024), (100, 192, 64), (257, 3072, 768), (300, 8, 128), (5000, 83, 256), (2056, 1024, 4096)])
 def test_linear_backward_split_matches_float64(M, N, K):
     from vicasplat_amd import ops

@@ -632,6 +632,31 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restr
     }
 }
 
+// out[n, m] (+)= sum_s ws[(s * M + m) * N + n]: the second stage writing the TRANSPOSE of the GEMM's [M, N] result (32 x 32 tiles through LDS) --
+// for a weight gradient computed as dW^T = X^T dY (vs_gemm_wgrad_split_atn, transpose_out).  M, N multiples of 32.
+__global__ void __launch_bounds__(256) splitk_reduce_t_kernel(const float *__restrict__ ws, float *__restrict__ out, int M, int N, int ks, long long ldo,
+                                                              int accumulate) {
+    __shared__ float t[32][33];
+    const int tiles_n = N >> 5;
+    const int m0 = (int)(blockIdx.x / tiles_n) * 32, n0 = (int)(blockIdx.x % tiles_n) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long slice = (long long)M * N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float *p = ws + (long long)(m0 + ty + 8 * r) * N + n0 + tx;
+        float a = 0.f;
+        for (int s_ = 0; s_ < ks; ++s_) a += p[s_ * slice];
+        t[ty + 8 * r][tx] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float *o = out + (long long)(n0 + ty + 8 * r) * ldo + m0 + tx;
+        const float a = t[tx][ty + 8 * r];
+        *o = accumulate ? *o + a : a;
+    }
+}
+
 // Weight-gradient launches (split-K, optionally tap-fused): 256x256 tiles on the phase-interleaved main loop when the
 // output is made of whole 256-tiles and every K slice is an even number (>= 2) of 64-wide K tiles; 128x128 tiles otherwise.
 // With a workspace of ksplit * ntaps * M * N floats the slices store partial tiles and a second kernel sums them; without
@@ -922,6 +947,54 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     else hipLaunchKernelGGL((gemm256_tn_splitk_kernel<false>), dim3((unsigned)nwg), dim3(512), 0, stream, g);
     if (workspace) {
         const bool v4 = N % 4 == 0 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        const long long items = (long long)M * (v4 ? N / 4 : N);
+        const dim3 grid((unsigned)((items + 255) / 256));
+        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+// Split-class weight gradient with dY read as it is in memory: out32[M, N] (+)= sum_{k < Kred} A[k, m] Wp[n, k]; A [Kred, M] f32 (row stride lda
+// floats), Wp [N, Kpad] the packed (hi, lo) transposed X of vs_transpose_pack_split (row stride ldw 4-byte units, zero beyond Kred).  M, N multiples
+// of 256, Kpad a multiple of 64 * ksplit (an even number of 32-token K tiles per slice); rows of A in [Kred, Kpad) are not read.
+// transpose_out: out is [N, M] (row stride ldo >= M) = the transpose of the product, written by the second stage (workspace required).
+extern "C" int vs_gemm_wgrad_split_atn(const float *A, const void *Wp, float *out, int32_t M, int32_t N, int32_t Kred, int32_t Kpad, int32_t lda,
+                                       int32_t ldw, int32_t ldo, int32_t ksplit, int32_t transpose_out, void *workspace, int64_t workspace_bytes,
+                                       int32_t accumulate, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(A && Wp && out, "vs_gemm_wgrad_split_atn: null pointer");
+    VS_CHECK(!transpose_out || workspace, "vs_gemm_wgrad_split_atn: transpose_out needs a workspace (the transposing second stage)");
+    VS_CHECK(M > 0 && N > 0 && Kred > 0 && Kpad >= Kred && ksplit >= 1 && ksplit <= 65535, "vs_gemm_wgrad_split_atn: bad sizes");
+    VS_CHECK(M % 256 == 0 && N % 256 == 0, "vs_gemm_wgrad_split_atn: M=%d and N=%d must be multiples of 256", M, N);
+    VS_CHECK(Kpad % (64 * ksplit) == 0, "vs_gemm_wgrad_split_atn: Kpad=%d must be a multiple of 64 * ksplit (ksplit=%d)", Kpad, ksplit);
+    VS_CHECK(lda % 4 == 0 && lda >= M && ldw % 4 == 0 && ldw >= Kpad && ldo >= (transpose_out ? M : N), "vs_gemm_wgrad_split_atn: lda / ldw must be multiples of 4 and cover the rows");
+    VS_CHECK((((uintptr_t)A | (uintptr_t)Wp) & 15) == 0, "vs_gemm_wgrad_split_atn: A and Wp must be 16-byte aligned");
+    VS_CHECK(accumulate || workspace, "vs_gemm_wgrad_split_atn: accumulate = 0 (overwrite out) needs a workspace");
+    GemmArgs g;
+    g.A = A; g.W = Wp; g.bias = nullptr; g.out = out; g.gate = nullptr; g.resid = nullptr;
+    g.M = M; g.N = N; g.K = Kpad; g.lda = lda; g.ldw = 2 * ldw; g.ldo = ldo;
+    g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
+    g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
+    g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
+    const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
+    if (workspace) {
+        VS_CHECK(workspace_bytes >= need, "vs_gemm_wgrad_split_atn: workspace of %lld bytes given, %lld needed", (long long)workspace_bytes, need);
+        VS_CHECK(((uintptr_t)workspace & 15) == 0, "vs_gemm_wgrad_split_atn: workspace must be 16-byte aligned");
+        g.partials = (float *)workspace;
+    }
+    const long long nwg = (long long)(M / 256) * (N / 256) * ksplit;
+    VS_CHECK(nwg <= 0x7fffffffLL, "vs_gemm_wgrad_split_atn: grid too large");
+    hipLaunchKernelGGL(gemm256_split_atn_splitk_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, g);
+    if (transpose_out) {
+        hipLaunchKernelGGL(splitk_reduce_t_kernel, dim3((unsigned)((M / 32) * (N / 32))), dim3(256), 0, stream, (const float *)workspace, out, M, N, ksplit,
+                           (long long)ldo, accumulate);
+    } else if (workspace) {
+        const bool v4 = ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
         const long long items = (long long)M * (v4 ? N / 4 : N);
         const dim3 grid((unsigned)((items + 255) / 256));
         if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, (const float *)workspace, out, M, N, 1, ksplit, (long long)ldo, 0LL, accumulate);

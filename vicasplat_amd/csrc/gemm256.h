@@ -184,9 +184,19 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
 // segment for one and a read segment for the other.  The ReLU of an implicit-GEMM convolution is applied during the conversion.
 // A_PACKED: the A units arrive ALREADY converted (the packed (hi, lo) image of vs_split_pack_weight, whose 128-byte block of 32 k is exactly
 // the post-conversion LDS row: hi chunks 0..3 | lo chunks 0..3): no conversion segment, the loop is VALU-free like the 16-bit one.
-template <bool RELU_A, class Stager, bool A_PACKED = false>
+// A_TN (round 4, the weight gradient dW = dY^T X without a transposed copy of dY): the A operand is REDUCTION-MAJOR f32 in memory (element
+// (k, m) at k * lda + m).  An A unit is then [wave group g][32 k][64 tile rows x 4 B]: wave w of group g stages k rows 8 (w & 3) .. + 7 of
+// its group's half (still its own 2 KiB of the unit) and converts exactly those: a lane takes 8 floats = 8 consecutive tile rows of one k
+// (16-byte slots 4i + 2c, 4i + 2c + 1 of the 16-slot row; i = 16-row fragment, c = its half) and writes hi to slot 4i + c, lo to slot
+// 4i + 2 + c -- the two halves of a fragment swap slots inside ONE wave, whose loads all return before its stores issue.  A fragment is
+// gathered by the LDS transpose read (mainloop256, TN): lane t of a 16-lane group supplies the 8 bytes of tile rows 4 (t & 3) .. + 3 at
+// k = kb + (t >> 2) and receives tile row t at k = kb .. kb + 3; kb = 4 kg and 16 + 4 kg, the k order of chunk kg of the packed W operand
+// (gemm_common.h).  Slots are XORed with (k & 3) << 1 on the global-source side and on every LDS access (four k rows of a transpose read in
+// four different 8-bank windows; the XOR is even, so slot pairs stay pairs).  Conversions, waits and barriers are those of the NT loop.
+template <bool RELU_A, class Stager, bool A_PACKED = false, bool A_TN = false>
 __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (&acc)[8][4], unsigned char *smem, const int lane, const int wid) {
     static_assert(!(RELU_A && A_PACKED), "a packed A operand carries its ReLU already");
+    static_assert(!(A_TN && (A_PACKED || RELU_A)), "the reduction-major A operand is plain f32");
     constexpr unsigned UNITB = kUnitBytes256;
     constexpr int BF16 = kDtSplit;
     const int wr = wid >> 2, wc = wid & 3;
@@ -205,8 +215,30 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
     // CONTIGUOUS lanes under a 32-bank modulus, where rows 2k and 2k + 1 share their chunk slot (PMC, round 3: 18 % of the LDS cycles of
     // the kernel were bank conflicts with the fragment order); the ds_read_b128 groups stay conflict-free under this order too
     const int crow = 2 * (frow & 7) + (frow >> 3);
-    const unsigned cv0 = (unsigned)(crow * 128 + (((0 + fg) ^ (crow >> 1)) << 4));
-    const unsigned cv1 = (unsigned)(crow * 128 + (((4 + fg) ^ (crow >> 1)) << 4));
+    unsigned cv0 = (unsigned)(crow * 128 + (((0 + fg) ^ (crow >> 1)) << 4));     // conversion loads ...
+    unsigned cv1 = (unsigned)(crow * 128 + (((4 + fg) ^ (crow >> 1)) << 4));
+    unsigned cw0 = cv0, cw1 = cv1;                                              // ... and stores (in place)
+    [[maybe_unused]] unsigned tnA[4];
+    if constexpr (A_TN) {
+        // conversion item of this lane inside the wave's own 2 KiB (= wid * 2048 = cvp): k row lane >> 3 of the wave's 8, fragment half lane & 7
+        const int rr = lane >> 3, pi = lane & 7, ci = pi >> 1, cc = pi & 1, sw = (rr & 3) << 1;
+        cv0 = (unsigned)(rr * 256 + (((4 * ci + 2 * cc) ^ sw) << 4));
+        cv1 = cv0 + 16u;
+        cw0 = (unsigned)(rr * 256 + (((4 * ci + cc) ^ sw) << 4));
+        cw1 = cw0 ^ 32u;
+        // transpose reads: t = lane in its 16-lane group, kg = group
+        const int t = lane & 15, kg = lane >> 4, tq = t >> 2, c1 = (t & 3) >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tnA[i] = (unsigned)(wr * 8192 + (4 * kg + tq) * 256 + (((4 * i + c1) ^ (tq << 1)) << 4) + (t & 1) * 8);
+    }
+    typedef short tr4 __attribute__((ext_vector_type(4)));
+    typedef tr4 __attribute__((address_space(3))) *trp_t;
+    [[maybe_unused]] auto tr8 = [&](const unsigned char *p) -> uint4 {   // k = kb .. kb + 3 and kb + 16 .. kb + 19 of one tile row
+        const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned char *>(p)));
+        const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp_t)(const_cast<unsigned char *>(p + 16 * 256)));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
     uint4 fa[4][2], fb[2][2][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -215,8 +247,13 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
 
 #define VS_RD_A(h_, d_)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
-        fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd0);           \
-        fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd1);           \
+        if constexpr (A_TN) {                                                                                    \
+            fa[i][0] = tr8(smem + ((d_) * 4 + (h_)) * UNITB + tnA[i]);                                           \
+            fa[i][1] = tr8(smem + ((d_) * 4 + (h_)) * UNITB + (tnA[i] ^ 32u));                                   \
+        } else {                                                                                                 \
+            fa[i][0] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd0);       \
+            fa[i][1] = *reinterpret_cast<const uint4 *>(rdA + ((d_) * 4 + (h_)) * UNITB + i * 2048 + rd1);       \
+        }                                                                                                        \
     }
 #define VS_RD_B(h_, d_)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
@@ -239,8 +276,8 @@ __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (
             cx1.x = relu_f32_lds(cx1.x); cx1.y = relu_f32_lds(cx1.y); cx1.z = relu_f32_lds(cx1.z); cx1.w = relu_f32_lds(cx1.w); \
         }                                                                                                        \
         split8_lds(cx0, cx1);                                                                                    \
-        *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cv0) = cx0;                                 \
-        *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cv1) = cx1;                                 \
+        *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cw0) = cx0;                                 \
+        *reinterpret_cast<uint4 *>(cvp + ((d_) * 4 + (h_)) * UNITB + cw1) = cx1;                                 \
     }
 #define VS_LGK0 if constexpr (!A_PACKED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* conversion stores are in LDS before the barrier that publishes them */
 #define VS_MM(ha_, hb_)                                                                                          \
@@ -621,6 +658,80 @@ __global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArg
         g.ksplit = -1;
     }
     gemm_epilogue<BF16, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
+// ---- split-class weight gradient with the A operand reduction-major (mainloop256_split, A_TN): out32[M, N] (+)= sum_k A[k, m] Wp[n, k],
+// A = dY [tokens, M] f32 as it is in memory, Wp = the packed transposed X (vs_transpose_pack_split) [N, tokens].  Tiling, K slicing and
+// epilogue of gemm256_splitk_kernel; a K-tile is 32 tokens.  g.K = padded reduction length in tokens, g.k_valid = rows of A that exist. ----
+struct SplitStagerATN {
+    const float *pa[2][2];            // [A unit h][round]: this lane's 16 bytes in k row rrow[round] of K-tile 0 (nullptr: beyond the row)
+    const unsigned short *pw[2][2];   // [B unit h][round]
+    long long kstA;                   // floats per K-tile of A (32 rows)
+    int rrow[2], klim;
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
+        if (u < 2) {
+            const unsigned short *z = vs_zero_row256;
+            glds16((kt * 32 + rrow[0] < klim && pa[u][0]) ? (const void *)(pa[u][0] + kt * kstA) : (const void *)z, lds);
+            glds16((kt * 32 + rrow[1] < klim && pa[u][1]) ? (const void *)(pa[u][1] + kt * kstA) : (const void *)z, lds + 1024u);
+        } else {
+            glds16(pw[u - 2][0] + kt * 64, lds);
+            glds16(pw[u - 2][1] + kt * 64, lds + 1024u);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(512, 1) gemm256_split_atn_splitk_kernel(const GemmArgs g_in) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    GemmArgs g = g_in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles_n = (g.N + BN2 - 1) / BN2;
+    const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
+    const int ksp = blockIdx.x / tiles;
+    const int bid = blockIdx.x - ksp * tiles;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int KT = g.K / 32 / g.ksplit;                  // K-tiles of 32 tokens in this slice (even, >= 2: checked by the entry)
+    const long long k0 = (long long)ksp * KT * 32;
+
+    const float *A = reinterpret_cast<const float *>(g.A) + k0 * g.lda;
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + k0 * 2;     // packed: 64 two-byte units per 32 tokens
+    SplitStagerATN st;
+    st.kstA = 32LL * g.lda;
+    st.klim = (int)max(0LL, min((long long)KT * 32, (long long)g.k_valid - k0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        {   // A: k row and 16-byte slot of this lane inside its wave's 2 KiB; the slot holds logical chunk slot ^ ((k & 3) << 1)
+            const int rr = lane >> 4, r = (wid & 3) * 8 + j * 4 + rr;
+            const int c = (lane & 15) ^ (rr << 1);
+            st.rrow[j] = r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ca = m0 + wr * 128 + h * 64 + c * 4;
+                st.pa[h][j] = ca + 4 <= g.lda ? A + (long long)r * g.lda + ca : nullptr;
+            }
+        }
+        const int q = unit_row256(wid, j, lane);
+        const int src_chunk = unit_src_chunk256(q, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.N - 1);
+            st.pw[h][j] = W + (size_t)rw_ * g.ldw + src_chunk * 8;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256_split<false, SplitStagerATN, false, true>(st, KT, acc, smem, lane, wid);
+    g.bias = nullptr;
+    g.gate = nullptr;
+    g.ksplit = 2;
+    if (g.partials) {
+        g.out = g.partials + ((long long)ksp * g.M) * g.N;
+        g.ldo = g.N;
+        g.ksplit = -1;
+    }
+    gemm_epilogue<kDtSplit, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 
 // ---- reduction-major weight gradient of a 3x3 convolution (stride 1, pad 1): out32[tap][ci][co] (+)= sum over pixels p of

@@ -5,6 +5,7 @@ Every function requires HIP device tensors and raises otherwise -- there is no P
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -1150,6 +1151,29 @@ def gemm_wgrad_split(a: torch.Tensor, w: SplitWeight, out: torch.Tensor, ksplit:
     return out
 
 
+def gemm_wgrad_split_atn(a: torch.Tensor, w: SplitWeight, out: torch.Tensor, ksplit: int, *, transpose_out: bool = False) -> torch.Tensor:
+    """out32 [M,N] (or [N,M] with transpose_out) = a^T @ w^T in the split class: a [Kred, M] f32 AS IT IS in memory (reduction-major), w the packed
+    transposed other operand [N, Kpad] (transpose_pack_split); M, N multiples of 256, Kpad % (64 * ksplit) == 0 (vs_gemm_wgrad_split_atn)."""
+    wd = w.data
+    dev = L.require_device(a, wd, out)
+    assert a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and wd.dim() == 2 and wd.stride(1) == 1
+    Kred, M = a.shape
+    N, Kpad = wd.shape
+    assert Kpad >= Kred and Kpad % (64 * ksplit) == 0 and M % 256 == 0 and N % 256 == 0, (a.shape, wd.shape, ksplit)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape == ((N, M) if transpose_out else (M, N))
+    ws = torch.empty(ksplit * M * N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_gemm_wgrad_split_atn(L.ptr(a), L.ptr(wd), L.ptr(out), M, N, Kred, Kpad, a.stride(0), wd.stride(0), out.stride(0), ksplit,
+                                             int(transpose_out), L.ptr(ws), ws.numel() * 4, 0, L.stream_ptr(dev))
+    L.check(rc, "vs_gemm_wgrad_split_atn")
+    if w.acc_scale != 1.0:
+        out.mul_(w.acc_scale)
+    return out
+
+
+_WGRAD_ATN = os.environ.get("VS_WGRAD_ATN", "1") != "0"       # 0: the round-3 route (both operands through transposing passes): same-box A/B
+
+
 def _wgrad_split(dyT: torch.Tensor, xT: SplitWeight, out: torch.Tensor) -> torch.Tensor:
     M, N, K = dyT.shape[0], xT.shape[0], dyT.shape[1]
     if M % 256 == 0 and N % 256 == 0:
@@ -1195,10 +1219,19 @@ def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *,
         xs = x if (x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
         if need_db:
             db = torch.empty(N, dtype=torch.float32, device=dev)          # the bias gradient rides on the transpose of dY
-        dyT = transpose_f32(dys, Mp, colsum=db)      # [N, Mp]
-        xT = transpose_pack_split(xs, Mp)            # [K, Mp] packed
         dw = torch.empty((N, K), dtype=torch.float32, device=dev)
-        _wgrad_split(dyT, xT, dw)
+        if _WGRAD_ATN and N % 256 == 0 and K % 256 == 0:
+            # dW^T [K, N] = X^T dY with X read as it is (reduction-major A operand); only dY goes through a transposing (packing) pass
+            dyTp = transpose_pack_split(dys, Mp, colsum=db)               # [N, Mp] packed
+            tiles = (N // 256) * (K // 256)
+            ks = max(1, min((256 + tiles // 2) // tiles, Mp // 512))
+            while ks > 1 and Mp % (64 * ks) != 0:
+                ks -= 1
+            gemm_wgrad_split_atn(xs, dyTp, dw, ks, transpose_out=True)
+        else:
+            dyT = transpose_f32(dys, Mp, colsum=db)      # [N, Mp]
+            xT = transpose_pack_split(xs, Mp)            # [K, Mp] packed
+            _wgrad_split(dyT, xT, dw)
     if need_db and db is None:
         db = colsum(dy)
     return dx, dw, db
