@@ -463,6 +463,12 @@ int vs_transpose_pack_split(const float *in, int64_t ld_in, void *out, int64_t l
 int vs_gemm_wgrad_split_atn(const float *A, const void *Wp, float *out, int32_t M, int32_t N, int32_t Kred, int32_t Kpad, int32_t lda, int32_t ldw,
                             int32_t ldo, int32_t ksplit, int32_t transpose_out, void *workspace, int64_t workspace_bytes, int32_t accumulate,
                             vs_stream_t stream);
+/* The 3x3 convolution's weight gradient on the same main loop: out32[tap][ci][co] (+)= sum over pixels p of act(x)[p + tap offset][ci] dy[p][co] (zero
+ * outside the image), x [Nimg,H,W,Cin] f32 NHWC as it is (no zero-bordered transposed copy), dyTp = vs_transpose_pack_split(dy [pixels, Cout])
+ * [Cout, Ppad]; Cin, Cout multiples of 256, Ppad % (64 * ksplit) == 0; workspace >= ksplit * 9 * Cin * Cout floats or null (atomics). */
+int vs_conv3x3_wgrad_split_atn(const float *x, const void *dyTp, float *out, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t Ppad,
+                               int32_t ldw, int32_t relu_in, int32_t ksplit, void *workspace, int64_t workspace_bytes, int32_t accumulate,
+                               vs_stream_t stream);
 /* hi = rne16(x), lo = rne16(x - hi) as two 16-bit images [rows, ld_out] of the f32 tensor in [rows, ld_in] (C columns, C % 4 == 0). */
 int vs_split16(const float *in, int64_t ld_in, void *hi, void *lo, int64_t ld_out, int64_t rows, int32_t C, vs_stream_t stream);
 /* Backward of vs_attention(_lse) with dtype 4 (same addressing, mask and key segments as vs_attention_backward).  *_hi / *_lo: the

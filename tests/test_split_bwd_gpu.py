@@ -189,7 +189,9 @@ def test_attention_backward_split_matches_float64(case):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,relu_in", [(2, 16, 16, 64, 128, False), (1, 37, 21, 128, 256, True), (3, 64, 64, 256, 256, True),
-                                                    (1, 8, 8, 768, 256, False), (2, 32, 32, 128, 128, True)])
+                                                    (1, 8, 8, 768, 256, False), (2, 32, 32, 128, 128, True),
+                                                    # Cin, Cout multiples of 256: X read reduction-major by vs_conv3x3_wgrad_split_atn
+                                                    (1, 16, 16, 256, 512, False), (2, 37, 21, 256, 256, True), (5, 7, 50, 512, 256, False)])
 def test_conv3x3_backward_split_matches_float64(N, H, W, Cin, Cout, relu_in):
     from vicasplat_amd import ops
     d = _dev()

@@ -184,6 +184,8 @@ def lib() -> C.CDLL:
             L.vs_transpose_f32.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
             L.vs_gemm_wgrad_split_atn.restype = C.c_int
             L.vs_gemm_wgrad_split_atn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]
+            L.vs_conv3x3_wgrad_split_atn.restype = C.c_int
+            L.vs_conv3x3_wgrad_split_atn.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]
             L.vs_transpose_pack_split.restype = C.c_int
             L.vs_transpose_pack_split.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
             L.vs_split16.restype = C.c_int

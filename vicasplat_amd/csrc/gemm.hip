@@ -1004,6 +1004,50 @@ extern "C" int vs_gemm_wgrad_split_atn(const float *A, const void *Wp, float *ou
     return 0;
 }
 
+// Split-class weight gradient of nn.Conv2d(k=3, s=1, p=1) with X read as it is: out32[tap][ci][co] (+)= sum over pixels p of act(x)[p + tap offset][ci]
+// dy[p][co] (zero outside the image); x [Nimg,H,W,Cin] f32 NHWC contiguous, dyTp = vs_transpose_pack_split(dy [pixels, Cout]) [Cout, Ppad] (row stride ldw
+// 4-byte units, zero beyond the pixels), out [9, Cin, Cout].  Cin, Cout multiples of 256, Ppad a multiple of 64 * ksplit.
+extern "C" int vs_conv3x3_wgrad_split_atn(const float *x, const void *dyTp, float *out, int32_t Nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                          int32_t Ppad, int32_t ldw, int32_t relu_in, int32_t ksplit, void *workspace, int64_t workspace_bytes,
+                                          int32_t accumulate, vs_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK(x && dyTp && out, "vs_conv3x3_wgrad_split_atn: null pointer");
+    VS_CHECK(Nimg > 0 && H > 0 && W > 0 && ksplit >= 1 && ksplit <= 65535, "vs_conv3x3_wgrad_split_atn: bad sizes");
+    VS_CHECK(Cin > 0 && Cout > 0 && Cin % 256 == 0 && Cout % 256 == 0, "vs_conv3x3_wgrad_split_atn: Cin=%d and Cout=%d must be multiples of 256", Cin, Cout);
+    const long long P = (long long)Nimg * H * W;
+    VS_CHECK(P < 2147483647LL && Ppad >= P && Ppad % (64 * ksplit) == 0 && ldw % 4 == 0 && ldw >= Ppad, "vs_conv3x3_wgrad_split_atn: Ppad=%d must cover the pixels and be a multiple of 64 * ksplit", Ppad);
+    VS_CHECK((((uintptr_t)x | (uintptr_t)dyTp) & 15) == 0, "vs_conv3x3_wgrad_split_atn: x and dyTp must be 16-byte aligned");
+    VS_CHECK(accumulate || workspace, "vs_conv3x3_wgrad_split_atn: accumulate = 0 (overwrite out) needs a workspace");
+    GemmArgs g;
+    g.A = x; g.W = dyTp; g.bias = nullptr; g.out = out; g.gate = nullptr; g.resid = nullptr;
+    g.M = Cin; g.N = Cout; g.K = Ppad; g.lda = Cin; g.ldw = 2 * ldw; g.ldo = Cout;
+    g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
+    g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
+    g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 1;
+    g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
+    g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
+    const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
+    if (workspace) {
+        VS_CHECK(workspace_bytes >= need, "vs_conv3x3_wgrad_split_atn: workspace of %lld bytes given, %lld needed", (long long)workspace_bytes, need);
+        VS_CHECK(((uintptr_t)workspace & 15) == 0, "vs_conv3x3_wgrad_split_atn: workspace must be 16-byte aligned");
+        g.partials = (float *)workspace;
+    }
+    const long long nwg = (long long)(Cin / 256) * (Cout / 256) * 9 * ksplit;
+    VS_CHECK(nwg <= 0x7fffffffLL, "vs_conv3x3_wgrad_split_atn: grid too large");
+    if (relu_in) hipLaunchKernelGGL(conv3x3_wgrad_split_atn_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL(conv3x3_wgrad_split_atn_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, stream, g);
+    if (workspace) {
+        const bool v4 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        const long long items = 9LL * Cin * (v4 ? Cout / 4 : Cout);
+        const dim3 grid((unsigned)((items + 255) / 256));
+        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, stream, (const float *)workspace, out, Cin, Cout, 9, ksplit, (long long)Cout, g.tap_out_stride, accumulate);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(256), 0, stream, (const float *)workspace, out, Cin, Cout, 9, ksplit, (long long)Cout, g.tap_out_stride, accumulate);
+    }
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
 // Weight gradient of nn.Conv2d(k=3, s=1, p=1) from the NHWC tensors as they are: out32[tap][ci][co] (+)= sum over pixels of
 // act(x)[pixel + tap offset][ci] * dy[pixel][co] (zero outside the image), x [Nimg,H,W,Cin], dy [Nimg,H,W,Cout] contiguous 16-bit,
 // out [9, Cin, Cout] (tap = ky*3 + kx; transpose the last two axes for the module's [Cout, Cin, ky, kx]).  relu_in applies the

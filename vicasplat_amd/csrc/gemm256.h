@@ -196,7 +196,7 @@ __device__ __forceinline__ void mainloop256(Stager &st, const int KT, f4 (&acc)[
 template <bool RELU_A, class Stager, bool A_PACKED = false, bool A_TN = false>
 __device__ __forceinline__ void mainloop256_split(Stager &st, const int KT, f4 (&acc)[8][4], unsigned char *smem, const int lane, const int wid) {
     static_assert(!(RELU_A && A_PACKED), "a packed A operand carries its ReLU already");
-    static_assert(!(A_TN && (A_PACKED || RELU_A)), "the reduction-major A operand is plain f32");
+    static_assert(!(A_TN && A_PACKED), "the reduction-major A operand is plain f32");
     constexpr unsigned UNITB = kUnitBytes256;
     constexpr int BF16 = kDtSplit;
     const int wr = wid >> 2, wc = wid & 3;
@@ -728,6 +728,100 @@ __global__ void __launch_bounds__(512, 1) gemm256_split_atn_splitk_kernel(const 
     g.ksplit = 2;
     if (g.partials) {
         g.out = g.partials + ((long long)ksp * g.M) * g.N;
+        g.ldo = g.N;
+        g.ksplit = -1;
+    }
+    gemm_epilogue<kDtSplit, 2, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
+}
+
+// ---- split-class weight gradient of a 3x3 convolution (stride 1, pad 1) with X read as it is: out32[tap][ci][co] (+)= sum over pixels p of
+// act(X)[p + shift(tap)][ci] * dY[p][co]; X [pixels, Cin] f32 NHWC (the reduction-major A operand: tap shift = pixel-row shift, zero page
+// outside the image, per lane with an incremental (y, x) counter as ConvWgradStagerTN), Wp = vs_transpose_pack_split(dY) [Cout, Ppad].
+// blockIdx.x = (k-slice, tap, tile), tile fastest: the nine taps of a slice share X and dY through L2.  Cin, Cout multiples of 256. ----
+struct ConvSplitStagerATN {
+    const float *pa[2][2];            // [A unit h][round]: tap-shifted, K-tile 0
+    const unsigned short *pw[2][2];
+    long long kstA;
+    int rrow[2], klim;
+    int py[2][2], px[2][2];           // [A unit h][round]: (y, x) of the lane's (unshifted) pixel at the unit's NEXT staging call
+    int ty, tx, H, W, q32, r32;       // tap offset in {-1, 0, 1}^2; 32 = q32 * W + r32
+    __device__ __forceinline__ void stage(int u, int kt, unsigned lds) {
+        if (u < 2) {
+            const unsigned short *z = vs_zero_row256;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = py[u][j] + ty, x = px[u][j] + tx;
+                const bool ok = kt * 32 + rrow[j] < klim && pa[u][j] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                glds16(ok ? (const void *)(pa[u][j] + kt * kstA) : (const void *)z, lds + 1024u * j);
+                int nx = px[u][j] + r32, ny = py[u][j] + q32;
+                if (nx >= W) { nx -= W; ++ny; }
+                while (ny >= H) ny -= H;
+                px[u][j] = nx; py[u][j] = ny;
+            }
+        } else {
+            glds16(pw[u - 2][0] + kt * 64, lds);
+            glds16(pw[u - 2][1] + kt * 64, lds + 1024u);
+        }
+    }
+};
+
+template <bool RELU_A>
+__global__ void __launch_bounds__(512, 1) conv3x3_wgrad_split_atn_kernel(const GemmArgs g_in) {
+    constexpr int BM2 = 256, BN2 = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
+    GemmArgs g = g_in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles_n = g.N / BN2;
+    const int tiles = (g.M / BM2) * tiles_n;
+    const int ksp = blockIdx.x / (tiles * 9);
+    const int rem = blockIdx.x - ksp * tiles * 9;
+    const int tap = rem / tiles, bid = rem - tap * tiles;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int KT = g.K / 32 / g.ksplit;
+    const long long k0 = (long long)ksp * KT * 32;
+
+    ConvSplitStagerATN st;
+    st.ty = tap / 3 - 1; st.tx = tap - (tap / 3) * 3 - 1;
+    st.H = g.conv_H; st.W = g.conv_W; st.q32 = 32 / g.conv_W; st.r32 = 32 % g.conv_W;
+    const long long shift = (long long)st.ty * g.conv_W + st.tx;
+    const float *A = reinterpret_cast<const float *>(g.A) + (k0 + shift) * g.lda;
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W) + k0 * 2;
+    st.kstA = 32LL * g.lda;
+    st.klim = (int)max(0LL, min((long long)KT * 32, (long long)g.k_valid - k0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        {
+            const int rr = lane >> 4, r = (wid & 3) * 8 + j * 4 + rr;
+            const int c = (lane & 15) ^ (rr << 1);
+            st.rrow[j] = r;
+            const int rem_p = (int)((k0 + r) % ((long long)g.conv_H * g.conv_W));
+            const int y0 = rem_p / g.conv_W, x0 = rem_p - y0 * g.conv_W;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ca = m0 + wr * 128 + h * 64 + c * 4;
+                st.pa[h][j] = ca + 4 <= g.lda ? A + (long long)r * g.lda + ca : nullptr;
+                st.py[h][j] = y0; st.px[h][j] = x0;
+            }
+        }
+        const int q = unit_row256(wid, j, lane);
+        const int src_chunk = unit_src_chunk256(q, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rw_ = min(n0 + unit_b_tile_row256(q, h), g.N - 1);
+            st.pw[h][j] = W + (size_t)rw_ * g.ldw + src_chunk * 8;
+        }
+    }
+    f4 acc[8][4];
+    mainloop256_split<RELU_A, ConvSplitStagerATN, false, true>(st, KT, acc, smem, lane, wid);
+    g.bias = nullptr;
+    g.gate = nullptr;
+    g.out = reinterpret_cast<float *>(g.out) + (long long)tap * g.tap_out_stride;
+    g.ksplit = 2;
+    if (g.partials) {
+        g.out = g.partials + ((long long)(ksp * 9 + tap) * g.M) * g.N;
         g.ldo = g.N;
         g.ksplit = -1;
     }

@@ -1299,6 +1299,20 @@ def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *
     # shifts are column offsets of this operand: LDS-DMA reads any 4-byte aligned f32 address), W = dY^T [Cout, pixels] packed (hi, lo);
     # out[tap] = [Cin, Cout].  Two transposing passes instead of nine packed shifted images.
     P = N * H * W
+    if _WGRAD_ATN and Cin % 256 == 0 and Cout % 256 == 0:
+        # X read as it is by the reduction-major A operand (tap shift = pixel-row shift, zero page outside the image): only dY goes through a
+        # transposing (packing) pass, which also yields the bias gradient
+        tiles = (Cin // 256) * (Cout // 256) * 9
+        ks = max(1, min((256 + tiles // 2) // tiles, P // 512))
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if need_db else None
+        dyTp = transpose_pack_split(dy.view(P, Cout), 64 * ks, colsum=db)                                   # [Cout, Ppad] packed
+        dw9 = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
+        ws = torch.empty(ks * 9 * Cin * Cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lib().vs_conv3x3_wgrad_split_atn(L.ptr(x), L.ptr(dyTp.data), L.ptr(dw9), N, H, W, Cin, Cout, dyTp.data.shape[1], dyTp.data.stride(0),
+                                                    int(relu_in), ks, L.ptr(ws), ws.numel() * 4, 0, L.stream_ptr(dev))
+        L.check(rc, "vs_conv3x3_wgrad_split_atn")
+        return dx, dw9.view(3, 3, Cin, Cout).permute(3, 2, 0, 1).contiguous(), db
     Wp = W + 2
     Pb = N * (H + 2) * Wp
     tiles = ((Cin + 255) // 256) * ((Cout + 255) // 256) * 9 if (Cin % 256 == 0 and Cout % 256 == 0) else ((Cin + 127) // 128) * ((Cout + 127) // 128) * 9
