@@ -825,21 +825,15 @@ def layernorm_backward(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, b: 
         dx_add = dx
     assert dx_add is None or (dx_add.dtype == torch.float32 and dx_add.stride(1) == 1 and dx_add.shape == (M, Cc))
     assert dx16 is None or (dx16.dtype in (torch.float16, torch.bfloat16) and dx16.stride(1) == 1 and dx16.shape == (M, Cc))
-    dw = torch.zeros(Cc, dtype=torch.float32, device=dev)
-    db = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    dw, db = torch.zeros((2, Cc), dtype=torch.float32, device=dev).unbind(0)      # (one fill for the pair: the accumulators of f32 atomics)
     dscale = dshift = None
     mod_ld = 0
     if scale is not None:
         assert scale.dtype == torch.float32 and scale.stride(-1) == 1
-        dscale = torch.zeros((scale.shape[0], Cc), dtype=torch.float32, device=dev)
-        dshift = torch.zeros_like(dscale)
         mod_ld = scale.stride(0)
-        assert mod_ld == Cc or scale.shape[0] == 1 or True
+        # dscale / dshift are written with the row stride of `scale`: allocate [G, mod_ld] when the rows are wider than C
+        dscale, dshift = torch.zeros((2, scale.shape[0], mod_ld if mod_ld != Cc else Cc), dtype=torch.float32, device=dev).unbind(0)
     with torch.cuda.device(dev):
-        # dscale / dshift are written with the row stride of `scale`; give them the same stride by allocating [G, mod_ld]
-        if scale is not None and mod_ld != Cc:
-            dscale = torch.zeros((scale.shape[0], mod_ld), dtype=torch.float32, device=dev)
-            dshift = torch.zeros_like(dscale)
         rc = L.lib().vs_layernorm_backward_ex(L.ptr(dout), dout.stride(-2), _DT3[dout.dtype], L.ptr(x), x.stride(0), L.ptr(w), L.ptr(b),
                                               L.ptr(scale), mod_rows, mod_ld, L.ptr(dx), dx.stride(0), L.ptr(dx_add),
                                               dx_add.stride(0) if dx_add is not None else 0, L.ptr(dx16),
