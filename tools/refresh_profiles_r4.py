@@ -12,6 +12,9 @@ tr = "train2" if os.path.isdir(os.path.join(P3, "train2")) else "train"
 shutil.copy(one(tr + "/**/*kernel_stats.csv"), os.path.join(OUT, "round4_train_kernel_stats.csv"))
 if os.path.isdir(os.path.join(P3, "train_split")):
     shutil.copy(one("train_split/**/*kernel_stats.csv"), os.path.join(OUT, "round4_train_split_kernel_stats.csv"))
+for src, dst in (("train_line.json", "round4_train_step.json"), ("train_split_line.json", "round4_train_split_step.json")):
+    if os.path.exists(os.path.join(P3, src)) and open(os.path.join(P3, src)).read().strip():
+        json.dump(json.loads(open(os.path.join(P3, src)).read().strip().splitlines()[-1]), open(os.path.join(OUT, dst), "w"), indent=1)
 subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_traffic.py"), one("fetch/**/*counter_collection.csv"), one("write/**/*counter_collection.csv"),
                        "2", os.path.join(OUT, "round4_pmc_traffic.json")])
 pm = json.load(open(os.path.join(OUT, "round4_pmc_traffic.json")))

@@ -210,14 +210,15 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
     __shared__ float red[NW][MF][256];  // [wave][m-frag][16x16]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n0 = blockIdx.x * 16;
+    const int mlo = g.m_lo + (int)blockIdx.y * 16 * MF;     // (blockIdx.y: row groups of 16 * MF rows -- the <= 256-row tails of the big GEMMs)
     const int frow = lane & 15, fg = lane >> 4;
     const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
     const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
-    // MF 16-row fragments cover rows [m_lo, m_lo + 16*MF); rows past M are clamped duplicates whose results are dropped
+    // MF 16-row fragments cover rows [mlo, mlo + 16*MF); rows past M are clamped duplicates whose results are dropped
     const unsigned short *pa[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const int ra_ = min(g.m_lo + i * 16 + frow, g.M - 1);
+        const int ra_ = min(mlo + i * 16 + frow, g.M - 1);
         const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
         pa[i] = A + arow * g.lda + fg * 8;
     }
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
-                    split8(fa[u][i][0], fa[u][i][1]);
+                    if (!g.a_packed) split8(fa[u][i][0], fa[u][i][1]);      // (a packed row holds hi chunk fg / lo chunk fg at the same two addresses)
                     acc[i] = mma2<BF16>(fa[u][i][0], fa[u][i][1], fb[u][0], fb[u][1], acc[i]);
                 }
         }
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 uint4 fa0 = *reinterpret_cast<const uint4 *>(pa[i] + kp * 64), fa1 = *reinterpret_cast<const uint4 *>(pa[i] + kp * 64 + 32);
-                split8(fa0, fa1);
+                if (!g.a_packed) split8(fa0, fa1);
                 acc[i] = mma2<BF16>(fa0, fa1, fb0, fb1, acc[i]);
             }
         }
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
         for (int r = 0; r < 4; ++r) red[wid][i][(fg * 4 + r) * 16 + frow] = acc[i][r];
     __syncthreads();
     for (int e = tid; e < MF * 256; e += 64 * NW) {
-        const int i = e >> 8, rc = e & 255, m = g.m_lo + i * 16 + (rc >> 4), n = n0 + (rc & 15);
+        const int i = e >> 8, rc = e & 255, m = mlo + i * 16 + (rc >> 4), n = n0 + (rc & 15);
         if (m >= g.M || n >= g.N) continue;
         float v = 0.0f;
 #pragma unroll
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
 
 template <int BF16, int NW, int MF>
 int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
-    dim3 grid(vs::cdiv(g.N, 16)), block(64 * NW);
+    dim3 grid(vs::cdiv(g.N, 16), vs::cdiv(g.M - g.m_lo, 16 * MF)), block(64 * NW);
     switch (epi) {
         case 0: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 0, NW, MF>), grid, block, 0, stream, g); break;
         case 1: hipLaunchKernelGGL((gemm_smallm_kernel<BF16, 1, NW, MF>), grid, block, 0, stream, g); break;
@@ -536,8 +537,16 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
         while (ks < 8 && (g.K / 32) % (ks * 2) == 0 && g.K / 32 / (ks * 2) >= 8 && tiles * ks * 2 <= 512) ks *= 2;
         t.ksplit = ks;
     }
-    // (the RoPE epilogue pairs columns 16 apart: only the tile kernels hold both in one workgroup)
-    return rem <= 64 && epi != 4 && !g.a_packed ? launch_smallm<BF16>(t, epi, stream) : launch_mi<BF16, 4>(t, epi, stream);
+    // (the RoPE epilogue pairs columns 16 apart and a packed output is written in 32-column blocks: only the tile kernels hold those in one
+    // workgroup).  Round 4: the weight-streaming kernel takes row groups of 64 (blockIdx.y) and packed A rows, so VS_GEMM_TAIL_SMALLM=256 sends
+    // the 192-row tails of the bench step to it (plain stores of whole-K sums instead of the K-split tiles' f32 atomics).  Measured same-box:
+    // 246.6 / 248.3 vs 247.6 / 247.7 ms per step -- no gain (A is re-read by each of the N / 16 column workgroups); the default stays 64.
+    static const int tail_rows = [] { const char *e = getenv("VS_GEMM_TAIL_SMALLM"); return e ? atoi(e) : 64; }();
+    if (rem <= (BF16 == kDtSplit ? tail_rows : 64) && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) {
+        t.ksplit = 1;
+        return launch_smallm<BF16>(t, epi, stream);
+    }
+    return launch_mi<BF16, 4>(t, epi, stream);
 }
 
 // reference-precision path (exact f32 MFMA at 1/16 of the 16-bit rate): the matrix pipe, not the tile schedule, sets the time, so
@@ -553,7 +562,7 @@ template <int BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
-    if (g.M <= 64 && force == 0 && epi != 4 && !g.a_packed) return launch_smallm<BF16>(g, epi, stream);
+    if (g.M <= 64 && force == 0 && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) return launch_smallm<BF16>(g, epi, stream);
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
     // 256x256 tiles run one 8-wave workgroup per CU, i.e. in rounds of 256 tiles, and a partly filled round costs as much
