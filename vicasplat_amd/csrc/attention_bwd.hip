@@ -66,6 +66,19 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The same convert for a value that goes straight into an MFMA: compiler-visible instructions, so that the hazard recogniser inserts the
+// VALU-write -> MFMA-read wait states (it does not look inside inline asm; attention.hip, pack2v).
+template <bool BF16>
+__device__ __forceinline__ unsigned pack2v(float a, float b) {
+    typedef float f2p_ __attribute__((ext_vector_type(2)));
+    if constexpr (BF16) {
+        typedef __bf16 b2p_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2p_{a, b}, b2p_));
+    } else {
+        typedef _Float16 h2p_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2p_{a, b}, h2p_));
+    }
+}
 
 // 8 lanes per (row, head): each lane multiplies 8 elements (one 16-byte load of O and of dO), three DPP steps sum the 8 lanes.
 template <bool BF16>
@@ -142,32 +155,43 @@ __device__ __forceinline__ void dma_tile(const unsigned short *src, int ld, int 
     }
 }
 
-// ---- dQ: workgroup = 64 queries (4 waves x 16), lane = (query c16, key group g); loops over 64-key tiles ----
-template <bool BF16>
-__global__ void __launch_bounds__(256)
+// ---- dQ: workgroup = 64 * NG queries (4 waves x NG groups of 16; group u of wave w = rows q0 + (4u + w) * 16 ..), lane = (query c16, key
+// group g); loops over 64-key tiles.  NG = 2 (round 4): a K / V fragment read from LDS feeds the MFMAs of BOTH query groups -- with one group
+// per wave a tile costs a wave 24 LDS fragment reads for 24 MFMAs and the kernel was bound by the LDS pipe, not by the matrix pipe.  A
+// group whose 16 rows lie beyond Lq is skipped (wave-uniform); VS_ATTN_BWD_NG=1 restores one group per wave. ----
+template <bool BF16, int NG>
+__global__ void __launch_bounds__(256, 2)
 attn_bwd_dq_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2][2][TB * HD];   // [ring slot][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * NG);
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     const KeyList kl = key_list(a, b);
-    const int qi = q0 + wid * 16 + c16;
-    const bool qvalid = qi < a.Lq;
-    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
-    int my_len = qvalid ? kl.Lk : 0;
-    if (a.q_kvlen && qvalid) my_len = min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
-    // B-operand fragments (rows = queries): Q and dO
-    const unsigned short *qp = a.q + qrow * a.ldq + h * HD + g * 8, *dop = a.dout + qrow * a.lddo + h * HD + g * 8;
-    uint4 qf[2], dof[2];
-    qf[0] = *reinterpret_cast<const uint4 *>(qp); qf[1] = *reinterpret_cast<const uint4 *>(qp + 32);
-    dof[0] = *reinterpret_cast<const uint4 *>(dop); dof[1] = *reinterpret_cast<const uint4 *>(dop + 32);
-    if (!qvalid) dof[0] = dof[1] = make_uint4(0, 0, 0, 0);
-    const float L = qvalid ? a.lse[qrow * a.H + h] : INFINITY;
-    const float D = qvalid ? a.delta[qrow * a.H + h] : 0.f;
-    f4 dq[4];
+    bool qvalid[NG];
+    long long qrow[NG];
+    int my_len[NG], nact = 0;
+    uint4 qf[NG][2], dof[NG][2];
+    float L[NG], D[NG];
+    f4 dq[NG][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NG; ++u) {
+        const int qi = q0 + (u * 4 + wid) * 16 + c16;
+        qvalid[u] = qi < a.Lq;
+        if (q0 + (u * 4 + wid) * 16 < a.Lq) nact = u + 1;          // (wave-uniform: groups 0 .. nact - 1 hold at least one real query)
+        qrow[u] = b * a.q_batch_rows + (qvalid[u] ? qi : a.Lq - 1);
+        my_len[u] = qvalid[u] ? kl.Lk : 0;
+        if (a.q_kvlen && qvalid[u]) my_len[u] = min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+        // B-operand fragments (rows = queries): Q and dO
+        const unsigned short *qp = a.q + qrow[u] * a.ldq + h * HD + g * 8, *dop = a.dout + qrow[u] * a.lddo + h * HD + g * 8;
+        qf[u][0] = *reinterpret_cast<const uint4 *>(qp); qf[u][1] = *reinterpret_cast<const uint4 *>(qp + 32);
+        dof[u][0] = *reinterpret_cast<const uint4 *>(dop); dof[u][1] = *reinterpret_cast<const uint4 *>(dop + 32);
+        if (!qvalid[u]) dof[u][0] = dof[u][1] = make_uint4(0, 0, 0, 0);
+        L[u] = qvalid[u] ? a.lse[qrow[u] * a.H + h] : INFINITY;
+        D[u] = qvalid[u] ? a.delta[qrow[u] * a.H + h] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     auto issue = [&](int kt, int slot) {
         auto rk = [&](int r) { return kl.row(kt + r); };   // (clamped to the last key)
         dma_tile(a.k, a.ldk, h * HD, rk, lds0 + (unsigned)(slot * 2) * (TB * HD * 2), tid);
@@ -178,38 +202,57 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed ...
         __syncthreads();                                     // ... and everybody's; all waves are done with the other slot
         if (kt + TB < kl.Lk) issue(kt + TB, (it + 1) & 1);
+        if (nact == 0) continue;                             // (no real query in this wave: it only stages)
         const unsigned short *sK = smem[it & 1][0], *sV = smem[it & 1][1];
-        const bool tile_full = __builtin_amdgcn_ballot_w64(my_len < kt + TB) == 0ull;
-        uint4 dsf[2];
-        f4 ds[4];
+        bool short_row = false;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+        for (int u = 0; u < NG; ++u) short_row = short_row || (u < nact && my_len[u] < kt + TB);
+        const bool tile_full = __builtin_amdgcn_ballot_w64(short_row) == 0ull;
+        uint4 dsf[NG][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[sw_off(nb * 16 + c16, ks * 4 + g)]);
-                const uint4 vf = *reinterpret_cast<const uint4 *>(&sV[sw_off(nb * 16 + c16, ks * 4 + g)]);
-                s = mfma<BF16>(kf, qf[ks], s);      // S^T[key][query]
-                dp = mfma<BF16>(vf, dof[ks], dp);   // dP^T[key][query]
-            }
-            if (tile_full) {   // every key of the tile is visible to every query of the wave: no mask arithmetic
+        for (int ks2 = 0; ks2 < 2; ++ks2) {                  // key blocks 2 ks2, 2 ks2 + 1 -> the ks2-th k-step of dQ += dS K
+            f4 ds[NG][2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[nb][r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) * (dp[r] - D) * a.scale;
-            } else {
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int nb = 2 * ks2 + n2;
+                f4 s[NG], dp[NG];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + nb * 16 + g * 4 + r;
-                    const float p = key < my_len ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) : 0.f;
-                    ds[nb][r] = p * (dp[r] - D) * a.scale;
+                for (int u = 0; u < NG; ++u) s[u] = dp[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint4 kf = *reinterpret_cast<const uint4 *>(&sK[sw_off(nb * 16 + c16, ks * 4 + g)]);
+                    const uint4 vf = *reinterpret_cast<const uint4 *>(&sV[sw_off(nb * 16 + c16, ks * 4 + g)]);
+#pragma unroll
+                    for (int u = 0; u < NG; ++u)
+                        if (u < nact) {
+                            s[u] = mfma<BF16>(kf, qf[u][ks], s[u]);      // S^T[key][query]
+                            dp[u] = mfma<BF16>(vf, dof[u][ks], dp[u]);   // dP^T[key][query]
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    if (u >= nact) continue;
+                    if (tile_full) {   // every key of the tile is visible to every query of the wave: no mask arithmetic
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ds[u][n2][r] = __builtin_amdgcn_exp2f(fmaf(s[u][r], a.scale_log2e, -L[u])) * (dp[u][r] - D[u]) * a.scale;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt + nb * 16 + g * 4 + r;
+                            const float p = key < my_len[u] ? __builtin_amdgcn_exp2f(fmaf(s[u][r], a.scale_log2e, -L[u])) : 0.f;
+                            ds[u][n2][r] = p * (dp[u][r] - D[u]) * a.scale;
+                        }
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            dsf[ks].x = pack2<BF16>(ds[2 * ks][0], ds[2 * ks][1]);
-            dsf[ks].y = pack2<BF16>(ds[2 * ks][2], ds[2 * ks][3]);
-            dsf[ks].z = pack2<BF16>(ds[2 * ks + 1][0], ds[2 * ks + 1][1]);
-            dsf[ks].w = pack2<BF16>(ds[2 * ks + 1][2], ds[2 * ks + 1][3]);
+            for (int u = 0; u < NG; ++u) {
+                if (u >= nact) continue;
+                dsf[u][ks2].x = pack2v<BF16>(ds[u][0][0], ds[u][0][1]);
+                dsf[u][ks2].y = pack2v<BF16>(ds[u][0][2], ds[u][0][3]);
+                dsf[u][ks2].z = pack2v<BF16>(ds[u][1][0], ds[u][1][1]);
+                dsf[u][ks2].w = pack2v<BF16>(ds[u][1][2], ds[u][1][3]);
+            }
         }
         // dQ += dS K : A = dS (rows = query, k = keys in the permuted order of dsf), B = K^T rows d
 #pragma unroll
@@ -218,31 +261,36 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
             for (int ks = 0; ks < 2; ++ks) {
                 const uint2 lo = tr_rows4_sw(sK, (2 * ks) * 16 + g * 4, db * 16, c16);        // K[keys g*4..+3 of block 2ks][d = db*16 + c16]
                 const uint2 hi = tr_rows4_sw(sK, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                dq[db] = mfma<BF16>(make_uint4(lo.x, lo.y, hi.x, hi.y), dsf[ks], dq[db]);   // dQ^T += K^T dS^T: lane = query, registers = 4 consecutive d
+                const uint4 kt4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int u = 0; u < NG; ++u)
+                    if (u < nact) dq[u][db] = mfma<BF16>(kt4, dsf[u][ks], dq[u][db]);   // dQ^T += K^T dS^T: lane = query, registers = 4 consecutive d
             }
     }
     // dQ^T: query = this lane's c16, d = db*16 + g*4 + r; 16-byte stores (v_permlane16_swap: an even-g lane takes 8 consecutive d of
     // block db, an odd-g lane 8 of block db + 1), as the forward's store_o_rows
-    {
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        if (u >= nact) continue;
         typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
         uint2 pk[4];
 #pragma unroll
-        for (int db = 0; db < 4; ++db) { pk[db].x = pack2<BF16>(dq[db][0], dq[db][1]); pk[db].y = pack2<BF16>(dq[db][2], dq[db][3]); }
-        unsigned short *op = a.dq + qrow * a.lddq + h * HD + (g & ~1) * 4;
+        for (int db = 0; db < 4; ++db) { pk[db].x = pack2<BF16>(dq[u][db][0], dq[u][db][1]); pk[db].y = pack2<BF16>(dq[u][db][2], dq[u][db][3]); }
+        unsigned short *op = a.dq + qrow[u] * a.lddq + h * HD + (g & ~1) * 4;
         const bool odd = g & 1;
 #pragma unroll
         for (int d2 = 0; d2 < 4; d2 += 2) {
             const u2v_ sx = __builtin_amdgcn_permlane16_swap(pk[d2].x, pk[d2 + 1].x, false, false);
             const u2v_ sy = __builtin_amdgcn_permlane16_swap(pk[d2].y, pk[d2 + 1].y, false, false);
-            if (qvalid) *reinterpret_cast<uint4 *>(op + (d2 + (odd ? 1 : 0)) * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
+            if (qvalid[u]) *reinterpret_cast<uint4 *>(op + (d2 + (odd ? 1 : 0)) * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
         }
     }
 }
 
-// ---- dK, dV: workgroup = 64 keys of the batch item's key list (4 waves x 16), lane = (key c16, query group g); loops over
-// 64-query tiles ----
-template <bool BF16>
-__global__ void __launch_bounds__(256)
+// ---- dK, dV: workgroup = 64 * NG keys of the batch item's key list (4 waves x NG groups of 16, interleaved as in the dQ kernel), lane =
+// (key c16, query group g); loops over 64-query tiles: a Q / dO fragment read feeds the MFMAs of all the wave's key groups ----
+template <bool BF16, int NG>
+__global__ void __launch_bounds__(256, 2)
 attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2][2][TB * HD];   // [ring slot][Q | dO]
     __shared__ __attribute__((aligned(16))) float sL2[2][TB], sD2[2][TB];
@@ -250,20 +298,27 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     __shared__ int s_minlen2[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * (64 * NG);
     const KeyList kl = key_list(a, b);
     if (kt0 >= kl.Lk) return;
-    const int kj = kt0 + wid * 16 + c16;        // position of this lane's key in the key list
-    const bool kvalid = kj < kl.Lk;
-    const long long krow = kl.row(kj);
-    // B-operand fragments (rows = keys): K and V
-    const unsigned short *kp = a.k + krow * a.ldk + h * HD + g * 8, *vp = a.v + krow * a.ldv + h * HD + g * 8;
-    uint4 kf[2], vf[2];
-    kf[0] = *reinterpret_cast<const uint4 *>(kp); kf[1] = *reinterpret_cast<const uint4 *>(kp + 32);
-    vf[0] = *reinterpret_cast<const uint4 *>(vp); vf[1] = *reinterpret_cast<const uint4 *>(vp + 32);
-    f4 dk[4], dv[4];
+    int kj[NG], kg0[NG], nact = 0;              // position of this lane's key in the key list; first position of the group
+    bool kvalid[NG];
+    uint4 kf[NG][2], vf[NG][2];
+    f4 dk[NG][4], dv[NG][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NG; ++u) {
+        kg0[u] = kt0 + (u * 4 + wid) * 16;
+        kj[u] = kg0[u] + c16;
+        kvalid[u] = kj[u] < kl.Lk;
+        if (kg0[u] < kl.Lk) nact = u + 1;
+        const long long krow = kl.row(kj[u]);
+        // B-operand fragments (rows = keys): K and V
+        const unsigned short *kp = a.k + krow * a.ldk + h * HD + g * 8, *vp = a.v + krow * a.ldv + h * HD + g * 8;
+        kf[u][0] = *reinterpret_cast<const uint4 *>(kp); kf[u][1] = *reinterpret_cast<const uint4 *>(kp + 32);
+        vf[u][0] = *reinterpret_cast<const uint4 *>(vp); vf[u][1] = *reinterpret_cast<const uint4 *>(vp + 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dk[u][i] = dv[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     auto issue = [&](int qt, int slot) {
         auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
@@ -304,83 +359,108 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
         const float *sL = sL2[slot], *sD = sD2[slot];
         const int *sLen = sLen2[slot];
         const int s_minlen = s_minlen2[slot];
-        // all 16 keys of the wave are real and visible to all 64 queries of the tile: no mask arithmetic, no per-element length reads
-        const bool tile_full = kt0 + wid * 16 + 16 <= min(kl.Lk, s_minlen);
-        f4 p[4], ds[4];
+        if (nact > 0) {
+            uint4 pf[NG][2], dsf[NG][2];
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+            for (int ks2 = 0; ks2 < 2; ++ks2) {              // query blocks 2 ks2, 2 ks2 + 1 -> the ks2-th k-step of dV / dK
+                f4 p[NG][2], ds[NG][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint4 qa = *reinterpret_cast<const uint4 *>(&sQ[sw_off(qb * 16 + c16, ks * 4 + g)]);
-                const uint4 da = *reinterpret_cast<const uint4 *>(&sDO[sw_off(qb * 16 + c16, ks * 4 + g)]);
-                s = mfma<BF16>(qa, kf[ks], s);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
-                dp = mfma<BF16>(da, vf[ks], dp);   // dP[query][key]
-            }
-            const float4 L4 = *reinterpret_cast<const float4 *>(&sL[qb * 16 + g * 4]), D4 = *reinterpret_cast<const float4 *>(&sD[qb * 16 + g * 4]);
-            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
-            if (tile_full) {
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const int qb = 2 * ks2 + n2;
+                    f4 s[NG], dp[NG];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -Lr[r]));
-                    p[qb][r] = pv;
-                    ds[qb][r] = pv * (dp[r] - Dr[r]) * a.scale;
+                    for (int u = 0; u < NG; ++u) s[u] = dp[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const uint4 qa = *reinterpret_cast<const uint4 *>(&sQ[sw_off(qb * 16 + c16, ks * 4 + g)]);
+                        const uint4 da = *reinterpret_cast<const uint4 *>(&sDO[sw_off(qb * 16 + c16, ks * 4 + g)]);
+#pragma unroll
+                        for (int u = 0; u < NG; ++u)
+                            if (u < nact) {
+                                s[u] = mfma<BF16>(qa, kf[u][ks], s[u]);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
+                                dp[u] = mfma<BF16>(da, vf[u][ks], dp[u]);   // dP[query][key]
+                            }
+                    }
+                    const float4 L4 = *reinterpret_cast<const float4 *>(&sL[qb * 16 + g * 4]), D4 = *reinterpret_cast<const float4 *>(&sD[qb * 16 + g * 4]);
+                    const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+                    const int4 N4 = *reinterpret_cast<const int4 *>(&sLen[qb * 16 + g * 4]);
+                    const int Nr[4] = {N4.x, N4.y, N4.z, N4.w};
+#pragma unroll
+                    for (int u = 0; u < NG; ++u) {
+                        if (u >= nact) continue;
+                        // all 16 keys of the group are real and visible to all 64 queries of the tile: no mask arithmetic
+                        const bool tile_full = kg0[u] + 16 <= min(kl.Lk, s_minlen);
+                        if (tile_full) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][r], a.scale_log2e, -Lr[r]));
+                                p[u][n2][r] = pv;
+                                ds[u][n2][r] = pv * (dp[u][r] - Dr[r]) * a.scale;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float pv = (kvalid[u] && kj[u] < Nr[r]) ? __builtin_amdgcn_exp2f(fmaf(s[u][r], a.scale_log2e, -Lr[r])) : 0.f;
+                                p[u][n2][r] = pv;
+                                ds[u][n2][r] = pv * (dp[u][r] - Dr[r]) * a.scale;
+                            }
+                        }
+                    }
                 }
-            } else {
-                const int4 N4 = *reinterpret_cast<const int4 *>(&sLen[qb * 16 + g * 4]);
-                const int Nr[4] = {N4.x, N4.y, N4.z, N4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = (kvalid && kj < Nr[r]) ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -Lr[r])) : 0.f;
-                    p[qb][r] = pv;
-                    ds[qb][r] = pv * (dp[r] - Dr[r]) * a.scale;
+                for (int u = 0; u < NG; ++u) {
+                    if (u >= nact) continue;
+                    pf[u][ks2].x = pack2v<BF16>(p[u][0][0], p[u][0][1]);   pf[u][ks2].y = pack2v<BF16>(p[u][0][2], p[u][0][3]);
+                    pf[u][ks2].z = pack2v<BF16>(p[u][1][0], p[u][1][1]);   pf[u][ks2].w = pack2v<BF16>(p[u][1][2], p[u][1][3]);
+                    dsf[u][ks2].x = pack2v<BF16>(ds[u][0][0], ds[u][0][1]); dsf[u][ks2].y = pack2v<BF16>(ds[u][0][2], ds[u][0][3]);
+                    dsf[u][ks2].z = pack2v<BF16>(ds[u][1][0], ds[u][1][1]); dsf[u][ks2].w = pack2v<BF16>(ds[u][1][2], ds[u][1][3]);
                 }
             }
+            // dV += P^T dO, dK += dS^T Q : A = P^T / dS^T (rows = key, k = queries in the packed order), B = dO^T / Q^T rows d
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint2 dlo = tr_rows4_sw(sDO, (2 * ks) * 16 + g * 4, db * 16, c16), dhi = tr_rows4_sw(sDO, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                    const uint2 qlo = tr_rows4_sw(sQ, (2 * ks) * 16 + g * 4, db * 16, c16), qhi = tr_rows4_sw(sQ, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
+                    const uint4 dO4 = make_uint4(dlo.x, dlo.y, dhi.x, dhi.y), q4 = make_uint4(qlo.x, qlo.y, qhi.x, qhi.y);
+#pragma unroll
+                    for (int u = 0; u < NG; ++u)
+                        if (u < nact) {
+                            dv[u][db] = mfma<BF16>(pf[u][ks], dO4, dv[u][db]);
+                            dk[u][db] = mfma<BF16>(dsf[u][ks], q4, dk[u][db]);
+                        }
+                }
         }
-        uint4 pf[2], dsf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            pf[ks].x = pack2<BF16>(p[2 * ks][0], p[2 * ks][1]);       pf[ks].y = pack2<BF16>(p[2 * ks][2], p[2 * ks][3]);
-            pf[ks].z = pack2<BF16>(p[2 * ks + 1][0], p[2 * ks + 1][1]); pf[ks].w = pack2<BF16>(p[2 * ks + 1][2], p[2 * ks + 1][3]);
-            dsf[ks].x = pack2<BF16>(ds[2 * ks][0], ds[2 * ks][1]);       dsf[ks].y = pack2<BF16>(ds[2 * ks][2], ds[2 * ks][3]);
-            dsf[ks].z = pack2<BF16>(ds[2 * ks + 1][0], ds[2 * ks + 1][1]); dsf[ks].w = pack2<BF16>(ds[2 * ks + 1][2], ds[2 * ks + 1][3]);
-        }
-        // dV += P^T dO, dK += dS^T Q : A = P^T / dS^T (rows = key, k = queries in the packed order), B = dO^T / Q^T rows d
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint2 dlo = tr_rows4_sw(sDO, (2 * ks) * 16 + g * 4, db * 16, c16), dhi = tr_rows4_sw(sDO, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                const uint2 qlo = tr_rows4_sw(sQ, (2 * ks) * 16 + g * 4, db * 16, c16), qhi = tr_rows4_sw(sQ, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                dv[db] = mfma<BF16>(pf[ks], make_uint4(dlo.x, dlo.y, dhi.x, dhi.y), dv[db]);
-                dk[db] = mfma<BF16>(dsf[ks], make_uint4(qlo.x, qlo.y, qhi.x, qhi.y), dk[db]);
-            }
         if (more && tid < TB) aux_store((it + 1) & 1);   // (read after the next barrier; last read two barriers ago)
     }
-    // dK / dV rows key = g*4 + r (of this wave's 16), cols d = db*16 + c16
+    // dK / dV rows key = g*4 + r (of the group's 16), cols d = db*16 + c16
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kpos = kt0 + wid * 16 + g * 4 + r;
-        if (kpos >= kl.Lk) continue;
-        const long long row = kl.row(kpos);
-        if (a.dk16) {
-            unsigned short *pk = a.dk16 + row * a.lddk + h * HD + c16, *pv = a.dv16 + row * a.lddv + h * HD + c16;
+    for (int u = 0; u < NG; ++u) {
+        if (u >= nact) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kpos = kg0[u] + g * 4 + r;
+            if (kpos >= kl.Lk) continue;
+            const long long row = kl.row(kpos);
+            if (a.dk16) {
+                unsigned short *pk = a.dk16 + row * a.lddk + h * HD + c16, *pv = a.dv16 + row * a.lddv + h * HD + c16;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    pk[db * 16] = (unsigned short)(pack2<BF16>(dk[u][db][r], 0.f) & 0xffffu);
+                    pv[db * 16] = (unsigned short)(pack2<BF16>(dv[u][db][r], 0.f) & 0xffffu);
+                }
+                continue;
+            }
+            float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                pk[db * 16] = (unsigned short)(pack2<BF16>(dk[db][r], 0.f) & 0xffffu);
-                pv[db * 16] = (unsigned short)(pack2<BF16>(dv[db][r], 0.f) & 0xffffu);
+                unsafeAtomicAdd(pk + db * 16, dk[u][db][r]);
+                unsafeAtomicAdd(pv + db * 16, dv[u][db][r]);
             }
-            continue;
-        }
-        float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            unsafeAtomicAdd(pk + db * 16, dk[db][r]);
-            unsafeAtomicAdd(pv + db * 16, dv[db][r]);
         }
     }
 }
-
 
 // ================= split operand class (dtype 4): the reference-precision backward =================
 // Every tensor is f32 in HBM; the MFMA operands are (hi, lo) f16 pairs, hi = rne16(x), lo = rne16(x - hi), and every product is three
@@ -426,33 +506,42 @@ attn_delta_f32_kernel(const AttnBwdArgs a, long long rows) {
     if (live && sub == 0) a.delta[item] = v;
 }
 
-__global__ void __launch_bounds__(256)
+// NG row groups of 16 per wave (round 4), as the 16-bit kernels above: one K / V (Q / dO) fragment read from LDS feeds the 3-MFMA products of
+// all the wave's groups.
+template <int NG>
+__global__ void __launch_bounds__(256, 2)
 attn_bwd_dq_split_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2][4][TB * HD];   // [ring slot][K hi | K lo | V hi | V lo]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * NG);
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     const KeyList kl = key_list(a, b);
-    const int qi = q0 + wid * 16 + c16;
-    const bool qvalid = qi < a.Lq;
-    const long long qrow = b * a.q_batch_rows + (qvalid ? qi : a.Lq - 1);
-    int my_len = qvalid ? kl.Lk : 0;
-    if (a.q_kvlen && qvalid) my_len = min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
-    uint4 qh[2], ql[2], doh[2], dol[2];
-    {
-        const long long qo = qrow * a.ldq + h * HD + g * 8, dO = qrow * a.lddo + h * HD + g * 8;
-        qh[0] = *reinterpret_cast<const uint4 *>(a.q + qo); qh[1] = *reinterpret_cast<const uint4 *>(a.q + qo + 32);
-        ql[0] = *reinterpret_cast<const uint4 *>(a.q_lo + qo); ql[1] = *reinterpret_cast<const uint4 *>(a.q_lo + qo + 32);
-        doh[0] = *reinterpret_cast<const uint4 *>(a.dout + dO); doh[1] = *reinterpret_cast<const uint4 *>(a.dout + dO + 32);
-        dol[0] = *reinterpret_cast<const uint4 *>(a.dout_lo + dO); dol[1] = *reinterpret_cast<const uint4 *>(a.dout_lo + dO + 32);
-    }
-    if (!qvalid) doh[0] = doh[1] = dol[0] = dol[1] = make_uint4(0, 0, 0, 0);
-    const float L = qvalid ? a.lse[qrow * a.H + h] : INFINITY;
-    const float D = qvalid ? a.delta[qrow * a.H + h] : 0.f;
-    f4 dq[4];
+    bool qvalid[NG];
+    long long qrow[NG];
+    int my_len[NG], nact = 0;
+    uint4 qh[NG][2], ql[NG][2], doh[NG][2], dol[NG][2];
+    float L[NG], D[NG];
+    f4 dq[NG][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dq[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NG; ++u) {
+        const int qi = q0 + (u * 4 + wid) * 16 + c16;
+        qvalid[u] = qi < a.Lq;
+        if (q0 + (u * 4 + wid) * 16 < a.Lq) nact = u + 1;
+        qrow[u] = b * a.q_batch_rows + (qvalid[u] ? qi : a.Lq - 1);
+        my_len[u] = qvalid[u] ? kl.Lk : 0;
+        if (a.q_kvlen && qvalid[u]) my_len[u] = min(kl.Lk, a.q_kvlen[(long long)b * a.Lq + qi]);
+        const long long qo = qrow[u] * a.ldq + h * HD + g * 8, dO = qrow[u] * a.lddo + h * HD + g * 8;
+        qh[u][0] = *reinterpret_cast<const uint4 *>(a.q + qo); qh[u][1] = *reinterpret_cast<const uint4 *>(a.q + qo + 32);
+        ql[u][0] = *reinterpret_cast<const uint4 *>(a.q_lo + qo); ql[u][1] = *reinterpret_cast<const uint4 *>(a.q_lo + qo + 32);
+        doh[u][0] = *reinterpret_cast<const uint4 *>(a.dout + dO); doh[u][1] = *reinterpret_cast<const uint4 *>(a.dout + dO + 32);
+        dol[u][0] = *reinterpret_cast<const uint4 *>(a.dout_lo + dO); dol[u][1] = *reinterpret_cast<const uint4 *>(a.dout_lo + dO + 32);
+        if (!qvalid[u]) doh[u][0] = doh[u][1] = dol[u][0] = dol[u][1] = make_uint4(0, 0, 0, 0);
+        L[u] = qvalid[u] ? a.lse[qrow[u] * a.H + h] : INFINITY;
+        D[u] = qvalid[u] ? a.delta[qrow[u] * a.H + h] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     auto issue = [&](int kt, int slot) {
         auto rk = [&](int r) { return kl.row(kt + r); };
         const unsigned base = lds0 + (unsigned)(slot * 4) * (TB * HD * 2);
@@ -466,70 +555,97 @@ attn_bwd_dq_split_kernel(const AttnBwdArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + TB < kl.Lk) issue(kt + TB, (it + 1) & 1);
+        if (nact == 0) continue;                             // (no real query in this wave: it only stages)
         const unsigned short *sKh = smem[it & 1][0], *sKl = smem[it & 1][1], *sVh = smem[it & 1][2], *sVl = smem[it & 1][3];
-        f4 ds[4];
+        uint4 dsh[NG][2], dsl[NG][2];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            f4 ds[NG][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = sw_off(nb * 16 + c16, ks * 4 + g);
-                const uint4 kfh = *reinterpret_cast<const uint4 *>(&sKh[off]), kfl = *reinterpret_cast<const uint4 *>(&sKl[off]);
-                const uint4 vfh = *reinterpret_cast<const uint4 *>(&sVh[off]), vfl = *reinterpret_cast<const uint4 *>(&sVl[off]);
-                s = mma3(kfh, kfl, qh[ks], ql[ks], s);       // S^T[key][query]
-                dp = mma3(vfh, vfl, doh[ks], dol[ks], dp);   // dP^T[key][query]
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const int nb = 2 * ks2 + n2;
+                f4 s[NG], dp[NG];
+#pragma unroll
+                for (int u = 0; u < NG; ++u) s[u] = dp[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int off = sw_off(nb * 16 + c16, ks * 4 + g);
+                    const uint4 kfh = *reinterpret_cast<const uint4 *>(&sKh[off]), kfl = *reinterpret_cast<const uint4 *>(&sKl[off]);
+                    const uint4 vfh = *reinterpret_cast<const uint4 *>(&sVh[off]), vfl = *reinterpret_cast<const uint4 *>(&sVl[off]);
+#pragma unroll
+                    for (int u = 0; u < NG; ++u)
+                        if (u < nact) {
+                            s[u] = mma3(kfh, kfl, qh[u][ks], ql[u][ks], s[u]);        // S^T[key][query]
+                            dp[u] = mma3(vfh, vfl, doh[u][ks], dol[u][ks], dp[u]);    // dP^T[key][query]
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    if (u >= nact) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt + nb * 16 + g * 4 + r;
+                        const float p = key < my_len[u] ? __builtin_amdgcn_exp2f(fmaf(s[u][r], a.scale_log2e, -L[u])) : 0.f;
+                        ds[u][n2][r] = p * (dp[u][r] - D[u]) * a.scale;
+                    }
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + nb * 16 + g * 4 + r;
-                const float p = key < my_len ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -L)) : 0.f;
-                ds[nb][r] = p * (dp[r] - D) * a.scale;
-            }
+            for (int u = 0; u < NG; ++u)
+                if (u < nact) split_frag(ds[u][0], ds[u][1], dsh[u][ks2], dsl[u][ks2], 0);
         }
-        uint4 dsh[2], dsl[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) split_frag(ds[2 * ks], ds[2 * ks + 1], dsh[ks], dsl[ks], 0);
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const uint2 hlo = tr_rows4_sw(sKh, (2 * ks) * 16 + g * 4, db * 16, c16), hhi = tr_rows4_sw(sKh, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
                 const uint2 llo = tr_rows4_sw(sKl, (2 * ks) * 16 + g * 4, db * 16, c16), lhi = tr_rows4_sw(sKl, (2 * ks + 1) * 16 + g * 4, db * 16, c16);
-                dq[db] = mma3(make_uint4(hlo.x, hlo.y, hhi.x, hhi.y), make_uint4(llo.x, llo.y, lhi.x, lhi.y), dsh[ks], dsl[ks], dq[db]);
+                const uint4 kth = make_uint4(hlo.x, hlo.y, hhi.x, hhi.y), ktl = make_uint4(llo.x, llo.y, lhi.x, lhi.y);
+#pragma unroll
+                for (int u = 0; u < NG; ++u)
+                    if (u < nact) dq[u][db] = mma3(kth, ktl, dsh[u][ks], dsl[u][ks], dq[u][db]);
             }
     }
     // dQ^T: query = this lane's c16, d = db*16 + g*4 + r: one 16-byte f32 store per block
-    if (qvalid) {
-        float *op = a.dq32 + qrow * a.lddq32 + h * HD + g * 4;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) *reinterpret_cast<float4 *>(op + db * 16) = make_float4(dq[db][0], dq[db][1], dq[db][2], dq[db][3]);
+    for (int u = 0; u < NG; ++u) {
+        if (u >= nact || !qvalid[u]) continue;
+        float *op = a.dq32 + qrow[u] * a.lddq32 + h * HD + g * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<float4 *>(op + db * 16) = make_float4(dq[u][db][0], dq[u][db][1], dq[u][db][2], dq[u][db][3]);
     }
 }
 
-__global__ void __launch_bounds__(256)
+template <int NG>
+__global__ void __launch_bounds__(256, 2)
 attn_bwd_dkv_split_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2][4][TB * HD];   // [ring slot][Q hi | Q lo | dO hi | dO lo]
     __shared__ __attribute__((aligned(16))) float sL2[2][TB], sD2[2][TB];
     __shared__ __attribute__((aligned(16))) int sLen2[2][TB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * (64 * NG);
     const KeyList kl = key_list(a, b);
     if (kt0 >= kl.Lk) return;
-    const int kj = kt0 + wid * 16 + c16;
-    const bool kvalid = kj < kl.Lk;
-    const long long krow = kl.row(kj);
-    uint4 kh[2], klo[2], vh[2], vl[2];
-    {
-        const long long ko = krow * a.ldk + h * HD + g * 8, vo = krow * a.ldv + h * HD + g * 8;
-        kh[0] = *reinterpret_cast<const uint4 *>(a.k + ko); kh[1] = *reinterpret_cast<const uint4 *>(a.k + ko + 32);
-        klo[0] = *reinterpret_cast<const uint4 *>(a.k_lo + ko); klo[1] = *reinterpret_cast<const uint4 *>(a.k_lo + ko + 32);
-        vh[0] = *reinterpret_cast<const uint4 *>(a.v + vo); vh[1] = *reinterpret_cast<const uint4 *>(a.v + vo + 32);
-        vl[0] = *reinterpret_cast<const uint4 *>(a.v_lo + vo); vl[1] = *reinterpret_cast<const uint4 *>(a.v_lo + vo + 32);
-    }
-    f4 dk[4], dv[4];
+    int kj[NG], kg0[NG], nact = 0;
+    bool kvalid[NG];
+    uint4 kh[NG][2], klo[NG][2], vh[NG][2], vl[NG][2];
+    f4 dk[NG][4], dv[NG][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NG; ++u) {
+        kg0[u] = kt0 + (u * 4 + wid) * 16;
+        kj[u] = kg0[u] + c16;
+        kvalid[u] = kj[u] < kl.Lk;
+        if (kg0[u] < kl.Lk) nact = u + 1;
+        const long long krow = kl.row(kj[u]);
+        const long long ko = krow * a.ldk + h * HD + g * 8, vo = krow * a.ldv + h * HD + g * 8;
+        kh[u][0] = *reinterpret_cast<const uint4 *>(a.k + ko); kh[u][1] = *reinterpret_cast<const uint4 *>(a.k + ko + 32);
+        klo[u][0] = *reinterpret_cast<const uint4 *>(a.k_lo + ko); klo[u][1] = *reinterpret_cast<const uint4 *>(a.k_lo + ko + 32);
+        vh[u][0] = *reinterpret_cast<const uint4 *>(a.v + vo); vh[u][1] = *reinterpret_cast<const uint4 *>(a.v + vo + 32);
+        vl[u][0] = *reinterpret_cast<const uint4 *>(a.v_lo + vo); vl[u][1] = *reinterpret_cast<const uint4 *>(a.v_lo + vo + 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dk[u][i] = dv[u][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     auto issue = [&](int qt, int slot) {
         auto rq = [&](int r) { return b * a.q_batch_rows + min(qt + r, a.Lq - 1); };
@@ -565,60 +681,87 @@ attn_bwd_dkv_split_kernel(const AttnBwdArgs a) {
         const unsigned short *sQh = smem[slot][0], *sQl = smem[slot][1], *sDh = smem[slot][2], *sDl = smem[slot][3];
         const float *sL = sL2[slot], *sD = sD2[slot];
         const int *sLen = sLen2[slot];
-        f4 p[4], ds[4];
+        if (nact > 0) {
+            uint4 pfh[NG][2], pfl[NG][2], dsh[NG][2], dsl[NG][2];
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            f4 s = f4{0.f, 0.f, 0.f, 0.f}, dp = s;
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                f4 p[NG][2], ds[NG][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = sw_off(qb * 16 + c16, ks * 4 + g);
-                const uint4 qah = *reinterpret_cast<const uint4 *>(&sQh[off]), qal = *reinterpret_cast<const uint4 *>(&sQl[off]);
-                const uint4 dah = *reinterpret_cast<const uint4 *>(&sDh[off]), dal = *reinterpret_cast<const uint4 *>(&sDl[off]);
-                s = mma3(qah, qal, kh[ks], klo[ks], s);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
-                dp = mma3(dah, dal, vh[ks], vl[ks], dp);    // dP[query][key]
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const int qb = 2 * ks2 + n2;
+                    f4 s[NG], dp[NG];
+#pragma unroll
+                    for (int u = 0; u < NG; ++u) s[u] = dp[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int off = sw_off(qb * 16 + c16, ks * 4 + g);
+                        const uint4 qah = *reinterpret_cast<const uint4 *>(&sQh[off]), qal = *reinterpret_cast<const uint4 *>(&sQl[off]);
+                        const uint4 dah = *reinterpret_cast<const uint4 *>(&sDh[off]), dal = *reinterpret_cast<const uint4 *>(&sDl[off]);
+#pragma unroll
+                        for (int u = 0; u < NG; ++u)
+                            if (u < nact) {
+                                s[u] = mma3(qah, qal, kh[u][ks], klo[u][ks], s[u]);     // S[query][key]: lane & 15 = key, registers = queries g*4 + r
+                                dp[u] = mma3(dah, dal, vh[u][ks], vl[u][ks], dp[u]);    // dP[query][key]
+                            }
+                    }
+                    const float4 L4 = *reinterpret_cast<const float4 *>(&sL[qb * 16 + g * 4]), D4 = *reinterpret_cast<const float4 *>(&sD[qb * 16 + g * 4]);
+                    const int4 N4 = *reinterpret_cast<const int4 *>(&sLen[qb * 16 + g * 4]);
+                    const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+                    const int Nr[4] = {N4.x, N4.y, N4.z, N4.w};
+#pragma unroll
+                    for (int u = 0; u < NG; ++u) {
+                        if (u >= nact) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = (kvalid[u] && kj[u] < Nr[r]) ? __builtin_amdgcn_exp2f(fmaf(s[u][r], a.scale_log2e, -Lr[r])) : 0.f;
+                            p[u][n2][r] = pv;
+                            ds[u][n2][r] = pv * (dp[u][r] - Dr[r]) * a.scale;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    if (u >= nact) continue;
+                    split_frag(p[u][0], p[u][1], pfh[u][ks2], pfl[u][ks2], 0);
+                    split_frag(ds[u][0], ds[u][1], dsh[u][ks2], dsl[u][ks2], 0);
+                }
             }
-            const float4 L4 = *reinterpret_cast<const float4 *>(&sL[qb * 16 + g * 4]), D4 = *reinterpret_cast<const float4 *>(&sD[qb * 16 + g * 4]);
-            const int4 N4 = *reinterpret_cast<const int4 *>(&sLen[qb * 16 + g * 4]);
-            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
-            const int Nr[4] = {N4.x, N4.y, N4.z, N4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = (kvalid && kj < Nr[r]) ? __builtin_amdgcn_exp2f(fmaf(s[r], a.scale_log2e, -Lr[r])) : 0.f;
-                p[qb][r] = pv;
-                ds[qb][r] = pv * (dp[r] - Dr[r]) * a.scale;
-            }
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int r0 = (2 * ks) * 16 + g * 4, r1 = (2 * ks + 1) * 16 + g * 4;
+                    const uint2 dh0 = tr_rows4_sw(sDh, r0, db * 16, c16), dh1 = tr_rows4_sw(sDh, r1, db * 16, c16);
+                    const uint2 dl0 = tr_rows4_sw(sDl, r0, db * 16, c16), dl1 = tr_rows4_sw(sDl, r1, db * 16, c16);
+                    const uint2 qh0 = tr_rows4_sw(sQh, r0, db * 16, c16), qh1 = tr_rows4_sw(sQh, r1, db * 16, c16);
+                    const uint2 ql0 = tr_rows4_sw(sQl, r0, db * 16, c16), ql1 = tr_rows4_sw(sQl, r1, db * 16, c16);
+                    const uint4 d4h = make_uint4(dh0.x, dh0.y, dh1.x, dh1.y), d4l = make_uint4(dl0.x, dl0.y, dl1.x, dl1.y);
+                    const uint4 q4h = make_uint4(qh0.x, qh0.y, qh1.x, qh1.y), q4l = make_uint4(ql0.x, ql0.y, ql1.x, ql1.y);
+#pragma unroll
+                    for (int u = 0; u < NG; ++u)
+                        if (u < nact) {
+                            dv[u][db] = mma3(pfh[u][ks], pfl[u][ks], d4h, d4l, dv[u][db]);
+                            dk[u][db] = mma3(dsh[u][ks], dsl[u][ks], q4h, q4l, dk[u][db]);
+                        }
+                }
         }
-        uint4 pfh[2], pfl[2], dsh[2], dsl[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            split_frag(p[2 * ks], p[2 * ks + 1], pfh[ks], pfl[ks], 0);
-            split_frag(ds[2 * ks], ds[2 * ks + 1], dsh[ks], dsl[ks], 0);
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int r0 = (2 * ks) * 16 + g * 4, r1 = (2 * ks + 1) * 16 + g * 4;
-                const uint2 dh0 = tr_rows4_sw(sDh, r0, db * 16, c16), dh1 = tr_rows4_sw(sDh, r1, db * 16, c16);
-                const uint2 dl0 = tr_rows4_sw(sDl, r0, db * 16, c16), dl1 = tr_rows4_sw(sDl, r1, db * 16, c16);
-                const uint2 qh0 = tr_rows4_sw(sQh, r0, db * 16, c16), qh1 = tr_rows4_sw(sQh, r1, db * 16, c16);
-                const uint2 ql0 = tr_rows4_sw(sQl, r0, db * 16, c16), ql1 = tr_rows4_sw(sQl, r1, db * 16, c16);
-                dv[db] = mma3(pfh[ks], pfl[ks], make_uint4(dh0.x, dh0.y, dh1.x, dh1.y), make_uint4(dl0.x, dl0.y, dl1.x, dl1.y), dv[db]);
-                dk[db] = mma3(dsh[ks], dsl[ks], make_uint4(qh0.x, qh0.y, qh1.x, qh1.y), make_uint4(ql0.x, ql0.y, ql1.x, ql1.y), dk[db]);
-            }
         if (more && tid < TB) aux_store((it + 1) & 1);
     }
-    // dK / dV rows key = g*4 + r (of this wave's 16), cols d = db*16 + c16
+    // dK / dV rows key = g*4 + r (of the group's 16), cols d = db*16 + c16
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kpos = kt0 + wid * 16 + g * 4 + r;
-        if (kpos >= kl.Lk) continue;
-        const long long row = kl.row(kpos);
-        float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
+    for (int u = 0; u < NG; ++u) {
+        if (u >= nact) continue;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            if (a.kv_direct) { pk[db * 16] = dk[db][r]; pv[db * 16] = dv[db][r]; }
-            else { unsafeAtomicAdd(pk + db * 16, dk[db][r]); unsafeAtomicAdd(pv + db * 16, dv[db][r]); }
+        for (int r = 0; r < 4; ++r) {
+            const int kpos = kg0[u] + g * 4 + r;
+            if (kpos >= kl.Lk) continue;
+            const long long row = kl.row(kpos);
+            float *pk = a.dk + row * a.lddk + h * HD + c16, *pv = a.dv + row * a.lddv + h * HD + c16;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                if (a.kv_direct) { pk[db * 16] = dk[u][db][r]; pv[db * 16] = dv[u][db][r]; }
+                else { unsafeAtomicAdd(pk + db * 16, dk[u][db][r]); unsafeAtomicAdd(pv + db * 16, dv[u][db][r]); }
+            }
         }
     }
 }
@@ -650,14 +793,26 @@ int attention_backward_impl(const void *q, const void *k, const void *v, const v
     const long long rows = (long long)(nbatch - 1) * q_batch_rows + Lq;
     const int keys = kv_seg ? max_keys : Lk;
     dim3 block(256);
+    static const int ng = [] { const char *e = getenv("VS_ATTN_BWD_NG"); return e && atoi(e) == 1 ? 1 : 2; }();   // row groups of 16 per wave
+    const dim3 gq(vs::cdiv(Lq, 64 * ng), H, nbatch), gk(vs::cdiv(keys, 64 * ng), H, nbatch);
     if (dtype == 2) {
         hipLaunchKernelGGL(attn_delta_kernel<true>, dim3((unsigned)vs::cdiv64(rows * H, 32)), block, 0, stream, a, rows);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+        if (ng == 1) {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 1>), gq, block, 0, stream, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 1>), gk, block, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 2>), gq, block, 0, stream, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, block, 0, stream, a);
+        }
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<false>, dim3((unsigned)vs::cdiv64(rows * H, 32)), block, 0, stream, a, rows);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+        if (ng == 1) {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 1>), gq, block, 0, stream, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 1>), gk, block, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 2>), gq, block, 0, stream, a);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 2>), gk, block, 0, stream, a);
+        }
     }
     VS_HIP(hipGetLastError());
     return 0;
@@ -716,8 +871,14 @@ extern "C" int vs_attention_backward_split(const void *q_hi, const void *q_lo, c
     const int keys = kv_seg ? max_keys : Lk;
     dim3 block(256);
     hipLaunchKernelGGL(attn_delta_f32_kernel, dim3((unsigned)vs::cdiv64(rows * H, 32)), block, 0, stream, a, rows);
-    hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+    static const int ngq = [] { const char *e = getenv("VS_ATTN_BWD_NG"); return e && atoi(e) == 1 ? 1 : 2; }();       // row groups of 16 per wave
+    // (dK / dV: two key groups need 64 + 64 + 64 registers for the K | V fragments, the accumulators and the (hi, lo) P | dS fragments alone:
+    // the NG = 2 instantiation spills 102 VGPRs under the 256-register cap -- one group per wave unless VS_ATTN_BWD_NG_KV=2)
+    static const int ngk = [] { const char *e = getenv("VS_ATTN_BWD_NG_KV"); return e && atoi(e) == 2 ? 2 : 1; }();
+    if (ngq == 1) hipLaunchKernelGGL(attn_bwd_dq_split_kernel<1>, dim3(vs::cdiv(Lq, 64), H, nbatch), block, 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_split_kernel<2>, dim3(vs::cdiv(Lq, 128), H, nbatch), block, 0, stream, a);
+    if (ngk == 1) hipLaunchKernelGGL(attn_bwd_dkv_split_kernel<1>, dim3(vs::cdiv(keys, 64), H, nbatch), block, 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_split_kernel<2>, dim3(vs::cdiv(keys, 128), H, nbatch), block, 0, stream, a);
     VS_HIP(hipGetLastError());
     return 0;
 }
