@@ -5,7 +5,9 @@
     (re10k_8view: num_context_views 8, num_target_views 12, config/experiment/re10k_8view.yaml:19-20).
 
 A "step" = one pass of that path over one batch of `--scenes-per-gpu` synthetic scenes already resident in HBM.
-`python bench.py --gpus N --steps K --warmup W`; for N>1 launch with torch.distributed.run (one rank per GPU, RCCL).
+`python bench.py --gpus N --steps K --warmup W`.  N ranks, one per GPU, over RCCL: under a launcher (`torch.distributed.run ... bench.py
+--gpus N`, WORLD_SIZE set) this process IS one of the ranks; started plainly (`python bench.py --gpus N`, no WORLD_SIZE) it launches the N
+ranks itself -- like a plain `python -m src.main` under Lightning (src/main.py:104-116) -- and every rank asserts world size == --gpus.
 Scenes are independent: they are sharded over ranks with NO data-path collective ("scaling": "weak").
 Prints ONE JSON line (rank 0) with `roofline` (dominant hand-written kernel, measured with HIP events on the launch
 stream in an extra instrumented step) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
@@ -176,6 +178,12 @@ def dry_run_dist(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo")
+    nseen = 1
+    if world > 1:
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        nseen = int(ones.item())
+        assert nseen == args.gpus
     B = args.scenes_per_gpu
     g = torch.Generator().manual_seed(rank)
     x = torch.randn(B, 32, 32, generator=g)                         # this rank's scene shard: scenes are sharded, no data-path collective
@@ -225,6 +233,7 @@ def dry_run_dist(args):
         print(json.dumps(dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(world * B * args.steps / max(elapsed, 1e-9), 3), unit="scenes/s",
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                               scaling="weak", vs_baseline=None, dtype="dry run (CPU toy computation)", data="synthetic", dry_run=True,
+                              distributed=dict(backend="gloo" if world > 1 else "none (1 rank)", ranks_seen=nseen),
                               config=dict(workload="control-flow dry run: no kernel of the hot path is executed", scenes_per_gpu=B,
                                           parallelism=f"scene-sharded x{world} (no collective)"),
                               train=dict(gradient_exchange=("none (1 rank)" if world == 1 else f"GradReducer: {ncoll} bucket all-reduces launched during backward, gloo x{world}"),
@@ -233,8 +242,34 @@ def dry_run_dist(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (src/main.py:104-116: Lightning spawns one process per
+    visible GPU from a plain `python -m src.main`).  Re-executes this file under torch.distributed.run on 127.0.0.1 with a free port; the
+    children see WORLD_SIZE and take the rank path of main().  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what this pool's host driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def check_world(args, world):
+    """--gpus is a contract, not a hint: a run whose rank count differs from it would print a line for a different machine."""
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world} or fix the launcher")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    check_world(args, int(os.environ.get("WORLD_SIZE", 1)))
     if args.dry_run_dist:
         return dry_run_dist(args)
     if args.mode == "train":      # only the training leg is of interest: keep the forward part to one untimed-quality pass
@@ -248,6 +283,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    # what the collective library itself saw: one all-reduce of ones over RCCL = the rank count, reported in the line beside n_gpus
+    dist_info = dict(backend="none (1 rank)", ranks_seen=1)
+    if dist is not None:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ver = torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else None
+        dist_info = dict(backend="nccl (RCCL)", rccl_version=".".join(str(v) for v in ver) if ver else None, ranks_seen=int(ones.item()),
+                         launcher=("torch.distributed.run (external)" if os.environ.get("TORCHELASTIC_RUN_ID") else "environment"))
+        assert dist_info["ranks_seen"] == args.gpus, f"RCCL counted {dist_info['ranks_seen']} ranks, --gpus says {args.gpus}"
 
     import json as _json
     from vicasplat_amd import ops, raster, synthetic
@@ -598,7 +642,7 @@ def main():
     def headline(train):
         return dict(metric="scenes/sec (8-view 256x256) encode+rasterize", value=round(value, 3), unit="scenes/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype=DTYPE_NOTE[args.dtype], data="synthetic",
+                    vs_baseline=None, dtype=DTYPE_NOTE[args.dtype], data="synthetic", distributed=dist_info,
                     config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
                                          f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
                                 parallelism=f"scene-sharded x{world} (no collective)"),

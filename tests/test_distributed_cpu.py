@@ -294,6 +294,48 @@ def test_bench_dry_run_dist_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["train"]["gradient_exchange"].startswith("GradReducer") and d["train"]["replicas_identical"] is True
+    assert d["distributed"]["ranks_seen"] == 2
+
+
+def _bench_env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with NO launcher around it starts the two ranks itself (a plain `python -m src.main`
+    does under Lightning, src/main.py:104-116) and the line says n_gpus 2 with the collective library's own rank count beside it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-dist"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=_bench_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["ranks_seen"] == 2 and d["train"]["replicas_identical"] is True
+    # --gpus 1: unchanged, no launcher, one rank
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--dry-run-dist"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=_bench_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["distributed"]["ranks_seen"] == 1
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus is asserted against the launcher's WORLD_SIZE: an 8-rank line can never come out of a 1-rank run (or the reverse)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _bench_env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-dist"], capture_output=True, text=True,
+                       timeout=300, cwd=root, env=env)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 # ---- the Module API's internal gradient scale under torch's DistributedDataParallel (what Lightning wraps the reference's ModelWrapper in,
