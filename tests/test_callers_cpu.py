@@ -377,6 +377,56 @@ def test_boundary_grad_scale_leaves_plain_gradients_and_handles_accumulation():
     assert one.outputs(t)[0] is t
 
 
+def test_boundary_grad_scale_late_unfreeze_input_grads_failed_backward_and_overflow():
+    """ADVICE r4 on autograd.BoundaryGradScale: (1) parameters unfrozen after the scaler was built are unscaled too (the set is re-read at
+    every backward); (2) non-parameter leaves entering through `inputs()` get PLAIN gradients; (3) a backward that raises does not leave
+    the scaler armed; (4) an inf / NaN gradient raises the device-side overflow flag."""
+    from vicasplat_amd import autograd as A
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4))
+    ref.load_state_dict(net.state_dict())
+    net[0].requires_grad_(False)
+    sc = A.BoundaryGradScale(net, 8192.0)
+    x = torch.randn(3, 6)
+    sc.outputs(net(x))[0].square().sum().backward()
+    assert net[0].weight.grad is None and float(sc.last_overflow) == 0.0
+    net[0].requires_grad_(True)                                       # unfrozen AFTER the scaler exists
+    net.zero_grad()
+    xi = x.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    sc.rearm()
+    (xin,) = sc.inputs(xi)
+    sc.outputs(net(xin))[0].square().sum().backward()
+    ref(xr).square().sum().backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(p.grad, q.grad)
+    assert torch.equal(xi.grad, xr.grad)                              # (2)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise ValueError("boom")
+
+    net.zero_grad()
+    with pytest.raises(ValueError):
+        sc.outputs(Boom.apply(net(x)))[0].sum().backward()
+    assert sc._armed                                                   # the failed pass left it armed ...
+    sc.rearm()                                                         # ... the next forward clears that (VicaSplat._forward_autograd)
+    net.zero_grad(); ref.zero_grad()
+    sc.outputs(net(x))[0].square().sum().backward()
+    ref(x).square().sum().backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(p.grad, q.grad)
+    net.zero_grad()
+    (sc.outputs(net(x))[0].sum() * float("inf")).backward()            # (4)
+    assert float(sc.last_overflow) > 0
+
+
 def test_split_weight_exponent_cache_policy():
     """autograd.LinearSplitFn._scale_exp (the cached power-of-two scale of a split-class weight pack): an all-zero weight is
     never cached (the zero-initialised pose head would otherwise be packed unscaled for 64 steps), a stacked temporary takes the smallest

@@ -395,3 +395,96 @@ def test_boundary_grad_scale_under_ddp_matches_the_unscaled_full_batch_gradient(
             g = torch.from_numpy(out[rank][n])
             assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-8), (rank, n, float((g - p.grad).abs().max()))
         assert np.array_equal(out[0][n], out[1][n]), n               # replicas bit-identical
+
+
+# ---- the same internal scale under THIS package's GradReducer: p.grad are views of flat buckets whose all-reduces are in
+# flight when backward ends, so the end-of-backward callback must not touch them; the 1/S is applied by finish() after the wait ----
+def _reducer_scale_worker(rank, world, port, q, comm_bf16):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        m = _ScaledToy()
+        # small buckets: the first ones are launched (and, staged, copied out) long before backward ends -- the case the advisor described
+        red = vd.GradReducer(m.parameters(), bucket_bytes=256, comm_dtype=torch.bfloat16 if comm_bf16 else None)
+        x, y = _toy_batch()
+        r = vd.shard_range(x.shape[0], rank, world)
+        launched_early = 0
+        for step in range(2):
+            red.zero_grad()
+            loss = ((m(x[r.start:r.stop]) - y[r.start:r.stop]) ** 2).mean()
+            loss.backward()
+            launched_early = max(launched_early, len(red._pending))
+            red.finish()
+        ovf = float(red.last_overflow)
+        q.put((rank, dict(grads={n: p.grad.detach().numpy().copy() for n, p in m.named_parameters()}, early=launched_early, ovf=ovf)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_reducer_scale(comm_bf16):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_scale_worker, args=(r, 2, port, q, comm_bf16)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(v, dict) for v in out.values()), out
+    return out
+
+
+def test_boundary_grad_scale_under_the_grad_reducer_f32_wire():
+    out = _run_reducer_scale(False)
+    torch.manual_seed(3)
+    ref = _ScaledToy()
+    x, y = _toy_batch()
+    ((ref.net(x) - y) ** 2).mean().backward()
+    assert out[0]["early"] >= 2 and out[0]["ovf"] == 0.0            # buckets really were in flight when backward ended
+    for n, p in ref.named_parameters():
+        for rank in (0, 1):
+            g = torch.from_numpy(out[rank]["grads"][n])
+            assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-8), (rank, n, float((g - p.grad).abs().max()))
+        assert np.array_equal(out[0]["grads"][n], out[1]["grads"][n]), n
+
+
+def test_boundary_grad_scale_under_the_grad_reducer_bf16_wire():
+    """comm_dtype staging: finish() copies the reduced stage back over the bucket AFTER backward ended -- a bucket unscaled by the callback
+    would come back S times too large (early buckets) next to correct late ones.  Every gradient must be the plain one to bf16 rounding."""
+    out = _run_reducer_scale(True)
+    torch.manual_seed(3)
+    ref = _ScaledToy()
+    x, y = _toy_batch()
+    ((ref.net(x) - y) ** 2).mean().backward()
+    for n, p in ref.named_parameters():
+        g = torch.from_numpy(out[0]["grads"][n])
+        assert float((g - p.grad).abs().max()) <= 2.0 ** -7 * float(p.grad.abs().max()) + 1e-8, (n, float(g.abs().max()), float(p.grad.abs().max()))
+        assert np.array_equal(out[0]["grads"][n], out[1]["grads"][n]), n
+
+
+def test_grad_reducer_unused_set_is_learned_once_and_only_shrinks():
+    """a finish() without a backward (skipped step) or a step with fewer gradients than usual must not grow the learned set
+    of gradient-less parameters -- the next full step would launch buckets before their gradients arrive and raise."""
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)     # c never used
+    red = vd.GradReducer(list(a.parameters()) + list(b.parameters()) + list(c.parameters()), bucket_bytes=64)
+    x = torch.randn(2, 4)
+    red.zero_grad(); red.finish()                                    # a skipped step: nothing learned
+    assert not red._unused_learned and not red._unused_ids
+    red.zero_grad(); b(a(x)).sum().backward(); red.finish()          # first complete step: c's parameters are the static unused set
+    assert red._unused_learned and red._unused_ids == {id(p) for p in c.parameters()}
+    red.zero_grad(); a(x).sum().backward(); red.finish()             # partial step (b unused this time): the set does not grow
+    assert red._unused_ids == {id(p) for p in c.parameters()}
+    red.zero_grad(); red.finish()                                    # another skipped step
+    assert red._unused_ids == {id(p) for p in c.parameters()}
+    red.zero_grad(); b(a(x)).sum().backward(); red.finish()          # the full step again: no "graph is not static" error
+    assert all(p.grad is not None for p in list(a.parameters()) + list(b.parameters())) and all(p.grad is None for p in c.parameters())
+    red.reset_unused()
+    assert not red._unused_ids and not red._unused_learned
+    red.remove()
+    assert not hasattr(next(a.parameters()), "_vs_bucket")

@@ -28,19 +28,41 @@ class BoundaryGradScale:
     gradient is multiplied by 1/S (exact), so the caller observes plain unscaled `.grad`s as from the reference.  Gradients that were
     already in `.grad` before this backward (accumulation over micro-batches) are lifted by S first, so the sum stays consistent.  The
     callback re-queues itself once so that it runs after DDP's own end-of-backward callback (the bucket all-reduce runs on scaled values:
-    exact for a power of two).  S = 1 disables all of it."""
+    exact for a power of two).  S = 1 disables all of it.
+
+    * `inputs(...)`: non-parameter leaves (the image, the intrinsics) enter through the inverse node -- their cotangent leaves the encoder
+      multiplied by 1/S, so d(loss)/d(image) is plain as well.
+    * The set of parameters is re-read from `params` (the module itself, or a fixed list) at the START of every
+      backward pass: parameters unfrozen after the scaler was built are unscaled like the rest.
+    * Under this package's `dist.GradReducer` the `.grad`s are views of flat buckets whose all-reduces are still in flight when the
+      callback runs: the unscale is then handed to the reducer (`defer_unscale`), which applies it in `finish()` after the wait, together
+      with the averaging -- never on a buffer a collective is reading.
+    * Overflow: the unscale pass also checks the gradients for inf / NaN on the device (one fused pass); the flag of the last backward is
+      `last_overflow` (a 0-d device tensor, no host synchronisation here; under a GradReducer: `reducer.last_overflow` after `finish()`).  A cotangent with |dy| * S >= 65520 (e.g. a
+      sum-reduced loss over many pixels) leaves f16's range where the reference's fp32 backward has it; lower `encoder.grad_scale` then.
+    * `torch.autograd.grad(loss, params)` bypasses the end-of-backward callback: it returns gradients in units of S (divide by `scale`)."""
 
     def __init__(self, params, scale: float):
-        self.params, self.scale = [p for p in params if p.requires_grad], float(scale)
+        self._module = params if isinstance(params, torch.nn.Module) else None      # re-read at every backward
+        self._list = None if self._module is not None else list(params)
+        self.scale = float(scale)
         m, e = __import__("math").frexp(self.scale)
         assert self.scale >= 1.0 and m == 0.5, "the boundary gradient scale must be a power of two"
         self._armed = False
+        self._active = []
+        self.last_overflow = None
+
+    @property
+    def params(self):
+        src = self._module.parameters() if self._module is not None else self._list
+        return [p for p in src if p.requires_grad]
 
     def _begin(self):
         if self._armed:
             return
         self._armed = True
-        old = [p.grad for p in self.params if p.grad is not None]
+        self._active = self.params
+        old = [p.grad for p in self._active if p.grad is not None]
         if old:
             torch._foreach_mul_(old, self.scale)
         torch.autograd.Variable._execution_engine.queue_callback(self._requeue)
@@ -50,10 +72,28 @@ class BoundaryGradScale:
 
     def _end(self):
         self._armed = False
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if grads:
+        active, self._active = self._active, []
+        inv = 1.0 / self.scale
+        plain, reducers = [], {}
+        for p in active:
+            if p.grad is None:
+                continue
+            red = getattr(p, "_vs_reducer", None)
+            red = red() if red is not None else None
+            if red is not None and red.owns(p):
+                reducers[id(red)] = red
+            else:
+                plain.append(p.grad)
+        for red in reducers.values():          # gradients living in a GradReducer's buckets: unscaled by finish(), after the collectives
+            red.defer_unscale(inv)
+        if plain:
             with torch.no_grad():
-                torch._foreach_mul_(grads, 1.0 / self.scale)
+                self.last_overflow = unscale_and_check_(plain, inv)
+
+    def rearm(self):
+        """Called at every forward: a backward pass that raised leaves `_armed` set (its callbacks never ran)."""
+        self._armed = False
+        self._active = []
 
     def outputs(self, *tensors):
         """Identity on the values; cotangents x S (None stays None).  One autograd node PER tensor: an output no loss reads (the poses
@@ -61,19 +101,45 @@ class BoundaryGradScale:
         producers materialised zero cotangents, i.e. zero `.grad`s where the reference leaves None."""
         if self.scale == 1.0:
             return tensors
-        return tuple(None if t is None else _BoundaryScaleFn.apply(self, t) for t in tensors)
+        return tuple(None if t is None else _BoundaryScaleFn.apply(self, t, self.scale) for t in tensors)
+
+    def inputs(self, *tensors):
+        """Identity on the values of non-parameter inputs that require grad; their cotangents x 1/S on the way OUT of the encoder."""
+        if self.scale == 1.0:
+            return tensors
+        return tuple(t if (t is None or not t.requires_grad) else _BoundaryScaleFn.apply(None, t, 1.0 / self.scale) for t in tensors)
+
+
+def unscale_and_check_(grads, inv_scale: float) -> torch.Tensor:
+    """grads *= inv_scale in place (exact for a power of two) and a 0-d float flag (> 0: some gradient holds inf / NaN), one fused pass per
+    device / dtype group on the GPU (the AMP foreach primitive), no host synchronisation."""
+    dev = grads[0].device
+    found = torch.zeros((), dtype=torch.float32, device=dev)
+    if dev.type == "cuda" and all(g.device == dev for g in grads):
+        by_dtype = {}
+        for g in grads:
+            by_dtype.setdefault(g.dtype, []).append(g)
+        inv = torch.full((), inv_scale, dtype=torch.float32, device=dev)
+        for gs in by_dtype.values():
+            torch._amp_foreach_non_finite_check_and_unscale_(gs, found, inv)
+        return found
+    torch._foreach_mul_(grads, inv_scale)
+    for g in grads:
+        found = torch.maximum(found, (~torch.isfinite(g)).any().to(device=dev, dtype=torch.float32))
+    return found
 
 
 class _BoundaryScaleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scaler, t):
-        ctx.scaler = scaler
+    def forward(ctx, scaler, t, factor):
+        ctx.scaler, ctx.factor = scaler, factor
         return t.view_as(t)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.scaler._begin()
-        return None, g * ctx.scaler.scale
+        if ctx.scaler is not None:
+            ctx.scaler._begin()
+        return None, g * ctx.factor, None
 
 
 def act_dtype(dt):

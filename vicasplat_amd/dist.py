@@ -9,6 +9,7 @@ heads) are zero-filled so every rank reduces identical buckets witho
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Sequence
 
 import torch
@@ -103,6 +104,11 @@ class GradReducer:
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring collectives are per-link bound, so buckets are large (64 MiB
     default -> ~36 collectives for the 2.31 GB gradient) rather than DDP's 25 MB.  `comm_dtype=torch.bfloat16` halves the bytes
     on the links (1.16 GB): the bucket is cast into a staging buffer, reduced, and cast back.
+
+    The Module API's internal gradient scale (autograd.BoundaryGradScale: cotangents x S through the encoder, gradients / S when backward
+    ends) meets this class through `defer_unscale`: the end-of-backward callback runs while the bucket all-reduces are in flight, so it
+    does not touch the buckets; it hands 1/S over and `finish()` applies it after the wait, fused with the averaging.  The sum of scaled
+    gradients times 1/S is exact for a power of two (barring overflow: `last_overflow`, a 0-d device flag set by `finish()`).
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, average: bool = True, group=None,
@@ -128,7 +134,25 @@ class GradReducer:
             self._close(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._pending: List[tuple] = []
+        self._unused_learned = unused_params is not None     # the static set is learned from the first COMPLETE step only
+        self._unscale = 1.0
+        self.last_overflow = None
         self.zero_grad()
+
+    def owns(self, p) -> bool:
+        """True while `p.grad` is (supposed to be) a view of one of this reducer's buckets, i.e. until remove()."""
+        return bool(self._hooks) and getattr(p, "_vs_bucket", None) is not None
+
+    def defer_unscale(self, inv_scale: float):
+        """Called by autograd.BoundaryGradScale when backward ends: the gradients in the buckets are in units of 1 / inv_scale; finish()
+        multiplies every bucket by it after its collective has completed."""
+        self._unscale = float(inv_scale)
+
+    def reset_unused(self):
+        """Forget the learned set of gradient-less parameters (call when the graph changes on purpose: e.g. the distillation phase, which
+        skips the Gaussian-parameter head, followed by the full objective).  The next complete step learns it again."""
+        self._unused_ids = set()
+        self._unused_learned = False
 
     def _close(self, plist):
         dev = plist[0].device
@@ -142,6 +166,7 @@ class GradReducer:
                                  stage=torch.empty(n, dtype=self.comm_dtype, device=dev) if self.comm_dtype else None))
         for i, p in enumerate(plist):
             p._vs_bucket, p._vs_slot = len(self.buckets) - 1, i
+            p._vs_reducer = weakref.ref(self)
 
     def zero_grad(self):
         """Zero the flat buckets and (re)attach every p.grad as a view of its bucket."""
@@ -152,6 +177,7 @@ class GradReducer:
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
         self._pending = []
+        self._unscale = 1.0
         self._next = 0            # buckets are launched strictly in index order: every rank issues the same collective sequence
 
     def _launch(self, b):
@@ -178,7 +204,7 @@ class GradReducer:
                 b["ready"] += 1
             elif b["launched"]:
                 raise RuntimeError("GradReducer: a parameter recorded as unused (no gradient in the previous step) received a gradient after "
-                                   "its bucket was exchanged -- the graph is not static; rebuild the reducer")
+                                   "its bucket was exchanged -- the graph is not static; call reset_unused() at a phase change (or rebuild the reducer)")
         # launch in INDEX order only (a bucket that completes before an earlier one waits for it): the order in which hooks fire may
         # differ between ranks or steps, the order of the collectives must not
         while self._next < len(self.buckets) and self.buckets[self._next]["ready"] == len(self.buckets[self._next]["params"]):
@@ -191,26 +217,53 @@ class GradReducer:
             self._launch(b)
         self._next = len(self.buckets)
         n = len(self._pending)
+        waited = set()
         for b, work in self._pending:
             work.wait()
             if b["stage"] is not None:
                 b["flat"].copy_(b["stage"])
-            if self.average:
-                b["flat"] /= self.world
+            waited.add(id(b))
+        # averaging and the deferred 1/S of the Module API's internal gradient scale, one pass per bucket, after its collective
+        found = None
+        for b in self.buckets:
+            f = self._unscale / (self.world if (self.average and id(b) in waited) else 1)
+            if self._unscale != 1.0:
+                from .autograd import unscale_and_check_
+                fl = unscale_and_check_([b["flat"]], f)
+                found = fl if found is None else torch.maximum(found, fl)
+            elif f != 1.0:
+                b["flat"] *= f
+        if found is not None:
+            self.last_overflow = found
+        self._unscale = 1.0
         self._pending = []
         # parameters that received no gradient this step keep .grad = None, as under DDP: the optimizer skips them (a zero gradient
         # would still be weight-decayed by AdamW every step).  The model's graph does not depend on the rank or the data, so the set is
         # the same on every rank; the zeros they contributed to the buckets kept the collectives identical.  zero_grad() re-attaches.
-        unused = set()
+        unused, arrivals = set(), 0
         for b in self.buckets:
             for p, got in zip(b["params"], b["got"]):
                 if not got:
                     p.grad = None
                     unused.add(id(p))
-        self._unused_ids = unused        # learned for the next step (a parameter that did get a gradient this time leaves the set)
+                else:
+                    arrivals += 1
+        # The static set is LEARNED from the first step in which a backward pass actually ran, and only shrinks afterwards (a parameter
+        # that does get a gradient leaves it).  A finish() without arrivals (skipped / failed step) teaches nothing, and a step with
+        # FEWER gradients than usual (a partial loss, the distillation phase) does not grow the set: growing it would let the next full
+        # step launch a bucket before one of its gradients has arrived.  `reset_unused()` relearns on purpose.
+        if arrivals:
+            if not self._unused_learned:
+                self._unused_ids, self._unused_learned = unused, True
+            else:
+                self._unused_ids &= unused
         return n
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            for a in ("_vs_bucket", "_vs_slot", "_vs_reducer"):
+                if hasattr(p, a):
+                    delattr(p, a)

@@ -42,6 +42,20 @@ class VicaSplatCfg:
     gs_param_head_type: str = "dpt_gs"
     predict_conf: bool = False
     camera_type: Literal["dq", "qt"] = "dq"
+    # MI355X-side field (not in the reference's schema; a config that omits it gets the default): operand class of the MFMA kernels the
+    # module is built with -- "split" (default: f32 activations, products as three f16 MFMAs on (hi, lo) pairs; meets the 1e-4 dB render
+    # tolerance against an fp32 evaluation of the reference), "f16" / "bf16" (opt-in fast path, TF32-class products), "f32" (exact-f32 MFMA)
+    compute_class: str = "split"
+
+
+_WARNED = set()
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def _clear_split_caches():
@@ -76,12 +90,14 @@ class VicaSplat(Encoder[VicaSplatCfg]):
     patch_size: int = 16
 
     def __init__(self, cfg: VicaSplatCfg, weight_dtype: Optional[torch.dtype] = None, device=None,
-                 compute_dtype: torch.dtype = torch.float16) -> None:
+                 compute_dtype=None) -> None:
         super().__init__(cfg)
+        if compute_dtype is None:       # get_encoder(cfg) / `VicaSplat(cfg)` as src/main.py:128 and demo.py:367 build it: the config decides
+            compute_dtype = getattr(cfg, "compute_class", "split")
         if cfg.camera_type != "dq" or cfg.gs_center_head_type != "dpt" or cfg.gs_param_head_type != "dpt_gs" or cfg.predict_conf:
             raise NotImplementedError("only the released configuration (dq camera, dpt + dpt_gs heads, no confidence) is implemented")
         self.camera_extrinsic_channels = 8
-        self.backbone = VicaNet(**dict(cfg.backbone), compute_dtype=compute_dtype)
+        self.backbone = VicaNet(**dict(cfg.backbone))
         self.gaussian_adapter = MyGaussianAdapter(cfg.gaussian_adapter)
         self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
         self.predict_confidence = False
@@ -127,6 +143,14 @@ class VicaSplat(Encoder[VicaSplatCfg]):
     # unscaled gradients, as from the reference's fp32 training.  `encoder.grad_scale = 1.0` turns it off (e.g. when the caller runs its
     # own loss scaling, as callers.training_step does through forward_train).
     grad_scale: Optional[float] = None
+
+    @property
+    def last_backward_overflow(self):
+        """0-d device flag (> 0: the last Module-API backward left an inf / NaN in some parameter gradient -- a cotangent times the
+        internal scale left f16's range) or None before the first backward.  Reading it with bool() / .item() synchronises.  Under a
+        dist.GradReducer the check happens in its finish(): see `reducer.last_overflow`."""
+        sc = getattr(self, "_boundary_scaler", None)
+        return None if sc is None else sc.last_overflow
     # Debug mode of the split operand class (`encoder.range_guard = True`): the class multiplies UNSCALED f16 (hi, lo) pairs of the f32
     # activations, so an activation with |x| >= 65520 turns into +-inf where the reference's fp32 / TF32 arithmetic has range.  With the
     # guard on, every forward audits its operands on the device (ops.range_guard) and raises ops.SplitRangeError instead of returning
@@ -160,7 +184,16 @@ class VicaSplat(Encoder[VicaSplatCfg]):
     def _dispatch(self, context, global_step, visualization_dump, distill, compute_viewspace_depth) -> dict:
         image = context["image"]
         if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return self._forward_autograd(context, global_step, visualization_dump, distill, compute_viewspace_depth)
+            if self.train_compute_class() == torch.float32:
+                # the exact-f32 MFMA class has no backward kernels: run inference (as eval under no_grad would) and say so, once
+                _warn_once("f32-no-grad", "VicaSplat.forward: the exact-f32 operand class is inference-only; grad mode is on and a parameter "
+                           "requires grad, but this call runs the fused no-grad path (outputs carry no graph).  Train in the \"split\" class.")
+            else:
+                if not self.training:
+                    _warn_once("eval-autograd", "VicaSplat.forward: eval() mode with grad enabled and trainable parameters -> the differentiable "
+                               "(non-fused, slower, memory-hungry) forward runs, as it would for the reference module.  For inference wrap the "
+                               "call in torch.no_grad() or freeze the weights (requires_grad_(False)) to get the fused path.")
+                return self._forward_autograd(context, global_step, visualization_dump, distill, compute_viewspace_depth)
         with torch.no_grad():
             return self._forward_fused(context, global_step, visualization_dump, distill, compute_viewspace_depth)
 
@@ -170,11 +203,15 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         image = context["image"]
         B, T = image.shape[:2]
         cls = self.train_compute_class()
-        o = forward_train(self, image, context.get("intrinsics", None), cls, global_step=global_step, distill=distill)
         S = self.grad_scale if self.grad_scale is not None else self._DEFAULT_GRAD_SCALE[cls]
         sc = getattr(self, "_boundary_scaler", None)
         if sc is None or sc.scale != S:
-            sc = self._boundary_scaler = A.BoundaryGradScale(list(self.parameters()), S)
+            # (the scaler reads self.parameters() anew at every backward: parameters unfrozen later are unscaled like the rest)
+            sc = self._boundary_scaler = A.BoundaryGradScale(self, S)
+        sc.rearm()
+        # non-parameter leaves: their cotangents leave the encoder through the inverse node, so d(loss)/d(image) is plain too
+        image, intr = sc.inputs(image, context.get("intrinsics", None))
+        o = forward_train(self, image, intr, cls, global_step=global_step, distill=distill)
         g = o.get("gaussians")
         names = ("means", "covariances", "harmonics", "opacities", "scales", "rotations")
         outs = sc.outputs(o["pred_extrins"], o["pred_intrins"], o.get("raw_gaussians"), o["gaussian_centers"] if distill else None,
