@@ -105,6 +105,40 @@ class KernelTimer:
         return out
 
 
+def raster_roofline(rs, traffic, design_min, R, gaussians, views, pmc_file):
+    """The rasterizer against the rooflines that bind it.  HBM: `achieved` = the bytes the PMC counters saw per forward
+    (FETCH_SIZE + WRITE_SIZE of its six kernels, committed pass of the same workload) / the live event-timed duration; `frac` = that / 8 TB/s.
+    Without a counter file for this workload: the bytes this DESIGN must move (`design_min_*`: attributes once per scene).  SURVEY 8(d)'s
+    per-view formula (P*280 + R*68 + 1.8 MB per view: counts the P*232 input bytes once per VIEW, 12x per scene -- bytes this design does
+    not move) is kept as a footnote only.  VALU: `preprocess_kernel` and `render_kernel` are issue-bound, not HBM-bound: their executed
+    VALU wave-instructions (SQ_INSTS_VALU, committed PMC pass) x 2 cycles (a wave64 instruction occupies its SIMD-32 for two cycles,
+    MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x the kernel's traced duration)."""
+    sec = rs["ms"] * 1e-3
+    byt = traffic if traffic else design_min
+    d = dict(bound="hbm", achieved=round(byt / sec / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(byt / sec / 1e9 / PEAK_HBM_GBS, 4),
+             traffic=traffic, bytes_basis=("PMC counters (FETCH_SIZE x2 gfx950 correction except the gather kernel, + WRITE_SIZE), per forward"
+                                           if traffic else "design minimum (no counter file for this workload)"),
+             design_min_bytes=int(design_min), design_min_achieved=round(design_min / sec / 1e9, 1),
+             design_min_frac=round(design_min / sec / 1e9 / PEAK_HBM_GBS, 4),
+             traffic_over_design_min=(round(traffic / design_min, 3) if traffic else None),
+             num_rendered=int(R), gaussians=gaussians, views=views, ms=round(rs["ms"], 3),
+             footnote_survey_8d_formula=dict(algorithmic_bytes=int(rs["bytes"]), achieved=round(rs["bytes"] / sec / 1e9, 1),
+                                             frac=round(rs["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4),
+                                             note="P*280 + R*68 + 1.8 MB per rendered VIEW; not the bytes this design moves"))
+    try:
+        pm = json.load(open(pmc_file))
+        valu = {}
+        for k, v in pm.get("raster_valu", {}).items():
+            peak_rate = 1024 * 2.4e9 / 2.0                         # wave-instructions per second, all SIMDs
+            valu[k] = dict(valu_insts_per_launch=int(v["valu_insts_per_launch"]), traced_us=round(v["traced_us"], 1),
+                           frac=round(v["valu_insts_per_launch"] / (v["traced_us"] * 1e-6) / peak_rate, 4),
+                           insts_per_unit=round(v["valu_insts_per_launch"] * 64.0 / v["units_per_launch"], 1), unit=v["unit"])
+        d["valu_issue"] = dict(bound="valu-issue", peak="1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction", kernels=valu) if valu else None
+    except Exception:
+        d["valu_issue"] = None
+    return d
+
+
 def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, steps=None, checkpoint=False):
     """BASELINE configs 4 / 5: the full training step -- encoder + decoder + rasterizer forward, MSE, backward on the HIP kernels,
     gradient exchange (GradReducer: bucketed all-reduce over RCCL overlapped with backward; N > 1 only), clip 0.5, AdamW -- on
@@ -416,11 +450,14 @@ def main():
         gemm_tf = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         # dominant hand-written kernel family of the step: the MFMA GEMM (ViT encoder/decoder linears, 1x1 convolutions)
         traffic = {}
+        pmc_file = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null unless they cover this workload and operand class
-            fn = {"split": "round4_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
-            if fn == "round4_pmc_traffic.json" and not os.path.exists(os.path.join(ROOT, "profiles", fn)):
-                fn = "round3_pmc_traffic.json"
-            pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            fn = {"split": "round5_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
+            for older in ("round4_pmc_traffic.json", "round3_pmc_traffic.json"):
+                if fn and fn.startswith("round") and args.dtype == "split" and not os.path.exists(os.path.join(ROOT, "profiles", fn)):
+                    fn = older
+            pmc_file = os.path.join(ROOT, "profiles", fn)
+            pm = json.load(open(pmc_file))
             if pm.get("workload", {}).get("scenes_per_gpu") == B and V == 8 and Vt == 12 and pm["workload"].get("dtype", "f16") == args.dtype:
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in pm["kernels"].items()}
                 traffic["rasterizer"] = pm["kernels"]["rasterizer"]["hbm_bytes_per_step"]  # one forward = 6 kernels
@@ -463,14 +500,7 @@ def main():
                                unit="TFLOP/s", frac=round(cv["flops"] / (cv["ms"] * 1e-3) / 1e12 * mfma_mult / peak_tf, 4)),
             roofline_attention=dict(bound="mfma", achieved=round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 1), peak=round(peak_tf / mfma_mult, 1), unit="TFLOP/s",
                                     frac=round(at["flops"] / (at["ms"] * 1e-3) / 1e12 * mfma_mult / peak_tf, 4)),
-            roofline_rasterizer=dict(bound="hbm", achieved=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                     frac=round(rs["bytes"] / (rs["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                     traffic=traffic.get("rasterizer"), algorithmic_bytes=int(rs["bytes"]), num_rendered=int(R),
-                                     gaussians=P * B, views=B * Vt,
-                                     design_min_bytes=int(raster_min), design_min_achieved=round(raster_min / (rs["ms"] * 1e-3) / 1e9, 1),
-                                     design_min_frac=round(raster_min / (rs["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                     note="frac uses SURVEY 8(d)'s per-view formula (P*280 + R*68 + 1.8 MB); design_min_* counts the Gaussian "
-                                          "attributes once per scene, which is what this design reads: the honest figure for its kernels"),
+            roofline_rasterizer=raster_roofline(rs, traffic.get("rasterizer"), raster_min, R, P * B, B * Vt, pmc_file),
             mfma_util_step=round(mfma_flops / (mfma_ms * 1e-3) / 1e12 * mfma_mult / peak_tf, 4))
 
     cpu_baseline = None

@@ -273,14 +273,18 @@ def dpt_trunk(W, pre, cfg, inter, gh, gw):
 
 
 def pts3d_head(W, cfg, inter, gh, gw):
-    """downstream_head1: regression head + 'exp' depth mode (heads/postprocess.py:46-56).  -> [BT,H,W,3]."""
+    """downstream_head1: regression head + 'exp' depth mode (heads/postprocess.py:46-56).  -> ([BT,H,W,3], confidence [BT,H,W] | None):
+    a 4-row last convolution is the predict_conf=true layout (vicasplat.py:75), confidence = 1 + exp(x_3)
+    (conf_mode ('exp', 1, inf), postprocess.py:17-18,66-75)."""
     pre = "downstream_head1.dpt"
     x = dpt_trunk(W, pre, cfg, inter, gh, gw)
     x = conv(W, pre + ".head.0", x, padding=1)
     x = conv(W, pre + ".head.2", up2(x), padding=1)
-    x = conv(W, pre + ".head.4", F.relu(x)).permute(0, 2, 3, 1)[..., :3]
+    f = conv(W, pre + ".head.4", F.relu(x)).permute(0, 2, 3, 1)
+    conf = 1.0 + torch.exp(f[..., 3]) if f.shape[-1] == 4 else None
+    x = f[..., :3]
     d = x.norm(dim=-1, keepdim=True)
-    return x / d.clip(min=1e-8) * torch.expm1(d)
+    return x / d.clip(min=1e-8) * torch.expm1(d), conf
 
 
 def gs_head(W, cfg, inter, frames, gh, gw):
@@ -369,11 +373,13 @@ def forward(W: dict, cfg: dict, image: torch.Tensor, intrinsics: torch.Tensor, r
     n_img = N1 - 1 if use_intr else N1
     inter = [t[:, :, :n_img].reshape(B * V, n_img, -1) for t in inter]  # drop the intrinsic token (:570-572)
     dq, c2w = pose_from_camera_tokens(W, cam[:, 1:])
-    centers = pts3d_head(W, cfg, inter, gh, gw).reshape(B, V, H, Wd, 3)
+    centers, conf = pts3d_head(W, cfg, inter, gh, gw)
+    centers = centers.reshape(B, V, H, Wd, 3)
     params = gs_head(W, cfg, inter, frames, gh, gw).reshape(B, V, -1, H, Wd).permute(0, 1, 3, 4, 2)
     raw = torch.cat([centers, params], -1)
     out = dict(pred_extrins=dq, gaussian_camera_extrins=c2w, raw_gaussians=raw, gaussian_centers=centers,
-               gaussians=gaussian_adapter(raw, cfg["sh_degree"]), pred_intrins=None, gaussian_camera_intrins=None)
+               gaussians=gaussian_adapter(raw, cfg["sh_degree"]), pred_intrins=None, gaussian_camera_intrins=None,
+               confidence=None if conf is None else conf.reshape(B, V, H, Wd))
     if not use_intr:   # fov head on camera token 0 (vicasplat.py:129-138,201-205) -> pinhole K (cam_utils.py:220-234)
         fov = lin(W, "camera_intrinsic_head.1", F.relu(cam[:, 0]))
         Kp = torch.eye(3, dtype=fov.dtype).repeat(B, 1, 1)

@@ -59,15 +59,21 @@ def run(model, image, K, dtype):
                raw=lat(out["raw_gaussians"]), means=lat(g.means), covariances=lat(g.covariances), harmonics=lat(g.harmonics),
                opacities=lat(g.opacities), scales=lat(g.scales), rotations=lat(g.rotations),
                blocks=np.stack([sums[k] for k in sorted(sums)]), block_names=np.array(sorted(sums)))
+    if out.get("confidence") is not None:        # predict_conf=true (config/experiment/distill.yaml:24): 1 + exp(4th channel of the pts3d head)
+        res["confidence"] = out["confidence"][:, :, LATTICE, LATTICE].double().numpy()
+        with torch.no_grad():                    # the stage that configuration runs: distill=True returns the centres + confidence only
+            od = model(dict(image=image.to(dtype), intrinsics=K.to(dtype)), compute_viewspace_depth=False, distill=True)
+        res["distill_centers"] = lat(od["gaussian_centers"])
+        res["distill_confidence"] = od["confidence"][:, :, LATTICE, LATTICE].double().numpy()
     if out.get("pred_intrins") is not None:      # use_intrinsic_embedding=false: fov head + pinhole intrinsics
         res["pred_intrins"] = out["pred_intrins"].double().numpy()
         res["intrins_3x3"] = out["gaussian_camera_intrins"].double().numpy()
     return res
 
 
-def make(name, overrides, B, V, seed=0, do_f64=True):
+def make(name, overrides, B, V, seed=0, do_f64=True, predict_conf=False):
     t0 = time.time()
-    model = ref_import.build_reference_encoder(overrides)
+    model = ref_import.build_reference_encoder(overrides, predict_conf=predict_conf)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     if name.startswith("tiny_noint"):
         import json
@@ -146,6 +152,10 @@ if __name__ == "__main__":
         make("tiny_v3", TINY, B=2, V=3)
     if "tiny_v2" in which:
         make("tiny_v2", TINY, B=1, V=2)
+    if "tiny_conf_v3" in which:     # predict_conf=true (distill.yaml:24): 4-channel pts3d head, confidence = 1 + exp(x)
+        make("tiny_conf_v3", TINY, B=2, V=3, predict_conf=True)
+    if "full_conf_v2" in which:
+        make("full_conf_v2", None, B=1, V=2, predict_conf=True)
     if "full_v2" in which:
         make("full_v2", None, B=1, V=2)
     if "full_v8" in which:

@@ -180,7 +180,7 @@ BACKBONE_CFG = dict(img_size=256, patch_size=16, enc_embed_dim=1024, enc_depth=2
                     use_intrinsic_embedding=True)
 
 
-def build_reference_encoder(backbone_overrides: dict | None = None):
+def build_reference_encoder(backbone_overrides: dict | None = None, predict_conf: bool = False):
     """Returns the reference's VicaSplat(nn.Module) built from config/model/encoder/vicasplat.yaml + vica.yaml +
     the experiment overrides (use_intrinsic_embedding=true, temporal_rope_theta)."""
     install()
@@ -191,7 +191,7 @@ def build_reference_encoder(backbone_overrides: dict | None = None):
     bb.update(backbone_overrides or {})
     cfg = VicaSplatCfg(name="vicasplat", backbone=bb, visualizer=None,
                        gaussian_adapter=GaussianAdapterCfg(0.005, 0.04, 4, "softplus"), apply_bounds_shim=True,
-                       opacity_mapping=OpacityMappingCfg(0.0, 0.0, 1), predict_opacity=False)
+                       opacity_mapping=OpacityMappingCfg(0.0, 0.0, 1), predict_opacity=False, predict_conf=predict_conf)
     return VicaSplat(cfg).eval()
 
 

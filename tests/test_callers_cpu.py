@@ -483,3 +483,27 @@ def test_load_images_reproduces_the_reference_preprocessing_of_its_example_frame
         y = callers.load_images([str(tmp_path / (name + ".png"))])
         want = (torch.from_numpy(zl["out_" + name]).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
         assert y.shape == (1, 3, 256, 256) and torch.equal(y[0], want), name
+
+
+def test_state_dict_with_the_confidence_channel_loads_strict_in_both_layouts():
+    """a stage-1 checkpoint (predict_conf=true, distill.yaml:24: `downstream_head1.dpt.head.4` has 4 rows) loads
+    `strict=True` into a predict_conf model as it is, and into a model WITHOUT the confidence channel through the slicing rule the
+    reference applies when it loads such a checkpoint (src/main.py:146-151: rows 0..2 kept)."""
+    import dataclasses
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    tiny = dict(enc_depth=1, dec_depth=10, dec_embed_dim=64, dec_num_heads=1, enc_embed_dim=64, enc_num_heads=1)
+    mc, _ = get_encoder(dataclasses.replace(default_cfg(**tiny), predict_conf=True))
+    assert mc.predict_confidence and mc.downstream_head1.dpt.head[4].out_channels == 4
+    sd4 = {k: v.clone() for k, v in mc.state_dict().items()}
+    torch.manual_seed(0)
+    sd4["downstream_head1.dpt.head.4.weight"] = torch.randn_like(sd4["downstream_head1.dpt.head.4.weight"])
+    sd4["downstream_head1.dpt.head.4.bias"] = torch.randn_like(sd4["downstream_head1.dpt.head.4.bias"])
+    mc.load_state_dict(sd4, strict=True)
+    m3, _ = get_encoder(default_cfg(**tiny))
+    assert not m3.predict_confidence and m3.downstream_head1.dpt.head[4].out_channels == 3
+    m3.load_state_dict(sd4, strict=True)                                         # 4 -> 3 inside load_state_dict
+    assert torch.equal(m3.downstream_head1.dpt.head[4].weight, sd4["downstream_head1.dpt.head.4.weight"][:3])
+    assert torch.equal(m3.downstream_head1.dpt.head[4].bias, sd4["downstream_head1.dpt.head.4.bias"][:3])
+    assert sd4["downstream_head1.dpt.head.4.bias"].shape[0] == 4                 # the caller's dict is not modified
+    with pytest.raises(RuntimeError):                                            # the other direction is a real mismatch
+        mc.load_state_dict(m3.state_dict(), strict=True)

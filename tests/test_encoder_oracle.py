@@ -17,10 +17,20 @@ TINY = dict(enc_depth=2, dec_embed_dim=192, dec_num_heads=3)
 LAT = slice(8, 256, 16)
 
 
+def conf_shapes(shapes):
+    """State-dict shapes of the predict_conf=true layout (distill.yaml:24): the pts3d head's last 1x1 convolution has a fourth row."""
+    s = dict(shapes)
+    s["downstream_head1.dpt.head.4.weight"] = [4] + list(shapes["downstream_head1.dpt.head.4.weight"])[1:]
+    s["downstream_head1.dpt.head.4.bias"] = [4]
+    return s
+
+
 def _load(name):
     z = np.load(os.path.join(G, f"encoder_{name}.npz"))
     kind = "tiny_noint" if name.startswith("tiny_noint") else "tiny" if name.startswith("tiny") else "full"
     shapes = json.load(open(os.path.join(G, f"shapes_{kind}.json")))
+    if "_conf_" in name:
+        shapes = conf_shapes(shapes)
     cfg = er.default_cfg(**(TINY if kind.startswith("tiny") else {}))
     if kind == "tiny_noint":
         cfg["use_intrinsic_embedding"] = False
@@ -67,6 +77,18 @@ def test_oracle_matches_reference_without_intrinsic_embedding():
     assert np.abs(out["gaussian_camera_intrins"].double().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     z, out = _run("tiny_noint_v3", torch.float64)
     _check(z, out, "f64", 1e-6)
+
+
+def test_oracle_matches_reference_with_the_confidence_channel():
+    """predict_conf=true (config/experiment/distill.yaml:24): goldens from the real reference built with that flag -- 4-channel pts3d
+    head, confidence = 1 + exp(x_3) (postprocess.py:66-75), also from the distill=True call that configuration makes."""
+    for dtype, tag, tol in ((torch.float32, "f32", 1e-4), (torch.float64, "f64", 1e-6)):
+        z, out = _run("tiny_conf_v3", dtype)
+        _check(z, out, tag, tol)
+        c = out["confidence"][:, :, LAT, LAT].double().numpy()
+        assert c.min() > 1.0 and np.abs(c - z[f"{tag}_confidence"]).max() <= tol * np.abs(z[f"{tag}_confidence"]).max()
+        assert np.array_equal(z[f"{tag}_confidence"], z[f"{tag}_distill_confidence"])      # the reference's two call modes agree
+        assert np.abs(out["gaussian_centers"][:, :, LAT, LAT].double().numpy() - z[f"{tag}_distill_centers"]).max() <= tol * np.abs(z[f"{tag}_distill_centers"]).max()
 
 
 def test_oracle_matches_reference_f64():

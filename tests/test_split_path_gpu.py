@@ -390,6 +390,79 @@ def test_encoder_split_matches_reference_f64_goldens(name):
     assert max(errs.values()) <= 2e-4, errs
 
 
+def _golden_errs(out, z, conf=False):
+    LAT = slice(8, 256, 16)
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max() / (np.abs(b).max() + 1e-12))
+    cpu = lambda t: t.detach().cpu()
+    errs = dict(pose=rel(cpu(out["pred_extrins"]), z["f64_pred_extrins"]), c2w=rel(cpu(out["gaussian_camera_extrins"]), z["f64_c2w"]))
+    if out.get("raw_gaussians") is not None:
+        raw = cpu(out["raw_gaussians"][:, :, LAT, LAT]).numpy()
+        for nm, sl in (("xyz", slice(0, 3)), ("opacity", slice(3, 4)), ("scale", slice(4, 7)), ("quat", slice(7, 11)), ("sh", slice(11, 86))):
+            errs[nm] = rel(raw[..., sl], z["f64_raw"][..., sl])
+        g = out["gaussians"]
+        for k in ("means", "covariances", "harmonics", "opacities"):
+            errs["g_" + k] = rel(cpu(getattr(g, k)[:, :, LAT, LAT]).numpy().reshape(z[f"f64_{k}"].shape), z[f"f64_{k}"])
+    else:
+        errs["centers"] = rel(cpu(out["gaussian_centers"][:, :, LAT, LAT]).numpy(), z["f64_distill_centers"])
+    if conf:
+        errs["confidence"] = rel(cpu(out["confidence"][:, :, LAT, LAT]).numpy(), z["f64_confidence"])
+    return errs
+
+
+def test_default_encoder_is_the_reference_precision_class():
+    """`get_encoder(default_cfg())` with NO set_compute_dtype call -- what src/main.py:128 / demo.py:367 get with only the
+    import line changed -- runs the split class and meets the reference-precision bound (<= 2e-4 of the real reference's f64 outputs); f16
+    stays the opt-in fast path (`cfg.compute_class = "f16"` or set_compute_dtype)."""
+    import dataclasses
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    shapes = json.load(open(os.path.join(G, "shapes_full.json")))
+    m, _ = get_encoder(default_cfg())
+    m.load_state_dict(er.golden_weights(shapes, seed=0), strict=True)
+    m = m.cuda().eval().requires_grad_(False)
+    assert m.train_compute_class() == "split"
+    z = np.load(os.path.join(G, "encoder_full_v2.npz"))
+    img, K = er.synthetic_input(int(z["cfg_B"]), int(z["cfg_V"]), 256, int(z["cfg_seed"]))
+    errs = _golden_errs(m(dict(image=img.cuda(), intrinsics=K.cuda()), compute_viewspace_depth=False), z)
+    print("default class vs reference f64:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) <= 2e-4, errs
+    mf, _ = get_encoder(dataclasses.replace(default_cfg(), compute_class="f16"))
+    assert mf.train_compute_class() == torch.float16
+
+
+@pytest.mark.parametrize("name", ["tiny_conf_v3", "full_conf_v2"])
+def test_encoder_with_the_confidence_channel_matches_reference_goldens(name):
+    """predict_conf=true (config/experiment/distill.yaml:24; vicasplat.py:75,87-91,216-217; postprocess.py:17-18,66-75):
+    fourth channel on the pts3d head's last 1x1 convolution, confidence = 1 + exp(x).  Goldens from the real reference built with the flag;
+    fused inference forward, its distill=True form, and the differentiable forward, all <= 2e-4 of the reference's f64 outputs."""
+    import dataclasses
+    from test_encoder_oracle import conf_shapes
+    from vicasplat_amd.model.encoder import default_cfg, get_encoder
+    kind = "tiny" if name.startswith("tiny") else "full"
+    shapes = conf_shapes(json.load(open(os.path.join(G, f"shapes_{kind}.json"))))
+    m, _ = get_encoder(dataclasses.replace(default_cfg(**(TINY if kind == "tiny" else {})), predict_conf=True))
+    m.load_state_dict(er.golden_weights(shapes, seed=0), strict=True)
+    m = m.cuda().eval().requires_grad_(False)
+    z = np.load(os.path.join(G, f"encoder_{name}.npz"))
+    B, V = int(z["cfg_B"]), int(z["cfg_V"])
+    img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    ctx = dict(image=img.cuda(), intrinsics=K.cuda())
+    out = m(ctx, compute_viewspace_depth=False)
+    assert out["confidence"].shape == (B, V, 256, 256) and float(out["confidence"].min()) > 1.0
+    e = _golden_errs(out, z, conf=True)
+    ed = _golden_errs(m(ctx, compute_viewspace_depth=False, distill=True), z, conf=True)
+    print(name, "fused:", {k: f"{v:.1e}" for k, v in e.items()}, "distill:", {k: f"{v:.1e}" for k, v in ed.items()})
+    assert max(e.values()) <= 2e-4 and max(ed.values()) <= 2e-4, (e, ed)
+    if kind == "tiny":       # the differentiable forward (ModelWrapper.training_step's call) + a gradient through the confidence
+        m.train().requires_grad_(True)
+        ot = m(ctx, compute_viewspace_depth=False)
+        et = _golden_errs(ot, z, conf=True)
+        print(name, "autograd:", {k: f"{v:.1e}" for k, v in et.items()})
+        assert max(et.values()) <= 2e-4, et
+        torch.log(ot["confidence"]).mean().backward()
+        gw = m.downstream_head1.dpt.head[4].weight.grad
+        assert gw is not None and float(gw[3].abs().max()) > 0 and float(gw[:3].abs().max()) == 0.0 and torch.isfinite(gw).all()
+
+
 @pytest.mark.parametrize("V,Vt", [(2, 4), (8, 12)])
 def test_end_to_end_split_render_matches_the_oracle_chain(V, Vt):
     from vicasplat_amd.model.decoder.cuda_splatting import camera_matrices

@@ -244,7 +244,9 @@ class PixelwiseTaskWithDPT(nn.Module):
         return self._fusion(P, 1, p2, l0, packed_out=packed_out), P
 
     def forward_pts3d_raw(self, tokens, gh: int, gw: int) -> torch.Tensor:
-        """-> [BT,3,H,W] view (channels-last memory) of the head output in the compute dtype, BEFORE the 'exp' post-process."""
+        """-> [BT,C,H,W] view (channels-last memory, pixel stride 4) of the head output in the compute dtype, BEFORE the 'exp' post-process;
+        C = 3 (xyz), or 4 with the confidence channel (predict_conf: the same fused kernels, whose fourth output column was zero padding)."""
+        nc = self.num_channels
         pk = _PTS_UP_PACKED and self.split and self.dpt.head[0].out_channels == 128 and self.dpt.head[0].in_channels in (64, 128, 256)
         x, P = self._trunk(tokens, gh, gw, packed_out=pk and (tokens[self.dpt.hooks[0]].shape[0] * 64 * gh * gw) >= 224 * 256)
         x = ops.conv3x3_nhwc(x, P["h0.w"], P["h0.b"])
@@ -257,8 +259,8 @@ class PixelwiseTaskWithDPT(nn.Module):
                 P["h4f32.w"] = torch.nn.functional.pad(c4.weight.detach().float().flatten(1), (0, 0, 0, 4 - c4.out_channels)).contiguous()
                 P["h4f32.b"] = torch.nn.functional.pad(c4.bias.detach().float(), (0, 4 - c4.out_channels)).contiguous()
             xp = ops.upsample2x_nhwc(x, packed=True)
-            y = ops.conv3x3_head1x1_nhwc(xp, P["h2.w"], P["h2.b"], P["h4f32.w"], P["h4f32.b"], 3)          # [BT,H,W,4] f32
-            return y[..., :3].permute(0, 3, 1, 2)
+            y = ops.conv3x3_head1x1_nhwc(xp, P["h2.w"], P["h2.b"], P["h4f32.w"], P["h4f32.b"], nc)          # [BT,H,W,4] f32
+            return y[..., :nc].permute(0, 3, 1, 2)
         x = ops.upsample2x_nhwc(x)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
         if self.split and npix % 256 == 0 and x.shape[-1] == 128 and self.dpt.head[2].out_channels == 128:
@@ -267,20 +269,25 @@ class PixelwiseTaskWithDPT(nn.Module):
                 c4 = self.dpt.head[4]
                 P["h4f32.w"] = torch.nn.functional.pad(c4.weight.detach().float().flatten(1), (0, 0, 0, 4 - c4.out_channels)).contiguous()
                 P["h4f32.b"] = torch.nn.functional.pad(c4.bias.detach().float(), (0, 4 - c4.out_channels)).contiguous()
-            y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f32.w"], P["h4f32.b"], 3)          # [BT,H,W,4] f32
-            return y[..., :3].permute(0, 3, 1, 2)
+            y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f32.w"], P["h4f32.b"], nc)          # [BT,H,W,4] f32
+            return y[..., :nc].permute(0, 3, 1, 2)
         if self.compute_dtype != torch.float32 and npix % 256 == 0 and x.shape[-1] == 128:
             # conv3(128->128) -> ReLU -> conv1(128->3) in one kernel: the 128-channel activation at full resolution never reaches HBM
-            y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f.w"], P["h4f.b"], 3)          # [BT,H,W,4]
-            return y[..., :3].permute(0, 3, 1, 2)
+            y = ops.conv3x3_head1x1_nhwc(x, P["h2.w"], P["h2.b"], P["h4f.w"], P["h4f.b"], nc)          # [BT,H,W,4]
+            return y[..., :nc].permute(0, 3, 1, 2)
         x = ops.conv3x3_nhwc(x, P["h2.w"], P["h2.b"], relu_out=True)
-        y = self._gemm1x1(x, P, "h4")[..., :3]
-        return y.contiguous().permute(0, 3, 1, 2)
+        y = self._gemm1x1(x, P, "h4f")                                                               # [BT,H,W,4]: rows >= nc are zero padding
+        return y[..., :nc].permute(0, 3, 1, 2)
 
     def forward_pts3d(self, tokens, gh: int, gw: int) -> torch.Tensor:
         """-> [BT,H,W,3] f32 points; 'exp' depth mode (postprocess.py:46-56).  (distillation path only; the main
         path fuses this into the adapter kernel.)"""
-        xyz = self.forward_pts3d_raw(tokens, gh, gw).float().permute(0, 2, 3, 1)
+        return self.postprocess_pts3d(self.forward_pts3d_raw(tokens, gh, gw))
+
+    @staticmethod
+    def postprocess_pts3d(raw: torch.Tensor) -> torch.Tensor:
+        """[BT,>=3,H,W] raw head output -> [BT,H,W,3] f32 points, 'exp' depth mode: xyz / |xyz| * expm1(|xyz|) (postprocess.py:46-56)."""
+        xyz = raw[:, :3].float().permute(0, 2, 3, 1)
         dist = xyz.norm(dim=-1, keepdim=True)
         return xyz / dist.clip(min=1e-8) * torch.expm1(dist)
 

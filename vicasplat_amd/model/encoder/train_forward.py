@@ -202,7 +202,9 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     t = trunk(pre)
     t = A.conv3x3(t, P[pre + ".head.0.weight"], P[pre + ".head.0.bias"])
     t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"], relu_out=True)
-    pts16 = conv1x1(pre + ".head.4", t)                                                              # [BT,H,W,4] 16-bit: xyz | confidence
+    pts16 = conv1x1(pre + ".head.4", t)                                                              # [BT,H,W,3 | 4]: xyz (| confidence logit)
+    # predict_conf (distill.yaml:24): confidence = 1 + exp(x) on the fourth channel (postprocess.py:17-18,66-75); element-wise glue in torch
+    conf = (1.0 + torch.exp(pts16[..., 3].float())).unflatten(0, (B, V)) if pts16.shape[-1] == 4 else None
 
     pred_intrins = None
     if not use_intr:
@@ -211,7 +213,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         xyz = pts16[..., :3].float()
         nrm = xyz.norm(dim=-1, keepdim=True)
         centers = (xyz / nrm.clamp(min=1e-8) * torch.expm1(nrm)).unflatten(0, (B, V))
-        return dict(pred_extrins=d, gaussian_centers=centers, camera_tokens=cam, pred_intrins=pred_intrins)
+        return dict(pred_extrins=d, gaussian_centers=centers, camera_tokens=cam, pred_intrins=pred_intrins, confidence=conf)
 
     pre = "gaussian_param_head.dpt"
     t = A.upsample2x_add_relu(trunk(pre), stem7x7(pre + ".input_merger.0", frames))             # up2(trunk) + relu(stem), one launch
@@ -229,4 +231,4 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     raw = un(raw)
     gaussians = dict(means=un(means), covariances=un(cov), harmonics=un(sh), opacities=un(op), scales=un(scales), rotations=un(rot))
     return dict(raw_gaussians=raw, pred_extrins=d, gaussians=gaussians, gaussian_centers=gaussians["means"], camera_tokens=cam,
-                pred_intrins=pred_intrins)
+                pred_intrins=pred_intrins, confidence=conf)

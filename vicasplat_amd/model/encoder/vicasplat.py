@@ -94,14 +94,16 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         super().__init__(cfg)
         if compute_dtype is None:       # get_encoder(cfg) / `VicaSplat(cfg)` as src/main.py:128 and demo.py:367 build it: the config decides
             compute_dtype = getattr(cfg, "compute_class", "split")
-        if cfg.camera_type != "dq" or cfg.gs_center_head_type != "dpt" or cfg.gs_param_head_type != "dpt_gs" or cfg.predict_conf:
-            raise NotImplementedError("only the released configuration (dq camera, dpt + dpt_gs heads, no confidence) is implemented")
+        if cfg.camera_type != "dq" or cfg.gs_center_head_type != "dpt" or cfg.gs_param_head_type != "dpt_gs":
+            raise NotImplementedError("only the released configurations (dq camera, dpt + dpt_gs heads) are implemented")
         self.camera_extrinsic_channels = 8
         self.backbone = VicaNet(**dict(cfg.backbone))
         self.gaussian_adapter = MyGaussianAdapter(cfg.gaussian_adapter)
         self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
-        self.predict_confidence = False
-        self.downstream_head1 = PixelwiseTaskWithDPT(self.backbone, 3, "regression")
+        # predict_conf (config/experiment/distill.yaml:24, vicasplat.py:75,87-91): a fourth channel on the pts3d head's last 1x1
+        # convolution, confidence = 1 + exp(x) (conf_mode ('exp', 1, inf), heads/postprocess.py:17-18,66-75)
+        self.predict_confidence = bool(cfg.predict_conf)
+        self.downstream_head1 = PixelwiseTaskWithDPT(self.backbone, 3 + int(self.predict_confidence), "regression")
         self.gaussian_param_head = PixelwiseTaskWithDPT(self.backbone, self.raw_gs_dim, "gs_params")
         self.camera_extrinsic_head = nn.Sequential(nn.ReLU(), nn.Linear(self.backbone.config.dec_embed_dim, 8))
         nn.init.zeros_(self.camera_extrinsic_head[1].weight)  # predicts the identity pose at init (vicasplat.py:126-127)
@@ -115,8 +117,17 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         self.set_compute_dtype(compute_dtype)
         # new VALUES under the same storage: the cached split-class weight exponents of the training Functions are stale
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: _clear_split_caches())
+        self._register_load_state_dict_pre_hook(self._slice_confidence_channel, with_module=False)
         if device is not None or weight_dtype is not None:
             self.to(device=device, dtype=weight_dtype)
+
+    def _slice_confidence_channel(self, state_dict, prefix, *unused):
+        """A stage-1 (predict_conf=true) checkpoint loaded into a model without the confidence channel: the 4-row last convolution of
+        the pts3d head is cut to its xyz rows -- the rule the reference applies when it loads such a checkpoint (src/main.py:146-151),
+        here inside load_state_dict so that `strict=True` works for both layouts."""
+        kb, kw = prefix + "downstream_head1.dpt.head.4.bias", prefix + "downstream_head1.dpt.head.4.weight"
+        if not self.predict_confidence and kb in state_dict and kw in state_dict and state_dict[kb].shape[0] == 4:
+            state_dict[kw], state_dict[kb] = state_dict[kw][0:3], state_dict[kb][0:3]
 
     def set_compute_dtype(self, dt):
         """Operand dtype of the MFMA kernels: torch.float16 (default; 10-bit mantissa = the TF32 products the reference runs at,
@@ -215,8 +226,8 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         g = o.get("gaussians")
         names = ("means", "covariances", "harmonics", "opacities", "scales", "rotations")
         outs = sc.outputs(o["pred_extrins"], o["pred_intrins"], o.get("raw_gaussians"), o["gaussian_centers"] if distill else None,
-                          *([g[k] for k in names] if g is not None else []))
-        pred_extrins, pred_intrins, raw_gaussians, centers = outs[:4]
+                          o.get("confidence"), *([g[k] for k in names] if g is not None else []))
+        pred_extrins, pred_intrins, raw_gaussians, centers, conf = outs[:5]
         dev = image.device
         eye = torch.eye(4, device=dev, dtype=pred_extrins.dtype).expand(B, 1, 4, 4)
         pred_extrinsics_4x4 = torch.cat([eye, camera_matrix_from_dq_array(pred_extrins)], dim=1)
@@ -227,16 +238,16 @@ class VicaSplat(Encoder[VicaSplatCfg]):
             pred_K = torch.stack([fx, zero, half, zero, fy, half, zero, zero, one], -1).view(B, 1, 3, 3).repeat(1, T, 1, 1)
         if distill:
             return dict(pred_extrins=pred_extrins, pred_intrins=pred_intrins, gaussian_camera_extrins=pred_extrinsics_4x4,
-                        gaussian_camera_intrins=pred_K, gaussian_centers=centers, confidence=None,
+                        gaussian_camera_intrins=pred_K, gaussian_centers=centers, confidence=conf,
                         context_view_depths=self._viewspace_depth(context, centers) if compute_viewspace_depth else None)
-        gv = dict(zip(names, outs[4:]))
+        gv = dict(zip(names, outs[5:]))
         gaussians = Gaussians(means=gv["means"], covariances=gv["covariances"], harmonics=gv["harmonics"],
                               opacities=gv["opacities"].unsqueeze(-1), scales=gv["scales"], rotations=gv["rotations"])
         if visualization_dump is not None:
             visualization_dump["depth"] = gaussians.means[..., -1:]
         return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=pred_intrins, raw_gaussians=raw_gaussians,
                     gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=pred_K, gaussian_centers=gaussians.means,
-                    confidence=None,
+                    confidence=conf,
                     context_view_depths=self._viewspace_depth(context, gaussians.means) if compute_viewspace_depth else None)
 
     def _forward_fused(self, context: dict, global_step: int = 0, visualization_dump: Optional[dict] = None, distill: bool = False,
@@ -263,13 +274,17 @@ class VicaSplat(Encoder[VicaSplatCfg]):
             pred_K = pred_K[:, None].repeat(1, T, 1, 1)
 
         tokens = [None if t is None else t.flatten(0, 1) for t in interms]
+        conf_of = lambda raw: (1.0 + torch.exp(raw[:, 3].float())).unflatten(0, (B, T)) if self.predict_confidence else None
         if distill:
-            gs_centers = self.downstream_head1.forward_pts3d(tokens, gh, gw).unflatten(0, (B, T))
+            pts_raw = self.downstream_head1.forward_pts3d_raw(tokens, gh, gw)
+            gs_centers = self.downstream_head1.postprocess_pts3d(pts_raw).unflatten(0, (B, T))
             return dict(pred_extrins=pred_extrins, pred_intrins=pred_intrins, gaussian_camera_extrins=pred_extrinsics_4x4,
-                        gaussian_camera_intrins=pred_K, gaussian_centers=gs_centers, confidence=None,
+                        gaussian_camera_intrins=pred_K, gaussian_centers=gs_centers, confidence=conf_of(pts_raw),
                         context_view_depths=self._viewspace_depth(context, gs_centers) if compute_viewspace_depth else None)
         # heads -> ONE fused kernel: 'exp' depth post-process + raw_gaussians concat + Gaussian adapter
         pts_raw = self.downstream_head1.forward_pts3d_raw(tokens, gh, gw)
+        conf = conf_of(pts_raw)
+        pts_raw = pts_raw[:, :3]
         gs_raw = self.gaussian_param_head.forward_gs(tokens, image.flatten(0, 1), gh, gw)
         if pts_raw.dtype != gs_raw.dtype:
             pts_raw = pts_raw.to(gs_raw.dtype)
@@ -288,7 +303,7 @@ class VicaSplat(Encoder[VicaSplatCfg]):
             visualization_dump["depth"] = gaussians.means[..., -1:]
         return dict(gaussians=gaussians, pred_extrins=pred_extrins, pred_intrins=pred_intrins, raw_gaussians=raw_gaussians,
                     gaussian_camera_extrins=pred_extrinsics_4x4, gaussian_camera_intrins=pred_K, gaussian_centers=gs_centers,
-                    confidence=None, context_view_depths=viewspace_depth)
+                    confidence=conf, context_view_depths=viewspace_depth)
 
     @staticmethod
     def _viewspace_depth(context: dict, gs_centers: torch.Tensor) -> torch.Tensor:
