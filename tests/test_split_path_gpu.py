@@ -62,7 +62,10 @@ def test_split_pack_weight_roundtrip():
 
 
 @pytest.mark.parametrize("M,N,K", [(2056, 3072, 1024), (257, 1024, 4096), (100, 768, 768), (16, 2304, 768), (1, 128, 64), (300, 144, 160),
-                                   (513, 83, 256), (4112, 1024, 96), (49344, 768, 1024)])
+                                   (513, 83, 256), (4112, 1024, 96), (49344, 768, 1024),
+                                   # round 5, the skinny kernel (65 .. 256 rows; K quarters per wave, K split over workgroups for the residual
+                                   # epilogue): the bench step's tail / camera-token shapes, ragged row counts, and a 16-row-tile GEMM + 192-row tail
+                                   (192, 4096, 1024), (192, 1024, 4096), (200, 768, 3072), (65, 2304, 768), (256, 768, 768), (4288, 4096, 1024)])
 def test_gemm_split_epilogues(M, N, K):
     from vicasplat_amd import ops
     d = _dev()
@@ -158,6 +161,10 @@ def test_gemm_qkv_rope_split():
     out = torch.empty(rows, 3 * C, device=d)
     ops.gemm_qkv_rope(a, ops.split_pack_weight(w), bias, out, C, pos, kind, 100.0, 30.0)
     assert float((out.reshape(rows, 3, H, 64) - exp).abs().max()) <= 2e-5 * float(exp.abs().max())
+    for m in (192, 130):        # <= 256 rows: the skinny kernel's RoPE epilogue (round 5), all three row kinds inside
+        o2 = torch.empty(m, 3 * C, device=d)
+        ops.gemm_qkv_rope(a[:m].contiguous(), ops.split_pack_weight(w), bias, o2, C, pos[:m].contiguous(), kind[:m].contiguous(), 100.0, 30.0)
+        assert float((o2.reshape(m, 3, H, 64) - exp[:m]).abs().max()) <= 2e-5 * float(exp.abs().max()), m
 
 
 def _attn_ref(q, k, v, lens=None):
@@ -492,7 +499,8 @@ def test_end_to_end_split_render_matches_the_oracle_chain(V, Vt):
         assert pose <= 2e-5
 
 
-@pytest.mark.parametrize("M,C,N", [(2056, 1024, 3072), (49344 // 8 + 192, 1024, 1024), (516, 768, 2304), (300, 192, 576), (70, 256, 256)])
+@pytest.mark.parametrize("M,C,N", [(2056, 1024, 3072), (49344 // 8 + 192, 1024, 1024), (516, 768, 2304), (300, 192, 576), (70, 256, 256),
+                                   (192, 1024, 4096), (4288, 1024, 4096)])
 def test_packed_activation_producers_are_bit_identical(M, C, N):
     """Round 3: activations that only feed a GEMM are written by their producer in the packed (hi, lo) form (ops.split_act): LayerNorm
     (plain, AdaLN-modulated, with the decoder's interleaving row map) and the GEMM store / GELU epilogues; the consuming GEMM
@@ -524,7 +532,10 @@ def test_packed_activation_producers_are_bit_identical(M, C, N):
     r1, r2 = x.clone(), x.clone()
     ops.gemm(hid32, w2, None, r1, ops.EPI_RESID32)
     ops.gemm(hidp, w2, None, r2, ops.EPI_RESID32)
-    assert torch.equal(r1, r2)
+    if M <= 256 and N >= 2048:      # skinny kernel, long reduction: K is split over workgroups whose partial sums meet through f32 atomics
+        assert _rel(r1, r2) <= 1e-6     # (the order of the additions varies from launch to launch)
+    else:
+        assert torch.equal(r1, r2)
     # AdaLN modulation + the decoder's interleaved rows (one extra row in front of every `grp` rows), read back through the input row map
     grp = M // 2 if M % 2 == 0 else M
     G = M // grp
@@ -719,6 +730,12 @@ def test_gemm_qkv_rope_split_packed_output():
     op = ops.split_act(M, 3 * C, d)
     ops.gemm_qkv_rope(a, w, b, op, C, pos, None, 100.0, 1.0)
     assert torch.equal(op.data, ops.split_pack_weight(o32, 0).data)
+    m = 192                     # the skinny kernel (<= 256 rows): packed A in, packed RoPE'd q | k | v out, bit-identical to the f32 route
+    ap = ops.split_pack_weight(a[:m].contiguous(), 0)
+    o32s, ops_ = torch.empty(m, 3 * C, device=d), ops.split_act(m, 3 * C, d)
+    ops.gemm_qkv_rope(a[:m].contiguous(), w, b, o32s, C, pos[:m].contiguous(), None, 100.0, 1.0)
+    ops.gemm_qkv_rope(ap, w, b, ops_, C, pos[:m].contiguous(), None, 100.0, 1.0)
+    assert torch.equal(o32s, o32[:m]) and torch.equal(ops_.data, ops.split_pack_weight(o32s, 0).data)
 
 
 @pytest.mark.parametrize("N,Hs,Ws", [(2, 32, 32), (1, 128, 128)])

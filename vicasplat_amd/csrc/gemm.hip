@@ -321,6 +321,121 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
     }
 }
 
+// ---- skinny path, split class (round 5): M - m_lo <= 256 rows -- the 192-row tails of the big ViT GEMMs (M = frames x 257 never fills the
+// last 256-row tile) and the decoder's camera-token GEMMs (M = frames).  Those launches were LATENCY bound, not bandwidth or MFMA bound:
+// a handful of 128 x 128 tiles each walking all of K one 32-wide stage per barrier (32-90 us for 5-15 us of work; 11 ms of the 257 ms
+// step), or -- on the weight-streaming kernel above -- 16 output columns per workgroup, i.e. A re-read N / 16 times through L2.
+// Here a workgroup owns a 64 x 64 output tile; its four waves split K into contiguous quarters and each keeps the WHOLE tile in
+// registers (16 accumulator fragments), reading its operand fragments straight from global memory (packed rows are fragment-ready:
+// 16 B hi + 16 B lo per lane and 32-k block), two 32-k blocks = 32 x 16-byte loads in flight per lane, no LDS staging and no barrier in
+// the K loop.  The partial tiles meet once in LDS; wave w then runs the shared epilogue on row fragment w, so every fused epilogue (GELU,
+// RoPE, packed output, gated f32 residual) is the tile kernels' code.  Epilogue 2 may also split K over blockIdx.z (atomics, as the tile
+// kernels' tails do) when N is too narrow to give the chip enough workgroups.
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_skinny_split_kernel(const GemmArgs g_in) {
+    __shared__ __attribute__((aligned(16))) float red[4][4][16][64];   // [wave][row fragment][j * 4 + r][lane]: 64 KiB
+    __shared__ __attribute__((aligned(16))) float2 rope_tab[64 * 16];  // gemm_epilogue<., 4>'s (sin, cos) table
+    GemmArgs g = g_in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 64, m0 = g.m_lo + (int)blockIdx.y * 64;
+    const int ksp = (int)blockIdx.z, nks = (int)gridDim.z;
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned short *A = reinterpret_cast<const unsigned short *>(g.A);
+    const unsigned short *W = reinterpret_cast<const unsigned short *>(g.W);
+    const unsigned short *pa[4], *pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra_ = min(m0 + i * 16 + frow, g.M - 1);           // rows past M: clamped duplicates, dropped by the epilogue
+        const size_t arow = (size_t)(ra_ / g.a_grp_in) * g.a_grp_out + g.a_grp_off + (ra_ % g.a_grp_in);
+        pa[i] = A + arow * g.lda + fg * 8;
+        pw[i] = W + (size_t)min(n0 + i * 16 + frow, g.N - 1) * g.ldw + fg * 8;
+    }
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    // 32-k blocks (128 bytes of a packed or f32 row) of this workgroup's K slice, cut into four contiguous wave ranges
+    const int kb_all = g.K / 64, kb_per_wg = (kb_all + nks - 1) / nks;
+    const int kb_lo = ksp * kb_per_wg, kb_hi = min(kb_all, kb_lo + kb_per_wg);
+    const int per = (kb_hi - kb_lo + 3) / 4;
+    const int kb0 = kb_lo + wid * per, kb1 = min(kb_hi, kb0 + per);
+    const bool apk = g.a_packed != 0;
+    int kb = kb0;
+    for (; kb + 2 <= kb1; kb += 2) {
+        uint4 fa[2][4][2], fb[2][4][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fb[u][i][0] = *reinterpret_cast<const uint4 *>(pw[i] + (kb + u) * 64);
+                fb[u][i][1] = *reinterpret_cast<const uint4 *>(pw[i] + (kb + u) * 64 + 32);
+                fa[u][i][0] = *reinterpret_cast<const uint4 *>(pa[i] + (kb + u) * 64);
+                fa[u][i][1] = *reinterpret_cast<const uint4 *>(pa[i] + (kb + u) * 64 + 32);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!apk) split8(fa[u][i][0], fa[u][i][1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma2<kDtSplit>(fb[u][j][0], fb[u][j][1], fa[u][i][0], fa[u][i][1], acc[i][j]);
+            }
+    }
+    for (; kb < kb1; ++kb) {
+        uint4 fa[4][2], fb[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fb[i][0] = *reinterpret_cast<const uint4 *>(pw[i] + kb * 64);
+            fb[i][1] = *reinterpret_cast<const uint4 *>(pw[i] + kb * 64 + 32);
+            fa[i][0] = *reinterpret_cast<const uint4 *>(pa[i] + kb * 64);
+            fa[i][1] = *reinterpret_cast<const uint4 *>(pa[i] + kb * 64 + 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!apk) split8(fa[i][0], fa[i][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma2<kDtSplit>(fb[j][0], fb[j][1], fa[i][0], fa[i][1], acc[i][j]);
+        }
+    }
+    // ---- the four K quarters meet: wave w sums row fragment w
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid][i][j * 4 + r][lane] = acc[i][j][r];
+    __syncthreads();
+    f4 sum[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            sum[0][j][r] = (red[0][wid][j * 4 + r][lane] + red[1][wid][j * 4 + r][lane]) + (red[2][wid][j * 4 + r][lane] + red[3][wid][j * 4 + r][lane]);
+    if (ksp > 0) g.bias = nullptr;                      // split-K over workgroups: the bias belongs to slice 0
+    g.ksplit = nks;                                     // > 1: the epilogue adds its (gated) partial sums into out with f32 atomics
+    gemm_epilogue<kDtSplit, EPI, 1>(g, sum, m0 + wid * 16, n0, rope_tab, wid, lane);
+}
+
+int launch_skinny_split(const GemmArgs &g, int epi, hipStream_t stream) {
+    const int rows = g.M - g.m_lo, gy = vs::cdiv(rows, 64), gx = vs::cdiv(g.N, 64);
+    // epilogue 2 with the residual already in `out`: split K over workgroups while the grid is small and a slice keeps >= 8 blocks per wave
+    int ks = 1;
+    if (epi == 2 && !g.resid)
+        while (ks < 8 && gx * gy * ks * 2 <= 384 && g.K / 64 / (ks * 2) >= 32) ks *= 2;
+    dim3 grid(gx, gy, ks), block(256);
+    switch (epi) {
+        case 0: hipLaunchKernelGGL(gemm_skinny_split_kernel<0>, grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL(gemm_skinny_split_kernel<1>, grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL(gemm_skinny_split_kernel<2>, grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL(gemm_skinny_split_kernel<3>, grid, block, 0, stream, g); break;
+        case 4: hipLaunchKernelGGL(gemm_skinny_split_kernel<4>, grid, block, 0, stream, g); break;
+        default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
+    }
+    return 0;
+}
+
 template <int BF16, int NW, int MF>
 int launch_smallm_nw(const GemmArgs &g, int epi, hipStream_t stream) {
     dim3 grid(vs::cdiv(g.N, 16), vs::cdiv(g.M - g.m_lo, 16 * MF)), block(64 * NW);
@@ -542,6 +657,11 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     // the 192-row tails of the bench step to it (plain stores of whole-K sums instead of the K-split tiles' f32 atomics).  Measured same-box:
     // 246.6 / 248.3 vs 247.6 / 247.7 ms per step -- no gain (A is re-read by each of the N / 16 column workgroups); the default stays 64.
     static const int tail_rows = [] { const char *e = getenv("VS_GEMM_TAIL_SMALLM"); return e ? atoi(e) : 64; }();
+    // round 5: tails of 65 .. 256 rows of the split class run on the skinny kernel (every epilogue, packed A / packed output included)
+    static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+    if constexpr (BF16 == kDtSplit) {
+        if (skinny && rem > (skinny == 2 ? 0 : 64) && rem <= 256 && g.K % 64 == 0) { t.ksplit = 1; return launch_skinny_split(t, epi, stream); }
+    }
     if (rem <= (BF16 == kDtSplit ? tail_rows : 64) && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) {
         t.ksplit = 1;
         return launch_smallm<BF16>(t, epi, stream);
@@ -563,6 +683,10 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
     if (g.M <= 64 && force == 0 && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) return launch_smallm<BF16>(g, epi, stream);
+    if constexpr (BF16 == kDtSplit) {   // camera-token GEMMs and other launches of <= 256 rows: the skinny kernel (round 5)
+        static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
+        if (skinny && force == 0 && g.M - g.m_lo <= 256 && g.K % 64 == 0 && g.ntaps == 0 && !g.partials && g.ksplit <= 1) return launch_skinny_split(g, epi, stream);
+    }
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
     // 256x256 tiles run one 8-wave workgroup per CU, i.e. in rounds of 256 tiles, and a partly filled round costs as much
