@@ -806,7 +806,7 @@ __device__ __forceinline__ void softmax_half(f4 (&st)[2], float scale_log2e, flo
 // query groups hold real queries) and MASKED (some query of the wave does not see all 32 keys) are compile-time, so the 96 MFMAs, the four
 // softmax steps and the 24 LDS reads of a tile form ONE basic block the scheduler can interleave.  kofs / vofs: per-lane byte offsets inside a
 // K / V tile (swizzle applied), loop invariant; the ring slot is a compile-time constant, so every LDS address is register + immediate.
-template <int NG, bool ALLQ, bool MASKED>
+template <int NG, bool ALLQ, bool MASKED, bool PLO>
 __device__ __forceinline__ void sp_tile(const unsigned char *sK, const unsigned char *sV, const int (&kofs)[2][2], const int (&vofs)[8], int nact,
                                         const int (&my_len)[NG], int kbase, int g, float scale_log2e, const uint4 (&qfh)[NG][2], const uint4 (&qfl)[NG][2],
                                         float (&m_run)[NG], float (&l_run)[NG], f4 (&o)[NG][4]) {
@@ -838,9 +838,9 @@ __device__ __forceinline__ void sp_tile(const unsigned char *sK, const unsigned 
         }
         softmax_half<MASKED>(st[u], scale_log2e, m_run[u], l_run[u], o[u], pfh[u]);     // st now holds P (f32), pfh its rne16
         const unsigned hh[4] = {pfh[u].x, pfh[u].y, pfh[u].z, pfh[u].w};
-        unsigned ll[4];
+        unsigned ll[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < (PLO ? 4 : 0); ++w) {
             // lo = rne16(p - float(hi)): the difference on v_fma_mix_f32 (f16 source operand, exact f32 result: one instruction instead of a
             // convert and a subtract), the rounding on a COMPILER-VISIBLE convert -- the value that feeds the P V MFMAs must come out of an
             // instruction the hazard recogniser sees (VALU write -> MFMA read wait states); asm -> VALU needs no software wait
@@ -867,11 +867,18 @@ __device__ __forceinline__ void sp_tile(const unsigned char *sK, const unsigned 
         const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
 #pragma unroll
         for (int u = 0; u < NG; ++u)
-            if (ALLQ || u < nact) o[u][db] = mma3(vh, vl, pfh[u], pfl[u], o[u][db]);
+            if (ALLQ || u < nact) {
+                if constexpr (PLO) {
+                    o[u][db] = mma3(vh, vl, pfh[u], pfl[u], o[u][db]);
+                } else {      // P as ONE f16 (p in [0, 1]: its lo half carries <= 2^-12 p): V_lo P_hi + V_hi P_hi, two MFMAs instead of three
+                    o[u][db] = mfma<false>(vl, pfh[u], o[u][db]);
+                    o[u][db] = mfma<false>(vh, pfh[u], o[u][db]);
+                }
+            }
     }
 }
 
-template <int NG>
+template <int NG, bool PLO = true>
 __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a) {
     constexpr int QW = 16 * NG;                                               // queries per wave (NG MFMA groups of 16), 2 * QW per workgroup
     constexpr int TILE_B = KB * 256;                                          // one K (or V) tile: 64 keys x 256 bytes
@@ -1010,10 +1017,10 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
         if (kb >= wave_len) return;                          // none of this wave's queries sees any of its keys of this tile
         const bool masked = kb + 32 > wave_min;              // (wave-uniform)
         if (allq) {
-            if (masked) sp_tile<NG, true, true>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
-            else sp_tile<NG, true, false>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
+            if (masked) sp_tile<NG, true, true, PLO>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
+            else sp_tile<NG, true, false, PLO>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
         } else {
-            sp_tile<NG, false, true>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
+            sp_tile<NG, false, true, PLO>(sK, sV, kofs, vofs, nact, my_len, kb, g, a.scale_log2e, qfh, qfl, m_run, l_run, o);
         }
     };
     for (int kt = 0; kt < maxlen; kt += 2 * KB) {            // two tiles per trip: the ring slot is a compile-time constant
@@ -1072,6 +1079,14 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
     }
 }
 
+// (Measured and not kept, round 5: folding a segment's single remainder key (257 = 4 tiles + 1 key; 257 + 257 = 8 aligned tiles + 2 keys) into
+//  the initial online-softmax state on the VALU -- m = s, l = 1, O = v from 48 v_dot2_f32_f16 per query group -- instead of a fifth / ninth
+//  tile: correct (4.8e-7 of float64), and 386 vs 392 us on the frame encoder's shape, 415 vs 408 on the cross-neighbour shape: nothing.  A
+//  workgroup of these shapes spends ~2 us of its ~21 us in MFMAs; the rest is the dependent chain Q load -> first DMA -> barrier -> ...
+//  -> merge -> store at 8 waves per CU, which a shorter key loop does not shorten.  Also measured: P as ONE f16 in the P V product
+//  (VS_ATTN_PLO=0: two MFMAs instead of three, no lo split): 25.95 -> 22.95 ms per step, but the encoder's error against the reference's
+//  f64 goldens grows 1.3e-5 -> 9e-5, the render PSNR against the oracle chain drops 73 -> 58.5 dB and the pose error 1.4e-6 -> 1.4e-5
+//  (video attention alone: 2.2e-5 at 8 views, over the 2e-5 bar): an opt-in switch, not the default.)
 // (Measured and not kept, round 3: a resident variant -- one 8-wave workgroup per (frame, head), all K / V converted once into 153 KiB of
 // LDS -- runs the frame encoder's 257 x 257 attention at the same 28 ms per step as this tiled kernel: the time is the per-group softmax /
 // split VALU work and the 3 x MFMAs, not the re-staging.)
@@ -1263,8 +1278,10 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
             f.out_packed = out_packed;
             const long long nwg = (long long)f.nqt * H * nbatch;
             VS_CHECK(nwg < (1LL << 31), "vs_attention: grid too large");
+            static const int plo = [] { const char *e = getenv("VS_ATTN_PLO"); return e ? atoi(e) : 1; }();
             if (ng == 4) hipLaunchKernelGGL(attention_sp_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
             else if (ng == 2) hipLaunchKernelGGL(attention_sp_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
+            else if (plo == 0 || (plo == 2 && q_kvlen) || (plo == 3 && !q_kvlen)) hipLaunchKernelGGL((attention_sp_kernel<3, false>), dim3((unsigned)nwg), dim3(256), 0, stream, f);
             else hipLaunchKernelGGL(attention_sp_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, stream, f);
             VS_HIP(hipGetLastError());
             return 0;
