@@ -425,6 +425,10 @@ scatter_kernel(int P, int tiles, int gx, const float *__restrict__ depth, const 
 //               chunk uses wave ballots (8 per key) + a 4x256 per-wave digit-count table.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSortLds = 1024;
+constexpr int kSortWave = 256;    // lists up to this length are sorted by one wave in registers inside tile_sort_kernel
+constexpr int kSegShift = 6;      // a tile list [x, y) owns the run-table slots (x >> kSegShift) + t .. (y >> kSegShift) + t
+constexpr int kRunKeys = 112;     // published runs are cut every kRunKeys keys (at bucket starts): with ~10 keys per bucket nearly every run is <= 128
+                                  // keys, i.e. the 28-stage network on two registers instead of 36 stages on four
 
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr a, int N) {
@@ -462,12 +466,12 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v)
     const unsigned lo = lane_xor<J>((unsigned)v), hi = lane_xor<J>((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-template <int K, int J>
-__device__ __forceinline__ void wave_bitonic_step(unsigned long long (&v)[4], int lane) {
+template <int NR, int K, int J>
+__device__ __forceinline__ void wave_bitonic_step(unsigned long long (&v)[NR], int lane) {
     if constexpr (J >= 64) {
         constexpr int dr = J >> 6;  // 1 or 2: partner register r ^ dr
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             if ((r & dr) == 0) {
                 const bool up = ((r * 64) & K) == 0;  // lane bits are below 64 <= J < K
                 const unsigned long long x = v[r], y = v[r | dr];
@@ -477,21 +481,23 @@ __device__ __forceinline__ void wave_bitonic_step(unsigned long long (&v)[4], in
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int e = r * 64 + lane;
             const unsigned long long x = v[r], y = shfl_xor_u64<J>(x);
             const bool up = (e & K) == 0, lower = (lane & J) == 0;
             v[r] = ((x > y) == (up == lower)) ? y : x;
         }
     }
-    if constexpr (J > 1) wave_bitonic_step<K, (J >> 1)>(v, lane);
+    if constexpr (J > 1) wave_bitonic_step<NR, K, (J >> 1)>(v, lane);
 }
-template <int K>
-__device__ __forceinline__ void wave_bitonic_merge(unsigned long long (&v)[4], int lane) {
-    wave_bitonic_step<K, (K >> 1)>(v, lane);
-    if constexpr (K < 256) wave_bitonic_merge<(K << 1)>(v, lane);
+template <int NR, int K>
+__device__ __forceinline__ void wave_bitonic_merge(unsigned long long (&v)[NR], int lane) {
+    wave_bitonic_step<NR, K, (K >> 1)>(v, lane);
+    if constexpr (K < 64 * NR) wave_bitonic_merge<NR, (K << 1)>(v, lane);
 }
-__device__ __forceinline__ void wave_bitonic256(unsigned long long (&v)[4], int lane) { wave_bitonic_merge<2>(v, lane); }
+// 64 * NR keys of one wave (NR = 2: 128 keys, 28 compare-exchange stages on two registers; NR = 4: 256 keys, 36 stages on four)
+template <int NR>
+__device__ __forceinline__ void wave_bitonic(unsigned long long (&v)[NR], int lane) { wave_bitonic_merge<NR, 2>(v, lane); }
 
 constexpr int kDigitBits = 8;
 constexpr int kBins = 1 << kDigitBits;
@@ -510,8 +516,15 @@ __device__ __forceinline__ unsigned long long digit_peers(int d, bool valid) {
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict__ keys, uint32_t *__restrict__ point_list,
                  unsigned long long *__restrict__ scratch, int2 *__restrict__ segs) {
-    __shared__ unsigned long long skeys[kSortLds];
-    __shared__ int whist[2][4][kBins];  // [current | next pass][wave][digit]
+    // one LDS object, 24.6 KiB: the bitonic image | the bucket starts and cursors; the radix path's per-wave digit
+    // tables ([current | next pass][wave][digit]) reuse the bucket arrays, which are dead by then
+    constexpr int kBucketsT = 2048;
+    __shared__ __attribute__((aligned(16))) unsigned char sort_lds[kSortLds * 8 + (kBucketsT + 4) * 4 + kBucketsT * 4];
+    unsigned long long *const skeys = reinterpret_cast<unsigned long long *>(sort_lds);
+    int *const bstart = reinterpret_cast<int *>(sort_lds + kSortLds * 8);
+    int *const bcur = bstart + kBucketsT + 4;
+    int (*const whist)[4][kBins] = reinterpret_cast<int (*)[4][kBins]>(sort_lds + kSortLds * 8);
+    static_assert(2 * 4 * kBins * 4 <= (kBucketsT + 4) * 4 + kBucketsT * 4, "digit tables must fit in the bucket arrays");
     __shared__ int wave_tot[4];
     const size_t ntile_all = (size_t)gridDim.x * gridDim.y;
     const size_t t = (size_t)reinterpret_cast<const int32_t *>(ranges + ntile_all)[(size_t)blockIdx.y * gridDim.x + blockIdx.x];   // longest first
@@ -519,19 +532,42 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
     const int n = rg.y - rg.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // this tile's slots in the segment table consumed by segment_sort_kernel (see the bucket path): clear them first
-    const size_t seg_base = (size_t)(rg.x >> 7) + t;
-    const int seg_slots = (rg.y >> 7) - (rg.x >> 7) + 1;
+    const size_t seg_base = (size_t)(rg.x >> kSegShift) + t;
+    const int seg_slots = (rg.y >> kSegShift) - (rg.x >> kSegShift) + 1;
     if (segs) {
         for (int k = tid; k < seg_slots; k += 256) segs[seg_base + k] = make_int2(0, 0);
         __syncthreads();
     }
     if (n <= 0) return;
     unsigned long long *a = keys + rg.x;
-    if (n == 1) {
-        if (tid == 0) point_list[rg.x] = (uint32_t)a[0];
+    if (n <= kSortWave) {
+        // round 5: a list of <= 256 keys is ONE wave's register sort (the network segment_sort_kernel uses): no LDS image, no barrier
+        if (wid != 0) return;
+        if (n <= 64) {
+            unsigned long long v[1] = {lane < n ? a[lane] : ~0ull};
+            wave_bitonic<1>(v, lane);
+            if (lane < n) point_list[rg.x + lane] = (uint32_t)v[0];
+        } else if (n <= 128) {
+            unsigned long long v[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) v[r] = (r * 64 + lane) < n ? a[r * 64 + lane] : ~0ull;
+            wave_bitonic<2>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (r * 64 + lane < n) point_list[rg.x + r * 64 + lane] = (uint32_t)v[r];
+        } else {
+            unsigned long long v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (r * 64 + lane) < n ? a[r * 64 + lane] : ~0ull;
+            wave_bitonic<4>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r * 64 + lane < n) point_list[rg.x + r * 64 + lane] = (uint32_t)v[r];
+        }
         return;
     }
-    if (n <= kSortLds) {
+    if (!scratch) {     // (a caller without the scratch buffer: not reached from vs_raster_forward, which provides it whenever a list is longer)
+        if (n > kSortLds) return;
         int N = 2;
         while (N < n) N <<= 1;
         for (int k = tid; k < N; k += 256) skeys[k] = k < n ? a[k] : ~0ull;
@@ -541,32 +577,57 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
         return;
     }
     unsigned long long *b = scratch + rg.x;
-    // ---- large tiles: ONE order-preserving bucket pass + in-LDS sorts.  A radix pass scatters 8-byte keys over the whole
+    // ---- every longer list (round 5: from 257 keys on, not only the > 1024-key lists -- the 55-stage block-wide bitonic network with a barrier
+    // per stage that lists of 257 .. 1024 keys used to take was most of this kernel's time on the bench step, whose median list is 845
+    // keys): ONE order-preserving bucket pass + register / in-LDS sorts.  A radix pass scatters 8-byte keys over the whole
     // tile (every store its own cache line), so passes are what cost: bucket the keys by (depth - min) >> shift into
     // kBuckets ranges (one scattered pass, any order inside a bucket), then sort runs of consecutive buckets of <= 1024
     // keys with the bitonic network on the full 64-bit (depth, index) key and write the index list coalesced.  Tiles
     // whose depths pile up in one bucket (> 512 keys) take the radix path below instead. ----
     {
-        constexpr int kBuckets = 2048, kSeg = kSortLds / 2;
-        __shared__ int bstart[kBuckets + 1];
-        __shared__ int bcur[kBuckets];
+        constexpr int kBuckets = kBucketsT, kSeg = kSortLds / 2;
         __shared__ unsigned s_mn, s_mx;
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
         for (int k = tid; k < kBuckets; k += 256) bcur[k] = 0;
         __syncthreads();
-        unsigned mn = ~0u, mx = 0u;
-        for (int i = tid; i < n; i += 256) {
-            const unsigned hi = (unsigned)(a[i] >> 32);
-            mn = min(mn, hi); mx = max(mx, hi);
+        // Round 5: the depth range comes from a strided SAMPLE of 256 keys (one key per thread) instead of a pass over the whole list, padded
+        // by 1/32 of itself on both sides; keys outside it land in the first / last bucket (the bucket function stays monotone, so the
+        // result is the same exact sort -- only the balance of the buckets depends on the sample; a list whose tails pile up takes the
+        // fat / clustered routes below like any other piled-up list).  And the keys are read ONCE: a thread keeps its first kKeep keys
+        // (tiles up to 256 * kKeep = 8192 entries completely) in registers between the histogram and the scatter pass.  Before: three
+        // reads of the list from HBM (min / max, histogram, scatter): 8.7 GB of the forward's 39.8 GB on the bench step.  (Measured and not
+        // kept: 16 kept keys and 72 VGPRs for six instead of four workgroups per CU -- 1.92 -> 2.63 ms: more lists in flight than L2 holds.)
+        constexpr int kKeep = 32;
+        unsigned mn, mx;
+        {
+            const unsigned hi = (unsigned)(a[(int)(((long long)tid * n) >> 8)] >> 32);
+            mn = mx = hi;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64)); }
         if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
         __syncthreads();
-        mn = s_mn;
-        const unsigned range = s_mx - mn;
+        {
+            const unsigned pad = ((s_mx - s_mn) >> 5) + 1u;
+            mn = s_mn > pad ? s_mn - pad : 0u;
+            mx = s_mx < 0xffffffffu - pad ? s_mx + pad : 0xffffffffu;
+        }
+        const unsigned range = mx - mn;
         const int shift = range >= (unsigned)kBuckets ? (32 - __clz(range)) - 11 : 0;
-        for (int i = tid; i < n; i += 256) atomicAdd(&bcur[(int)((((unsigned)(a[i] >> 32)) - mn) >> shift)], 1);
+        auto bucket_of = [&](unsigned long long key) -> int {
+            const unsigned hi = (unsigned)(key >> 32);
+            return hi <= mn ? 0 : (int)min((hi - mn) >> shift, (unsigned)(kBuckets - 1));
+        };
+        unsigned long long kreg[kKeep];
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) {
+            const int i = tid + j * 256;
+            kreg[j] = i < n ? a[i] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j)
+            if (tid + j * 256 < n) atomicAdd(&bcur[bucket_of(kreg[j])], 1);
+        for (int i = tid + kKeep * 256; i < n; i += 256) atomicAdd(&bcur[bucket_of(a[i])], 1);
         __syncthreads();
         int loc[kBuckets / 256], sum = 0, big = 0;
 #pragma unroll
@@ -587,9 +648,12 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
             for (int q = 0; q < kBuckets / 256; ++q) { bstart[tid * (kBuckets / 256) + q] = run; bcur[tid * (kBuckets / 256) + q] = run; run += loc[q]; }
             if (tid == 255) bstart[kBuckets] = n;
             __syncthreads();
-            for (int i = tid; i < n; i += 256) {
+#pragma unroll
+            for (int j = 0; j < kKeep; ++j)
+                if (tid + j * 256 < n) b[atomicAdd(&bcur[bucket_of(kreg[j])], 1)] = kreg[j];
+            for (int i = tid + kKeep * 256; i < n; i += 256) {
                 const unsigned long long key = a[i];
-                b[atomicAdd(&bcur[(int)((((unsigned)(key >> 32)) - mn) >> shift)], 1)] = key;
+                b[atomicAdd(&bcur[bucket_of(key)], 1)] = key;
             }
             __syncthreads();
             auto boundary = [&](int k, int seg, int nseg) -> int {  // largest bucket start <= k * seg (tile end for k == nseg)
@@ -603,10 +667,10 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
                 return bstart[lo];
             };
             if (!fat) {
-                // every bucket <= 128 keys: runs of consecutive buckets cut every ~128 keys are <= 256 keys.  They are not
+                // every bucket <= 128 keys: runs of consecutive buckets cut every kRunKeys keys are < 256 keys.  They are not
                 // sorted here (a 20k-key tile would walk 160 of them on 4 waves while small tiles' CUs idle): publish
                 // them, segment_sort_kernel sorts one run per wave across the whole chip.
-                constexpr int kW = 128;
+                constexpr int kW = kRunKeys;
                 const int nseg = (n + kW - 1) / kW;  // <= seg_slots
                 for (int k = tid; k < nseg; k += 256) {
                     const int s_lo = boundary(k, kW, nseg), m_ = boundary(k + 1, kW, nseg) - s_lo;
@@ -729,10 +793,26 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
     if (slot >= nslots) return;
     const int2 sg = segs[slot];
     if (sg.y <= 0) return;
+    if (sg.y <= 64) {
+        unsigned long long v[1] = {lane < sg.y ? scratch[(size_t)sg.x + lane] : ~0ull};
+        wave_bitonic<1>(v, lane);
+        if (lane < sg.y) point_list[(size_t)sg.x + lane] = (uint32_t)v[0];
+        return;
+    }
+    if (sg.y <= 128) {     // (wave-uniform) nearly every published run: the 128-key network is 2.5x less compare-exchange work
+        unsigned long long v[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) v[r] = (r * 64 + lane) < sg.y ? scratch[(size_t)sg.x + r * 64 + lane] : ~0ull;
+        wave_bitonic<2>(v, lane);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r * 64 + lane < sg.y) point_list[(size_t)sg.x + r * 64 + lane] = (uint32_t)v[r];
+        return;
+    }
     unsigned long long v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = (r * 64 + lane) < sg.y ? scratch[(size_t)sg.x + r * 64 + lane] : ~0ull;
-    wave_bitonic256(v, lane);
+    wave_bitonic<4>(v, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (r * 64 + lane < sg.y) point_list[(size_t)sg.x + r * 64 + lane] = (uint32_t)v[r];
@@ -999,15 +1079,16 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     unsigned long long *keys = (unsigned long long *)get(VS_BUF_KEYS, (size_t)R * 8);
     uint32_t *point_list = (uint32_t *)get(VS_BUF_POINT_LIST, (size_t)R * 4);
     unsigned long long *scratch = nullptr;
-    // large tiles: [R] u64 bucketized keys followed by the segment table: tile t owns slots (x_t >> 7) + t .. (y_t >> 7) + t,
-    // which tile the table exactly ((R >> 7) + tiles * C slots of {start, length}) because the ranges are contiguous
-    const long long nslots = (R >> 7) + (long long)tiles * C;
+    // lists longer than one wave's register sort: [R] u64 bucketized keys followed by the run table: tile t owns slots
+    // (x_t >> kSegShift) + t .. (y_t >> kSegShift) + t, which tile the table exactly ((R >> kSegShift) + tiles * C slots of {start, length})
+    // because the ranges are contiguous
+    const long long nslots = (R >> kSegShift) + (long long)tiles * C;
     int2 *segs = nullptr;
-    if (max_tile > kSortLds) {
+    if (max_tile > kSortWave) {
         scratch = (unsigned long long *)get(VS_BUF_SORT_SCRATCH, (size_t)R * 8 + (size_t)nslots * sizeof(int2));
         segs = scratch ? reinterpret_cast<int2 *>(scratch + R) : nullptr;
     }
-    VS_CHECK(keys && point_list && (max_tile <= kSortLds || scratch), "vs_raster_forward: allocator returned null");
+    VS_CHECK(keys && point_list && (max_tile <= kSortWave || scratch), "vs_raster_forward: allocator returned null");
     // capacity mode: the table is sized for `capacity` instances but tile_sort_kernel only clears the slots of the instances that exist
     if (segs && in->capacity > 0) VS_HIP(hipMemsetAsync(segs, 0, (size_t)nslots * sizeof(int2), stream));
     if (R > 0) {
