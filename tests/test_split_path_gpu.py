@@ -735,7 +735,8 @@ def test_gemm_qkv_rope_split_packed_output():
     o32s, ops_ = torch.empty(m, 3 * C, device=d), ops.split_act(m, 3 * C, d)
     ops.gemm_qkv_rope(a[:m].contiguous(), w, b, o32s, C, pos[:m].contiguous(), None, 100.0, 1.0)
     ops.gemm_qkv_rope(ap, w, b, ops_, C, pos[:m].contiguous(), None, 100.0, 1.0)
-    assert torch.equal(o32s, o32[:m]) and torch.equal(ops_.data, ops.split_pack_weight(o32s, 0).data)
+    assert torch.equal(ops_.data, ops.split_pack_weight(o32s, 0).data)        # packed A / packed output: the same roundings, bit for bit
+    assert _rel(o32s, o32[:m]) <= 1e-6                                         # vs the tile kernel: another summation order (K quarters per wave)
 
 
 @pytest.mark.parametrize("N,Hs,Ws", [(2, 32, 32), (1, 128, 128)])

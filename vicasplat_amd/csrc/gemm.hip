@@ -660,7 +660,8 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     // round 5: tails of 65 .. 256 rows of the split class run on the skinny kernel (every epilogue, packed A / packed output included)
     static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
     if constexpr (BF16 == kDtSplit) {
-        if (skinny && rem > (skinny == 2 ? 0 : 64) && rem <= 256 && g.K % 64 == 0) { t.ksplit = 1; return launch_skinny_split(t, epi, stream); }
+        // (<= 64 rows stay on the weight-streaming kernel where it applies; the RoPE epilogue and packed outputs, which it does not have, come here)
+        if (skinny && rem <= 256 && g.K % 64 == 0 && (rem > 64 || skinny == 2 || epi == 4 || g.out_packed)) { t.ksplit = 1; return launch_skinny_split(t, epi, stream); }
     }
     if (rem <= (BF16 == kDtSplit ? tail_rows : 64) && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) {
         t.ksplit = 1;
