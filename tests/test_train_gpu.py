@@ -340,14 +340,14 @@ def test_config5_per_gpu_batch_split_class_checkpointed():
     from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
     d = torch.device("cuda:0")
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
-    batch = _config4_batch(24, 8, 12, d)
+    batch = _config4_batch(24, 8, 12, d, with_extrinsics=True)
     m = _full_model("split")
     m.enable_gradient_checkpointing()
     opt, sched = callers.configure_optimizer(m, lr=4e-5, backbone_lr_multiplier=0.25, warm_up_steps=100)
     reducer = vdist.GradReducer(m.parameters())
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
     torch.cuda.reset_peak_memory_stats()
-    r = callers.training_step(m, dec, batch, opt, scheduler=sched, compute_dtype="split", reducer=reducer)
+    r = callers.training_step(m, dec, batch, opt, scheduler=sched, camera_weight=1.0, compute_dtype="split", reducer=reducer)
     torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     print(f"config 5 per-GPU step [split, checkpointed, 24 scenes]: loss {float(r['loss']):.6f} grad_norm {float(r['grad_norm']):.4f} peak {peak:.1f} GB")

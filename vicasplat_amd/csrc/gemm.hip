@@ -325,15 +325,16 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
 // last 256-row tile) and the decoder's camera-token GEMMs (M = frames).  Those launches were LATENCY bound, not bandwidth or MFMA bound:
 // a handful of 128 x 128 tiles each walking all of K one 32-wide stage per barrier (32-90 us for 5-15 us of work; 11 ms of the 257 ms
 // step), or -- on the weight-streaming kernel above -- 16 output columns per workgroup, i.e. A re-read N / 16 times through L2.
-// Here a workgroup owns a 64 x 64 output tile; its four waves split K into contiguous quarters and each keeps the WHOLE tile in
+// Here a workgroup owns a 64 x 64 output tile; its eight waves split K into contiguous ranges and each keeps the WHOLE tile in
 // registers (16 accumulator fragments), reading its operand fragments straight from global memory (packed rows are fragment-ready:
 // 16 B hi + 16 B lo per lane and 32-k block), two 32-k blocks = 32 x 16-byte loads in flight per lane, no LDS staging and no barrier in
 // the K loop.  The partial tiles meet once in LDS; wave w then runs the shared epilogue on row fragment w, so every fused epilogue (GELU,
 // RoPE, packed output, gated f32 residual) is the tile kernels' code.  Epilogue 2 may also split K over blockIdx.z (atomics, as the tile
 // kernels' tails do) when N is too narrow to give the chip enough workgroups.
 template <int EPI>
-__global__ void __launch_bounds__(256) gemm_skinny_split_kernel(const GemmArgs g_in) {
-    __shared__ __attribute__((aligned(16))) float red[4][4][16][64];   // [wave][row fragment][j * 4 + r][lane]: 64 KiB
+__global__ void __launch_bounds__(512) gemm_skinny_split_kernel(const GemmArgs g_in) {
+    constexpr int NW = 8;                                                // waves = K slices of the workgroup (two per SIMD: twice the loads in flight)
+    __shared__ __attribute__((aligned(16))) float red[4][4][16][64];   // [wave pair][row fragment][j * 4 + r][lane]: 64 KiB
     __shared__ __attribute__((aligned(16))) float2 rope_tab[64 * 16];  // gemm_epilogue<., 4>'s (sin, cos) table
     GemmArgs g = g_in;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -356,10 +357,10 @@ __global__ void __launch_bounds__(256) gemm_skinny_split_kernel(const GemmArgs g
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    // 32-k blocks (128 bytes of a packed or f32 row) of this workgroup's K slice, cut into four contiguous wave ranges
+    // 32-k blocks (128 bytes of a packed or f32 row) of this workgroup's K slice, cut into NW contiguous wave ranges
     const int kb_all = g.K / 64, kb_per_wg = (kb_all + nks - 1) / nks;
     const int kb_lo = ksp * kb_per_wg, kb_hi = min(kb_all, kb_lo + kb_per_wg);
-    const int per = (kb_hi - kb_lo + 3) / 4;
+    const int per = (kb_hi - kb_lo + NW - 1) / NW;
     const int kb0 = kb_lo + wid * per, kb1 = min(kb_hi, kb0 + per);
     const bool apk = g.a_packed != 0;
     int kb = kb0;
@@ -399,23 +400,37 @@ __global__ void __launch_bounds__(256) gemm_skinny_split_kernel(const GemmArgs g
             for (int j = 0; j < 4; ++j) acc[i][j] = mma2<kDtSplit>(fb[j][0], fb[j][1], fa[i][0], fa[i][1], acc[i][j]);
         }
     }
-    // ---- the four K quarters meet: wave w sums row fragment w
+    // ---- the eight K slices meet in two steps through one 64 KiB image: waves 4..7 hand their tiles to waves 0..3, which add them to
+    // their own and publish the four pair sums; wave w < 4 then sums row fragment w (waves 4..7 run the epilogue on no rows: its
+    // workgroup barrier -- the RoPE table -- needs every wave)
+    if (wid >= 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wid][i][j * 4 + r][lane] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) red[wid - 4][i][j * 4 + r][lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wid < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wid][i][j * 4 + r][lane] += acc[i][j][r];
+    }
     __syncthreads();
     f4 sum[1][4];
+    const int wf = wid & 3;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            sum[0][j][r] = (red[0][wid][j * 4 + r][lane] + red[1][wid][j * 4 + r][lane]) + (red[2][wid][j * 4 + r][lane] + red[3][wid][j * 4 + r][lane]);
+            sum[0][j][r] = (red[0][wf][j * 4 + r][lane] + red[1][wf][j * 4 + r][lane]) + (red[2][wf][j * 4 + r][lane] + red[3][wf][j * 4 + r][lane]);
     if (ksp > 0) g.bias = nullptr;                      // split-K over workgroups: the bias belongs to slice 0
     g.ksplit = nks;                                     // > 1: the epilogue adds its (gated) partial sums into out with f32 atomics
-    gemm_epilogue<kDtSplit, EPI, 1>(g, sum, m0 + wid * 16, n0, rope_tab, wid, lane);
+    gemm_epilogue<kDtSplit, EPI, 1>(g, sum, wid < 4 ? m0 + wid * 16 : g.M, n0, rope_tab, wid, lane);
 }
 
 int launch_skinny_split(const GemmArgs &g, int epi, hipStream_t stream) {
@@ -424,7 +439,7 @@ int launch_skinny_split(const GemmArgs &g, int epi, hipStream_t stream) {
     int ks = 1;
     if (epi == 2 && !g.resid)
         while (ks < 8 && gx * gy * ks * 2 <= 384 && g.K / 64 / (ks * 2) >= 32) ks *= 2;
-    dim3 grid(gx, gy, ks), block(256);
+    dim3 grid(gx, gy, ks), block(512);
     switch (epi) {
         case 0: hipLaunchKernelGGL(gemm_skinny_split_kernel<0>, grid, block, 0, stream, g); break;
         case 1: hipLaunchKernelGGL(gemm_skinny_split_kernel<1>, grid, block, 0, stream, g); break;
