@@ -57,6 +57,12 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                   int32_t *__restrict__ radii, float *__restrict__ depth, int32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
     __shared__ int cams[kCamChunk];
+    // round 5: the parameters of the scene's first kParCams cameras (view 16 | proj 16 | campos 3 | tanfov 2 | pad: 40 floats each), staged
+    // once per block.  The kernel argument is a struct of pointers, so the compiler cannot prove that the loop's stores leave the camera
+    // arrays alone and fetched them with VECTOR loads at the top of every camera iteration (PMC: 5 scalar-memory instructions per wave, 43 %
+    // of the wave cycles waiting); an LDS broadcast read costs a tenth of that latency.  Same values, same arithmetic: bit-identical.
+    constexpr int kParCams = 32, kParStride = 40;
+    __shared__ __attribute__((aligned(16))) float cpar[kParCams * kParStride];
     extern __shared__ int hist_dyn[];   // 2 x tiles bins (launch-sized: 2 KiB for a 256 x 256 image instead of 2 x 16 KiB for the 4096-tile capacity)
     __shared__ int ncam_s;
     const int s = blockIdx.y;
@@ -134,16 +140,45 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
       }
       __syncthreads();
       const int ncam = ncam_s;
+      {   // stage the camera parameters (element e of camera slot kk: one thread each, strided)
+          const int nst = min(ncam, kParCams);
+          for (int e = threadIdx.x; e < nst * kParStride; e += 256) {
+              const int kk = e / kParStride, q = e - kk * kParStride, cc = cams[kk];
+              float v = 0.f;
+              if (q < 16) v = in.viewmatrix[16 * cc + q];
+              else if (q < 32) v = in.projmatrix[16 * cc + q - 16];
+              else if (q < 35) v = in.campos[3 * cc + q - 32];
+              else if (q < 37) v = in.tanfov[2 * cc + q - 35];
+              else if (q == 37) v = (float)W / (2.0f * in.tanfov[2 * cc]);          // focal_x, focal_y: the same expression the loop used per lane
+              else if (q == 38) v = (float)H / (2.0f * in.tanfov[2 * cc + 1]);
+              cpar[e] = v;
+          }
+          __syncthreads();
+      }
       for (int k = 0; k < ncam; ++k) {
-        const int c = __builtin_amdgcn_readfirstlane(cams[k]);   // wave-uniform: the camera matrices become scalar loads (SGPRs), not 37 per-lane loads
+        const int c = __builtin_amdgcn_readfirstlane(cams[k]);   // wave-uniform
         const size_t ci = (size_t)c * P + i;
         bool visible = false;
         int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
         if (live) {
-            const float *__restrict__ vm = in.viewmatrix + 16 * c;
-            const float *__restrict__ pm = in.projmatrix + 16 * c;
-            const float tanfovx = in.tanfov[2 * c], tanfovy = in.tanfov[2 * c + 1];
-            const float focal_x = (float)W / (2.0f * tanfovx), focal_y = (float)H / (2.0f * tanfovy);
+            float vm[16], pm[16], cp[3], tanfovx, tanfovy, focal_x, focal_y;
+            if (k < kParCams) {                                  // (wave-uniform) LDS broadcast reads, 16 bytes each
+                const float4 *q4 = reinterpret_cast<const float4 *>(cpar + k * kParStride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 a4 = q4[j], b4 = q4[4 + j];
+                    vm[4 * j] = a4.x; vm[4 * j + 1] = a4.y; vm[4 * j + 2] = a4.z; vm[4 * j + 3] = a4.w;
+                    pm[4 * j] = b4.x; pm[4 * j + 1] = b4.y; pm[4 * j + 2] = b4.z; pm[4 * j + 3] = b4.w;
+                }
+                const float4 c4 = q4[8], d4 = q4[9];
+                cp[0] = c4.x; cp[1] = c4.y; cp[2] = c4.z; tanfovx = c4.w; tanfovy = d4.x; focal_x = d4.y; focal_y = d4.z;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { vm[j] = in.viewmatrix[16 * c + j]; pm[j] = in.projmatrix[16 * c + j]; }
+                cp[0] = in.campos[3 * c]; cp[1] = in.campos[3 * c + 1]; cp[2] = in.campos[3 * c + 2];
+                tanfovx = in.tanfov[2 * c]; tanfovy = in.tanfov[2 * c + 1];
+                focal_x = (float)W / (2.0f * tanfovx); focal_y = (float)H / (2.0f * tanfovy);
+            }
             int radius_i = 0;
             uint32_t clamp_bits = 0;
             do {
@@ -199,7 +234,6 @@ preprocess_kernel(const VsRasterIn in, float *__restrict__ geom, ushort4 *__rest
                 if (!has_sh) {
                     rgb[0] = sh[0][0]; rgb[1] = sh[0][1]; rgb[2] = sh[0][2];
                 } else {
-                    const float *__restrict__ cp = in.campos + 3 * c;
                     const float dx = px - cp[0], dy = py - cp[1], dz = pz - cp[2];
                     // (v_rsq_f32 + three multiplies instead of an IEEE sqrt and three IEEE divisions -- ~45 VALU of this kernel's ~600 per
                     //  (Gaussian, camera): the view direction only feeds the COLOUR, which is float-tolerant (1 ulp of the direction = 1e-7 of
