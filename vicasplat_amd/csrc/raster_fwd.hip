@@ -873,13 +873,13 @@ segment_sort_kernel(const int2 *__restrict__ segs, int nslots, const unsigned lo
 // staged record's footprint test is read from LDS once per tile instead of once per quadrant-wave, the batch barriers are wave-local, and
 // a tile occupies one wave slot (12 tiles per CU by LDS instead of 3-4 workgroups of four waves).  Same arithmetic, same order per pixel:
 // bit-identical output (tests/test_raster_gpu.py runs both).  Measured: see DESIGN 5.
-template <bool COUNT_TOUCHED, int NW>
+template <bool COUNT_TOUCHED, int NW, int NTB = 256>
 __global__ void __launch_bounds__(64 * NW)
 render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ background, float *__restrict__ out_color,
               float *__restrict__ out_depth, float *__restrict__ out_opacity, float *__restrict__ final_T,
               int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched) {
-    constexpr int NTHR = 64 * NW, NT = 256, RPT = NT / NTHR, NQ = 4 / NW;   // staged batch: 256 records, RPT per thread; NQ quadrants per wave
+    constexpr int NTHR = 64 * NW, NT = NTB, RPT = NT / NTHR, NQ = 4 / NW;   // staged batch: NT records, RPT per thread; NQ quadrants per wave
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
     __shared__ uint32_t sid[NT];
     const int gx = (W + kTile - 1) / kTile;
@@ -1143,7 +1143,19 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
 #define VS_RENDER(CNT_, NW_)                                                                                                         \
     hipLaunchKernelGGL((render_kernel<CNT_, NW_>), rgrid, dim3(64 * NW_), 0, stream, P, W, H, ranges, point_list, geom, in->background, \
                        out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched)
-    if (render_waves == 1) { if (count) VS_RENDER(true, 1); else VS_RENDER(false, 1); }
+    // one wave per tile: staged batches of 64 records (round 5: 96 VGPRs and 3.3 KiB of LDS per wave -> five waves per SIMD instead of
+    // three; the kernel is latency bound -- PMC: VALU issue 0.42, 38 % of the wave cycles waiting -- and a batch is one round of the
+    // 64-entry footprint test anyway.  256 / 128 / 64: 5.23 / 4.73 / 4.60 ms on the bench step, bit-identical; VS_RENDER_NT = 256 | 128 for A/B)
+    static const int ntb = [] { const char *e = getenv("VS_RENDER_NT"); return e ? atoi(e) : 64; }();
+#define VS_RENDER1(CNT_, NT_)                                                                                                         \
+    hipLaunchKernelGGL((render_kernel<CNT_, 1, NT_>), rgrid, dim3(64), 0, stream, P, W, H, ranges, point_list, geom, in->background,   \
+                       out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched)
+    if (render_waves == 1) {
+        if (ntb == 256) { if (count) VS_RENDER1(true, 256); else VS_RENDER1(false, 256); }
+        else if (ntb == 128) { if (count) VS_RENDER1(true, 128); else VS_RENDER1(false, 128); }
+        else { if (count) VS_RENDER1(true, 64); else VS_RENDER1(false, 64); }
+    }
+#undef VS_RENDER1
     else { if (count) VS_RENDER(true, 4); else VS_RENDER(false, 4); }
 #undef VS_RENDER
     VS_HIP(hipGetLastError());
