@@ -210,7 +210,11 @@ def test_attention_split_plain_prefix_mask_and_segments(nb, H, L):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 64, 64, 256, 256, 1), (1, 32, 48, 128, 128, 1), (2, 16, 16, 192, 256, 1), (1, 33, 20, 768, 64, 2),
-                                                   (3, 40, 24, 64, 83, 1), (2, 128, 128, 128, 128, 1), (8, 64, 64, 256, 256, 1)])
+                                                   (3, 40, 24, 64, 83, 1), (2, 128, 128, 128, 128, 1), (8, 64, 64, 256, 256, 1),
+                                                   # round 5: channel counts that are not a power of two on the 256 x 256 tile kernel (>= 150 tiles:
+                                                   # K-tiles per tap 6 / 12 / 24 through the magic division), ragged last tile, stride 2, and the
+                                                   # 16 x 16 maps the lowered tile threshold moved there
+                                                   (40, 32, 32, 192, 256, 1), (151, 16, 16, 384, 256, 1), (140, 33, 33, 768, 256, 2), (150, 16, 16, 256, 256, 1)])
 def test_conv3x3_split(N, H, W, Cin, Cout, stride):
     from vicasplat_amd import ops
     d = _dev()

@@ -435,10 +435,10 @@ struct ConvStager256 {
     const unsigned short *pz[2];     // [round] this lane's 16 bytes of the zero page
     unsigned vmask[2][2];            // [A_h][round] bit t: tap t is inside the image (0 for rows past M)
     const unsigned short *pw[2][2];  // [B_h][round]
-    int Cin, Win, cshift;
+    int Cin, Win, kpt, kinv;         // kpt = K-tiles per tap (Cin / 64, any value <= 64: round 5 -- was a power of two), kinv = ceil(2^16 / kpt)
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
         if (u < 2) {
-            const int tap = kt >> cshift, kc = kt & ((1 << cshift) - 1);
+            const int tap = (kt * kinv) >> 16, kc = kt - tap * kpt;      // kt / kpt, exact for kt < 9 * kpt (checked for every kpt <= 64)
             const int ty = (tap * 11) >> 5;                      // tap / 3 for tap in 0..8
             const int dy = ty - 1, dx = tap - ty * 3 - 1;
             const long long off = (long long)(dy * Win + dx) * Cin + kc * 64;   // wave-uniform
@@ -455,7 +455,7 @@ struct ConvStager256 {
 };
 
 template <int BF16, bool RELU_IN, int FUSE_NF = 0, bool APACK = false>
-__global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, const int cshift) {
+__global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, const int kpt) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kLdsBytes256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     const int m0 = tm * 256, n0 = tn * 256;
 
     ConvStager256 st;
-    st.Cin = g.Cin; st.Win = g.Win; st.cshift = cshift;
+    st.Cin = g.Cin; st.Win = g.Win; st.kpt = kpt; st.kinv = (65536 + kpt - 1) / kpt;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = unit_row256(wid, j, lane);
@@ -515,10 +515,10 @@ struct ConvStager256x128 {
     const unsigned short *pz[2];
     unsigned vmask[2][2];
     const unsigned short *pw[2];     // [round] the B unit: 128 weight rows
-    int Cin, Win, cshift;
+    int Cin, Win, kpt, kinv;         // kpt = K-tiles per tap (Cin / 64, any value <= 64: round 5 -- was a power of two), kinv = ceil(2^16 / kpt)
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
         if (u < 2) {
-            const int tap = kt >> cshift, kc = kt & ((1 << cshift) - 1);
+            const int tap = (kt * kinv) >> 16, kc = kt - tap * kpt;      // kt / kpt, exact for kt < 9 * kpt (checked for every kpt <= 64)
             const int ty = (tap * 11) >> 5;
             const int dy = ty - 1, dx = tap - ty * 3 - 1;
             const long long off = (long long)(dy * Win + dx) * Cin + kc * 64;
@@ -538,7 +538,7 @@ template <int BF16, int MI>
 __device__ __forceinline__ void conv_head_dot_epilogue(const ConvArgs &g, f4 (&acc)[MI][4], int m0, int wr, int wc, float *red, int lane);
 
 template <bool RELU_IN, bool FUSE_DOT, bool A_PACKED = false>
-__global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const ConvArgs g, const int cshift) {
+__global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const ConvArgs g, const int kpt) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 3 * kUnitBytes256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const Con
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * 256, n0 = tn * 128;
     ConvStager256x128 st;
-    st.Cin = g.Cin; st.Win = g.Win; st.cshift = cshift;
+    st.Cin = g.Cin; st.Win = g.Win; st.kpt = kpt; st.kinv = (65536 + kpt - 1) / kpt;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = unit_row256(wid, j, lane);                 // unit row 0..127 this lane stages
@@ -1064,22 +1064,36 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     int cshift = -1;
     for (int sft = 0; sft < 4; ++sft)
         if (Cin == (64 << sft)) cshift = sft;
+    // round 5: the 256 x 256 tile kernel takes any Cin that is a whole number of 64-unit K-tiles per tap (96 -> 128, 192, 384, 768 channels of
+    // the DPT reassemble / layer_rn convolutions and the stride-2 768 -> 768 convolution used to run on the 4-wave kernels at 170-270 TF/s)
+    const int kpt_any = (Cin % 64 == 0 && Cin / 64 <= 64) ? Cin / 64 : -1;
     const long long t256 = vs::cdiv64(M, 256) * vs::cdiv(Cout, 256);
-    if (force != 8 && force != 4 && cshift >= 0 && Cout % 256 == 0 && (9 * Cin / 64) % 2 == 0 && t256 >= 224) {
+    static const int t256_min_env = [] { const char *e = getenv("VS_CONV_T256_MIN"); return e ? atoi(e) : 0; }();
+    // >= 150 tiles (round 5; was 224): a 59 %-full round of 256 x 256 tiles beats the 4-wave kernel's one and a half rounds at two workgroups
+    // per CU in the split class (16 x 16 maps of the bench step: 0.21 -> 0.17 ms per convolution); 8 x 8 maps (48 tiles) stay where they were
+    const long long t256_min = t256_min_env > 0 ? t256_min_env : (dtype == 4 ? 150 : 224);
+    if (force != 8 && force != 4 && dtype == 4 && cshift < 0 && kpt_any > 0 && Cout % 256 == 0 && (9 * kpt_any) % 2 == 0 && t256 >= t256_min && !g.a_packed) {
+        dim3 grid((unsigned)t256), block(512);
+        if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, true>), grid, block, 0, stream, g, kpt_any);
+        else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false>), grid, block, 0, stream, g, kpt_any);
+        VS_HIP(hipGetLastError());
+        return 0;
+    }
+    if (force != 8 && force != 4 && cshift >= 0 && Cout % 256 == 0 && (9 * Cin / 64) % 2 == 0 && t256 >= t256_min) {
         dim3 grid((unsigned)t256), block(512);
         if (dtype == 4) {
-            if (g.a_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 0, true>), grid, block, 0, stream, g, cshift);
-            else if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, true>), grid, block, 0, stream, g, cshift);
-            else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false>), grid, block, 0, stream, g, cshift);
+            if (g.a_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, 0, true>), grid, block, 0, stream, g, 1 << cshift);
+            else if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, true>), grid, block, 0, stream, g, 1 << cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false>), grid, block, 0, stream, g, 1 << cshift);
         } else if (dtype == 3) {
-            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, true>), grid, block, 0, stream, g, cshift);
-            else hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, false>), grid, block, 0, stream, g, cshift);
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, true>), grid, block, 0, stream, g, 1 << cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<kDtF32, false>), grid, block, 0, stream, g, 1 << cshift);
         } else if (dtype == 2) {
-            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<true, true>), grid, block, 0, stream, g, cshift);
-            else hipLaunchKernelGGL((conv3x3_256_kernel<true, false>), grid, block, 0, stream, g, cshift);
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<true, true>), grid, block, 0, stream, g, 1 << cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<true, false>), grid, block, 0, stream, g, 1 << cshift);
         } else {
-            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<false, true>), grid, block, 0, stream, g, cshift);
-            else hipLaunchKernelGGL((conv3x3_256_kernel<false, false>), grid, block, 0, stream, g, cshift);
+            if (relu_in) hipLaunchKernelGGL((conv3x3_256_kernel<false, true>), grid, block, 0, stream, g, 1 << cshift);
+            else hipLaunchKernelGGL((conv3x3_256_kernel<false, false>), grid, block, 0, stream, g, 1 << cshift);
         }
         VS_HIP(hipGetLastError());
         return 0;
@@ -1090,9 +1104,9 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
         static const int no128 = [] { const char *e = getenv("VS_CONV_SPLIT_NO256X128"); return e ? atoi(e) : 0; }();
         if (!no128 && cshift >= 0 && Cout % 128 == 0 && Cout % 256 != 0 && (9 * Cin / 64) % 2 == 0 && big >= 224) {   // (Cout = 256 maps too small for the 256 x 256 kernel: the 4-wave kernel is 8 % faster there, measured)
             dim3 grid((unsigned)(vs::cdiv64(M, 256) * (Cout / 128))), block(512);
-            if (g.a_packed) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false, true>), grid, block, 0, stream, g, cshift);
-            else if (relu_in) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<true, false>), grid, block, 0, stream, g, cshift);
-            else hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false>), grid, block, 0, stream, g, cshift);
+            if (g.a_packed) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false, true>), grid, block, 0, stream, g, 1 << cshift);
+            else if (relu_in) hipLaunchKernelGGL((conv3x3_256x128_split_kernel<true, false>), grid, block, 0, stream, g, 1 << cshift);
+            else hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, false>), grid, block, 0, stream, g, 1 << cshift);
             VS_HIP(hipGetLastError());
             return 0;
         }
@@ -1167,8 +1181,8 @@ extern "C" int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const floa
                  "vs_conv3x3_head1x1_nhwc: need C2pad in 16..96 (multiple of 16), ld2 >= C2pad, no relu_in (C2pad=%d ld2=%d)", C2pad, ld2);
         dim3 grid((unsigned)(M / 256)), block(512);
 #define VS_FUSE(NF_)                                                                                                        \
-        if (dtype == 2) hipLaunchKernelGGL((conv3x3_256_kernel<1, false, NF_>), grid, block, 0, stream, g, cshift);         \
-        else hipLaunchKernelGGL((conv3x3_256_kernel<0, false, NF_>), grid, block, 0, stream, g, cshift);
+        if (dtype == 2) hipLaunchKernelGGL((conv3x3_256_kernel<1, false, NF_>), grid, block, 0, stream, g, 1 << cshift);         \
+        else hipLaunchKernelGGL((conv3x3_256_kernel<0, false, NF_>), grid, block, 0, stream, g, 1 << cshift);
         switch (C2pad / 16) {
             case 1: VS_FUSE(1) break;
             case 2: VS_FUSE(2) break;
@@ -1212,9 +1226,9 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
     const bool tile128 = !no128 && cshift >= 0 && (9 * 2 * Cin / 64) % 2 == 0 && !relu_in;
     VS_CHECK(!in_packed || tile128, "vs_conv3x3_head_dot_split_nhwc: a packed input needs the 256 x 128 tile kernel (Cin in {32, 64, 128, 256}, no relu_in)");
     if (tile128 && in_packed)
-        hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, cshift);
+        hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, 1 << cshift);
     else if (tile128)
-        hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, cshift);
+        hipLaunchKernelGGL((conv3x3_256x128_split_kernel<false, true>), dim3((unsigned)(M / 256)), dim3(512), 0, stream, g, 1 << cshift);
     else
         hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8, true>), dim3((unsigned)(M / 256)), dim3(256), 0, stream, g);
     VS_HIP(hipGetLastError());
@@ -1245,8 +1259,8 @@ extern "C" int vs_conv3x3_head1x1_split_nhwc(const float *in, const void *wp, fl
                (const unsigned short *)w2p, bias2, (unsigned short *)out2, C2, C2pad, ld2, acc_scale, acc_scale2};
     dim3 grid((unsigned)(M / 256)), block(512);
     g.a_packed = in_packed;
-#define VS_HEAD(NF_) { if (in_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_, true>), grid, block, 0, stream, g, cshift); \
-                       else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_>), grid, block, 0, stream, g, cshift); }
+#define VS_HEAD(NF_) { if (in_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_, true>), grid, block, 0, stream, g, 1 << cshift); \
+                       else hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_>), grid, block, 0, stream, g, 1 << cshift); }
     switch (C2pad / 16) {
         case 1: VS_HEAD(1) break;
         case 2: VS_HEAD(2) break;
