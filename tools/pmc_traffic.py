@@ -11,7 +11,7 @@ HBM rate the kernel's duration allows).
 """
 import csv, json, sys, collections
 
-FAMILIES = [("gemm", ("gemm256_kernel", "gemm_kernel", "gemm_smallm_kernel", "gemm_skinny_split_kernel", "conv7x7_256_kernel")), ("conv3x3", ("conv3x3_256_kernel", "conv3x3_kernel")),
+FAMILIES = [("gemm", ("gemm256_kernel", "gemm_kernel", "gemm_smallm_kernel", "gemm_skinny_kernel", "conv7x7_256_kernel")), ("conv3x3", ("conv3x3_256_kernel", "conv3x3_kernel")),
             ("attention", ("attention_kernel", "attention_res_kernel", "attention_split_kernel", "attention_sp_kernel", "attention_f32_kernel")), ("rasterizer", ("preprocess_kernel", "scatter_kernel", "tile_scan_kernel", "tile_sort_kernel",
                                                                   "segment_sort_kernel", "render_kernel")),
             ("layernorm", ("layernorm_mod_kernel", "layernorm_rows_kernel")), ("upsample", ("upsample2x_kernel", "upsample2x_f32")), ("adapter", ("adapter_",))]

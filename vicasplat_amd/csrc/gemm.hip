@@ -331,8 +331,8 @@ __global__ void __launch_bounds__(64 * NW) gemm_smallm_kernel(const GemmArgs g) 
 // the K loop.  The partial tiles meet once in LDS; wave w then runs the shared epilogue on row fragment w, so every fused epilogue (GELU,
 // RoPE, packed output, gated f32 residual) is the tile kernels' code.  Epilogue 2 may also split K over blockIdx.z (atomics, as the tile
 // kernels' tails do) when N is too narrow to give the chip enough workgroups.
-template <int EPI>
-__global__ void __launch_bounds__(512) gemm_skinny_split_kernel(const GemmArgs g_in) {
+template <int BF16, int EPI>
+__global__ void __launch_bounds__(512) gemm_skinny_kernel(const GemmArgs g_in) {
     constexpr int NW = 8;                                                // waves = K slices of the workgroup (two per SIMD: twice the loads in flight)
     __shared__ __attribute__((aligned(16))) float red[4][4][16][64];   // [wave pair][row fragment][j * 4 + r][lane]: 64 KiB
     __shared__ __attribute__((aligned(16))) float2 rope_tab[64 * 16];  // gemm_epilogue<., 4>'s (sin, cos) table
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(512) gemm_skinny_split_kernel(const GemmArgs g
     const int kb_lo = ksp * kb_per_wg, kb_hi = min(kb_all, kb_lo + kb_per_wg);
     const int per = (kb_hi - kb_lo + NW - 1) / NW;
     const int kb0 = kb_lo + wid * per, kb1 = min(kb_hi, kb0 + per);
-    const bool apk = g.a_packed != 0;
+    const bool apk = BF16 != kDtSplit || g.a_packed != 0;    // (16-bit classes: rows are fragment-ready as they are; a block = two 32-wide k-steps)
     int kb = kb0;
     for (; kb + 2 <= kb1; kb += 2) {
         uint4 fa[2][4][2], fb[2][4][2];
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(512) gemm_skinny_split_kernel(const GemmArgs g
             for (int i = 0; i < 4; ++i) {
                 if (!apk) split8(fa[u][i][0], fa[u][i][1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma2<kDtSplit>(fb[u][j][0], fb[u][j][1], fa[u][i][0], fa[u][i][1], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma2<BF16>(fb[u][j][0], fb[u][j][1], fa[u][i][0], fa[u][i][1], acc[i][j]);
             }
     }
     for (; kb < kb1; ++kb) {
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(512) gemm_skinny_split_kernel(const GemmArgs g
         for (int i = 0; i < 4; ++i) {
             if (!apk) split8(fa[i][0], fa[i][1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mma2<kDtSplit>(fb[j][0], fb[j][1], fa[i][0], fa[i][1], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma2<BF16>(fb[j][0], fb[j][1], fa[i][0], fa[i][1], acc[i][j]);
         }
     }
     // ---- the eight K slices meet in two steps through one 64 KiB image: waves 4..7 hand their tiles to waves 0..3, which add them to
@@ -430,10 +430,11 @@ __global__ void __launch_bounds__(512) gemm_skinny_split_kernel(const GemmArgs g
             sum[0][j][r] = (red[0][wf][j * 4 + r][lane] + red[1][wf][j * 4 + r][lane]) + (red[2][wf][j * 4 + r][lane] + red[3][wf][j * 4 + r][lane]);
     if (ksp > 0) g.bias = nullptr;                      // split-K over workgroups: the bias belongs to slice 0
     g.ksplit = nks;                                     // > 1: the epilogue adds its (gated) partial sums into out with f32 atomics
-    gemm_epilogue<kDtSplit, EPI, 1>(g, sum, wid < 4 ? m0 + wid * 16 : g.M, n0, rope_tab, wid, lane);
+    gemm_epilogue<BF16, EPI, 1>(g, sum, wid < 4 ? m0 + wid * 16 : g.M, n0, rope_tab, wid, lane);
 }
 
-int launch_skinny_split(const GemmArgs &g, int epi, hipStream_t stream) {
+template <int BF16>
+int launch_skinny(const GemmArgs &g, int epi, hipStream_t stream) {
     const int rows = g.M - g.m_lo, gy = vs::cdiv(rows, 64), gx = vs::cdiv(g.N, 64);
     // epilogue 2 with the residual already in `out`: split K over workgroups while the grid is small and a slice keeps >= 8 blocks per wave
     int ks = 1;
@@ -441,11 +442,11 @@ int launch_skinny_split(const GemmArgs &g, int epi, hipStream_t stream) {
         while (ks < 8 && gx * gy * ks * 2 <= 384 && g.K / 64 / (ks * 2) >= 32) ks *= 2;
     dim3 grid(gx, gy, ks), block(512);
     switch (epi) {
-        case 0: hipLaunchKernelGGL(gemm_skinny_split_kernel<0>, grid, block, 0, stream, g); break;
-        case 1: hipLaunchKernelGGL(gemm_skinny_split_kernel<1>, grid, block, 0, stream, g); break;
-        case 2: hipLaunchKernelGGL(gemm_skinny_split_kernel<2>, grid, block, 0, stream, g); break;
-        case 3: hipLaunchKernelGGL(gemm_skinny_split_kernel<3>, grid, block, 0, stream, g); break;
-        case 4: hipLaunchKernelGGL(gemm_skinny_split_kernel<4>, grid, block, 0, stream, g); break;
+        case 0: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 0>), grid, block, 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 1>), grid, block, 0, stream, g); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 2>), grid, block, 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 3>), grid, block, 0, stream, g); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 4>), grid, block, 0, stream, g); break;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -674,9 +675,12 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     static const int tail_rows = [] { const char *e = getenv("VS_GEMM_TAIL_SMALLM"); return e ? atoi(e) : 64; }();
     // round 5: tails of 65 .. 256 rows of the split class run on the skinny kernel (every epilogue, packed A / packed output included)
     static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
-    if constexpr (BF16 == kDtSplit) {
+    if constexpr (BF16 == kDtSplit || BF16 == 0 || BF16 == 1) {   // (split class and, since late round 5, the 16-bit classes)
         // (<= 64 rows stay on the weight-streaming kernel where it applies; the RoPE epilogue and packed outputs, which it does not have, come here)
-        if (skinny && rem <= 256 && g.K % 64 == 0 && (rem > 64 || skinny == 2 || epi == 4 || g.out_packed)) { t.ksplit = 1; return launch_skinny_split(t, epi, stream); }
+        if (skinny && rem <= 256 && g.K % 64 == 0 && (rem > 64 || skinny == 2 || epi == 4 || g.out_packed) && (BF16 == kDtSplit || (!g.a_packed && !g.out_packed))) {
+            t.ksplit = 1;
+            return launch_skinny<BF16>(t, epi, stream);
+        }
     }
     if (rem <= (BF16 == kDtSplit ? tail_rows : 64) && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) {
         t.ksplit = 1;
@@ -699,9 +703,11 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
     if (g.M <= 64 && force == 0 && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) return launch_smallm<BF16>(g, epi, stream);
-    if constexpr (BF16 == kDtSplit) {   // camera-token GEMMs and other launches of <= 256 rows: the skinny kernel (round 5)
+    if constexpr (BF16 == kDtSplit || BF16 == 0 || BF16 == 1) {   // camera-token GEMMs and other launches of <= 256 rows: the skinny kernel (round 5)
         static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
-        if (skinny && force == 0 && g.M - g.m_lo <= 256 && g.K % 64 == 0 && g.ntaps == 0 && !g.partials && g.ksplit <= 1) return launch_skinny_split(g, epi, stream);
+        if (skinny && force == 0 && g.M - g.m_lo <= 256 && g.K % 64 == 0 && g.ntaps == 0 && !g.partials && g.ksplit <= 1 && g.a_sup_extra == 0 && g.a_kstride == 32 &&
+            (BF16 == kDtSplit || (!g.a_packed && !g.out_packed)))
+            return launch_skinny<BF16>(g, epi, stream);
     }
     if (force == 8) return launch_mi<BF16, 8>(g, epi, stream);
     if (force == 4) return launch_mi<BF16, 4>(g, epi, stream);
