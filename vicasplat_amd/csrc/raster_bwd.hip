@@ -271,6 +271,8 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
     constexpr int kCamChunk = 2048;
     __shared__ int cams[kCamChunk];
     __shared__ int ncam_s;
+    constexpr int kParCams = 32, kParStride = 40;
+    __shared__ __attribute__((aligned(16))) float cpar[kParCams * kParStride];
     for (int cbase = 0; cbase < in.num_cameras; cbase += kCamChunk) {
       __syncthreads();
       if (threadIdx.x < 64) {
@@ -288,14 +290,42 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
       }
       __syncthreads();
       const int ncam = ncam_s;
+      {   // camera parameters of the first kParCams cameras, staged once per block (as in the forward's preprocess_kernel, round 5: the
+          // kernel argument is a struct of pointers, so the compiler fetched them with vector loads in every camera iteration)
+          const int nst = min(ncam, kParCams);
+          for (int e = threadIdx.x; e < nst * kParStride; e += 256) {
+              const int kk = e / kParStride, q = e - kk * kParStride, cc = cams[kk];
+              float v = 0.f;
+              if (q < 16) v = in.viewmatrix[16 * cc + q];
+              else if (q < 32) v = in.projmatrix[16 * cc + q - 16];
+              else if (q < 35) v = in.campos[3 * cc + q - 32];
+              else if (q < 37) v = in.tanfov[2 * cc + q - 35];
+              cpar[e] = v;
+          }
+          __syncthreads();
+      }
       for (int kc = 0; kc < ncam; ++kc) {
-        const int c = __builtin_amdgcn_readfirstlane(cams[kc]);   // wave-uniform: scalar loads of the camera matrices
+        const int c = __builtin_amdgcn_readfirstlane(cams[kc]);   // wave-uniform
         const size_t ci = (size_t)c * P + (live ? i : 0);
         float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live && radii[ci] > 0) {
-            const float *__restrict__ vm = in.viewmatrix + 16 * c;
-            const float *__restrict__ pm = in.projmatrix + 16 * c;
-            const float tanfovx = in.tanfov[2 * c], tanfovy = in.tanfov[2 * c + 1];
+            float vm[16], pm[16], cp[3], tanfovx, tanfovy;
+            if (kc < kParCams) {                                  // (wave-uniform) LDS broadcast reads
+                const float4 *q4 = reinterpret_cast<const float4 *>(cpar + kc * kParStride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 a4 = q4[j], b4 = q4[4 + j];
+                    vm[4 * j] = a4.x; vm[4 * j + 1] = a4.y; vm[4 * j + 2] = a4.z; vm[4 * j + 3] = a4.w;
+                    pm[4 * j] = b4.x; pm[4 * j + 1] = b4.y; pm[4 * j + 2] = b4.z; pm[4 * j + 3] = b4.w;
+                }
+                const float4 c4 = q4[8], d4 = q4[9];
+                cp[0] = c4.x; cp[1] = c4.y; cp[2] = c4.z; tanfovx = c4.w; tanfovy = d4.x;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { vm[j] = in.viewmatrix[16 * c + j]; pm[j] = in.projmatrix[16 * c + j]; }
+                cp[0] = in.campos[3 * c]; cp[1] = in.campos[3 * c + 1]; cp[2] = in.campos[3 * c + 2];
+                tanfovx = in.tanfov[2 * c]; tanfovy = in.tanfov[2 * c + 1];
+            }
             const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
             const float *__restrict__ r = grec + ci * kG;
             const float g2x = r[0], g2y = r[1], gA = r[2], gB = r[3], gC = r[4];
@@ -386,7 +416,6 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
             if (!has_sh) {
                 g_cp[0] += gcol[0]; g_cp[1] += gcol[1]; g_cp[2] += gcol[2];
             } else {
-                const float *__restrict__ cp = in.campos + 3 * c;
                 const float dxo = px - cp[0], dyo = py - cp[1], dzo = pz - cp[2];
                 const float len = sqrtf(dxo * dxo + dyo * dyo + dzo * dzo);
                 const float x = dxo / len, y = dyo / len, z = dzo / len;
