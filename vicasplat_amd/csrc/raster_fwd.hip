@@ -623,8 +623,7 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
         __shared__ unsigned s_mn, s_mx;
         if (tid == 0) { s_mn = ~0u; s_mx = 0u; }
         for (int k = tid; k < kBuckets; k += 256) bcur[k] = 0;
-        __syncthreads();
-        // Round 5: the depth range comes from a strided SAMPLE of 256 keys (one key per thread) instead of a pass over the whole list, padded
+        // Round 5: the depth range of a list longer than 8192 keys comes from the keys a thread holds plus a strided SAMPLE of 256 keys, padded
         // by 1/32 of itself on both sides; keys outside it land in the first / last bucket (the bucket function stays monotone, so the
         // result is the same exact sort -- only the balance of the buckets depends on the sample; a list whose tails pile up takes the
         // fat / clustered routes below like any other piled-up list).  And the keys are read ONCE: a thread keeps its first kKeep keys
@@ -632,17 +631,29 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
         // reads of the list from HBM (min / max, histogram, scatter): 8.7 GB of the forward's 39.8 GB on the bench step.  (Measured and not
         // kept: 16 kept keys and 72 VGPRs for six instead of four workgroups per CU -- 1.92 -> 2.63 ms: more lists in flight than L2 holds.)
         constexpr int kKeep = 32;
-        unsigned mn, mx;
-        {
+        // the key loads go out FIRST (32 per thread in flight under the setup above); the range is then taken from the registers -- exact
+        // for lists up to 8192 keys -- plus, for longer lists, the strided sample of the rest: one dependent memory round trip less
+        unsigned long long kreg[kKeep];
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) {
+            const int i = tid + j * 256;
+            kreg[j] = i < n ? a[i] : 0ull;
+        }
+        unsigned mn = ~0u, mx = 0u;
+        if (n > kKeep * 256) {
             const unsigned hi = (unsigned)(a[(int)(((long long)tid * n) >> 8)] >> 32);
             mn = mx = hi;
         }
 #pragma unroll
+        for (int j = 0; j < kKeep; ++j)
+            if (tid + j * 256 < n) { const unsigned hi = (unsigned)(kreg[j] >> 32); mn = min(mn, hi); mx = max(mx, hi); }
+#pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64)); }
+        __syncthreads();                       // s_mn / s_mx initialised, bcur zeroed
         if (lane == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
         __syncthreads();
         {
-            const unsigned pad = ((s_mx - s_mn) >> 5) + 1u;
+            const unsigned pad = n > kKeep * 256 ? ((s_mx - s_mn) >> 5) + 1u : 0u;     // (sampled ranges only)
             mn = s_mn > pad ? s_mn - pad : 0u;
             mx = s_mx < 0xffffffffu - pad ? s_mx + pad : 0xffffffffu;
         }
@@ -652,12 +663,6 @@ tile_sort_kernel(const int2 *__restrict__ ranges, unsigned long long *__restrict
             const unsigned hi = (unsigned)(key >> 32);
             return hi <= mn ? 0 : (int)min((hi - mn) >> shift, (unsigned)(kBuckets - 1));
         };
-        unsigned long long kreg[kKeep];
-#pragma unroll
-        for (int j = 0; j < kKeep; ++j) {
-            const int i = tid + j * 256;
-            kreg[j] = i < n ? a[i] : 0ull;
-        }
 #pragma unroll
         for (int j = 0; j < kKeep; ++j)
             if (tid + j * 256 < n) atomicAdd(&bcur[bucket_of(kreg[j])], 1);
