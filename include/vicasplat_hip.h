@@ -491,6 +491,19 @@ int vs_gated_resid_f32(const float *x, const float *y, int64_t ldy, const float 
 int vs_gated_resid_backward_f32(const float *dout, const float *y, int64_t ldy, const float *gate, int32_t gate_rows, float *dy, int64_t lddy,
                                 float *dgate, int32_t M, int32_t C, int32_t grp_in, int32_t grp_out, int32_t grp_off, vs_stream_t stream);
 int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg, int32_t H, int32_t W, int32_t C, vs_stream_t stream);
+/* Backward of the LAST 1x1 convolution of a DPT head fused with the ReLU backward of its input (split class, one pass over the full-resolution
+ * tensors): t = relu(conv3x3(...)) [P, Cin], y = t W^T + b [P, Cout] (heads/dpt_block.py:316-343 head.2 -> head.4; dpt_gs_head.py:120-157) ->
+ *   dt[p, c] = (relu ? t[p, c] > 0 : 1) * sum_n dy[p, n] W[n, c]      dW[n, c] = sum_p dy[p, n] t[p, c]      db[n] = sum_p dy[p, n]
+ * dy [P, Cout] f32 with row stride ldy (Cout <= ldy <= 128; padding columns are not read as data), t [P, Cin], dt [P, Cin] f32 contiguous, all 16-byte aligned, W [Cout, Cin] f32 (the module's parameter, packed in the kernel
+ * with scale 2^w_scale_exp).  Cin = 128 | 256, Cout <= 96, P % 32 == 0.  nwg persistent workgroups; dW / db leave as per-workgroup partial
+ * sums dw_part [nwg, R, Cin], db_part [nwg, R] (R = 96 if Cout > 16 else 16; rows >= Cout are padding) which the caller adds up --
+ * deterministic.  Replaces autograd's nn.Conv2d(k=1) backward + the ReLU backward of the reference's training step (model_wrapper.py:207-230). */
+int vs_head1x1_backward_split(const float *dy, int64_t ldy, const float *t, const float *w, int32_t w_scale_exp, float *dt, float *dw_part,
+                              float *db_part, int64_t P, int32_t Cin, int32_t Cout, int32_t relu, int32_t nwg, vs_stream_t stream);
+/* The same in the 16-bit operand classes: dy [P, Cout] (row stride ldy elements), t, dt [P, Cin] f16 (dtype 1) or bf16 (2), W f32
+ * (converted in the kernel), dw_part / db_part f32 as above. */
+int vs_head1x1_backward16(const void *dy, int64_t ldy, const void *t, const float *w, void *dt, float *dw_part, float *db_part, int64_t P,
+                          int32_t Cin, int32_t Cout, int32_t relu, int32_t nwg, int32_t dtype, vs_stream_t stream);
 
 /* Measurement aid of bench.py (`roofline.sustained_mfma_tflops`): back-to-back v_mfma_f32_16x16x32_f16 on register operands filled from
  * `operands` (>= 1 MiB of f16 data), no memory traffic in the loop, 512 workgroups x 4 waves x iters x 16 MFMAs; scratch >= 131072 floats.

@@ -367,3 +367,87 @@ def test_split_training_backward_tight_against_float64_autograd():
             "gaussian_param_head.dpt.head.4.bias", "camera_extrinsic_head.1.weight", "camera_extrinsic_head.1.bias"]
     print("           | right behind the loss:", {k.split(".dpt.")[-1]: f"{mx[k]:.1e}" for k in near})
     assert max(mx[k] for k in near) <= 1e-5
+
+
+@pytest.mark.parametrize("P,Cin,Cout,relu", [(64, 256, 83, True), (32 * 700, 256, 83, True), (4096, 128, 3, True), (4096, 128, 4, True),
+                                             (2048, 128, 83, False), (2048, 256, 16, True), (32 * 999, 256, 96, True)])
+def test_head1x1_backward_split_matches_float64(P, Cin, Cout, relu):
+    """vs_head1x1_backward_split (csrc/head_bwd.hip): dt = (t > 0) * (dy W), dW = dy^T t, db = column sums of dy in ONE pass over dy and t --
+    against float64 on the same f32 inputs; the mask is exact (taken from the f32 t, zeros and tiny positives included)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(P + Cin + Cout)
+    t = torch.randn(P, Cin, generator=g).clamp_min(0)
+    t[0, :8] = torch.tensor([0.0, 1e-30, 1e-9, -0.0, 3e-8, 6e-8, 1.0, 0.0])        # mask edge cases: +0 / -0 off, any positive on
+    dy = torch.randn(P, Cout, generator=g) * 0.25
+    w = torch.randn(Cout, Cin, generator=g) * 0.05
+    t, dy, w = t.to(d), dy.to(d), w.to(d)
+    e = ops.split_scale_exp(w)
+    dt, dw, db = ops.head1x1_backward_split(dy, t, w, relu=relu, scale_exp=e)
+    want_dt = dy.double() @ w.double()
+    if relu:
+        want_dt = want_dt * (t > 0)
+        assert torch.equal(dt == 0, ~(t > 0) | (want_dt == 0).to(dt.device))
+    assert _rel(dt, want_dt) <= TOL
+    assert _rel(dw, dy.double().t() @ t.double()) <= TOL
+    assert _rel(db, dy.double().sum(0)) <= TOL
+    # deterministic: per-workgroup partials summed in a fixed order
+    dt2, dw2, db2 = ops.head1x1_backward_split(dy, t, w, relu=relu, scale_exp=e)
+    assert torch.equal(dt, dt2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(256, 83), (128, 3)])
+def test_head_tail_fn_equals_the_operator_route(Cin, Cout):
+    """HeadTailSplitFn behind Conv3x3Fn(relu_out=True) gives the gradients of the operator-by-operator route (linear_split + the
+    convolution's own ReLU backward): same forward bits, backward to the split class's rounding, and the convolution skips its mask."""
+    from vicasplat_amd import autograd as A, ops
+    d = _dev()
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(2, 16, 32, Cin, generator=g).to(d).requires_grad_(True)
+    w3 = (torch.randn(Cin, Cin, 3, 3, generator=g) * 0.02).to(d).requires_grad_(True)
+    w1 = (torch.randn(Cout, Cin, generator=g) * 0.05).to(d).requires_grad_(True)
+    b1 = torch.randn(Cout, generator=g).to(d).requires_grad_(True)
+    gy = torch.randn(2, 16, 32, Cout, generator=g).to(d)
+    outs = []
+    calls = []
+    orig = ops.relu_mask
+    ops.relu_mask = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        for fused in (False, True):
+            for p_ in (x, w3, w1, b1):
+                p_.grad = None
+            t = A.conv3x3(x, w3, None, relu_out=True)
+            assert A.head_tail_ok(t, w1)
+            y = A.HeadTailSplitFn.apply(t, w1, b1) if fused else A.linear_split(t, w1, b1)
+            n0 = len(calls)
+            (y * gy).sum().backward()
+            assert len(calls) - n0 == (0 if fused else 1)
+            outs.append((y.detach().clone(), x.grad.clone(), w3.grad.clone(), w1.grad.clone(), b1.grad.clone()))
+    finally:
+        ops.relu_mask = orig
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a_, b_ in zip(outs[0][1:], outs[1][1:]):
+        assert _rel(b_, a_) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("P,Cin,Cout,ldy", [(32 * 300, 256, 83, 88), (4096, 128, 3, 8), (2048, 128, 4, 4), (2048, 256, 83, 83)])
+def test_head1x1_backward_16bit_classes(dtype, P, Cin, Cout, ldy):
+    """The 16-bit instantiations of csrc/head_bwd.hip (one MFMA per product) on row-padded gradients (the adapter's backward writes 16-byte
+    aligned rows; the padding holds garbage here and must not be read as data): against float64 on the same 16-bit inputs."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(P + Cin + Cout + ldy)
+    t = torch.randn(P, Cin, generator=g).clamp_min(0).to(dtype).to(d)
+    buf = torch.full((P, ldy), float("nan"), dtype=dtype)
+    buf[:, :Cout] = (torch.randn(P, Cout, generator=g) * 0.25).to(dtype)
+    buf = buf.to(d)
+    dy = buf[:, :Cout]
+    w = (torch.randn(Cout, Cin, generator=g) * 0.05).to(d)
+    dt, dw, db = ops.head1x1_backward(dy, t, w, relu=True)
+    w16 = w.to(dtype).double()
+    want_dt = (dy.double() @ w16) * (t > 0)
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert dt.dtype == dtype and bool((dt[~(t > 0)] == 0).all())        # (f16 results below 2^-25 round to zero: no exact zero-pattern check)
+    assert _rel(dt, want_dt) <= eps
+    assert _rel(dw, dy.double().t() @ t.double()) <= 1e-5 and _rel(db, dy.double().sum(0)) <= 1e-5

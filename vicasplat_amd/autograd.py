@@ -298,6 +298,81 @@ def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], ro
     return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources))
 
 
+def _tail_dy(dy, N, dtype):
+    """The incoming gradient as [P, N] rows the fused kernel reads in place: unit column stride, a 16-byte aligned base, row stride <= 128
+    elements (the adapter's backward pads its rows for alignment: the padding is skipped, not copied away)."""
+    dy2 = dy.reshape(-1, N)
+    if dy2.dtype != dtype:
+        dy2 = dy2.to(dtype)
+    if dy2.stride(1) != 1 or dy2.data_ptr() % 16 != 0 or not (N <= dy2.stride(0) <= 128):
+        dy2 = dy2.contiguous()
+    return dy2
+
+
+class HeadTailSplitFn(torch.autograd.Function):
+    """y = t @ w^T + b for the LAST 1x1 convolution of a DPT head whose input t is the output of a ReLU (Conv3x3Fn(..., relu_out=True)), split
+    class.  Forward = LinearSplitFn's GEMM; backward = ONE fused pass (ops.head1x1_backward, csrc/head_bwd.hip): dt comes back ALREADY
+    masked by t > 0 -- the producer's ReLU backward, which Conv3x3Fn.backward then skips (`_vs_relu_masked`) -- with dw and db from the same
+    read of dy and t.  Only valid behind a ReLU (where t == 0 the producer's own backward would zero the gradient anyway)."""
+
+    @staticmethod
+    def forward(ctx, t, w, b):
+        K, N = t.shape[-1], w.shape[0]
+        t2 = t.reshape(-1, K)
+        e = LinearSplitFn._scale_exp(w)
+        ctx.scale_exp = e
+        wp = ops.split_pack_weight(LinearSplitFn._pad32(w.detach().float(), 1), e)
+        y = torch.empty((t2.shape[0], N), dtype=torch.float32, device=t.device)
+        ops.gemm(t2, wp, None if b is None else b.detach().float().contiguous(), y, ops.EPI_STORE32)
+        ctx.save_for_backward(t2, w)
+        ctx.meta = (t.shape, b is not None)
+        return y.view(*t.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t2, w = ctx.saved_tensors
+        tshape, has_b = ctx.meta
+        dt, dw, db = ops.head1x1_backward(_tail_dy(dy, w.shape[0], torch.float32), t2, w.detach().float().contiguous(), relu=True,
+                                          scale_exp=ctx.scale_exp)
+        dt = dt.view(tshape)
+        dt._vs_relu_masked = True      # Conv3x3Fn.backward: the trailing ReLU's mask is already applied
+        return dt, dw, (db if has_b else None)
+
+
+class HeadTail16Fn(torch.autograd.Function):
+    """HeadTailSplitFn in the 16-bit operand classes (f16 / bf16 activations, one MFMA per product): LinearFn's forward GEMM, the fused backward."""
+
+    @staticmethod
+    def forward(ctx, t, w, b, dt):
+        K = t.shape[-1]
+        t2 = t.reshape(-1, K)
+        w16 = w.detach().to(dt).contiguous()
+        y = torch.empty((t2.shape[0], w16.shape[0]), dtype=dt, device=t.device)
+        ops.gemm(t2, w16, None if b is None else b.detach().float().contiguous(), y, ops.EPI_STORE16)
+        ctx.save_for_backward(t2, w)
+        ctx.meta = (t.shape, b is not None)
+        return y.view(*t.shape[:-1], w16.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        t2, w = ctx.saved_tensors
+        tshape, has_b = ctx.meta
+        dt, dw, db = ops.head1x1_backward(_tail_dy(dy, w.shape[0], t2.dtype), t2, w.detach().float().contiguous(), relu=True)
+        dt = dt.view(tshape)
+        dt._vs_relu_masked = True
+        return dt, dw, (db if has_b else None), None
+
+
+def head_tail_ok(t: torch.Tensor, w: torch.Tensor) -> bool:
+    """Shapes csrc/head_bwd.hip serves: [.., Cin] contiguous rows (f32 = split class, f16, bf16), Cin 128 | 256, Cout <= 96, pixels a multiple of 32."""
+    return (t.dtype in (torch.float32, torch.float16, torch.bfloat16) and t.is_contiguous() and t.shape[-1] in (128, 256) and w.shape[0] <= 96
+            and w.shape[1] == t.shape[-1] and (t.numel() // t.shape[-1]) % 32 == 0)
+
+
+def head_tail(t: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt) -> torch.Tensor:
+    return HeadTailSplitFn.apply(t, w, b) if dt == SPLIT else HeadTail16Fn.apply(t, w, b, dt)
+
+
 def clear_split_caches() -> None:
     """Forget the cached power-of-two weight exponents of the split class (call after overwriting parameter VALUES in place by hand;
     load_state_dict on a VicaSplat does it by itself)."""
@@ -447,8 +522,8 @@ class Conv3x3Fn(torch.autograd.Function):
         x, wp, y = ctx.saved_tensors
         relu_in, has_b, stride, has_res, split = ctx.meta
         dy = dy.contiguous()
-        if y is not None:                                  # trailing ReLU: gradient only where the output is positive
-            dy = ops.relu_mask(dy, y)
+        if y is not None and not getattr(dy, "_vs_relu_masked", False):   # trailing ReLU: gradient only where the output is positive
+            dy = ops.relu_mask(dy, y)                                     # (HeadTailSplitFn hands its input gradient over masked)
         dres = dy if has_res else None
         if stride != 1:
             full = torch.zeros(x.shape[:3] + (dy.shape[3],), dtype=dy.dtype, device=dy.device)

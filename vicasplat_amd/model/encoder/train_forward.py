@@ -11,6 +11,8 @@ First version of the training path: correct and kernel-backed
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 import torch.utils.checkpoint
@@ -18,6 +20,7 @@ import torch.utils.checkpoint
 from ... import autograd as A
 
 LN_EPS = 1e-6
+_HEAD_TAIL = os.environ.get("VS_HEAD_TAIL", "1") != "0"      # 0: the operator-by-operator backward of the heads' last 1x1 convolution (A/B runs)
 
 
 def _ln_f32(P, name, x):
@@ -148,6 +151,12 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     def conv1x1(name, t):
         return A.linear(t, P[name + ".weight"].flatten(1), P.get(name + ".bias"), dt)
 
+    def conv1x1_tail(name, t):              # the head's last 1x1 convolution behind a ReLU: one fused backward pass (csrc/head_bwd.hip)
+        w = P[name + ".weight"].flatten(1)
+        if _HEAD_TAIL and A.head_tail_ok(t, w) and t.dtype == adt:
+            return A.head_tail(t, w, P.get(name + ".bias"), dt)
+        return conv1x1(name, t)
+
     def convT(name, t, k):                                       # ConvTranspose2d(kernel = stride = k): a GEMM + depth-to-space
         w = P[name + ".weight"]                                  # [Cin, Cout, k, k]
         Cout = w.shape[1]
@@ -202,7 +211,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     t = trunk(pre)
     t = A.conv3x3(t, P[pre + ".head.0.weight"], P[pre + ".head.0.bias"])
     t = A.conv3x3(up2(t), P[pre + ".head.2.weight"], P[pre + ".head.2.bias"], relu_out=True)
-    pts16 = conv1x1(pre + ".head.4", t)                                                              # [BT,H,W,3 | 4]: xyz (| confidence logit)
+    pts16 = conv1x1_tail(pre + ".head.4", t)                                                              # [BT,H,W,3 | 4]: xyz (| confidence logit)
     # predict_conf (distill.yaml:24): confidence = 1 + exp(x) on the fourth channel (postprocess.py:17-18,66-75); element-wise glue in torch
     conf = (1.0 + torch.exp(pts16[..., 3].float())).unflatten(0, (B, V)) if pts16.shape[-1] == 4 else None
 
@@ -218,7 +227,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     pre = "gaussian_param_head.dpt"
     t = A.upsample2x_add_relu(trunk(pre), stem7x7(pre + ".input_merger.0", frames))             # up2(trunk) + relu(stem), one launch
     t = A.conv3x3(t, P[pre + ".head.0.weight"], None, relu_out=True)
-    gs16 = conv1x1(pre + ".head.4", t)                                                               # [BT,H,W,8+3*d_sh] 16-bit
+    gs16 = conv1x1_tail(pre + ".head.4", t)                                                               # [BT,H,W,8+3*d_sh] 16-bit
 
     # ---------------- 'exp' depth post-process (postprocess.py:46-56) + raw_gaussians concat (vicasplat.py:256) + Gaussian adapter
     # (common/gaussian_adapter.py:168-212): ONE fused HIP kernel per direction on the heads' 16-bit NHWC outputs ----------------

@@ -1231,6 +1231,41 @@ def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *,
     return dx, dw, db
 
 
+def head1x1_backward(dy: torch.Tensor, t: torch.Tensor, w: torch.Tensor, *, relu: bool = True, scale_exp: int = 0):
+    """Backward of y = t @ w^T + b (the last 1x1 convolution of a DPT head) fused with the ReLU backward of t = relu(...), ONE pass over the
+    full-resolution tensors (csrc/head_bwd.hip).  dy [P, Cout] (row stride >= Cout allowed: aligned rows of the adapter's backward), t [P, Cin]
+    contiguous, both f32 (split class: three f16 MFMAs per product, w packed with 2^scale_exp) or both f16 / bf16; w [Cout, Cin] f32 ->
+    dt [P, Cin] = (t > 0) * (dy @ w) in t's dtype, dw [Cout, Cin] = dy^T t and db [Cout] in f32 (per-workgroup partials summed here)."""
+    dev = L.require_device(dy, t, w)
+    P, Cout = dy.shape
+    Cin = t.shape[1]
+    assert dy.dtype == t.dtype and w.dtype == torch.float32 and dy.stride(1) == 1 and t.is_contiguous() and w.is_contiguous()
+    assert t.shape[0] == P and w.shape == (Cout, Cin) and P % 32 == 0 and Cin in (128, 256) and 1 <= Cout <= 96
+    split = dy.dtype == torch.float32
+    ldy = dy.stride(0)
+    assert Cout <= ldy <= 128 and dy.data_ptr() % 16 == 0
+    rows = 96 if Cout > 16 else 16
+    per_cu = 2 if (Cin == 128 and Cout <= 16) else 1        # resident workgroups per CU (101 / 206 VGPRs x 8 waves)
+    nwg = max(1, min(P // 32, per_cu * torch.cuda.get_device_properties(dev).multi_processor_count))
+    dt = torch.empty_like(t)
+    dw_part = torch.empty((nwg, rows, Cin), dtype=torch.float32, device=dev)
+    db_part = torch.empty((nwg, rows), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if split:
+            rc = L.lib().vs_head1x1_backward_split(L.ptr(dy), ldy, L.ptr(t), L.ptr(w), int(scale_exp), L.ptr(dt), L.ptr(dw_part), L.ptr(db_part), P, Cin,
+                                                   Cout, int(relu), nwg, L.stream_ptr(dev))
+        else:
+            rc = L.lib().vs_head1x1_backward16(L.ptr(dy), ldy, L.ptr(t), L.ptr(w), L.ptr(dt), L.ptr(dw_part), L.ptr(db_part), P, Cin, Cout, int(relu),
+                                               nwg, _DTX[dy.dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_head1x1_backward")
+    return dt, dw_part.sum(0)[:Cout].contiguous(), db_part.sum(0)[:Cout].contiguous()
+
+
+def head1x1_backward_split(dy, t, w, *, relu: bool = True, scale_exp: int = 0):
+    assert dy.dtype == torch.float32
+    return head1x1_backward(dy, t, w, relu=relu, scale_exp=scale_exp)
+
+
 def attention_backward_split(qkv_q: torch.Tensor, qkv_k: torch.Tensor, qkv_v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, *,
                              nbatch: int, H: int, Lq: int, Lk: int = 0, q_batch_rows: int, k_batch_rows: int = 0,
                              kv_seg: Optional[torch.Tensor] = None, q_kvlen: Optional[torch.Tensor] = None, max_keys: int = 0, scale: float = 0.125,
