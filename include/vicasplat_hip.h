@@ -500,6 +500,13 @@ int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg,
  * deterministic.  Replaces autograd's nn.Conv2d(k=1) backward + the ReLU backward of the reference's training step (model_wrapper.py:207-230). */
 int vs_head1x1_backward_split(const float *dy, int64_t ldy, const float *t, const float *w, int32_t w_scale_exp, float *dt, float *dw_part,
                               float *db_part, int64_t P, int32_t Cin, int32_t Cout, int32_t relu, int32_t nwg, vs_stream_t stream);
+/* Weight (and bias) gradient of a 3x3 convolution (stride 1, pad 1), split class, as ONE streaming pass over x [N,H,W,Cin] and dy [N,H,W,Cout]
+ * (f32 NHWC as they are: no transposed / bordered copies) for the narrow layers of the DPT heads (heads/dpt_block.py:316-343; Cin, Cout multiples of
+ * 64, W a multiple of 32): dw_part [workers, 9, Cin, Cout] (tap = ky * 3 + kx), db_part [workers, Cout] = per-worker partial sums the caller adds
+ * up (deterministic); relu_in = the convolution read relu(x).  workers: a multiple of 8; the launch has workers * (Cin / 64) * (Cout / 64)
+ * persistent workgroups -- choose it so that they are all resident (one per CU). */
+int vs_conv3x3_wgrad_split_stream(const float *x, const float *dy, float *dw_part, float *db_part, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                  int32_t Cout, int32_t relu_in, int32_t workers, vs_stream_t stream);
 /* The same in the 16-bit operand classes: dy [P, Cout] (row stride ldy elements), t, dt [P, Cin] f16 (dtype 1) or bf16 (2), W f32
  * (converted in the kernel), dw_part / db_part f32 as above. */
 int vs_head1x1_backward16(const void *dy, int64_t ldy, const void *t, const float *w, void *dt, float *dw_part, float *db_part, int64_t P,

@@ -451,3 +451,25 @@ def test_head1x1_backward_16bit_classes(dtype, P, Cin, Cout, ldy):
     assert dt.dtype == dtype and bool((dt[~(t > 0)] == 0).all())        # (f16 results below 2^-25 round to zero: no exact zero-pattern check)
     assert _rel(dt, want_dt) <= eps
     assert _rel(dw, dy.double().t() @ t.double()) <= 1e-5 and _rel(db, dy.double().sum(0)) <= 1e-5
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,relu", [(1, 1, 32, 64, 64, False), (2, 5, 64, 128, 128, False), (3, 7, 32, 256, 128, True), (2, 3, 96, 128, 64, True),
+                                                 (9, 4, 64, 64, 192, False)])
+def test_conv3x3_wgrad_split_stream_matches_float64(N, H, W, Cin, Cout, relu):
+    """vs_conv3x3_wgrad_split_stream (csrc/conv_wgrad_stream.hip): dW and db of a 3x3 convolution in one pass over X and dY as they are, against
+    float64 autograd of F.conv2d on the same f32 inputs (image borders, strips of a row, several images per worker, relu_in)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(N * 1000 + H * 100 + W + Cin + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    dy = (torch.randn(N, H, W, Cout, generator=g) * 0.5).to(d)
+    dw9, db = ops.conv3x3_wgrad_split_stream(dy, x, relu_in=relu)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, device=d, requires_grad=True)
+    xin = x.double().permute(0, 3, 1, 2)
+    y = F.conv2d(xin.clamp_min(0) if relu else xin, w, None, padding=1)
+    (y * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    want = w.grad.permute(2, 3, 1, 0).reshape(9, Cin, Cout)        # [ky, kx, ci, co]
+    assert _rel(dw9, want) <= TOL
+    assert _rel(db, dy.double().sum((0, 1, 2))) <= TOL
+    dw9b, dbb = ops.conv3x3_wgrad_split_stream(dy, x, relu_in=relu)
+    assert torch.equal(dw9, dw9b) and torch.equal(db, dbb)

@@ -157,15 +157,24 @@ colsum16_kernel(const unsigned short *__restrict__ x, long long ld, float *__res
     const int c = blockIdx.x * 128 + cg * 8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < N) {
-        for (int m = blockIdx.y * 16 + rl; m < M; m += gridDim.y * 16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(x + (long long)m * ld + c);
+        // four rows per trip: four independent 16-byte loads in flight per thread (one per trip ran at 2.75 TB/s: 12 ms of column sums per
+        // 24-scene f16 training step)
+        const long long step = (long long)gridDim.y * 16;
+        long long m = blockIdx.y * 16 + rl;
+        auto add = [&](const uint4 v) {
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 s[2 * k] += ld16<BF16>((unsigned short)(w[k] & 0xffffu));
                 s[2 * k + 1] += ld16<BF16>((unsigned short)(w[k] >> 16));
             }
+        };
+        for (; m + 3 * step < M; m += 4 * step) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(x + m * ld + c), v1 = *reinterpret_cast<const uint4 *>(x + (m + step) * ld + c);
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(x + (m + 2 * step) * ld + c), v3 = *reinterpret_cast<const uint4 *>(x + (m + 3 * step) * ld + c);
+            add(v0); add(v1); add(v2); add(v3);
         }
+        for (; m < M; m += step) add(*reinterpret_cast<const uint4 *>(x + m * ld + c));
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) part[rl][cg * 8 + k] = s[k];
@@ -187,8 +196,16 @@ colsum32_kernel(const float *__restrict__ x, long long ld, float *__restrict__ o
     const int c = blockIdx.x * 128 + cg * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < N) {
-        for (int m = blockIdx.y * 8 + rl; m < M; m += gridDim.y * 8) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + (long long)m * ld + c);
+        const long long step = (long long)gridDim.y * 8;
+        long long m = blockIdx.y * 8 + rl;
+        for (; m + 3 * step < M; m += 4 * step) {      // four independent loads in flight (see colsum16_kernel)
+            const float4 v0 = *reinterpret_cast<const float4 *>(x + m * ld + c), v1 = *reinterpret_cast<const float4 *>(x + (m + step) * ld + c);
+            const float4 v2 = *reinterpret_cast<const float4 *>(x + (m + 2 * step) * ld + c), v3 = *reinterpret_cast<const float4 *>(x + (m + 3 * step) * ld + c);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; m < M; m += step) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + m * ld + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }

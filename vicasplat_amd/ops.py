@@ -1303,6 +1303,29 @@ def attention_backward_split(qkv_q: torch.Tensor, qkv_k: torch.Tensor, qkv_v: to
     return dq, dk, dv
 
 
+_WGRAD_STREAM = os.environ.get("VS_WGRAD_STREAM", "1") != "0"
+
+
+def conv3x3_wgrad_split_stream(dy: torch.Tensor, x: torch.Tensor, *, relu_in: bool = False):
+    """dw9 [9, Cin, Cout] (tap = ky * 3 + kx) and db [Cout] of a 3x3 convolution (stride 1, pad 1) from x [N,H,W,Cin] and dy [N,H,W,Cout] f32 NHWC,
+    split class, one streaming pass (vs_conv3x3_wgrad_split_stream); Cin, Cout multiples of 64, W a multiple of 32."""
+    dev = L.require_device(dy, x)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert dy.dtype == x.dtype == torch.float32 and dy.is_contiguous() and x.is_contiguous() and dy.shape[:3] == x.shape[:3]
+    assert Cin % 64 == 0 and Cout % 64 == 0 and W % 32 == 0
+    nblk = (Cin // 64) * (Cout // 64)
+    items = N * (W // 32)
+    workers = max(8, min(torch.cuda.get_device_properties(dev).multi_processor_count // nblk, (items + 7) // 8 * 8) // 8 * 8)
+    dw_part = torch.empty((workers, 9, Cin, Cout), dtype=torch.float32, device=dev)
+    db_part = torch.empty((workers, Cout), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_conv3x3_wgrad_split_stream(L.ptr(x), L.ptr(dy), L.ptr(dw_part), L.ptr(db_part), N, H, W, Cin, Cout, int(relu_in), workers,
+                                                   L.stream_ptr(dev))
+    L.check(rc, "vs_conv3x3_wgrad_split_stream")
+    return dw_part.sum(0), db_part.sum(0)
+
+
 def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, relu_in: bool = False, need_dx: bool = True, need_db: bool = True,
                            scale_exp: Optional[int] = None):
     """Backward of conv3x3_nhwc(x, pack(w), relu_in=relu_in) (stride 1, pad 1) in the split class.  dy [N,H,W,Cout], x [N,H,W,Cin] f32 NHWC,
@@ -1342,6 +1365,11 @@ def conv3x3_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *
                                                     int(relu_in), ks, L.ptr(ws), ws.numel() * 4, 0, L.stream_ptr(dev))
         L.check(rc, "vs_conv3x3_wgrad_split_atn")
         return dx, dw9.view(3, 3, Cin, Cout).permute(3, 2, 0, 1).contiguous(), db
+    if _WGRAD_STREAM and Cin % 64 == 0 and Cout % 64 == 0 and W % 32 == 0:
+        # narrow layers (the pts3d head's 256 -> 128 and 128 -> 128 convolutions): one streaming pass over X and dY as they are
+        # (csrc/conv_wgrad_stream.hip) instead of two transposing passes + nine 128 x 128 tiles per K slice on the 4-wave kernel
+        dw9, db = conv3x3_wgrad_split_stream(dy, x, relu_in=relu_in)
+        return dx, dw9.view(3, 3, Cin, Cout).permute(3, 2, 0, 1).contiguous(), (db if need_db else None)
     Wp = W + 2
     Pb = N * (H + 2) * Wp
     tiles = ((Cin + 255) // 256) * ((Cout + 255) // 256) * 9 if (Cin % 256 == 0 and Cout % 256 == 0) else ((Cin + 127) // 128) * ((Cout + 127) // 128) * 9
