@@ -500,6 +500,12 @@ int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg,
  * deterministic.  Replaces autograd's nn.Conv2d(k=1) backward + the ReLU backward of the reference's training step (model_wrapper.py:207-230). */
 int vs_head1x1_backward_split(const float *dy, int64_t ldy, const float *t, const float *w, int32_t w_scale_exp, float *dt, float *dw_part,
                               float *db_part, int64_t P, int32_t Cin, int32_t Cout, int32_t relu, int32_t nwg, vs_stream_t stream);
+/* The Gaussian-parameter head's 7x7 RGB stem fused with its upsample-add (dpt_gs_head.py:112-118,142-150), split class, streaming form of
+ * vs_conv7x7_rgb_split_up_nhwc: out = packed (hi, lo) rows [N*H*W, Cout] of bilinear_x2(trunk [N, H/2, W/2, Cout] f32) + relu(conv7x7(image) + bias).
+ * img_padded: zero-bordered NHWC f32 frames [N, Hp, Wp, 3] (3 pixels before, >= 3 after); w: the module's [Cout, 3, 7, 7] f32 parameter, packed in
+ * the kernel with scale 2^w_scale_exp.  Cout == 256, H even, W % 32 == 0; nwg persistent workgroups (one per CU). */
+int vs_stem7x7_up_split_stream(const float *img_padded, const float *w, int32_t w_scale_exp, const float *bias, const float *trunk, void *out,
+                               int32_t N, int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t Cout, int32_t nwg, vs_stream_t stream);
 /* Weight (and bias) gradient of a 3x3 convolution (stride 1, pad 1), split class, as ONE streaming pass over x [N,H,W,Cin] and dy [N,H,W,Cout]
  * (f32 NHWC as they are: no transposed / bordered copies) for the narrow layers of the DPT heads (heads/dpt_block.py:316-343; Cin, Cout multiples of
  * 64, W a multiple of 32): dw_part [workers, 9, Cin, Cout] (tap = ky * 3 + kx), db_part [workers, Cout] = per-worker partial sums the caller adds

@@ -779,3 +779,37 @@ def test_stem_with_fused_upsample_add_matches_the_two_kernel_route(N, Hs, Ws):
     print(f"fused stem + upsample-add N={N} {H}x{W}: rel err vs float64 {e:.2e}; vs the two-kernel route {e12:.2e} (bit-identical: {same})")
     # (the same expression per output; the two kernels contract their multiply-adds differently, so the f32 values agree to an ulp, not bit for bit)
     assert e <= TOL and e12 <= 6e-6
+
+
+@pytest.mark.parametrize("N,Hs,Ws", [(1, 16, 16), (2, 32, 48), (3, 128, 128)])
+def test_streaming_stem_matches_the_tile_route(N, Hs, Ws):
+    """Round 5: vs_stem7x7_up_split_stream (csrc/stem_stream.hip) = vs_conv7x7_rgb_split_up_nhwc as a streaming kernel (image ring in LDS, taps by
+    transpose reads, reduction ordered (channel, kx) x ky): the same expression per output against float64 and against the tile route (the two
+    sum the 147 taps in different orders: f32 rounding apart, not bit for bit)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(7 * N + Hs)
+    H, W, C = 2 * Hs, 2 * Ws, 256
+    frames = (torch.rand(N, 3, H, W, generator=g) * 2 - 1).to(d)
+    w = (torch.randn(C, 3, 7, 7, generator=g) * 0.1).to(d)
+    b = (torch.randn(C, generator=g) * 0.1).to(d)
+    trunk = torch.randn(N, Hs, Ws, C, generator=g).to(d)
+    img = ops.pad_rgb_nhwc(frames, torch.float32)
+    tile = ops.conv7x7_rgb_nhwc(img, ops.pack_conv7x7_rgb_weight(w, "split"), b, H, W, up_add=trunk)
+    strm = ops.stem7x7_up_split_stream(img, w, b, H, W, trunk, ops.split_scale_exp(w))
+    assert strm.data.shape == tile.data.shape == (N, H, W, C)
+    ref = F.interpolate(trunk.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True) + \
+        F.relu(F.conv2d(frames.double(), w.double(), b.double(), padding=3))
+    def unpack(sw):
+        halves = sw.data.view(torch.float16).reshape(N, H, W, C // 32, 2, 32).float()
+        pos = torch.arange(32)
+        gi, t = pos // 8, pos % 8
+        k_of_pos = torch.where(t < 4, 4 * gi + t, 16 + 4 * gi + (t - 4))
+        rec = torch.zeros(N, H, W, C // 32, 32, device=d)
+        rec[..., k_of_pos] = halves[..., 0, :] + halves[..., 1, :]
+        return rec.reshape(N, H, W, C)
+    v1, v2 = unpack(strm), unpack(tile)
+    e = _rel(v1.permute(0, 3, 1, 2).cpu(), ref.cpu())
+    e12 = _rel(v1.cpu(), v2.cpu())
+    print(f"streaming stem N={N} {H}x{W}: rel err vs float64 {e:.2e}; vs the tile route {e12:.2e}")
+    assert e <= TOL and e12 <= 6e-6

@@ -17,6 +17,7 @@ import os
 from .... import ops
 
 _PTS_UP_PACKED = os.environ.get("VS_PTS_UP_PACKED", "1") != "0"     # A/B switch: 0 = f32 upsampled map into the pts3d head's fused conv (round 3)
+_STEM_STREAM = os.environ.get("VS_STEM_STREAM", "1") != "0"       # A/B switch: 0 = the tile route of the fused stem (round 4)
 _STEM_UP_FUSED = os.environ.get("VS_STEM_UP_FUSED", "1") != "0"   # A/B switch: 0 = stem -> f32 map -> upsample-add kernel (round 3)
 
 
@@ -310,7 +311,15 @@ class PixelwiseTaskWithDPT(nn.Module):
                     and (2 * x.shape[1], 2 * x.shape[2]) == (H_, W_)):
                 # round 4: up2(trunk) + relu(stem) leaves the STEM kernel's epilogue in the packed form -- the f32 stem map (12.9 GB written and
                 # read back per 24-scene step) and the stand-alone upsample-add launch are gone
-                xp = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], H_, W_, up_add=x)
+                if _STEM_STREAM and W_ % 32 == 0 and d.input_merger[0].out_channels == 256:
+                    # round 5: the streaming form (csrc/stem_stream.hip): the image as an LDS ring, taps by transpose reads, 9.4 -> see DESIGN
+                    if "stem.w32" not in P:
+                        c7 = d.input_merger[0]
+                        P["stem.w32"] = c7.weight.detach().float().contiguous()
+                        P["stem.e"] = ops.split_scale_exp(P["stem.w32"])
+                    xp = ops.stem7x7_up_split_stream(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.w32"], P["stem.b"], H_, W_, x, P["stem.e"])
+                else:
+                    xp = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], H_, W_, up_add=x)
                 y = ops.conv3x3_head1x1_nhwc(xp, P["h0.w"], None, P["h4f.w"], P["h4f.b"], self.num_channels)   # [BT,H,W,96] f32
                 return y[..., :self.num_channels].permute(0, 3, 1, 2)
             img = ops.conv7x7_rgb_nhwc(ops.pad_rgb_nhwc(frames, torch.float32), P["stem.ws7"], P["stem.b"], H_, W_)

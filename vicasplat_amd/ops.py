@@ -648,6 +648,26 @@ def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[t
     return out
 
 
+def stem7x7_up_split_stream(img_padded: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, up_add: torch.Tensor, scale_exp: int):
+    """conv7x7_rgb_nhwc(img_padded, pack(w), bias, H, W, up_add=up_add) of the split class as the streaming kernel (csrc/stem_stream.hip):
+    w = the module's [256, 3, 7, 7] f32 parameter (packed in the kernel with 2^scale_exp), returns the packed SplitWeight [N,H,W,256]."""
+    dev = L.require_device(img_padded, w, bias, up_add)
+    N, Hp, Wp, C = img_padded.shape
+    Cout = w.shape[0]
+    assert C == 3 and img_padded.is_contiguous() and img_padded.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
+    assert tuple(w.shape) == (256, 3, 7, 7) and W % 32 == 0 and H % 2 == 0 and bias.dtype == torch.float32 and bias.is_contiguous()
+    assert up_add.dtype == torch.float32 and up_add.is_contiguous() and tuple(up_add.shape) == (N, H // 2, W // 2, Cout)
+    if RANGE_GUARD.enabled:
+        RANGE_GUARD.check(f"stem + upsample-add: trunk {Cout} @{H // 2}x{W // 2}", up_add)
+    outp = torch.empty((N, H, W, Cout), dtype=torch.int32, device=dev)
+    nwg = max(1, min(N * (W // 32), torch.cuda.get_device_properties(dev).multi_processor_count))
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_stem7x7_up_split_stream(L.ptr(img_padded), L.ptr(w), int(scale_exp), L.ptr(bias), L.ptr(up_add), L.ptr(outp), N, H, W, Hp, Wp, Cout,
+                                                nwg, L.stream_ptr(dev))
+    L.check(rc, "vs_stem7x7_up_split_stream")
+    return SplitWeight(outp, 1.0, outp.shape)
+
+
 def upsample2x_nhwc(x: torch.Tensor, add: Optional[torch.Tensor] = None, relu_add: bool = False, packed: bool = False):
     """Bilinear x2, align_corners=True, on [N,H,W,C] contiguous 16-bit / f32; optional fused `+ add` / `+ relu(add)`.
     packed=True (f32 input, C % 32 == 0): the result is written in the packed (hi, lo) form of the split class and returned as a SplitWeight
