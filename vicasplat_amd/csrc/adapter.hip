@@ -12,6 +12,8 @@
 // (means [P,3], covariances [P,3,3], harmonics [P,3,d_sh], opacities [P], scales [P,3], rotations [P,4], raw [P,11+3*d_sh]).
 #include "common.h"
 
+#include <cstdlib>
+
 #include <type_traits>
 
 namespace {
@@ -153,21 +155,24 @@ __device__ __forceinline__ void write_rows(float *__restrict__ dst, int np, int 
 }
 
 // DT: 0 = f32 inputs (the f32 / split operand classes), 1 = f16, 2 = bf16
-template <int DT>
+// NPX pixels per workgroup (64 or 32).  Round 5: the f32 inputs of the split class need 34.5 KB of LDS per 64-pixel block -- four one-wave
+// workgroups per CU, i.e. ONE wave per SIMD for a kernel that only moves bytes (4.46 ms per 24-scene step = 3.1 TB/s of its 14 GB).  With 32
+// pixels per block (the upper half of the lanes idles in the per-pixel arithmetic, which is nothing beside the traffic) nine workgroups fit.
+template <int DT, int NPX = 64>
 __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a) {
     typedef typename std::conditional<DT == 0, float, unsigned short>::type elem_t;
     constexpr int EV = 16 / (int)sizeof(elem_t);   // elements per 16-byte vector
     // pixel strides may exceed the channel counts (gs rows padded to a multiple of 16 channels, pts rows to 4: what the fused
     // conv3 -> conv1 head kernel writes); the staged blocks keep the stride
     constexpr int kPx = 28;   // per-pixel results: means 3 | raw opacity 1 | raw scale 3 | raw quat 4 | cov 9 | scale 3 | quat 4 | opacity 1
-    __shared__ __attribute__((aligned(16))) elem_t sin[64 * kMaxPixStride + 64 * 8 + 16];
-    __shared__ float spx[64][kPx + 1];
+    __shared__ __attribute__((aligned(16))) elem_t sin[NPX * kMaxPixStride + NPX * 8 + 16];
+    __shared__ float spx[NPX][kPx + 1];
     __shared__ float smask[kMaxCh];
     const int lane = threadIdx.x;
-    const long long p0 = (long long)blockIdx.x * 64;
-    const int np = (int)min((long long)64, a.npix - p0);
+    const long long p0 = (long long)blockIdx.x * NPX;
+    const int np = (int)min((long long)NPX, a.npix - p0);
     const int nsh = a.d_sh, cg = (int)a.gs_pix, cp = (int)a.pts_pix, craw = 11 + 3 * nsh;
-    elem_t *sgs = sin, *spt = sin + ((64 * cg + 7) & ~7);
+    elem_t *sgs = sin, *spt = sin + ((NPX * cg + 7) & ~7);
     {   // coalesced 16-byte loads of the two input blocks
         const elem_t *ggs = reinterpret_cast<const elem_t *>(a.gs) + p0 * cg;
         const elem_t *gpt = reinterpret_cast<const elem_t *>(a.pts) + p0 * cp;
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(64) adapter_nhwc16_kernel(const AdapterArgs a)
 #pragma unroll
             for (int c = 0; c < 3; ++c) cov[3 * r + c] = RS[r][0] * RS[c][0] + RS[r][1] * RS[c][1] + RS[r][2] * RS[c][2];
     }
-    {   // per-pixel results -> LDS rows (29-float stride: conflict-free for the row-per-lane stores), read back by the block writers
+    if (lane < NPX) {   // per-pixel results -> LDS rows (29-float stride: conflict-free for the row-per-lane stores), read back by the block writers
         float *r = spx[lane];
         r[0] = mx; r[1] = my; r[2] = mz; r[3] = o_raw;
 #pragma unroll
@@ -471,7 +476,10 @@ extern "C" int vs_gaussian_adapter(const void *pts, int64_t pts_pix, int64_t pts
                          ((64 * pts_pix) % ev == 0) && ((64 * gs_pix) % ev == 0);
     if (dense16) {
         dim3 g64((unsigned)vs::cdiv64(npix, 64));
-        if (in_dtype == 0) hipLaunchKernelGGL(adapter_nhwc16_kernel<0>, g64, dim3(64), 0, stream, a);
+        static const int npx = [] { const char *e = getenv("VS_ADAPTER_NPX"); return e ? atoi(e) : 32; }();
+        if (in_dtype == 0 && npx == 32 && ((32 * pts_pix) % ev == 0) && ((32 * gs_pix) % ev == 0))
+            hipLaunchKernelGGL((adapter_nhwc16_kernel<0, 32>), dim3((unsigned)vs::cdiv64(npix, 32)), dim3(64), 0, stream, a);
+        else if (in_dtype == 0) hipLaunchKernelGGL(adapter_nhwc16_kernel<0>, g64, dim3(64), 0, stream, a);
         else if (in_dtype == 1) hipLaunchKernelGGL(adapter_nhwc16_kernel<1>, g64, dim3(64), 0, stream, a);
         else hipLaunchKernelGGL(adapter_nhwc16_kernel<2>, g64, dim3(64), 0, stream, a);
         VS_HIP(hipGetLastError());
