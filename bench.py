@@ -425,6 +425,7 @@ def main():
                    (ops, "conv3x3_head1x1_nhwc", lambda r, x, w, b, w2, b2, n_out, *a, **k: dict(
                        flops=2.0 * x.shape[0] * x.shape[1] * x.shape[2] * (9.0 * w.shape[3] * w.shape[0] + w.shape[0] * n_out))),
                    (ops, "conv7x7_rgb_nhwc", lambda r, x, w, *a, **k: dict(flops=2.0 * r.numel() * 147)),
+                   (ops, "stem7x7_up_split_stream", lambda r, x, w, *a, **k: dict(flops=2.0 * r.data.numel() * 147)),      # (round 5: the streaming stem)
                    (ops, "upsample2x_nhwc", lambda r, x, *a, **k: dict(bytes=r.numel() * 2.0 * (2.25 if (len(a) or k.get("add") is not None) else 1.25))),
                    (ops, "gaussian_adapter", lambda r, *a, **k: dict()),
                    (raster, "_forward_impl", raster_meta)]
@@ -436,8 +437,11 @@ def main():
         for m, n, o in saved:
             setattr(m, n, o)
         zero = dict(ms=0.0, calls=0, flops=0.0, bytes=0.0)
-        for k_ in ("gemm", "gemm_qkv_rope", "conv3x3_nhwc", "conv3x3_head1x1_nhwc", "conv7x7_rgb_nhwc", "upsample2x_nhwc", "gaussian_adapter"):
+        for k_ in ("gemm", "gemm_qkv_rope", "conv3x3_nhwc", "conv3x3_head1x1_nhwc", "conv7x7_rgb_nhwc", "stem7x7_up_split_stream", "upsample2x_nhwc",
+                   "gaussian_adapter"):
             summ.setdefault(k_, dict(zero))
+        for k_ in ("ms", "calls", "flops"):      # the 7x7 stem: tile route or streaming kernel, one family
+            summ["conv7x7_rgb_nhwc"][k_] = summ["conv7x7_rgb_nhwc"].get(k_, 0.0) + summ["stem7x7_up_split_stream"].get(k_, 0.0)
         tot_ms = s.elapsed_time(e)
         # every vs_gemm_* launch: plain/fused-epilogue GEMMs and the qkv projections with RoPE in the epilogue
         gm = {k_: summ["gemm"][k_] + summ["gemm_qkv_rope"][k_] for k_ in ("ms", "calls", "flops")}

@@ -11,7 +11,7 @@ HBM rate the kernel's duration allows).
 """
 import csv, json, sys, collections
 
-FAMILIES = [("gemm", ("gemm256_kernel", "gemm_kernel", "gemm_smallm_kernel", "gemm_skinny_kernel", "conv7x7_256_kernel")), ("conv3x3", ("conv3x3_256_kernel", "conv3x3_kernel")),
+FAMILIES = [("gemm", ("gemm256_kernel", "gemm_kernel", "gemm_smallm_kernel", "gemm_skinny_kernel", "conv7x7_256_kernel", "stem_up_stream_kernel")), ("conv3x3", ("conv3x3_256_kernel", "conv3x3_kernel")),
             ("attention", ("attention_kernel", "attention_res_kernel", "attention_split_kernel", "attention_sp_kernel", "attention_f32_kernel")), ("rasterizer", ("preprocess_kernel", "scatter_kernel", "tile_scan_kernel", "tile_sort_kernel",
                                                                   "segment_sort_kernel", "render_kernel")),
             ("layernorm", ("layernorm_mod_kernel", "layernorm_rows_kernel")), ("upsample", ("upsample2x_kernel", "upsample2x_f32")), ("adapter", ("adapter_",))]
@@ -41,6 +41,11 @@ def load(path, counter):
         if counter == "FETCH_SIZE" and not any(k in r["Kernel_Name"] for k in GATHER_KERNELS):
             v *= 2.0
         per[fam][1] += v
+        if fam == "conv3x3":        # per-instantiation detail of the convolutions (where the family's fetch bytes go)
+            short = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0].replace(" ", "")
+            per["conv3x3/" + short][1] += v
+            if (r["Dispatch_Id"], short) not in seen:
+                seen.add((r["Dispatch_Id"], short)); per["conv3x3/" + short][0] += 1
         if fam == "rasterizer":     # per-kernel detail of the rasterizer
             short = next(k for k in FAMILIES[3][1] if k in r["Kernel_Name"])
             per["rasterizer/" + short][1] += v

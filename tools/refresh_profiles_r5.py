@@ -85,7 +85,7 @@ for tag in ("video", "encoder"):
         att += f"## {tag}\n\n```\n" + "".join(l for l in open(f) if "amdgpu.ids" not in l) + "```\n\n"
 open(os.path.join(OUT, "round5_pmc_attention.md"), "w").write(att)
 print(md)
-FAM = [("gemm", r"gemm256_kernel|gemm_kernel|gemm_smallm|gemm_skinny|conv7x7_256|split_pack"), ("wgrad", r"tn_splitk|wgrad|splitk_reduce"), ("conv3x3", r"conv3x3"), ("attention bwd", r"attn_bwd|attn_delta"),
+FAM = [("gemm", r"gemm256_kernel|gemm_kernel|gemm_smallm|gemm_skinny|conv7x7_256|stem_up_stream|split_pack"), ("wgrad", r"tn_splitk|wgrad|splitk_reduce|head1x1_bwd"), ("conv3x3", r"conv3x3"), ("attention bwd", r"attn_bwd|attn_delta"),
        ("attention", r"attention"), ("raster bwd", r"render_backward|preprocess_backward"), ("raster fwd", r"render_kernel|preprocess_kernel|tile_sort|scatter_kernel|segment_sort|tile_scan"),
        ("layernorm", r"layernorm"), ("upsample", r"upsample"), ("adapter", r"adapter"), ("adamw", r"multi_tensor_apply"),
        ("torch glue", r"at::native|rocclr|Cijk"), ("other hip", r".")]
