@@ -9,7 +9,7 @@ tools/probe/fetch_calib.hip (profiles/round2_fetch_calibration.md) -- a streamin
 gather of 16 M 48-byte records reports 1.66x the requested bytes, which is already the line-granular traffic (doubling it would exceed the
 HBM rate the kernel's duration allows).
 """
-import csv, json, sys, collections
+import csv, json, re, sys, collections
 
 FAMILIES = [("gemm", ("gemm256_kernel", "gemm_kernel", "gemm_smallm_kernel", "gemm_skinny_kernel", "conv7x7_256_kernel", "stem_up_stream_kernel")), ("conv3x3", ("conv3x3_256_kernel", "conv3x3_kernel")),
             ("attention", ("attention_kernel", "attention_res_kernel", "attention_split_kernel", "attention_sp_kernel", "attention_f32_kernel")), ("rasterizer", ("preprocess_kernel", "scatter_kernel", "tile_scan_kernel", "tile_sort_kernel",
@@ -42,7 +42,7 @@ def load(path, counter):
             v *= 2.0
         per[fam][1] += v
         if fam == "conv3x3":        # per-instantiation detail of the convolutions (where the family's fetch bytes go)
-            short = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0].replace(" ", "")
+            short = re.search(r"conv3x3\w*(<[^>]*>)?", r["Kernel_Name"]).group(0).replace(" ", "")
             per["conv3x3/" + short][1] += v
             if (r["Dispatch_Id"], short) not in seen:
                 seen.add((r["Dispatch_Id"], short)); per["conv3x3/" + short][0] += 1

@@ -36,7 +36,17 @@ struct ConvArgs {
     float acc_scale2;           // split operands, fused head: 2^-e of the packed w2
     int a_packed;               // split operands: `in` is already the packed (hi, lo) image (ops.split_act; any ReLU applied by its producer)
     const float *res2;          // f32 activations: a SECOND residual [N,H,W,Cout] added with `res` (the FeatureFusionBlock's x + rcu(skip), dpt_block.py:196-208)
+    int korder;                 // 256-tile kernels: 0 = K-tiles tap-major (tap, channel block), 1 = channel-block-major (see ConvStager256)
 };
+
+// K-tile order of the 256-tile implicit-GEMM kernels (VS_CONV_KORDER, default 1).  Tap-major, the three kx taps of one image row re-read the
+// same lines kpt K-tiles apart -- x 32 resident workgroups per XCD that is more than the 4 MB L2 holds, and the counters showed the fused
+// Gaussian head fetching 124 GB per step for a 12.9 GB input.  Channel-block-major, the nine taps of one 64-channel block are consecutive
+// K-tiles: the kx re-reads are one K-tile apart.  Only the ORDER of the reduction changes (f32 rounding), not the operands.
+static int conv_korder() {
+    static const int v = [] { const char *e = getenv("VS_CONV_KORDER"); return e ? atoi(e) : 1; }();
+    return v;
+}
 
 // epilogue shared by the conv kernels (accumulators are C^T, see gemm_common.h: a lane holds 4 consecutive output
 // channels of one pixel per fragment): + bias, + residual (8-byte load, added in f32), ReLU, round to 16 bit, one 8-byte
@@ -436,9 +446,12 @@ struct ConvStager256 {
     unsigned vmask[2][2];            // [A_h][round] bit t: tap t is inside the image (0 for rows past M)
     const unsigned short *pw[2][2];  // [B_h][round]
     int Cin, Win, kpt, kinv;         // kpt = K-tiles per tap (Cin / 64, any value <= 64: round 5 -- was a power of two), kinv = ceil(2^16 / kpt)
+    int chmajor;                     // K-tile order: 0 (tap, channel block), 1 (channel block, tap) -- late round 5, see conv_korder()
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
         if (u < 2) {
-            const int tap = (kt * kinv) >> 16, kc = kt - tap * kpt;      // kt / kpt, exact for kt < 9 * kpt (checked for every kpt <= 64)
+            int tap, kc;
+            if (chmajor) { kc = (kt * 7282) >> 16; tap = kt - kc * 9; }     // kt / 9, exact for kt < 576
+            else { tap = (kt * kinv) >> 16; kc = kt - tap * kpt; }          // kt / kpt, exact for kt < 9 * kpt (checked for every kpt <= 64)
             const int ty = (tap * 11) >> 5;                      // tap / 3 for tap in 0..8
             const int dy = ty - 1, dx = tap - ty * 3 - 1;
             const long long off = (long long)(dy * Win + dx) * Cin + kc * 64;   // wave-uniform
@@ -448,8 +461,10 @@ struct ConvStager256 {
                 glds16(ok ? pa[u][j] + off : pz[j], lds + j * 1024u);
             }
         } else {
-            glds16(pw[u - 2][0] + kt * 64, lds);
-            glds16(pw[u - 2][1] + kt * 64, lds + 1024u);
+            int wk = kt;
+            if (chmajor) { const int kc = (kt * 7282) >> 16; wk = (kt - kc * 9) * kpt + kc; }     // the weight rows stay [tap][channel]
+            glds16(pw[u - 2][0] + wk * 64, lds);
+            glds16(pw[u - 2][1] + wk * 64, lds + 1024u);
         }
     }
 };
@@ -475,7 +490,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256_kernel(const ConvArgs g, c
     const int m0 = tm * 256, n0 = tn * 256;
 
     ConvStager256 st;
-    st.Cin = g.Cin; st.Win = g.Win; st.kpt = kpt; st.kinv = (65536 + kpt - 1) / kpt;
+    st.Cin = g.Cin; st.Win = g.Win; st.kpt = kpt; st.kinv = (65536 + kpt - 1) / kpt; st.chmajor = g.korder;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = unit_row256(wid, j, lane);
@@ -516,9 +531,12 @@ struct ConvStager256x128 {
     unsigned vmask[2][2];
     const unsigned short *pw[2];     // [round] the B unit: 128 weight rows
     int Cin, Win, kpt, kinv;         // kpt = K-tiles per tap (Cin / 64, any value <= 64: round 5 -- was a power of two), kinv = ceil(2^16 / kpt)
+    int chmajor;                     // K-tile order: 0 (tap, channel block), 1 (channel block, tap) -- late round 5, see conv_korder()
     __device__ __forceinline__ void stage(int u, int kt, unsigned lds) const {
         if (u < 2) {
-            const int tap = (kt * kinv) >> 16, kc = kt - tap * kpt;      // kt / kpt, exact for kt < 9 * kpt (checked for every kpt <= 64)
+            int tap, kc;
+            if (chmajor) { kc = (kt * 7282) >> 16; tap = kt - kc * 9; }     // kt / 9, exact for kt < 576
+            else { tap = (kt * kinv) >> 16; kc = kt - tap * kpt; }          // kt / kpt, exact for kt < 9 * kpt (checked for every kpt <= 64)
             const int ty = (tap * 11) >> 5;
             const int dy = ty - 1, dx = tap - ty * 3 - 1;
             const long long off = (long long)(dy * Win + dx) * Cin + kc * 64;
@@ -528,8 +546,10 @@ struct ConvStager256x128 {
                 glds16(ok ? pa[u][j] + off : pz[j], lds + j * 1024u);
             }
         } else {
-            glds16(pw[0] + kt * 64, lds);
-            glds16(pw[1] + kt * 64, lds + 1024u);
+            int wk = kt;
+            if (chmajor) { const int kc = (kt * 7282) >> 16; wk = (kt - kc * 9) * kpt + kc; }
+            glds16(pw[0] + wk * 64, lds);
+            glds16(pw[1] + wk * 64, lds + 1024u);
         }
     }
 };
@@ -556,7 +576,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_256x128_split_kernel(const Con
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * 256, n0 = tn * 128;
     ConvStager256x128 st;
-    st.Cin = g.Cin; st.Win = g.Win; st.kpt = kpt; st.kinv = (65536 + kpt - 1) / kpt;
+    st.Cin = g.Cin; st.Win = g.Win; st.kpt = kpt; st.kinv = (65536 + kpt - 1) / kpt; st.chmajor = g.korder;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = unit_row256(wid, j, lane);                 // unit row 0..127 this lane stages
@@ -1058,6 +1078,7 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
     VS_CHECK(!in_packed || (dtype == 4 && relu_in == 0), "vs_conv3x3_split_nhwc: a packed input is a split-class operand that carries its ReLU already");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, (const unsigned short *)residual, (unsigned short *)out,
                Nimg, H, W, Cin, Cout, relu_in, relu_out, Hin, Win, stride, nullptr, nullptr, nullptr, 0, 0, 0, acc_scale, 1.f, in_packed, residual2};
+    g.korder = conv_korder();
     VS_CHECK(!residual2 || ((dtype == 3 || dtype == 4) && relu_out != 2), "vs_conv3x3_nhwc: a second residual needs f32 activations (dtype 3 / 4) and no mask epilogue");
     const long long M = (long long)Nimg * H * W;
     static const int force = [] { const char *e = getenv("VS_CONV_MI"); return e ? atoi(e) : 0; }();
@@ -1172,6 +1193,7 @@ extern "C" int vs_conv3x3_head1x1_nhwc(const void *in, const void *w, const floa
     VS_CHECK(relu_out == 0 || relu_out == 1, "vs_conv3x3_head1x1_nhwc: relu_out must be 0 or 1");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)w, bias, nullptr, nullptr, Nimg, H, W, Cin, Cout, relu_in, relu_out, H, W, 1,
                (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2pad, ld2, 1.f, 1.f};
+    g.korder = conv_korder();
     if (Cout == 256) {
         int cshift = -1;
         for (int sft = 0; sft < 4; ++sft)
@@ -1219,6 +1241,7 @@ extern "C" int vs_conv3x3_head_dot_split_nhwc(const float *in, const void *wp, f
     VS_CHECK((((uintptr_t)in | (uintptr_t)wp | (uintptr_t)out2 | (uintptr_t)bias2) & 15) == 0, "vs_conv3x3_head_dot_split_nhwc: 16-byte alignment required");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 128, relu_in, relu_out, H, W, 1,
                (const unsigned short *)w2, bias2, (unsigned short *)out2, C2, C2, ld2, acc_scale, 1.f};
+    g.korder = conv_korder();
     int cshift = -1;
     for (int sft = 0; sft < 4; ++sft)
         if (2 * Cin == (64 << sft)) cshift = sft;
@@ -1257,6 +1280,7 @@ extern "C" int vs_conv3x3_head1x1_split_nhwc(const float *in, const void *wp, fl
              "vs_conv3x3_head1x1_split_nhwc: 16-byte alignment required");
     ConvArgs g{(const unsigned short *)in, (const unsigned short *)wp, bias, nullptr, nullptr, Nimg, H, W, 2 * Cin, 256, 0, relu_out, H, W, 1,
                (const unsigned short *)w2p, bias2, (unsigned short *)out2, C2, C2pad, ld2, acc_scale, acc_scale2};
+    g.korder = conv_korder();
     dim3 grid((unsigned)(M / 256)), block(512);
     g.a_packed = in_packed;
 #define VS_HEAD(NF_) { if (in_packed) hipLaunchKernelGGL((conv3x3_256_kernel<kDtSplit, false, NF_, true>), grid, block, 0, stream, g, 1 << cshift); \

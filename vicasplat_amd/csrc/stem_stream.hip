@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(512) stem_up_stream_kernel(const StemStreamArg
         const float *r0 = a.trunk + ((long long)(n * Hs) * Ws) * C + chb + 4 * g;      // output row 0: source rows 0 and min(1, Hs - 1), ly = 0
         const float *r1 = a.trunk + ((long long)(n * Hs + min(1, Hs - 1)) * Ws) * C + chb + 4 * g;
         float ly_c = 0.f;
+        bool same_prev = false;                 // this output row's two source rows = the previous row's (every other row at scale 2)
         load_taps(tpA, r0, r1, 0);
         for (int yo = 0; yo < a.H; ++yo) {
             // the ring is refreshed four rows at a time: steps 4b .. 4b + 3 read padded rows 4b .. 4b + 11; the rows stored here (4b + 8 .. 4b + 11) take
@@ -163,6 +164,7 @@ __global__ void __launch_bounds__(512) stem_up_stream_kernel(const StemStreamArg
             const float sy_n = (float)(yo + 1) * ry;
             const int y0_n = min((int)sy_n, Hs - 1), y1_n = min(y0_n + 1, Hs - 1);
             const float *r0_n = a.trunk + ((long long)(n * Hs + y0_n) * Ws) * C + chb + 4 * g, *r1_n = a.trunk + ((long long)(n * Hs + y1_n) * Ws) * C + chb + 4 * g;
+            const bool same_next = r0_n == r0 && r1_n == r1;
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 // ---- software pipeline: the bilinear taps of the NEXT tile are requested before this tile's MFMAs (8 x 16 bytes per lane in flight
@@ -170,8 +172,9 @@ __global__ void __launch_bounds__(512) stem_up_stream_kernel(const StemStreamArg
                 // the previous tile's stores: vmcnt counts in order) ----
                 float4 (&tc)[2][4] = ((PT * 0 + pt) & 1) ? tpB : tpA;      // this tile's taps
                 float4 (&tn)[2][4] = ((PT * 0 + pt) & 1) ? tpA : tpB;      // the next tile's
-                if (pt + 1 < PT) load_taps(tn, r0, r1, pt + 1);
-                else if (yo + 1 < a.H) load_taps(tn, r0_n, r1_n, 0);
+                // (source rows that do not change from one output row to the next leave both tiles' taps where they are: half the gathers)
+                if (pt + 1 < PT) { if (!same_prev) load_taps(tn, r0, r1, pt + 1); }
+                else if (yo + 1 < a.H && !same_next) load_taps(tn, r0_n, r1_n, 0);
                 // ---- conv: C[ch][px] over six k-steps; a patch fragment (B operand) is read once for the wave's two channel tiles ----
                 f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -204,13 +207,13 @@ __global__ void __launch_bounds__(512) stem_up_stream_kernel(const StemStreamArg
                 float *rowp = a.out + ((long long)(n * a.H + yo) * a.W + x0s + pt * 16 + l16) * C;
                 store_split8(rowp, chb + 4 * g, v[0], v[1]);
             }
-            if (PT == 1) {      // (one tile per row: the roles of the two tap buffers alternate from row to row)
+            if (PT == 1 && !same_next) {      // (one tile per row: the next row's taps were loaded into the second buffer)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) tpA[ct][k] = tpB[ct][k];
             }
-            r0 = r0_n; r1 = r1_n;
+            r0 = r0_n; r1 = r1_n; same_prev = same_next;
             ly_c = sy_n - (float)y0_n;
         }
     }
