@@ -508,7 +508,14 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm = bid / tiles_n, tn = bid % tiles_n;
+    if (g.row_band > 0 && tiles_n > 4) {
+        // bands of row_band row tiles, column tile slowest inside a band: the ~32 workgroups an XCD runs at a time then cover row_band row
+        // tiles x (32 / row_band) column tiles instead of 2 x 16 -- fewer distinct W panels in flight per XCD, each A panel shared less
+        const int per_band = g.row_band * tiles_n, band = bid / per_band, rows = min(g.row_band, tiles_m - band * g.row_band);
+        const int r = bid - band * per_band;
+        tn = r / rows; tm = band * g.row_band + (r - tn * rows);
+    }
     const int m0 = g.m_lo + tm * BM2, n0 = tn * BN2;
     if (g.stagger > 0 && blockIdx.x < 256) {
         const int n = (int)((blockIdx.x >> 3) & 7) * g.stagger;

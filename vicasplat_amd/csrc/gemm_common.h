@@ -56,6 +56,7 @@ struct GemmArgs {
     int rope_C;  // columns [0, C) = q, [C, 2C) = k, rest untouched
     float rope_l2base, rope_l2theta;  // log2 of the 2-D base / 1-D theta
     int stagger;  // experiment: first-round workgroups of gemm256_kernel sleep (bid % 8) * stagger * ~4 us before starting
+    int row_band; // gemm256_kernel: > 0 = tiles are walked in bands of row_band row tiles, column tile slowest inside a band (L2: see gemm256_kernel)
     int tap_on_a;     // tap-fused weight gradient: the tap shift moves the A operand instead of W (split class: a packed W cannot be shifted)
     int out_packed;   // split operands, epilogues 0 / 1 / 3: the output is written in the packed (hi, lo) form (the A operand of the next GEMM)
     int a_packed;     // split operands: A is ALREADY in the packed (hi, lo) form of vs_split_pack_weight (scale 2^0): the kernels skip the conversion
