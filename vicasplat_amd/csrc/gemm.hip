@@ -754,6 +754,13 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     return launch_tail<BF16>(g, rem, epi, stream);
 }
 
+// XCD-aware logical block ids in the split-K / tap-fused weight-gradient kernels (gemm256.h splitk_logical_block): VS_WGRAD_XCD=0 restores the
+// plain blockIdx order for an A/B.
+static int wgrad_xcd() {
+    static const int v = [] { const char *e = getenv("VS_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 // out[t][m, n] += sum_s partials[((s * ntaps + t) * M + m) * N + n]: second stage of a weight-gradient GEMM with a workspace.
 template <int VEC>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out, int M, int N, int ntaps,
@@ -1049,7 +1056,7 @@ extern "C" int vs_gemm_wgrad(const void *A, const void *W, float *out, int32_t M
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = ntaps; g.tap_out_stride = ntaps > 0 ? tap_out_stride : 0;
     g.a_slice_stride = a_slice_stride; g.w_slice_stride = w_slice_stride; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
     VS_CHECK(a_slice_stride >= 0 && w_slice_stride >= 0, "vs_gemm_wgrad: negative slice stride");
@@ -1088,7 +1095,7 @@ extern "C" int vs_gemm_wgrad_tn(const void *A, const void *W, float *out, int32_
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
@@ -1134,7 +1141,7 @@ extern "C" int vs_gemm_wgrad_split_atn(const float *A, const void *Wp, float *ou
     g.grp_in = M; g.grp_out = M; g.grp_off = 0; g.gate_rows = M; g.gate_ld = N;
     g.a_grp_in = M; g.a_grp_out = M; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = 0; g.tap_out_stride = 0; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = Kred; g.partials = nullptr; g.conv_H = 0; g.conv_W = 0;
     const long long need = (long long)ksplit * M * N * (long long)sizeof(float);
@@ -1180,7 +1187,7 @@ extern "C" int vs_conv3x3_wgrad_split_atn(const float *x, const void *dyTp, floa
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 1;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 1;
     g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
     const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
@@ -1230,7 +1237,7 @@ extern "C" int vs_conv3x3_wgrad_tn(const void *x, const void *dy, float *out, in
     g.grp_in = Cin; g.grp_out = Cin; g.grp_off = 0; g.gate_rows = Cin; g.gate_ld = Cout;
     g.a_grp_in = Cin; g.a_grp_out = Cin; g.a_grp_off = 0; g.m_lo = 0;
     g.a_sup_in = 0x7fffffff; g.a_sup_extra = 0; g.a_kstride = 32;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     g.ntaps = 9; g.tap_out_stride = (long long)Cin * Cout; g.a_slice_stride = 0; g.w_slice_stride = 0;
     g.ksplit = ksplit; g.k_valid = (int)P; g.partials = nullptr; g.conv_H = H; g.conv_W = W;
     const long long need = (long long)ksplit * 9 * Cin * Cout * (long long)sizeof(float);
@@ -1302,7 +1309,7 @@ extern "C" int vs_conv7x7_rgb_nhwc(const void *in_padded, const void *w, const f
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;      // ... plus the padding rows of the images before it
     g.a_kstride = Wp * 3;                               // next kernel row = next padded image row
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = 1.f; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     static const int no256 = [] { const char *e = getenv("VS_STEM_NO256"); return e ? atoi(e) : 0; }();
     if (Cout % 256 == 0 && g.M >= 256 && !no256) {
         const int nwg = vs::cdiv(g.M, 256) * (Cout / 256);
@@ -1340,7 +1347,7 @@ extern "C" int vs_conv7x7_rgb_split_nhwc(const float *in_padded, const void *wp,
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
     g.a_kstride = Wp * 6;
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = 0; g.conv_W = 0;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     hipLaunchKernelGGL(conv7x7_256_kernel<kDtSplit>, dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;
@@ -1372,7 +1379,7 @@ extern "C" int vs_conv7x7_rgb_split_up_nhwc(const float *in_padded, const void *
     g.a_sup_in = H; g.a_sup_extra = (Hp - H) * Wp;
     g.a_kstride = Wp * 6;
     g.ksplit = 1; g.ntaps = 0; g.tap_out_stride = 0; g.partials = nullptr; g.a_slice_stride = 0; g.w_slice_stride = 0; g.k_valid = 0; g.conv_H = H / 2; g.conv_W = W / 2;
-    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = 0; g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
+    g.rope_pos = nullptr; g.rope_kind = nullptr; g.rope_C = 0; g.rope_l2base = 0.f; g.rope_l2theta = 0.f; g.stagger = 0; g.row_band = wgrad_xcd(); g.acc_scale = acc_scale; g.a_packed = 0; g.out_packed = 0; g.tap_on_a = 0;
     hipLaunchKernelGGL((conv7x7_256_kernel<kDtSplit, true>), dim3(vs::cdiv(g.M, 256) * (Cout / 256)), dim3(512), 0, stream, g);
     VS_HIP(hipGetLastError());
     return 0;

@@ -544,6 +544,18 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(const GemmArgs g) {
     gemm_epilogue<BF16, EPI, 8>(g, acc, m0 + wr * 128, n0 + wc * 64, smem, wid, lane);
 }
 
+// Logical workgroup id of the split-K / tap-fused kernels.  The hardware hands consecutive blockIdx.x to consecutive XCDs (8 on MI355X, each
+// with its own 4 MB L2), so "tile fastest inside a K slice" put the workgroups that read the same rows of A and W on EIGHT different L2s:
+// the counters showed the split-class weight gradients fetching 151 GB (linears) + 122 GB (3x3 convolutions) per 8-scene training step for
+// ~55 GB of operands, at 4-5.5 TB/s.  With g.row_band != 0 (the weight-gradient entries set it: VS_WGRAD_XCD, default 1) consecutive LOGICAL
+// ids share an XCD (gemm256_kernel's remap): the nine taps / the tiles of one K slice meet in one L2.
+__device__ __forceinline__ int splitk_logical_block(const GemmArgs &g) {
+    const int b = blockIdx.x;
+    if (g.row_band == 0) return b;
+    const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // Split-K / tap-fused variant for weight gradients: out32[tap][M,N] += A[M, Kslice] (W + shift[tap])[N, Kslice]^T through f32
 // atomics, or (g.partials) per-slice partial tiles for splitk_reduce_kernel.  blockIdx.x = (k-slice, tap, tile), tile fastest: the workgroups of one K slice run together, so A and the (up to
 // nine, overlapping) shifted views of W of that slice are shared through L2.  K / 64 / ksplit must be even and >= 2.
@@ -559,8 +571,9 @@ __global__ void __launch_bounds__(512, 1) gemm256_splitk_kernel(const GemmArgs g
     const int tiles_n = (g.N + BN2 - 1) / BN2;
     const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
     const int ntaps = g.ntaps > 0 ? g.ntaps : 1;
-    const int ksp = blockIdx.x / (tiles * ntaps);
-    const int rem = blockIdx.x - ksp * tiles * ntaps;
+    const int lb = splitk_logical_block(g);
+    const int ksp = lb / (tiles * ntaps);
+    const int rem = lb - ksp * tiles * ntaps;
     const int tap = rem / tiles, bid = rem - tap * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM2, n0 = tn * BN2;
@@ -627,8 +640,9 @@ __global__ void __launch_bounds__(512, 1) gemm256_tn_splitk_kernel(const GemmArg
     const int wr = wid >> 2, wc = wid & 3;
     const int tiles_n = (g.N + BN2 - 1) / BN2;
     const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
-    const int ksp = blockIdx.x / tiles;
-    const int bid = blockIdx.x - ksp * tiles;
+    const int lb = splitk_logical_block(g);
+    const int ksp = lb / tiles;
+    const int bid = lb - ksp * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM2, n0 = tn * BN2;
     const int KT = g.K / 64 / g.ksplit;
@@ -696,8 +710,9 @@ __global__ void __launch_bounds__(512, 1) gemm256_split_atn_splitk_kernel(const 
     const int wr = wid >> 2, wc = wid & 3;
     const int tiles_n = (g.N + BN2 - 1) / BN2;
     const int tiles = ((g.M + BM2 - 1) / BM2) * tiles_n;
-    const int ksp = blockIdx.x / tiles;
-    const int bid = blockIdx.x - ksp * tiles;
+    const int lb = splitk_logical_block(g);
+    const int ksp = lb / tiles;
+    const int bid = lb - ksp * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM2, n0 = tn * BN2;
     const int KT = g.K / 32 / g.ksplit;                  // K-tiles of 32 tokens in this slice (even, >= 2: checked by the entry)
@@ -782,8 +797,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_split_atn_kernel(const G
     const int wr = wid >> 2, wc = wid & 3;
     const int tiles_n = g.N / BN2;
     const int tiles = (g.M / BM2) * tiles_n;
-    const int ksp = blockIdx.x / (tiles * 9);
-    const int rem = blockIdx.x - ksp * tiles * 9;
+    const int lb = splitk_logical_block(g);
+    const int ksp = lb / (tiles * 9);
+    const int rem = lb - ksp * tiles * 9;
     const int tap = rem / tiles, bid = rem - tap * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM2, n0 = tn * BN2;
@@ -883,8 +899,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_tn_kernel(const GemmArgs
     const int ngroups = (9 + G - 1) / G;
     const int tiles_n = (g.N + BN2 - 1) / BN2;
     const int tiles = (G > 1 ? 1 : (Cin + BM2 - 1) / BM2) * tiles_n;
-    const int ksp = blockIdx.x / (tiles * ngroups);        // (k-slice, tap group, tile): the taps of a slice share X and dY through L2
-    const int rem = blockIdx.x - ksp * tiles * ngroups;
+    const int lb = splitk_logical_block(g);
+    const int ksp = lb / (tiles * ngroups);        // (k-slice, tap group, tile): the taps of a slice share X and dY through L2
+    const int rem = lb - ksp * tiles * ngroups;
     const int grp = rem / tiles, bid = rem - grp * tiles;
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM2, n0 = tn * BN2;
