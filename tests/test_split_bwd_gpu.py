@@ -473,3 +473,14 @@ def test_conv3x3_wgrad_split_stream_matches_float64(N, H, W, Cin, Cout, relu):
     assert _rel(db, dy.double().sum((0, 1, 2))) <= TOL
     dw9b, dbb = ops.conv3x3_wgrad_split_stream(dy, x, relu_in=relu)
     assert torch.equal(dw9, dw9b) and torch.equal(db, dbb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_im2col7x7_rgb_equals_unfold(dtype):
+    """vs_im2col7x7_rgb = F.unfold(frames.to(dtype), 7, padding=3).transpose(1, 2) padded with zero columns, bit for bit (a copy)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    fr = (torch.rand(3, 3, 20, 36, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(d)
+    got = ops.im2col7x7_rgb(fr, dtype, 256)
+    want = F.pad(F.unfold(fr.to(dtype).float(), 7, padding=3).transpose(1, 2), (0, 256 - 147)).to(dtype)
+    assert got.shape == (3, 20 * 36, 256) and torch.equal(got, want)

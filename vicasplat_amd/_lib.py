@@ -199,7 +199,8 @@ def lib() -> C.CDLL:
                            ("vs_head1x1_backward_split", [vp, i64, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
                            ("vs_head1x1_backward16", [vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
                            ("vs_conv3x3_wgrad_split_stream", [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-                           ("vs_stem7x7_up_split_stream", [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])):
+                           ("vs_stem7x7_up_split_stream", [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+                           ("vs_im2col7x7_rgb", [vp, vp, i32, i32, i32, i32, i32, vp])):
                 getattr(L, nm).restype = C.c_int
                 getattr(L, nm).argtypes = at
             if hasattr(L, "vs_raster_backward"):

@@ -13,6 +13,7 @@
 // Reference: torch autograd of nn.Linear / nn.Conv2d / F.gelu / F.interpolate in the reference's fp32 training step
 // (model_wrapper.py:184-321, config/experiment/re10k_8view.yaml:75-80).
 #include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -270,6 +271,39 @@ int transpose_f32_entry(const char *fn, bool pack, const float *in, int64_t ld_i
     return 0;
 }
 
+// im2col rows of the 7x7 / pad 3 RGB stem for the TRAINING path (the stem runs as a GEMM over these rows: train_forward.stem7x7): out[p, k] =
+// frames[n, c, y + ky - 3, x + kx - 3] (0 outside) for k = c * 49 + ky * 7 + kx < 147, zeros for 147 <= k < ld -- F.unfold + transpose + F.pad in
+// ONE pass (the three PyTorch passes moved 13.6 GB per 8-scene step for the 4.3 GB this writes).  One wave writes one pixel's ld = 256 columns.
+template <int OUT>   // 0 f32, 1 f16, 2 bf16
+__global__ void __launch_bounds__(256) im2col7x7_rgb_kernel(const float *__restrict__ fr, void *__restrict__ out, long long npix, int H, int W, int ld) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int per = ld >> 2;
+    const long long p = t / per;
+    if (p >= npix) return;
+    const int k0 = (int)(t - p * per) * 4;
+    const long long hw = (long long)H * W;
+    const long long n = p / hw, rem = p - n * hw;
+    const int y = (int)(rem / W), x = (int)(rem - (long long)y * W);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + i;
+        float a = 0.f;
+        if (k < 147) {
+            const int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
+            const int yy = y + ky - 3, xx = x + kx - 3;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) a = fr[((n * 3 + c) * H + yy) * W + xx];
+        }
+        v[i] = a;
+    }
+    if constexpr (OUT == 0) {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + p * ld + k0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(out) + p * ld + k0) =
+            make_uint2(pack16x2<OUT == 2 ? 1 : 0>(v[0], v[1]), pack16x2<OUT == 2 ? 1 : 0>(v[2], v[3]));
+    }
+}
+
 }  // namespace
 
 extern "C" int vs_transpose_f32(const float *in, int64_t ld_in, float *out, int64_t ld_out, int32_t R, int32_t C, int32_t Rpad, int32_t relu,
@@ -292,6 +326,22 @@ extern "C" int vs_split16(const float *in, int64_t ld_in, void *hi, void *lo, in
     const long long items = rows * (C / 4);
     hipLaunchKernelGGL(split16_kernel, dim3((unsigned)vs::cdiv64(items, 256)), dim3(256), 0, (hipStream_t)stream_, in, (long long)ld_in, (unsigned short *)hi,
                        (unsigned short *)lo, (long long)ld_out, (long long)rows, C / 4);
+    VS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vs_im2col7x7_rgb(const float *frames, void *out, int32_t N, int32_t H, int32_t W, int32_t ld, int32_t out_dtype, vs_stream_t stream_) {
+    VS_CHECK(frames && out && N >= 0 && H > 0 && W > 0, "vs_im2col7x7_rgb: null pointer / bad sizes");
+    VS_CHECK(ld >= 148 && ld % 4 == 0 && out_dtype >= 0 && out_dtype <= 2, "vs_im2col7x7_rgb: ld=%d must be a multiple of 4 covering 147 columns; out_dtype 0 f32 / 1 f16 / 2 bf16", ld);
+    VS_CHECK(((uintptr_t)out & 15) == 0, "vs_im2col7x7_rgb: out must be 16-byte aligned");
+    const long long npix = (long long)N * H * W, items = npix * (ld / 4);
+    if (items == 0) return 0;
+    VS_CHECK(vs::cdiv64(items, 256) < (1LL << 31), "vs_im2col7x7_rgb: too large");
+    dim3 grid((unsigned)vs::cdiv64(items, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream_;
+    if (out_dtype == 0) hipLaunchKernelGGL(im2col7x7_rgb_kernel<0>, grid, block, 0, s, frames, out, npix, H, W, ld);
+    else if (out_dtype == 1) hipLaunchKernelGGL(im2col7x7_rgb_kernel<1>, grid, block, 0, s, frames, out, npix, H, W, ld);
+    else hipLaunchKernelGGL(im2col7x7_rgb_kernel<2>, grid, block, 0, s, frames, out, npix, H, W, ld);
     VS_HIP(hipGetLastError());
     return 0;
 }

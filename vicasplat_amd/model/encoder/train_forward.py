@@ -18,8 +18,10 @@ import torch.nn.functional as F
 import torch.utils.checkpoint
 
 from ... import autograd as A
+from ... import ops
 
 LN_EPS = 1e-6
+_IM2COL = os.environ.get("VS_IM2COL", "1") != "0"            # 0: F.unfold + F.pad rows of the training stem (A/B runs)
 _HEAD_TAIL = os.environ.get("VS_HEAD_TAIL", "1") != "0"      # 0: the operator-by-operator backward of the heads' last 1x1 convolution (A/B runs)
 
 
@@ -176,9 +178,12 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     def stem7x7(name, fr):                                       # 7x7, pad 3 conv on the RGB frames as im2col rows + the MFMA GEMM
         w = P[name + ".weight"]                                  # [Cout, 3, 7, 7]
         n_, _, h_, w_ = fr.shape
-        f = lambda u: F.unfold(u.to(adt), 7, padding=3).transpose(1, 2)          # [n, h*w, 147] in (c, ky, kx) order = weight.flatten(1)
-        cols = chunked(f, fr, h_ * w_ * 147)
-        cols = F.pad(cols, (0, 256 - 147))     # 256 columns: whole tiles for the reduction-major weight-gradient kernel (no transposes)
+        if fr.requires_grad or fr.dtype != torch.float32 or not _IM2COL:      # a gradient for the image: torch differentiates unfold / pad
+            f = lambda u: F.unfold(u.to(adt), 7, padding=3).transpose(1, 2)          # [n, h*w, 147] in (c, ky, kx) order = weight.flatten(1)
+            cols = chunked(f, fr, h_ * w_ * 147)
+            cols = F.pad(cols, (0, 256 - 147))     # 256 columns: whole tiles for the reduction-major weight-gradient kernel (no transposes)
+        else:                                                  # the same rows written once, padded, by one HIP pass (vs_im2col7x7_rgb)
+            cols = ops.im2col7x7_rgb(fr.contiguous(), adt, 256)
         wk = F.pad(w.flatten(1), (0, 256 - 147))
         return A.linear(cols, wk, P.get(name + ".bias"), dt, scale_sources=(w,)).view(n_, h_, w_, w.shape[0])
 

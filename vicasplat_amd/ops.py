@@ -648,6 +648,19 @@ def conv7x7_rgb_nhwc(img_padded: torch.Tensor, w: torch.Tensor, bias: Optional[t
     return out
 
 
+def im2col7x7_rgb(frames: torch.Tensor, dtype: torch.dtype, ld: int = 256) -> torch.Tensor:
+    """frames [N,3,H,W] f32 -> [N, H*W, ld] rows of the 7x7 / pad 3 windows in (c, ky, kx) order (columns 147.. zero), `dtype` f32 / f16 / bf16:
+    F.unfold(frames.to(dtype), 7, padding=3).transpose(1, 2) padded to ld columns, in one pass (vs_im2col7x7_rgb)."""
+    dev = L.require_device(frames)
+    N, C, H, W = frames.shape
+    assert C == 3 and frames.dtype == torch.float32 and frames.is_contiguous() and ld % 4 == 0 and ld >= 148
+    out = torch.empty((N, H * W, ld), dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().vs_im2col7x7_rgb(L.ptr(frames), L.ptr(out), N, H, W, ld, {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype], L.stream_ptr(dev))
+    L.check(rc, "vs_im2col7x7_rgb")
+    return out
+
+
 def stem7x7_up_split_stream(img_padded: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, H: int, W: int, up_add: torch.Tensor, scale_exp: int):
     """conv7x7_rgb_nhwc(img_padded, pack(w), bias, H, W, up_add=up_add) of the split class as the streaming kernel (csrc/stem_stream.hip):
     w = the module's [256, 3, 7, 7] f32 parameter (packed in the kernel with 2^scale_exp), returns the packed SplitWeight [N,H,W,256]."""
