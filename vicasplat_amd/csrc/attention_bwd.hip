@@ -13,6 +13,8 @@
 // S and dP are recomputed in both kernels (7 instead of 5 MFMA products per (i, j) tile, no atomics on dQ).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -44,7 +46,20 @@ struct AttnBwdArgs {
     const float *o32, *dout32;
     float *dq32;
     int ldo32, lddo32, lddq32, kv_direct;
+    int xcd;     // 1: XCD-aware block ids (block_bhx): the tiles of one (batch, head) run behind ONE L2
 };
+
+// (tile, head, batch) of this workgroup.  The hardware deals consecutive workgroups (x fastest) to consecutive XCDs, which puts the tiles of one
+// (batch, head) -- they all read that head's whole K / V (dq kernels) or Q / dO (dk|dv kernels) -- behind eight different L2s (counters: 76 GB
+// fetched per 8-scene split training step for ~38 GB of operands).  With a.xcd consecutive LOGICAL ids share an XCD (gemm256_kernel's remap).
+__device__ __forceinline__ void block_bhx(const AttnBwdArgs &a, int &b, int &h, int &x) {
+    if (!a.xcd) { b = blockIdx.z; h = blockIdx.y; x = blockIdx.x; return; }
+    const int gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int q = n >> 3, r = n & 7, xc = lin & 7, idx = lin >> 3;
+    const int l = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + idx;
+    x = l % gx; const int t = l / gx; h = t % gy; b = t / gy;
+}
 
 template <bool BF16>
 __device__ __forceinline__ f4 mfma(const uint4 &a, const uint4 &b, f4 c) {
@@ -165,7 +180,9 @@ attn_bwd_dq_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2][2][TB * HD];   // [ring slot][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * NG);
+    int b, h, bx_;
+    block_bhx(a, b, h, bx_);
+    const int q0 = bx_ * (64 * NG);
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     const KeyList kl = key_list(a, b);
     bool qvalid[NG];
@@ -298,7 +315,9 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     __shared__ int s_minlen2[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * (64 * NG);
+    int b, h, bx_;
+    block_bhx(a, b, h, bx_);
+    const int kt0 = bx_ * (64 * NG);
     const KeyList kl = key_list(a, b);
     if (kt0 >= kl.Lk) return;
     int kj[NG], kg0[NG], nact = 0;              // position of this lane's key in the key list; first position of the group
@@ -514,7 +533,9 @@ attn_bwd_dq_split_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2][4][TB * HD];   // [ring slot][K hi | K lo | V hi | V lo]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * NG);
+    int b, h, bx_;
+    block_bhx(a, b, h, bx_);
+    const int q0 = bx_ * (64 * NG);
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)&smem[0][0][0];
     const KeyList kl = key_list(a, b);
     bool qvalid[NG];
@@ -624,7 +645,9 @@ attn_bwd_dkv_split_kernel(const AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) int sLen2[2][TB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * (64 * NG);
+    int b, h, bx_;
+    block_bhx(a, b, h, bx_);
+    const int kt0 = bx_ * (64 * NG);
     const KeyList kl = key_list(a, b);
     if (kt0 >= kl.Lk) return;
     int kj[NG], kg0[NG], nact = 0;
@@ -784,6 +807,7 @@ int attention_backward_impl(const void *q, const void *k, const void *v, const v
     VS_CHECK(kv_seg ? max_keys > 0 : Lk > 0, "vs_attention_backward: Lk (or max_keys with kv_seg) must be positive");
     if (nbatch == 0 || Lq == 0) return 0;
     AttnBwdArgs a;
+    { static const int x_ = [] { const char *e = getenv("VS_ATTN_BWD_XCD"); return e ? atoi(e) : 1; }(); a.xcd = x_; }
     a.q = (const unsigned short *)q; a.k = (const unsigned short *)k; a.v = (const unsigned short *)v;
     a.o = (const unsigned short *)o; a.dout = (const unsigned short *)dout; a.lse = lse; a.delta = delta;
     a.dq = (unsigned short *)dq; a.dk = dk; a.dv = dv; a.dk16 = (unsigned short *)dk16; a.dv16 = (unsigned short *)dv16; a.kv_seg = kv_seg; a.q_kvlen = q_kvlen;
@@ -859,6 +883,7 @@ extern "C" int vs_attention_backward_split(const void *q_hi, const void *q_lo, c
     VS_CHECK(kv_seg ? max_keys > 0 : Lk > 0, "vs_attention_backward_split: Lk (or max_keys with kv_seg) must be positive");
     if (nbatch == 0 || Lq == 0) return 0;
     AttnBwdArgs a;
+    { static const int x_ = [] { const char *e = getenv("VS_ATTN_BWD_XCD"); return e ? atoi(e) : 1; }(); a.xcd = x_; }
     a.q = (const unsigned short *)q_hi; a.k = (const unsigned short *)k_hi; a.v = (const unsigned short *)v_hi; a.dout = (const unsigned short *)do_hi;
     a.q_lo = (const unsigned short *)q_lo; a.k_lo = (const unsigned short *)k_lo; a.v_lo = (const unsigned short *)v_lo; a.dout_lo = (const unsigned short *)do_lo;
     a.o = nullptr; a.o32 = o; a.dout32 = dout; a.lse = lse; a.delta = delta;
