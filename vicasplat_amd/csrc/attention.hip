@@ -500,6 +500,7 @@ struct AttnArgsSplit {
     float scale_log2e;
     float *lse;
     int out_packed;   // write O in the packed (hi, lo) form of the split class (the A operand of the projection GEMM: vs_gemm_split_packed)
+    int xcd;          // 1: XCD-aware (tile, head, batch) ids: the query tiles of one (batch, head) read its K / V behind ONE L2 (attention_bwd.hip block_bhx)
 };
 
 // four consecutive columns n .. n + 3 of an f32 row written in the packed (hi, lo) layout of vs_split_pack_weight (gemm_common.h, store_split4)
@@ -548,7 +549,15 @@ __global__ void __launch_bounds__(256, 2) attention_split_kernel(const AttnArgsS
     __shared__ int s_maxlen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QBLK;
+    int b = blockIdx.z, h = blockIdx.y, bx_ = blockIdx.x;
+    if (a.xcd) {      // consecutive workgroups are dealt to consecutive XCDs: make consecutive LOGICAL ids share one (gemm256_kernel's remap)
+        const int gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int q_ = n >> 3, r_ = n & 7, xc = lin & 7, idx = lin >> 3;
+        const int l = (xc < r_ ? xc * (q_ + 1) : r_ * (q_ + 1) + (xc - r_) * q_) + idx;
+        bx_ = l % gx; const int t_ = l / gx; h = t_ % gy; b = t_ / gy;
+    }
+    const int q0 = bx_ * QBLK;
 
     int base0, len0, base1, len1;
     if (a.kv_seg) {
@@ -1299,6 +1308,7 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
             return 0;
         }
         AttnArgsSplit f;
+        { static const int x_ = [] { const char *e = getenv("VS_ATTN_SPLIT_XCD"); return e ? atoi(e) : 1; }(); f.xcd = x_; }
         f.q = (const float *)q; f.k = (const float *)k; f.v = (const float *)v; f.out = (float *)out; f.kv_seg = kv_seg; f.q_kvlen = q_kvlen;
         f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
         f.ldq = ldq; f.ldk = ldk; f.ldv = ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse; f.out_packed = out_packed;
