@@ -493,7 +493,7 @@ int vs_gated_resid_backward_f32(const float *dout, const float *y, int64_t ldy, 
 int vs_upsample2x_backward_f32_nhwc(const float *dout, float *din, int32_t Nimg, int32_t H, int32_t W, int32_t C, vs_stream_t stream);
 /* im2col rows of the Gaussian-parameter head's 7x7 / pad 3 RGB stem (dpt_gs_head.py:112-118) for the training path, where the stem runs as a GEMM
  * over them: out[p, k] = frames[n, c, y + ky - 3, x + kx - 3] (zero outside the image) for k = c * 49 + ky * 7 + kx < 147 (= weight.flatten(1) order),
- * zeros for 147 <= k < ld.  frames [N, 3, H, W] f32 contiguous; out [N*H*W, ld] in out_dtype (0 f32, 1 f16, 2 bf16), ld % 4 == 0, 16-byte aligned.
+ * zeros for 147 <= k < ld.  frames [N, 3, H, W] f32 contiguous; out [N*H*W, ld] in out_dtype (0 f32, 1 f16, 2 bf16), ld % 8 == 0, 16-byte aligned.
  * F.unfold(..., 7, padding=3).transpose(1, 2) + F.pad in one pass. */
 int vs_im2col7x7_rgb(const float *frames, void *out, int32_t N, int32_t H, int32_t W, int32_t ld, int32_t out_dtype, vs_stream_t stream);
 /* Backward of the LAST 1x1 convolution of a DPT head fused with the ReLU backward of its input (split class, one pass over the full-resolution

@@ -653,7 +653,7 @@ def im2col7x7_rgb(frames: torch.Tensor, dtype: torch.dtype, ld: int = 256) -> to
     F.unfold(frames.to(dtype), 7, padding=3).transpose(1, 2) padded to ld columns, in one pass (vs_im2col7x7_rgb)."""
     dev = L.require_device(frames)
     N, C, H, W = frames.shape
-    assert C == 3 and frames.dtype == torch.float32 and frames.is_contiguous() and ld % 4 == 0 and ld >= 148
+    assert C == 3 and frames.dtype == torch.float32 and frames.is_contiguous() and ld % 8 == 0 and ld >= 148
     out = torch.empty((N, H * W, ld), dtype=dtype, device=dev)
     with torch.cuda.device(dev):
         rc = L.lib().vs_im2col7x7_rgb(L.ptr(frames), L.ptr(out), N, H, W, ld, {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype], L.stream_ptr(dev))
