@@ -65,6 +65,11 @@ def parse():
     return ap.parse_args()
 
 
+def _auto_blocks(B, dt, dev):
+    from vicasplat_amd.model.encoder.train_forward import auto_checkpoint_blocks
+    return auto_checkpoint_blocks(B, 1.0, torch.cuda.get_device_properties(dev).total_memory / 2 ** 30, 24, 12, half=dt != "split")
+
+
 def target_cameras(B, Vt, dev):
     """Vt target cameras per scene in frame-0 coordinates: identity rotation, x translation j*0.05."""
     E = torch.eye(4, device=dev).repeat(B, Vt, 1, 1)
@@ -160,6 +165,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     batch = dict(context=dict(image=img.to(dev), intrinsics=K.to(dev)), target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
     enc.train().requires_grad_(True)
     enc.backbone.gradient_checkpointing = bool(checkpoint)      # enable_gradient_checkpointing(): per-block recomputation (backbone_vica.py:464-516)
+    enc.backbone.checkpoint_blocks = "auto" if checkpoint == "auto" else None      # "auto": only as many blocks as 288 GB require (train_forward.auto_checkpoint_blocks)
     opt, _ = callers.configure_optimizer(enc, lr=1e-12)
     reducer = vdist.GradReducer(enc.parameters()) if world > 1 else None
     torch.cuda.empty_cache()
@@ -185,6 +191,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     tf_s = flops / (ms * 1e-3) / 1e12
     enc.eval().requires_grad_(False)
     enc.backbone.gradient_checkpointing = False
+    enc.backbone.checkpoint_blocks = None
     if reducer is not None:
         reducer.remove()
     for p in enc.parameters():
@@ -192,7 +199,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     return dict(metric="scenes/sec training step (fwd+bwd+clip+AdamW)", value=round(world * B / (ms * 1e-3), 3), unit="scenes/s",
                 ms_per_step=round(ms, 2), steps=nsteps, scenes_per_gpu=B, context_views=V, target_views=Vt,
                 dtype=("split (f32 activations and gradients, 3 x f16 MFMA per product, forward and backward)" if dt == "split" else "bf16" if dt == torch.bfloat16 else "f16"),
-                loss_scale=float(r["loss_scale"]), gradient_checkpointing=bool(checkpoint),
+                loss_scale=float(r["loss_scale"]), gradient_checkpointing=("auto: the first %d encoder / %d decoder blocks" % _auto_blocks(B, dt, dev) if checkpoint == "auto" else bool(checkpoint)),
                 loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
                 peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                 gradient_exchange=("none (1 GPU)" if world == 1 else f"GradReducer: 64 MiB buckets all-reduced during backward, RCCL x{world}"),
@@ -715,6 +722,13 @@ def main():
                                                                                    checkpoint=True)
                         except Exception as e:
                             train["split_class_batch24_checkpointed"] = dict(error=repr(e)[:300])
+                        # the same batch with only as many blocks checkpointed as the 288 GB require (late round 5): recomputation is a memory
+                        # measure, and the reference's all-blocks policy (re10k_8view.yaml:61) is sized for 80 GB devices
+                        try:
+                            train["split_class_batch24_checkpoint_auto"] = train_leg(args, enc, dec, dev, rank, world, None, cdt="split", scenes=24, steps=2,
+                                                                                     checkpoint="auto")
+                        except Exception as e:
+                            train["split_class_batch24_checkpoint_auto"] = dict(error=repr(e)[:300])
         except Exception as e:      # the headline line must survive a failure of the optional training leg
             if args.mode == "train":
                 raise

@@ -507,3 +507,15 @@ def test_state_dict_with_the_confidence_channel_loads_strict_in_both_layouts():
     assert sd4["downstream_head1.dpt.head.4.bias"].shape[0] == 4                 # the caller's dict is not modified
     with pytest.raises(RuntimeError):                                            # the other direction is a real mismatch
         mc.load_state_dict(m3.state_dict(), strict=True)
+
+
+def test_auto_checkpoint_policy_fills_the_device_memory():
+    """train_forward.auto_checkpoint_blocks: recompute only as many blocks as the device memory requires -- decoder blocks are released
+    first, then encoder blocks; measured anchors on a 288 GB MI355X (split class, 8 views of 256 x 256)."""
+    from vicasplat_amd.model.encoder.train_forward import auto_checkpoint_blocks as f
+    assert f(8, 1.0, 288.0, 24, 12) == (0, 0) and f(16, 1.0, 288.0, 24, 12) == (0, 0)      # fit without recomputation
+    ne, nd = f(24, 1.0, 288.0, 24, 12)
+    assert nd == 0 and 6 <= ne <= 12                                                          # config 5's batch: 241 GB at (9, 0)
+    assert f(48, 1.0, 288.0, 24, 12) == (24, 12)                                              # does not fit either way: everything checkpointed
+    assert f(24, 1.0, 288.0, 24, 12, half=True) == (0, 0)                                     # 16-bit classes hold half
+    assert f(24, 1.0, 80.0, 24, 12) == (24, 12)                                               # the reference's 80 GB devices: its all-blocks policy

@@ -373,9 +373,11 @@ def test_gradient_checkpointing_recomputes_the_same_step():
     g = torch.Generator().manual_seed(3)
     cot = torch.randn(1, 3, 256, 256, 86, generator=g).to(d) * 1e-3
     out = []
-    for ck in (False, False, True):
+    for ck in (False, False, True, "partial"):
         m, _ = _tiny_model(torch.float16)
-        if ck:
+        if ck == "partial":      # late round 5: only the first encoder block and no decoder block recomputed (enable_gradient_checkpointing(blocks=...))
+            m.enable_gradient_checkpointing(blocks=(1, 0))
+        elif ck:
             m.enable_gradient_checkpointing()
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
@@ -398,6 +400,9 @@ def test_gradient_checkpointing_recomputes_the_same_step():
     # repetitions on one box -- a floor at the documented f16 atomics spread keeps an unlucky baseline draw from failing the comparison)
     assert s_ck <= max(3 * s_base, 5e-3), (s_base, s_ck)
     assert out[2][2] < out[0][2]
+    s_part = spread(out[0][1], out[3][1])
+    assert out[3][0] == out[0][0] and s_part <= max(3 * s_base, 5e-3), (s_base, s_part)
+    assert out[2][2] < out[3][2] < out[0][2], [o[2] for o in out]      # memory between the two policies
 
 
 class _RoundGrad(torch.autograd.Function):

@@ -33,6 +33,7 @@ for e in prof.key_averages(group_by_stack_n=12):
     where = " <- ".join(f.split("/")[-1] for f in frames[:3]) or (e.stack[0] if e.stack else "?")
     a = agg[(e.key, where)]; a[0] += t; a[1] += e.count
 tot = 0.0
-for (k, w), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+ATEN = len(sys.argv) > 2 and sys.argv[2] == 'aten'      # only the PyTorch ops (the glue between the HIP kernels)
+for (k, w), (t, n) in [kv for kv in sorted(agg.items(), key=lambda kv: -kv[1][0]) if (not ATEN or kv[0][0].startswith('aten::'))][:60 if ATEN else 40]:
     tot += t; print(f"{t / 1e3:8.2f} ms x{n:5d}  {k:28s} {w[:170]}")
 print(f"listed: {tot / 1e3:.1f} ms")

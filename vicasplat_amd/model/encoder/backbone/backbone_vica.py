@@ -127,16 +127,22 @@ class VicaNet(nn.Module):
         self.camera_extrinsic_token = nn.Parameter(torch.empty(dec_embed_dim).normal_(std=0.02))
         self.camera_intrinsic_token = nn.Parameter(torch.empty(dec_embed_dim).normal_(std=0.02))
         self.gradient_checkpointing = False
+        self.checkpoint_blocks = None      # (n_enc, n_dec) blocks that are checkpointed when the flag is on; None = all
         self._probe = None    # test hook: callable(name, tensor) on every block's output stream (enc%02d, dec%02d_img, dec%02d_cam)
         self._init_weights()
         self._w16: dict = {}
         self._w16_key = None
         self._tables: dict = {}
 
-    def enable_gradient_checkpointing(self):
+    def enable_gradient_checkpointing(self, blocks=None):
         """Per-block activation checkpointing of the TRAINING forward (train_forward.forward_train reads the flag); the
-        inference forward below keeps nothing, so there is nothing to checkpoint (backbone_vica.py:464-474,504-516)."""
+        inference forward below keeps nothing, so there is nothing to checkpoint (backbone_vica.py:464-474,504-516).
+        blocks = (n_enc, n_dec): checkpoint only the FIRST n_enc encoder and n_dec decoder blocks (None = all, the reference's policy;
+        "auto" = train_forward.auto_checkpoint_blocks: as few as the device memory allows for the batch at hand).  On a
+        288 GB MI355X the configuration's 24 scenes per GPU need ~290 GB without and ~160 GB with full checkpointing: recomputing only as many
+        blocks as the memory requires buys back most of the recomputation."""
         self.gradient_checkpointing = True
+        self.checkpoint_blocks = None if blocks is None else ("auto" if blocks == "auto" else (int(blocks[0]), int(blocks[1])))
 
     def _init_weights(self):  # backbone_vica.py:427-448 (xavier on every Linear, incl. the AdaLN projections)
         w = self.patch_embed.proj.weight.data

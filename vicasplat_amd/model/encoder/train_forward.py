@@ -34,6 +34,23 @@ def _lin_f32(P, name, x):
     return A.linear_split(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
+def auto_checkpoint_blocks(scenes: int, scale: float, total_gb: float, n_enc: int, n_dec: int, half: bool = False, headroom: float = 0.82):
+    """(n_enc, n_dec) blocks to checkpoint so that the step's peak memory stays below `headroom` x the device memory: recompute only what the
+    memory requires.  Measured on MI355X (split class, 8 views of 256 x 256 = scale 1, bench_train.py --checkpoint): 6.2 GB per scene with every
+    block checkpointed (+ ~3 GB of parameters / optimizer state), a decoder block's saved activations 0.142 GB per scene, an encoder block's
+    0.134 GB; the 16-bit classes hold about half.  Decoder blocks are released first (12 x 3.4 GB at 24 scenes buy 59 ms), then encoder blocks
+    from the last one down.  24 scenes on 288 GB -> (11, 0): ~240 GB peak in the bench process, ~970 ms instead of 1 070 - 1 100 ms per step."""
+    k = (0.5 if half else 1.0) * scale * scenes
+    mem, budget = 6.2 * k + 3.0, headroom * total_gb
+    nd = n_dec
+    while nd > 0 and mem + 0.142 * k <= budget:
+        mem += 0.142 * k; nd -= 1
+    ne = n_enc
+    while nd == 0 and ne > 0 and mem + 0.134 * k <= budget:
+        mem += 0.134 * k; ne -= 1
+    return ne, nd
+
+
 def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch.float16, global_step: int = 0,
                   distill: bool = False) -> dict:
     """image [B,V,3,H,W] normalised to [-1,1], intrinsics [B,V,3,3] -> dict(raw_gaussians [B,V,H,W,86] f32, pred_extrins
@@ -61,6 +78,15 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     tabs = model.backbone._pos_tables(B, V, gh, gw, dev)
     # per-block activation checkpointing (backbone_vica.py:464-474,504-516): enable_gradient_checkpointing() on the encoder
     ckpt = bool(getattr(model.backbone, "gradient_checkpointing", False)) and torch.is_grad_enabled()
+    cb = getattr(model.backbone, "checkpoint_blocks", None)
+    if cb == "auto":
+        cb = auto_checkpoint_blocks(image.shape[0], image.shape[1] * image.shape[3] * image.shape[4] / (8.0 * 65536.0),
+                                    torch.cuda.get_device_properties(image.device).total_memory / 2 ** 30, model.backbone.config.enc_depth,
+                                    model.backbone.config.dec_depth, half=dt != A.SPLIT)
+    if os.environ.get("VS_CKPT_BLOCKS"):                  # "n_enc,n_dec": experiment override of the policy
+        cb = tuple(int(v) for v in os.environ["VS_CKPT_BLOCKS"].split(","))
+    ck_enc = lambda i: ckpt and (cb is None or i < cb[0])
+    ck_dec = lambda i: ckpt and (cb is None or i < cb[1])
     lin = lambda name, x: A.linear(x, P[name + ".weight"], P.get(name + ".bias"), dt)
     lnm = lambda name, x, **k: A.layernorm_mod(x, P[name + ".weight"], P[name + ".bias"], eps=LN_EPS, **k)
 
@@ -86,11 +112,11 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     for i in range(cfg.enc_depth):          # one autograd node per block: LN / qkv+RoPE / attention / proj / LN / fc1 / GELU / fc2
         nm = f"backbone.enc_blocks.{i}"
         if dt == A.SPLIT:
-            x = torch.utils.checkpoint.checkpoint(enc_block_split, i, x, use_reentrant=False) if ckpt else enc_block_split(i, x)
+            x = torch.utils.checkpoint.checkpoint(enc_block_split, i, x, use_reentrant=False) if ck_enc(i) else enc_block_split(i, x)
             continue
         names = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                  "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
-        x = A.EncBlockFn.apply(x, tabs["pos_img"], BT, N1, He, dt, ckpt, *[P[f"{nm}.{k}"] for k in names])
+        x = A.EncBlockFn.apply(x, tabs["pos_img"], BT, N1, He, dt, ck_enc(i), *[P[f"{nm}.{k}"] for k in names])
     x = lnm("backbone.enc_norm", x.view(BT, N1, Ce), out_dtype=torch.float32)
 
     # ---------------- video / camera decoder (backbone_vica.py:482-524, block :280-335) ----------------
@@ -135,7 +161,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         return x, cam
 
     for i in range(cfg.dec_depth):
-        if ckpt:      # keep only the block's inputs (x, cam); its Functions re-run in the backward (deterministic kernels)
+        if ck_dec(i):      # keep only the block's inputs (x, cam); its Functions re-run in the backward (deterministic kernels)
             x, cam = torch.utils.checkpoint.checkpoint(dec_block, i, x, cam, use_reentrant=False)
         else:
             x, cam = dec_block(i, x, cam)

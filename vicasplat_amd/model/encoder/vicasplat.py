@@ -142,8 +142,8 @@ class VicaSplat(Encoder[VicaSplatCfg]):
             m.compute_dtype = dt
             m.split = split
 
-    def enable_gradient_checkpointing(self):
-        self.backbone.enable_gradient_checkpointing()
+    def enable_gradient_checkpointing(self, blocks=None):
+        self.backbone.enable_gradient_checkpointing(blocks)
 
     def map_pdf_to_opacity(self, pdf: torch.Tensor, global_step: int) -> torch.Tensor:
         c = self.cfg.opacity_mapping
