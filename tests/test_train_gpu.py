@@ -328,7 +328,8 @@ def test_config4_full_size_training_step(cdt):
     assert abs(res[0][2] - res[1][2]) <= 1e-4 * res[0][2], res                 # gradient norm: f32 atomics re-associate
 
 
-def test_config5_per_gpu_batch_split_class_checkpointed():
+@pytest.mark.parametrize("blocks", [None, "auto"])
+def test_config5_per_gpu_batch_split_class_checkpointed(blocks):
     """BASELINE config 5's per-GPU work item under the test record: 24 scenes per GPU (README.md:104, re10k_8view:
     batch 24 on 8 GPUs), 8 context + 12 target views, the reference's precision (split class: f32 activations and gradients) with
     enable_gradient_checkpointing() -- the reference trains with it on (re10k_8view.yaml:61), and 24 scenes only fit 288 GB that way.
@@ -342,7 +343,8 @@ def test_config5_per_gpu_batch_split_class_checkpointed():
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], False)).to(d)
     batch = _config4_batch(24, 8, 12, d, with_extrinsics=True)
     m = _full_model("split")
-    m.enable_gradient_checkpointing()
+    # None: the reference's policy (every block recomputed); "auto" (late round 5): only as many blocks as the 288 GB require
+    m.enable_gradient_checkpointing(blocks)
     opt, sched = callers.configure_optimizer(m, lr=4e-5, backbone_lr_multiplier=0.25, warm_up_steps=100)
     reducer = vdist.GradReducer(m.parameters())
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
@@ -350,14 +352,16 @@ def test_config5_per_gpu_batch_split_class_checkpointed():
     r = callers.training_step(m, dec, batch, opt, scheduler=sched, camera_weight=1.0, compute_dtype="split", reducer=reducer)
     torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    print(f"config 5 per-GPU step [split, checkpointed, 24 scenes]: loss {float(r['loss']):.6f} grad_norm {float(r['grad_norm']):.4f} peak {peak:.1f} GB")
+    print(f"config 5 per-GPU step [split, checkpointed ({blocks or 'all blocks'}), 24 scenes]: loss {float(r['loss']):.6f} grad_norm {float(r['grad_norm']):.4f} peak {peak:.1f} GB")
     assert not r["skipped"] and torch.isfinite(r["loss"]) and torch.isfinite(r["grad_norm"]) and float(r["grad_norm"]) > 0, r
     unreached = [n for n, p in m.named_parameters() if p.grad is None]
     assert unreached and all("refinenet4.resConfUnit1" in n for n in unreached), unreached[:5]
     same = [n for n, p in m.named_parameters() if p.grad is not None and torch.equal(before[n], p.detach())]
     assert not same, same[:10]
-    assert peak < 260.0, peak
+    assert peak < 262.0, peak
     reducer.remove()
+    del m, opt, reducer, before, batch
+    torch.cuda.empty_cache()
 
 
 def test_gradient_checkpointing_recomputes_the_same_step():
