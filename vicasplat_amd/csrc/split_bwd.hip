@@ -117,6 +117,62 @@ transpose_f32_kernel(const float *__restrict__ in, long long ld_in, void *__rest
     }
 }
 
+// The plain form of the packing transpose (no convolution tap; C a multiple of 64, 16-byte aligned rows) -- the dY^T operand of every linear /
+// 1x1 weight gradient of the split-class training step.  TR x 64 tile; the (hi, lo) conversion and the store take one 8-half CHUNK per
+// thread (rows {4g..4g+3, 16+4g..16+4g+3} of a 32-row block: 8 LDS reads -> one 16-byte hi store + one 16-byte lo store; four lanes fill
+// the 64 + 64 bytes of a block), LDS rows of 66 words (the chunk reads of 32 lanes fall into 32 different banks), the bias gradient summed
+// from the registers of the load phase (two DPP steps + one LDS row per wave) instead of a second walk over the tile.
+// RFAST: consecutive workgroups walk DOWN the rows of one 64-column band (their stores extend the same output rows).
+template <int TR, bool RFAST>
+__global__ void __launch_bounds__(256)
+transpose_pack_plain_kernel(const float *__restrict__ in, long long ld_in, unsigned short *__restrict__ out, long long ld_out, int R, int C, int Rpad,
+                            int relu, float scale, float *__restrict__ colsum) {
+    constexpr int S = 66;
+    __shared__ float t[TR][S];
+    __shared__ float cs[4][64];
+    const int tiles_c = C >> 6, tiles_r = Rpad / TR;
+    const int r0 = (RFAST ? (int)(blockIdx.x % tiles_r) : (int)(blockIdx.x / tiles_c)) * TR;
+    const int c0 = (RFAST ? (int)(blockIdx.x / tiles_r) : (int)(blockIdx.x % tiles_c)) * 64;
+    const int c4 = (threadIdx.x & 15) * 4;
+    float4 v[TR / 16];
+#pragma unroll
+    for (int i = 0; i < TR / 16; ++i) {
+        const int r = r0 + (int)(threadIdx.x >> 4) + 16 * i;
+        v[i] = r < R ? *reinterpret_cast<const float4 *>(in + (long long)r * ld_in + c0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TR / 16; ++i) {
+        float4 w = v[i];
+        if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        sum.x += w.x; sum.y += w.y; sum.z += w.z; sum.w += w.w;
+        float *p = &t[(threadIdx.x >> 4) + 16 * i][c4];
+        *reinterpret_cast<float2 *>(p) = make_float2(w.x * scale, w.y * scale);
+        *reinterpret_cast<float2 *>(p + 2) = make_float2(w.z * scale, w.w * scale);
+    }
+    if (colsum) {
+        sum.x += __shfl_xor(sum.x, 16); sum.y += __shfl_xor(sum.y, 16); sum.z += __shfl_xor(sum.z, 16); sum.w += __shfl_xor(sum.w, 16);
+        sum.x += __shfl_xor(sum.x, 32); sum.y += __shfl_xor(sum.y, 32); sum.z += __shfl_xor(sum.z, 32); sum.w += __shfl_xor(sum.w, 32);
+        if ((threadIdx.x & 63) < 16) *reinterpret_cast<float4 *>(&cs[threadIdx.x >> 6][c4]) = sum;
+    }
+    __syncthreads();
+    if (colsum && threadIdx.x < 64) unsafeAtomicAdd(colsum + c0 + threadIdx.x, (cs[0][threadIdx.x] + cs[1][threadIdx.x]) + (cs[2][threadIdx.x] + cs[3][threadIdx.x]));
+#pragma unroll
+    for (int i = 0; i < TR / 32; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int g = idx & 3, cc = (idx >> 2) & 63, blk = idx >> 8;
+        const int rb = blk * 32 + 4 * g;
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        split_pair(t[rb][cc], t[rb + 1][cc], h0, l0);
+        split_pair(t[rb + 2][cc], t[rb + 3][cc], h1, l1);
+        split_pair(t[rb + 16][cc], t[rb + 17][cc], h2, l2);
+        split_pair(t[rb + 18][cc], t[rb + 19][cc], h3, l3);
+        unsigned short *o = out + (long long)(c0 + cc) * (2 * ld_out) + ((long long)(r0 >> 5) + blk) * 64 + g * 8;
+        *reinterpret_cast<uint4 *>(o) = make_uint4(h0, h1, h2, h3);
+        *reinterpret_cast<uint4 *>(o + 32) = make_uint4(l0, l1, l2, l3);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 split16_kernel(const float *__restrict__ in, long long ld_in, unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, long long ld_out,
                long long rows, int C4) {
@@ -265,6 +321,25 @@ int transpose_f32_entry(const char *fn, bool pack, const float *in, int64_t ld_i
     VS_CHECK(nblk <= 0x7fffffffLL, "%s: too many tiles", fn);
     dim3 grid((unsigned)nblk), block(256);
     const float scale = ldexpf(1.0f, scale_exp);
+    // plain packing transposes (every linear / 1x1 weight gradient's dY^T) take the chunk-store kernel; VS_TP_PLAIN = 0 / 64 / 128 / 256 (rows per
+    // tile) and VS_TP_RFAST for the A/B
+    if (pack && cH == 0 && C % 64 == 0 && ld_in % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const char *e = getenv("VS_TP_PLAIN"), *e2 = getenv("VS_TP_RFAST");
+        int tr = e ? atoi(e) : 128;
+        const bool rfast = e2 ? atoi(e2) != 0 : false;
+        while (tr > 64 && Rpad % tr != 0) tr >>= 1;
+        if (tr == 64 || tr == 128 || tr == 256) {
+            dim3 g2((unsigned)((long long)(C / 64) * (Rpad / tr)));
+            unsigned short *o16 = reinterpret_cast<unsigned short *>(out);
+#define VS_TP(TR_, RF_) hipLaunchKernelGGL((transpose_pack_plain_kernel<TR_, RF_>), g2, block, 0, stream, in, (long long)ld_in, o16, (long long)ld_out, R, C, Rpad, relu, scale, colsum)
+            if (tr == 64) { if (rfast) VS_TP(64, true); else VS_TP(64, false); }
+            else if (tr == 128) { if (rfast) VS_TP(128, true); else VS_TP(128, false); }
+            else { if (rfast) VS_TP(256, true); else VS_TP(256, false); }
+#undef VS_TP
+            VS_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (pack) hipLaunchKernelGGL(transpose_f32_kernel<true>, grid, block, 0, stream, in, (long long)ld_in, out, (long long)ld_out, R, C, relu, cH, cW, dy, dx, scale, colsum);
     else hipLaunchKernelGGL(transpose_f32_kernel<false>, grid, block, 0, stream, in, (long long)ld_in, out, (long long)ld_out, R, C, relu, cH, cW, dy, dx, scale, colsum);
     VS_HIP(hipGetLastError());
