@@ -756,7 +756,6 @@ struct AttnArgsSP {
     float scale_log2e;
     float *lse;
     int out_packed;
-    int early_dma;
 };
 
 typedef void __attribute__((address_space(3))) *lds_ptr_sp_t;
@@ -926,43 +925,6 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
     }
     const int Lk = len0 + len1;
 
-    // ---- staging: per tile 16 pieces of 1 KiB (4 key rows) for K and for V; wave w issues pieces w, w + 4, w + 8, w + 12 of each.  Lane l of
-    // a piece = (row l >> 4, LDS slot l & 15); (row & 15) == (w * 4 + (l >> 4)) & 15 for every piece of this wave, so the swizzled source
-    // chunk is a per-thread constant
-    const int r0 = wid * 4 + (lane >> 4);
-    const int kchunk = (lane & 15) ^ (r0 & 15);
-    const int vchunk = ((((lane & 15) >> 1) ^ (r0 & 7)) << 1) | (lane & 1);
-    const unsigned char *kbase = a.k + h * 256 + kchunk * 16, *vbase = a.v + h * 256 + vchunk * 16;
-    auto key_row = [&](int j) -> long long {
-        j = min(j, Lk - 1);
-        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
-    };
-    auto issue = [&](int kt, int slot) {
-        const unsigned ldsk = lds0 + (unsigned)(slot * 2) * TILE_B + (unsigned)wid * 1024u, ldsv = ldsk + TILE_B;
-        long long rowbase = -1;                  // whole tile inside one segment (and inside the list): rows are base + r
-        if (kt + KB <= len0) rowbase = (long long)base0 + kt;
-        else if (kt >= len0 && kt + KB <= Lk) rowbase = (long long)base1 + (kt - len0);
-        if (rowbase >= 0) {
-            const unsigned char *kp = kbase + (rowbase + r0) * a.ldk_b, *vp = vbase + (rowbase + r0) * a.ldv_b;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                glds16_sp(kp + (long long)j * 16 * a.ldk_b, __builtin_amdgcn_readfirstlane(ldsk + (unsigned)j * 4096u));
-                glds16_sp(vp + (long long)j * 16 * a.ldv_b, __builtin_amdgcn_readfirstlane(ldsv + (unsigned)j * 4096u));
-            }
-        } else {                                 // a tile that straddles the segment boundary or the end of the list: per-row lookup
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long long r = key_row(kt + j * 16 + r0);
-                glds16_sp(kbase + r * a.ldk_b, __builtin_amdgcn_readfirstlane(ldsk + (unsigned)j * 4096u));
-                glds16_sp(vbase + r * a.ldv_b, __builtin_amdgcn_readfirstlane(ldsv + (unsigned)j * 4096u));
-            }
-        }
-    };
-    // The first tile's DMA goes out BEFORE the Q loads (it depends on nothing they return): a short-sequence workgroup (257 keys = five tiles)
-    // otherwise starts with two dependent memory round trips, Q then tile 0; VS_ATTN_EARLY_DMA=0 restores that order for the A/B.  The wait the
-    // compiler places for the Q fragments below (vmcnt counts in issue order) then covers tile 0 as well.
-    if (a.early_dma && Lk > 0) issue(0, 0);
-
     // ---- Q fragments: straight from the packed rows (hi chunk g, lo chunk g of the head's two 32-column blocks)
     int my_len[NG];
     uint4 qfh[NG][2], qfl[NG][2];
@@ -1021,7 +983,39 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
         for (int i = 0; i < 4; ++i) o[u][i] = f4{0.f, 0.f, 0.f, 0.f};
     }
 
-    if (!a.early_dma && maxlen > 0) issue(0, 0);
+    // ---- staging: per tile 16 pieces of 1 KiB (4 key rows) for K and for V; wave w issues pieces w, w + 4, w + 8, w + 12 of each.  Lane l of
+    // a piece = (row l >> 4, LDS slot l & 15); (row & 15) == (w * 4 + (l >> 4)) & 15 for every piece of this wave, so the swizzled source
+    // chunk is a per-thread constant
+    const int r0 = wid * 4 + (lane >> 4);
+    const int kchunk = (lane & 15) ^ (r0 & 15);
+    const int vchunk = ((((lane & 15) >> 1) ^ (r0 & 7)) << 1) | (lane & 1);
+    const unsigned char *kbase = a.k + h * 256 + kchunk * 16, *vbase = a.v + h * 256 + vchunk * 16;
+    auto key_row = [&](int j) -> long long {
+        j = min(j, Lk - 1);
+        return j < len0 ? (long long)base0 + j : (long long)base1 + (j - len0);
+    };
+    auto issue = [&](int kt, int slot) {
+        const unsigned ldsk = lds0 + (unsigned)(slot * 2) * TILE_B + (unsigned)wid * 1024u, ldsv = ldsk + TILE_B;
+        long long rowbase = -1;                  // whole tile inside one segment (and inside the list): rows are base + r
+        if (kt + KB <= len0) rowbase = (long long)base0 + kt;
+        else if (kt >= len0 && kt + KB <= Lk) rowbase = (long long)base1 + (kt - len0);
+        if (rowbase >= 0) {
+            const unsigned char *kp = kbase + (rowbase + r0) * a.ldk_b, *vp = vbase + (rowbase + r0) * a.ldv_b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16_sp(kp + (long long)j * 16 * a.ldk_b, __builtin_amdgcn_readfirstlane(ldsk + (unsigned)j * 4096u));
+                glds16_sp(vp + (long long)j * 16 * a.ldv_b, __builtin_amdgcn_readfirstlane(ldsv + (unsigned)j * 4096u));
+            }
+        } else {                                 // a tile that straddles the segment boundary or the end of the list: per-row lookup
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long r = key_row(kt + j * 16 + r0);
+                glds16_sp(kbase + r * a.ldk_b, __builtin_amdgcn_readfirstlane(ldsk + (unsigned)j * 4096u));
+                glds16_sp(vbase + r * a.ldv_b, __builtin_amdgcn_readfirstlane(ldsv + (unsigned)j * 4096u));
+            }
+        }
+    };
+    if (maxlen > 0) issue(0, 0);
 
     // ---- loop-invariant LDS offsets of this lane's fragments (bytes inside a K / V tile, swizzle applied)
     const int kw = kh * 32;                       // this wave's keys inside a tile
@@ -1059,7 +1053,6 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
         tile(kt + KB, &smem[1][0][0], &smem[1][1][0]);
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (an early tile-0 DMA of a workgroup whose queries see no key at all)
     // ---- merge the two key halves of every query (once): the kh = 1 wave hands (m, l, O) to its kh = 0 partner through LDS
 #pragma unroll
     for (int u = 0; u < NG; ++u) l_run[u] = rows_sum(l_run[u]);       // the per-lane partial sums of a query column meet here, once
@@ -1115,6 +1108,10 @@ __global__ void __launch_bounds__(256, 2) attention_sp_kernel(const AttnArgsSP a
 //  of the reference's f64 goldens (bar 2e-4), the render PSNR against the oracle chain from 73-79 to 71.5-73.7 dB, the poses from 1.4e-6 to
 //  3.7e-6 (bar 2e-5) -- without it (row sum over the exact p): 9e-5, 58.5 dB, 1.4e-5.  It is not the default because the OPERATOR is then
 //  f16-class on its own (1e-4 of float64 on random inputs against 5e-7; tests/test_split_path_gpu.py holds the class to 6e-6 per operator).)
+// (Measured and not kept, late round 5: the first tile's DMA issued BEFORE the Q loads -- a 257-key workgroup otherwise starts with two dependent
+//  memory round trips, Q then tile 0.  Bit-identical, and over 4 x 60 launches per shape same-process (tools/ab_attn_early.py at that commit):
+//  encoder 327.6 vs 329.0 us, video 1057.6 vs 1058.9, cross-neighbour 374.2 vs 375.4 -- nothing: with two workgroups per CU the other
+//  workgroup's tiles cover the start-up chain; the CU's time is the per-tile work itself.)
 // (Measured and not kept, round 3: a resident variant -- one 8-wave workgroup per (frame, head), all K / V converted once into 153 KiB of
 // LDS -- runs the frame encoder's 257 x 257 attention at the same 28 ms per step as this tiled kernel: the time is the per-group softmax /
 // split VALU work and the 3 x MFMAs, not the re-staging.)
@@ -1304,7 +1301,6 @@ extern "C" int vs_attention_lse(const void *q, const void *k, const void *v, voi
             f.nbatch = nbatch; f.H = H; f.Lq = Lq; f.Lk = Lk; f.nqt = vs::cdiv(Lq, 32 * ng); f.q_batch_rows = q_batch_rows; f.k_batch_rows = k_batch_rows;
             f.ldq_b = 4LL * ldq; f.ldk_b = 4LL * ldk; f.ldv_b = 4LL * ldv; f.ldo = ldo; f.scale_log2e = scale * 1.4426950408889634f; f.lse = lse;
             f.out_packed = out_packed;
-            { const char *e = getenv("VS_ATTN_EARLY_DMA"); f.early_dma = e ? atoi(e) : 1; }   // (read per call: same-process A/B)
             const long long nwg = (long long)f.nqt * H * nbatch;
             VS_CHECK(nwg < (1LL << 31), "vs_attention: grid too large");
             static const int plo = [] { const char *e = getenv("VS_ATTN_PLO"); return e ? atoi(e) : 1; }();
