@@ -23,7 +23,7 @@ def _rel(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max().cpu() + 1e-300))
 
 
-@pytest.mark.parametrize("R,C,relu", [(257, 64, False), (1000, 96, True), (64, 8, False), (4100, 256, False)])
+@pytest.mark.parametrize("R,C,relu", [(257, 64, False), (1000, 96, True), (64, 8, False), (4100, 256, False), (1000, 128, True), (300, 192, False)])
 def test_transpose_f32_and_pack(R, C, relu):
     """vs_transpose_f32 is an exact transpose (+ ReLU, zero padding); vs_transpose_pack_split is vs_split_pack_weight of that transpose."""
     from vicasplat_amd import ops
