@@ -197,6 +197,64 @@ def test_full_size_scene_invariants():
     assert bool(torch.isfinite(g["color"]).all()) and float(g["final_T"].min()) >= 0.0 and float(g["final_T"].max()) <= 1.0
 
 
+def test_full_size_render_is_linear_in_colour_affine_in_background_and_order_free():
+    """BASELINE config-4 size (524 288 Gaussians, 4 target views of 256x256): properties the blend C = sum_i c_i a_i T_i + bg T_final has at ANY
+    size, with the geometry (means, covariances, opacities -> a_i, T_i, the tile lists) held fixed --
+      * linear in the per-Gaussian colours: render(2 c1 - 0.5 c2, bg = 0) = 2 render(c1) - 0.5 render(c2);
+      * affine in the background: render(c, bg) = render(c, 0) + bg * final_T, and opacity / depth / n_contrib do not depend on it;
+      * free of the ORDER the Gaussians are stored in: a permuted scene gives the same tile populations, the same sorted depths and -- depth
+        ties (broken by index) aside -- the same image."""
+    from vicasplat_amd.raster import forward_debug
+    d = _dev()
+    sc = rr.synthetic_scene(V=8, res=256, Vt=4, seed=5)
+    cams = rr.make_cameras(sc["extrinsics"], sc["intrinsics"], sc["near"], sc["far"])
+    gc = _gpu_cams(cams)
+    C, P = len(cams), sc["means"].shape[0]
+    assert P == 524288
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=d)[None]
+    rng = np.random.default_rng(0)
+    c1, c2 = rng.uniform(0, 1, (P, 3)).astype(np.float32), rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    mean_, cov_, op_ = T(sc["means"]), T(rr.cov6(sc["covariances"])), T(sc["opacities"])
+    zero = torch.zeros(C, 3, device=d)
+    run = lambda col, bg, m=mean_, cv=cov_, o=op_: forward_debug(m, cv, o, gc["viewmatrix"], gc["projmatrix"], gc["campos"], gc["tanfov"], bg, 256, 256,
+                                                                 colors_precomp=col)
+    r1, r2 = run(T(c1), zero), run(T(c2), zero)
+    r12 = run(T(2.0 * c1 - 0.5 * c2), zero)
+    assert float((r1["opacity"] > 0.5).float().mean()) > 0.3, "the scene must actually cover the image"
+    assert torch.equal(r1["point_list"], r2["point_list"]) and torch.equal(r1["final_T"], r2["final_T"]) and torch.equal(r1["n_contrib"], r2["n_contrib"])
+    lin = 2.0 * r1["color"] - 0.5 * r2["color"]
+    assert float((r12["color"] - lin).abs().max()) <= 5e-5 * max(1.0, float(lin.abs().max())), float((r12["color"] - lin).abs().max())
+    bg = torch.tensor([[0.25, 0.5, 0.75]], device=d).expand(C, 3).contiguous()
+    rb = run(T(c1), bg)
+    assert torch.equal(rb["final_T"], r1["final_T"]) and torch.equal(rb["opacity"], r1["opacity"]) and torch.equal(rb["depth"], r1["depth"])
+    assert torch.equal(rb["n_contrib"], r1["n_contrib"])
+    want = r1["color"] + bg[:, :, None, None] * r1["final_T"][:, None]
+    assert float((rb["color"] - want).abs().max()) <= 2e-6
+    perm = rng.permutation(P)
+    rp = run(T(c1[perm]), zero, T(sc["means"][perm]), T(rr.cov6(sc["covariances"])[perm]), T(sc["opacities"][perm]))
+    assert rp["R"] == r1["R"]
+    pop = lambda r: (r["ranges"][..., 1] - r["ranges"][..., 0])
+    assert torch.equal(pop(rp), pop(r1)), "tile populations do not depend on the storage order"
+    inv = torch.tensor(perm, device=d)                  # new index j holds old Gaussian perm[j]
+    assert torch.equal(rp["radii"], r1["radii"][:, inv])
+    # the sorted DEPTH sequence of every tile list is the same; the ids agree wherever the depth is not tied inside its list
+    def keyed(r):
+        rg = r["ranges"].long()
+        tile_of = torch.repeat_interleave(torch.arange(C * 256, device=d), (rg[..., 1] - rg[..., 0]).flatten())
+        return tile_of, r["geom"][tile_of // 256, r["point_list"].long(), 11]
+    t1, d1 = keyed(r1)
+    tp, dp = keyed(rp)
+    assert torch.equal(t1, tp) and torch.equal(d1, dp)
+    tied = torch.zeros_like(d1, dtype=torch.bool)
+    eq = (d1[1:] == d1[:-1]) & (t1[1:] == t1[:-1])
+    tied[1:] |= eq; tied[:-1] |= eq
+    assert torch.equal(inv[rp["point_list"].long()][~tied], r1["point_list"].long()[~tied])
+    tf = float(tied.float().mean())
+    assert tf < 0.02, tf
+    assert float((rp["color"] - r1["color"]).abs().max()) <= (2e-6 if tf == 0.0 else 2e-2)
+    assert float(((rp["color"] - r1["color"]).abs() > 2e-6).float().mean()) <= 1e-4 + 20 * tf
+
+
 def test_empty_and_culled():
     d = _dev()
     cams = _two_cams()
