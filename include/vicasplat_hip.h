@@ -161,7 +161,9 @@ int vs_split_pack_weight(const float *w, int64_t ldw, void *out, int64_t ldo, in
 
 /* out = epilogue(acc_scale * (A Wp^T) + bias), A [M, K] f32, Wp from vs_split_pack_weight, out f32.  epilogue 0 / 3 store, 1 exact-erf
  * GELU, 2 out = (resid ? resid : out) + (1 + gate) * (...), 4 packed q|k|v with RoPE (pos, kind, C, base2d, theta1d as vs_gemm_qkv_rope).
- * Row maps / gate / strides (in floats) as vs_gemm_bias_act. */
+ * Row maps / gate / strides (in floats) as vs_gemm_bias_act.  Epilogue 5 (late round 5; vs_gemm_split only): out = (A Wp^T) * GELU'(z), z = resid
+ * [M, ldo] f32 in the layout of out (no bias / gate / row map / packed output) -- the gradient of the MLP's pre-activation straight from the dX
+ * GEMM of its second linear (torch autograd of fc2(act(fc1(x))), croco/blocks.py:60-72 under model_wrapper.py:184-321). */
 int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,
                   int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t grp_in, int32_t grp_out,
                   int32_t grp_off, int32_t gate_rows, int32_t gate_ld, int32_t a_grp_in, int32_t a_grp_out, int32_t a_grp_off,

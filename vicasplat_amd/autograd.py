@@ -9,6 +9,7 @@ scaled-dot-product attention and nn.Conv2d(k=3, s=1, p=1) on that path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -187,11 +188,17 @@ class LinearFn(torch.autograd.Function):
         return (None if dx is None else dx.view(xshape).to(xdtype)), dw, db, None, None
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype, rope=None, scale_sources=()) -> torch.Tensor:
+_MLP_DGELU_EPI = os.environ.get("VS_MLP_DGELU_EPI", "1") != "0"      # A/B switch: 0 = GELU and its backward as separate nodes in the split class too
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt: torch.dtype, rope=None, scale_sources=(), gelu_in: bool = False) -> torch.Tensor:
     """nn.Linear in the operand dtype `dt`.  K must be a multiple of 64 for the MFMA kernels; tiny odd shapes (the 9 -> C
-    intrinsic embedding) stay on torch in f32."""
+    intrinsic embedding) stay on torch in f32.  gelu_in: y = gelu(x) @ w^T + b (croco/blocks.py:60-72: fc2(act(fc1(x)))) -- in the split class ONE
+    node whose backward multiplies by GELU'(x) in the dX GEMM's epilogue."""
+    if gelu_in and not (dt == SPLIT and _MLP_DGELU_EPI and rope is None):
+        x, gelu_in = gelu(x), False
     if dt == SPLIT:
-        return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources))
+        return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources), gelu_in)
     K = x.shape[-1]
     if K % 64 != 0:
         assert rope is None
@@ -252,9 +259,13 @@ class LinearSplitFn(torch.autograd.Function):
         return ent[0]
 
     @staticmethod
-    def forward(ctx, x, w, b, rope=None, scale_sources=()):
+    def forward(ctx, x, w, b, rope=None, scale_sources=(), gelu_in=False):
         K, N = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, K).float()
+        ctx.gelu_in = bool(gelu_in)
+        if gelu_in:                       # x is the pre-activation z: a = gelu(z) is this linear's input; z is kept for GELU'(z) in the backward
+            z = x2.contiguous()
+            x2 = ops.gelu16(z)
         xp = LinearSplitFn._pad32(x2, 1)
         e = LinearSplitFn._scale_exp(w, *scale_sources)
         ctx.scale_exp = e
@@ -266,13 +277,20 @@ class LinearSplitFn(torch.autograd.Function):
         else:
             pos, kind, H, C, base2d, theta1d = rope
             ops.gemm_qkv_rope(xp, wp, bf, y, C, pos, kind, base2d, theta1d)
-        ctx.save_for_backward(xp, w)
+        if gelu_in:
+            ctx.save_for_backward(xp, w, z)
+        else:
+            ctx.save_for_backward(xp, w)
         ctx.meta = (x.shape, b is not None, rope)
         return y if x.dim() == 2 else y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        xp, w = ctx.saved_tensors
+        z = None
+        if ctx.gelu_in:
+            xp, w, z = ctx.saved_tensors
+        else:
+            xp, w = ctx.saved_tensors
         xshape, has_b, rope = ctx.meta
         N, K = w.shape
         dy2 = dy.reshape(-1, N).float()
@@ -285,17 +303,23 @@ class LinearSplitFn(torch.autograd.Function):
             ops.rope_qk(dy2, H, C, pos, kind, base2d, theta1d, inverse=True)
         Kp = xp.shape[1]
         wk = w.detach().float() if Kp == K else torch.nn.functional.pad(w.detach().float(), (0, Kp - K))
+        if z is not None and Kp != K:      # (padded reduction dimension: GELU'(z) after the slice below)
+            zz, z = z, None
+        else:
+            zz = None
         dx, dw, db = ops.linear_backward_split(dy2, xp, wk, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
-                                               need_db=has_b and ctx.needs_input_grad[2], scale_exp=ctx.scale_exp)
+                                               need_db=has_b and ctx.needs_input_grad[2], scale_exp=ctx.scale_exp, dgelu_z=z)
         if dx is not None:
             dx = dx[:, :K].reshape(xshape) if Kp != K else dx.view(xshape)
+            if zz is not None:
+                dx = ops.gelu_backward(dx.reshape(-1, K).contiguous(), zz).view(xshape)
         if dw is not None and Kp != K:
             dw = dw[:, :K].contiguous()
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def linear_split(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], rope=None, scale_sources=()) -> torch.Tensor:
-    return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources))
+    return LinearSplitFn.apply(x, w, b, rope, tuple(scale_sources), False)
 
 
 def _tail_dy(dy, N, dtype):

@@ -447,6 +447,8 @@ int launch_skinny(const GemmArgs &g, int epi, hipStream_t stream) {
         case 2: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 2>), grid, block, 0, stream, g); break;
         case 3: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 3>), grid, block, 0, stream, g); break;
         case 4: hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 4>), grid, block, 0, stream, g); break;
+        case 5: if constexpr (BF16 == kDtSplit) { hipLaunchKernelGGL((gemm_skinny_kernel<BF16, 5>), grid, block, 0, stream, g); break; }
+                vs::set_error("epilogue 5 (x GELU') is a split-class epilogue"); return -1;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -484,6 +486,8 @@ int launch_mi(const GemmArgs &g, int epi, hipStream_t stream) {
         case 2: hipLaunchKernelGGL((gemm_kernel<BF16, 2, MI>), grid, block, 0, stream, g); break;
         case 3: hipLaunchKernelGGL((gemm_kernel<BF16, 3, MI>), grid, block, 0, stream, g); break;
         case 4: hipLaunchKernelGGL((gemm_kernel<BF16, 4, MI>), grid, block, 0, stream, g); break;
+        case 5: if constexpr (BF16 == kDtSplit) { hipLaunchKernelGGL((gemm_kernel<BF16, 5, MI>), grid, block, 0, stream, g); break; }
+                vs::set_error("epilogue 5 (x GELU') is a split-class epilogue"); return -1;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -649,6 +653,8 @@ int launch_256(const GemmArgs &g, int epi, hipStream_t stream) {
         case 2: hipLaunchKernelGGL((gemm256_kernel<BF16, 2>), grid, block, 0, stream, g); break;
         case 3: hipLaunchKernelGGL((gemm256_kernel<BF16, 3>), grid, block, 0, stream, g); break;
         case 4: hipLaunchKernelGGL((gemm256_kernel<BF16, 4>), grid, block, 0, stream, g); break;
+        case 5: if constexpr (BF16 == kDtSplit) { hipLaunchKernelGGL((gemm256_kernel<BF16, 5>), grid, block, 0, stream, g); break; }
+                vs::set_error("epilogue 5 (x GELU') is a split-class epilogue"); return -1;
         default: vs::set_error("vs_gemm_bias_act: unknown epilogue %d", epi); return -1;
     }
     return 0;
@@ -677,12 +683,12 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
     if constexpr (BF16 == kDtSplit || BF16 == 0 || BF16 == 1) {   // (split class and, since late round 5, the 16-bit classes)
         // (<= 64 rows stay on the weight-streaming kernel where it applies; the RoPE epilogue and packed outputs, which it does not have, come here)
-        if (skinny && rem <= 256 && g.K % 64 == 0 && (rem > 64 || skinny == 2 || epi == 4 || g.out_packed) && (BF16 == kDtSplit || (!g.a_packed && !g.out_packed))) {
+        if (skinny && rem <= 256 && g.K % 64 == 0 && (rem > 64 || skinny == 2 || epi == 4 || epi == 5 || g.out_packed) && (BF16 == kDtSplit || (!g.a_packed && !g.out_packed))) {
             t.ksplit = 1;
             return launch_skinny<BF16>(t, epi, stream);
         }
     }
-    if (rem <= (BF16 == kDtSplit ? tail_rows : 64) && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) {
+    if (rem <= (BF16 == kDtSplit ? tail_rows : 64) && epi != 4 && epi != 5 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) {
         t.ksplit = 1;
         return launch_smallm<BF16>(t, epi, stream);
     }
@@ -702,7 +708,7 @@ template <int BF16>
 int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     // VS_GEMM_MI = 4 | 8 | 16 forces the 128x128 | 256x128 | 256x256 kernel (benchmarks, tests).
     static const int force = [] { const char *e = getenv("VS_GEMM_MI"); return e ? atoi(e) : 0; }();
-    if (g.M <= 64 && force == 0 && epi != 4 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) return launch_smallm<BF16>(g, epi, stream);
+    if (g.M <= 64 && force == 0 && epi != 4 && epi != 5 && !g.out_packed && (BF16 == kDtSplit || !g.a_packed)) return launch_smallm<BF16>(g, epi, stream);
     if constexpr (BF16 == kDtSplit || BF16 == 0 || BF16 == 1) {   // camera-token GEMMs and other launches of <= 256 rows: the skinny kernel (round 5)
         static const int skinny = [] { const char *e = getenv("VS_GEMM_SKINNY"); return e ? atoi(e) : 1; }();
         if (skinny && force == 0 && g.M - g.m_lo <= 256 && g.K % 64 == 0 && g.ntaps == 0 && !g.partials && g.ksplit <= 1 && g.a_sup_extra == 0 && g.a_kstride == 32 &&
@@ -986,7 +992,7 @@ extern "C" int vs_split_pack_weight(const float *w, int64_t ldw, void *out, int6
 }
 
 // out = epilogue(acc_scale * (A Wp^T) + bias): A [M, K] f32 activations, Wp = vs_split_pack_weight image of the f32 weight (acc_scale =
-// 2^-scale_exp), every output f32.  Epilogues 0 / 3 store, 1 exact-erf GELU, 2 gated residual update (resid null: in place), 4 packed
+// 2^-scale_exp), every output f32.  Epilogues 0 / 3 store, 1 exact-erf GELU, 2 gated residual update (resid null: in place), 5 x GELU'(resid), 4 packed
 // q|k|v with RoPE (pos / kind / C / bases as vs_gemm_qkv_rope).  Row maps, gate and strides (in floats) as vs_gemm_bias_act.
 extern "C" int vs_gemm_split(const float *A, const void *Wp, float acc_scale, const float *bias, float *out, const float *gate, const float *resid,
                              int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t epilogue, int32_t grp_in,
@@ -995,7 +1001,8 @@ extern "C" int vs_gemm_split(const float *A, const void *Wp, float acc_scale, co
                              vs_stream_t stream_) {
     const int out_packed = (epilogue & 16) ? 1 : 0;      // + 16: packed (hi, lo) output (epilogues 0 / 1 / 3: the A operand of vs_gemm_split_packed; 4: q | k | v for vs_attention dtype 4 + 32)
     epilogue &= ~16;
-    VS_CHECK(epilogue >= 0 && epilogue <= 4, "vs_gemm_split: unknown epilogue %d", epilogue);
+    VS_CHECK(epilogue >= 0 && epilogue <= 5, "vs_gemm_split: unknown epilogue %d", epilogue);
+    VS_CHECK(epilogue != 5 || (resid && !bias && !gate && !out_packed && grp_in == 0 && K % 64 == 0), "vs_gemm_split: epilogue 5 (x GELU'(z)) needs z in `resid` (the layout of out), no bias / gate / row map / packed output, K %% 64 == 0");
     VS_CHECK(!out_packed || ((epilogue == 0 || epilogue == 1 || epilogue == 3 || epilogue == 4) && N % 64 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
              "vs_gemm_split: a packed output needs epilogue 0 / 1 / 3 / 4, N %% 64 == 0, ldo %% 32 == 0 and a 128-byte aligned buffer");
     VS_CHECK(epilogue != 4 || (pos && C > 0 && C % 64 == 0 && N >= 2 * C && N % 64 == 0 && base2d > 0.f && theta1d > 0.f),

@@ -292,6 +292,26 @@ __device__ __forceinline__ f2v gelu_erf2(f2v v) {
     return v * 0.5f * (e + 1.0f);
 }
 
+// d/dv [v Phi(v)] = Phi(v) + v phi(v) on the same Abramowitz-Stegun erf and the SAME exponential (exp(-v^2 / 2) is both the erf's tail factor
+// and the density): epilogue 5 of the split class -- dX of the MLP's second linear multiplied by GELU'(pre-activation) where it is produced.
+__device__ __forceinline__ f2v dgelu_erf2(f2v v) {
+    f2v x;
+    x.x = fabsf(v.x); x.y = fabsf(v.y);
+    x = x * 0.70710678118654752440f;
+    f2v t = x * 0.3275911f + 1.0f;
+    t.x = __frcp_rn(t.x); t.y = __frcp_rn(t.y);
+    f2v p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f2v nx2 = x * x * (-1.4426950408889634f);
+    f2v e2;
+    e2.x = __builtin_amdgcn_exp2f(nx2.x); e2.y = __builtin_amdgcn_exp2f(nx2.y);     // exp(-v^2 / 2)
+    f2v e = 1.0f - p * t * e2;
+    e.x = copysignf(e.x, v.x); e.y = copysignf(e.y, v.y);
+    return (e + 1.0f) * 0.5f + v * (e2 * 0.3989422804014327f);
+}
+
 // GELU for the 16-bit epilogues without transcendentals: erf(x / sqrt 2) ~ t * P(t^2), t = clamp(x, -4.2, 4.2) / 4.2, P of degree 7
 // (minimax fit of the GELU error with P(1) = 1 so that the clamp is seamless; tools/fit_gelu_poly.py).  |gelu_poly - gelu_erf| <= 8.1e-5
 // absolute in f32 evaluation -- a sixth of an f16 ulp at 1 -- for 13 packed issue slots per two elements instead of ~30 (the rcp and
@@ -394,7 +414,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
     // residual / gate load of a batch of 4 row fragments is issued before the first use (16 x 16 B in flight per lane). ----
     {
         const bool plain_resid = EPI != 2 || (g.ksplit <= 1 && g.ksplit >= 0);
-        const bool res_ok = EPI != 2 || !g.resid || (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0;
+        const bool res_ok = (EPI != 2 && EPI != 5) || !g.resid || (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0;
         const bool gate_ok = EPI != 2 || !g.gate || (g.gate_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(g.gate) & 15) == 0);
         if (vec_ok && mw0 + 16 * MI <= g.M && plain_resid && res_ok && gate_ok) {
             size_t orow[MI];
@@ -484,6 +504,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                                 v[j][r + 1] = acc[i][j][r + 1] + bv[j][r + 1];
                             }
                         }
+                    if constexpr (EPI == 5) {     // x GELU'(z), z = g.resid (f32, the layout of out): four 16-byte loads in flight per row fragment
+                        const float *zp = g.resid + orow[i] * g.ldo + nbase + c4;
+                        float4 z[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[j] = *reinterpret_cast<const float4 *>(zp + j * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f2v d0 = dgelu_erf2(f2v{z[j].x, z[j].y}), d1 = dgelu_erf2(f2v{z[j].z, z[j].w});
+                            v[j][0] *= d0.x; v[j][1] *= d0.y; v[j][2] *= d1.x; v[j][3] *= d1.y;
+                        }
+                    }
                     if constexpr (EPI == 4) {
                         if (rope_on) {
                             if (rk[i] == 0) {
@@ -587,6 +618,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f4 (&acc)[MI][4
                 v[j][r] = acc[i][j][r] + bv[j][r];
                 if constexpr (EPI == 1) v[j][r] = is_f32io(BF16) ? gelu_erf(v[j][r]) : gelu_poly(v[j][r]);   // same function as the wide path: results do not depend on the tile path
             }
+        if constexpr (EPI == 5) {
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const int n = nbase + j * 16 + c4 + r;
+                        const float z0 = n < g.N ? g.resid[orow * g.ldo + n] : 0.f, z1 = n + 1 < g.N ? g.resid[orow * g.ldo + n + 1] : 0.f;
+                        const f2v dd = dgelu_erf2(f2v{z0, z1});      // (the pair form of the wide path: results do not depend on the tile path)
+                        v[j][r] *= dd.x; v[j][r + 1] *= dd.y;
+                    }
+            }
+        }
         if constexpr (EPI == 4) {
             if (rope_on) {
                 const int kd = g.rope_kind ? (int)g.rope_kind[orow] : 0;

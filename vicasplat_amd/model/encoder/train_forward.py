@@ -88,6 +88,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     ck_enc = lambda i: ckpt and (cb is None or i < cb[0])
     ck_dec = lambda i: ckpt and (cb is None or i < cb[1])
     lin = lambda name, x: A.linear(x, P[name + ".weight"], P.get(name + ".bias"), dt)
+    lin_gelu = lambda name, z: A.linear(z, P[name + ".weight"], P.get(name + ".bias"), dt, gelu_in=True)     # fc2(gelu(z))
     lnm = lambda name, x, **k: A.layernorm_mod(x, P[name + ".weight"], P[name + ".bias"], eps=LN_EPS, **k)
 
     # ---------------- frame encoder (backbone_vica.py:450-480) ----------------
@@ -107,7 +108,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         att = A.AttentionFn.apply(qkv, BT, He, N1, N1, N1, N1, None, None, 0)
         x = A.gated_resid(x, lin(nm + ".attn.proj", att))
         h2 = lnm(nm + ".norm2", x, out_dtype=adt)
-        return A.gated_resid(x, lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", h2))))
+        return A.gated_resid(x, lin_gelu(nm + ".mlp.fc2", lin(nm + ".mlp.fc1", h2)))
 
     for i in range(cfg.enc_depth):          # one autograd node per block: LN / qkv+RoPE / attention / proj / LN / fc1 / GELU / fc2
         nm = f"backbone.enc_blocks.{i}"
@@ -156,7 +157,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
         x = A.gated_resid(x, lin(ca + ".proj", att), g2.reshape(BT, C), N1)
         himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=adt)
-        x = A.gated_resid(x, lin(nm + ".mlp.fc2", A.gelu(lin(nm + ".mlp.fc1", himg))), g3.reshape(BT, C), N1)
+        x = A.gated_resid(x, lin_gelu(nm + ".mlp.fc2", lin(nm + ".mlp.fc1", himg)), g3.reshape(BT, C), N1)
         cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
         return x, cam
 

@@ -1217,9 +1217,11 @@ def _wgrad_split(dyT: torch.Tensor, xT: SplitWeight, out: torch.Tensor) -> torch
 
 
 def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *, need_dx: bool = True, need_dw: bool = True, need_db: bool = True,
-                          scale_exp: Optional[int] = None):
+                          scale_exp: Optional[int] = None, dgelu_z: Optional[torch.Tensor] = None):
     """Backward of y = x @ w^T + b in the split class: dy [M,N], x [M,K], w [N,K] all f32 -> dx [M,K], dw [N,K], db [N] f32.
-    dx = vs_gemm_split(dy, pack(w^T)); dw = vs_gemm_wgrad(transpose(dy), transpose_pack(x)) over the M rows; db = column sums."""
+    dx = vs_gemm_split(dy, pack(w^T)); dw = vs_gemm_wgrad(transpose(dy), transpose_pack(x)) over the M rows; db = column sums.
+    dgelu_z [M,K] f32 (x = gelu(z), the MLP's second linear): the returned dx is the gradient of z, dy w^T * GELU'(z), multiplied in the dX
+    GEMM's epilogue (vs_gemm_split epilogue 5) instead of a separate pass over dx and z."""
     M, N = dy.shape
     K = x.shape[1]
     dev = dy.device
@@ -1239,7 +1241,12 @@ def linear_backward_split(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, *,
                 dyp = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
             wtp = split_pack_weight(wt.contiguous(), scale_exp)
         dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-        _gemm_split(dyp, wtp, None, dx, EPI_STORE32)
+        if dgelu_z is not None and dyp.shape[1] % 64 == 0 and dgelu_z.shape == dx.shape and dgelu_z.is_contiguous() and dgelu_z.dtype == torch.float32:
+            _gemm_split(dyp, wtp, None, dx, 5, resid=dgelu_z)
+        else:
+            _gemm_split(dyp, wtp, None, dx, EPI_STORE32)
+            if dgelu_z is not None:
+                dx = gelu_backward(dx, dgelu_z.contiguous())
     if need_dw:
         Mp = (M + 1023) // 1024 * 1024 if M >= 4096 else (M + 127) // 128 * 128      # (room for the K split; zero rows cost nothing exact)
         dys = dy if (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
