@@ -484,3 +484,45 @@ def test_im2col7x7_rgb_equals_unfold(dtype):
     got = ops.im2col7x7_rgb(fr, dtype, 256)
     want = F.pad(F.unfold(fr.to(dtype).float(), 7, padding=3).transpose(1, 2), (0, 256 - 147)).to(dtype)
     assert got.shape == (3, 20 * 36, 256) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 512), (200, 128, 256), (64, 64, 128), (4100, 192, 320)])
+def test_linear_backward_split_with_gelu_derivative_in_the_epilogue(M, N, K):
+    """vs_gemm_split epilogue 5: dz = (dy w) * GELU'(z) from the dX GEMM of fc2(gelu(z)) -- every tile route (256 x 256 tiles, 128 x 128 tiles, the
+    skinny kernel's 64-row tail) against float64 and against the two-pass route (dX GEMM, then vs_gelu_backward_f32)."""
+    from vicasplat_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = (torch.randn(M, N, generator=g) * 0.1).to(d)
+    z = (torch.randn(M, K, generator=g) * 1.5).to(d)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(d)
+    a = ops.gelu16(z)
+    e = ops.split_scale_exp(w)
+    one, dw1, db1 = ops.linear_backward_split(dy, a, w, scale_exp=e, dgelu_z=z)
+    two, dw2, db2 = ops.linear_backward_split(dy, a, w, scale_exp=e)
+    two = ops.gelu_backward(two, z)
+    zd = z.double()
+    ref = (dy.double() @ w.double()) * (0.5 * (1 + torch.erf(zd / 2 ** 0.5)) + zd * torch.exp(-0.5 * zd * zd) / (2 * math.pi) ** 0.5)
+    assert _rel(one, ref) <= 3e-6 and _rel(two, ref) <= 3e-6, (_rel(one, ref), _rel(two, ref))
+    assert torch.equal(dw1, dw2) and _rel(db1, db2) <= 1e-6
+
+
+def test_fc2_of_gelu_as_one_autograd_node_matches_the_two_node_chain():
+    """autograd.linear(z, w, b, SPLIT, gelu_in=True) = linear(gelu(z)): same forward bits, gradients of z, w, b equal to float64 autograd to 3e-6."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    g = torch.Generator().manual_seed(5)
+    z0 = (torch.randn(3, 130, 256, generator=g) * 1.2).to(d)
+    w0, b0 = (torch.randn(128, 256, generator=g) * 0.05).to(d), (torch.randn(128, generator=g) * 0.1).to(d)
+    gy = torch.randn(3, 130, 128, generator=g).to(d)
+    outs = []
+    for fused in (True, False):
+        z, w, b = z0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = A.linear(z, w, b, A.SPLIT, gelu_in=True) if fused else A.linear(A.gelu(z), w, b, A.SPLIT)
+        y.backward(gy)
+        outs.append((y.detach(), z.grad, w.grad, b.grad))
+    assert torch.equal(outs[0][0], outs[1][0])
+    zd, wd, bd = z0.double().requires_grad_(True), w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    torch.nn.functional.linear(torch.nn.functional.gelu(zd), wd, bd).backward(gy.double())
+    for got, want in zip(outs[0][1:], (zd.grad, wd.grad, bd.grad)):
+        assert _rel(got, want) <= 3e-6, _rel(got, want)
