@@ -526,3 +526,16 @@ def test_fc2_of_gelu_as_one_autograd_node_matches_the_two_node_chain():
     torch.nn.functional.linear(torch.nn.functional.gelu(zd), wd, bd).backward(gy.double())
     for got, want in zip(outs[0][1:], (zd.grad, wd.grad, bd.grad)):
         assert _rel(got, want) <= 3e-6, _rel(got, want)
+
+
+def test_ungated_f32_residual_backward_is_a_pass_through():
+    """gated_resid(x, y) without a gate and with an f32 branch: out = x + y, and the backward hands the incoming gradient to both inputs as it is."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(390, 128, generator=g).to(d).requires_grad_(True), torch.randn(390, 128, generator=g).to(d).requires_grad_(True)
+    gy = torch.randn(390, 128, generator=g).to(d)
+    out = A.gated_resid(x, y)
+    assert torch.equal(out, x.detach() + y.detach())
+    (out * 1.0).backward(gy)
+    assert torch.equal(x.grad, gy) and torch.equal(y.grad, gy)
