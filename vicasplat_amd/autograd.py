@@ -495,11 +495,9 @@ class AttentionFn(torch.autograd.Function):
             if kv_seg is None:
                 ops.attention_backward_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, dk_out=dqkv[:, C:2 * C],
                                              dv_out=dqkv[:, 2 * C:], **kw)
-            else:
-                _, dk, dv = ops.attention_backward_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, kv_seg=kv_seg,
-                                                         max_keys=max_keys, **kw)
-                dqkv[:, C:2 * C] = dk
-                dqkv[:, 2 * C:] = dv
+            else:       # (key segments: dk / dv meet through f32 atomics -- in their blocks of dqkv, zeroed by the call: no fresh buffers + copies)
+                ops.attention_backward_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, kv_seg=kv_seg,
+                                             max_keys=max_keys, dk_out=dqkv[:, C:2 * C], dv_out=dqkv[:, 2 * C:], **kw)
         elif kv_seg is None:   # every K/V row has one owner: dk / dv land in their blocks directly (no zero fill, atomics or cast pass)
             ops.attention_backward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout.contiguous(), lse, nbatch=nbatch, H=H, Lq=Lq, Lk=Lk,
                                    q_batch_rows=qbr, k_batch_rows=kbr, q_kvlen=q_kvlen, dq_out=dqkv[:, :C], dk_out=dqkv[:, C:2 * C],

@@ -1326,10 +1326,9 @@ def attention_backward_split(qkv_q: torch.Tensor, qkv_k: torch.Tensor, qkv_v: to
     if kv_seg is None:
         dk = dk_out if dk_out is not None else torch.empty((qkv_k.shape[0], Cc), dtype=torch.float32, device=dev)
         dv = dv_out if dv_out is not None else torch.empty((qkv_v.shape[0], Cc), dtype=torch.float32, device=dev)
-    else:
-        assert dk_out is None and dv_out is None
-        dk = torch.zeros((qkv_k.shape[0], Cc), dtype=torch.float32, device=dev)
-        dv = torch.zeros((qkv_v.shape[0], Cc), dtype=torch.float32, device=dev)
+    else:       # (dk_out / dv_out given: accumulated where they are wanted -- zeroed here -- instead of in fresh buffers that are copied afterwards)
+        dk = dk_out.zero_() if dk_out is not None else torch.zeros((qkv_k.shape[0], Cc), dtype=torch.float32, device=dev)
+        dv = dv_out.zero_() if dv_out is not None else torch.zeros((qkv_v.shape[0], Cc), dtype=torch.float32, device=dev)
     for t in (dq, dk, dv):
         assert t.dtype == torch.float32 and t.stride(1) == 1
     delta = torch.empty((qkv_q.shape[0], H), dtype=torch.float32, device=dev)
