@@ -170,7 +170,9 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
     reducer = vdist.GradReducer(enc.parameters()) if world > 1 else None
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
-    r = callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer)      # warm-up (allocator, optimizer state)
+    for _ in range(2):      # warm-up: optimizer state, then the caching allocator's pool in its steady shape (one step is not enough: the second step of
+        # a leg can still grow the pool by tens of GB of fresh hipMallocs -- seen once as a 2.2 s "step" in the two-step split leg)
+        r = callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
