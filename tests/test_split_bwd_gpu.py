@@ -539,3 +539,37 @@ def test_ungated_f32_residual_backward_is_a_pass_through():
     assert torch.equal(out, x.detach() + y.detach())
     (out * 1.0).backward(gy)
     assert torch.equal(x.grad, gy) and torch.equal(y.grad, gy)
+
+
+@pytest.mark.parametrize("mod", [False, True])
+def test_layernorm_node_carries_the_residual_stream(mod):
+    """layernorm_mod(x, ..., skip=True) -> (LN(x), x'): x' + branch(LN(x)) differentiates to d x' + LN'(x)^T d h in ONE kernel (dx_add of
+    vs_layernorm_backward) -- equal to float64 autograd of the same expression, with and without the AdaLN modulation; an unused x' costs nothing."""
+    from vicasplat_amd import autograd as A
+    d = _dev()
+    g = torch.Generator().manual_seed(3 + int(mod))
+    M, C, rows = 6 * 50, 256, 50
+    x0 = torch.randn(M, C, generator=g).to(d)
+    w0, b0 = (1 + 0.1 * torch.randn(C, generator=g)).to(d), (0.1 * torch.randn(C, generator=g)).to(d)
+    sc0, sh0 = (0.2 * torch.randn(M // rows, C, generator=g)).to(d), (0.2 * torch.randn(M // rows, C, generator=g)).to(d)
+    gy = torch.randn(M, C, generator=g).to(d)
+    x, w, b, sc, sh = (t.clone().requires_grad_(True) for t in (x0, w0, b0, sc0, sh0))
+    kw = dict(scale=sc, shift=sh, mod_rows=rows) if mod else {}
+    h, xs = A.layernorm_mod(x, w, b, out_dtype=torch.float32, skip=True, **kw)
+    assert torch.equal(xs, x0)
+    ((xs + 0.5 * h * h) * gy).sum().backward()
+    xd, wd, bd, scd, shd = (t.double().requires_grad_(True) for t in (x0, w0, b0, sc0, sh0))
+    hd = torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-6)
+    if mod:
+        hd = hd * (1 + scd.repeat_interleave(rows, 0)) + shd.repeat_interleave(rows, 0)
+    assert _rel(h, hd) <= 2e-6
+    ((xd + 0.5 * hd * hd) * gy.double()).sum().backward()
+    for got, want in ((x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)) + (((sc.grad, scd.grad), (sh.grad, shd.grad)) if mod else ()):
+        assert _rel(got, want) <= 5e-6, _rel(got, want)
+    # only LN(x) used: the skip gradient is None, the backward is the plain one
+    x2 = x0.clone().requires_grad_(True)
+    h2, _ = A.layernorm_mod(x2, w0, b0, out_dtype=torch.float32, skip=True)
+    (h2 * gy).sum().backward()
+    x3 = x0.clone().requires_grad_(True)
+    (A.layernorm_mod(x3, w0, b0, out_dtype=torch.float32) * gy).sum().backward()
+    assert torch.equal(x2.grad, x3.grad)

@@ -410,8 +410,10 @@ class LayerNormModFn(torch.autograd.Function):
     rows straight into that interleaved buffer, so no concatenation pass exists."""
 
     @staticmethod
-    def forward(ctx, x, w, b, scale, shift, mod_rows, out_dtype, eps, lead, lead_rows):
+    def forward(ctx, x, w, b, scale, shift, mod_rows, out_dtype, eps, lead, lead_rows, skip=False):
         M, C = x.shape
+        ctx.skip = bool(skip)
+        ctx.set_materialize_grads(False)          # (an unused output's gradient stays None instead of a zero tensor)
         xf = x.float().contiguous()
         sc = None if scale is None else scale.detach().float().contiguous()
         sh = None if shift is None else shift.detach().float().contiguous()
@@ -427,25 +429,44 @@ class LayerNormModFn(torch.autograd.Function):
         ops.layernorm_mod(xf, wf, bf, out, eps=eps, scale=sc, shift=sh, mod_rows=mod_rows, grp_in=grp[0], grp_out=grp[1], grp_off=grp[2])
         ctx.save_for_backward(xf, wf, bf, sc)
         ctx.meta = (mod_rows, eps, x.dtype, scale is not None, grp, None if lead is None else (lead.shape, lead.dtype))
+        if skip:      # (out, x): the residual stream leaves through THIS node too, so that its backward sees both gradients of x and adds the
+            return out, x.view_as(x)      # residual one inside the LayerNorm backward kernel (dx_add) instead of in a separate autograd add pass
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dskip=None):
         xf, w, b, sc = ctx.saved_tensors
         mod_rows, eps, xdtype, has_mod, grp, lead_meta = ctx.meta
+        if dout is None:          # only the residual stream was used downstream
+            return dskip, None, None, None, None, None, None, None, None, None, None
         dout = dout.contiguous()
+        add = None
+        if dskip is not None and dskip.dtype == torch.float32 and dskip.shape == xf.shape and dskip.stride(1) == 1:
+            add, dskip = dskip, None
         dx, dw, db, dsc, dsh = ops.layernorm_backward(dout, xf, w, b, scale=sc, mod_rows=mod_rows, eps=eps, grp_in=grp[0], grp_out=grp[1],
-                                                      grp_off=grp[2])
+                                                      grp_off=grp[2], dx_add=add)
         dlead = None
         if lead_meta is not None:
             dlead = dout.view(-1, grp[1], dout.shape[1])[:, 0].to(lead_meta[1]).reshape(lead_meta[0])
-        return dx.to(xdtype), dw, db, (dsc if has_mod else None), (dsh if has_mod else None), None, None, None, dlead, None
+        dx = dx.to(xdtype)
+        if dskip is not None:
+            dx = dx + dskip.to(xdtype).reshape(dx.shape)
+        return dx, dw, db, (dsc if has_mod else None), (dsh if has_mod else None), None, None, None, dlead, None, None
 
 
-def layernorm_mod(x, w, b, *, scale=None, shift=None, mod_rows=0, out_dtype=torch.float16, eps=1e-6, lead=None, lead_rows=0):
+_LN_SKIP = os.environ.get("VS_LN_SKIP_FUSED", "1") != "0"       # A/B switch: 0 = the residual gradient meets the LayerNorm's in an autograd add pass
+
+
+def layernorm_mod(x, w, b, *, scale=None, shift=None, mod_rows=0, out_dtype=torch.float16, eps=1e-6, lead=None, lead_rows=0, skip=False):
     """x [..., C] (any leading dims; scale/shift [G, C] apply to consecutive groups of mod_rows rows).  With `lead` the result is
-    2-D [rows + rows // lead_rows, C] (see LayerNormModFn)."""
+    2-D [rows + rows // lead_rows, C] (see LayerNormModFn).  skip=True (x 2-D): returns (LN(x), x') with x' = x routed through the node -- use x' as
+    the residual operand that follows (x' + branch(LN(x))): the backward then adds the residual gradient inside its kernel."""
     lead_shape = x.shape[:-1]
+    if skip:
+        assert x.dim() == 2
+        if not _LN_SKIP:
+            return layernorm_mod(x, w, b, scale=scale, shift=shift, mod_rows=mod_rows, out_dtype=out_dtype, eps=eps, lead=lead, lead_rows=lead_rows), x
+        return LayerNormModFn.apply(x, w, b, scale, shift, mod_rows, out_dtype, eps, lead, lead_rows, True)
     y = LayerNormModFn.apply(x.reshape(-1, x.shape[-1]), w, b, scale, shift, mod_rows, out_dtype, eps, lead, lead_rows)
     return y if lead is not None else y.view(*lead_shape, x.shape[-1])
 

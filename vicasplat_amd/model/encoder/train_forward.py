@@ -103,11 +103,11 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
     x = x.reshape(BT * N1, Ce)
     def enc_block_split(i, x):              # the block composed of the split-class Functions (croco/blocks.py:114-130)
         nm = f"backbone.enc_blocks.{i}"
-        h1 = lnm(nm + ".norm1", x, out_dtype=adt)
+        h1, x = lnm(nm + ".norm1", x, out_dtype=adt, skip=True)        # (x leaves through the LayerNorm node: its backward adds the residual gradient)
         qkv = A.linear(h1, P[nm + ".attn.qkv.weight"], P[nm + ".attn.qkv.bias"], dt, rope=(tabs["pos_img"], None, He, Ce, 100.0, 1.0))
         att = A.AttentionFn.apply(qkv, BT, He, N1, N1, N1, N1, None, None, 0)
         x = A.gated_resid(x, lin(nm + ".attn.proj", att))
-        h2 = lnm(nm + ".norm2", x, out_dtype=adt)
+        h2, x = lnm(nm + ".norm2", x, out_dtype=adt, skip=True)
         return A.gated_resid(x, lin_gelu(nm + ".mlp.fc2", lin(nm + ".mlp.fc1", h2)))
 
     for i in range(cfg.enc_depth):          # one autograd node per block: LN / qkv+RoPE / attention / proj / LN / fc1 / GELU / fc2
@@ -136,7 +136,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         nm = f"backbone.dec_blocks.{i}"
         cn = _ln_f32(P, nm + ".cam_norm1", cam)
         s1, b1, g1 = _lin_f32(P, nm + ".modulation1.proj", F.silu(cn)).chunk(3, -1)                   # [B,T,C] each
-        hmix = lnm(nm + ".norm1", x, scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=adt,
+        hmix, x = lnm(nm + ".norm1", x, skip=True, scale=s1.reshape(BT, C), shift=b1.reshape(BT, C), mod_rows=N1, out_dtype=adt,
                    lead=cn.to(adt).reshape(BT, C), lead_rows=N1)                                       # [BT*M2, C]: camera token first
         qkv = A.linear(hmix, P[nm + ".attn.qkv.weight"], P[nm + ".attn.qkv.bias"], dt,
                        rope=(tabs["pos_mix"], tabs["kind_mix"], Hd, C, 100.0, theta))                 # RoPE in the GEMM epilogue
@@ -147,7 +147,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
         s2, b2, g2, s3, b3, g3 = _lin_f32(P, nm + ".modulation2.proj", F.silu(cn)).chunk(6, -1)
         # cross-neighbour attention (:152-191): q | k | v of frame t (one GEMM over the stacked projq / projk / projv weights),
         # keys gathered from frames t-1 / t+1 by row segments
-        himg = lnm(nm + ".norm2", x, scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=adt)
+        himg, x = lnm(nm + ".norm2", x, skip=True, scale=s2.reshape(BT, C), shift=b2.reshape(BT, C), mod_rows=N1, out_dtype=adt)
         ca = nm + ".cross_attn"
         wqkv = torch.cat([P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]], 0)
         bqkv = torch.cat([P[ca + ".projq.bias"], P[ca + ".projk.bias"], P[ca + ".projv.bias"]], 0)
@@ -156,7 +156,7 @@ def forward_train(model, image: torch.Tensor, intrinsics: torch.Tensor, dt=torch
                        scale_sources=(P[ca + ".projq.weight"], P[ca + ".projk.weight"], P[ca + ".projv.weight"]))
         att = A.AttentionFn.apply(qkv, BT, Hd, N1, 0, N1, 0, tabs["seg"], None, 2 * N1)
         x = A.gated_resid(x, lin(ca + ".proj", att), g2.reshape(BT, C), N1)
-        himg = lnm(nm + ".norm3", x, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=adt)
+        himg, x = lnm(nm + ".norm3", x, skip=True, scale=s3.reshape(BT, C), shift=b3.reshape(BT, C), mod_rows=N1, out_dtype=adt)
         x = A.gated_resid(x, lin_gelu(nm + ".mlp.fc2", lin(nm + ".mlp.fc1", himg)), g3.reshape(BT, C), N1)
         cam = cam + _lin_f32(P, nm + ".mlp_cam.fc2", F.gelu(_lin_f32(P, nm + ".mlp_cam.fc1", cn)))
         return x, cam
