@@ -26,7 +26,10 @@ def test_library_exports_every_declared_symbol():
             "vs_rope_qk", "vs_gaussian_adapter", "vs_last_error", "vs_abi_version"} <= syms
     missing = [s for s in sorted(syms) if not hasattr(L, s)]
     assert not missing, missing
-    assert _lib.lib().vs_abi_version() >= 1
+    assert _lib.lib().vs_abi_version() == _lib.ABI_VERSION
+    # the documented version is the library's (INTEGRATION.md said 7 while the library said 6)
+    doc = open(os.path.join(os.path.dirname(__file__), '..', 'INTEGRATION.md')).read()
+    assert f'(ABI {_lib.ABI_VERSION})' in doc
 
 
 def test_argument_validation_reports_errors():

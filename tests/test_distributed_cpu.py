@@ -488,3 +488,70 @@ def test_grad_reducer_unused_set_is_learned_once_and_only_shrinks():
     assert not red._unused_ids and not red._unused_learned
     red.remove()
     assert not hasattr(next(a.parameters()), "_vs_bucket")
+
+
+# ---- (i) a reducer attached to a module must not break pickling; (ii) the deferred 1/S of the boundary scale applies to the
+# scaler's parameters only; (iii) two backward passes before one finish() accumulate consistently ----
+def test_module_with_a_reducer_attached_pickles():
+    import io
+    import pickle
+    m = torch.nn.Linear(4, 3)
+    red = vd.GradReducer(m.parameters(), bucket_bytes=64)
+    m(torch.randn(2, 4)).sum().backward()
+    red.finish()
+    assert vd.reducer_of(m.weight) is red
+    pickle.dumps(m.weight)                          # was: TypeError: cannot pickle 'weakref.ReferenceType'
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert torch.equal(m2.weight, m.weight) and vd.reducer_of(m2.weight) is None
+    red.remove()
+    assert vd.reducer_of(m.weight) is None
+
+
+def test_deferred_unscale_touches_only_the_scalers_parameters():
+    """A reducer built over the encoder's parameters AND others (a decoder-side trainable, say): the others' gradients are plain when
+    backward ends and must not be divided by S in finish()."""
+    from vicasplat_amd import autograd as A
+    torch.manual_seed(0)
+    enc, other = torch.nn.Linear(6, 6), torch.nn.Linear(6, 2)
+    x = torch.randn(5, 6)
+    other(enc(x)).square().mean().backward()
+    ref = {id(p): p.grad.clone() for p in list(enc.parameters()) + list(other.parameters())}
+    for p in list(enc.parameters()) + list(other.parameters()):
+        p.grad = None
+    S = 4096.0
+    scaler = A.BoundaryGradScale(enc, S)
+    for bucket_bytes in (1 << 20, 32):               # one mixed bucket / one bucket per tensor
+        red = vd.GradReducer(list(enc.parameters()) + list(other.parameters()), bucket_bytes=bucket_bytes)
+        red.zero_grad()
+        scaler.rearm()
+        h = scaler.outputs(enc(x))[0]
+        other(h).square().mean().backward()
+        red.finish()
+        for p in list(enc.parameters()) + list(other.parameters()):
+            assert torch.allclose(p.grad, ref[id(p)], rtol=1e-5, atol=1e-9), float((p.grad - ref[id(p)]).abs().max())
+        assert float(red.last_overflow) == 0.0
+        red.remove()
+
+
+def test_two_backwards_before_one_finish_accumulate_under_the_boundary_scale():
+    from vicasplat_amd import autograd as A
+    torch.manual_seed(1)
+    enc = torch.nn.Linear(6, 3)
+    x1, x2 = torch.randn(4, 6), torch.randn(4, 6)
+    (enc(x1).square().mean() + enc(x2).square().mean()).backward()
+    ref = [p.grad.clone() for p in enc.parameters()]
+    for p in enc.parameters():
+        p.grad = None
+    scaler = A.BoundaryGradScale(enc, 1024.0)
+    red = vd.GradReducer(enc.parameters())
+    red.zero_grad()
+    for x in (x1, x2):                               # micro-batches: the second backward finds gradients still in units of S
+        scaler.rearm()
+        scaler.outputs(enc(x))[0].square().mean().backward()
+    red.finish()
+    for p, r in zip(enc.parameters(), ref):
+        assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-9)
+    red.remove()

@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("VICASPLAT_HIP_LIB") or os.path.join(_HERE, "libvicasplat_hip.so")   # (override: A/B runs of two builds)
 _lock = threading.Lock()
+ABI_VERSION = 7     # == vs_abi_version() of csrc/api.hip; INTEGRATION.md lists the entries of every version
 _lib = None
 
 VS_BUF_GEOM, VS_BUF_RECT, VS_BUF_CLAMPED, VS_BUF_TILE_RANGES, VS_BUF_TILE_CURSOR, VS_BUF_KEYS, VS_BUF_POINT_LIST, \
@@ -75,8 +76,8 @@ def lib() -> C.CDLL:
             L = C.CDLL(_SO)
             L.vs_last_error.restype = C.c_char_p
             L.vs_abi_version.restype = C.c_int
-            if L.vs_abi_version() != 6:     # the ctypes mirrors of the structs below are for exactly this layout
-                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs 6: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+            if L.vs_abi_version() != ABI_VERSION:     # the ctypes mirrors of the structs below are for exactly this layout
+                raise RuntimeError(f"{_SO} has ABI version {L.vs_abi_version()}, this package needs {ABI_VERSION}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
             L.vs_raster_forward.restype = C.c_int64
             L.vs_raster_forward.argtypes = [C.POINTER(VsRasterIn), C.POINTER(VsRasterOut), AllocFn, C.c_void_p, C.c_void_p]
             L.vs_rope2d.restype = C.c_int

@@ -63,7 +63,16 @@ class BoundaryGradScale:
             return
         self._armed = True
         self._active = self.params
-        old = [p.grad for p in self._active if p.grad is not None]
+        # gradients already in .grad (accumulation over micro-batches) are lifted to units of S -- except those in a GradReducer's buckets
+        # whose deferred unscale is still pending (a second backward before finish()): they ARE in units of S already
+        from .dist import reducer_of
+        old = []
+        for p in self._active:
+            if p.grad is None:
+                continue
+            red = reducer_of(p)
+            if red is None or not red.pending_unscale(p):
+                old.append(p.grad)
         if old:
             torch._foreach_mul_(old, self.scale)
         torch.autograd.Variable._execution_engine.queue_callback(self._requeue)
@@ -75,18 +84,18 @@ class BoundaryGradScale:
         self._armed = False
         active, self._active = self._active, []
         inv = 1.0 / self.scale
+        from .dist import reducer_of
         plain, reducers = [], {}
         for p in active:
             if p.grad is None:
                 continue
-            red = getattr(p, "_vs_reducer", None)
-            red = red() if red is not None else None
-            if red is not None and red.owns(p):
-                reducers[id(red)] = red
+            red = reducer_of(p)
+            if red is not None:
+                reducers.setdefault(id(red), (red, []))[1].append(p)
             else:
                 plain.append(p.grad)
-        for red in reducers.values():          # gradients living in a GradReducer's buckets: unscaled by finish(), after the collectives
-            red.defer_unscale(inv)
+        for red, ps in reducers.values():      # gradients living in a GradReducer's buckets: unscaled by finish(), after the collectives --
+            red.defer_unscale(inv, ps)         # exactly these parameters, not every bucket of the reducer
         if plain:
             with torch.no_grad():
                 self.last_overflow = unscale_and_check_(plain, inv)
@@ -390,10 +399,21 @@ class HeadTail16Fn(torch.autograd.Function):
 def head_tail_ok(t: torch.Tensor, w: torch.Tensor) -> bool:
     """Shapes csrc/head_bwd.hip serves: [.., Cin] contiguous rows (f32 = split class, f16, bf16), Cin 128 | 256, Cout <= 96, pixels a multiple of 32."""
     return (t.dtype in (torch.float32, torch.float16, torch.bfloat16) and t.is_contiguous() and t.shape[-1] in (128, 256) and w.shape[0] <= 96
-            and w.shape[1] == t.shape[-1] and (t.numel() // t.shape[-1]) % 32 == 0)
+            and w.shape[1] == t.shape[-1] and (t.numel() // t.shape[-1]) % 32 == 0 and _behind_relu(t))
+
+
+def _behind_relu(t: torch.Tensor) -> bool:
+    """The fused tail hands its input gradient over ALREADY masked by t > 0 and tells the producer to skip its own ReLU backward
+    (`_vs_relu_masked`): only valid when t IS the output of Conv3x3Fn(..., relu_out=True).  The producer is identified by its autograd node
+    (a custom Function's grad_fn is its ctx), not by convention at the call site; a t outside any graph has no consumer of dt."""
+    fn = t.grad_fn
+    return fn is None or (isinstance(fn, Conv3x3Fn._backward_cls) and bool(getattr(fn, "relu_out", False)))
 
 
 def head_tail(t: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], dt) -> torch.Tensor:
+    if not _behind_relu(t):
+        raise ValueError("autograd.head_tail: t must be the output of conv3x3(..., relu_out=True) -- the fused backward masks dt by t > 0 and the "
+                         "producer skips its ReLU backward; use autograd.linear for any other input")
     return HeadTailSplitFn.apply(t, w, b) if dt == SPLIT else HeadTail16Fn.apply(t, w, b, dt)
 
 
@@ -558,6 +578,7 @@ class Conv3x3Fn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, wp, y if relu_out else None)
         ctx.meta = (relu_in, b is not None, stride, residual is not None, split)
+        ctx.relu_out = bool(relu_out)      # read by head_tail_ok / head_tail through y.grad_fn
         return y
 
     @staticmethod

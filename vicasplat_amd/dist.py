@@ -85,6 +85,17 @@ def bucketed_allreduce_grads(params: Iterable[torch.nn.Parameter], bucket_bytes:
     return n_coll
 
 
+# parameter -> the GradReducer whose buckets hold its .grad.  Kept OUTSIDE the Parameter: Parameter.__reduce_ex__ pickles __dict__, and a
+# weakref there made torch.save(model) / pickling fail while a reducer was attached.  Weak values: a dropped reducer leaves no entry.
+_REDUCER_OF: "weakref.WeakValueDictionary[int, GradReducer]" = weakref.WeakValueDictionary()
+
+
+def reducer_of(p):
+    """The live GradReducer that owns p.grad, or None."""
+    r = _REDUCER_OF.get(id(p))
+    return r if (r is not None and r.owns(p)) else None
+
+
 class GradReducer:
     """Gradient exchange overlapped with the backward pass (what Lightning's DDP gives the reference, src/main.py:110-115).
 
@@ -135,7 +146,7 @@ class GradReducer:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._pending: List[tuple] = []
         self._unused_learned = unused_params is not None     # the static set is learned from the first COMPLETE step only
-        self._unscale = 1.0
+        self._unscale, self._unscale_ids, self._unscale_any = 1.0, None, False
         self.last_overflow = None
         self.zero_grad()
 
@@ -143,10 +154,25 @@ class GradReducer:
         """True while `p.grad` is (supposed to be) a view of one of this reducer's buckets, i.e. until remove()."""
         return bool(self._hooks) and getattr(p, "_vs_bucket", None) is not None
 
-    def defer_unscale(self, inv_scale: float):
-        """Called by autograd.BoundaryGradScale when backward ends: the gradients in the buckets are in units of 1 / inv_scale; finish()
-        multiplies every bucket by it after its collective has completed."""
-        self._unscale = float(inv_scale)
+    def defer_unscale(self, inv_scale: float, params=None):
+        """Called by autograd.BoundaryGradScale when backward ends: the gradients of `params` (None: of every parameter of this reducer)
+        sit in the buckets in units of 1 / inv_scale; finish() multiplies exactly those by it after their collective has completed.
+        Parameters of the reducer that the scaler does not cover (outside the encoder module, or whose gradient did not flow through the
+        boundary node) keep plain gradients."""
+        inv_scale = float(inv_scale)
+        if self._unscale != 1.0 and self._unscale != inv_scale:
+            raise RuntimeError("GradReducer: two backward passes with different boundary gradient scales before one finish()")
+        self._unscale = inv_scale
+        if params is None:
+            self._unscale_ids = None
+        elif self._unscale_ids is not None or not self._unscale_any:
+            self._unscale_ids = (self._unscale_ids or set()) | {id(p) for p in params}
+        self._unscale_any = True
+
+    def pending_unscale(self, p) -> bool:
+        """True while p's gradient in the bucket is still in units of the boundary scale (between the end of a backward and finish()): a
+        second backward before finish() accumulates onto it as it is -- the scaler must not lift it by S again."""
+        return self._unscale_any and (self._unscale_ids is None or id(p) in self._unscale_ids)
 
     def reset_unused(self):
         """Forget the learned set of gradient-less parameters (call when the graph changes on purpose: e.g. the distillation phase, which
@@ -165,8 +191,8 @@ class GradReducer:
         self.buckets.append(dict(params=plist, flat=flat, views=views, ready=0, launched=False, got=[False] * len(plist),
                                  stage=torch.empty(n, dtype=self.comm_dtype, device=dev) if self.comm_dtype else None))
         for i, p in enumerate(plist):
-            p._vs_bucket, p._vs_slot = len(self.buckets) - 1, i
-            p._vs_reducer = weakref.ref(self)
+            p._vs_bucket, p._vs_slot = len(self.buckets) - 1, i      # plain ints: a Parameter's __dict__ is pickled with it
+            _REDUCER_OF[id(p)] = self                               # (a weakref stored ON the parameter broke torch.save(model))
 
     def zero_grad(self):
         """Zero the flat buckets and (re)attach every p.grad as a view of its bucket."""
@@ -177,7 +203,7 @@ class GradReducer:
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
         self._pending = []
-        self._unscale = 1.0
+        self._unscale, self._unscale_ids, self._unscale_any = 1.0, None, False
         self._next = 0            # buckets are launched strictly in index order: every rank issues the same collective sequence
 
     def _launch(self, b):
@@ -226,16 +252,25 @@ class GradReducer:
         # averaging and the deferred 1/S of the Module API's internal gradient scale, one pass per bucket, after its collective
         found = None
         for b in self.buckets:
-            f = self._unscale / (self.world if (self.average and id(b) in waited) else 1)
-            if self._unscale != 1.0:
+            avg = 1.0 / (self.world if (self.average and id(b) in waited) else 1)
+            if self._unscale_any and self._unscale != 1.0:
                 from .autograd import unscale_and_check_
-                fl = unscale_and_check_([b["flat"]], f)
-                found = fl if found is None else torch.maximum(found, fl)
-            elif f != 1.0:
-                b["flat"] *= f
+                ids = self._unscale_ids
+                cov = [ids is None or id(p) in ids or not got for p, got in zip(b["params"], b["got"])]
+                if all(cov):      # the usual case: every gradient of the bucket came through the boundary node (or is absent: zeros)
+                    fl = unscale_and_check_([b["flat"]], self._unscale * avg)
+                else:             # a reducer over encoder + other parameters: only the scaler's own are in units of S
+                    fl = unscale_and_check_([v for v, c in zip(b["views"], cov) if c], self._unscale * avg) if any(cov) else None
+                    rest = [v for v, c in zip(b["views"], cov) if not c]
+                    if avg != 1.0 and rest:
+                        torch._foreach_mul_(rest, avg)
+                if fl is not None:
+                    found = fl if found is None else torch.maximum(found, fl)
+            elif avg != 1.0:
+                b["flat"] *= avg
         if found is not None:
             self.last_overflow = found
-        self._unscale = 1.0
+        self._unscale, self._unscale_ids, self._unscale_any = 1.0, None, False
         self._pending = []
         # parameters that received no gradient this step keep .grad = None, as under DDP: the optimizer skips them (a zero gradient
         # would still be weight-decayed by AdamW every step).  The model's graph does not depend on the rank or the data, so the set is
@@ -264,6 +299,8 @@ class GradReducer:
             h.remove()
         self._hooks = []
         for p in self.params:
-            for a in ("_vs_bucket", "_vs_slot", "_vs_reducer"):
+            for a in ("_vs_bucket", "_vs_slot"):
                 if hasattr(p, a):
                     delattr(p, a)
+            if _REDUCER_OF.get(id(p)) is self:
+                del _REDUCER_OF[id(p)]

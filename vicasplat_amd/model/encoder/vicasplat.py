@@ -196,7 +196,13 @@ class VicaSplat(Encoder[VicaSplatCfg]):
         image = context["image"]
         if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in self.parameters())):
             if self.train_compute_class() == torch.float32:
-                # the exact-f32 MFMA class has no backward kernels: run inference (as eval under no_grad would) and say so, once
+                # the exact-f32 MFMA class has no backward kernels.  In train() mode this is a training loop: fail HERE with the reason,
+                # not later in loss.backward() with "does not require grad" (ADVICE r5).  In eval() mode run inference (as under no_grad)
+                # and say so.
+                if self.training:
+                    raise RuntimeError("VicaSplat.forward: the exact-f32 operand class is inference-only (no backward kernels), but the module is in "
+                                       "train() mode with grad enabled and trainable parameters.  Train in the \"split\" class "
+                                       "(set_compute_dtype(\"split\"): f32 activations and gradients), or call under torch.no_grad() / eval().")
                 _warn_once("f32-no-grad", "VicaSplat.forward: the exact-f32 operand class is inference-only; grad mode is on and a parameter "
                            "requires grad, but this call runs the fused no-grad path (outputs carry no graph).  Train in the \"split\" class.")
             else:
