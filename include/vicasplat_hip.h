@@ -67,7 +67,8 @@ typedef struct VsRasterIn {
 
 enum {
     VS_RASTER_COUNT_TOUCHED = 1, /* fill n_touched (MonoGS bookkeeping; VicaSplat discards it) */
-    VS_RASTER_SAVE_FOR_BACKWARD = 2,
+    VS_RASTER_SAVE_FOR_BACKWARD = 2, /* (ABI 8) the forward also stores VS_BUF_CHECKPOINT; vs_raster_backward then needs saved->color (and
+                                        saved->depth when dL_ddepth is given) alive as well.  Without it the backward walks every list in one piece */
     VS_RASTER_SH_RGB_MAJOR = 4,  /* shs laid out [S,P,3,M] (the encoder's native `harmonics` layout,
                                     gaussian_adapter.py:183) instead of [S,P,M,3]: saves the transpose copy of
                                     cuda_splatting.py:182 */
@@ -90,7 +91,10 @@ enum {
     VS_BUF_N_CONTRIB = 9, /* [C,H,W] i32 */
     VS_BUF_MISC = 10,     /* int64[4] control block: [0] R, [1] largest tile population, [2] capacity overflow flag */
     VS_BUF_DEPTH = 11,    /* [C,P] f32 view-space depth of the visible pairs (sort-key source; undefined where rect is all-zero) */
-    VS_BUF_COUNT = 12
+    VS_BUF_CHECKPOINT = 12, /* (ABI 8; only under VS_RASTER_SAVE_FOR_BACKWARD) [slots,5,256] f32 blending state (T | Cr | Cg | Cb | D) of a tile's 256
+                               pixels in front of every 512th entry of its list, then [slots] {i32 tile, i32 segment}; slots = (R >> 9) + C * tiles.
+                               With it vs_raster_backward replays the 512-entry segments of a list independently (front to back) */
+    VS_BUF_COUNT = 13
 };
 typedef void *(*VsAllocFn)(void *ctx, int32_t tag, size_t bytes);
 

@@ -358,8 +358,17 @@ def _close(a, b, name, rtol):
     assert np.abs(a - b).max() <= rtol * scale, (name, float(np.abs(a - b).max()), float(scale))
 
 
+@pytest.fixture(params=["0", "4", "1"])
+def rbwd_waves(request, monkeypatch):
+    """The three render-backward kernels (round 6; VS_RBWD_WAVES is read per call): 0 = the default of every differentiated call -- the
+    segment-parallel replay from the forward's blending checkpoints (front to back, a wave per 512-entry segment); 4 / 1 = the whole-list
+    kernels a caller without VS_RASTER_SAVE_FOR_BACKWARD gets (four waves per tile, a quadrant each / one wave per tile, a 2x2 block per lane)."""
+    monkeypatch.setenv("VS_RBWD_WAVES", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("W,H,P", [(48, 32, 60), (64, 64, 400)])
-def test_backward_matches_oracle(W, H, P):
+def test_backward_matches_oracle(W, H, P, rbwd_waves):
     from vicasplat_amd.raster import rasterize
     d = _dev()
     means, cov, sh, op = _random_small(P, seed=100 + P)
@@ -394,7 +403,7 @@ def test_backward_matches_oracle(W, H, P):
     _close(theta.grad.cpu(), tau[:, 3:], "theta", 5e-3)
 
 
-def test_backward_through_render_cuda_native_layouts():
+def test_backward_through_render_cuda_native_layouts(rbwd_waves):
     """[S,P,3,3] covariances + [S,P,3,25] harmonics (encoder-native layouts): gradients land in those layouts."""
     from vicasplat_amd.model.decoder.cuda_splatting import render_cuda
     d = _dev()
@@ -477,7 +486,7 @@ def _config3_backward(n_views=1, seed_grad=11):
     return sc, cams, c6, shs, gC, gD, run
 
 
-def test_backward_config3_scene_131k_matches_oracle():
+def test_backward_config3_scene_131k_matches_oracle(rbwd_waves):
     sc, cams, c6, shs, gC, gD, run = _config3_backward(1)
     _, g = run()
     bg = np.zeros(3, np.float32)

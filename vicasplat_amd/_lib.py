@@ -15,11 +15,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("VICASPLAT_HIP_LIB") or os.path.join(_HERE, "libvicasplat_hip.so")   # (override: A/B runs of two builds)
 _lock = threading.Lock()
-ABI_VERSION = 7     # == vs_abi_version() of csrc/api.hip; INTEGRATION.md lists the entries of every version
+ABI_VERSION = 8     # == vs_abi_version() of csrc/api.hip; INTEGRATION.md lists the entries of every version
 _lib = None
 
 VS_BUF_GEOM, VS_BUF_RECT, VS_BUF_CLAMPED, VS_BUF_TILE_RANGES, VS_BUF_TILE_CURSOR, VS_BUF_KEYS, VS_BUF_POINT_LIST, \
-    VS_BUF_SORT_SCRATCH, VS_BUF_FINAL_T, VS_BUF_N_CONTRIB, VS_BUF_MISC, VS_BUF_DEPTH, VS_BUF_COUNT = range(13)
+    VS_BUF_SORT_SCRATCH, VS_BUF_FINAL_T, VS_BUF_N_CONTRIB, VS_BUF_MISC, VS_BUF_DEPTH, VS_BUF_CHECKPOINT, VS_BUF_COUNT = range(14)
 VS_RASTER_COUNT_TOUCHED = 1
 VS_RASTER_SAVE_FOR_BACKWARD = 2
 VS_RASTER_SH_RGB_MAJOR = 4

@@ -12,7 +12,7 @@ void set_error(const char *fmt, ...) {
 }  // namespace vs
 
 extern "C" const char *vs_last_error(void) { return vs::g_err; }
-extern "C" int vs_abi_version(void) { return 7; }   // 7: the round-5 entries (vs_head1x1_backward_split/16, vs_conv3x3_wgrad_split_stream, vs_stem7x7_up_split_stream, vs_im2col7x7_rgb); 6: colsum argument of vs_transpose_f32 / vs_transpose_pack_split; 5: round 4 -- vs_range_check (split-class range guard), ...; 2: VsRasterIn.capacity, VS_BUF_DEPTH (round 2); 3: split operands (dtype 4, vs_gemm_split, ...);
+extern "C" int vs_abi_version(void) { return 8; }   // 8 (round 6): VS_BUF_CHECKPOINT / VS_RASTER_SAVE_FOR_BACKWARD (VsRasterOut.buffers[13]), vs_raster_backward reads saved->color / depth on that route; 7: the round-5 entries (vs_head1x1_backward_split/16, vs_conv3x3_wgrad_split_stream, vs_stem7x7_up_split_stream, vs_im2col7x7_rgb); 6: colsum argument of vs_transpose_f32 / vs_transpose_pack_split; 5: round 4 -- vs_range_check (split-class range guard), ...; 2: VsRasterIn.capacity, VS_BUF_DEPTH (round 2); 3: split operands (dtype 4, vs_gemm_split, ...);
                                                       // 4: split-class backward entries, packed activations (+16 flags, vs_gemm_split_packed), vs_probe_mfma_rate
 
 // ---- measurement aid (bench.py `roofline.sustained_mfma_tflops`): the rate the chip SUSTAINS on the matrix pipe alone.  The MFMA kernels

@@ -34,5 +34,8 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kTile = 16;           // 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y)
 constexpr int kGeomFloats = 12;     // VS_BUF_GEOM record
+constexpr int kCkShift = 9;         // VS_BUF_CHECKPOINT: the render kernel stores the blending state of a tile every 2^kCkShift list entries
+constexpr int kCkSeg = 1 << kCkShift;
+constexpr int kCkFloats = 5 * 256;  // T | Cr | Cg | Cb | D of the 256 pixels, in 2x2-block order
 
 }  // namespace vs

@@ -883,8 +883,9 @@ __global__ void __launch_bounds__(64 * NW)
 render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ background, float *__restrict__ out_color,
               float *__restrict__ out_depth, float *__restrict__ out_opacity, float *__restrict__ final_T,
-              int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched) {
+              int32_t *__restrict__ n_contrib, int32_t *__restrict__ n_touched, float *__restrict__ ckpt, int2 *__restrict__ cktab) {
     constexpr int NTHR = 64 * NW, NT = NTB, RPT = NT / NTHR, NQ = 4 / NW;   // staged batch: NT records, RPT per thread; NQ quadrants per wave
+    static_assert(vs::kCkSeg % NTB == 0, "checkpoints fall on batch boundaries");
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
     __shared__ uint32_t sid[NT];
     const int gx = (W + kTile - 1) / kTile;
@@ -913,6 +914,17 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
     const uint32_t *__restrict__ plist = point_list + rg.x;
     const int n = rg.y - rg.x;
+    // VS_RASTER_SAVE_FOR_BACKWARD (round 6): the blending state of the tile's 256 pixels is stored every kCkSeg list entries, so that the
+    // backward can replay the segments of a list INDEPENDENTLY (render_backward_seg_kernel, raster_bwd.hip) instead of walking the whole
+    // list in one wave.  Tile t (linear index) owns the slots (x >> kCkShift) + t .. (y >> kCkShift) + t of the checkpoint table -- the
+    // ranges are contiguous, so the slots tile the table exactly, as the sort's run table does.  Slot k of the tile = segment k = entries
+    // [k * kCkSeg, (k + 1) * kCkSeg); its state is written when the loop reaches it (a tile whose pixels are all done earlier never
+    // writes it: the backward reads the last contributors first and never asks for it).
+    const size_t ck_base = (size_t)(rg.x >> vs::kCkShift) + (size_t)t_lin;
+    if (cktab) {
+        const int slots = (rg.y >> vs::kCkShift) - (rg.x >> vs::kCkShift) + 1;
+        for (int k = tid; k < slots; k += NTHR) cktab[ck_base + k] = (k * vs::kCkSeg < n) ? make_int2(t_lin, k) : make_int2(-1, 0);
+    }
 
     float T[NQ], Cr[NQ], Cg[NQ], Cb[NQ], Dd[NQ], thr[NQ];
     int last_contrib[NQ];
@@ -980,6 +992,15 @@ render_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32
     for (int base = 0; base < n; base += NT) {
         // (also orders the previous batch's LDS reads before this batch's stores)
         if (__syncthreads_count(lane_done()) == NTHR) break;
+        if (ckpt && base > 0 && (base & (vs::kCkSeg - 1)) == 0) {   // state in front of entry `base`: [T | Cr | Cg | Cb | D][block (by * 8 + bx)][pixel of the 2x2 block]
+            float *ck = ckpt + (ck_base + (size_t)(base >> vs::kCkShift)) * vs::kCkFloats;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int quad = NW == 4 ? wid : q;
+                const int idx = ((((quad >> 1) * 4 + byi) * 8) + (quad & 1) * 4 + bxi) * 4 + (lane & 3);
+                ck[idx] = T[q]; ck[256 + idx] = Cr[q]; ck[512 + idx] = Cg[q]; ck[768 + idx] = Cb[q]; ck[1024 + idx] = Dd[q];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             const int e = u * NTHR + tid;
@@ -1139,6 +1160,16 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
                                scratch, point_list);
     }
     const bool count = (in->flags & VS_RASTER_COUNT_TOUCHED) && out->n_touched;
+    // blending checkpoints for the segment-parallel backward: [slots][5][256] f32 followed by the slot table [slots] {tile, segment}
+    float *ckpt = nullptr;
+    int2 *cktab = nullptr;
+    if ((in->flags & VS_RASTER_SAVE_FOR_BACKWARD) && R > 0) {
+        const size_t ck_slots = (size_t)(R >> vs::kCkShift) + (size_t)tiles * C;
+        ckpt = (float *)get(VS_BUF_CHECKPOINT, ck_slots * (vs::kCkFloats * sizeof(float) + sizeof(int2)));
+        VS_CHECK(ckpt, "vs_raster_forward: allocator returned null");
+        cktab = reinterpret_cast<int2 *>(ckpt + ck_slots * vs::kCkFloats);
+        VS_HIP(hipMemsetAsync(cktab, 0xFF, ck_slots * sizeof(int2), stream));   // slots no tile owns (capacity mode) stay {-1, -1}
+    }
     dim3 rgrid(tiles, C);
     // One wave per tile when there are enough tiles to fill the chip with single waves (>= 16 per CU: the batched bench / training calls),
     // four waves per tile (a quadrant each) for small calls, where a tile's latency matters more than wave slots.  Same results either
@@ -1147,14 +1178,14 @@ extern "C" int64_t vs_raster_forward(const VsRasterIn *in, VsRasterOut *out, VsA
     const int render_waves = force_waves ? force_waves : ((long long)tiles * C >= 4096 ? 1 : 4);
 #define VS_RENDER(CNT_, NW_)                                                                                                         \
     hipLaunchKernelGGL((render_kernel<CNT_, NW_>), rgrid, dim3(64 * NW_), 0, stream, P, W, H, ranges, point_list, geom, in->background, \
-                       out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched)
+                       out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched, ckpt, cktab)
     // one wave per tile: staged batches of 64 records (round 5: 96 VGPRs and 3.3 KiB of LDS per wave -> five waves per SIMD instead of
     // three; the kernel is latency bound -- PMC: VALU issue 0.42, 38 % of the wave cycles waiting -- and a batch is one round of the
     // 64-entry footprint test anyway.  256 / 128 / 64: 5.23 / 4.73 / 4.60 ms on the bench step, bit-identical; VS_RENDER_NT = 256 | 128 for A/B)
     static const int ntb = [] { const char *e = getenv("VS_RENDER_NT"); return e ? atoi(e) : 64; }();
 #define VS_RENDER1(CNT_, NT_)                                                                                                         \
     hipLaunchKernelGGL((render_kernel<CNT_, 1, NT_>), rgrid, dim3(64), 0, stream, P, W, H, ranges, point_list, geom, in->background,   \
-                       out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched)
+                       out->color, out->depth, out->opacity, final_T, n_contrib, out->n_touched, ckpt, cktab)
     if (render_waves == 1) {
         if (ntb == 256) { if (count) VS_RENDER1(true, 256); else VS_RENDER1(false, 256); }
         else if (ntb == 128) { if (count) VS_RENDER1(true, 128); else VS_RENDER1(false, 128); }

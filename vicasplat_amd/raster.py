@@ -143,6 +143,10 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
                 cam_scene, theta, rho, projmatrix_raw, H, W, sh_degree, flags):
+        # a differentiated call also stores the blending checkpoints (VS_BUF_CHECKPOINT): the backward then replays the 512-entry segments
+        # of every tile list independently instead of walking each list in one wave (round 6)
+        if any(ctx.needs_input_grad):
+            flags |= L.VS_RASTER_SAVE_FOR_BACKWARD
         outs, st = _forward_impl(means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov,
                                  background, cam_scene, H, W, sh_degree, flags)
         color, radii, depth, opacity, n_touched = outs
@@ -157,7 +161,9 @@ class _Rasterize(torch.autograd.Function):
         # The backward needs exactly one output, radii (ctx.out.radii): it goes through save_for_backward.
         ctx.keep = (means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
                     cam_scene, projmatrix_raw)
-        ctx.save_for_backward(radii)
+        # outputs the backward reads (radii always; the rendered colour / depth on the checkpoint route): through save_for_backward only
+        ctx.save_for_backward(radii, color, depth)
+        ctx.set_materialize_grads(False)     # an output no loss reads (the depth image, usually) arrives as None, not as a zero image
         ctx.want_tau = theta is not None or rho is not None
         ctx.dims = st["dims"]
         ctx.num_rendered = st["num_rendered"]
@@ -171,24 +177,25 @@ class _Rasterize(torch.autograd.Function):
             raise RuntimeError("libvicasplat_hip.so was built without vs_raster_backward")
         (means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background, cam_scene,
          projmatrix_raw) = ctx.keep
-        (radii,) = ctx.saved_tensors               # keeps the buffer behind ctx.out.radii alive
-        ctx.out.radii = L.ptr(radii)
+        radii, color, depth = ctx.saved_tensors    # keeps the buffers behind ctx.out.radii / color / depth alive
+        ctx.out.radii, ctx.out.color, ctx.out.depth = L.ptr(radii), L.ptr(color), L.ptr(depth)
         S, P, Cn, M, H, W, cov33 = ctx.dims
         dev = means3D.device
         g_color = _f32c(g_color) if g_color is not None else torch.zeros((Cn, 3, H, W), dtype=torch.float32, device=dev)
         g_depth = _f32c(g_depth)
         g = L.VsRasterGrads()
-        # every element of these is stored by preprocess_backward_kernel (one thread per Gaussian); dL_dmeans2D is cleared by the C side
+        # every element of these is stored by preprocess_backward_kernel (one thread per Gaussian)
         d_means = torch.empty_like(means3D)
         d_cov = torch.empty((S, P, 3, 3) if cov33 else (S, P, 6), dtype=torch.float32, device=dev)   # layout of the input covariances
         d_shs = torch.empty_like(shs) if shs is not None else None
         d_cp = torch.empty_like(colors_precomp) if colors_precomp is not None else None
         d_op = torch.empty_like(opacities)
-        d_m2d = torch.empty((Cn, P, 2), dtype=torch.float32, device=dev)
+        # dL_dmeans2D (upstream's screen-space gradient holder, a densification statistic) has no consumer on this path: not requested --
+        # [C,P,2] f32 that the C side would clear and preprocess_backward_kernel would fill (2.4 GB of traffic per 288 views)
         d_tau = torch.zeros((Cn, 6), dtype=torch.float32, device=dev) if ctx.want_tau else None
         g.dL_dcolor, g.dL_ddepth = L.ptr(g_color), L.ptr(g_depth)
         g.dL_dmeans3D, g.dL_dcov3D, g.dL_dshs, g.dL_dcolors_precomp = L.ptr(d_means), L.ptr(d_cov), L.ptr(d_shs), L.ptr(d_cp)
-        g.dL_dopacities, g.dL_dmeans2D, g.dL_dtau = L.ptr(d_op), L.ptr(d_m2d), L.ptr(d_tau)
+        g.dL_dopacities, g.dL_dmeans2D, g.dL_dtau = L.ptr(d_op), None, L.ptr(d_tau)
         alloc = L.TorchAllocator(dev)
         with torch.cuda.device(dev):
             rc = lib.vs_raster_backward(C.byref(ctx.inp), C.byref(ctx.out), C.byref(g), alloc.fn, None, L.stream_ptr(dev))
