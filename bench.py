@@ -144,6 +144,60 @@ def raster_roofline(rs, traffic, design_min, R, gaussians, views, pmc_file):
     return d
 
 
+def raster_backward_roofline(step, B, V, Vt):
+    """the rasterizer BACKWARD (cuda_splatting.py:226-235 under autograd) against the HBM roofline, measured inside one
+    extra (untimed-for-the-headline) training step: vs_raster_backward bracketed with events on the launch stream (its three parts: the zero
+    fill of the per-(camera, Gaussian) gradient records, the render replay, the per-Gaussian reduction), the forward beside it.  `achieved`
+    = counter bytes (FETCH_SIZE x2 gfx950 correction except the gather kernel + WRITE_SIZE of those kernels, separate PMC passes of
+    tools/raster_fb_prof.sh on the same scene family, committed as profiles/round6_pmc_raster_bwd.json) / the live duration; the bytes this
+    design must move at minimum are stated beside it: list + record gathers R * 52, the pixel data, the gradient records written once and
+    read once (views * P * 40 each way), radii / clamp masks views * P * 5, the scene's attributes in and gradients out S * P * (232 + 352)."""
+    from vicasplat_amd import raster
+    rec = {}
+
+    def wrap(name):
+        orig = getattr(raster, name)
+
+        def f(*a, **k):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(); r = orig(*a, **k); e_.record()
+            rec.setdefault(name, []).append((s_, e_, r if name == "_forward_impl" else a[1]))
+            return r
+
+        setattr(raster, name, f)
+        return orig
+
+    o1, o2 = wrap("_forward_impl"), wrap("_backward_impl")
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        raster._forward_impl, raster._backward_impl = o1, o2
+    fwd_ms = sum(s_.elapsed_time(e_) for s_, e_, _ in rec["_forward_impl"])
+    bwd_ms = sum(s_.elapsed_time(e_) for s_, e_, _ in rec["_backward_impl"])
+    st = rec["_forward_impl"][0][2][1]
+    S, Pn, Cn, M, H, W, _ = st["dims"]
+    R = sum(x[2][1]["num_rendered"] for x in rec["_forward_impl"])
+    design_min = R * 52.0 + Cn * H * W * 32.0 + 2.0 * Cn * Pn * 40.0 + Cn * Pn * 5.0 + S * Pn * (232.0 + 352.0)
+    d = dict(bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", ms=round(bwd_ms, 3), forward_ms=round(fwd_ms, 3), views=Cn, gaussians=S * Pn, num_rendered=int(R),
+             ms_per_288_views=round(bwd_ms * 288.0 / Cn, 2), design_min_bytes=int(design_min),
+             design_min_achieved=round(design_min / (bwd_ms * 1e-3) / 1e9, 1), design_min_frac=round(design_min / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+             kernels="hipMemset of the gradient records + render_backward_seg_kernel (segment-parallel replay from the forward's checkpoints) + preprocess_backward_kernel")
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "round6_pmc_raster_bwd.json")))
+        per_view = pm["backward"]["hbm_bytes_per_view"]
+        traffic = per_view * Cn
+        d["traffic_basis"] = pm["backward"]["basis"]
+        d["valu_issue"] = pm.get("valu_issue")
+    except Exception:
+        pass
+    byt = traffic if traffic else design_min
+    d.update(achieved=round(byt / (bwd_ms * 1e-3) / 1e9, 1), frac=round(byt / (bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), traffic=(int(traffic) if traffic else None),
+             traffic_over_design_min=(round(traffic / design_min, 3) if traffic else None))
+    return d
+
+
 def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, steps=None, checkpoint=False):
     """BASELINE configs 4 / 5: the full training step -- encoder + decoder + rasterizer forward, MSE, backward on the HIP kernels,
     gradient exchange (GradReducer: bucketed all-reduce over RCCL overlapped with backward; N > 1 only), clip 0.5, AdamW -- on
@@ -188,6 +242,12 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms = el / nsteps * 1e3
+    rb = None
+    if rank == 0:
+        try:
+            rb = raster_backward_roofline(lambda: callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer), B, V, Vt)
+        except Exception as ex:      # an instrumentation failure must not take the leg with it
+            rb = dict(error=repr(ex)[:200])
     # algorithmic FLOPs of the step: 3 407 GFLOP forward per 8-view scene, backward = 2x forward
     flops = 3.0 * 3407e9 * (V / 8.0) * B
     tf_s = flops / (ms * 1e-3) / 1e12
@@ -205,6 +265,7 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
                 loss=float(r["loss"]), grad_norm=float(r["grad_norm"]), skipped=bool(r["skipped"]),
                 peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 1),
                 gradient_exchange=("none (1 GPU)" if world == 1 else f"GradReducer: 64 MiB buckets all-reduced during backward, RCCL x{world}"),
+                roofline_rasterizer_backward=rb,
                 roofline=dict(bound="mfma", achieved=round(tf_s, 1), peak=round(peak_tf, 1), unit="TFLOP/s",
                               frac=round(tf_s / peak_tf, 4),
                               what="whole step: 3 x 3407 GFLOP per 8-view scene (fwd + 2x bwd, SURVEY 8d) / step time"))

@@ -586,22 +586,22 @@ render_backward_seg_kernel(int P, int W, int H, int tiles, const int2 *__restric
     }
 }
 
-__device__ __forceinline__ float block_sum(float v, float *sm) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) sm[wid] = v;
-    __syncthreads();
-    return sm[0] + sm[1] + sm[2] + sm[3];
-}
-
+// K2, round 6.  Same mathematics as rounds 2-5 (one thread per Gaussian of a scene, the scene's cameras summed in registers, plain stores),
+// re-cut for the machine: the round-5 kernel held 249 VGPRs and 59 KB of LDS (two waves per SIMD) and waited on two dependent global round
+// trips per camera (radius -> gradient record): 0.20 of the VALU issue rate, 9.4 ms per 288 views.
+//   * the view-direction gradient of the colour no longer forms dRGB/d(dir) per channel (3 x 45 coefficient reads, ~270 FLOPs): the
+//     channel sum is taken FIRST, w_k = sum_ch sh[k][ch] g[ch] (45 FMAs, every coefficient read once from LDS), then
+//     d(dir) = sum_k grad(basis_k) w_k (45 FMAs on polynomials shared by the channels);
+//   * software pipeline over the cameras: the radius of camera k + 2 and the gradient record / clamp mask of camera k + 1 are in
+//     flight while camera k is computed;
+//   * the camera-twist sums leave per wave (shuffle reduction + one atomic per wave and component) instead of twelve block barriers per camera;
+//   * the SH gradient (75 floats per Gaussian at a 300-byte stride: 64 cache lines per store instruction, 9.2 GB written for 5.6 GB of
+//     results) leaves through the LDS image of the coefficients, which is dead by then: coalesced dword stores.
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
                            const float *__restrict__ grec, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dcov3D,
                            float *__restrict__ dL_dshs, float *__restrict__ dL_dcolors_precomp, float *__restrict__ dL_dopac,
                            float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dtau) {
-    __shared__ float sm[4];
     const int s = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int P = in.P;
@@ -613,10 +613,10 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
     const int M = in.sh_coeffs;
     const int deg = in.sh_degree;
     const int ncoef = deg >= 3 ? 16 : (deg + 1) * (deg + 1);
+    const int lane = threadIdx.x & 63;
 
     float px = 0.f, py = 0.f, pz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
-    // the Gaussian's SH coefficients (bands 1..3, read 45 times per camera by the view-direction gradient) live in LDS, one column per
-    // thread: 48 registers less than a register copy -- with it and the 48 SH gradients the kernel needed 308 registers (one wave per SIMD)
+    // the Gaussian's SH coefficients of bands 1..3 live in LDS, one column per thread (45 x 256 floats)
     __shared__ float s_sh[45][256];
 #define SHV(k_, ch_) s_sh[((k_) - 1) * 3 + (ch_)][threadIdx.x]
 #pragma unroll
@@ -642,24 +642,21 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
     const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
 
     float g_mean[3] = {0.f, 0.f, 0.f}, g_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g_op = 0.f, g_cp[3] = {0.f, 0.f, 0.f};
-    float g_sh[16][3];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
 
-    // the scene's cameras, ascending (built once per block by wave 0 with ballot compaction, as in the forward's preprocess_kernel)
-    constexpr int kCamChunk = 2048;
+    // the scene's cameras, ascending (built per block by wave 0 with ballot compaction, as in the forward's preprocess_kernel)
+    constexpr int kCamChunk = 512;
     __shared__ int cams[kCamChunk];
     __shared__ int ncam_s;
     constexpr int kParCams = 32, kParStride = 40;
     __shared__ __attribute__((aligned(16))) float cpar[kParCams * kParStride];
-    for (int cbase = 0; cbase < in.num_cameras; cbase += kCamChunk) {
+    // the camera list of chunk [cbase, cbase + kCamChunk) and the staged parameters of its first kParCams cameras (block-wide: two barriers)
+    auto build_cams = [&](int cbase) -> int {
       __syncthreads();
       if (threadIdx.x < 64) {
-          const int lane = threadIdx.x;
           int n = 0;
           const int cend = min(in.num_cameras, cbase + kCamChunk);
-          for (int c0 = cbase; c0 < cend; c0 += 64) {
-              const int c = c0 + lane;
+          for (int cc0 = cbase; cc0 < cend; cc0 += 64) {
+              const int c = cc0 + lane;
               const bool mine = c < cend && (in.cam_scene ? in.cam_scene[c] : (c % in.num_scenes)) == s;
               const unsigned long long m = __ballot(mine);
               if (mine) cams[n + __popcll(m & ((1ull << lane) - 1ull))] = c;
@@ -669,26 +666,47 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
       }
       __syncthreads();
       const int ncam = ncam_s;
-      {   // camera parameters of the first kParCams cameras, staged once per block (as in the forward's preprocess_kernel, round 5: the
-          // kernel argument is a struct of pointers, so the compiler fetched them with vector loads in every camera iteration)
-          const int nst = min(ncam, kParCams);
-          for (int e = threadIdx.x; e < nst * kParStride; e += 256) {
-              const int kk = e / kParStride, q = e - kk * kParStride, cc = cams[kk];
-              float v = 0.f;
-              if (q < 16) v = in.viewmatrix[16 * cc + q];
-              else if (q < 32) v = in.projmatrix[16 * cc + q - 16];
-              else if (q < 35) v = in.campos[3 * cc + q - 32];
-              else if (q < 37) v = in.tanfov[2 * cc + q - 35];
-              cpar[e] = v;
-          }
-          __syncthreads();
+      // (the kernel argument is a struct of pointers: the compiler would fetch the camera parameters with vector loads in every iteration)
+      const int nst = min(ncam, kParCams);
+      for (int e = threadIdx.x; e < nst * kParStride; e += 256) {
+          const int kk = e / kParStride, q = e - kk * kParStride, cc = cams[kk];
+          float v = 0.f;
+          if (q < 16) v = in.viewmatrix[16 * cc + q];
+          else if (q < 32) v = in.projmatrix[16 * cc + q - 16];
+          else if (q < 35) v = in.campos[3 * cc + q - 32];
+          else if (q < 37) v = in.tanfov[2 * cc + q - 35];
+          cpar[e] = v;
+      }
+      __syncthreads();
+      return ncam;
+    };
+    for (int cbase = 0; cbase < in.num_cameras; cbase += kCamChunk) {
+      const int ncam = build_cams(cbase);
+      // ---- TWO passes over the cameras (the second one below, after this loop), so that the register file holds either the geometry path's state or the colour path's 48 SH
+      // accumulators, not both (251 VGPRs -> two waves per SIMD when they shared one loop).  Each pass is software-pipelined: the radius
+      // of camera k + 2 and its part of the gradient record of camera k + 1 are in flight while camera k is computed. ----
+      // pass A: 2-D covariance, projected mean, depth -> g_mean, g_cov, g_op (and their part of the twist gradient)
+      {
+      int rad0 = 0, rad1 = 0;
+      float2 ra0 = make_float2(0.f, 0.f), rb0 = ra0, rc0 = ra0, re0 = ra0;
+      if (live && ncam > 0) rad0 = radii[(size_t)cams[0] * P + i];
+      if (live && ncam > 1) rad1 = radii[(size_t)cams[1] * P + i];
+      if (rad0 > 0) {
+          const float2 *r2 = reinterpret_cast<const float2 *>(grec + ((size_t)cams[0] * P + i) * kG);
+          ra0 = r2[0]; rb0 = r2[1]; rc0 = r2[2]; re0 = r2[4];
       }
       for (int kc = 0; kc < ncam; ++kc) {
         const int c = __builtin_amdgcn_readfirstlane(cams[kc]);   // wave-uniform
-        const size_t ci = (size_t)c * P + (live ? i : 0);
+        int rad2 = 0;
+        if (live && kc + 2 < ncam) rad2 = radii[(size_t)cams[kc + 2] * P + i];
+        float2 ra1 = make_float2(0.f, 0.f), rb1 = ra1, rc1 = ra1, re1 = ra1;
+        if (rad1 > 0) {   // (rad1 > 0 implies live and kc + 1 < ncam)
+            const float2 *r2 = reinterpret_cast<const float2 *>(grec + ((size_t)cams[kc + 1] * P + i) * kG);
+            ra1 = r2[0]; rb1 = r2[1]; rc1 = r2[2]; re1 = r2[4];
+        }
         float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (live && radii[ci] > 0) {
-            float vm[16], pm[16], cp[3], tanfovx, tanfovy;
+        if (rad0 > 0) {
+            float vm[16], pm[16], tanfovx, tanfovy;
             if (kc < kParCams) {                                  // (wave-uniform) LDS broadcast reads
                 const float4 *q4 = reinterpret_cast<const float4 *>(cpar + kc * kParStride);
 #pragma unroll
@@ -697,21 +715,18 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
                     vm[4 * j] = a4.x; vm[4 * j + 1] = a4.y; vm[4 * j + 2] = a4.z; vm[4 * j + 3] = a4.w;
                     pm[4 * j] = b4.x; pm[4 * j + 1] = b4.y; pm[4 * j + 2] = b4.z; pm[4 * j + 3] = b4.w;
                 }
-                const float4 c4 = q4[8], d4 = q4[9];
-                cp[0] = c4.x; cp[1] = c4.y; cp[2] = c4.z; tanfovx = c4.w; tanfovy = d4.x;
+                const float4 c4_ = q4[8], d4 = q4[9];
+                tanfovx = c4_.w; tanfovy = d4.x;
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { vm[j] = in.viewmatrix[16 * c + j]; pm[j] = in.projmatrix[16 * c + j]; }
-                cp[0] = in.campos[3 * c]; cp[1] = in.campos[3 * c + 1]; cp[2] = in.campos[3 * c + 2];
                 tanfovx = in.tanfov[2 * c]; tanfovy = in.tanfov[2 * c + 1];
             }
             const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
-            const float *__restrict__ r = grec + ci * kG;
-            const float g2x = r[0], g2y = r[1], gA = r[2], gB = r[3], gC = r[4];
-            g_op += r[5];
-            const float gcol[3] = {r[6], r[7], r[8]};
-            const float gdep = r[9];
-            if (dL_dmeans2D) { dL_dmeans2D[2 * ci] = g2x; dL_dmeans2D[2 * ci + 1] = g2y; }
+            const float g2x = ra0.x, g2y = ra0.y, gA = rb0.x, gB = rb0.y, gC = rc0.x;
+            g_op += rc0.y;
+            const float gdep = re0.y;
+            if (dL_dmeans2D) { const size_t ci = (size_t)c * P + i; dL_dmeans2D[2 * ci] = g2x; dL_dmeans2D[2 * ci + 1] = g2y; }
             const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
             const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
             const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
@@ -720,11 +735,13 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
             // ---- 2-D covariance path ----
             {
                 const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-                const float txtz = vx / vz, tytz = vy / vz;
-                const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz, ty = fminf(limy, fmaxf(-limy, tytz)) * vz, tz = vz;
+                const float rz = 1.0f / vz;
+                const float txtz = vx * rz, tytz = vy * rz;
+                const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz, ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
                 const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
                 const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-                const float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+                const float tz2 = rz * rz, tz3 = tz2 * rz;
+                const float J00 = fx * rz, J02 = -(fx * tx) * tz2, J11 = fy * rz, J12 = -(fy * ty) * tz2;
                 float M0[3], M1[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -769,7 +786,6 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
                     gR[1][k] += J11 * gM1[k];
                     gR[2][k] += J02 * gM0[k] + J12 * gM1[k];
                 }
-                const float tz2 = 1.0f / (tz * tz), tz3 = tz2 / tz;
                 gpc[0] += xmul * (-fx * tz2) * gJ02;
                 gpc[1] += ymul * (-fy * tz2) * gJ12;
                 gpc[2] += -fx * tz2 * gJ00 - fy * tz2 * gJ11 + (2.f * fx * tx) * tz3 * gJ02 + (2.f * fy * ty) * tz3 * gJ12;
@@ -790,104 +806,203 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
             }
             // ---- depth path ----
             gpc[2] += gdep;
-            // ---- colour path ----
-            float gdir[3] = {0.f, 0.f, 0.f};
-            if (!has_sh) {
-                g_cp[0] += gcol[0]; g_cp[1] += gcol[1]; g_cp[2] += gcol[2];
-            } else {
-                const float dxo = px - cp[0], dyo = py - cp[1], dzo = pz - cp[2];
-                const float len = sqrtf(dxo * dxo + dyo * dyo + dzo * dzo);
-                const float x = dxo / len, y = dyo / len, z = dzo / len;
-                const uint32_t cb = clamped[ci];
-                float g[3];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) g[ch] = (cb >> ch) & 1u ? 0.f : gcol[ch];
-                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    float dRx = 0.f, dRy = 0.f, dRz = 0.f;
-                    g_sh[0][ch] += SH_C0 * g[ch];
-                    if (deg > 0) {
-                        g_sh[1][ch] += -SH_C1 * y * g[ch];
-                        g_sh[2][ch] += SH_C1 * z * g[ch];
-                        g_sh[3][ch] += -SH_C1 * x * g[ch];
-                        dRx = -SH_C1 * SHV(3, ch); dRy = -SH_C1 * SHV(1, ch); dRz = SH_C1 * SHV(2, ch);
-                        if (deg > 1) {
-                            g_sh[4][ch] += SH_C2[0] * xy * g[ch];
-                            g_sh[5][ch] += SH_C2[1] * yz * g[ch];
-                            g_sh[6][ch] += SH_C2[2] * (2.0f * zz - xx - yy) * g[ch];
-                            g_sh[7][ch] += SH_C2[3] * xz * g[ch];
-                            g_sh[8][ch] += SH_C2[4] * (xx - yy) * g[ch];
-                            dRx += SH_C2[0] * y * SHV(4, ch) + SH_C2[2] * 2.0f * -x * SHV(6, ch) + SH_C2[3] * z * SHV(7, ch) + SH_C2[4] * 2.0f * x * SHV(8, ch);
-                            dRy += SH_C2[0] * x * SHV(4, ch) + SH_C2[1] * z * SHV(5, ch) + SH_C2[2] * 2.0f * -y * SHV(6, ch) + SH_C2[4] * 2.0f * -y * SHV(8, ch);
-                            dRz += SH_C2[1] * y * SHV(5, ch) + SH_C2[2] * 4.0f * z * SHV(6, ch) + SH_C2[3] * x * SHV(7, ch);
-                            if (deg > 2) {
-                                g_sh[9][ch] += SH_C3[0] * y * (3.0f * xx - yy) * g[ch];
-                                g_sh[10][ch] += SH_C3[1] * xy * z * g[ch];
-                                g_sh[11][ch] += SH_C3[2] * y * (4.0f * zz - xx - yy) * g[ch];
-                                g_sh[12][ch] += SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * g[ch];
-                                g_sh[13][ch] += SH_C3[4] * x * (4.0f * zz - xx - yy) * g[ch];
-                                g_sh[14][ch] += SH_C3[5] * z * (xx - yy) * g[ch];
-                                g_sh[15][ch] += SH_C3[6] * x * (xx - 3.0f * yy) * g[ch];
-                                dRx += SH_C3[0] * SHV(9, ch) * 6.0f * xy + SH_C3[1] * SHV(10, ch) * yz + SH_C3[2] * SHV(11, ch) * -2.0f * xy +
-                                       SH_C3[3] * SHV(12, ch) * -6.0f * xz + SH_C3[4] * SHV(13, ch) * (-3.0f * xx + 4.0f * zz - yy) +
-                                       SH_C3[5] * SHV(14, ch) * 2.0f * xz + SH_C3[6] * SHV(15, ch) * 3.0f * (xx - yy);
-                                dRy += SH_C3[0] * SHV(9, ch) * 3.0f * (xx - yy) + SH_C3[1] * SHV(10, ch) * xz +
-                                       SH_C3[2] * SHV(11, ch) * (-3.0f * yy + 4.0f * zz - xx) + SH_C3[3] * SHV(12, ch) * -6.0f * yz +
-                                       SH_C3[4] * SHV(13, ch) * -2.0f * xy + SH_C3[5] * SHV(14, ch) * -2.0f * yz + SH_C3[6] * SHV(15, ch) * -6.0f * xy;
-                                dRz += SH_C3[1] * SHV(10, ch) * xy + SH_C3[2] * SHV(11, ch) * 8.0f * yz +
-                                       SH_C3[3] * SHV(12, ch) * 3.0f * (2.0f * zz - xx - yy) + SH_C3[4] * SHV(13, ch) * 8.0f * xz +
-                                       SH_C3[5] * SHV(14, ch) * (xx - yy);
-                            }
-                        }
-                    }
-                    ddx += dRx * g[ch]; ddy += dRy * g[ch]; ddz += dRz * g[ch];
-                }
-                const float dot = x * ddx + y * ddy + z * ddz;
-                gdir[0] = (ddx - x * dot) / len; gdir[1] = (ddy - y * dot) / len; gdir[2] = (ddz - z * dot) / len;
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr) tau[rr] += vm[0 + rr] * gdir[0] + vm[4 + rr] * gdir[1] + vm[8 + rr] * gdir[2];
-            }
             // ---- assemble: p_C = R p + t ----
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                g_mean[k] += gdir[k] + vm[4 * k + 0] * gpc[0] + vm[4 * k + 1] * gpc[1] + vm[4 * k + 2] * gpc[2];
+            for (int k = 0; k < 3; ++k) g_mean[k] += vm[4 * k + 0] * gpc[0] + vm[4 * k + 1] * gpc[1] + vm[4 * k + 2] * gpc[2];
             tau[0] += gpc[0]; tau[1] += gpc[1]; tau[2] += gpc[2];
             tau[3] += vy * gpc[2] - vz * gpc[1];
             tau[4] += vz * gpc[0] - vx * gpc[2];
             tau[5] += vx * gpc[1] - vy * gpc[0];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float r0 = vm[4 * j + 0], r1 = vm[4 * j + 1], r2 = vm[4 * j + 2];
-                tau[3] += r1 * gR[2][j] - r2 * gR[1][j];
-                tau[4] += r2 * gR[0][j] - r0 * gR[2][j];
-                tau[5] += r0 * gR[1][j] - r1 * gR[0][j];
+                const float r0_ = vm[4 * j + 0], r1_ = vm[4 * j + 1], r2_ = vm[4 * j + 2];
+                tau[3] += r1_ * gR[2][j] - r2_ * gR[1][j];
+                tau[4] += r2_ * gR[0][j] - r0_ * gR[2][j];
+                tau[5] += r0_ * gR[1][j] - r1_ * gR[0][j];
             }
         }
-        if (dL_dtau) {
+        if (dL_dtau) {   // per wave: shuffle reduction, one atomic per component
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const float tsum = block_sum(tau[k], sm);
-                if (threadIdx.x == 0 && tsum != 0.f) atomicAdd(&dL_dtau[6 * c + k], tsum);
+                float v = tau[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0 && v != 0.f) atomicAdd(&dL_dtau[6 * c + k], v);
             }
         }
+        rad0 = rad1; rad1 = rad2;
+        ra0 = ra1; rb0 = rb1; rc0 = rc1; re0 = re1;
+      }
       }
     }
-    if (!live) return;
-    dL_dmeans3D[3 * gi] = g_mean[0]; dL_dmeans3D[3 * gi + 1] = g_mean[1]; dL_dmeans3D[3 * gi + 2] = g_mean[2];
-    if (in.flags & VS_RASTER_COV_3X3) {   // the caller differentiates the symmetric 3x3 layout: off-diagonal partials split in halves
-        float *o = dL_dcov3D + 9 * gi;
-        o[0] = g_cov[0]; o[4] = g_cov[3]; o[8] = g_cov[5];
-        o[1] = o[3] = 0.5f * g_cov[1]; o[2] = o[6] = 0.5f * g_cov[2]; o[5] = o[7] = 0.5f * g_cov[4];
-    } else {
+    float g_sh[16][3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * gi + k] = g_cov[k];
+    for (int k = 0; k < 16; ++k) g_sh[k][0] = g_sh[k][1] = g_sh[k][2] = 0.f;
+    for (int cbase = 0; cbase < in.num_cameras; cbase += kCamChunk) {
+      const int ncam = in.num_cameras > kCamChunk ? build_cams(cbase) : ncam_s;      // (one chunk: the list and the parameters of pass A stand)
+      // pass B: colour -> g_sh (or g_cp), the view-direction part of g_mean and of the twist's translation
+      {
+      int rad0 = 0, rad1 = 0;
+      float2 rd0 = make_float2(0.f, 0.f), re0 = rd0;
+      uint32_t cl0 = 0;
+      if (live && ncam > 0) rad0 = radii[(size_t)cams[0] * P + i];
+      if (live && ncam > 1) rad1 = radii[(size_t)cams[1] * P + i];
+      if (rad0 > 0) {
+          const size_t ci0 = (size_t)cams[0] * P + i;
+          const float2 *r2 = reinterpret_cast<const float2 *>(grec + ci0 * kG);
+          rd0 = r2[3]; re0 = r2[4];
+          if (has_sh) cl0 = clamped[ci0];
+      }
+      for (int kc = 0; kc < ncam; ++kc) {
+        const int c = __builtin_amdgcn_readfirstlane(cams[kc]);
+        int rad2 = 0;
+        if (live && kc + 2 < ncam) rad2 = radii[(size_t)cams[kc + 2] * P + i];
+        float2 rd1 = make_float2(0.f, 0.f), re1 = rd1;
+        uint32_t cl1 = 0;
+        if (rad1 > 0) {
+            const size_t ci1 = (size_t)cams[kc + 1] * P + i;
+            const float2 *r2 = reinterpret_cast<const float2 *>(grec + ci1 * kG);
+            rd1 = r2[3]; re1 = r2[4];
+            if (has_sh) cl1 = clamped[ci1];
+        }
+        float tau[3] = {0.f, 0.f, 0.f};
+        if (rad0 > 0) {
+            const float gcol[3] = {rd0.x, rd0.y, re0.x};
+            if (!has_sh) {
+                g_cp[0] += gcol[0]; g_cp[1] += gcol[1]; g_cp[2] += gcol[2];
+            } else {
+                float cp[3];
+                if (kc < kParCams) {
+                    const float4 c4_ = reinterpret_cast<const float4 *>(cpar + kc * kParStride)[8];
+                    cp[0] = c4_.x; cp[1] = c4_.y; cp[2] = c4_.z;
+                } else {
+                    cp[0] = in.campos[3 * c]; cp[1] = in.campos[3 * c + 1]; cp[2] = in.campos[3 * c + 2];
+                }
+                const float dxo = px - cp[0], dyo = py - cp[1], dzo = pz - cp[2];
+                const float rlen = 1.0f / sqrtf(dxo * dxo + dyo * dyo + dzo * dzo);
+                const float x = dxo * rlen, y = dyo * rlen, z = dzo * rlen;
+                float g[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) g[ch] = (cl0 >> ch) & 1u ? 0.f : gcol[ch];
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+                // w_k = sum over the channels of sh[k][ch] g[ch]: the colour gradient seen by coefficient row k (every coefficient read once)
+#define WK(k_) (SHV(k_, 0) * g[0] + SHV(k_, 1) * g[1] + SHV(k_, 2) * g[2])
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) g_sh[0][ch] += SH_C0 * g[ch];
+                if (deg > 0) {
+                    const float b1 = -SH_C1 * y, b2 = SH_C1 * z, b3 = -SH_C1 * x;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) { g_sh[1][ch] += b1 * g[ch]; g_sh[2][ch] += b2 * g[ch]; g_sh[3][ch] += b3 * g[ch]; }
+                    const float w1 = WK(1), w2 = WK(2), w3 = WK(3);
+                    ddx = -SH_C1 * w3; ddy = -SH_C1 * w1; ddz = SH_C1 * w2;
+                    if (deg > 1) {
+                        const float b4 = SH_C2[0] * xy, b5 = SH_C2[1] * yz, b6 = SH_C2[2] * (2.0f * zz - xx - yy), b7 = SH_C2[3] * xz, b8 = SH_C2[4] * (xx - yy);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            g_sh[4][ch] += b4 * g[ch]; g_sh[5][ch] += b5 * g[ch]; g_sh[6][ch] += b6 * g[ch]; g_sh[7][ch] += b7 * g[ch]; g_sh[8][ch] += b8 * g[ch];
+                        }
+                        const float w4 = WK(4), w5 = WK(5), w6 = WK(6), w7 = WK(7), w8 = WK(8);
+                        ddx += SH_C2[0] * y * w4 - 2.0f * SH_C2[2] * x * w6 + SH_C2[3] * z * w7 + 2.0f * SH_C2[4] * x * w8;
+                        ddy += SH_C2[0] * x * w4 + SH_C2[1] * z * w5 - 2.0f * SH_C2[2] * y * w6 - 2.0f * SH_C2[4] * y * w8;
+                        ddz += SH_C2[1] * y * w5 + 4.0f * SH_C2[2] * z * w6 + SH_C2[3] * x * w7;
+                        if (deg > 2) {
+                            const float b9 = SH_C3[0] * y * (3.0f * xx - yy), b10 = SH_C3[1] * xy * z, b11 = SH_C3[2] * y * (4.0f * zz - xx - yy),
+                                        b12 = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), b13 = SH_C3[4] * x * (4.0f * zz - xx - yy),
+                                        b14 = SH_C3[5] * z * (xx - yy), b15 = SH_C3[6] * x * (xx - 3.0f * yy);
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) {
+                                g_sh[9][ch] += b9 * g[ch]; g_sh[10][ch] += b10 * g[ch]; g_sh[11][ch] += b11 * g[ch]; g_sh[12][ch] += b12 * g[ch];
+                                g_sh[13][ch] += b13 * g[ch]; g_sh[14][ch] += b14 * g[ch]; g_sh[15][ch] += b15 * g[ch];
+                            }
+                            const float w9 = WK(9), w10 = WK(10), w11 = WK(11), w12 = WK(12), w13 = WK(13), w14 = WK(14), w15 = WK(15);
+                            ddx += SH_C3[0] * w9 * 6.0f * xy + SH_C3[1] * w10 * yz + SH_C3[2] * w11 * -2.0f * xy + SH_C3[3] * w12 * -6.0f * xz +
+                                   SH_C3[4] * w13 * (-3.0f * xx + 4.0f * zz - yy) + SH_C3[5] * w14 * 2.0f * xz + SH_C3[6] * w15 * 3.0f * (xx - yy);
+                            ddy += SH_C3[0] * w9 * 3.0f * (xx - yy) + SH_C3[1] * w10 * xz + SH_C3[2] * w11 * (-3.0f * yy + 4.0f * zz - xx) +
+                                   SH_C3[3] * w12 * -6.0f * yz + SH_C3[4] * w13 * -2.0f * xy + SH_C3[5] * w14 * -2.0f * yz + SH_C3[6] * w15 * -6.0f * xy;
+                            ddz += SH_C3[1] * w10 * xy + SH_C3[2] * w11 * 8.0f * yz + SH_C3[3] * w12 * 3.0f * (2.0f * zz - xx - yy) +
+                                   SH_C3[4] * w13 * 8.0f * xz + SH_C3[5] * w14 * (xx - yy);
+                        }
+                    }
+                }
+#undef WK
+                const float dot = x * ddx + y * ddy + z * ddz;
+                const float gd0 = (ddx - x * dot) * rlen, gd1 = (ddy - y * dot) * rlen, gd2 = (ddz - z * dot) * rlen;
+                g_mean[0] += gd0; g_mean[1] += gd1; g_mean[2] += gd2;
+                if (dL_dtau) {
+                    float r9[9];
+                    if (kc < kParCams) {
+                        const float4 *q4 = reinterpret_cast<const float4 *>(cpar + kc * kParStride);
+                        const float4 a0 = q4[0], a1 = q4[1], a2 = q4[2];
+                        r9[0] = a0.x; r9[1] = a0.y; r9[2] = a0.z; r9[3] = a1.x; r9[4] = a1.y; r9[5] = a1.z; r9[6] = a2.x; r9[7] = a2.y; r9[8] = a2.z;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { r9[3 * j] = in.viewmatrix[16 * c + 4 * j]; r9[3 * j + 1] = in.viewmatrix[16 * c + 4 * j + 1]; r9[3 * j + 2] = in.viewmatrix[16 * c + 4 * j + 2]; }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) tau[rr] = r9[rr] * gd0 + r9[3 + rr] * gd1 + r9[6 + rr] * gd2;
+                }
+            }
+        }
+        if (dL_dtau && has_sh) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = tau[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0 && v != 0.f) atomicAdd(&dL_dtau[6 * c + k], v);
+            }
+        }
+        rad0 = rad1; rad1 = rad2;
+        rd0 = rd1; re0 = re1; cl0 = cl1;
+      }
+      }
     }
-    dL_dopac[gi] = g_op;
-    if (has_sh) {
-        if (dL_dshs) {
-            float *o = dL_dshs + gi * (size_t)M * 3;
+    if (live) {
+        dL_dmeans3D[3 * gi] = g_mean[0]; dL_dmeans3D[3 * gi + 1] = g_mean[1]; dL_dmeans3D[3 * gi + 2] = g_mean[2];
+        if (in.flags & VS_RASTER_COV_3X3) {   // the caller differentiates the symmetric 3x3 layout: off-diagonal partials split in halves
+            float *o = dL_dcov3D + 9 * gi;
+            o[0] = g_cov[0]; o[4] = g_cov[3]; o[8] = g_cov[5];
+            o[1] = o[3] = 0.5f * g_cov[1]; o[2] = o[6] = 0.5f * g_cov[2]; o[5] = o[7] = 0.5f * g_cov[4];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dL_dcov3D[6 * gi + k] = g_cov[k];
+        }
+        dL_dopac[gi] = g_op;
+        if (!has_sh && dL_dcolors_precomp) {
+            dL_dcolors_precomp[3 * gi] = g_cp[0]; dL_dcolors_precomp[3 * gi + 1] = g_cp[1]; dL_dcolors_precomp[3 * gi + 2] = g_cp[2];
+        }
+    }
+    if (has_sh && dL_dshs) {
+        // the SH gradient leaves through the (now dead) LDS image of the coefficients: a half block's 128 x 3M floats are one contiguous
+        // run of the output, written as coalesced dwords
+        float *stage = &s_sh[0][0];
+        const int row = 3 * M;
+        if (128 * row <= 45 * 256) {
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                __syncthreads();   // the camera loop's last reads of s_sh / the previous half's copy are done
+                if ((threadIdx.x >> 7) == h) {
+                    float *o = stage + (threadIdx.x & 127) * row;
+                    for (int k = 16; k < M; ++k)      // bands the rasterizer never reads: zero gradient
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) o[rgb_major ? ch * M + k : 3 * k + ch] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            if (k < M) o[rgb_major ? ch * M + k : 3 * k + ch] = g_sh[k][ch];
+                }
+                __syncthreads();
+                const int first = blockIdx.x * 256 + h * 128;                 // first Gaussian of this half
+                const int nlive = min(128, P - first);
+                if (nlive > 0) {
+                    float *dst = dL_dshs + ((size_t)s * P + first) * (size_t)row;
+                    for (int e = threadIdx.x; e < nlive * row; e += 256) dst[e] = stage[e];
+                }
+            }
+        } else if (live) {      // (more than 30 coefficients per channel in memory: direct stores)
+            float *o = dL_dshs + gi * (size_t)row;
             for (int k = 0; k < M; ++k)
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -897,8 +1012,6 @@ preprocess_backward_kernel(const VsRasterIn in, const int32_t *__restrict__ radi
                     if (rgb_major) o[ch * M + k] = v; else o[3 * k + ch] = v;
                 }
         }
-    } else if (dL_dcolors_precomp) {
-        dL_dcolors_precomp[3 * gi] = g_cp[0]; dL_dcolors_precomp[3 * gi + 1] = g_cp[1]; dL_dcolors_precomp[3 * gi + 2] = g_cp[2];
     }
 }
 

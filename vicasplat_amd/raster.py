@@ -139,6 +139,17 @@ def forward_debug(means3D, cov3D, opacities, viewmatrix, projmatrix, campos, tan
                 n_contrib=t[L.VS_BUF_N_CONTRIB].view(torch.int32)[:Cn * H * W].view(Cn, H, W), _state=st)
 
 
+def _backward_impl(inp, out, grads, dev) -> None:
+    """Calls vs_raster_backward (its scratch -- the per-(camera, Gaussian) gradient records -- comes from torch's caching allocator and goes
+    back to it on return).  A module-level function so that bench.py can bracket it with events."""
+    lib = L.lib()
+    alloc = L.TorchAllocator(dev)
+    with torch.cuda.device(dev):
+        rc = lib.vs_raster_backward(C.byref(inp), C.byref(out), C.byref(grads), alloc.fn, None, L.stream_ptr(dev))
+    alloc.fn = None
+    L.check(rc, "vs_raster_backward")
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, cov3D, shs, colors_precomp, opacities, viewmatrix, projmatrix, campos, tanfov, background,
@@ -196,11 +207,7 @@ class _Rasterize(torch.autograd.Function):
         g.dL_dcolor, g.dL_ddepth = L.ptr(g_color), L.ptr(g_depth)
         g.dL_dmeans3D, g.dL_dcov3D, g.dL_dshs, g.dL_dcolors_precomp = L.ptr(d_means), L.ptr(d_cov), L.ptr(d_shs), L.ptr(d_cp)
         g.dL_dopacities, g.dL_dmeans2D, g.dL_dtau = L.ptr(d_op), None, L.ptr(d_tau)
-        alloc = L.TorchAllocator(dev)
-        with torch.cuda.device(dev):
-            rc = lib.vs_raster_backward(C.byref(ctx.inp), C.byref(ctx.out), C.byref(g), alloc.fn, None, L.stream_ptr(dev))
-        alloc.fn = None
-        L.check(rc, "vs_raster_backward")
+        _backward_impl(ctx.inp, ctx.out, g, dev)
         d_theta = d_tau[:, 3:] if d_tau is not None else None
         d_rho = d_tau[:, :3] if d_tau is not None else None
         return (d_means, d_cov, d_shs, d_cp, d_op, None, None, None, None, None, None, d_theta, d_rho, None, None, None,
