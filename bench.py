@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 MFMA leg")
     ap.add_argument("--no-fast", action="store_true", help="skip the 16-bit (f16) fast-path leg")
     ap.add_argument("--no-targets70", action="store_true", help="skip the 70-view demo workload leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-scene (B = 1) latency leg")
+    ap.add_argument("--latency-iters", type=int, default=25)
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="no GPU work: run the N > 1 control flow of this file (process-group init from the launcher's environment, barriers, MAX-reduce of "
                          "the elapsed time, the training leg's watchdog and one GradReducer exchange) on CPU with the gloo backend and print the JSON line")
@@ -736,6 +738,69 @@ def main():
     if rank == 0 and world == 1 and args.mode != "train" and not args.no_targets70:
         targets70 = targets70_leg()
 
+    # ---- single-scene latency: the reference's ONLY published number for this path is "~0.1 s" per scene end to end
+    # (README.md:16), and its demo is a B = 1 caller (demo.py:180-243).  One 8-view scene: encoder + 12 target views, and encoder + the
+    # demo's 70 interpolated views; every iteration is synchronised (a latency, not a throughput), median and p90 of `--latency-iters`. ----
+    def latency_leg():
+        try:
+            from vicasplat_amd import callers
+            import statistics
+            ctx1 = dict(image=ctx["image"][:1].contiguous(), intrinsics=ctx["intrinsics"][:1].contiguous())
+            E12, K12, n12, f12 = tE[:1], tK[:1], tnear[:1], tfar[:1]
+            t_ = torch.linspace(0, 1, 10, dtype=torch.float32)
+            n70 = (V - 1) * 10
+            near70, far70 = torch.full((1, n70), 0.01, device=dev), torch.full((1, n70), 100.0, device=dev)
+            K_host = ctx1["intrinsics"].float().cpu()
+            caps = {"12": None, "70": None}
+
+            def run12():
+                out = enc(ctx1, compute_viewspace_depth=False)
+                g = out["gaussians"]
+                with raster.instance_capacity(caps["12"]) as scope:
+                    r = dec(Gaussians(g.means, g.covariances, g.harmonics, g.opacities), E12, K12, n12, f12, (256, 256))
+                if caps["12"] is None:
+                    caps["12"] = int(max(n for n, _ in scope.calls) * 1.25) + 65536
+                return r
+
+            def run70():
+                out = enc(ctx1, compute_viewspace_depth=False)
+                P_ = out["gaussian_camera_extrins"].cpu()        # the demo's camera path is host code (demo.py:204-243): includes its device -> host round trip
+                E70 = callers.interpolate_extrinsics(P_[:, :-1].reshape(-1, 4, 4), P_[:, 1:].reshape(-1, 4, 4), t_).reshape(1, n70, 4, 4).float().to(dev)
+                K70 = callers.interpolate_intrinsics(K_host[:, :-1].reshape(-1, 3, 3), K_host[:, 1:].reshape(-1, 3, 3), t_).reshape(1, n70, 3, 3).float().to(dev)
+                g = out["gaussians"]
+                with raster.instance_capacity(caps["70"]) as scope:
+                    r = dec(Gaussians(g.means, g.covariances, g.harmonics, g.opacities), E70, K70, near70, far70, (256, 256))
+                if caps["70"] is None:
+                    caps["70"] = int(max(n for n, _ in scope.calls) * 1.25) + 65536
+                return r
+
+            def enc_only():
+                return enc(ctx1, compute_viewspace_depth=False)
+
+            res = {}
+            for name, fn in (("encoder_plus_12_views", run12), ("encoder_plus_70_views", run70), ("encoder_only", enc_only)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(args.latency_iters):
+                    t1 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                ts.sort()
+                res[name] = dict(median_ms=round(statistics.median(ts), 3), p90_ms=round(ts[int(0.9 * (len(ts) - 1))], 3), min_ms=round(ts[0], 3))
+            return dict(metric="single-scene latency (B = 1, 8 context views 256x256), synchronised per iteration", unit="ms", iters=args.latency_iters,
+                        dtype=DTYPE_NOTE[args.dtype], reference_published="~0.1 s per scene (README.md:16, other hardware, 2-view demo class)", **res)
+        except Exception as e:
+            return dict(error=repr(e)[:300])
+        finally:
+            torch.cuda.empty_cache()
+
+    latency_b1 = None
+    if rank == 0 and world == 1 and args.mode != "train" and not args.no_latency:
+        latency_b1 = latency_leg()
+
     f32_path = fast_path = None
     if rank == 0 and world == 1 and args.mode != "train":
         if not args.no_fast and args.dtype not in ("f16", "bf16"):
@@ -750,7 +815,7 @@ def main():
                     config=dict(workload="re10k_8view full pipeline fwd: ViT-L encoder+decoder+DPT heads -> 524288 Gaussians/scene, "
                                          f"{Vt} target views/scene rasterized at 256x256", scenes_per_gpu=B, context_views=V, target_views=Vt,
                                 parallelism=f"scene-sharded x{world} (no collective)"),
-                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, targets70=targets70, fast_path=fast_path, f32_path=f32_path, train=train, **extra)
+                    roofline=roofline, cpu_baseline=cpu_baseline, psnr_vs_oracle=psnr_vs_oracle, targets70=targets70, latency_b1=latency_b1, fast_path=fast_path, f32_path=f32_path, train=train, **extra)
 
     train = None
     if args.mode in ("train", "both"):

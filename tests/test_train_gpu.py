@@ -297,8 +297,9 @@ def test_config4_full_size_training_step(cdt):
     BASELINE config 4 at FULL size: re10k_8view (config/experiment/re10k_8view.yaml:19-20,61): batch 2, 8 context views, 12 target
     views, ViT-L, 524 288 Gaussians per scene; encoder + decoder + rasterizer forward + backward + clip + AdamW, once.
     Checks: finite loss / gradient norm, every parameter the loss reaches is updated (only scratch.refinenet4.resConfUnit1 of the two
-    DPT heads is unreachable), and the loss of the step is run-to-run reproducible (the encoder's kernels are
-    deterministic; the rasterizer backward's float atomics only touch the gradients)."""
+    DPT heads is unreachable), and the loss of the step is run-to-run reproducible (the TRAINING forward's kernels are
+    deterministic -- the split-K residual epilogues that make the fused inference forward reproducible only to rounding, unless
+    VS_DETERMINISTIC=1, are not on this path; the rasterizer backward's float atomics only touch the gradients)."""
     from vicasplat_amd import callers
     from vicasplat_amd.model.decoder import DecoderSplattingCUDACfg, get_decoder
     d = torch.device("cuda:0")

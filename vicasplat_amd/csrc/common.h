@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/vicasplat_hip.h"
 
@@ -28,6 +29,13 @@ void set_error(const char *fmt, ...);
             return -2;                                                                         \
         }                                                                                      \
     } while (0)
+
+// VS_DETERMINISTIC=1 (read per call: tests flip it): no result may depend on the arrival order of f32 atomics -- the GEMM routes that
+// split K over workgroups (residual epilogue) run unsplit or through the two-pass reduction instead (tests/test_encoder_gpu.py).
+static inline bool deterministic() {
+    const char *e = getenv("VS_DETERMINISTIC");
+    return e && e[0] != '0' && e[0] != 0;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -438,7 +438,7 @@ int launch_skinny(const GemmArgs &g, int epi, hipStream_t stream) {
     const int rows = g.M - g.m_lo, gy = vs::cdiv(rows, 64), gx = vs::cdiv(g.N, 64);
     // epilogue 2 with the residual already in `out`: split K over workgroups while the grid is small and a slice keeps >= 8 blocks per wave
     int ks = 1;
-    if (epi == 2 && !g.resid)
+    if (epi == 2 && !g.resid && !vs::deterministic())
         while (ks < 8 && gx * gy * ks * 2 <= 384 && g.K / 64 / (ks * 2) >= 32) ks *= 2;
     dim3 grid(gx, gy, ks), block(512);
     switch (epi) {
@@ -668,7 +668,7 @@ int launch_tail(const GemmArgs &g, int rem, int epi, hipStream_t stream) {
     // a tail is a handful of tiles walking all of K serially: for the f32 residual epilogue split K over up to 8 workgroups
     // per tile (>= 8 k-steps each) and let the partial sums meet through f32 atomics
     static const int no_ksplit = [] { const char *e = getenv("VS_GEMM_NO_KSPLIT"); return e ? atoi(e) : 0; }();
-    if (epi == 2 && rem > 64 && !no_ksplit && !g.resid) {   // (split-K partial sums meet in out: it must already hold the residual)
+    if (epi == 2 && rem > 64 && !no_ksplit && !g.resid && !vs::deterministic()) {   // (split-K partial sums meet in out: it must already hold the residual)
         const int tiles = vs::cdiv(rem, 128) * vs::cdiv(g.N, BN);
         int ks = 1;
         while (ks < 8 && (g.K / 32) % (ks * 2) == 0 && g.K / 32 / (ks * 2) >= 8 && tiles * ks * 2 <= 512) ks *= 2;
@@ -755,6 +755,9 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     const bool split = full > 0 && rem > 0 && rem <= bm / 2 && (full + tiles_n + slots - 1) / slots > (full + slots - 1) / slots;
     GemmArgs main_g = g;
     if (split) main_g.M = g.M - rem;
+    // (Round 6, measured and not kept: cutting K over blockIdx.y for the 136-tile residual-epilogue GEMMs of a ONE-scene batch -- 2 056 rows,
+    // N = 1024: half the chip for one pass over K -- until the grid fills the chip.  The partial sums meet through f32 atomics and the
+    // epilogue's atomic traffic costs more than the idle CUs: B = 1 encoder 22.2 -> 26.2 ms, B = 2 29.7 -> 35.3 ms.)
     int rc = mi == 8 ? launch_mi<BF16, 8>(main_g, epi, stream) : launch_mi<BF16, 4>(main_g, epi, stream);
     if (rc || !split) return rc;
     return launch_tail<BF16>(g, rem, epi, stream);
