@@ -290,6 +290,57 @@ def _config4_batch(B, V, Vt, d, with_extrinsics=False):
     return dict(context=ctx, target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
 
 
+def test_full_vit_l_backward_matches_the_real_references_gradient_goldens():
+    """config 4's backward pinned to the REAL reference, not only to property checks.  tests/golden/
+    encoder_full_v2_grads.npz holds float64 gradients of the imported reference encoder (full ViT-L: 24 + 12 blocks, both DPT heads, adapter,
+    pose head; 1 scene x 2 views x 256 x 256) for a seeded linear functional of raw_gaussians, pred_extrins and the covariances
+    (gen_encoder_grad_golden.py).  The split-class training path (f32 activations and gradients, three f16 MFMAs per product, forward and
+    backward) runs the same functional; for 41 parameters spread over every part of the model the gradient's lattice elements, its sum
+    and its sum of magnitudes must agree with the reference's, relative to the gradient's largest element."""
+    import json
+    import numpy as np
+    from vicasplat_amd.model.encoder.train_forward import forward_train
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(G, "encoder_full_v2_grads.npz"))
+    B, V = int(z["cfg_B"]), int(z["cfg_V"])
+    m = _full_model("split").eval()          # eval: the heads' Dropout(0.1) is the identity, as in the generator
+    m.requires_grad_(True)
+    img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
+    g = torch.Generator().manual_seed(1)     # the functional of gen_encoder_grad_golden.functional()
+    r_raw = torch.randn(B, V, 256, 256, 86, generator=g) * 1e-3
+    r_raw[..., :3] *= 0.1
+    r_pose = torch.randn(B, V - 1, 8, generator=g)
+    r_cov = torch.randn(B, V, 256, 256, 3, 3, generator=g) * 10.0
+    out = forward_train(m, img.cuda(), K.cuda(), "split")
+    loss = (out["raw_gaussians"] * r_raw.cuda()).sum() + (out["pred_extrins"] * r_pose.cuda()).sum() + (out["gaussians"]["covariances"] * r_cov.cuda()).sum()
+    S = 4096.0                               # power-of-two scale: keeps the (hi, lo) operand pairs of the backward in f16's normal range
+    (loss * S).backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-4 * abs(float(z["loss"])) + 1e-6, (float(loss.detach()), float(z["loss"]))
+    named = dict(m.named_parameters())
+    nlat = int(z["nlat"])
+    worst = {}
+    for i, n in enumerate(str(x) for x in z["names"]):
+        gr = named[n].grad.detach().double().flatten().cpu() / S
+        stats, lat = z[f"p{i}_stats"], z[f"p{i}_lat"]
+        idx = torch.from_numpy((np.arange(nlat, dtype=np.int64) * 2654435761 % gr.numel()).astype(np.int64))
+        scale = float(stats[2]) + 1e-300
+        e_lat = float((gr[idx] - torch.from_numpy(lat)).abs().max()) / scale
+        e_sum = abs(float(gr.sum()) - float(stats[0])) / (float(stats[1]) + 1e-300)
+        e_abs = abs(float(gr.abs().sum()) - float(stats[1])) / (float(stats[1]) + 1e-300)
+        worst[n] = (e_lat, e_sum, e_abs)
+    top = sorted(worst.items(), key=lambda kv: -max(kv[1]))[:6]
+    print("gradient goldens: worst parameters (lattice / sum / |sum|):", [(k, ["%.2e" % v for v in e]) for k, e in top])
+    # split operands carry ~22 bits per product: the forward sits at 1e-5 of the reference's f64 outputs (tests/test_split_path_gpu.py); a
+    # gradient element is a sum over up to 131 072 pixels / 514 tokens of such products.  Measured: lattice elements <= 1.6e-3 of the
+    # gradient's largest element (the 7x7 stem's weight: a sum over every pixel of both frames; every transformer weight <= 6.1e-4), sums
+    # and sums of magnitudes <= 1.9e-4.  Bounds = 3x that.
+    for n, (e_lat, e_sum, e_abs) in worst.items():
+        assert e_lat <= 5e-3 and e_sum <= 6e-4 and e_abs <= 6e-4, (n, e_lat, e_sum, e_abs)
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)) / S
+    assert abs(float(gn) - float(z["grad_norm_all"])) <= 1e-3 * float(z["grad_norm_all"]), (float(gn), float(z["grad_norm_all"]))
+
+
 @pytest.mark.parametrize("cdt", ["f16", "split"])
 def test_config4_full_size_training_step(cdt):
     """(cdt = "split": the same step at the REFERENCE'S precision -- f32 activations and gradients, three f16 MFMAs per product in the
