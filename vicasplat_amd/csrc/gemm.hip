@@ -752,9 +752,26 @@ int launch(const GemmArgs &g, int epi, hipStream_t stream) {
     const int mi = t8 >= 256 ? 8 : 4, bm = 32 * mi, slots = 256 * (mi == 8 ? 2 : 3);
     const int rem = g.M % bm;
     const long long full = (long long)(g.M / bm) * tiles_n;
-    const bool split = full > 0 && rem > 0 && rem <= bm / 2 && (full + tiles_n + slots - 1) / slots > (full + slots - 1) / slots;
+    // a partly filled extra round costs a whole one.  Round 6: the matrix pipes of a CU are shared by its resident workgroups, so a "round"
+    // of MFMA-bound tiles is 256 tiles (one per CU), not `slots` -- one 8-view scene's fc1 (2 056 rows x 4 096 columns) is 288 tiles of
+    // 256 x 128, i.e. TWO rounds with the second 12 % full; peeling the 8 leftover rows makes it one (110 -> 70 us).
+    const bool split = full > 0 && rem > 0 && rem <= bm / 2 &&
+                       ((full + tiles_n + slots - 1) / slots > (full + slots - 1) / slots || (full + tiles_n + 255) / 256 > (full + 255) / 256);
     GemmArgs main_g = g;
     if (split) main_g.M = g.M - rem;
+    // Round 6, small batches (one 8-view scene = 2 056 rows): the residual epilogue's GEMMs (attention projection, fc2: N = 1024 / 768) are
+    // 136 / 102 tiles of 128 x 128 -- half the chip for one pass over K.  64-row tiles (MI = 2: the same kernel, each wave a 32 x 64 slab)
+    // double the workgroups: VS_GEMM_MI2=0 for the A/B.
+    if constexpr (BF16 == kDtSplit) {
+        static const int mi2 = [] { const char *e = getenv("VS_GEMM_MI2"); return e ? atoi(e) : 1; }();
+        const long long tiles4 = (long long)vs::cdiv(main_g.M - main_g.m_lo, 128) * tiles_n;
+        if (mi2 && mi == 4 && epi == 2 && g.ntaps == 0 && g.ksplit <= 1 && !g.partials && tiles4 <= 192 && main_g.M - main_g.m_lo > 64) {
+            const long long nwg = (long long)vs::cdiv(main_g.M - main_g.m_lo, 64) * tiles_n;
+            hipLaunchKernelGGL((gemm_kernel<kDtSplit, 2, 2>), dim3((unsigned)nwg, 1), dim3(256), 0, stream, main_g);
+            if (!split) return 0;
+            return launch_tail<BF16>(g, rem, epi, stream);
+        }
+    }
     // (Round 6, measured and not kept: cutting K over blockIdx.y for the 136-tile residual-epilogue GEMMs of a ONE-scene batch -- 2 056 rows,
     // N = 1024: half the chip for one pass over K -- until the grid fills the chip.  The partial sums meet through f32 atomics and the
     // epilogue's atomic traffic costs more than the idle CUs: B = 1 encoder 22.2 -> 26.2 ms, B = 2 29.7 -> 35.3 ms.)
