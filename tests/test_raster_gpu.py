@@ -358,11 +358,11 @@ def _close(a, b, name, rtol):
     assert np.abs(a - b).max() <= rtol * scale, (name, float(np.abs(a - b).max()), float(scale))
 
 
-@pytest.fixture(params=["0", "4", "1"])
+@pytest.fixture(params=["0", "4"])
 def rbwd_waves(request, monkeypatch):
-    """The three render-backward kernels (round 6; VS_RBWD_WAVES is read per call): 0 = the default of every differentiated call -- the
-    segment-parallel replay from the forward's blending checkpoints (front to back, a wave per 512-entry segment); 4 / 1 = the whole-list
-    kernels a caller without VS_RASTER_SAVE_FOR_BACKWARD gets (four waves per tile, a quadrant each / one wave per tile, a 2x2 block per lane)."""
+    """Both render-backward routes (round 6; VS_RBWD_WAVES is read per call): 0 = the default of every differentiated call -- the
+    segment-parallel replay from the forward's blending checkpoints (front to back, a wave per 512-entry segment, atomics-free staging);
+    4 = the whole-list kernel a caller without VS_RASTER_SAVE_FOR_BACKWARD gets (four waves per tile, back to front from final_T)."""
     monkeypatch.setenv("VS_RBWD_WAVES", request.param)
     return request.param
 

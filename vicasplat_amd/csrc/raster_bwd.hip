@@ -209,15 +209,7 @@ render_backward_kernel(int P, int W, int H, const int2 *__restrict__ ranges, con
     }
 }
 
-// Round 6: K1 for the batched calls -- ONE wave per tile, lane = one 2x2 pixel block of the 16x16 tile (8 x 8 blocks), the block's four
-// pixels replayed by the SAME lane one after the other.  The 4-wave kernel above spends 40 of its ~170 instructions per trip on the
-// cross-lane sums of a block's four pixels (ten components x quad reduction), issues ten LDS atomics per trip for at most sixteen
-// (block, entry) pairs and repeats the per-trip bookkeeping once per quadrant wave (PMC, bench scene: VALU issue 0.32, 25 % of the wave
-// cycles waiting on LDS, 19.1 ms per 288 views against the forward's 4.0).  Here a trip serves up to SIXTY-FOUR (block, entry) pairs:
-// the four pixels' contributions are summed in the lane's registers (no cross-lane traffic at all), the conic factors of the mean
-// gradient are applied once per trip to the sums, one 1/(1 - alpha) serves both divisions of a pixel (v_rcp_f32: the backward is
-// float-tolerant; nothing here feeds an integer decision), and the LDS atomics are one set per (block, entry).  A tile is one wave slot
-// with 6 KiB of LDS, as in the forward's one-wave render kernel.  Same tile order, same lists, same per-pixel recurrence as above.
+// column / row mask of block b out of the eight ballots of a footprint test
 __device__ __forceinline__ unsigned long long sel8(int b, unsigned long long m0, unsigned long long m1, unsigned long long m2,
                                                    unsigned long long m3, unsigned long long m4, unsigned long long m5,
                                                    unsigned long long m6, unsigned long long m7) {
@@ -226,210 +218,36 @@ __device__ __forceinline__ unsigned long long sel8(int b, unsigned long long m0,
     return (b & 4) ? c1 : c0;
 }
 
-template <int NT, bool DEPTH>     // DEPTH: a gradient of the depth image exists (the training objectives of the path differentiate the colour only)
-__global__ void __launch_bounds__(64)
-render_backward_block_kernel(int P, int W, int H, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                             const float *__restrict__ geom, const float *__restrict__ background, const float *__restrict__ final_T,
-                             const int32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
-                             const float *__restrict__ dL_dpixdepth, float *__restrict__ grec) {
-    static_assert(NT % 64 == 0, "staged batches are whole rounds of 64 entries");
-    constexpr int RPT = NT / 64;
-    __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
-    __shared__ uint32_t sid[NT];
-    __shared__ float sgr[NT][kG + 1];
-    const int gx = (W + kTile - 1) / kTile;
-    const int tiles = gridDim.x;
-    const int t_lin = reinterpret_cast<const int32_t *>(ranges + (size_t)gridDim.x * gridDim.y)[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
-    const int c = t_lin / tiles;
-    const int tile = t_lin - c * tiles;
-    const int lane = threadIdx.x;
-    const int tile_x = tile % gx, tile_y = tile / gx;
-    const int bx = lane & 7, by = lane >> 3;                       // this lane's 2x2 block of the tile
-    const int x0 = tile_x * kTile, y0 = tile_y * kTile;
-    const float pfx[2] = {(float)(x0 + 2 * bx), (float)(x0 + 2 * bx + 1)}, pfy[2] = {(float)(y0 + 2 * by), (float)(y0 + 2 * by + 1)};
-    const float bcx = (float)x0 + 0.5f, bcy = (float)y0 + 0.5f;    // centre of block column / row 0; 2 px apart, half size 0.5 px
-    const int2 rg = ranges[(size_t)c * tiles + tile];
-    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(geom + (size_t)c * P * kGeomFloats);
-    const uint32_t *__restrict__ plist = point_list + rg.x;
-    const size_t HW = (size_t)H * W;
-
-    int last[4];
-    float T[4], Tfin[4], dLr[4], dLg[4], dLb[4], dLd[4], bgd[4];
-    float acc_r[4], acc_g[4], acc_b[4], acc_d[4], last_r[4], last_g[4], last_b[4], last_d[4], last_alpha[4];
-    const float bg0 = background[3 * c], bg1 = background[3 * c + 1], bg2 = background[3 * c + 2];
-    int lmax = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int px = x0 + 2 * bx + (p & 1), py = y0 + 2 * by + (p >> 1);
-        const bool inside = px < W && py < H;
-        const size_t pix = (size_t)py * W + px;
-        last[p] = inside ? n_contrib[c * HW + pix] : 0;
-        Tfin[p] = inside ? final_T[c * HW + pix] : 0.f;
-        T[p] = Tfin[p];
-        dLr[p] = dLg[p] = dLb[p] = dLd[p] = 0.f;
-        if (inside) {
-            dLr[p] = dL_dpix[(c * 3 + 0) * HW + pix]; dLg[p] = dL_dpix[(c * 3 + 1) * HW + pix]; dLb[p] = dL_dpix[(c * 3 + 2) * HW + pix];
-            if (DEPTH) dLd[p] = dL_dpixdepth[c * HW + pix];
-        }
-        bgd[p] = -Tfin[p] * (bg0 * dLr[p] + bg1 * dLg[p] + bg2 * dLb[p]);      // (-T_final * bg . dL): times 1 / (1 - alpha) per entry
-        acc_r[p] = acc_g[p] = acc_b[p] = acc_d[p] = last_r[p] = last_g[p] = last_b[p] = last_d[p] = last_alpha[p] = 0.f;
-        lmax = max(lmax, last[p]);
-    }
-    int nmax = lmax;                                               // entries [0, nmax) of the list can contribute to some pixel of the tile
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-
-    float *__restrict__ gr = grec + (size_t)c * P * kG;
-    const int nb = (nmax + NT - 1) / NT;
-    uint32_t g_cur[RPT], g_nxt[RPT];
-    float4 r0[RPT], r1[RPT], r2[RPT];
-#pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        const int e = u * 64 + lane;
-        g_cur[u] = g_nxt[u] = 0u;
-        r0[u] = r1[u] = r2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nb > 0 && (nb - 1) * NT + e < nmax) g_cur[u] = plist[(nb - 1) * NT + e];
-        if (nb > 1) g_nxt[u] = plist[(nb - 2) * NT + e];
-    }
-#pragma unroll
-    for (int u = 0; u < RPT; ++u)
-        if (nb > 0 && (nb - 1) * NT + u * 64 + lane < nmax) {
-            r0[u] = g4[(size_t)g_cur[u] * 3 + 0]; r1[u] = g4[(size_t)g_cur[u] * 3 + 1]; r2[u] = g4[(size_t)g_cur[u] * 3 + 2];
-        }
-    for (int b = nb - 1; b >= 0; --b) {
-        const int p0 = b * NT;
-        const int cnt = min(NT, nmax - p0);
-        __syncthreads();   // the previous batch's flush has read sgr / sid (one wave: orders the LDS traffic)
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int e = u * 64 + lane;
-            if (e < cnt) { sq0[e] = r0[u]; sq1[e] = r1[u]; sq2[e] = r2[u]; sid[e] = g_cur[u]; }
-#pragma unroll
-            for (int k = 0; k < kG; ++k) sgr[e][k] = 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int e = u * 64 + lane;
-            g_cur[u] = g_nxt[u];
-            if (b > 0) {   // (batches below the last one are full)
-                r0[u] = g4[(size_t)g_cur[u] * 3 + 0]; r1[u] = g4[(size_t)g_cur[u] * 3 + 1]; r2[u] = g4[(size_t)g_cur[u] * 3 + 2];
-            }
-            if (b > 1) g_nxt[u] = plist[(b - 2) * NT + e];
-        }
-        for (int j0 = (cnt - 1) & ~63; j0 >= 0; j0 -= 64) {
-            const int je = j0 + lane;
-            float tx = 0.f, ty = 0.f, ex = -1.f, ey = -1.f;
-            if (je < cnt) {
-                const float4 t = sq0[je];
-                tx = t.x - bcx; ty = t.y - bcy; ex = t.z + 0.5f; ey = t.w + 0.5f;
-            }
-            const unsigned long long mx0 = __ballot(fabsf(tx) <= ex), mx1 = __ballot(fabsf(tx - 2.0f) <= ex),
-                                     mx2 = __ballot(fabsf(tx - 4.0f) <= ex), mx3 = __ballot(fabsf(tx - 6.0f) <= ex),
-                                     mx4 = __ballot(fabsf(tx - 8.0f) <= ex), mx5 = __ballot(fabsf(tx - 10.0f) <= ex),
-                                     mx6 = __ballot(fabsf(tx - 12.0f) <= ex), mx7 = __ballot(fabsf(tx - 14.0f) <= ex);
-            const unsigned long long my0 = __ballot(fabsf(ty) <= ey), my1 = __ballot(fabsf(ty - 2.0f) <= ey),
-                                     my2 = __ballot(fabsf(ty - 4.0f) <= ey), my3 = __ballot(fabsf(ty - 6.0f) <= ey),
-                                     my4 = __ballot(fabsf(ty - 8.0f) <= ey), my5 = __ballot(fabsf(ty - 10.0f) <= ey),
-                                     my6 = __ballot(fabsf(ty - 12.0f) <= ey), my7 = __ballot(fabsf(ty - 14.0f) <= ey);
-            unsigned long long mine = sel8(bx, mx0, mx1, mx2, mx3, mx4, mx5, mx6, mx7) & sel8(by, my0, my1, my2, my3, my4, my5, my6, my7);
-            {   // entries at or behind the last contributor of all four pixels of this block cannot act: drop them before the walk
-                const int lim = lmax - (p0 + j0);
-                mine = lim >= 64 ? mine : (lim <= 0 ? 0ull : (mine & ((1ull << lim) - 1ull)));
-            }
-            while (__any(mine != 0ull)) {
-                const bool blk = mine != 0ull;
-                const int jj = blk ? 63 - __builtin_clzll(mine) : 0;
-                mine &= ~(1ull << jj);
-                const int j = j0 + jj;
-                const int posn = p0 + j;  // 0-based position; upstream's `contributor` = posn + 1
-                const float4 q0 = sq0[j];
-                const float4 q1 = sq1[j];
-                const float4 q2 = sq2[j];
-                float A = 0.f, B = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-                bool any_act = false;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float dx = q0.x - pfx[p & 1], dy = q0.y - pfy[p >> 1];
-                    const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                    const float G = __expf(fminf(power, 0.0f));
-                    const float alpha = fminf(0.99f, q1.w * G);
-                    const bool act = blk && posn < last[p] && power <= 0.0f && alpha >= 1.0f / 255.0f;
-                    any_act = any_act || act;
-                    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    const float Tn = T[p] * rinv;
-                    T[p] = act ? Tn : T[p];
-                    const float la = act ? last_alpha[p] : 0.0f;      // la = 0: the accumulators below keep their values exactly
-                    const float om = 1.0f - la;
-                    acc_r[p] = la * last_r[p] + om * acc_r[p];
-                    acc_g[p] = la * last_g[p] + om * acc_g[p];
-                    acc_b[p] = la * last_b[p] + om * acc_b[p];
-                    if (DEPTH) acc_d[p] = la * last_d[p] + om * acc_d[p];
-                    float dL_dalpha = (q2.x - acc_r[p]) * dLr[p] + (q2.y - acc_g[p]) * dLg[p] + (q2.z - acc_b[p]) * dLb[p];
-                    if (DEPTH) dL_dalpha += (q2.w - acc_d[p]) * dLd[p];
-                    dL_dalpha = dL_dalpha * Tn + bgd[p] * rinv;
-                    dL_dalpha = act ? dL_dalpha : 0.0f;
-                    const float dch = act ? alpha * Tn : 0.0f;
-                    last_r[p] = act ? q2.x : last_r[p]; last_g[p] = act ? q2.y : last_g[p];
-                    last_b[p] = act ? q2.z : last_b[p];
-                    if (DEPTH) last_d[p] = act ? q2.w : last_d[p];
-                    last_alpha[p] = act ? alpha : last_alpha[p];
-                    const float dL_dG = q1.w * dL_dalpha;
-                    const float a_ = dL_dG * (G * dx), b_ = dL_dG * (G * dy);
-                    A += a_; B += b_;
-                    s2 += a_ * dx; s3 += a_ * dy; s4 += b_ * dy;
-                    v5 += G * dL_dalpha;
-                    v6 += dch * dLr[p]; v7 += dch * dLg[p]; v8 += dch * dLb[p];
-                    if (DEPTH) v9 += dch * dLd[p];
-                }
-                if (any_act) {
-                    float *rec = &sgr[j][0];
-                    atomicAdd(rec + 0, -(A * q1.x + B * q1.y) * ddelx_dx);
-                    atomicAdd(rec + 1, -(B * q1.z + A * q1.y) * ddely_dy);
-                    atomicAdd(rec + 2, -0.5f * s2);
-                    atomicAdd(rec + 3, -s3);
-                    atomicAdd(rec + 4, -0.5f * s4);
-                    atomicAdd(rec + 5, v5);
-                    atomicAdd(rec + 6, v6);
-                    atomicAdd(rec + 7, v7);
-                    atomicAdd(rec + 8, v8);
-                    if (DEPTH) atomicAdd(rec + 9, v9);
-                }
-            }
-        }
-        __syncthreads();   // the LDS adds of this batch are done
-        {   // flush: lane = (entry slot 0..5, component 0..9): the ten atomics of one record are ten adjacent lanes of one instruction
-            const int sub = lane / kG, e = lane - sub * kG;
-            for (int k = 0; k < cnt; k += 6) {
-                const int j = k + sub;
-                if (lane < 6 * kG && j < cnt) {
-                    const float x = sgr[j][e];
-                    if (x != 0.0f) atomicAdd(gr + (size_t)sid[j] * kG + e, x);
-                }
-            }
-        }
-    }
-}
-
-// Round 6, the batched route proper: SEGMENT-PARALLEL replay.  Both kernels above walk a tile's list in one piece, back to front, from
-// final_T: their duration is the LONGEST list's (PMC on the bench scene: 1.2 resident waves per SIMD averaged over the kernel -- the 23 k-entry
-// tiles finish milliseconds after everything else).  With VS_BUF_CHECKPOINT (the forward's blending state in front of every 512th entry,
+// Round 6, the route of every differentiated call: SEGMENT-PARALLEL replay, lane = one 2x2 pixel block of the tile (8 x 8 blocks; the block's
+// four pixels are replayed by the same lane one after the other, so a trip of the survivor walk serves up to 64 (block, entry) pairs and no
+// cross-lane sum exists).  The whole-list kernel above walks a tile's list in one piece, back to front, from final_T; PMC on the bench scene
+// showed it bound by the LDS pipeline, not by arithmetic (ds_add_f32 retires about a lane per cycle: 85 % LDS-busy, VALU issue 0.32,
+// 19.1 ms per 288 views against the forward's 4.0).  With VS_BUF_CHECKPOINT (the forward's blending state in front of every 512th entry,
 // raster_fwd.hip) a wave replays ONE 512-entry segment of ONE tile, FRONT to back, from the state the forward had there:
 //     T_i, D_i = sum_{k<=i} w_k (c_k . dL)   (w = alpha T: the forward's own recurrence)
 //     dL/dalpha_i = T_i (c_i . dL) - (out . dL - D_i) / (1 - alpha_i)        (out = rendered pixel incl. background: the suffix sum + T_final bg)
-// so the per-pixel state is T, D and four constants instead of the nine running values of the back-to-front form, a trip is ~45 instead of
-// ~70 VALU per pixel, and the work items are (tile, segment) pairs of at most eight rounds each: no tail.  Lane = 2x2 pixel block as above.
+// so the per-pixel state is T, D and four constants instead of the nine running values of the back-to-front form (a trip is ~45 instead of
+// ~70 VALU per pixel, one v_rcp_f32 serves the division: the backward is float-tolerant, nothing here feeds an integer decision), and the
+// work items are (tile, segment) pairs of at most eight rounds each.
 template <bool DEPTH>
 __global__ void __launch_bounds__(64)
 render_backward_seg_kernel(int P, int W, int H, int tiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
                            const float *__restrict__ geom, const float *__restrict__ ckpt, const int2 *__restrict__ cktab,
                            const int32_t *__restrict__ n_contrib, const float *__restrict__ out_color, const float *__restrict__ out_depth,
                            const float *__restrict__ dL_dpix, const float *__restrict__ dL_dpixdepth, float *__restrict__ grec) {
+    // Accumulation WITHOUT LDS atomics (PMC: the atomic form above spends ~85 % of its time in the LDS pipeline -- ds_add_f32 retires about one
+    // lane per cycle, and every trip issues nine of them).  The blocks an entry covers are a RECTANGLE of the 8 x 8 block grid (the footprint
+    // test is separable), so block (bx, by) has a rank inside it: each (block, entry) pair owns a slot of a staging area -- entry j's slots
+    // start at the exclusive scan of the areas -- written with plain 8-byte stores (9-10 sums + an epoch tag: a pair that was pruned or had no
+    // active pixel writes nothing and reads as zero), and lane j, the OWNER of entry j, then adds its slots in registers.  One set of global
+    // atomics per (segment, entry) leaves straight from the owner's registers.  Batches whose pairs outnumber the staging area are cut into
+    // chunks of consecutive entries.
     constexpr int NT = 64;
+    constexpr int SW = DEPTH ? 12 : 10;           // words per slot: sums, tag (, pad): a whole number of 8-byte stores
+    constexpr int CAP = DEPTH ? 184 : 224;        // slots (>= 64: the largest rectangle)
     __shared__ float4 sq0[NT], sq1[NT], sq2[NT];
-    __shared__ uint32_t sid[NT];
-    __shared__ float sgr[NT][kG + 1];
+    __shared__ uint32_t sinfo[NT];
+    __shared__ __attribute__((aligned(8))) float stage[CAP * SW];
     const int2 slot = cktab[blockIdx.x];
     if (slot.x < 0) return;
     const int t_lin = slot.x, seg = slot.y;
@@ -496,39 +314,66 @@ render_backward_seg_kernel(int P, int W, int H, int tiles, const int2 *__restric
     }
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     float *__restrict__ gr = grec + (size_t)c * P * kG;
+    for (int k = lane; k < CAP; k += 64) stage[k * SW + (DEPTH ? 10 : 9)] = 0.f;     // tags: epochs start at 1
+    int epoch = 0;
 
     for (int base = 0; base < n; base += NT) {
         const int cnt = min(NT, n - base);
-        __syncthreads();   // the previous batch's flush has read sgr / sid
-        if (lane < cnt) { sq0[lane] = r0; sq1[lane] = r1; sq2[lane] = r2; sid[lane] = g_cur; }
-#pragma unroll
-        for (int k = 0; k < kG; ++k) sgr[lane][k] = 0.f;
-        __syncthreads();
+        __syncthreads();   // the previous batch's owners have read the staging area / sinfo
+        if (lane < cnt) { sq0[lane] = r0; sq1[lane] = r1; sq2[lane] = r2; }
+        const uint32_t my_id = g_cur;
+        const float4 r0_own = r0;
         g_cur = g_nxt;
         if (base + NT + lane < n) { r0 = g4[(size_t)g_cur * 3 + 0]; r1 = g4[(size_t)g_cur * 3 + 1]; r2 = g4[(size_t)g_cur * 3 + 2]; }
         if (base + 2 * NT + lane < n) g_nxt = plist[base + 2 * NT + lane];
         float tx = 0.f, ty = 0.f, ex = -1.f, ey = -1.f;
-        if (lane < cnt) {
-            const float4 t = sq0[lane];
-            tx = t.x - bcx; ty = t.y - bcy; ex = t.z + 0.5f; ey = t.w + 0.5f;
+        if (lane < cnt) { tx = r0_own.x - bcx; ty = r0_own.y - bcy; ex = r0_own.z + 0.5f; ey = r0_own.w + 0.5f; }
+        const bool c0 = fabsf(tx) <= ex, c1 = fabsf(tx - 2.0f) <= ex, c2 = fabsf(tx - 4.0f) <= ex, c3 = fabsf(tx - 6.0f) <= ex,
+                   c4 = fabsf(tx - 8.0f) <= ex, c5 = fabsf(tx - 10.0f) <= ex, c6 = fabsf(tx - 12.0f) <= ex, c7 = fabsf(tx - 14.0f) <= ex;
+        const bool w0 = fabsf(ty) <= ey, w1 = fabsf(ty - 2.0f) <= ey, w2 = fabsf(ty - 4.0f) <= ey, w3 = fabsf(ty - 6.0f) <= ey,
+                   w4 = fabsf(ty - 8.0f) <= ey, w5 = fabsf(ty - 10.0f) <= ey, w6 = fabsf(ty - 12.0f) <= ey, w7 = fabsf(ty - 14.0f) <= ey;
+        const unsigned long long mx0 = __ballot(c0), mx1 = __ballot(c1), mx2 = __ballot(c2), mx3 = __ballot(c3),
+                                 mx4 = __ballot(c4), mx5 = __ballot(c5), mx6 = __ballot(c6), mx7 = __ballot(c7);
+        const unsigned long long my0 = __ballot(w0), my1 = __ballot(w1), my2 = __ballot(w2), my3 = __ballot(w3),
+                                 my4 = __ballot(w4), my5 = __ballot(w5), my6 = __ballot(w6), my7 = __ballot(w7);
+        // this lane's ENTRY: the rectangle of blocks it covers (the same predicates as the ballots: the two views cannot disagree)
+        const unsigned cb = (c0 ? 1u : 0u) | (c1 ? 2u : 0u) | (c2 ? 4u : 0u) | (c3 ? 8u : 0u) | (c4 ? 16u : 0u) | (c5 ? 32u : 0u) | (c6 ? 64u : 0u) | (c7 ? 128u : 0u);
+        const unsigned rb = (w0 ? 1u : 0u) | (w1 ? 2u : 0u) | (w2 ? 4u : 0u) | (w3 ? 8u : 0u) | (w4 ? 16u : 0u) | (w5 ? 32u : 0u) | (w6 ? 64u : 0u) | (w7 ? 128u : 0u);
+        const int nx = __popc(cb), ny = __popc(rb);
+        const int area = nx * ny;
+        const int cx0 = cb ? __builtin_ctz(cb) : 0, cy0 = rb ? __builtin_ctz(rb) : 0;
+        int off_end = area;                       // inclusive scan over the lanes -> [off, off_end) = this entry's slots
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(off_end, o, 64);
+            if (lane >= o) off_end += y;
         }
-        const unsigned long long mx0 = __ballot(fabsf(tx) <= ex), mx1 = __ballot(fabsf(tx - 2.0f) <= ex),
-                                 mx2 = __ballot(fabsf(tx - 4.0f) <= ex), mx3 = __ballot(fabsf(tx - 6.0f) <= ex),
-                                 mx4 = __ballot(fabsf(tx - 8.0f) <= ex), mx5 = __ballot(fabsf(tx - 10.0f) <= ex),
-                                 mx6 = __ballot(fabsf(tx - 12.0f) <= ex), mx7 = __ballot(fabsf(tx - 14.0f) <= ex);
-        const unsigned long long my0 = __ballot(fabsf(ty) <= ey), my1 = __ballot(fabsf(ty - 2.0f) <= ey),
-                                 my2 = __ballot(fabsf(ty - 4.0f) <= ey), my3 = __ballot(fabsf(ty - 6.0f) <= ey),
-                                 my4 = __ballot(fabsf(ty - 8.0f) <= ey), my5 = __ballot(fabsf(ty - 10.0f) <= ey),
-                                 my6 = __ballot(fabsf(ty - 12.0f) <= ey), my7 = __ballot(fabsf(ty - 14.0f) <= ey);
+        const int off = off_end - area;
+        sinfo[lane] = (uint32_t)cx0 | ((uint32_t)nx << 3) | ((uint32_t)cy0 << 7) | ((uint32_t)off << 10);
+        __syncthreads();
         unsigned long long mine = sel8(bx, mx0, mx1, mx2, mx3, mx4, mx5, mx6, mx7) & sel8(by, my0, my1, my2, my3, my4, my5, my6, my7);
         {   // entries at or behind the last contributor of all four pixels of this block cannot act
             const int lim = lmax - (s0 + base);
             mine = lim >= 64 ? mine : (lim <= 0 ? 0ull : (mine & ((1ull << lim) - 1ull)));
         }
-        while (__any(mine != 0ull)) {
-            const bool blk = mine != 0ull;
-            const int j = blk ? __builtin_ctzll(mine) : 0;
-            mine &= mine - 1ull;
+        float acc[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) acc[e] = 0.f;
+        int lo = 0;
+        while (lo < cnt) {
+            // chunk [lo, hi): the longest run of entries from lo whose slots fit the staging area
+            const int off_lo = __builtin_amdgcn_readlane(off, __builtin_amdgcn_readfirstlane(lo));
+            const unsigned long long fit = __ballot(lane >= lo && off_end - off_lo <= CAP);
+            const unsigned long long rest = ~(fit >> lo);
+            const int hi = rest ? min(64, lo + __builtin_ctzll(rest)) : 64;
+            const unsigned long long cmask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            ++epoch;
+            const float tagf = __int_as_float(epoch);
+            unsigned long long mc = mine & cmask;
+        while (__any(mc != 0ull)) {
+            const bool blk = mc != 0ull;
+            const int j = blk ? __builtin_ctzll(mc) : 0;
+            mc &= mc - 1ull;
             const int posn = s0 + base + j;   // 0-based position in the tile's list; upstream's `contributor` = posn + 1
             const float4 q0 = sq0[j];
             const float4 q1 = sq1[j];
@@ -559,27 +404,49 @@ render_backward_seg_kernel(int P, int W, int H, int tiles, const int2 *__restric
                 if (DEPTH) v9 += w * dLd[p];
             }
             if (any_act) {
-                float *rec = &sgr[j][0];
-                atomicAdd(rec + 0, -(A * q1.x + B * q1.y) * ddelx_dx);
-                atomicAdd(rec + 1, -(B * q1.z + A * q1.y) * ddely_dy);
-                atomicAdd(rec + 2, -0.5f * s2);
-                atomicAdd(rec + 3, -s3);
-                atomicAdd(rec + 4, -0.5f * s4);
-                atomicAdd(rec + 5, v5);
-                atomicAdd(rec + 6, v6);
-                atomicAdd(rec + 7, v7);
-                atomicAdd(rec + 8, v8);
-                if (DEPTH) atomicAdd(rec + 9, v9);
+                const uint32_t info = sinfo[j];
+                const int slot = (int)(info >> 10) - off_lo + (by - (int)((info >> 7) & 7u)) * (int)((info >> 3) & 15u) + (bx - (int)(info & 7u));
+                float2 *rec = reinterpret_cast<float2 *>(stage + slot * SW);
+                rec[0] = make_float2(-(A * q1.x + B * q1.y) * ddelx_dx, -(B * q1.z + A * q1.y) * ddely_dy);
+                rec[1] = make_float2(-0.5f * s2, -s3);
+                rec[2] = make_float2(-0.5f * s4, v5);
+                rec[3] = make_float2(v6, v7);
+                if (DEPTH) { rec[4] = make_float2(v8, v9); rec[5] = make_float2(tagf, 0.f); }
+                else rec[4] = make_float2(v8, tagf);
             }
         }
-        __syncthreads();   // the LDS adds of this batch are done
-        {   // flush: lane = (entry slot 0..5, component 0..9): the ten atomics of one record are ten adjacent lanes of one instruction
+            __syncthreads();   // the chunk's stores are visible to the owners
+            if (lane >= lo && lane < hi) {
+                for (int sI = 0; sI < area; ++sI) {
+                    const float2 *rec = reinterpret_cast<const float2 *>(stage + (off - off_lo + sI) * SW);
+                    const float2 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
+                    float2 a5 = make_float2(0.f, 0.f);
+                    if (DEPTH) a5 = rec[5];
+                    const bool ok = __float_as_int(DEPTH ? a5.x : a4.y) == epoch;
+                    if (ok) {
+                        acc[0] += a0.x; acc[1] += a0.y; acc[2] += a1.x; acc[3] += a1.y; acc[4] += a2.x; acc[5] += a2.y; acc[6] += a3.x; acc[7] += a3.y;
+                        acc[8] += a4.x;
+                        if (DEPTH) acc[9] += a4.y;
+                    }
+                }
+            }
+            __syncthreads();   // the owners are done with the staging area before the next chunk's stores
+            lo = hi;
+        }
+        // one set of global atomics per (segment, entry).  Through the staging area once more, so that the ten atomics of one record are ten
+        // adjacent lanes of one instruction (lane = (entry slot 0..5, component)): straight from the owners' registers every instruction
+        // touched 64 different records -- 64 cache lines -- and the kernel waited on the atomic path instead of the LDS (12.7 ms per launch)
+        sinfo[lane] = my_id;
+#pragma unroll
+        for (int e = 0; e < kG; ++e) stage[lane * SW + e] = (e < (DEPTH ? 10 : 9)) ? acc[e] : 0.f;
+        __syncthreads();
+        {
             const int sub = lane / kG, e = lane - sub * kG;
             for (int k = 0; k < cnt; k += 6) {
                 const int j = k + sub;
                 if (lane < 6 * kG && j < cnt) {
-                    const float x = sgr[j][e];
-                    if (x != 0.0f) atomicAdd(gr + (size_t)sid[j] * kG + e, x);
+                    const float x = stage[j * SW + e];
+                    if (x != 0.0f) atomicAdd(gr + (size_t)sinfo[j] * kG + e, x);
                 }
             }
         }
@@ -1044,11 +911,11 @@ extern "C" int vs_raster_backward(const VsRasterIn *in, const VsRasterOut *saved
         // kernel; four waves per tile (a quadrant each) for small calls.  VS_RBWD_WAVES = 1 | 4 forces one (read per call: the tests run both).
         const char *fw = getenv("VS_RBWD_WAVES");
         const float *ckpt = (const float *)saved->buffers[VS_BUF_CHECKPOINT];
-        // 0 (default whenever the forward saved checkpoints): segment-parallel replay; 1 | 4: the whole-list kernels
-        const int waves = fw ? atoi(fw) : (ckpt ? 0 : ((long long)tiles * C >= 4096 ? 1 : 4));
-        if (waves == 0) {
-            VS_CHECK(ckpt && saved->color && (!g->dL_ddepth || saved->depth),
-                     "vs_raster_backward: the segment-parallel route needs VS_BUF_CHECKPOINT (forward under VS_RASTER_SAVE_FOR_BACKWARD) and the rendered colour / depth");
+        // segment-parallel replay whenever the forward saved checkpoints (every differentiated call of this package); the whole-list kernel
+        // (four waves per tile) for a caller without VS_RASTER_SAVE_FOR_BACKWARD.  VS_RBWD_WAVES=4 forces the latter (read per call: tests).
+        const bool seg = ckpt && !(fw && atoi(fw) == 4);
+        if (seg) {
+            VS_CHECK(saved->color && (!g->dL_ddepth || saved->depth), "vs_raster_backward: the checkpoint route reads the rendered colour / depth of the forward");
             const size_t ck_slots = (size_t)(saved->num_rendered >> vs::kCkShift) + (size_t)tiles * C;
             const int2 *cktab = reinterpret_cast<const int2 *>(ckpt + ck_slots * vs::kCkFloats);
             if (g->dL_ddepth)
@@ -1057,15 +924,10 @@ extern "C" int vs_raster_backward(const VsRasterIn *in, const VsRasterOut *saved
             else
                 hipLaunchKernelGGL((render_backward_seg_kernel<false>), dim3((unsigned)ck_slots), dim3(64), 0, stream, P, W, H, tiles, ranges, point_list, geom,
                                    ckpt, cktab, n_contrib, saved->color, saved->depth, g->dL_dcolor, g->dL_ddepth, grec);
-        } else if (waves == 1 && g->dL_ddepth)
-            hipLaunchKernelGGL((render_backward_block_kernel<64, true>), dim3(tiles, C), dim3(64), 0, stream, P, W, H, ranges, point_list, geom,
-                               in->background, final_T, n_contrib, g->dL_dcolor, g->dL_ddepth, grec);
-        else if (waves == 1)
-            hipLaunchKernelGGL((render_backward_block_kernel<64, false>), dim3(tiles, C), dim3(64), 0, stream, P, W, H, ranges, point_list, geom,
-                               in->background, final_T, n_contrib, g->dL_dcolor, g->dL_ddepth, grec);
-        else
+        } else {
             hipLaunchKernelGGL(render_backward_kernel, dim3(tiles, C), dim3(256), 0, stream, P, W, H, ranges, point_list, geom,
                                in->background, final_T, n_contrib, g->dL_dcolor, g->dL_ddepth, grec);
+        }
     }
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(vs::cdiv(P, 256), in->num_scenes), dim3(256), 0, stream, *in, saved->radii,
                        clamped, grec, g->dL_dmeans3D, g->dL_dcov3D, g->dL_dshs, g->dL_dcolors_precomp, g->dL_dopacities,
