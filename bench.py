@@ -528,8 +528,8 @@ def main():
         traffic = {}
         pmc_file = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/README.md); null unless they cover this workload and operand class
-            fn = {"split": "round5_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
-            for older in ("round4_pmc_traffic.json", "round3_pmc_traffic.json"):
+            fn = {"split": "round6_pmc_traffic.json", "f16": "round2_pmc_traffic.json"}.get(args.dtype)
+            for older in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json"):
                 if fn and fn.startswith("round") and args.dtype == "split" and not os.path.exists(os.path.join(ROOT, "profiles", fn)):
                     fn = older
             pmc_file = os.path.join(ROOT, "profiles", fn)
