@@ -367,7 +367,7 @@ def rbwd_waves(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("W,H,P", [(48, 32, 60), (64, 64, 400)])
+@pytest.mark.parametrize("W,H,P", [(48, 32, 60), (64, 64, 400), (40, 24, 80)])     # (40 x 24: partial tiles on both edges)
 def test_backward_matches_oracle(W, H, P, rbwd_waves):
     from vicasplat_amd.raster import rasterize
     d = _dev()

@@ -1133,8 +1133,13 @@ static int conv3x3_entry(const void *in, const void *w, const float *bias, const
         }
         VS_CHECK(!g.a_packed, "vs_conv3x3_split_nhwc: a packed input is taken by the 256 x 256 and 256 x 128 tile kernels only (this shape runs on the 4-wave kernel)");
         static const int smi = [] { const char *e = getenv("VS_CONV_SPLIT_MI"); return e ? atoi(e) : 0; }();
+        // round 6, small batches (one 8-view scene: 16 x 16 / 32 x 32 maps = 2 048 / 8 192 pixels x 256 channels = 32 / 128 tiles of 128 x 128 for
+        // 256 CUs): 64-row tiles (MI = 2, the same kernel) double the workgroups.  VS_CONV_MI2=0 for the A/B.
+        static const int mi2 = [] { const char *e = getenv("VS_CONV_MI2"); return e ? atoi(e) : 1; }();
+        const long long t4 = vs::cdiv64(M, 128) * vs::cdiv(Cout, BN);
         if ((big >= 512 && smi != 4) || smi == 8) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 8>), dim3((unsigned)big), dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
+        else if (mi2 && smi == 0 && t4 <= 192 && M > 64) hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 2>), dim3((unsigned)(vs::cdiv64(M, 64) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((conv3x3_kernel<kDtSplit, 4>), dim3((unsigned)t4), dim3(256), 0, stream, g);
     } else if (dtype == 3) {
         hipLaunchKernelGGL((conv3x3_kernel<kDtF32, 4>), dim3((unsigned)(vs::cdiv64(M, 128) * vs::cdiv(Cout, BN))), dim3(256), 0, stream, g);
     } else if ((big >= 256 || force == 8) && force != 4) {
