@@ -235,13 +235,15 @@ render_backward_seg_kernel(int P, int W, int H, int tiles, const int2 *__restric
                            const float *__restrict__ geom, const float *__restrict__ ckpt, const int2 *__restrict__ cktab,
                            const int32_t *__restrict__ n_contrib, const float *__restrict__ out_color, const float *__restrict__ out_depth,
                            const float *__restrict__ dL_dpix, const float *__restrict__ dL_dpixdepth, float *__restrict__ grec) {
-    // Accumulation WITHOUT LDS atomics (PMC: the atomic form above spends ~85 % of its time in the LDS pipeline -- ds_add_f32 retires about one
-    // lane per cycle, and every trip issues nine of them).  The blocks an entry covers are a RECTANGLE of the 8 x 8 block grid (the footprint
-    // test is separable), so block (bx, by) has a rank inside it: each (block, entry) pair owns a slot of a staging area -- entry j's slots
-    // start at the exclusive scan of the areas -- written with plain 8-byte stores (9-10 sums + an epoch tag: a pair that was pruned or had no
-    // active pixel writes nothing and reads as zero), and lane j, the OWNER of entry j, then adds its slots in registers.  One set of global
-    // atomics per (segment, entry) leaves straight from the owner's registers.  Batches whose pairs outnumber the staging area are cut into
-    // chunks of consecutive entries.
+    // Accumulation WITHOUT LDS atomics (PMC: with one ds_add_f32 per sum and (block, entry) pair this kernel spent ~85 % of its time in the
+    // LDS pipeline -- the instruction retires about one lane per cycle, and every trip issued nine of them: 15.8 ms per 288 views).  The
+    // blocks an entry covers are a RECTANGLE of the 8 x 8 block grid (the footprint test is separable), so block (bx, by) has a rank inside
+    // it: each (block, entry) pair owns a slot of a staging area -- entry j's slots start at the exclusive scan of the areas -- written with
+    // plain 8-byte stores (9-10 sums + an epoch tag: a pair that was pruned or had no active pixel writes nothing and reads as zero), and
+    // lane j, the OWNER of entry j, then adds its slots in registers.  The owners' sums go through the staging area once more so that one
+    // global atomic instruction covers six records x ten adjacent floats (straight from the owners' registers an instruction touched 64
+    // different cache lines and the kernel waited on the atomic path: 12.7 ms per launch).  Batches whose pairs outnumber the staging area
+    // are cut into chunks of consecutive entries.
     constexpr int NT = 64;
     constexpr int SW = DEPTH ? 12 : 10;           // words per slot: sums, tag (, pad): a whole number of 8-byte stores
     constexpr int CAP = DEPTH ? 184 : 224;        // slots (>= 64: the largest rectangle)
