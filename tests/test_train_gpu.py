@@ -9,6 +9,7 @@ import torch
 from oracle import encoder_ref as er
 
 pytestmark = pytest.mark.gpu
+F16_GRAD_TOL = (8e-2, 2e-2, 3e-2, 2e-2)      # (lattice, sum, |sum|, norm) of the f16-class gradient-golden test = 3x the measured 2.6e-2 / 5.8e-3 / 9.1e-3 / 6.6e-3
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -290,7 +291,8 @@ def _config4_batch(B, V, Vt, d, with_extrinsics=False):
     return dict(context=ctx, target=dict(image=target, extrinsics=tE, intrinsics=tK, near=tn, far=tf))
 
 
-def test_full_vit_l_backward_matches_the_real_references_gradient_goldens():
+@pytest.mark.parametrize("cdt", ["split", "f16"])
+def test_full_vit_l_backward_matches_the_real_references_gradient_goldens(cdt):
     """config 4's backward pinned to the REAL reference, not only to property checks.  tests/golden/
     encoder_full_v2_grads.npz holds float64 gradients of the imported reference encoder (full ViT-L: 24 + 12 blocks, both DPT heads, adapter,
     pose head; 1 scene x 2 views x 256 x 256) for a seeded linear functional of raw_gaussians, pred_extrins and the covariances
@@ -303,7 +305,8 @@ def test_full_vit_l_backward_matches_the_real_references_gradient_goldens():
     G = os.path.join(os.path.dirname(__file__), "golden")
     z = np.load(os.path.join(G, "encoder_full_v2_grads.npz"))
     B, V = int(z["cfg_B"]), int(z["cfg_V"])
-    m = _full_model("split").eval()          # eval: the heads' Dropout(0.1) is the identity, as in the generator
+    dt = "split" if cdt == "split" else torch.float16
+    m = _full_model(dt).eval()               # eval: the heads' Dropout(0.1) is the identity, as in the generator
     m.requires_grad_(True)
     img, K = er.synthetic_input(B, V, 256, int(z["cfg_seed"]))
     g = torch.Generator().manual_seed(1)     # the functional of gen_encoder_grad_golden.functional()
@@ -311,12 +314,13 @@ def test_full_vit_l_backward_matches_the_real_references_gradient_goldens():
     r_raw[..., :3] *= 0.1
     r_pose = torch.randn(B, V - 1, 8, generator=g)
     r_cov = torch.randn(B, V, 256, 256, 3, 3, generator=g) * 10.0
-    out = forward_train(m, img.cuda(), K.cuda(), "split")
+    out = forward_train(m, img.cuda(), K.cuda(), dt)
     loss = (out["raw_gaussians"] * r_raw.cuda()).sum() + (out["pred_extrins"] * r_pose.cuda()).sum() + (out["gaussians"]["covariances"] * r_cov.cuda()).sum()
-    S = 4096.0                               # power-of-two scale: keeps the (hi, lo) operand pairs of the backward in f16's normal range
+    S = 4096.0 if cdt == "split" else 1024.0  # power-of-two scale: keeps the (hi, lo) operand pairs / the 16-bit gradients of the backward in f16's normal range
     (loss * S).backward()
     torch.cuda.synchronize()
-    assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-4 * abs(float(z["loss"])) + 1e-6, (float(loss.detach()), float(z["loss"]))
+    ltol = 2e-4 if cdt == "split" else 5e-2
+    assert abs(float(loss.detach()) - float(z["loss"])) <= ltol * abs(float(z["loss"])) + 1e-6, (float(loss.detach()), float(z["loss"]))
     named = dict(m.named_parameters())
     nlat = int(z["nlat"])
     worst = {}
@@ -335,10 +339,18 @@ def test_full_vit_l_backward_matches_the_real_references_gradient_goldens():
     # gradient element is a sum over up to 131 072 pixels / 514 tokens of such products.  Measured: lattice elements <= 1.6e-3 of the
     # gradient's largest element (the 7x7 stem's weight: a sum over every pixel of both frames; every transformer weight <= 6.1e-4), sums
     # and sums of magnitudes <= 1.9e-4.  Bounds = 3x that.
-    for n, (e_lat, e_sum, e_abs) in worst.items():
-        assert e_lat <= 5e-3 and e_sum <= 6e-4 and e_abs <= 6e-4, (n, e_lat, e_sum, e_abs)
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)) / S
-    assert abs(float(gn) - float(z["grad_norm_all"])) <= 1e-3 * float(z["grad_norm_all"]), (float(gn), float(z["grad_norm_all"]))
+    print("whole-gradient norm: ours %.6e reference %.6e" % (float(gn), float(z["grad_norm_all"])), "max lattice %.2e max sum %.2e max |sum| %.2e" % tuple(
+        max(v[k] for v in worst.values()) for k in range(3)))
+    if cdt == "split":
+        for n, (e_lat, e_sum, e_abs) in worst.items():
+            assert e_lat <= 5e-3 and e_sum <= 6e-4 and e_abs <= 6e-4, (n, e_lat, e_sum, e_abs)
+        assert abs(float(gn) - float(z["grad_norm_all"])) <= 1e-3 * float(z["grad_norm_all"]), (float(gn), float(z["grad_norm_all"]))
+    else:
+        # the 16-bit class (TF32-class operands, 16-bit activations and activation gradients): bounds = 3x the measured values
+        for n, (e_lat, e_sum, e_abs) in worst.items():
+            assert e_lat <= F16_GRAD_TOL[0] and e_sum <= F16_GRAD_TOL[1] and e_abs <= F16_GRAD_TOL[2], (n, e_lat, e_sum, e_abs)
+        assert abs(float(gn) - float(z["grad_norm_all"])) <= F16_GRAD_TOL[3] * float(z["grad_norm_all"]), (float(gn), float(z["grad_norm_all"]))
 
 
 @pytest.mark.parametrize("cdt", ["f16", "split"])
