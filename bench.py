@@ -244,12 +244,11 @@ def train_leg(args, enc, dec, dev, rank, world, dist, cdt=None, scenes=None, ste
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     ms = el / nsteps * 1e3
-    rb = None
-    if rank == 0:
-        try:
-            rb = raster_backward_roofline(lambda: callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer), B, V, Vt)
-        except Exception as ex:      # an instrumentation failure must not take the leg with it
-            rb = dict(error=repr(ex)[:200])
+    # (every rank runs the instrumented step: under N > 1 it contains the gradient exchange's collectives; rank 0's reading is reported)
+    try:
+        rb = raster_backward_roofline(lambda: callers.training_step(enc, dec, batch, opt, compute_dtype=dt, reducer=reducer), B, V, Vt)
+    except Exception as ex:      # an instrumentation failure must not take the leg with it
+        rb = dict(error=repr(ex)[:200])
     # algorithmic FLOPs of the step: 3 407 GFLOP forward per 8-view scene, backward = 2x forward
     flops = 3.0 * 3407e9 * (V / 8.0) * B
     tf_s = flops / (ms * 1e-3) / 1e12
