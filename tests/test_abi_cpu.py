@@ -51,3 +51,32 @@ def test_product_package_never_imports_the_oracle():
         if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
             bad.append(f)
     assert not bad, bad
+
+
+def test_python_constants_mirror_the_header_enums():
+    """The ctypes side indexes VsRasterOut.buffers and sets VsRasterIn.flags by number: the numbers are the header's."""
+    from vicasplat_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "vicasplat_hip.h")).read()
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(VS_(?:BUF|RASTER)_[A-Z_0-9]+)\s*=\s*(\d+)", hdr)}
+    assert enums["VS_BUF_COUNT"] == 13 and enums["VS_BUF_CHECKPOINT"] == 12
+    for name, val in enums.items():
+        if hasattr(_lib, name):
+            assert getattr(_lib, name) == val, (name, getattr(_lib, name), val)
+    for name in ("VS_BUF_GEOM", "VS_BUF_CHECKPOINT", "VS_BUF_COUNT", "VS_RASTER_SAVE_FOR_BACKWARD", "VS_RASTER_SH_RGB_MAJOR", "VS_RASTER_COV_3X3"):
+        assert hasattr(_lib, name) and name in enums, name
+    assert C.sizeof(_lib.VsRasterOut) == 6 * 8 + enums["VS_BUF_COUNT"] * 8
+
+
+def test_head_tail_refuses_an_input_that_is_not_a_relu_output():
+    """the fused tail of a DPT head masks its input gradient by t > 0 and tells the producer to skip its ReLU backward -- only
+    valid behind Conv3x3Fn(..., relu_out=True).  The producer is identified by its autograd node; anything else must not take the route."""
+    import pytest
+    import torch
+    from vicasplat_amd import autograd as A
+    t = torch.randn(32, 256, requires_grad=True) * 2.0          # produced by a multiplication, not by the ReLU convolution
+    w = torch.randn(83, 256)
+    assert not A.head_tail_ok(t, w)
+    with pytest.raises(ValueError, match="relu_out=True"):
+        A.head_tail(t, w, None, A.SPLIT)
+    leaf = torch.randn(32, 256)                                   # outside any graph: no consumer of dt, shapes decide
+    assert A.head_tail_ok(leaf, w)

@@ -244,3 +244,17 @@ def test_end_to_end_f32_render_matches_the_oracle_chain(V, Vt):
         assert max(c["dpsnr_common_target"]) <= 1e-4, c                                     # the north-star's 1e-4 dB bar
         assert tiles["visibility_flips"] + tiles["rect_changes"] <= 2e-3 * tiles["gaussian_views"], tiles
         assert pose <= 2e-5
+
+
+def test_f32_class_in_train_mode_raises_instead_of_running_the_no_grad_path():
+    """the exact-f32 operand class has no backward kernels.  train() + grad mode + trainable parameters is a training loop: it
+    must fail at the forward with the reason, not later in loss.backward() (eval() keeps the warned inference fallback)."""
+    m, _ = _model("tiny")
+    img, K = er.synthetic_input(1, 2, 256, 0)
+    ctx = dict(image=img.cuda(), intrinsics=K.cuda())
+    m.train().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m(ctx, compute_viewspace_depth=False)
+    m.eval()
+    out = m(ctx, compute_viewspace_depth=False)                   # eval + grad: the fused path, outputs without a graph
+    assert not out["raw_gaussians"].requires_grad
